@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes face of oracle/ctree_oracle.c with the reference's Cython
+module surface (lzero/mcts/ctree/ctree_efficientzero/ez_tree.pyx:6-121,
+ctree_muzero/mz_tree.pyx): ``Roots``, ``MinMaxStatsList``, ``ResultsWrapper``, ``batch_traverse``,
+``batch_backpropagate``.  Two module-like namespaces are exported: ``ez_tree`` and ``mz_tree``.
+"""
+import ctypes
+import os
+import subprocess
+import types
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libctree_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ctree_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libctree_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        P = ctypes.c_void_p
+        ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.otree_create.restype = P
+        L.otree_create.argtypes = [ctypes.c_int] * 4 + [ip, ip]
+        L.otree_destroy.argtypes = [P]
+        L.otree_set_tiebreak.argtypes = [P, ctypes.c_int]
+        L.otree_set_delta.argtypes = [P, ctypes.c_float]
+        L.otree_prepare.argtypes = [P, ctypes.c_float, P, fp, fp, ip]
+        L.otree_traverse.argtypes = [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, ip, ip, ip, ip, ip]
+        L.otree_backpropagate.argtypes = [P, ctypes.c_int, ctypes.c_float, fp, fp, fp, ip, ip]
+        L.otree_get_distributions.argtypes = [P, ip, ip]
+        L.otree_get_values.argtypes = [P, fp]
+        L.otree_get_minmax.argtypes = [P, fp]
+        L.otree_get_trajectories.argtypes = [P, ip, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _f32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def _i32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+
+
+def _make(variant):
+    class MinMaxStatsList(object):
+        def __init__(self, num):
+            self.num = num
+            self.delta = 0.0
+
+        def set_delta(self, value_delta_max):
+            self.delta = float(value_delta_max)
+
+    class ResultsWrapper(object):
+        def __init__(self, num):
+            self.num = num
+            self.search_lens = []
+
+        def get_search_len(self):
+            return self.search_lens
+
+    class Roots(object):
+        def __init__(self, root_num, legal_actions_list, action_space_size=None, max_simulations=512):
+            self.root_num = root_num
+            self._legal = [list(map(int, l)) for l in legal_actions_list]
+            self._A = action_space_size
+            self._S = max_simulations
+            self._h = None
+            self._tiebreak = 0
+            self._mm_bound = None
+
+        @property
+        def num(self):
+            return self.root_num
+
+        def _ensure(self, A):
+            if self._h is None:
+                if self._A is None:
+                    self._A = A
+                cnt = _i32([len(l) for l in self._legal])
+                flat = _i32([a for l in self._legal for a in l] or [0])
+                self._h = lib().otree_create(variant, self.root_num, self._A, self._S, flat, cnt)
+                lib().otree_set_tiebreak(self._h, self._tiebreak)
+
+        def set_tiebreak(self, mode):
+            self._tiebreak = int(mode)
+            if self._h is not None:
+                lib().otree_set_tiebreak(self._h, self._tiebreak)
+
+        def prepare(self, root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch):
+            logits = _f32(policy_logits_pool)
+            self._ensure(logits.shape[1])
+            nz = _f32([x for row in noises for x in row] or [0.0])
+            lib().otree_prepare(self._h, root_noise_weight, nz.ctypes.data, _f32(value_prefix_pool), logits,
+                                _i32(to_play_batch))
+
+        def prepare_no_noise(self, value_prefix_pool, policy_logits_pool, to_play_batch):
+            logits = _f32(policy_logits_pool)
+            self._ensure(logits.shape[1])
+            lib().otree_prepare(self._h, 0.0, None, _f32(value_prefix_pool), logits, _i32(to_play_batch))
+
+        def get_distributions(self):
+            out = np.zeros((self.root_num, self._A), np.int32)
+            cnt = np.zeros(self.root_num, np.int32)
+            lib().otree_get_distributions(self._h, out, cnt)
+            return [out[i, :cnt[i]].tolist() for i in range(self.root_num)]
+
+        def get_values(self):
+            out = np.zeros(self.root_num, np.float32)
+            lib().otree_get_values(self._h, out)
+            return out.tolist()
+
+        def get_minmax(self):
+            out = np.zeros((self.root_num, 2), np.float32)
+            lib().otree_get_minmax(self._h, out)
+            return out
+
+        def get_trajectories(self):
+            stride = self._S + 2
+            out = np.zeros((self.root_num, stride), np.int32)
+            lib().otree_get_trajectories(self._h, out, stride)
+            res = []
+            for i in range(self.root_num):
+                row = out[i].tolist()
+                res.append(row[:row.index(-1)])
+            return res
+
+        def clear(self):
+            if self._h is not None:
+                lib().otree_destroy(self._h)
+                self._h = None
+
+        def __del__(self):
+            try:
+                self.clear()
+            except Exception:
+                pass
+
+    def batch_traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, virtual_to_play_batch,
+                       deterministic=None):
+        B = roots.num
+        if roots._mm_bound is not min_max_stats_lst:
+            lib().otree_set_delta(roots._h, min_max_stats_lst.delta)
+            roots._mm_bound = min_max_stats_lst
+        vtp = _i32(virtual_to_play_batch).copy()
+        ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); la = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+        lib().otree_traverse(roots._h, int(pb_c_base), pb_c_init, discount_factor, vtp, ix, iy, la, sl)
+        results.search_lens = sl.tolist()
+        results._roots = roots
+        return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+    if variant == 0:
+        def batch_backpropagate(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                                min_max_stats_lst, results, is_reset_list, to_play_batch):
+            roots = results._roots
+            lib().otree_backpropagate(roots._h, current_latent_state_index, discount_factor, _f32(value_prefixs),
+                                      _f32(values), _f32(policies), _i32(is_reset_list), _i32(to_play_batch))
+    else:
+        def batch_backpropagate(current_latent_state_index, discount_factor, rewards, values, policies,
+                                min_max_stats_lst, results, to_play_batch):
+            roots = results._roots
+            lib().otree_backpropagate(roots._h, current_latent_state_index, discount_factor, _f32(rewards),
+                                      _f32(values), _f32(policies), _i32([0] * roots.num), _i32(to_play_batch))
+
+    ns = types.SimpleNamespace(MinMaxStatsList=MinMaxStatsList, ResultsWrapper=ResultsWrapper, Roots=Roots,
+                               batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate)
+    return ns
+
+
+ez_tree = _make(0)
+mz_tree = _make(1)

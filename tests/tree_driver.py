@@ -1,0 +1,121 @@
+"""Shared driver for the tree-only parity tests: steps any module exposing the reference's Cython
+surface (``Roots``, ``MinMaxStatsList``, ``ResultsWrapper``, ``batch_traverse``, ``batch_backpropagate``;
+lzero/mcts/ctree/ctree_efficientzero/ez_tree.pyx, ctree_muzero/mz_tree.pyx) through S simulations
+with *recorded* (seeded random) network outputs, the way EfficientZeroMCTSCtree.search does
+(lzero/mcts/tree_search/mcts_ctree.py:782-876), and records everything that is observable.
+"""
+import numpy as np
+
+# the 16-env x 9-action legal-action fixture of lzero/mcts/tests/test_mcts_ctree.py:122-152
+FIXTURE_ACTION_MASK = [
+    [0, 0, 0, 1, 0, 1, 1, 0, 0], [1, 0, 0, 1, 0, 0, 1, 0, 0], [1, 1, 0, 0, 1, 0, 1, 0, 1], [1, 0, 0, 1, 1, 1, 0, 0, 0],
+    [0, 0, 1, 0, 0, 1, 0, 0, 1], [0, 1, 1, 0, 1, 0, 0, 0, 0], [1, 0, 1, 1, 1, 0, 0, 1, 1], [1, 1, 1, 1, 1, 0, 0, 0, 1],
+    [0, 0, 0, 1, 0, 1, 1, 0, 0], [0, 1, 1, 0, 1, 1, 1, 1, 0], [1, 1, 1, 0, 0, 0, 1, 1, 1], [1, 1, 0, 1, 0, 1, 1, 0, 0],
+    [0, 0, 1, 0, 0, 1, 0, 0, 0], [1, 0, 1, 1, 0, 0, 1, 1, 0], [0, 1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 1, 1, 0, 0, 1],
+]
+FIXTURE_TO_PLAY = [2, 1, 2, 1, 1, 2, 2, 1, 1, 1, 2, 1, 2, 1, 1, 1]
+
+
+def fixture_legal_actions():
+    return [np.nonzero(np.array(m))[0].tolist() for m in FIXTURE_ACTION_MASK]
+
+
+CASES = {
+    # name: dict(variant, B, A, S, seed, legal, to_play, pb_c_base, pb_c_init, discount, delta, noise_w, horizon, scale)
+    "ez_probe_b4": dict(variant="ez", B=4, A=6, S=50, seed=0),
+    "ez_cfg2_b256": dict(variant="ez", B=256, A=6, S=50, seed=1),
+    "ez_fixture16": dict(variant="ez", B=16, A=9, S=8, seed=2, legal="fixture", to_play=[-1] * 16, pb_c_base=1,
+                         pb_c_init=1.0, discount=0.9, noise_w=0.2),
+    "ez_fixture16_2p": dict(variant="ez", B=16, A=9, S=40, seed=3, legal="fixture", to_play=FIXTURE_TO_PLAY,
+                            discount=1.0),
+    "ez_zero_ties": dict(variant="ez", B=8, A=6, S=30, seed=4, zero=True, noise_w=None),
+    "ez_big_a20": dict(variant="ez", B=32, A=20, S=100, seed=5),
+    "mz_cartpole": dict(variant="mz", B=8, A=2, S=25, seed=6),
+    "mz_breakout": dict(variant="mz", B=64, A=4, S=400, seed=7),
+    "mz_go82_2p": dict(variant="mz", B=16, A=82, S=200, seed=8, legal="random", to_play="random12", discount=1.0),
+    "mz_fixture16_2p": dict(variant="mz", B=16, A=9, S=40, seed=9, legal="fixture", to_play=FIXTURE_TO_PLAY),
+    "mz_zero_ties": dict(variant="mz", B=4, A=3, S=12, seed=10, zero=True, noise_w=None),
+}
+
+
+def make_inputs(case):
+    """Seeded synthetic 'network outputs' for every simulation of a case (all float32)."""
+    c = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.997, delta=0.01, noise_w=0.25, horizon=5, legal=None,
+             to_play=None, zero=False, scale=1.0)
+    c.update(case)
+    rng = np.random.default_rng(c["seed"])
+    B, A, S = c["B"], c["A"], c["S"]
+    if c["legal"] == "fixture":
+        legal = fixture_legal_actions()
+    elif c["legal"] == "random":
+        legal = []
+        for _ in range(B):
+            m = rng.random(A) < 0.6
+            m[A - 1] = True  # "pass" always legal
+            legal.append(np.nonzero(m)[0].tolist())
+    else:
+        legal = [list(range(A)) for _ in range(B)]
+    if c["to_play"] is None:
+        to_play = [-1] * B
+    elif c["to_play"] == "random12":
+        to_play = rng.integers(1, 3, size=B).tolist()
+    else:
+        to_play = list(c["to_play"])
+    z = 0.0 if c["zero"] else 1.0
+    root_logits = (z * c["scale"] * rng.standard_normal((B, A))).astype(np.float32)
+    root_vp = np.zeros(B, np.float32)  # initial_inference: value_prefix = [0.]*B (efficientzero_model.py:238)
+    if c["variant"] == "mz":
+        root_vp = (z * 0.1 * rng.standard_normal(B)).astype(np.float32)  # MuZero roots carry a reward
+    noises = None
+    if c["noise_w"] is not None:
+        noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    sims = []
+    for _ in range(S):
+        sims.append(dict(
+            vp=(z * 0.5 * rng.standard_normal(B)).astype(np.float32),
+            v=(z * rng.standard_normal(B)).astype(np.float32),
+            logits=(z * c["scale"] * rng.standard_normal((B, A))).astype(np.float32),
+        ))
+    c.update(legal_list=legal, to_play_list=to_play, root_logits=root_logits, root_vp=root_vp, noises=noises, sims=sims)
+    return c
+
+
+def run_tree(mod, c, roots_kwargs=None, traverse_kwargs=None):
+    """Returns dict(records=int32 [S,B,5] (ix,iy,last_action,search_len,virtual_to_play),
+    distributions=list[list[int]], values=float32 [B])."""
+    B, S = c["B"], c["S"]
+    ez = c["variant"] == "ez"
+    roots = mod.Roots(B, c["legal_list"], **(roots_kwargs or {}))
+    if c["noises"] is not None:
+        roots.prepare(c["noise_w"], c["noises"], c["root_vp"].tolist(), c["root_logits"].tolist(), list(c["to_play_list"]))
+    else:
+        roots.prepare_no_noise(c["root_vp"].tolist(), c["root_logits"].tolist(), list(c["to_play_list"]))
+    mm = mod.MinMaxStatsList(B)
+    mm.set_delta(c["delta"])
+    rec = np.zeros((S, B, 5), np.int32)
+    for s in range(S):
+        res = mod.ResultsWrapper(B)
+        ix, iy, la, vtp = mod.batch_traverse(roots, c["pb_c_base"], c["pb_c_init"], c["discount"], mm, res,
+                                             list(c["to_play_list"]), **(traverse_kwargs or {}))
+        sl = res.get_search_len()
+        rec[s, :, 0], rec[s, :, 1], rec[s, :, 2], rec[s, :, 3], rec[s, :, 4] = ix, iy, la, sl, vtp
+        sim = c["sims"][s]
+        if ez:
+            reset = [int(l % c["horizon"] == 0) for l in sl]
+            mod.batch_backpropagate(s + 1, c["discount"], sim["vp"].tolist(), sim["v"].tolist(), sim["logits"].tolist(),
+                                    mm, res, reset, vtp)
+        else:
+            mod.batch_backpropagate(s + 1, c["discount"], sim["vp"].tolist(), sim["v"].tolist(), sim["logits"].tolist(),
+                                    mm, res, vtp)
+    out = dict(records=rec, distributions=roots.get_distributions(),
+               values=np.asarray(roots.get_values(), np.float32))
+    if hasattr(roots, "get_minmax"):
+        out["minmax"] = np.asarray(roots.get_minmax(), np.float32)
+    return out
+
+
+def assert_same(a, b, what=""):
+    assert np.array_equal(a["records"], b["records"]), "%s: per-simulation (ix,iy,action,len,to_play) differ" % what
+    assert a["distributions"] == b["distributions"], "%s: visit-count distributions differ" % what
+    # bit-exact: same float32 op order on both sides
+    assert np.array_equal(a["values"].view(np.uint32), b["values"].view(np.uint32)), "%s: root values differ" % what
