@@ -1,0 +1,118 @@
+/*
+ * lz_mi355.h -- C ABI of the MI355X-native batched self-play / MCTS inference engine.
+ *
+ * This is the drop-in boundary for LightZero's hot path.  Each entry point
+ * names the reference interface it replaces (paths relative to the LightZero repository root).
+ * Plain C: opaque handles, pointers and sizes only -- no torch types.  Every function returns
+ * LZ_OK (0) or a negative lz_status; the message of the last error on the calling thread is
+ * available from lz_last_error().  Nothing throws, nothing calls exit().  One HIP stream per
+ * engine; calls on one engine / roots handle must be serialised by the caller (the reference's
+ * Cython module holds the GIL for the whole call and is not re-entrant either).
+ *
+ * Pointer conventions: parameters named  h_*  are HOST pointers (copied synchronously, like the
+ * reference's list -> std::vector deep copies, ez_tree.pyx:82-91); parameters named  d_*  are
+ * DEVICE (HBM) pointers used in place on the engine's stream.
+ */
+#ifndef LZ_MI355_H
+#define LZ_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lz_status {
+    LZ_OK = 0,
+    LZ_ERR_INVALID = -1,   /* bad argument / call order */
+    LZ_ERR_HIP = -2,       /* HIP runtime failure (message has the hipError string) */
+    LZ_ERR_NOMEM = -3,
+    LZ_ERR_NODEVICE = -4,  /* no gfx950 device visible: the product path fails loudly, no CPU fallback */
+    LZ_ERR_STATE = -5      /* weights missing / not finalized / capacity exceeded */
+} lz_status;
+
+typedef enum lz_variant {
+    LZ_TREE_EFFICIENTZERO = 0, /* lzero/mcts/ctree/ctree_efficientzero (value-prefix tree, is_reset) */
+    LZ_TREE_MUZERO = 1         /* lzero/mcts/ctree/ctree_muzero (reward tree) */
+} lz_variant;
+
+typedef enum lz_tiebreak {
+    LZ_TIE_FIRST = 0,  /* front of the reference's tie list == first arg-max (mz_tree deterministic=True,
+                          ctree_muzero/lib/cnode.cpp:592; the rand()->0 build of ctree_efficientzero) */
+    LZ_TIE_RANDOM = 1  /* uniform over the reference's tie list (cnode.cpp:668-693), counter-based RNG */
+} lz_tiebreak;
+
+typedef struct lz_engine lz_engine; /* device context: stream, weights, workspaces */
+typedef struct lz_roots lz_roots;   /* a batch of search trees + their min-max stats + last search results */
+
+const char *lz_last_error(void);
+int lz_version(void);
+/* number of visible gfx950 devices (0 => every compute entry point returns LZ_ERR_NODEVICE) */
+int lz_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine
+ * ---------------------------------------------------------------------------------------------- */
+/* device_index: HIP device ordinal (LOCAL_RANK in a one-process-per-GPU job). */
+int lz_engine_create(int device_index, lz_engine **out);
+int lz_engine_destroy(lz_engine *e);
+int lz_engine_synchronize(lz_engine *e);
+/* the engine's hipStream_t as an opaque pointer (so a caller can order its own work / events on it) */
+void *lz_engine_stream(lz_engine *e);
+
+/* ------------------------------------------------------------------------------------------------
+ * Trees -- replaces the Cython module surface of ez_tree.pyx / mz_tree.pyx
+ * ---------------------------------------------------------------------------------------------- */
+/* Roots(root_num, legal_actions_list)            ez_tree.pyx:29-32 -> CRoots::CRoots cnode.cpp:305-321
+ * + MinMaxStatsList(num)                         ez_tree.pyx:6-10  -> cminimax.cpp:51-59
+ * h_legal_flat: concatenated legal-action lists (order preserved), h_legal_count[root_num] their lengths
+ * (a length of 0 means "all actions", cnode.cpp:106-112).  max_simulations bounds the node pool:
+ * (max_simulations + 1) expanded nodes x action_space_size edges per root, resident in HBM. */
+int lz_roots_create(lz_engine *e, int variant, int root_num, int action_space_size, int max_simulations,
+                    const int32_t *h_legal_flat, const int32_t *h_legal_count, lz_roots **out);
+int lz_roots_destroy(lz_roots *r);
+int lz_roots_num(const lz_roots *r);
+/* MinMaxStatsList.set_delta                      ez_tree.pyx:12-14 -> cminimax.cpp:61-65.
+ * Also resets min/max to (+FLOAT_MAX, -FLOAT_MAX) like a freshly constructed MinMaxStatsList. */
+int lz_roots_minmax_reset(lz_roots *r, float value_delta_max);
+int lz_roots_set_tiebreak(lz_roots *r, int mode, uint64_t seed);
+
+/* Roots.prepare / prepare_no_noise               ez_tree.pyx:34-42 -> CRoots::prepare cnode.cpp:325-360
+ * h_noises_flat: per root, one noise per LEGAL action in list order (cnode.cpp:163-170); NULL => no noise.
+ * h_value_prefix: EZ value prefixes / MZ rewards [root_num]; h_policy_logits [root_num][A]; h_to_play [root_num]. */
+int lz_roots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises_flat, const float *h_value_prefix,
+                     const float *h_policy_logits, const int32_t *h_to_play);
+/* same with device-resident inputs; d_noises is [root_num][A] indexed by position in the legal list */
+int lz_roots_prepare_device(lz_roots *r, float root_noise_weight, const float *d_noises, const float *d_value_prefix,
+                            const float *d_policy_logits, const int32_t *d_to_play, int players);
+
+/* batch_traverse(roots, pb_c_base, pb_c_init, discount, minmax, results, virtual_to_play)
+ *                                                ez_tree.pyx:107-113 -> cbatch_traverse cnode.cpp:886-963
+ *                                                mz_tree.pyx:95-98   -> ctree_muzero cnode.cpp:754-825
+ * h_virtual_to_play is in/out (flipped once per level in 2-player mode).  Outputs [root_num] each:
+ * latent_state_index_in_search_path, latent_state_index_in_batch, last_actions, search_lens
+ * (ResultsWrapper.get_search_len, ez_tree.pyx:22-24). */
+int lz_batch_traverse(lz_roots *r, int pb_c_base, float pb_c_init, float discount_factor,
+                      int32_t *h_virtual_to_play, int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch,
+                      int32_t *h_out_last_actions, int32_t *h_out_search_lens);
+/* batch_backpropagate(current_latent_state_index, discount, value_prefixs, values, policies, minmax, results,
+ *                     is_reset_list, to_play_batch)
+ *                                                ez_tree.pyx:82-92 -> cbatch_backpropagate cnode.cpp:577-601
+ * h_is_reset is ignored (may be NULL) for LZ_TREE_MUZERO. */
+int lz_batch_backpropagate(lz_roots *r, int current_latent_state_index, float discount_factor,
+                           const float *h_value_prefixs, const float *h_values, const float *h_policy_logits,
+                           const int32_t *h_is_reset, const int32_t *h_to_play);
+
+/* Roots.get_distributions / get_values / get_trajectories   ez_tree.pyx:44-54 -> cnode.cpp:371-419
+ * h_out_dist [root_num][A]: child visit counts in legal-list order, -1 padded; h_out_count [root_num]. */
+int lz_roots_get_distributions(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count);
+int lz_roots_get_values(lz_roots *r, float *h_out_values);
+/* h_out [root_num][stride]: best-action chain from each root, -1 terminated */
+int lz_roots_get_trajectories(lz_roots *r, int32_t *h_out, int stride);
+/* (minimum, maximum) per root [root_num][2] -- observability for tests */
+int lz_roots_get_minmax(lz_roots *r, float *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZ_MI355_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of liblz_mi355.so (include/lz_mi355.h).  There is NO fallback: if the HIP
+library is missing or no gfx950 device is visible, compute entry points raise."""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblz_mi355.so")
+
+
+class LzError(RuntimeError):
+    pass
+
+
+_lib = None
+c_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+c_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+P = ctypes.c_void_p
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LzError("%s not found: build it with `python -m lightzero_amd.build` (hipcc, gfx950). "
+                      "lightzero_amd has no CPU/PyTorch fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.lz_last_error.restype = ctypes.c_char_p
+    L.lz_engine_stream.restype = P
+    sig = {
+        "lz_engine_create": [ctypes.c_int, ctypes.POINTER(P)],
+        "lz_engine_destroy": [P],
+        "lz_engine_synchronize": [P],
+        "lz_engine_stream": [P],
+        "lz_roots_create": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(P)],
+        "lz_roots_destroy": [P],
+        "lz_roots_minmax_reset": [P, ctypes.c_float],
+        "lz_roots_set_tiebreak": [P, ctypes.c_int, ctypes.c_uint64],
+        "lz_roots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_i32p],
+        "lz_roots_prepare_device": [P, ctypes.c_float, P, P, P, P, ctypes.c_int],
+        "lz_batch_traverse": [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
+        "lz_batch_backpropagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p, P, c_i32p],
+        "lz_roots_get_distributions": [P, c_i32p, c_i32p],
+        "lz_roots_get_values": [P, c_f32p],
+        "lz_roots_get_trajectories": [P, c_i32p, ctypes.c_int],
+        "lz_roots_get_minmax": [P, c_f32p],
+    }
+    for name, argtypes in sig.items():
+        getattr(L, name).argtypes = argtypes
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise LzError("liblz_mi355: %s (status %d)" % (lib().lz_last_error().decode(), rc))
+
+
+_engines = {}
+
+
+def default_engine(device_index=None):
+    """One engine (HIP stream + weights) per device per process; device defaults to LOCAL_RANK."""
+    if device_index is None:
+        device_index = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_index not in _engines:
+        h = P()
+        check(lib().lz_engine_create(device_index, ctypes.byref(h)))
+        _engines[device_index] = h
+    return _engines[device_index]
+
+
+def f32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def i32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int32))

@@ -1,0 +1,424 @@
+// lz_capi.hip -- the extern "C" boundary (include/lz_mi355.h): handle lifetime, host<->HBM staging
+// for the fine-grained tree API, error reporting.  No compute happens on the host.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "lz_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void lz_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *lz_last_error(void) { return g_err; }
+extern "C" int lz_version(void) { return 100; }
+
+extern "C" int lz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+void lz_model_destroy(lz_model *m);
+
+extern "C" int lz_engine_create(int device_index, lz_engine **out)
+{
+    LZ_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        lz_set_error("no HIP device visible: liblz_mi355 has no CPU fallback");
+        return LZ_ERR_NODEVICE;
+    }
+    LZ_REQUIRE(device_index >= 0 && device_index < n, "device_index out of range");
+    hipDeviceProp_t p;
+    LZ_HIP_CHECK(hipGetDeviceProperties(&p, device_index));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        lz_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device_index, p.gcnArchName);
+        return LZ_ERR_NODEVICE;
+    }
+    LZ_HIP_CHECK(hipSetDevice(device_index));
+    lz_engine *e = new (std::nothrow) lz_engine();
+    if (!e) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+    e->device = device_index;
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) { delete e; lz_set_error("hipStreamCreate: %s", hipGetErrorString(err)); return LZ_ERR_HIP; }
+    *out = e;
+    return LZ_OK;
+}
+
+extern "C" int lz_engine_destroy(lz_engine *e)
+{
+    if (!e) return LZ_OK;
+    (void)hipSetDevice(e->device);
+    if (e->model) lz_model_destroy(e->model);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return LZ_OK;
+}
+
+extern "C" int lz_engine_synchronize(lz_engine *e)
+{
+    LZ_REQUIRE(e != nullptr, "engine is NULL");
+    LZ_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return LZ_OK;
+}
+
+extern "C" void *lz_engine_stream(lz_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int ensure_stage(lz_roots *r, size_t bytes)
+{
+    if (bytes <= r->stage_bytes) return LZ_OK;
+    if (r->h_stage) (void)hipHostFree(r->h_stage);
+    if (r->d_stage) (void)hipFree(r->d_stage);
+    r->h_stage = r->d_stage = nullptr;
+    r->stage_bytes = 0;
+    bytes = align_up(bytes, 4096);
+    LZ_HIP_CHECK(hipHostMalloc(&r->h_stage, bytes, hipHostMallocDefault));
+    LZ_HIP_CHECK(hipMalloc(&r->d_stage, bytes));
+    r->stage_bytes = bytes;
+    return LZ_OK;
+}
+
+int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roots **out)
+{
+    lz_roots *r = new (std::nothrow) lz_roots();
+    if (!r) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+    r->eng = e;
+    lz_tree_dev &t = r->t;
+    t.B = B; t.A = A; t.NN = max_sims + 1; t.variant = variant;
+    const size_t nBNA = (size_t)B * t.NN * A, nBN = (size_t)B * t.NN;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_edge = take(nBNA * sizeof(float4)), o_child = take(nBNA * 4), o_vp = take(nBN * 4),
+                 o_reset = take(nBN * 4), o_tp = take(nBN * 4), o_best = take(nBN * 4), o_rv = take((size_t)B * 4),
+                 o_rs = take((size_t)B * 4), o_legal = take((size_t)B * A * 4), o_nl = take((size_t)B * 4),
+                 o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5);
+    hipError_t err = hipMalloc(&r->slab, off);
+    if (err != hipSuccess) {
+        delete r;
+        lz_set_error("hipMalloc(%zu bytes) for the node pool failed: %s", off, hipGetErrorString(err));
+        return err == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP;
+    }
+    r->slab_bytes = off;
+    char *base = (char *)r->slab;
+    t.edge = (float4 *)(base + o_edge); t.child = (int32_t *)(base + o_child); t.node_vp = (float *)(base + o_vp);
+    t.node_reset = (int32_t *)(base + o_reset); t.node_to_play = (int32_t *)(base + o_tp);
+    t.node_best = (int32_t *)(base + o_best); t.root_visit = (int32_t *)(base + o_rv); t.root_vsum = (float *)(base + o_rs);
+    t.legal = (int32_t *)(base + o_legal); t.n_legal = (int32_t *)(base + o_nl); t.minmax = (float *)(base + o_mm);
+    t.path_node = (int32_t *)(base + o_pn); t.path_act = (int32_t *)(base + o_pa);
+    int32_t *res = (int32_t *)(base + o_res);
+    t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
+    *out = r;
+    return LZ_OK;
+}
+
+int lz_roots_upload_legal(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count)
+{
+    const lz_tree_dev &t = r->t;
+    const int B = t.B, A = t.A;
+    int rc = ensure_stage(r, (size_t)B * A * 4 + (size_t)B * 4);
+    if (rc != LZ_OK) return rc;
+    int32_t *hl = (int32_t *)r->h_stage;
+    int32_t *hn = hl + (size_t)B * A;
+    size_t off = 0;
+    for (int i = 0; i < B; ++i) {
+        int n = h_legal_count ? h_legal_count[i] : 0;
+        if (n < 0 || n > A) { lz_set_error("legal action count %d of root %d out of range [0,%d]", n, i, A); return LZ_ERR_INVALID; }
+        if (n == 0) {  // empty list == all actions (cnode.cpp:106-112)
+            for (int a = 0; a < A; ++a) hl[(size_t)i * A + a] = a;
+            hn[i] = A;
+        } else {
+            for (int j = 0; j < n; ++j) {
+                int a = h_legal_flat[off + j];
+                if (a < 0 || a >= A) { lz_set_error("legal action %d of root %d out of range [0,%d)", a, i, A); return LZ_ERR_INVALID; }
+                hl[(size_t)i * A + j] = a;
+            }
+            for (int j = n; j < A; ++j) hl[(size_t)i * A + j] = 0;
+            hn[i] = n;
+            off += n;
+        }
+    }
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(t.legal, hl, (size_t)B * A * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(t.n_legal, hn, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_create(lz_engine *e, int variant, int root_num, int action_space_size, int max_simulations,
+                               const int32_t *h_legal_flat, const int32_t *h_legal_count, lz_roots **out)
+{
+    LZ_REQUIRE(e != nullptr && out != nullptr, "engine/out is NULL");
+    *out = nullptr;
+    LZ_REQUIRE(variant == LZ_TREE_EFFICIENTZERO || variant == LZ_TREE_MUZERO, "unknown tree variant");
+    LZ_REQUIRE(root_num > 0 && action_space_size > 0 && max_simulations > 0, "root_num, action_space_size, max_simulations must be positive");
+    LZ_REQUIRE(action_space_size <= 256, "action_space_size > 256 is not supported by the wave-per-root tree kernels");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    lz_roots *r = nullptr;
+    int rc = lz_roots_alloc(e, variant, root_num, action_space_size, max_simulations, &r);
+    if (rc != LZ_OK) return rc;
+    rc = lz_roots_upload_legal(r, h_legal_flat, h_legal_count);
+    if (rc != LZ_OK) { lz_roots_destroy(r); return rc; }
+    lz_tree_launch_minmax_reset(r->t, e->stream);
+    *out = r;
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_destroy(lz_roots *r)
+{
+    if (!r) return LZ_OK;
+    (void)hipSetDevice(r->eng->device);
+    (void)hipStreamSynchronize(r->eng->stream);
+    if (r->slab) (void)hipFree(r->slab);
+    if (r->h_stage) (void)hipHostFree(r->h_stage);
+    if (r->d_stage) (void)hipFree(r->d_stage);
+    delete r;
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_num(const lz_roots *r) { return r ? r->t.B : LZ_ERR_INVALID; }
+
+extern "C" int lz_roots_minmax_reset(lz_roots *r, float value_delta_max)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    r->delta = value_delta_max;
+    lz_tree_launch_minmax_reset(r->t, r->eng->stream);
+    LZ_HIP_CHECK(hipGetLastError());
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_set_tiebreak(lz_roots *r, int mode, uint64_t seed)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(mode == LZ_TIE_FIRST || mode == LZ_TIE_RANDOM, "unknown tie-break mode");
+    r->tiebreak = mode;
+    r->seed = seed;
+    return LZ_OK;
+}
+
+static int players_of(const int32_t *to_play, int n)
+{
+    int largest = to_play[0];  // cnode.cpp:906-915: players = 1 iff max(virtual_to_play) == -1
+    for (int i = 1; i < n; ++i) if (to_play[i] > largest) largest = to_play[i];
+    return largest == -1 ? 1 : 2;
+}
+
+extern "C" int lz_roots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
+                                const float *h_value_prefix, const float *h_policy_logits, const int32_t *h_to_play)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(h_value_prefix && h_policy_logits && h_to_play, "NULL input");
+    const lz_tree_dev &t = r->t;
+    const int B = t.B, A = t.A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    // staging layout: [noises B*A][noise_off B][vp B][logits B*A][to_play B]
+    const size_t need = ((size_t)B * A * 2 + (size_t)B * 3) * 4 + (size_t)B * A * 4 + (size_t)B * 4;
+    int rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    size_t o_nz = 0, o_off = o_nz + (size_t)B * A * 4, o_vp = o_off + (size_t)B * 4, o_lg = o_vp + (size_t)B * 4,
+           o_tp = o_lg + (size_t)B * A * 4, o_nl = o_tp + (size_t)B * 4, total = o_nl + (size_t)B * 4;
+    // noise offsets need the legal counts: fetch them (tiny)
+    int32_t *hn = (int32_t *)(h + o_nl);
+    LZ_HIP_CHECK(hipMemcpyAsync(hn, t.n_legal, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    int32_t *hoff = (int32_t *)(h + o_off);
+    size_t acc = 0;
+    for (int i = 0; i < B; ++i) { hoff[i] = (int32_t)acc; acc += hn[i]; }
+    if (h_noises_flat) memcpy(h + o_nz, h_noises_flat, acc * 4);
+    memcpy(h + o_vp, h_value_prefix, (size_t)B * 4);
+    memcpy(h + o_lg, h_policy_logits, (size_t)B * A * 4);
+    memcpy(h + o_tp, h_to_play, (size_t)B * 4);
+    (void)total;
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, o_nl, hipMemcpyHostToDevice, s));
+    lz_tree_launch_prepare(t, root_noise_weight, h_noises_flat ? (const float *)(d + o_nz) : nullptr, 1,
+                           (const int32_t *)(d + o_off), (const float *)(d + o_vp), (const float *)(d + o_lg),
+                           (const int32_t *)(d + o_tp), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    r->players = players_of(h_to_play, B);
+    r->prepared = true;
+    r->traverse_count = 0;
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_prepare_device(lz_roots *r, float root_noise_weight, const float *d_noises,
+                                       const float *d_value_prefix, const float *d_policy_logits,
+                                       const int32_t *d_to_play, int players)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(d_value_prefix && d_policy_logits && d_to_play, "NULL input");
+    LZ_REQUIRE(players == 1 || players == 2, "players must be 1 or 2");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    lz_tree_launch_prepare(r->t, root_noise_weight, d_noises, 0, nullptr, d_value_prefix, d_policy_logits, d_to_play,
+                           r->eng->stream);
+    LZ_HIP_CHECK(hipGetLastError());
+    r->players = players;
+    r->prepared = true;
+    r->traverse_count = 0;
+    return LZ_OK;
+}
+
+extern "C" int lz_batch_traverse(lz_roots *r, int pb_c_base, float pb_c_init, float discount_factor,
+                                 int32_t *h_virtual_to_play, int32_t *h_out_index_in_search_path,
+                                 int32_t *h_out_index_in_batch, int32_t *h_out_last_actions, int32_t *h_out_search_lens)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->prepared, "batch_traverse before Roots.prepare");
+    LZ_REQUIRE(h_virtual_to_play && h_out_index_in_search_path && h_out_index_in_batch && h_out_last_actions && h_out_search_lens, "NULL buffer");
+    const lz_tree_dev &t = r->t;
+    const int B = t.B;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = ensure_stage(r, (size_t)B * 4 * 6);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    memcpy(r->h_stage, h_virtual_to_play, (size_t)B * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(r->d_stage, r->h_stage, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    lz_traverse_args a;
+    a.pb_c_base = pb_c_base; a.pb_c_init = pb_c_init; a.discount = discount_factor;
+    a.players = players_of(h_virtual_to_play, B);
+    a.tiebreak = r->tiebreak; a.seed = r->seed; a.counter = r->traverse_count++;
+    r->players = a.players;
+    lz_tree_launch_traverse(t, a, r->delta, (const int32_t *)r->d_stage, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    // res_ix .. res_vtp are contiguous [5][B]
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, t.res_ix, (size_t)B * 4 * 5, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    const int32_t *h = (const int32_t *)r->h_stage;
+    memcpy(h_out_index_in_search_path, h, (size_t)B * 4);
+    memcpy(h_out_index_in_batch, h + B, (size_t)B * 4);
+    memcpy(h_out_last_actions, h + 2 * B, (size_t)B * 4);
+    memcpy(h_out_search_lens, h + 3 * B, (size_t)B * 4);
+    memcpy(h_virtual_to_play, h + 4 * B, (size_t)B * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_batch_backpropagate(lz_roots *r, int current_latent_state_index, float discount_factor,
+                                      const float *h_value_prefixs, const float *h_values, const float *h_policy_logits,
+                                      const int32_t *h_is_reset, const int32_t *h_to_play)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->prepared, "batch_backpropagate before Roots.prepare");
+    LZ_REQUIRE(h_value_prefixs && h_values && h_policy_logits && h_to_play, "NULL input");
+    const lz_tree_dev &t = r->t;
+    const int B = t.B, A = t.A;
+    if (current_latent_state_index < 1 || current_latent_state_index >= t.NN) {
+        lz_set_error("current_latent_state_index %d outside the node pool [1,%d]: create the roots with a larger max_simulations",
+                     current_latent_state_index, t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    LZ_REQUIRE(t.variant == LZ_TREE_MUZERO || h_is_reset != nullptr, "is_reset_list is required for the EfficientZero tree");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    const size_t need = ((size_t)B * 4 + (size_t)B * A) * 4;
+    int rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    const size_t o_vp = 0, o_v = (size_t)B * 4, o_rst = o_v + (size_t)B * 4, o_tp = o_rst + (size_t)B * 4, o_lg = o_tp + (size_t)B * 4;
+    memcpy(h + o_vp, h_value_prefixs, (size_t)B * 4);
+    memcpy(h + o_v, h_values, (size_t)B * 4);
+    if (h_is_reset) memcpy(h + o_rst, h_is_reset, (size_t)B * 4); else memset(h + o_rst, 0, (size_t)B * 4);
+    memcpy(h + o_tp, h_to_play, (size_t)B * 4);
+    memcpy(h + o_lg, h_policy_logits, (size_t)B * A * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, s));
+    lz_tree_launch_backprop(t, current_latent_state_index, discount_factor, (const float *)(d + o_vp), (const float *)(d + o_v),
+                            (const float *)(d + o_lg), (const int32_t *)(d + o_rst), 0, (const int32_t *)(d + o_tp), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_get_distributions(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count)
+{
+    LZ_REQUIRE(r != nullptr && h_out_dist != nullptr, "NULL argument");
+    const lz_tree_dev &t = r->t;
+    const int B = t.B, A = t.A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    if (!r->prepared) {  // get_children_distribution of an unexpanded root is empty (cnode.cpp:272)
+        for (size_t i = 0; i < (size_t)B * A; ++i) h_out_dist[i] = -1;
+        if (h_out_count) memset(h_out_count, 0, (size_t)B * 4);
+        return LZ_OK;
+    }
+    int rc = ensure_stage(r, ((size_t)B * A + 2 * (size_t)B) * 4);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    int32_t *d = (int32_t *)r->d_stage;
+    lz_tree_launch_readout(t, d, d + (size_t)B * A, nullptr, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, d, ((size_t)B * A + B) * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_out_dist, r->h_stage, (size_t)B * A * 4);
+    if (h_out_count) memcpy(h_out_count, (int32_t *)r->h_stage + (size_t)B * A, (size_t)B * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_get_values(lz_roots *r, float *h_out_values)
+{
+    LZ_REQUIRE(r != nullptr && h_out_values != nullptr, "NULL argument");
+    const lz_tree_dev &t = r->t;
+    const int B = t.B, A = t.A;
+    if (!r->prepared) { memset(h_out_values, 0, (size_t)B * 4); return LZ_OK; }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = ensure_stage(r, ((size_t)B * A + 2 * (size_t)B) * 4);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    int32_t *d = (int32_t *)r->d_stage;
+    float *dv = (float *)(d + (size_t)B * A + B);
+    lz_tree_launch_readout(t, d, nullptr, dv, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, dv, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_out_values, r->h_stage, (size_t)B * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_get_trajectories(lz_roots *r, int32_t *h_out, int stride)
+{
+    LZ_REQUIRE(r != nullptr && h_out != nullptr && stride >= 1, "bad argument");
+    const lz_tree_dev &t = r->t;
+    const int B = t.B;
+    if (!r->prepared) { for (int i = 0; i < B; ++i) h_out[(size_t)i * stride] = -1; return LZ_OK; }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = ensure_stage(r, (size_t)B * stride * 4);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    lz_tree_launch_trajectories(t, (int32_t *)r->d_stage, stride, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->d_stage, (size_t)B * stride * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_out, r->h_stage, (size_t)B * stride * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_get_minmax(lz_roots *r, float *h_out)
+{
+    LZ_REQUIRE(r != nullptr && h_out != nullptr, "NULL argument");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    int rc = ensure_stage(r, (size_t)r->t.B * 8);
+    if (rc != LZ_OK) return rc;
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->t.minmax, (size_t)r->t.B * 8, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_out, r->h_stage, (size_t)r->t.B * 8);
+    return LZ_OK;
+}

@@ -1,0 +1,101 @@
+// Internal (non-ABI) definitions shared by the translation units of liblz_mi355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lz_mi355.h"
+
+void lz_set_error(const char *fmt, ...);
+
+#define LZ_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            lz_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LZ_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define LZ_REQUIRE(cond, msg)                    \
+    do {                                         \
+        if (!(cond)) {                           \
+            lz_set_error("%s (%s)", msg, #cond); \
+            return LZ_ERR_INVALID;               \
+        }                                        \
+    } while (0)
+
+struct lz_model;  // network weights + workspaces (lz_nn.hip)
+
+struct lz_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    lz_model *model = nullptr;
+};
+
+// HBM-resident node arrays of a batch of trees.
+//
+// Expanded node n of root b  <=>  latent-state index n (root = 0; the node expanded by simulation s
+// is s + 1 == `current_latent_state_index`, mcts_ctree.py:870).  A node's statistics live on the
+// EDGE that leads to it (the parent's child slot), so that one pUCT selection step reads A
+// consecutive 16-byte records: edge[b][n][a] = {prior, visit_count, value_sum, value_prefix(child)}.
+struct lz_tree_dev {
+    int B, A, NN;               // roots, action space, nodes per root (= max_simulations + 1)
+    int variant;
+    float4 *edge;               // [B][NN][A]  {prior, visit(int bits), value_sum, child value_prefix / reward}
+    int32_t *child;             // [B][NN][A]  expanded-node index of the child, -1 = not expanded, -2 = illegal
+    float *node_vp;             // [B][NN]     value_prefix / reward of the expanded node itself
+    int32_t *node_reset;        // [B][NN]     is_reset (EZ)
+    int32_t *node_to_play;      // [B][NN]
+    int32_t *node_best;         // [B][NN]     best_action (last selected action at this node)
+    int32_t *root_visit;        // [B]
+    float *root_vsum;           // [B]
+    int32_t *legal;             // [B][A]      root legal-action list, order preserved
+    int32_t *n_legal;           // [B]         (A and identity list when the reference list is empty)
+    float *minmax;              // [B][2]      (minimum, maximum)
+    // results of the last traverse (CSearchResults, cnode.h:66-80)
+    int32_t *path_node;         // [B][NN]     expanded nodes on the search path, root first
+    int32_t *path_act;          // [B][NN]     action taken at path_node[k]
+    int32_t *res_ix, *res_iy, *res_last_action, *res_search_len, *res_vtp;  // [B] each
+};
+
+struct lz_roots {
+    lz_engine *eng = nullptr;
+    lz_tree_dev t{};
+    void *slab = nullptr;        // one allocation backing every array above
+    size_t slab_bytes = 0;
+    float delta = 0.0f;
+    int tiebreak = LZ_TIE_FIRST;
+    uint64_t seed = 0;
+    uint32_t traverse_count = 0;
+    int players = 1;             // from the last traverse's virtual_to_play (cnode.cpp:906-915)
+    bool prepared = false;
+    // pinned host staging for the fine-grained (host-pointer) API
+    void *h_stage = nullptr;
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+// lz_tree.hip launchers (all asynchronous on `stream`)
+struct lz_traverse_args {
+    int pb_c_base;
+    float pb_c_init, discount;
+    int players;
+    int tiebreak;
+    uint64_t seed;
+    uint32_t counter;
+};
+void lz_tree_launch_minmax_reset(const lz_tree_dev &t, hipStream_t s);
+void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int noises_ragged,
+                            const int32_t *d_noise_off, const float *d_vp, const float *d_logits,
+                            const int32_t *d_to_play, hipStream_t s);
+void lz_tree_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
+                             hipStream_t s);
+// d_is_reset may be null; when horizon > 0 the kernel derives is_reset = (search_len % horizon == 0)
+// (mcts_ctree.py:859) itself and also writes it to d_is_reset_out if that is non-null.
+void lz_tree_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp,
+                             const float *d_values, const float *d_logits, const int32_t *d_is_reset, int horizon,
+                             const int32_t *d_to_play, hipStream_t s);
+void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s);
+void lz_tree_launch_trajectories(const lz_tree_dev &t, int32_t *d_out, int stride, hipStream_t s);

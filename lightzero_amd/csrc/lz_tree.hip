@@ -1,0 +1,510 @@
+// lz_tree.hip -- on-device MCTS tree kernels for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one root's tree for a whole kernel: lanes span the children of the
+// current node (one coalesced 16-byte edge record per lane), selection is a wave arg-max, the
+// softmax/mean-Q sums are replayed in the reference's order with v_readlane so that every float
+// matches the CPU tree bit for bit, and the backup is a parallel path gather followed by a short
+// scalar recurrence.  One launch advances ALL roots by one simulation.
+//
+// Reference semantics restated here (LightZero v0.2.0):
+//   lzero/mcts/ctree/ctree_efficientzero/lib/cnode.cpp   expand :88-151, add_exploration_noise :153-171,
+//       compute_mean_q :173-212, cbackpropagate :482-575, cselect_child :651-695, cucb_score :756-814,
+//       cbatch_traverse :886-963, cbatch_backpropagate :577-601, get_distributions/values :389-419
+//   lzero/mcts/ctree/ctree_muzero/lib/cnode.cpp          (reward instead of value prefix, no is_reset)
+//   lzero/mcts/ctree/common_lib/cminimax.cpp             update :19-26, normalize :33-45
+//
+// Compiled with -ffp-contract=off: the reference is built for baseline x86-64 (no FMA), so
+// `r + gamma * v` must stay a rounded multiply followed by a rounded add.  expf/logf come from
+// lz_math.h (bit-identical to the host libm the reference links); division and sqrt are the
+// correctly rounded HIP defaults.
+#include "lz_internal.h"
+#include "lz_math.h"
+
+#define LZ_FLOAT_MAX 1000000.0f  // cminimax.h:9
+#define LZ_FLOAT_MIN (-LZ_FLOAT_MAX)
+
+namespace {
+
+__device__ __forceinline__ float rl_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float mm_normalize(float v, float mn, float mx, float delta_max)
+{
+    const float d = mx - mn;  // cminimax.cpp:33-45
+    if (d > 0) {
+        if (d < delta_max) v = (v - mn) / delta_max;
+        else v = (v - mn) / d;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepare: CRoots::prepare / prepare_no_noise  (cnode.cpp:325-360) = expand root + noise + visit_count += 1
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(64) void k_prepare(lz_tree_dev t, float noise_w, const float *__restrict__ noises,
+                                                int ragged, const int32_t *__restrict__ noise_off,
+                                                const float *__restrict__ vps, const float *__restrict__ logits,
+                                                const int32_t *__restrict__ to_play)
+{
+    extern __shared__ float sm[];  // [A] prior by action, then [A] int flag
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    float *s_prior = sm;
+    int *s_flag = reinterpret_cast<int *>(sm + A);
+    for (int a = lane; a < A; a += 64) { s_prior[a] = 0.0f; s_flag[a] = 0; }
+    __syncthreads();
+    const int n = uni(t.n_legal[b]);
+    float lg[NC], e[NC];
+    int act[NC];
+    float m = LZ_FLOAT_MIN;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        act[c] = (j < n) ? t.legal[(size_t)b * A + j] : 0;
+        lg[c] = (j < n) ? logits[(size_t)b * A + act[c]] : LZ_FLOAT_MIN;
+        m = fmaxf(m, lg[c]);
+    }
+    m = wave_max(m);  // policy_max (order independent); starts from FLOAT_MIN like cnode.cpp:123
+#pragma unroll
+    for (int c = 0; c < NC; ++c) e[c] = lz_expf(lg[c] - m);
+    float sum = 0.0f;  // policy_sum accumulated in legal-list order (cnode.cpp:132-137)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int cnt = min(64, n - c * 64);
+        for (int j = 0; j < cnt; ++j) sum += rl_f(e[c], j);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        if (j < n) {
+            float prior = e[c] / sum;
+            if (noises) {  // add_exploration_noise cnode.cpp:163-170: noise indexed by position in the legal list
+                const float nz = ragged ? noises[noise_off[b] + j] : noises[(size_t)b * A + j];
+                prior = prior * (1 - noise_w) + nz * noise_w;
+            }
+            s_prior[act[c]] = prior;
+            s_flag[act[c]] = 1;
+        }
+    }
+    __syncthreads();
+    for (int a = lane; a < A; a += 64) {
+        const size_t o = ((size_t)b * NN + 0) * A + a;
+        t.edge[o] = make_float4(s_prior[a], __int_as_float(0), 0.0f, 0.0f);
+        t.child[o] = s_flag[a] ? -1 : -2;
+    }
+    if (lane == 0) {
+        const size_t o = (size_t)b * NN;
+        t.node_vp[o] = vps[b];
+        t.node_reset[o] = 0;
+        t.node_to_play[o] = to_play[b];
+        t.node_best[o] = -1;
+        t.root_visit[b] = 1;  // visit_count += 1 (cnode.cpp:341)
+        t.root_vsum[b] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// traverse: cbatch_traverse (cnode.cpp:886-963) -- select down to an unexpanded child
+// ------------------------------------------------------------------------------------------------
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args a, float delta_max,
+                                                 const int32_t *__restrict__ vtp_in)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    const float4 *edge_b = t.edge + (size_t)b * NN * A;
+    const int32_t *child_b = t.child + (size_t)b * NN * A;
+    const float mn = t.minmax[2 * b], mx = t.minmax[2 * b + 1];
+    const float discount = a.discount;
+    const float base = (float)a.pb_c_base;
+    int vtp = vtp_in[b];
+    int node = 0, depth = 0, is_root = 1, last_action = -1;
+    int node_visit = t.root_visit[b];
+    float parent_q = 0.0f;
+
+    for (;;) {
+        const int n = is_root ? uni(t.n_legal[b]) : A;
+        const float node_vp = t.node_vp[(size_t)b * NN + node];
+        const int node_reset = t.node_reset[(size_t)b * NN + node];
+        float prior[NC], val[NC], tr[NC], score[NC];
+        int vis[NC], act[NC];
+        // ---- load the children (one 16-byte edge per lane) and compute_mean_q (cnode.cpp:173-212)
+        float total = 0.0f;
+        int nv = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            const bool valid = j < n;
+            act[c] = valid ? (is_root ? t.legal[(size_t)b * A + j] : j) : 0;
+            float4 e = valid ? edge_b[(size_t)node * A + act[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            prior[c] = e.x;
+            vis[c] = __float_as_int(e.y);
+            val[c] = (vis[c] == 0) ? 0.0f : e.z / (float)vis[c];  // CNode::value cnode.cpp:223-239
+            if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+                tr[c] = e.w - node_vp;
+                if (node_reset == 1) tr[c] = e.w;
+            } else {
+                tr[c] = e.w;
+            }
+            const float qsa = tr[c] + discount * val[c];
+            uint64_t mask = __ballot(valid && vis[c] > 0);
+            while (mask) {  // total_unsigned_q += qsa in legal-list order
+                const int j2 = __builtin_ctzll(mask);
+                total += rl_f(qsa, j2);
+                nv += 1;
+                mask &= mask - 1;
+            }
+        }
+        float mean_q;
+        if (is_root && nv > 0) mean_q = total / (float)nv;
+        else mean_q = (parent_q + total) / (float)(nv + 1);
+        is_root = 0;
+        parent_q = mean_q;
+
+        // ---- cucb_score (cnode.cpp:756-814) for every child
+        const float N = (float)(node_visit - 1);
+        const float pbc0 = lz_logf((N + base + 1) / base) + a.pb_c_init;
+        const float sq = sqrtf(N);
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            float pb_c = pbc0 * (sq / (float)(vis[c] + 1));
+            const float prior_score = pb_c * prior[c];
+            float value_score;
+            if (vis[c] == 0) value_score = mean_q;
+            else if (a.players == 1) value_score = tr[c] + discount * val[c];
+            else value_score = tr[c] + discount * (-val[c]);
+            value_score = mm_normalize(value_score, mn, mx, delta_max);
+            if (value_score < 0) value_score = 0;
+            else if (value_score > 1) value_score = 1;
+            score[c] = (j < n) ? prior_score + value_score : -__builtin_inff();
+            best = fmaxf(best, score[c]);
+        }
+        best = wave_max(best);
+        // ---- cselect_child (cnode.cpp:651-695): front of the tie list == first arg-max in list order
+        int pos = -1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const uint64_t mask = __ballot(score[c] == best);
+            if (pos < 0 && mask) pos = c * 64 + __builtin_ctzll(mask);
+        }
+        if (a.tiebreak == LZ_TIE_RANDOM && pos >= 0) {
+            // tie list = [first arg-max] + later entries with score >= max - 1e-6 (cnode.cpp:675-685)
+            const float thr = best - 0.000001f;
+            uint64_t masks[NC];
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int j = c * 64 + lane;
+                masks[c] = __ballot(j == pos || (j > pos && score[c] >= thr));
+                cnt += __builtin_popcountll(masks[c]);
+            }
+            const uint64_t h = mix64(a.seed ^ ((uint64_t)a.counter << 32) ^ ((uint64_t)b << 8) ^ (uint64_t)depth);
+            int r = (int)(h % (uint64_t)cnt);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint64_t mk = masks[c];
+                const int pc = __builtin_popcountll(mk);
+                if (r >= 0 && r < pc) {
+                    for (int q = 0; q < r; ++q) mk &= mk - 1;
+                    pos = c * 64 + __builtin_ctzll(mk);
+                    r = -1;
+                } else if (r >= pc) {
+                    r -= pc;
+                }
+            }
+        }
+        int action = 0, sel_visit = 0;
+        if (pos >= 0 && best > LZ_FLOAT_MIN) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if ((pos >> 6) == c) {
+                    action = rl_i(act[c], pos & 63);
+                    sel_visit = rl_i(vis[c], pos & 63);
+                }
+            }
+        }
+        if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
+        if (lane == 0) {
+            t.node_best[(size_t)b * NN + node] = action;
+            t.path_node[(size_t)b * NN + depth] = node;
+            t.path_act[(size_t)b * NN + depth] = action;
+        }
+        const int nxt = uni(child_b[(size_t)node * A + action]);
+        last_action = action;
+        depth += 1;
+        if (nxt < 0) break;  // reached an unexpanded child: the leaf
+        node = nxt;
+        node_visit = sel_visit;
+    }
+    if (lane == 0) {
+        t.res_ix[b] = node;  // parent->current_latent_state_index (cnode.cpp:955)
+        t.res_iy[b] = b;     // parent->batch_index
+        t.res_last_action[b] = last_action;
+        t.res_search_len[b] = depth;
+        t.res_vtp[b] = vtp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backpropagate: cbatch_backpropagate (cnode.cpp:577-601) = expand the leaf, then cbackpropagate
+// ------------------------------------------------------------------------------------------------
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_backprop(lz_tree_dev t, int new_node, float discount,
+                                                 const float *__restrict__ vps, const float *__restrict__ values,
+                                                 const float *__restrict__ logits,
+                                                 const int32_t *__restrict__ is_reset, int horizon,
+                                                 const int32_t *__restrict__ to_play_in)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    float4 *edge_b = t.edge + (size_t)b * NN * A;
+    int32_t *child_b = t.child + (size_t)b * NN * A;
+    const int d = uni(t.res_search_len[b]);
+    const int to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
+    const float vp_b = vps[b];
+    int reset = 0;
+    if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+        if (is_reset) reset = is_reset[b];
+        else if (horizon > 0) reset = (d % horizon == 0) ? 1 : 0;  // mcts_ctree.py:859
+    }
+    // ---- CNode::expand (cnode.cpp:88-151): all A actions are legal below the root
+    {
+        float lg[NC], e[NC];
+        float m = LZ_FLOAT_MIN;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            lg[c] = (j < A) ? logits[(size_t)b * A + j] : LZ_FLOAT_MIN;
+            m = fmaxf(m, lg[c]);
+        }
+        m = wave_max(m);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) e[c] = lz_expf(lg[c] - m);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cnt = min(64, A - c * 64);
+            for (int j = 0; j < cnt; ++j) sum += rl_f(e[c], j);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            if (j < A) {
+                const size_t o = (size_t)new_node * A + j;
+                edge_b[o] = make_float4(e[c] / sum, __int_as_float(0), 0.0f, 0.0f);
+                child_b[o] = -1;
+            }
+        }
+    }
+    const int parent = uni(t.path_node[(size_t)b * NN + d - 1]);
+    const int pact = uni(t.path_act[(size_t)b * NN + d - 1]);
+    if (lane == 0) {
+        child_b[(size_t)parent * A + pact] = new_node;
+        const size_t o = (size_t)b * NN + new_node;
+        t.node_vp[o] = vp_b;
+        t.node_reset[o] = reset;
+        t.node_to_play[o] = to_play;
+        t.node_best[o] = -1;
+    }
+    // ---- cbackpropagate (cnode.cpp:482-575): path node P_k, k = d (leaf) .. 0 (root); lane i of a
+    // chunk owns k = d - (chunk*64 + i).  Gather is parallel, the bootstrap recurrence is a scalar chain.
+    float bootstrap = values[b];
+    float mn = t.minmax[2 * b], mx = t.minmax[2 * b + 1];
+    for (int k0 = d; k0 >= 0; k0 -= 64) {
+        const int k = k0 - lane;
+        const bool valid = k >= 0;
+        int pn = 0, pa = 0, vis = 0, own_tp = to_play, parent_reset = 0;
+        float prior = 0.f, vsum = 0.f, own_vp = 0.f, parent_vp = 0.f;
+        if (valid) {
+            if (k >= 1) {
+                pn = t.path_node[(size_t)b * NN + k - 1];
+                pa = t.path_act[(size_t)b * NN + k - 1];
+                const float4 e = edge_b[(size_t)pn * A + pa];
+                prior = e.x;
+                vis = __float_as_int(e.y);
+                vsum = e.z;
+                own_vp = (k == d) ? vp_b : e.w;
+                parent_vp = t.node_vp[(size_t)b * NN + pn];
+                parent_reset = t.node_reset[(size_t)b * NN + pn];
+                if (k < d) own_tp = t.node_to_play[(size_t)b * NN + t.path_node[(size_t)b * NN + k]];
+            } else {
+                vis = t.root_visit[b];
+                vsum = t.root_vsum[b];
+                own_vp = t.node_vp[(size_t)b * NN];
+                own_tp = t.node_to_play[(size_t)b * NN];
+            }
+        }
+        float true_reward, tr_eff;
+        if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+            true_reward = own_vp - parent_vp;
+            tr_eff = (parent_reset == 1) ? own_vp : true_reward;
+        } else {
+            true_reward = own_vp;
+            tr_eff = own_vp;
+        }
+        const int same = (to_play == -1) ? 1 : (own_tp == to_play ? 1 : 0);
+        const int cnt = min(64, k0 + 1);
+        float my_boot = 0.0f;
+        for (int i = 0; i < cnt; ++i) {
+            if (lane == i) my_boot = bootstrap;
+            const float tre = rl_f(tr_eff, i);
+            if (to_play == -1) bootstrap = tre + discount * bootstrap;
+            else if (rl_i(same, i)) bootstrap = -tre + discount * bootstrap;
+            else bootstrap = tre + discount * bootstrap;
+        }
+        if (valid) {
+            vsum = same ? vsum + my_boot : vsum + (-my_boot);
+            vis += 1;
+            const float value = vsum / (float)vis;
+            float q;
+            if (VARIANT == LZ_TREE_EFFICIENTZERO) q = true_reward + discount * value;  // cnode.cpp:516/:558
+            else q = (to_play == -1) ? true_reward + discount * value : true_reward + discount * -value;
+            mx = fmaxf(mx, q);
+            mn = fminf(mn, q);
+            if (k >= 1) edge_b[(size_t)pn * A + pa] = make_float4(prior, __int_as_float(vis), vsum, own_vp);
+            else { t.root_visit[b] = vis; t.root_vsum[b] = vsum; }
+        }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    if (lane == 0) { t.minmax[2 * b] = mn; t.minmax[2 * b + 1] = mx; }
+}
+
+__global__ void k_minmax_reset(lz_tree_dev t)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.B) { t.minmax[2 * i] = LZ_FLOAT_MAX; t.minmax[2 * i + 1] = LZ_FLOAT_MIN; }  // cminimax.cpp:6-10
+}
+
+// get_distributions / get_values (cnode.cpp:389-419)
+__global__ void k_readout(lz_tree_dev t, int32_t *__restrict__ dist, int32_t *__restrict__ cnt,
+                          float *__restrict__ values)
+{
+    const int b = blockIdx.x;
+    const int A = t.A, NN = t.NN;
+    const int n = t.n_legal[b];
+    for (int j = threadIdx.x; j < A; j += blockDim.x) {
+        int v = -1;
+        if (j < n) v = __float_as_int(t.edge[((size_t)b * NN) * A + t.legal[(size_t)b * A + j]].y);
+        dist[(size_t)b * A + j] = v;
+    }
+    if (threadIdx.x == 0) {
+        if (cnt) cnt[b] = n;
+        const int rv = t.root_visit[b];
+        if (values) values[b] = (rv == 0) ? 0.0f : t.root_vsum[b] / (float)rv;
+    }
+}
+
+}  // namespace
+
+__global__ void lz_k_trajectories(lz_tree_dev t, int32_t *__restrict__ out, int stride)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= t.B) return;
+    const int A = t.A, NN = t.NN;
+    int node = 0, k = 0;
+    int best = t.node_best[(size_t)b * NN + node];  // CNode::get_trajectory cnode.cpp:241-261
+    while (best >= 0 && k < stride - 1) {
+        out[(size_t)b * stride + k++] = best;
+        node = t.child[((size_t)b * NN + node) * A + best];
+        if (node < 0) break;
+        best = t.node_best[(size_t)b * NN + node];
+    }
+    out[(size_t)b * stride + k] = -1;
+}
+
+static inline int nchunks(int A) { return (A + 63) / 64; }
+
+void lz_tree_launch_minmax_reset(const lz_tree_dev &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_minmax_reset, dim3((t.B + 255) / 256), dim3(256), 0, s, t);
+}
+
+void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int ragged,
+                            const int32_t *d_noise_off, const float *d_vp, const float *d_logits,
+                            const int32_t *d_to_play, hipStream_t s)
+{
+    const size_t sh = (size_t)t.A * 8;
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL(k_prepare<1>, dim3(t.B), dim3(64), sh, s, t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play); break;
+    case 2: hipLaunchKernelGGL(k_prepare<2>, dim3(t.B), dim3(64), sh, s, t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play); break;
+    default: hipLaunchKernelGGL(k_prepare<4>, dim3(t.B), dim3(64), sh, s, t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play); break;
+    }
+}
+
+template <int V>
+static void launch_traverse_v(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *vtp, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_traverse<1, V>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp); break;
+    case 2: hipLaunchKernelGGL((k_traverse<2, V>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp); break;
+    default: hipLaunchKernelGGL((k_traverse<4, V>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp); break;
+    }
+}
+
+void lz_tree_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
+                             hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO) launch_traverse_v<LZ_TREE_EFFICIENTZERO>(t, a, delta, d_vtp_in, s);
+    else launch_traverse_v<LZ_TREE_MUZERO>(t, a, delta, d_vtp_in, s);
+}
+
+template <int V>
+static void launch_backprop_v(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val,
+                              const float *lg, const int32_t *rst, int horizon, const int32_t *tp, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_backprop<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp); break;
+    case 2: hipLaunchKernelGGL((k_backprop<2, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp); break;
+    default: hipLaunchKernelGGL((k_backprop<4, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp); break;
+    }
+}
+
+void lz_tree_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp,
+                             const float *d_values, const float *d_logits, const int32_t *d_is_reset, int horizon,
+                             const int32_t *d_to_play, hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO)
+        launch_backprop_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s);
+    else
+        launch_backprop_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s);
+}
+
+void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_readout, dim3(t.B), dim3(64), 0, s, t, d_dist, d_cnt, d_values);
+}
+
+void lz_tree_launch_trajectories(const lz_tree_dev &t, int32_t *d_out, int stride, hipStream_t s)
+{
+    hipLaunchKernelGGL(lz_k_trajectories, dim3((t.B + 63) / 64), dim3(64), 0, s, t, d_out, stride);
+}

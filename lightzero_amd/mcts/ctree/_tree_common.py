@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's Cython tree modules on top of the C ABI.
+
+Same names, argument meaning and return values as lzero/mcts/ctree/ctree_efficientzero/ez_tree.pyx
+and lzero/mcts/ctree/ctree_muzero/mz_tree.pyx; the trees themselves live in HBM and every call
+runs HIP kernels (lightzero_amd/csrc/lz_tree.hip).  Differences, all forced by the flat node pool:
+
+* ``Roots(root_num, legal_actions_list, action_space_size=None, max_simulations=None)`` -- the node
+  pool is sized at construction; when the two extra arguments are omitted the action-space size is
+  taken at ``prepare`` time from the width of ``policy_logits_pool`` and ``max_simulations``
+  defaults to ``DEFAULT_MAX_SIMULATIONS``.
+* The min-max statistics live with the roots; a ``MinMaxStatsList`` is bound to the ``Roots`` it is
+  first used with (the reference constructs a fresh list for every search, mcts_ctree.py:778-779).
+* Tie-breaking defaults to the reference's stochastic rule (uniform over the tie list) for the
+  EfficientZero tree and follows the ``deterministic`` flag for the MuZero tree; call
+  ``Roots.set_tiebreak(0)`` for the deterministic first-arg-max rule.
+"""
+import ctypes
+
+import numpy as np
+
+from ... import _lib as L
+
+DEFAULT_MAX_SIMULATIONS = 512
+_seed_counter = [0x5EED]
+
+
+def make_module(variant, has_deterministic_flag):
+    class MinMaxStatsList(object):
+        def __init__(self, num):
+            self.num = int(num)
+            self._delta = 0.0
+            self._bound = None
+
+        def set_delta(self, value_delta_max):
+            self._delta = float(value_delta_max)
+
+    class ResultsWrapper(object):
+        def __init__(self, num):
+            self.num = int(num)
+            self._search_lens = []
+            self._roots = None
+
+        def get_search_len(self):
+            return self._search_lens
+
+    class Roots(object):
+        def __init__(self, root_num, legal_actions_list, action_space_size=None, max_simulations=None, engine=None):
+            self.root_num = int(root_num)
+            if len(legal_actions_list) != self.root_num:
+                raise ValueError("legal_actions_list must have root_num entries")
+            self._legal = [[int(a) for a in l] for l in legal_actions_list]
+            self._A = action_space_size
+            self._S = int(max_simulations) if max_simulations else DEFAULT_MAX_SIMULATIONS
+            self._engine = engine
+            self._h = None
+            self._tiebreak = None  # None -> module default
+            _seed_counter[0] += 1
+            self._seed = _seed_counter[0]
+
+        @property
+        def num(self):
+            return self.root_num
+
+        def _ensure(self, A):
+            if self._h is not None:
+                return
+            if self._A is None:
+                self._A = int(A)
+            if self._A != int(A):
+                raise ValueError("policy_logits width %d != action_space_size %d" % (A, self._A))
+            eng = self._engine if self._engine is not None else L.default_engine()
+            cnt = L.i32([len(l) for l in self._legal])
+            flat = L.i32([a for l in self._legal for a in l] or [0])
+            h = L.P()
+            L.check(L.lib().lz_roots_create(eng, variant, self.root_num, self._A, self._S, flat, cnt, ctypes.byref(h)))
+            self._h = h
+            mode = self._tiebreak if self._tiebreak is not None else (0 if has_deterministic_flag else 1)
+            L.check(L.lib().lz_roots_set_tiebreak(self._h, mode, self._seed))
+
+        def set_tiebreak(self, mode, seed=None):
+            """0: first arg-max (deterministic); 1: uniform over the reference's tie list."""
+            self._tiebreak = int(mode)
+            if seed is not None:
+                self._seed = int(seed)
+            if self._h is not None:
+                L.check(L.lib().lz_roots_set_tiebreak(self._h, self._tiebreak, self._seed))
+
+        def prepare(self, root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch):
+            logits = L.f32(policy_logits_pool)
+            if logits.ndim != 2 or logits.shape[0] != self.root_num:
+                raise ValueError("policy_logits_pool must be [root_num][action_space_size]")
+            self._ensure(logits.shape[1])
+            nz = L.f32([x for row in noises for x in row] or [0.0])
+            want = sum(len(l) if l else self._A for l in self._legal)
+            if nz.size < want:
+                raise ValueError("noises must hold one value per legal action")
+            L.check(L.lib().lz_roots_prepare(self._h, float(root_noise_weight), nz.ctypes.data,
+                                             L.f32(value_prefix_pool), logits, L.i32(to_play_batch)))
+
+        def prepare_no_noise(self, value_prefix_pool, policy_logits_pool, to_play_batch):
+            logits = L.f32(policy_logits_pool)
+            if logits.ndim != 2 or logits.shape[0] != self.root_num:
+                raise ValueError("policy_logits_pool must be [root_num][action_space_size]")
+            self._ensure(logits.shape[1])
+            L.check(L.lib().lz_roots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), logits,
+                                             L.i32(to_play_batch)))
+
+        def get_distributions(self):
+            if self._h is None:
+                return [[] for _ in range(self.root_num)]
+            out = np.zeros((self.root_num, self._A), np.int32)
+            cnt = np.zeros(self.root_num, np.int32)
+            L.check(L.lib().lz_roots_get_distributions(self._h, out, cnt))
+            return [out[i, :cnt[i]].tolist() for i in range(self.root_num)]
+
+        def get_values(self):
+            if self._h is None:
+                return [0.0] * self.root_num
+            out = np.zeros(self.root_num, np.float32)
+            L.check(L.lib().lz_roots_get_values(self._h, out))
+            return out.tolist()
+
+        def get_trajectories(self):
+            if self._h is None:
+                return [[] for _ in range(self.root_num)]
+            stride = self._S + 2
+            out = np.zeros((self.root_num, stride), np.int32)
+            L.check(L.lib().lz_roots_get_trajectories(self._h, out, stride))
+            res = []
+            for i in range(self.root_num):
+                row = out[i].tolist()
+                res.append(row[:row.index(-1)])
+            return res
+
+        def get_minmax(self):
+            out = np.zeros((self.root_num, 2), np.float32)
+            L.check(L.lib().lz_roots_get_minmax(self._h, out))
+            return out
+
+        def clear(self):
+            if self._h is not None:
+                L.lib().lz_roots_destroy(self._h)
+                self._h = None
+
+        def __del__(self):
+            try:
+                self.clear()
+            except Exception:
+                pass
+
+    def _bind(roots, mm):
+        if mm._bound is not roots:
+            L.check(L.lib().lz_roots_minmax_reset(roots._h, mm._delta))
+            mm._bound = roots
+
+    def _traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, virtual_to_play_batch):
+        if roots._h is None:
+            raise L.LzError("batch_traverse before Roots.prepare")
+        _bind(roots, min_max_stats_lst)
+        B = roots.root_num
+        vtp = L.i32(virtual_to_play_batch).copy()
+        if vtp.shape != (B,):
+            raise ValueError("virtual_to_play_batch must have root_num entries")
+        ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); la = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+        L.check(L.lib().lz_batch_traverse(roots._h, int(pb_c_base), float(pb_c_init), float(discount_factor), vtp,
+                                          ix, iy, la, sl))
+        results._search_lens = sl.tolist()
+        results._roots = roots
+        return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+    if has_deterministic_flag:
+        def batch_traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results,
+                           virtual_to_play_batch, deterministic=False):
+            if roots._h is not None and roots._tiebreak is None:
+                L.check(L.lib().lz_roots_set_tiebreak(roots._h, 0 if deterministic else 1, roots._seed))
+            return _traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results,
+                             virtual_to_play_batch)
+
+        def batch_backpropagate(current_latent_state_index, discount_factor, rewards, values, policies,
+                                min_max_stats_lst, results, to_play_batch):
+            roots = results._roots
+            L.check(L.lib().lz_batch_backpropagate(roots._h, int(current_latent_state_index), float(discount_factor),
+                                                   L.f32(rewards), L.f32(values), L.f32(policies), None,
+                                                   L.i32(to_play_batch)))
+    else:
+        def batch_traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results,
+                           virtual_to_play_batch):
+            return _traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results,
+                             virtual_to_play_batch)
+
+        def batch_backpropagate(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                                min_max_stats_lst, results, is_reset_list, to_play_batch):
+            roots = results._roots
+            rst = L.i32(is_reset_list)
+            L.check(L.lib().lz_batch_backpropagate(roots._h, int(current_latent_state_index), float(discount_factor),
+                                                   L.f32(value_prefixs), L.f32(values), L.f32(policies),
+                                                   rst.ctypes.data, L.i32(to_play_batch)))
+
+    return dict(MinMaxStatsList=MinMaxStatsList, ResultsWrapper=ResultsWrapper, Roots=Roots,
+                batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate)
