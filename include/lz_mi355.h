@@ -112,6 +112,61 @@ int lz_roots_get_trajectories(lz_roots *r, int32_t *h_out, int stride);
 /* (minimum, maximum) per root [root_num][2] -- observability for tests */
 int lz_roots_get_minmax(lz_roots *r, float *h_out);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Network -- replaces lzero/model/efficientzero_model.py (EfficientZeroModel.initial_inference :203-238,
+ * recurrent_inference :240-273) evaluated in eval() mode, with InverseScalarTransform
+ * (lzero/policy/scaling_transform.py:82-92) fused into the value / value-prefix heads.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lz_model_cfg {
+    int model_type;         /* 0: EfficientZeroModel (conv, downsample=True)   1: MuZeroModel (conv, downsample=True) */
+    int obs_c, obs_h, obs_w;/* observation_shape, e.g. 4, 96, 96 */
+    int action_space_size;
+    int num_channels;       /* 64 */
+    int lstm_hidden_size;   /* 512 (EfficientZero) */
+    int head_channels;      /* reward/value/policy head channels (16) */
+    int head_hidden;        /* hidden width of the head MLPs (32) */
+    int support_size;       /* 601 */
+    float support_min;      /* -300 */
+    float bn_eps;           /* 1e-5 */
+} lz_model_cfg;
+
+/* One model per engine.  Weights are ingested by their reference state_dict names
+ * (e.g. "dynamics_network.lstm.weight_ih_l0", "prediction_network.fc_value.3.bias"), fp32, C-contiguous,
+ * host memory; lz_model_finalize folds the eval-mode BatchNorms, re-lays the tensors out for the
+ * kernels and uploads them.  Replaces policy._collect_model.load_state_dict (muzero.py:1036-1058 format). */
+int lz_model_create(lz_engine *e, const lz_model_cfg *cfg);
+int lz_model_set_tensor(lz_engine *e, const char *name, const float *h_data, const int64_t *shape, int ndim);
+int lz_model_finalize(lz_engine *e);
+
+/* initial_inference for the roots' batch: d_obs is NCHW fp32 [root_num][obs_c][obs_h][obs_w] in HBM.
+ * The latent state goes to slot 0 of the roots' latent pool, LSTM state slot 0 is zeroed
+ * (efficientzero_model.py:229-238).  Predicted values (after h^-1) and policy logits stay in HBM and
+ * can be fetched with lz_roots_get_root_outputs. */
+int lz_initial_inference(lz_roots *r, const float *d_obs);
+int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits);
+/* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
+ * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
+int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
+                                    const int32_t *h_to_play);
+/* EfficientZeroMCTSCtree.search (lzero/mcts/tree_search/mcts_ctree.py:745-876): num_simulations x
+ * [select -> gather latent/LSTM state by (ix, iy) -> recurrent_inference -> h^-1 -> LSTM reset every
+ * lstm_horizon_len -> expand + backup], entirely on the device, no host synchronisation inside.
+ * Asynchronous on the engine stream; results via lz_roots_get_distributions / get_values. */
+int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, float discount_factor,
+              int lstm_horizon_len, float value_delta_max);
+
+/* observability for parity tests: per-simulation records and pools (host copies)                  */
+int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out /* [S][B][4] ix, action, search_len, to_play */);
+int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_prefix, float *h_value, float *h_policy_logits);
+int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw);
+int lz_roots_read_hidden(lz_roots *r, int slot, float *h_h, float *h_c);
+/* optional debug logits of the last head launch: which = 0 value [B][support], 1 value_prefix/reward [B][support] */
+int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out);
+/* debugging aids: stop lz_initial_inference after stage k ("stop_stage"), read a workspace buffer */
+int lz_debug_set(lz_engine *e, const char *key, int value);
+int lz_debug_read_ws(lz_engine *e, int which, float *h_out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

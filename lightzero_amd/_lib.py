@@ -13,6 +13,13 @@ class LzError(RuntimeError):
     pass
 
 
+class ModelCfg(ctypes.Structure):
+    _fields_ = [("model_type", ctypes.c_int), ("obs_c", ctypes.c_int), ("obs_h", ctypes.c_int), ("obs_w", ctypes.c_int),
+                ("action_space_size", ctypes.c_int), ("num_channels", ctypes.c_int), ("lstm_hidden_size", ctypes.c_int),
+                ("head_channels", ctypes.c_int), ("head_hidden", ctypes.c_int), ("support_size", ctypes.c_int),
+                ("support_min", ctypes.c_float), ("bn_eps", ctypes.c_float)]
+
+
 _lib = None
 c_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 c_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -46,6 +53,18 @@ def lib():
         "lz_roots_get_values": [P, c_f32p],
         "lz_roots_get_trajectories": [P, c_i32p, ctypes.c_int],
         "lz_roots_get_minmax": [P, c_f32p],
+        "lz_model_create": [P, ctypes.POINTER(ModelCfg)],
+        "lz_model_set_tensor": [P, ctypes.c_char_p, c_f32p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
+        "lz_model_finalize": [P],
+        "lz_initial_inference": [P, P],
+        "lz_roots_get_root_outputs": [P, c_f32p, c_f32p],
+        "lz_roots_prepare_from_inference": [P, ctypes.c_float, P, c_i32p],
+        "lz_search": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float],
+        "lz_roots_read_trace": [P, ctypes.c_int, c_i32p],
+        "lz_roots_read_sim_outputs": [P, ctypes.c_int, c_f32p, c_f32p, c_f32p],
+        "lz_roots_read_latent": [P, ctypes.c_int, c_f32p],
+        "lz_roots_read_hidden": [P, ctypes.c_int, c_f32p, c_f32p],
+        "lz_roots_read_debug_logits": [P, ctypes.c_int, c_f32p],
     }
     for name, argtypes in sig.items():
         getattr(L, name).argtypes = argtypes

@@ -189,6 +189,7 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     (void)hipSetDevice(r->eng->device);
     (void)hipStreamSynchronize(r->eng->stream);
     if (r->slab) (void)hipFree(r->slab);
+    if (r->pool_slab) (void)hipFree(r->pool_slab);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);
     delete r;

@@ -75,6 +75,24 @@ struct lz_roots {
     void *h_stage = nullptr;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    // ---- fused search state (allocated on first lz_initial_inference), all in HBM
+    void *pool_slab = nullptr;
+    float *latent_pool = nullptr;   // [NN][B][HW][C]   NHWC latent of every expanded node
+    float *h_pool = nullptr;        // [NN][B][H]       LSTM state pools (EfficientZero)
+    float *c_pool = nullptr;
+    float *sim_vp = nullptr;        // [NN][B]          value prefix / reward of node n (after h^-1)
+    float *sim_value = nullptr;     // [NN][B]
+    float *sim_logits = nullptr;    // [NN][B][A]
+    float *t_x1 = nullptr, *t_x2 = nullptr, *t_x3 = nullptr;  // [B][HW][C] scratch activations
+    float *t_rx = nullptr;          // [B][HW*HC] reward conv output
+    float *t_hbn = nullptr;         // [B][H]
+    float *dbg_logits[2] = {nullptr, nullptr};  // [B][support]
+    int32_t *trace = nullptr;       // [NN][5][B]  copies of res_* per simulation
+    int32_t *d_to_play = nullptr;   // [B]
+    float *d_zero_vp = nullptr;     // [B] zeros
+    float *d_noise = nullptr;       // [B][A]
+    int32_t *d_noise_off = nullptr; // [B]
+    bool inferred = false;
 };
 
 // lz_tree.hip launchers (all asynchronous on `stream`)

@@ -1,0 +1,660 @@
+// lz_search.hip -- weight ingestion (reference state_dict names -> kernel layouts), the fused
+// initial_inference / recurrent_inference launch chains and the on-device search loop.
+//
+// Reference call chain replaced (LightZero v0.2.0):
+//   EfficientZeroPolicy._forward_collect         lzero/policy/efficientzero.py:572-615
+//   EfficientZeroMCTSCtree.search                lzero/mcts/tree_search/mcts_ctree.py:745-876
+//   EfficientZeroModel.initial/recurrent_inference  lzero/model/efficientzero_model.py:203-273
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lz_internal.h"
+#include "lz_nn_kernels.h"
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvW {
+    float *w = nullptr, *scale = nullptr, *shift = nullptr;
+    int cin = 0, cout = 0;
+};
+struct MlpW {
+    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    int K1 = 0, NOUT = 0;
+};
+struct C1W {
+    float *w = nullptr, *b = nullptr, *s = nullptr, *t = nullptr;
+};
+
+struct lz_model {
+    lz_model_cfg cfg{};
+    std::map<std::string, HostTensor> raw;
+    bool finalized = false;
+    std::vector<void *> allocs;
+    int HWl = 0;  // latent pixels (6x6 = 36)
+    // representation
+    float *first_w = nullptr, *first_s = nullptr, *first_t = nullptr;
+    ConvW r1a, r1b, dn1, dn2, dn3, r2a, r2b, r3a, r3b, rpa, rpb;
+    // dynamics
+    ConvW dyn, dra, drb;
+    float *act_table = nullptr;
+    C1W rew_c;
+    float *lstm_w = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
+    MlpW fc_reward;
+    // prediction
+    ConvW pa, pb;
+    C1W val_c, pol_c;
+    MlpW fc_value, fc_policy;
+    // workspaces for initial inference
+    int ws_B = 0;
+    float *ws[3] = {nullptr, nullptr, nullptr};
+    int debug_stop = 0;  // lz_debug_set("stop_stage"): leave lz_initial_inference after stage k
+};
+
+void lz_model_destroy(lz_model *m)
+{
+    if (!m) return;
+    for (void *p : m->allocs) (void)hipFree(p);
+    for (int i = 0; i < 3; ++i) if (m->ws[i]) (void)hipFree(m->ws[i]);
+    delete m;
+}
+
+extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
+{
+    LZ_REQUIRE(e != nullptr && cfg != nullptr, "NULL argument");
+    LZ_REQUIRE(cfg->model_type == 0, "only model_type 0 (EfficientZeroModel conv, downsample) is implemented");
+    LZ_REQUIRE(cfg->num_channels == 64, "num_channels must be 64");
+    LZ_REQUIRE(cfg->obs_h == 96 && cfg->obs_w == 96, "observation must be 96x96 (downsample path)");
+    LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
+    LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
+    LZ_REQUIRE(cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0, "lstm_hidden_size must be a multiple of 64");
+    LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
+    LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
+    if (e->model) lz_model_destroy(e->model);
+    e->model = new (std::nothrow) lz_model();
+    if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+    e->model->cfg = *cfg;
+    if (e->model->cfg.bn_eps <= 0) e->model->cfg.bn_eps = 1e-5f;
+    e->model->HWl = 36;
+    return LZ_OK;
+}
+
+extern "C" int lz_model_set_tensor(lz_engine *e, const char *name, const float *h_data, const int64_t *shape, int ndim)
+{
+    LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
+    LZ_REQUIRE(name && h_data && (shape || ndim == 0) && ndim >= 0 && ndim <= 4, "bad tensor argument");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(h_data, h_data + n);
+    e->model->raw[name] = std::move(t);
+    e->model->finalized = false;
+    return LZ_OK;
+}
+
+namespace {
+
+struct Builder {
+    lz_model *m;
+    std::string err;
+    const HostTensor *get(const std::string &name, std::initializer_list<int64_t> shape)
+    {
+        auto it = m->raw.find(name);
+        if (it == m->raw.end()) { if (err.empty()) err = "missing tensor '" + name + "'"; return nullptr; }
+        const HostTensor &t = it->second;
+        if (t.shape.size() != shape.size() || !std::equal(shape.begin(), shape.end(), t.shape.begin())) {
+            if (err.empty()) err = "tensor '" + name + "' has an unexpected shape";
+            return nullptr;
+        }
+        return &t;
+    }
+    float *upload(const std::vector<float> &v)
+    {
+        float *d = nullptr;
+        if (hipMalloc((void **)&d, v.size() * 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
+        m->allocs.push_back(d);
+        if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
+        return d;
+    }
+    // eval-mode BatchNorm -> y = x*scale + shift
+    void bn(const std::string &prefix, int n, std::vector<float> &scale, std::vector<float> &shift)
+    {
+        const HostTensor *w = get(prefix + ".weight", {n}), *b = get(prefix + ".bias", {n}),
+                         *mu = get(prefix + ".running_mean", {n}), *var = get(prefix + ".running_var", {n});
+        scale.assign(n, 1.0f);
+        shift.assign(n, 0.0f);
+        if (!w || !b || !mu || !var) return;
+        for (int i = 0; i < n; ++i) {
+            const float inv = 1.0f / sqrtf(var->data[i] + m->cfg.bn_eps);
+            scale[i] = w->data[i] * inv;
+            shift[i] = b->data[i] - mu->data[i] * scale[i];
+        }
+    }
+    // conv weight [cout][cin_total][3][3] -> packed [cout/16][9][16][cin] (first `cin` input channels)
+    ConvW conv(const std::string &wname, const std::string &bnprefix, int cout, int cin_total, int cin)
+    {
+        ConvW c;
+        c.cin = cin;
+        c.cout = cout;
+        const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
+        std::vector<float> sc(cout, 1.0f), sh(cout, 0.0f);
+        if (!bnprefix.empty()) bn(bnprefix, cout, sc, sh);
+        if (!w) return c;
+        std::vector<float> p((size_t)cout * 9 * cin);
+        for (int co = 0; co < cout; ++co)
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < cin; ++ci)
+                    p[(((size_t)(co / 16) * 9 + t) * 16 + co % 16) * cin + ci] = w->data[(((size_t)co * cin_total + ci) * 9) + t];
+        c.w = upload(p);
+        c.scale = upload(sc);
+        c.shift = upload(sh);
+        return c;
+    }
+    ConvW resconv(const std::string &prefix, int idx, int cout, int cin)  // ding ResBlock convN = Sequential(conv, bn[, act])
+    {
+        const std::string p = prefix + ".conv" + std::to_string(idx);
+        return conv(p + ".0.weight", p + ".1", cout, cin, cin);
+    }
+    C1W conv1x1(const std::string &cprefix, const std::string &bnprefix, int cout, int cin)
+    {
+        C1W c;
+        const HostTensor *w = get(cprefix + ".weight", {cout, cin, 1, 1}), *b = get(cprefix + ".bias", {cout});
+        std::vector<float> sc, sh;
+        bn(bnprefix, cout, sc, sh);
+        if (!w || !b) return c;
+        c.w = upload(w->data);
+        c.b = upload(b->data);
+        c.s = upload(sc);
+        c.t = upload(sh);
+        return c;
+    }
+    // Linear - BN1d - ReLU - Linear; conv_flat: K1 = HC*HW in the reference's (channel, pixel) order ->
+    // permute the columns to this engine's (pixel, channel) order
+    MlpW mlp(const std::string &prefix, int K1, int HID, int NOUT, bool conv_flat, int HC, int HW)
+    {
+        MlpW o;
+        o.K1 = K1;
+        o.NOUT = NOUT;
+        const HostTensor *w1 = get(prefix + ".0.weight", {HID, K1}), *b1 = get(prefix + ".0.bias", {HID}),
+                         *w2 = get(prefix + ".3.weight", {NOUT, HID}), *b2 = get(prefix + ".3.bias", {NOUT});
+        std::vector<float> sc, sh;
+        bn(prefix + ".1", HID, sc, sh);
+        if (!w1 || !b1 || !w2 || !b2) return o;
+        std::vector<float> w1p(w1->data);
+        if (conv_flat) {
+            for (int u = 0; u < HID; ++u)
+                for (int p = 0; p < HW; ++p)
+                    for (int c = 0; c < HC; ++c) w1p[(size_t)u * K1 + p * HC + c] = w1->data[(size_t)u * K1 + c * HW + p];
+        }
+        o.w1 = upload(w1p);
+        o.b1 = upload(b1->data);
+        o.s1 = upload(sc);
+        o.t1 = upload(sh);
+        o.w2 = upload(w2->data);
+        o.b2 = upload(b2->data);
+        return o;
+    }
+};
+
+}  // namespace
+
+extern "C" int lz_model_finalize(lz_engine *e)
+{
+    LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    lz_model *m = e->model;
+    for (void *p : m->allocs) (void)hipFree(p);
+    m->allocs.clear();
+    const lz_model_cfg &c = m->cfg;
+    const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
+              H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size;
+    Builder b{m, ""};
+    // ---- representation (common.py:266-365, :706-787)
+    {
+        const std::string d = "representation_network.downsample_net.";
+        const HostTensor *w = b.get(d + "conv1.weight", {C2, c.obs_c, 3, 3});
+        std::vector<float> sc, sh;
+        b.bn(d + "norm1", C2, sc, sh);
+        if (w) {
+            std::vector<float> p((size_t)9 * c.obs_c * C2);  // [tap][ci][co]
+            for (int co = 0; co < C2; ++co)
+                for (int ci = 0; ci < c.obs_c; ++ci)
+                    for (int t = 0; t < 9; ++t) p[((size_t)t * c.obs_c + ci) * C2 + co] = w->data[((size_t)co * c.obs_c + ci) * 9 + t];
+            m->first_w = b.upload(p);
+            m->first_s = b.upload(sc);
+            m->first_t = b.upload(sh);
+        }
+        m->r1a = b.resconv(d + "resblocks1.0", 1, C2, C2);
+        m->r1b = b.resconv(d + "resblocks1.0", 2, C2, C2);
+        m->dn1 = b.resconv(d + "downsample_block", 1, C, C2);
+        m->dn2 = b.resconv(d + "downsample_block", 2, C, C);
+        m->dn3 = b.conv(d + "downsample_block.conv3.0.weight", "", C, C2, C2);
+        m->r2a = b.resconv(d + "resblocks2.0", 1, C, C);
+        m->r2b = b.resconv(d + "resblocks2.0", 2, C, C);
+        m->r3a = b.resconv(d + "resblocks3.0", 1, C, C);
+        m->r3b = b.resconv(d + "resblocks3.0", 2, C, C);
+        m->rpa = b.resconv("representation_network.resblocks.0", 1, C, C);
+        m->rpb = b.resconv("representation_network.resblocks.0", 2, C, C);
+    }
+    // ---- dynamics (efficientzero_model.py:427-569)
+    {
+        const std::string d = "dynamics_network.";
+        m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + A, C);
+        // one-hot action planes: plane a is all ones inside the 6x6 latent, so its contribution to output
+        // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image
+        const HostTensor *w = b.get(d + "conv.weight", {C, C + A, 3, 3});
+        if (w) {
+            const int S = 6;
+            std::vector<float> tab((size_t)A * HW * C);
+            for (int a = 0; a < A; ++a)
+                for (int y = 0; y < S; ++y)
+                    for (int x = 0; x < S; ++x)
+                        for (int co = 0; co < C; ++co) {
+                            float acc = 0.0f;
+                            for (int t = 0; t < 9; ++t) {
+                                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                                if (iy >= 0 && iy < S && ix >= 0 && ix < S) acc += w->data[((size_t)co * (C + A) + C + a) * 9 + t];
+                            }
+                            tab[((size_t)a * HW + y * S + x) * C + co] = acc;
+                        }
+            m->act_table = b.upload(tab);
+        }
+        m->dra = b.resconv(d + "resblocks.0", 1, C, C);
+        m->drb = b.resconv(d + "resblocks.0", 2, C, C);
+        m->rew_c = b.conv1x1(d + "conv1x1_reward", d + "norm_reward", HC, C);
+        // LSTM: rows re-ordered to 4*unit + gate; the x columns permuted from the reference's
+        // (channel, pixel) flatten order to (pixel, channel)
+        const int KX = HC * HW, K = KX + H;
+        const HostTensor *wih = b.get(d + "lstm.weight_ih_l0", {4 * H, KX}), *whh = b.get(d + "lstm.weight_hh_l0", {4 * H, H}),
+                         *bih = b.get(d + "lstm.bias_ih_l0", {4 * H}), *bhh = b.get(d + "lstm.bias_hh_l0", {4 * H});
+        if (wih && whh && bih && bhh) {
+            std::vector<float> wc((size_t)4 * H * K), bc((size_t)4 * H);
+            for (int g = 0; g < 4; ++g)
+                for (int u = 0; u < H; ++u) {
+                    const int src = g * H + u, dst = 4 * u + g;
+                    for (int p = 0; p < HW; ++p)
+                        for (int ch = 0; ch < HC; ++ch) wc[(size_t)dst * K + p * HC + ch] = wih->data[(size_t)src * KX + ch * HW + p];
+                    for (int k = 0; k < H; ++k) wc[(size_t)dst * K + KX + k] = whh->data[(size_t)src * H + k];
+                    bc[dst] = bih->data[src] + bhh->data[src];
+                }
+            m->lstm_w = b.upload(wc);
+            m->lstm_b = b.upload(bc);
+        }
+        std::vector<float> sc, sh;
+        b.bn(d + "norm_value_prefix", H, sc, sh);
+        m->vp_s = b.upload(sc);
+        m->vp_t = b.upload(sh);
+        m->fc_reward = b.mlp(d + "fc_reward_head", H, HID, SUP, false, HC, HW);
+    }
+    // ---- prediction (common.py:1081-1216)
+    {
+        const std::string d = "prediction_network.";
+        m->pa = b.resconv(d + "resblocks.0", 1, C, C);
+        m->pb = b.resconv(d + "resblocks.0", 2, C, C);
+        m->val_c = b.conv1x1(d + "conv1x1_value", d + "norm_value", HC, C);
+        m->pol_c = b.conv1x1(d + "conv1x1_policy", d + "norm_policy", HC, C);
+        m->fc_value = b.mlp(d + "fc_value", HC * HW, HID, SUP, true, HC, HW);
+        m->fc_policy = b.mlp(d + "fc_policy", HC * HW, HID, A, true, HC, HW);
+    }
+    if (!b.err.empty()) {
+        lz_set_error("lz_model_finalize: %s", b.err.c_str());
+        return LZ_ERR_STATE;
+    }
+    m->finalized = true;
+    return LZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int ensure_pools(lz_roots *r)
+{
+    if (r->pool_slab) return LZ_OK;
+    lz_model *m = r->eng->model;
+    const lz_model_cfg &c = m->cfg;
+    const size_t B = r->t.B, NN = r->t.NN, A = r->t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size,
+                 HC = c.head_channels, SUP = c.support_size;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_lat = take(NN * B * HW * C * 4), o_h = take(NN * B * H * 4), o_c = take(NN * B * H * 4),
+                 o_vp = take(NN * B * 4), o_val = take(NN * B * 4), o_lg = take(NN * B * A * 4),
+                 o_x1 = take(B * HW * C * 4), o_x2 = take(B * HW * C * 4), o_x3 = take(B * HW * C * 4),
+                 o_rx = take(B * HW * HC * 4), o_hbn = take(B * H * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
+                 o_tr = take(NN * 5 * B * 4), o_tp = take(B * 4), o_z = take(B * 4), o_nz = take(B * A * 4), o_no = take(B * 4);
+    hipError_t err = hipMalloc(&r->pool_slab, off);
+    if (err != hipSuccess) {
+        lz_set_error("hipMalloc(%zu bytes) for the latent/LSTM pools failed: %s", off, hipGetErrorString(err));
+        return err == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP;
+    }
+    char *base = (char *)r->pool_slab;
+    r->latent_pool = (float *)(base + o_lat); r->h_pool = (float *)(base + o_h); r->c_pool = (float *)(base + o_c);
+    r->sim_vp = (float *)(base + o_vp); r->sim_value = (float *)(base + o_val); r->sim_logits = (float *)(base + o_lg);
+    r->t_x1 = (float *)(base + o_x1); r->t_x2 = (float *)(base + o_x2); r->t_x3 = (float *)(base + o_x3);
+    r->t_rx = (float *)(base + o_rx); r->t_hbn = (float *)(base + o_hbn);
+    r->dbg_logits[0] = (float *)(base + o_d0); r->dbg_logits[1] = (float *)(base + o_d1);
+    r->trace = (int32_t *)(base + o_tr); r->d_to_play = (int32_t *)(base + o_tp); r->d_zero_vp = (float *)(base + o_z);
+    r->d_noise = (float *)(base + o_nz); r->d_noise_off = (int32_t *)(base + o_no);
+    LZ_HIP_CHECK(hipMemsetAsync(r->d_zero_vp, 0, B * 4, r->eng->stream));
+    return LZ_OK;
+}
+
+static int ensure_ws(lz_model *m, int B)
+{
+    if (m->ws_B >= B) return LZ_OK;
+    for (int i = 0; i < 3; ++i) { if (m->ws[i]) (void)hipFree(m->ws[i]); m->ws[i] = nullptr; }
+    const lz_model_cfg &c = m->cfg;
+    const size_t n = (size_t)B * (c.obs_h / 2) * (c.obs_w / 2) * (c.num_channels / 2);  // largest activation
+    for (int i = 0; i < 3; ++i) LZ_HIP_CHECK(hipMalloc((void **)&m->ws[i], n * 4));
+    m->ws_B = B;
+    return LZ_OK;
+}
+
+static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
+                 int relu, hipStream_t s)
+{
+    lz_conv_args a{};
+    a.in = in; a.w = w.w; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
+    a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
+    lz_launch_conv3x3(a, w.cin, stride, s);
+}
+
+static void prediction(lz_roots *r, const float *latent, float *out_value, float *out_logits, float *dbg_value_logits,
+                       const float *hbn, float *out_vp, float *dbg_vp_logits, hipStream_t s)
+{
+    lz_model *m = r->eng->model;
+    const lz_model_cfg &c = m->cfg;
+    const int B = r->t.B, HW = m->HWl, C = c.num_channels;
+    conv(m->pa, latent, r->t_x2, B, 6, 6, 1, nullptr, 1, s);
+    conv(m->pb, r->t_x2, r->t_x3, B, 6, 6, 1, latent, 1, s);
+    lz_head_desc h[3];
+    memset(h, 0, sizeof(h));
+    int n = 0;
+    h[n].in = r->t_x3; h[n].has_conv = 1; h[n].cw = m->val_c.w; h[n].cb = m->val_c.b; h[n].cscale = m->val_c.s; h[n].cshift = m->val_c.t;
+    h[n].w1 = m->fc_value.w1; h[n].b1 = m->fc_value.b1; h[n].s1 = m->fc_value.s1; h[n].t1 = m->fc_value.t1; h[n].w2 = m->fc_value.w2; h[n].b2 = m->fc_value.b2;
+    h[n].K1 = m->fc_value.K1; h[n].NOUT = m->fc_value.NOUT; h[n].categorical = 1; h[n].support_min = c.support_min;
+    h[n].out_logits = dbg_value_logits; h[n].out_scalar = out_value; n++;
+    h[n].in = r->t_x3; h[n].has_conv = 1; h[n].cw = m->pol_c.w; h[n].cb = m->pol_c.b; h[n].cscale = m->pol_c.s; h[n].cshift = m->pol_c.t;
+    h[n].w1 = m->fc_policy.w1; h[n].b1 = m->fc_policy.b1; h[n].s1 = m->fc_policy.s1; h[n].t1 = m->fc_policy.t1; h[n].w2 = m->fc_policy.w2; h[n].b2 = m->fc_policy.b2;
+    h[n].K1 = m->fc_policy.K1; h[n].NOUT = m->fc_policy.NOUT; h[n].categorical = 0; h[n].out_logits = out_logits; n++;
+    if (hbn) {
+        h[n].in = hbn; h[n].has_conv = 0;
+        h[n].w1 = m->fc_reward.w1; h[n].b1 = m->fc_reward.b1; h[n].s1 = m->fc_reward.s1; h[n].t1 = m->fc_reward.t1; h[n].w2 = m->fc_reward.w2; h[n].b2 = m->fc_reward.b2;
+        h[n].K1 = m->fc_reward.K1; h[n].NOUT = m->fc_reward.NOUT; h[n].categorical = 1; h[n].support_min = c.support_min;
+        h[n].out_logits = dbg_vp_logits; h[n].out_scalar = out_vp; n++;
+    }
+    lz_launch_heads(h, n, B, HW, C, c.head_channels, c.head_hidden, s);
+}
+
+extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
+{
+    LZ_REQUIRE(r != nullptr && d_obs != nullptr, "NULL argument");
+    lz_model *m = r->eng->model;
+    if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
+    LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
+    LZ_REQUIRE(r->t.variant == LZ_TREE_EFFICIENTZERO, "model_type 0 needs an EfficientZero tree");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = ensure_pools(r);
+    if (rc != LZ_OK) return rc;
+    rc = ensure_ws(m, r->t.B);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    const lz_model_cfg &c = m->cfg;
+    const int B = r->t.B, C = c.num_channels, H = c.lstm_hidden_size;
+    float *w0 = m->ws[0], *w1 = m->ws[1], *w2 = m->ws[2];
+    // DownSample (common.py:266-365)
+    int stage = 0;
+#define LZ_STAGE() do { if (m->debug_stop == ++stage) { LZ_HIP_CHECK(hipStreamSynchronize(s)); return LZ_OK; } } while (0)
+    lz_launch_conv_first(d_obs, m->first_w, m->first_s, m->first_t, w0, B, c.obs_c, c.obs_h, c.obs_w, C / 2, s);  // 48x48x32
+    LZ_STAGE();
+    conv(m->r1a, w0, w1, B, 48, 48, 1, nullptr, 1, s);
+    LZ_STAGE();
+    conv(m->r1b, w1, w2, B, 48, 48, 1, w0, 1, s);            // w2: 48x48x32
+    LZ_STAGE();
+    conv(m->dn1, w2, w0, B, 48, 24, 2, nullptr, 1, s);       // w0: 24x24x64
+    LZ_STAGE();
+    conv(m->dn3, w2, w1, B, 48, 24, 2, nullptr, 0, s);       // w1: identity path (no norm, no act)
+    LZ_STAGE();
+    conv(m->dn2, w0, w2, B, 24, 24, 1, w1, 1, s);            // w2: 24x24x64
+    LZ_STAGE();
+    conv(m->r2a, w2, w0, B, 24, 24, 1, nullptr, 1, s);
+    LZ_STAGE();
+    conv(m->r2b, w0, w1, B, 24, 24, 1, w2, 1, s);            // w1
+    LZ_STAGE();
+    lz_launch_avgpool(w1, w0, B, 24, 24, C, s);               // w0: 12x12x64
+    LZ_STAGE();
+    conv(m->r3a, w0, w1, B, 12, 12, 1, nullptr, 1, s);
+    LZ_STAGE();
+    conv(m->r3b, w1, w2, B, 12, 12, 1, w0, 1, s);            // w2
+    LZ_STAGE();
+    lz_launch_avgpool(w2, w0, B, 12, 12, C, s);               // w0: 6x6x64
+    LZ_STAGE();
+    // RepresentationNetwork.resblocks (common.py:775-776) -> latent pool slot 0
+    conv(m->rpa, w0, w1, B, 6, 6, 1, nullptr, 1, s);
+    LZ_STAGE();
+    conv(m->rpb, w1, r->latent_pool, B, 6, 6, 1, w0, 1, s);
+#undef LZ_STAGE
+    LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * H * 4, s));
+    LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
+    prediction(r, r->latent_pool, r->sim_value, r->sim_logits, r->dbg_logits[0], nullptr, nullptr, nullptr, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    r->inferred = true;
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits)
+{
+    LZ_REQUIRE(r != nullptr && r->inferred, "lz_initial_inference has not run on these roots");
+    const size_t B = r->t.B, A = r->t.A;
+    hipStream_t s = r->eng->stream;
+    if (h_pred_values) LZ_HIP_CHECK(hipMemcpyAsync(h_pred_values, r->sim_value, B * 4, hipMemcpyDeviceToHost, s));
+    if (h_policy_logits) LZ_HIP_CHECK(hipMemcpyAsync(h_policy_logits, r->sim_logits, B * A * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
+                                               const int32_t *h_to_play)
+{
+    LZ_REQUIRE(r != nullptr && r->inferred && h_to_play != nullptr, "lz_initial_inference must run first; to_play required");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    int players = 1;
+    {
+        int largest = h_to_play[0];
+        for (size_t i = 1; i < B; ++i) if (h_to_play[i] > largest) largest = h_to_play[i];
+        players = largest == -1 ? 1 : 2;
+    }
+    LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, h_to_play, B * 4, hipMemcpyHostToDevice, s));
+    const float *d_noise = nullptr;
+    if (h_noises_flat) {
+        std::vector<int32_t> nl(B), off(B);
+        LZ_HIP_CHECK(hipMemcpyAsync(nl.data(), t.n_legal, B * 4, hipMemcpyDeviceToHost, s));
+        LZ_HIP_CHECK(hipStreamSynchronize(s));
+        size_t acc = 0;
+        for (size_t i = 0; i < B; ++i) { off[i] = (int32_t)acc; acc += nl[i]; }
+        if (acc > B * A) { lz_set_error("noise count exceeds root_num * action_space_size"); return LZ_ERR_INVALID; }
+        LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise, h_noises_flat, acc * 4, hipMemcpyHostToDevice, s));
+        LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise_off, off.data(), B * 4, hipMemcpyHostToDevice, s));
+        LZ_HIP_CHECK(hipStreamSynchronize(s));
+        d_noise = r->d_noise;
+    }
+    lz_tree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_logits, r->d_to_play, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    r->players = players;
+    r->prepared = true;
+    r->traverse_count = 0;
+    return LZ_OK;
+}
+
+// one simulation: traverse -> recurrent_inference -> backpropagate (mcts_ctree.py:782-876)
+static void simulate(lz_roots *r, int sim, const lz_traverse_args &ta, float delta, int horizon, hipStream_t s)
+{
+    lz_model *m = r->eng->model;
+    const lz_model_cfg &c = m->cfg;
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size;
+    const int slot = sim + 1;
+    const size_t lat_slot = B * HW * C;
+    lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
+    (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
+    // ---- dynamics (efficientzero_model.py:527-569): conv over [latent | one-hot action] + BN + latent, ReLU
+    lz_conv_args a{};
+    a.in = r->latent_pool; a.gather_ix = t.res_ix; a.slot_stride = (int64_t)lat_slot;
+    a.w = m->dyn.w; a.scale = m->dyn.scale; a.shift = m->dyn.shift; a.act_table = m->act_table; a.action = t.res_last_action;
+    a.residual = r->latent_pool; a.residual_gather = 1; a.out = r->t_x1;
+    a.B = (int)B; a.Hin = a.Win = a.Hout = a.Wout = 6; a.Cout = (int)C; a.relu = 1;
+    lz_launch_conv3x3(a, 64, 1, s);
+    float *next_latent = r->latent_pool + (size_t)slot * lat_slot;
+    conv(m->dra, r->t_x1, r->t_x2, (int)B, 6, 6, 1, nullptr, 1, s);
+    conv(m->drb, r->t_x2, next_latent, (int)B, 6, 6, 1, r->t_x1, 1, s);
+    // ---- value prefix: conv1x1 + BN + ReLU -> LSTM -> BN1d + ReLU (-> MLP in the heads launch)
+    lz_launch_conv1x1(next_latent, m->rew_c.w, m->rew_c.b, m->rew_c.s, m->rew_c.t, r->t_rx, (int)B, (int)HW, (int)C, c.head_channels, s);
+    lz_lstm_args l{};
+    l.x = r->t_rx; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = m->lstm_w; l.bias = m->lstm_b;
+    l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
+    l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
+    l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
+    lz_launch_lstm(l, s);
+    // ---- prediction + the three heads, h^-1 fused
+    prediction(r, next_latent, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0],
+               r->t_hbn, r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
+    // ---- expand + backup; is_reset = search_len % horizon == 0 derived on the device
+    lz_tree_launch_backprop(t, slot, ta.discount, r->sim_vp + (size_t)slot * B, r->sim_value + (size_t)slot * B,
+                            r->sim_logits + (size_t)slot * B * A, nullptr, horizon, nullptr, s);
+}
+
+extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, float discount_factor,
+                         int lstm_horizon_len, float value_delta_max)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->inferred && r->prepared, "lz_search needs lz_initial_inference and a prepare call first");
+    LZ_REQUIRE(lstm_horizon_len > 0, "lstm_horizon_len must be positive (mcts_ctree.py:858)");
+    if (num_simulations < 1 || num_simulations >= r->t.NN) {
+        lz_set_error("num_simulations %d exceeds the node pool (max_simulations %d)", num_simulations, r->t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    r->delta = value_delta_max;
+    lz_tree_launch_minmax_reset(r->t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
+    lz_traverse_args ta;
+    ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
+    ta.tiebreak = r->tiebreak; ta.seed = r->seed;
+    for (int sim = 0; sim < num_simulations; ++sim) {
+        ta.counter = r->traverse_count++;
+        simulate(r, sim, ta, value_delta_max, lstm_horizon_len, s);
+    }
+    LZ_HIP_CHECK(hipGetLastError());
+    return LZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out)
+{
+    LZ_REQUIRE(r != nullptr && h_out != nullptr && r->trace != nullptr, "no trace");
+    LZ_REQUIRE(num_simulations >= 1 && num_simulations < r->t.NN, "num_simulations out of range");
+    const size_t B = r->t.B;
+    std::vector<int32_t> tmp((size_t)num_simulations * 5 * B);
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(tmp.data(), r->trace, tmp.size() * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    for (int sim = 0; sim < num_simulations; ++sim)
+        for (size_t b = 0; b < B; ++b) {
+            const int32_t *p = tmp.data() + (size_t)sim * 5 * B;  // [ix][iy][action][len][vtp]
+            int32_t *o = h_out + ((size_t)sim * B + b) * 4;
+            o[0] = p[b]; o[1] = p[2 * B + b]; o[2] = p[3 * B + b]; o[3] = p[4 * B + b];
+        }
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_prefix, float *h_value, float *h_policy_logits)
+{
+    LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr, "no pools");
+    LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
+    const size_t B = r->t.B, A = r->t.A;
+    hipStream_t s = r->eng->stream;
+    if (h_value_prefix) LZ_HIP_CHECK(hipMemcpyAsync(h_value_prefix, r->sim_vp + slot * B, B * 4, hipMemcpyDeviceToHost, s));
+    if (h_value) LZ_HIP_CHECK(hipMemcpyAsync(h_value, r->sim_value + slot * B, B * 4, hipMemcpyDeviceToHost, s));
+    if (h_policy_logits) LZ_HIP_CHECK(hipMemcpyAsync(h_policy_logits, r->sim_logits + slot * B * A, B * A * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw)
+{
+    LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr && h_out_nchw != nullptr, "no pools");
+    LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
+    lz_model *m = r->eng->model;
+    const size_t B = r->t.B, C = m->cfg.num_channels, HW = m->HWl;
+    std::vector<float> tmp(B * HW * C);
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(tmp.data(), r->latent_pool + slot * B * HW * C, tmp.size() * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p)
+            for (size_t ch = 0; ch < C; ++ch) h_out_nchw[(b * C + ch) * HW + p] = tmp[(b * HW + p) * C + ch];
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_read_hidden(lz_roots *r, int slot, float *h_h, float *h_c)
+{
+    LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr, "no pools");
+    LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
+    const size_t B = r->t.B, H = r->eng->model->cfg.lstm_hidden_size;
+    hipStream_t s = r->eng->stream;
+    if (h_h) LZ_HIP_CHECK(hipMemcpyAsync(h_h, r->h_pool + slot * B * H, B * H * 4, hipMemcpyDeviceToHost, s));
+    if (h_c) LZ_HIP_CHECK(hipMemcpyAsync(h_c, r->c_pool + slot * B * H, B * H * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out)
+{
+    LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr && h_out != nullptr && (which == 0 || which == 1), "bad argument");
+    const size_t B = r->t.B, SUP = r->eng->model->cfg.support_size;
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(h_out, r->dbg_logits[which], B * SUP * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// ---- debugging aids (not part of the documented ABI surface used by the shim)
+extern "C" int lz_debug_set(lz_engine *e, const char *key, int value)
+{
+    LZ_REQUIRE(e && e->model && key, "bad argument");
+    if (strcmp(key, "stop_stage") == 0) { e->model->debug_stop = value; return LZ_OK; }
+    lz_set_error("unknown debug key %s", key);
+    return LZ_ERR_INVALID;
+}
+extern "C" int lz_debug_read_ws(lz_engine *e, int which, float *h_out, int64_t n)
+{
+    LZ_REQUIRE(e && e->model && which >= 0 && which < 3 && e->model->ws[which] && h_out, "bad argument");
+    LZ_HIP_CHECK(hipMemcpy(h_out, e->model->ws[which], (size_t)n * 4, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}
+
+extern "C" int lz_debug_read_param(lz_engine *e, const char *name, float *h_out, int64_t n)
+{
+    LZ_REQUIRE(e && e->model && name && h_out, "bad argument");
+    lz_model *m = e->model;
+    const float *src = nullptr;
+    if (!strcmp(name, "first_w")) src = m->first_w;
+    else if (!strcmp(name, "first_s")) src = m->first_s;
+    else if (!strcmp(name, "first_t")) src = m->first_t;
+    else if (!strcmp(name, "r1a_w")) src = m->r1a.w;
+    else if (!strcmp(name, "r1a_s")) src = m->r1a.scale;
+    else if (!strcmp(name, "r1a_t")) src = m->r1a.shift;
+    LZ_REQUIRE(src != nullptr, "unknown param");
+    LZ_HIP_CHECK(hipMemcpy(h_out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}

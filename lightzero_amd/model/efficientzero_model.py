@@ -1,0 +1,66 @@
+"""Engine-backed counterpart of lzero/model/efficientzero_model.py::EfficientZeroModel (inference graph).
+
+Same constructor keywords as the reference class (the ones that shape the inference graph); weights
+are ingested from a reference-format ``state_dict`` (same key names) and live in HBM in the kernels'
+layouts.  ``initial_inference`` / the recurrent loop run as HIP kernels behind the C ABI
+(lightzero_amd/csrc/lz_nn.hip, lz_search.hip); there is no torch module inside and no fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib as L
+
+
+class EfficientZeroModel(object):
+    def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, lstm_hidden_size=512, num_res_blocks=1,
+                 num_channels=64, reward_head_channels=16, value_head_channels=16, policy_head_channels=16,
+                 reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
+                 reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
+                 categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
+                 engine=None, **kwargs):
+        if num_res_blocks != 1 or not downsample or norm_type != 'BN' or not categorical_distribution \
+                or discrete_action_encoding_type != 'one_hot':
+            raise NotImplementedError("engine model: num_res_blocks=1, downsample=True, norm_type='BN', "
+                                      "categorical_distribution=True, one_hot action encoding")
+        if tuple(reward_support_range) != tuple(value_support_range) or value_support_range[2] != 1.:
+            raise NotImplementedError("reward and value supports must be equal with step 1")
+        if not (reward_head_channels == value_head_channels == policy_head_channels):
+            raise NotImplementedError("head channel counts must be equal")
+        self.observation_shape = tuple(observation_shape)
+        self.action_space_size = int(action_space_size)
+        self.lstm_hidden_size = int(lstm_hidden_size)
+        self.num_channels = int(num_channels)
+        self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
+        self.reward_support_size = self.value_support_size
+        self._engine = engine if engine is not None else L.default_engine()
+        cfg = L.ModelCfg(0, self.observation_shape[0], self.observation_shape[1], self.observation_shape[2],
+                         self.action_space_size, self.num_channels, self.lstm_hidden_size, int(value_head_channels),
+                         int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5)
+        L.check(L.lib().lz_model_create(self._engine, ctypes.byref(cfg)))
+        self._loaded = False
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict=True):
+        """state_dict: reference key -> array-like (torch tensors or numpy), e.g. a LightZero checkpoint's ``model``."""
+        for name, value in state_dict.items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            arr = value.detach().cpu().numpy() if hasattr(value, "detach") else np.asarray(value)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (ctypes.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            L.check(L.lib().lz_model_set_tensor(self._engine, name.encode(), arr.reshape(-1), shape, arr.ndim))
+        L.check(L.lib().lz_model_finalize(self._engine))
+        self._loaded = True
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("the engine model is inference-only")
+        return self

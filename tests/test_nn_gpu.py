@@ -1,0 +1,106 @@
+"""GPU parity of the network kernels (through the C ABI) against the torch fp32 restatement of the
+reference model (oracle/torch_models.py), on shared seeded weights.
+
+Tolerances (fp32 everywhere; only summation order differs):
+  * latent / LSTM state / policy logits: |d| <= 2e-5 absolute (activations are O(1))
+  * value / value-prefix scalars after h^-1: |d| <= 3e-4.  The reference's own fp32 formula
+    sign(x)(((sqrt(1+4e(|x|+1+e))-1)/(2e))^2-1) (scaling_transform.py:88-91) subtracts 1 from a number
+    ~1.004 and divides by 0.002, so its OUTPUT is quantised in steps of ~1.3e-4 near 0; two correct fp32
+    pipelines whose inputs differ by 1e-6 can land on neighbouring steps.  The pre-transform logits are
+    compared at 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, A=6, S=12, seed=0):
+    from oracle import torch_models as tm
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=seed)
+    dev = EfficientZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(seed + 1)
+    obs = torch.rand(B, 4, 96, 96, generator=g)
+    roots = ez_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    roots._ensure(A)
+    return ref, dev, obs, roots
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+@pytest.mark.parametrize("B", [8, 37])
+def test_initial_inference_matches_torch(B):
+    from lightzero_amd import _lib as L
+    from oracle import torch_models as tm
+    ref, dev, obs, roots = _setup(B)
+    d_obs = obs.cuda().contiguous()
+    torch.cuda.synchronize()
+    L.check(L.lib().lz_initial_inference(roots._h, d_obs.data_ptr()))
+    lat = np.zeros((B, 64, 6, 6), np.float32)
+    L.check(L.lib().lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
+    val = np.zeros(B, np.float32); pol = np.zeros((B, 6), np.float32)
+    L.check(L.lib().lz_roots_get_root_outputs(roots._h, val, pol.reshape(-1)))
+    vlog = np.zeros((B, 601), np.float32)
+    L.check(L.lib().lz_roots_read_debug_logits(roots._h, 0, vlog.reshape(-1)))
+    with torch.no_grad():
+        o = ref.initial_inference(obs)
+        rv = tm.InverseScalarTransform()(o.value).reshape(-1).numpy()
+    assert _maxdiff(lat, o.latent_state.numpy()) < 2e-5
+    assert _maxdiff(pol, o.policy_logits.numpy()) < 2e-5
+    assert _maxdiff(vlog, o.value.numpy()) < 2e-5
+    assert _maxdiff(val, rv) < 3e-4
+
+
+def test_recurrent_inference_matches_torch_teacher_forced():
+    """Every simulation of a device search: feed the torch model the SAME (latent, h, c, action) the
+    device gathered and compare everything the step produced."""
+    from lightzero_amd import _lib as L
+    from oracle import torch_models as tm
+    B, A, S = 16, 6, 12
+    ref, dev, obs, roots = _setup(B, A, S)
+    d_obs = obs.cuda().contiguous()
+    torch.cuda.synchronize()
+    lib = L.lib()
+    L.check(lib.lz_initial_inference(roots._h, d_obs.data_ptr()))
+    rng = np.random.default_rng(0)
+    noises = rng.dirichlet([0.3] * A, size=B).astype(np.float32).reshape(-1)
+    L.check(lib.lz_roots_prepare_from_inference(roots._h, 0.25, noises.ctypes.data, L.i32([-1] * B)))
+    L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+    L.check(lib.lz_engine_synchronize(L.default_engine()))
+    trace = np.zeros((S, B, 4), np.int32)
+    L.check(lib.lz_roots_read_trace(roots._h, S, trace.reshape(-1)))
+    lat = np.zeros((S + 1, B, 64, 6, 6), np.float32); hh = np.zeros((S + 1, B, 512), np.float32); cc = np.zeros_like(hh)
+    vp = np.zeros((S + 1, B), np.float32); val = np.zeros_like(vp); pol = np.zeros((S + 1, B, A), np.float32)
+    for s in range(S + 1):
+        L.check(lib.lz_roots_read_latent(roots._h, s, lat[s].reshape(-1)))
+        L.check(lib.lz_roots_read_hidden(roots._h, s, hh[s].reshape(-1), cc[s].reshape(-1)))
+        L.check(lib.lz_roots_read_sim_outputs(roots._h, s, vp[s], val[s], pol[s].reshape(-1)))
+    ist = tm.InverseScalarTransform()
+    ar = np.arange(B)
+    worst = dict(lat=0.0, h=0.0, c=0.0, pol=0.0, vp=0.0, val=0.0)
+    for s in range(S):
+        ix, act, slen = trace[s, :, 0], trace[s, :, 1], trace[s, :, 2]
+        assert (ix <= s).all() and (act >= 0).all() and (act < A).all()
+        with torch.no_grad():
+            o = ref.recurrent_inference(torch.from_numpy(lat[ix, ar]),
+                                        (torch.from_numpy(hh[ix, ar]).unsqueeze(0), torch.from_numpy(cc[ix, ar]).unsqueeze(0)),
+                                        torch.from_numpy(act).long())
+            r_vp = ist(o.value_prefix).reshape(-1).numpy(); r_val = ist(o.value).reshape(-1).numpy()
+            rh = o.reward_hidden_state[0][0].numpy().copy(); rc = o.reward_hidden_state[1][0].numpy().copy()
+        reset = (slen % 5 == 0)
+        rh[reset] = 0; rc[reset] = 0  # mcts_ctree.py:859-863
+        worst["lat"] = max(worst["lat"], _maxdiff(lat[s + 1], o.latent_state.numpy()))
+        worst["h"] = max(worst["h"], _maxdiff(hh[s + 1], rh)); worst["c"] = max(worst["c"], _maxdiff(cc[s + 1], rc))
+        worst["pol"] = max(worst["pol"], _maxdiff(pol[s + 1], o.policy_logits.numpy()))
+        worst["vp"] = max(worst["vp"], _maxdiff(vp[s + 1], r_vp)); worst["val"] = max(worst["val"], _maxdiff(val[s + 1], r_val))
+    print("worst abs diffs:", worst)
+    assert worst["lat"] < 2e-5 and worst["h"] < 2e-5 and worst["c"] < 2e-5 and worst["pol"] < 2e-5, worst
+    assert worst["vp"] < 3e-4 and worst["val"] < 3e-4, worst
+    dist = np.array(roots.get_distributions())
+    assert (dist.sum(1) == S).all()
