@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark: self-play env-steps/s (and MCTS sims/s) for EfficientZero Atari, 96x96x4
+observations, 50 simulations, 256 parallel envs per MI355X (BASELINE.json configs[1]).
+
+A "step" is one pass of the hot path over one batch of 256 synthetic observations that are already
+resident in HBM: initial_inference -> root prepare with Dirichlet noise -> 50 x [select -> recurrent
+inference -> expand/backup] on the device -> visit-count distributions and root values on the host
+(the `_forward_collect` contract).  Weak scaling: every GPU owns its own 256 envs; the only collective
+is the all-gather of the packed trajectory rows (lightzero_amd/shard.py).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS, SIMS, ACTIONS = 256, 50, 6
+FLOP_RECURRENT = 18381312        # per env per simulation
+FLOP_INITIAL = 292222912         # per env-step
+FLOP_CONV6 = 2 * 36 * 64 * 64 * 9  # 64->64 3x3 conv on the 6x6 latent, per env = 2,654,208
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
+           lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
+
+
+def cpu_baseline(ref_model, obs_cpu, noises, budget_s=25.0):
+    """The reference pipeline on the host cores: reference ctree (compiled from its own sources when
+    oracle/_ref is present, else the C restatement) + restated Python driver + torch fp32 model."""
+    import torch
+    from oracle import build_ref, ctree as octree, search as osearch
+    mods = build_ref.load("stock")
+    kind_tree = "reference ctree (oracle/_ref/stock)" if mods else "C restatement of the ctree (oracle/ctree_oracle.c)"
+    tree = mods[0] if mods else octree.ez_tree
+    kw = {} if mods else dict(roots_kwargs=dict(action_space_size=ACTIONS, max_simulations=SIMS))
+    cores = torch.get_num_threads()
+    legal = [list(range(ACTIONS))] * ENVS
+    n, t_used = 0, 0.0
+    osearch.ez_forward_collect(tree, ref_model, obs_cpu[:32], legal[:32], [z for z in noises[:32]], [-1] * 32, CFG, **kw)  # warm-up
+    while t_used < budget_s * 0.5 and n < 3:
+        t0 = time.perf_counter()
+        osearch.ez_forward_collect(tree, ref_model, obs_cpu, legal, noises, [-1] * ENVS, CFG, **kw)
+        t_used += time.perf_counter() - t0
+        n += 1
+    return dict(value=ENVS * n / t_used, unit="env-steps/s", cores=cores, kind="port",
+                sample="%d full env-step batches (256 envs x 50 sims) after a 32-env warm-up; %s + restated "
+                       "EfficientZeroMCTSCtree.search driver + torch fp32 model on %d threads; %.1f s" %
+                       (n, kind_tree, cores, t_used))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiebreak", choices=["first", "random"], default="random",
+                    help="random = the reference's stochastic tie rule (default, like collection); first = parity mode")
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oracle import torch_models as tm  # synthetic weights of the named architecture (no checkpoints offline)
+    from lightzero_amd import _lib as L, shard
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    lib = L.lib()
+    ref_model = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=ACTIONS), seed=0)
+    eng = L.default_engine(local_rank)
+    model = EfficientZeroModel(action_space_size=ACTIONS, engine=eng).load_state_dict(ref_model.state_dict())
+    g = torch.Generator().manual_seed(1000 + rank)
+    obs_cpu = torch.rand(ENVS, 4, 96, 96, generator=g)
+    obs = obs_cpu.cuda().contiguous()
+    rng = np.random.default_rng(rank)
+    total = args.warmup + args.steps
+    noise_steps = [rng.dirichlet([0.3] * ACTIONS, size=ENVS).astype(np.float32) for _ in range(total)]
+    legal = [list(range(ACTIONS))] * ENVS
+    roots = ez_tree.Roots(ENVS, legal, action_space_size=ACTIONS, max_simulations=SIMS, engine=eng)
+    roots.set_tiebreak(0 if args.tiebreak == "first" else 1, seed=rank + 1)
+    roots._ensure(ACTIONS)
+    to_play = L.i32([-1] * ENVS)
+    dist_out = np.zeros((ENVS, ACTIONS), np.int32)
+    cnt_out = np.zeros(ENVS, np.int32)
+    val_out = np.zeros(ENVS, np.float32)
+    pred_out = np.zeros(ENVS, np.float32)
+    logit_out = np.zeros((ENVS, ACTIONS), np.float32)
+    rows_dev = torch.zeros(ENVS, 4 + ACTIONS, device="cuda")
+
+    def step(i):
+        L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
+        L.check(lib.lz_roots_prepare_from_inference(roots._h, CFG["root_noise_weight"],
+                                                    noise_steps[i].ctypes.data, to_play))
+        L.check(lib.lz_search(roots._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"],
+                              CFG["lstm_horizon_len"], CFG["value_delta_max"]))
+        L.check(lib.lz_roots_get_distributions(roots._h, dist_out, cnt_out))
+        L.check(lib.lz_roots_get_values(roots._h, val_out))
+        L.check(lib.lz_roots_get_root_outputs(roots._h, pred_out, logit_out.reshape(-1)))
+        if world > 1:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI)
+            rows = np.concatenate([np.zeros((ENVS, 1), np.float32), val_out[:, None], pred_out[:, None],
+                                   cnt_out[:, None].astype(np.float32), dist_out.astype(np.float32)], 1)
+            rows_dev.copy_(torch.from_numpy(rows))
+            shard.all_gather_rows(rows_dev)
+
+    for i in range(args.warmup):
+        step(i)
+    L.check(lib.lz_profile_enable(eng, 4 * SIMS * args.steps))
+    torch.cuda.synchronize()
+    L.check(lib.lz_engine_synchronize(eng))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    L.check(lib.lz_engine_synchronize(eng))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert (dist_out.sum(1) == SIMS).all(), "search did not run all simulations"
+    n_launch = ctypes.c_int64(0)
+    tot_ms = ctypes.c_double(0.0)
+    L.check(lib.lz_profile_read(eng, ctypes.byref(n_launch), ctypes.byref(tot_ms)))
+    L.check(lib.lz_profile_enable(eng, 0))
+
+    if rank == 0:
+        value = world * ENVS * args.steps / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        avg_us = tot_ms.value / max(n_launch.value, 1) * 1e3
+        achieved = (ENVS * FLOP_CONV6) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
+        out = {
+            "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Atari Pong EfficientZero, obs 4x96x96, 50 sims, "
+                                   "256 envs per GPU, A=6, support 601, LSTM 512; synthetic obs, seed-0 random-init weights",
+                       "envs_per_gpu": ENVS, "num_simulations": SIMS, "mcts_sims_per_s": value * SIMS,
+                       "tiebreak": args.tiebreak, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
+                       "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_conv3x3<64,1> (64->64 3x3 conv on the 6x6 latent, 4 launches/simulation)",
+                         "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": None,
+                         "avg_launch_us": avg_us, "launches_timed": n_launch.value,
+                         "algorithmic_flop_per_launch": ENVS * FLOP_CONV6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]])
+            out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,8 @@ int lz_model_finalize(lz_engine *e);
  * (efficientzero_model.py:229-238).  Predicted values (after h^-1) and policy logits stay in HBM and
  * can be fetched with lz_roots_get_root_outputs. */
 int lz_initial_inference(lz_roots *r, const float *d_obs);
+/* same from a HOST observation batch (staged through HBM; the PCIe copy is on the engine stream) */
+int lz_initial_inference_host(lz_roots *r, const float *h_obs);
 int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits);
 /* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
  * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
@@ -163,9 +165,14 @@ int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw);
 int lz_roots_read_hidden(lz_roots *r, int slot, float *h_h, float *h_c);
 /* optional debug logits of the last head launch: which = 0 value [B][support], 1 value_prefix/reward [B][support] */
 int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out);
+/* in-stream timing (HIP events on the engine stream) of the 64->64 3x3 convolution on the latent grid --
+ * the dominant kernel of the recurrent loop -- for bench.py's roofline object */
+int lz_profile_enable(lz_engine *e, int max_launches);
+int lz_profile_read(lz_engine *e, int64_t *out_launches, double *out_total_ms);
 /* debugging aids: stop lz_initial_inference after stage k ("stop_stage"), read a workspace buffer */
 int lz_debug_set(lz_engine *e, const char *key, int value);
 int lz_debug_read_ws(lz_engine *e, int which, float *h_out, int64_t n);
+int lz_debug_read_param(lz_engine *e, const char *name, float *h_out, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 library is missing or no gfx950 device is visible, compute entry points raise."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -33,6 +34,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise LzError("%s not found: build it with `python -m lightzero_amd.build` (hipcc, gfx950). "
                       "lightzero_amd has no CPU/PyTorch fallback." % LIB_PATH)
+    if "torch" not in sys.modules and not os.environ.get("LZ_NO_TORCH_PRELOAD"):
+        # PyTorch-ROCm bundles its own libamdhip64; when both live in one process the HIP runtime must be
+        # loaded once.  Importing torch first makes this library bind to the runtime torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     L.lz_last_error.restype = ctypes.c_char_p
     L.lz_engine_stream.restype = P
@@ -57,9 +65,12 @@ def lib():
         "lz_model_set_tensor": [P, ctypes.c_char_p, c_f32p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
         "lz_model_finalize": [P],
         "lz_initial_inference": [P, P],
+        "lz_initial_inference_host": [P, c_f32p],
         "lz_roots_get_root_outputs": [P, c_f32p, c_f32p],
         "lz_roots_prepare_from_inference": [P, ctypes.c_float, P, c_i32p],
         "lz_search": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float],
+        "lz_profile_enable": [P, ctypes.c_int],
+        "lz_profile_read": [P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
         "lz_roots_read_trace": [P, ctypes.c_int, c_i32p],
         "lz_roots_read_sim_outputs": [P, ctypes.c_int, c_f32p, c_f32p, c_f32p],
         "lz_roots_read_latent": [P, ctypes.c_int, c_f32p],

@@ -190,6 +190,7 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     (void)hipStreamSynchronize(r->eng->stream);
     if (r->slab) (void)hipFree(r->slab);
     if (r->pool_slab) (void)hipFree(r->pool_slab);
+    if (r->d_obs) (void)hipFree(r->d_obs);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);
     delete r;

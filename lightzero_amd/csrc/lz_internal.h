@@ -32,6 +32,11 @@ struct lz_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     lz_model *model = nullptr;
+    // optional in-stream timing of one kernel class (bench.py roofline): HIP event pairs recorded on the
+    // engine stream around every launch of the tagged kernel while enabled
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // 2 * capacity events, created on enable
+    size_t prof_used = 0;              // pairs recorded
 };
 
 // HBM-resident node arrays of a batch of trees.
@@ -92,6 +97,7 @@ struct lz_roots {
     float *d_zero_vp = nullptr;     // [B] zeros
     float *d_noise = nullptr;       // [B][A]
     int32_t *d_noise_off = nullptr; // [B]
+    float *d_obs = nullptr;         // staging for lz_initial_inference_host
     bool inferred = false;
 };
 

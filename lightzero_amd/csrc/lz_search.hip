@@ -358,8 +358,11 @@ static int ensure_ws(lz_model *m, int B)
 }
 
 static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
-                 int relu, hipStream_t s)
+                 int relu, hipStream_t s, lz_engine *prof = nullptr)
 {
+    const bool rec = prof && prof->prof_on && 2 * (prof->prof_used + 1) <= prof->prof_ev.size();
+    if (rec) (void)hipEventRecord(prof->prof_ev[2 * prof->prof_used], s);
+    struct Fin { lz_engine *p; bool rec; hipStream_t s; ~Fin() { if (rec) { (void)hipEventRecord(p->prof_ev[2 * p->prof_used + 1], s); p->prof_used++; } } } fin{prof, rec, s};
     lz_conv_args a{};
     a.in = in; a.w = w.w; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
@@ -372,8 +375,8 @@ static void prediction(lz_roots *r, const float *latent, float *out_value, float
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
     const int B = r->t.B, HW = m->HWl, C = c.num_channels;
-    conv(m->pa, latent, r->t_x2, B, 6, 6, 1, nullptr, 1, s);
-    conv(m->pb, r->t_x2, r->t_x3, B, 6, 6, 1, latent, 1, s);
+    conv(m->pa, latent, r->t_x2, B, 6, 6, 1, nullptr, 1, s, r->eng);
+    conv(m->pb, r->t_x2, r->t_x3, B, 6, 6, 1, latent, 1, s, r->eng);
     lz_head_desc h[3];
     memset(h, 0, sizeof(h));
     int n = 0;
@@ -449,6 +452,18 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     return LZ_OK;
 }
 
+extern "C" int lz_initial_inference_host(lz_roots *r, const float *h_obs)
+{
+    LZ_REQUIRE(r != nullptr && h_obs != nullptr, "NULL argument");
+    lz_model *m = r->eng->model;
+    if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    const size_t n = (size_t)r->t.B * m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
+    if (!r->d_obs) LZ_HIP_CHECK(hipMalloc((void **)&r->d_obs, n * 4));
+    LZ_HIP_CHECK(hipMemcpyAsync(r->d_obs, h_obs, n * 4, hipMemcpyHostToDevice, r->eng->stream));
+    return lz_initial_inference(r, r->d_obs);
+}
+
 extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits)
 {
     LZ_REQUIRE(r != nullptr && r->inferred, "lz_initial_inference has not run on these roots");
@@ -515,8 +530,8 @@ static void simulate(lz_roots *r, int sim, const lz_traverse_args &ta, float del
     a.B = (int)B; a.Hin = a.Win = a.Hout = a.Wout = 6; a.Cout = (int)C; a.relu = 1;
     lz_launch_conv3x3(a, 64, 1, s);
     float *next_latent = r->latent_pool + (size_t)slot * lat_slot;
-    conv(m->dra, r->t_x1, r->t_x2, (int)B, 6, 6, 1, nullptr, 1, s);
-    conv(m->drb, r->t_x2, next_latent, (int)B, 6, 6, 1, r->t_x1, 1, s);
+    conv(m->dra, r->t_x1, r->t_x2, (int)B, 6, 6, 1, nullptr, 1, s, r->eng);
+    conv(m->drb, r->t_x2, next_latent, (int)B, 6, 6, 1, r->t_x1, 1, s, r->eng);
     // ---- value prefix: conv1x1 + BN + ReLU -> LSTM -> BN1d + ReLU (-> MLP in the heads launch)
     lz_launch_conv1x1(next_latent, m->rew_c.w, m->rew_c.b, m->rew_c.s, m->rew_c.t, r->t_rx, (int)B, (int)HW, (int)C, c.head_channels, s);
     lz_lstm_args l{};
@@ -656,5 +671,37 @@ extern "C" int lz_debug_read_param(lz_engine *e, const char *name, float *h_out,
     else if (!strcmp(name, "r1a_t")) src = m->r1a.shift;
     LZ_REQUIRE(src != nullptr, "unknown param");
     LZ_HIP_CHECK(hipMemcpy(h_out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}
+
+// ---- in-stream kernel timing for the roofline line of bench.py: the tagged kernel class is the plain
+// 64->64 3x3 convolution on the 6x6 latent (dynamics + prediction residual blocks, 4 launches / simulation).
+extern "C" int lz_profile_enable(lz_engine *e, int max_launches)
+{
+    LZ_REQUIRE(e != nullptr && max_launches >= 0, "bad argument");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    e->prof_ev.clear();
+    e->prof_used = 0;
+    e->prof_on = max_launches > 0;
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t ev;
+        LZ_HIP_CHECK(hipEventCreate(&ev));
+        e->prof_ev.push_back(ev);
+    }
+    return LZ_OK;
+}
+extern "C" int lz_profile_read(lz_engine *e, int64_t *out_launches, double *out_total_ms)
+{
+    LZ_REQUIRE(e != nullptr && out_launches && out_total_ms, "bad argument");
+    LZ_HIP_CHECK(hipStreamSynchronize(e->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        float ms = 0.f;
+        LZ_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *out_launches = (int64_t)e->prof_used;
+    *out_total_ms = tot;
     return LZ_OK;
 }

@@ -105,6 +105,16 @@ def make_module(variant, has_deterministic_flag):
             L.check(L.lib().lz_roots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), logits,
                                              L.i32(to_play_batch)))
 
+        def prepare_from_inference(self, root_noise_weight, noises, to_play_batch):
+            """Roots.prepare with the policy logits an engine model's initial_inference left in HBM
+            (value prefix 0, efficientzero_model.py:238); noises: one list per root over its legal actions."""
+            nz = L.f32([x for row in noises for x in row] or [0.0])
+            L.check(L.lib().lz_roots_prepare_from_inference(self._h, float(root_noise_weight), nz.ctypes.data,
+                                                            L.i32(to_play_batch)))
+
+        def prepare_from_inference_no_noise(self, to_play_batch):
+            L.check(L.lib().lz_roots_prepare_from_inference(self._h, 0.0, None, L.i32(to_play_batch)))
+
         def get_distributions(self):
             if self._h is None:
                 return [[] for _ in range(self.root_num)]

@@ -1,0 +1,173 @@
+"""Drop-in for the EfficientZero/MuZero drivers of lzero/mcts/tree_search/mcts_ctree.py.
+
+``EfficientZeroMCTSCtree(cfg).roots(n, legal_actions)`` / ``.search(roots, model, latent_state_roots,
+reward_hidden_state_roots, to_play_batch)`` keep the reference's names, arguments and in-place effect
+on ``roots``.  Two execution paths:
+
+* ``model`` is an engine model (lightzero_amd.model.EfficientZeroModel) and the roots were filled by
+  its ``initial_inference``: the whole ``num_simulations`` loop runs on the device (lz_search) --
+  latent/LSTM pools, gathers, recurrent inference, h^-1, LSTM reset, expand and backup never leave HBM.
+* any other ``model`` exposing ``recurrent_inference`` (e.g. a torch module): the reference's loop
+  (mcts_ctree.py:782-876) is executed with the HBM-resident tree kernels doing batch_traverse /
+  batch_backpropagate -- the plumbing configuration.
+"""
+import copy
+
+import numpy as np
+
+from ..ctree.ctree_efficientzero import ez_tree as tree_efficientzero
+from ..ctree.ctree_muzero import mz_tree as tree_muzero
+from ... import _lib as L
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _get(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+def _inverse_scalar_transform(logits, support_min, epsilon=0.001):
+    """InverseScalarTransform.__call__ (lzero/policy/scaling_transform.py:82-92) with the same torch ops, for the
+    foreign-model path (``logits``: torch tensor [B, support]); returns numpy [B, 1]."""
+    import torch
+    support = (support_min + torch.arange(logits.shape[1], dtype=torch.float32, device=logits.device)).unsqueeze(0)
+    value_probs = torch.softmax(logits, dim=1)
+    value = value_probs.mul_(support).sum(1, keepdim=True)
+    tmp = ((torch.sqrt(1 + 4 * epsilon * (torch.abs(value) + 1 + epsilon)) - 1) / (2 * epsilon))
+    return (torch.sign(value) * (tmp * tmp - 1)).detach().cpu().numpy()
+
+
+class EfficientZeroMCTSCtree(object):
+    config = dict(root_dirichlet_alpha=0.3, root_noise_weight=0.25, pb_c_base=19652, pb_c_init=1.25,
+                  value_delta_max=0.01)
+
+    @classmethod
+    def default_config(cls):
+        cfg = _Cfg(copy.deepcopy(cls.config))
+        cfg["cfg_type"] = cls.__name__ + "Dict"
+        return cfg
+
+    def __init__(self, cfg=None):
+        default_config = self.default_config()
+        if cfg is not None:
+            default_config.update(dict(cfg) if isinstance(cfg, dict) else {k: getattr(cfg, k) for k in dir(cfg)
+                                                                            if not k.startswith("_")})
+        self._cfg = default_config
+        model_cfg = _get(self._cfg, "model", {}) or {}
+        rng = _get(model_cfg, "value_support_range", (-300., 301., 1.))
+        self._support_min = float(rng[0])
+
+    @classmethod
+    def roots(cls, active_collect_env_num, legal_actions, action_space_size=None, max_simulations=None):
+        return tree_efficientzero.Roots(active_collect_env_num, legal_actions, action_space_size=action_space_size,
+                                        max_simulations=max_simulations)
+
+    def search(self, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch):
+        cfg = self._cfg
+        num_simulations = int(cfg["num_simulations"])
+        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+            L.check(L.lib().lz_search(roots._h, num_simulations, int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
+                                      float(cfg["discount_factor"]), int(cfg["lstm_horizon_len"]),
+                                      float(cfg["value_delta_max"])))
+            return
+        self._search_foreign_model(roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch)
+
+    # the reference's loop with a foreign model; tree on the device
+    def _search_foreign_model(self, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch):
+        import torch
+        cfg = self._cfg
+        device = _get(cfg, "device", "cpu")
+        with torch.no_grad():
+            model.eval()
+            batch_size = roots.num
+            pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+            latent_pool = [np.asarray(latent_state_roots)]
+            c_pool = [np.asarray(reward_hidden_state_roots[0])]
+            h_pool = [np.asarray(reward_hidden_state_roots[1])]
+            min_max_stats_lst = tree_efficientzero.MinMaxStatsList(batch_size)
+            min_max_stats_lst.set_delta(cfg["value_delta_max"])
+            ar = np.arange(batch_size)
+            for simulation_index in range(int(cfg["num_simulations"])):
+                results = tree_efficientzero.ResultsWrapper(num=batch_size)
+                tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
+                ix, iy, last_actions, virtual_to_play_batch = tree_efficientzero.batch_traverse(
+                    roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, tp)
+                search_lens = results.get_search_len()
+                ix = np.asarray(ix); iy = np.asarray(iy)
+                lat_all = np.stack(latent_pool); c_all = np.stack(c_pool); h_all = np.stack(h_pool)
+                latent_states = torch.from_numpy(lat_all[ix, iy]).to(device)
+                hc = torch.from_numpy(c_all[ix, 0, iy]).to(device).unsqueeze(0)
+                hh = torch.from_numpy(h_all[ix, 0, iy]).to(device).unsqueeze(0)
+                out = model.recurrent_inference(latent_states, (hc, hh), torch.from_numpy(np.asarray(last_actions)).to(device).long())
+                latent_pool.append(out.latent_state.detach().cpu().numpy())
+                value = _inverse_scalar_transform(out.value, self._support_min)
+                value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min)
+                rhs = [out.reward_hidden_state[0].detach().cpu().numpy().copy(), out.reward_hidden_state[1].detach().cpu().numpy().copy()]
+                reset_idx = (np.array(search_lens) % int(cfg["lstm_horizon_len"]) == 0)
+                rhs[0][:, reset_idx, :] = 0
+                rhs[1][:, reset_idx, :] = 0
+                c_pool.append(rhs[0]); h_pool.append(rhs[1])
+                tree_efficientzero.batch_backpropagate(
+                    simulation_index + 1, discount_factor, value_prefix.reshape(-1), value.reshape(-1),
+                    out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
+                    reset_idx.astype(np.int32), virtual_to_play_batch)
+
+
+class MuZeroMCTSCtree(object):
+    """lzero/mcts/tree_search/mcts_ctree.py:211-368 (reference loop; tree kernels on the device)."""
+    config = dict(root_dirichlet_alpha=0.3, root_noise_weight=0.25, pb_c_base=19652, pb_c_init=1.25,
+                  value_delta_max=0.01)
+
+    @classmethod
+    def default_config(cls):
+        cfg = _Cfg(copy.deepcopy(cls.config))
+        cfg["cfg_type"] = cls.__name__ + "Dict"
+        return cfg
+
+    def __init__(self, cfg=None):
+        default_config = self.default_config()
+        if cfg is not None:
+            default_config.update(dict(cfg))
+        self._cfg = default_config
+        model_cfg = _get(self._cfg, "model", {}) or {}
+        self._support_min = float(_get(model_cfg, "value_support_range", (-300., 301., 1.))[0])
+        self._categorical = bool(_get(model_cfg, "categorical_distribution", True))
+
+    @classmethod
+    def roots(cls, active_collect_env_num, legal_actions, action_space_size=None, max_simulations=None):
+        return tree_muzero.Roots(active_collect_env_num, legal_actions, action_space_size=action_space_size,
+                                 max_simulations=max_simulations)
+
+    def search(self, roots, model, latent_state_roots, to_play_batch, task_id=None):
+        import torch
+        cfg = self._cfg
+        device = _get(cfg, "device", "cpu")
+        with torch.no_grad():
+            model.eval()
+            batch_size = roots.num
+            pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+            latent_pool = [np.asarray(latent_state_roots)]
+            min_max_stats_lst = tree_muzero.MinMaxStatsList(batch_size)
+            min_max_stats_lst.set_delta(cfg["value_delta_max"])
+            for simulation_index in range(int(cfg["num_simulations"])):
+                results = tree_muzero.ResultsWrapper(num=batch_size)
+                tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
+                ix, iy, last_actions, virtual_to_play_batch = tree_muzero.batch_traverse(
+                    roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, tp)
+                lat_all = np.stack(latent_pool)
+                latent_states = torch.from_numpy(lat_all[np.asarray(ix), np.asarray(iy)]).to(device)
+                out = model.recurrent_inference(latent_states, torch.from_numpy(np.asarray(last_actions)).to(device).long())
+                latent_pool.append(out.latent_state.detach().cpu().numpy())
+                if self._categorical:
+                    value = _inverse_scalar_transform(out.value, self._support_min)
+                    reward = _inverse_scalar_transform(out.reward, self._support_min)
+                else:
+                    value = out.value.detach().cpu().numpy(); reward = out.reward.detach().cpu().numpy()
+                tree_muzero.batch_backpropagate(simulation_index + 1, discount_factor, reward.reshape(-1), value.reshape(-1),
+                                                out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
+                                                virtual_to_play_batch)

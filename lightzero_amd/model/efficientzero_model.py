@@ -57,6 +57,42 @@ class EfficientZeroModel(object):
         self._loaded = True
         return self
 
+    _is_lz_engine_model = True
+
+    def initial_inference(self, obs, roots):
+        """EfficientZeroModel.initial_inference (efficientzero_model.py:203-238) for the batch held by ``roots``
+        (a lightzero_amd ez_tree.Roots): the latent state and the zero LSTM state are written into the roots'
+        HBM pools (slot 0) instead of being returned.  ``obs``: [B,C,H,W] fp32 -- a device tensor exposing
+        ``data_ptr()`` (used in place) or a host numpy array (staged over PCIe).
+        Returns an ``EZNetworkOutput``-like namespace: ``value`` is already passed through
+        InverseScalarTransform (shape [B]), ``value_prefix`` is ``[0.]*B``, ``policy_logits`` is [B,A] numpy;
+        ``latent_state`` / ``reward_hidden_state`` are opaque tokens bound to ``roots``."""
+        if not self._loaded:
+            raise L.LzError("EfficientZeroModel: load_state_dict has not been called")
+        B = roots.num
+        roots._ensure(self.action_space_size)
+        if hasattr(obs, "data_ptr"):
+            if tuple(obs.shape) != (B,) + self.observation_shape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":
+                raise ValueError("obs must be a contiguous float32 [B,C,H,W] tensor")
+            if getattr(obs, "is_cuda", False):
+                import torch
+                torch.cuda.current_stream().synchronize()  # torch produced obs on its own stream
+                L.check(L.lib().lz_initial_inference(roots._h, obs.data_ptr()))
+            else:
+                L.check(L.lib().lz_initial_inference_host(roots._h, np.ascontiguousarray(obs.numpy(), np.float32).reshape(-1)))
+        else:
+            arr = np.ascontiguousarray(obs, dtype=np.float32)
+            if arr.shape != (B,) + self.observation_shape:
+                raise ValueError("obs must be [B,C,H,W]")
+            L.check(L.lib().lz_initial_inference_host(roots._h, arr.reshape(-1)))
+        roots._inferred_by = self
+        values = np.zeros(B, np.float32)
+        logits = np.zeros((B, self.action_space_size), np.float32)
+        L.check(L.lib().lz_roots_get_root_outputs(roots._h, values, logits.reshape(-1)))
+        import types
+        return types.SimpleNamespace(value=values, value_prefix=[0. for _ in range(B)], policy_logits=logits,
+                                     latent_state=("hbm-pool", roots), reward_hidden_state=("hbm-pool", roots))
+
     def eval(self):
         return self
 

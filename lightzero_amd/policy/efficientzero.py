@@ -1,0 +1,122 @@
+"""Collect / eval halves of lzero/policy/efficientzero.py::EfficientZeroPolicy on the MI355X engine.
+
+``_forward_collect(data, action_mask, temperature, to_play, epsilon, ready_env_id)`` (efficientzero.py:539-657)
+and ``_forward_eval(data, action_mask, to_play, ready_env_id)`` (:670-747) keep the reference's arguments and
+the per-env output dict (``action``, ``visit_count_distributions``, ``visit_count_distribution_entropy``,
+``searched_value``, ``predicted_value``, ``predicted_policy_logits``).  The learn half is out of scope.
+"""
+import numpy as np
+
+from ..mcts.tree_search.mcts_ctree import EfficientZeroMCTSCtree as MCTSCtree
+from .utils import select_action
+
+
+def _g(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+class EfficientZeroPolicy(object):
+    def __init__(self, cfg, model):
+        """cfg: the reference policy config (dict / EasyDict-like): num_simulations, discount_factor,
+        lstm_horizon_len, root_dirichlet_alpha, root_noise_weight, pb_c_base, pb_c_init, value_delta_max, ...
+        model: lightzero_amd.model.efficientzero_model.EfficientZeroModel with weights loaded."""
+        self._cfg = cfg
+        self._collect_model = model
+        self._eval_model = model
+        mcfg = dict(num_simulations=_g(cfg, "num_simulations", 50), discount_factor=_g(cfg, "discount_factor", 0.997),
+                    lstm_horizon_len=_g(cfg, "lstm_horizon_len", 5), pb_c_base=_g(cfg, "pb_c_base", 19652),
+                    pb_c_init=_g(cfg, "pb_c_init", 1.25), value_delta_max=_g(cfg, "value_delta_max", 0.01),
+                    root_dirichlet_alpha=_g(cfg, "root_dirichlet_alpha", 0.3),
+                    root_noise_weight=_g(cfg, "root_noise_weight", 0.25), env_type=_g(cfg, "env_type", "not_board_games"),
+                    model=_g(cfg, "model", {}) or {})
+        self._mcfg = mcfg
+        self._mcts_collect = MCTSCtree(mcfg)
+        self._mcts_eval = MCTSCtree(mcfg)
+        self._collect_mcts_temperature = 1.
+        self.collect_epsilon = 0.0
+        # "random": the reference's stochastic tie rule (rand() over the tie list, cnode.cpp:691);
+        # "first": deterministic first arg-max (parity / reproducible evaluation)
+        self._tiebreak = {"random": 1, "first": 0}[_g(cfg, "mcts_tiebreak", "random")]
+
+    def forward(self, *args, **kwargs):
+        return self._forward_collect(*args, **kwargs)
+
+    def _roots(self, n, legal_actions):
+        roots = MCTSCtree.roots(n, legal_actions, action_space_size=self._collect_model.action_space_size,
+                                max_simulations=int(self._mcfg["num_simulations"]))
+        roots.set_tiebreak(self._tiebreak)
+        return roots
+
+    def _forward_collect(self, data, action_mask=None, temperature=1, to_play=[-1], epsilon=0.25, ready_env_id=None,
+                         **kwargs):
+        self._collect_mcts_temperature = temperature
+        self.collect_epsilon = epsilon
+        active_collect_env_num = data.shape[0]
+        if ready_env_id is None:
+            ready_env_id = np.arange(active_collect_env_num)
+        output = {i: None for i in ready_env_id}
+        to_play = list(to_play) if len(to_play) == active_collect_env_num else [to_play[0]] * active_collect_env_num
+        legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_collect_env_num)]
+        roots = self._roots(active_collect_env_num, legal_actions)
+        network_output = self._collect_model.initial_inference(data, roots)
+        pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
+        alpha = self._mcfg["root_dirichlet_alpha"]
+        noises = [np.random.dirichlet([alpha] * int(sum(action_mask[j]))).astype(np.float32).tolist()
+                  for j in range(active_collect_env_num)]  # efficientzero.py:599-602
+        roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
+        self._mcts_collect.search(roots, self._collect_model, network_output.latent_state,
+                                  network_output.reward_hidden_state, to_play)
+        roots_visit_count_distributions = roots.get_distributions()
+        roots_values = roots.get_values()
+        eps_cfg = _g(self._cfg, "eps", {}) or {}
+        eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
+        for i, env_id in enumerate(ready_env_id):
+            distributions, value = roots_visit_count_distributions[i], roots_values[i]
+            if eps_greedy:
+                idx, entropy = select_action(distributions, temperature=self._collect_mcts_temperature, deterministic=True)
+                action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
+                if np.random.rand() < self.collect_epsilon:
+                    action = np.random.choice(legal_actions[i])
+            else:
+                idx, entropy = select_action(distributions, temperature=self._collect_mcts_temperature, deterministic=False)
+                action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
+            output[env_id] = {
+                'action': action,
+                'visit_count_distributions': distributions,
+                'visit_count_distribution_entropy': entropy,
+                'searched_value': value,
+                'predicted_value': pred_values[i],
+                'predicted_policy_logits': policy_logits[i],
+            }
+        return output
+
+    def _forward_eval(self, data, action_mask, to_play=[-1], ready_env_id=None, **kwargs):
+        active_eval_env_num = data.shape[0]
+        if ready_env_id is None:
+            ready_env_id = np.arange(active_eval_env_num)
+        output = {i: None for i in ready_env_id}
+        to_play = list(to_play) if len(to_play) == active_eval_env_num else [to_play[0]] * active_eval_env_num
+        legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_eval_env_num)]
+        roots = self._roots(active_eval_env_num, legal_actions)
+        network_output = self._eval_model.initial_inference(data, roots)
+        pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
+        roots.prepare_from_inference_no_noise(to_play)  # efficientzero.py:721
+        self._mcts_eval.search(roots, self._eval_model, network_output.latent_state,
+                               network_output.reward_hidden_state, to_play)
+        roots_visit_count_distributions = roots.get_distributions()
+        roots_values = roots.get_values()
+        for i, env_id in enumerate(ready_env_id):
+            distributions, value = roots_visit_count_distributions[i], roots_values[i]
+            idx, entropy = select_action(distributions, temperature=1, deterministic=True)  # efficientzero.py:733
+            action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
+            output[env_id] = {
+                'action': action,
+                'visit_count_distributions': distributions,
+                'visit_count_distribution_entropy': entropy,
+                'searched_value': value,
+                'predicted_value': pred_values[i],
+                'predicted_policy_logits': policy_logits[i],
+            }
+        return output

@@ -1,0 +1,16 @@
+"""Host-side post-search helpers (restated from lzero/policy/utils.py)."""
+import numpy as np
+
+
+def select_action(visit_counts, temperature=1, deterministic=True):
+    """lzero/policy/utils.py:637-661: p ~ N^(1/T); argmax (eval) or sample (collect); entropy in bits."""
+    visit_counts = np.asarray(visit_counts, dtype=np.float64)
+    action_probs = visit_counts ** (1 / temperature)
+    action_probs = action_probs / action_probs.sum()
+    if deterministic:
+        action_pos = int(np.argmax(visit_counts))
+    else:
+        action_pos = int(np.random.choice(len(visit_counts), p=action_probs))
+    nz = action_probs[action_probs > 0]
+    entropy = float(-(nz * np.log2(nz)).sum())
+    return action_pos, entropy
