@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 ENVS, SIMS, ACTIONS = 256, 50, 6
 FLOP_RECURRENT = 18381312        # per env per simulation
 FLOP_INITIAL = 292222912         # per env-step
-FLOP_CONV6 = 2 * 36 * 64 * 64 * 9  # 64->64 3x3 conv on the 6x6 latent, per env = 2,654,208
+FLOP_CHAIN = 2 * 36 * 64 * (70 + 4 * 64) * 9 + 2 * 36 * 64 * 48  # dyn conv 70->64 + 4 convs 64->64 + three 1x1 64->16 = 13,741,056 per env
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
@@ -120,7 +120,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    L.check(lib.lz_profile_enable(eng, 4 * SIMS * args.steps))
+    L.check(lib.lz_profile_enable(eng, SIMS * args.steps))
     torch.cuda.synchronize()
     L.check(lib.lz_engine_synchronize(eng))
     if world > 1:
@@ -147,7 +147,7 @@ def main():
         value = world * ENVS * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         avg_us = tot_ms.value / max(n_launch.value, 1) * 1e3
-        achieved = (ENVS * FLOP_CONV6) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
+        achieved = (ENVS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
         out = {
             "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -158,11 +158,11 @@ def main():
                        "envs_per_gpu": ENVS, "num_simulations": SIMS, "mcts_sims_per_s": value * SIMS,
                        "tiebreak": args.tiebreak, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
                        "parallelism": "env-shard x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_conv3x3<64,1> (64->64 3x3 conv on the 6x6 latent, 4 launches/simulation)",
+            "roofline": {"bound": "mfma", "kernel": "k_chain (per root: dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": None,
                          "avg_launch_us": avg_us, "launches_timed": n_launch.value,
-                         "algorithmic_flop_per_launch": ENVS * FLOP_CONV6},
+                         "algorithmic_flop_per_launch": ENVS * FLOP_CHAIN},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]])

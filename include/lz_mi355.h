@@ -159,6 +159,8 @@ int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, 
               int lstm_horizon_len, float value_delta_max);
 
 /* observability for parity tests: per-simulation records and pools (host copies)                  */
+/* tracing is off by default (one extra D2D copy per simulation when on) */
+int lz_roots_enable_trace(lz_roots *r, int on);
 int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out /* [S][B][4] ix, action, search_len, to_play */);
 int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_prefix, float *h_value, float *h_policy_logits);
 int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw);

@@ -71,6 +71,7 @@ def lib():
         "lz_search": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float],
         "lz_profile_enable": [P, ctypes.c_int],
         "lz_profile_read": [P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
+        "lz_roots_enable_trace": [P, ctypes.c_int],
         "lz_roots_read_trace": [P, ctypes.c_int, c_i32p],
         "lz_roots_read_sim_outputs": [P, ctypes.c_int, c_f32p, c_f32p, c_f32p],
         "lz_roots_read_latent": [P, ctypes.c_int, c_f32p],

@@ -90,6 +90,8 @@ struct lz_roots {
     float *sim_logits = nullptr;    // [NN][B][A]
     float *t_x1 = nullptr, *t_x2 = nullptr, *t_x3 = nullptr;  // [B][HW][C] scratch activations
     float *t_rx = nullptr;          // [B][HW*HC] reward conv output
+    float *t_pv = nullptr;          // [B][HW][2*HC] value | policy conv outputs
+    bool trace_on = false;          // record res_* of every simulation (parity tests)
     float *t_hbn = nullptr;         // [B][H]
     float *dbg_logits[2] = {nullptr, nullptr};  // [B][support]
     int32_t *trace = nullptr;       // [NN][5][B]  copies of res_* per simulation

@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void k_conv3x3(lz_conv_args a, int npix_max)
     constexpr int VEC = CIN / 16;   // floats per lane per operand fetch (64 -> b128, 32 -> b64)
     constexpr int PS = CIN + 4;     // padded pixel stride (floats): conflict-free fragment reads
     constexpr int TM = 144, MT = 9;
+    constexpr int CH4 = CIN / 4;
     typedef typename vecf<VEC>::type vec_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sA = smem;
-    float *sB = smem + (size_t)npix_max * PS;
+    float *sA = smem;                                   // [npix_max + 1][PS]; the extra pixel is all zeros
+    float *sB = smem + (size_t)(npix_max + 1) * PS;     // [9][16][PS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int HWin = a.Hin * a.Win, HWout = a.Hout * a.Wout;
     const int M = a.B * HWout;
@@ -58,98 +59,133 @@ __global__ __launch_bounds__(256) void k_conv3x3(lz_conv_args a, int npix_max)
     const int in_hi = min(a.B * HWin, centre(m1) + a.Win + 2);
     const int npix = in_hi - in_lo;
 
-    // ---- stage the input halo (a contiguous pixel range of the NHWC tensor) and the weight slice
-    constexpr int CH4 = CIN / 4;
-    for (int idx = tid; idx < npix * CH4; idx += 256) {
-        const int pix = idx / CH4, c4 = idx - pix * CH4;
-        const int q = in_lo + pix;
-        const float *src;
-        if (a.gather_ix) {
-            const int b = q / HWin;
-            src = a.in + (size_t)a.gather_ix[b] * a.slot_stride + (size_t)q * CIN;
-        } else {
-            src = a.in + (size_t)q * CIN;
-        }
-        *reinterpret_cast<float4 *>(sA + (size_t)pix * PS + c4 * 4) = *reinterpret_cast<const float4 *>(src + c4 * 4);
-    }
+    // ---- stage the input halo (a contiguous pixel range of the NHWC tensor, optionally gathered per root from
+    // a pool) and the 16-channel weight slice.  Loads are issued in batches of 8 per thread so that the whole
+    // tile is in flight after 2-3 round trips instead of one round trip per 16 bytes.
     {
+        const int nA = npix * CH4, nB = 9 * 16 * CH4, nTot = nA + nB;
         const float *wsrc = a.w + (size_t)blockIdx.y * 9 * 16 * CIN;
-        for (int idx = tid; idx < 9 * 16 * CH4; idx += 256) {
-            const int row = idx / CH4, c4 = idx - row * CH4;
-            *reinterpret_cast<float4 *>(sB + (size_t)row * PS + c4 * 4) =
-                *reinterpret_cast<const float4 *>(wsrc + (size_t)row * CIN + c4 * 4);
+        constexpr int UB = 8;
+        for (int base0 = 0; base0 < nTot; base0 += UB * 256) {
+            float4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base0 + u * 256 + tid;
+                v[u] = vzero4();
+                if (idx < nA) {
+                    const int pix = idx / CH4, c4 = idx - pix * CH4;
+                    const int q = in_lo + pix;
+                    const float *src = a.in + (size_t)q * CIN + c4 * 4;
+                    if (a.gather_ix) src += (size_t)a.gather_ix[q / HWin] * a.slot_stride;
+                    v[u] = *reinterpret_cast<const float4 *>(src);
+                } else if (idx < nTot) {
+                    const int j = idx - nA;
+                    v[u] = *reinterpret_cast<const float4 *>(wsrc + (size_t)j * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base0 + u * 256 + tid;
+                if (idx < nA) {
+                    const int pix = idx / CH4, c4 = idx - pix * CH4;
+                    *reinterpret_cast<float4 *>(sA + (size_t)pix * PS + c4 * 4) = v[u];
+                } else if (idx < nTot) {
+                    const int j = idx - nA, row = j / CH4, c4 = j - row * CH4;
+                    *reinterpret_cast<float4 *>(sB + (size_t)row * PS + c4 * 4) = v[u];
+                }
+            }
         }
+        if (tid < CH4) *reinterpret_cast<float4 *>(sA + (size_t)npix_max * PS + tid * 4) = vzero4();
     }
-    // ---- per-lane geometry of its row in each of the 9 M-tiles
+    // ---- per-lane geometry of its row in each of the 9 M-tiles: LDS offset of the centre tap and a 9-bit
+    // mask of the taps that fall inside the image (masked taps read the all-zero pixel)
+    const int zoff = npix_max * PS;
     int base[MT], mask[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + i * 16 + (lane & 15);
-        int mk = 0, bs = 0;
-        if (m <= m1) {
-            const int b = m / HWout, p = m - b * HWout, y = p / a.Wout, x = p - y * a.Wout;
-            const int cy = STRIDE * y, cx = STRIDE * x;
-            bs = ((b * a.Hin + cy) * a.Win + cx - in_lo) * PS;
+        const int mm = min(m, m1);
+        const int b = mm / HWout, p = mm - b * HWout, y = p / a.Wout, x = p - y * a.Wout;
+        const int cy = STRIDE * y, cx = STRIDE * x;
+        int mk = 0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
-                if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) mk |= 1 << t;
-            }
+        for (int t = 0; t < 9; ++t) {
+            const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+            const int ok = (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win) & (m <= m1);
+            mk |= ok << t;
         }
+        int bs = ((b * a.Hin + cy) * a.Win + cx - in_lo) * PS;
+        // keep the tap mask an opaque integer: otherwise the compiler turns it into 81 separate lane-mask
+        // predicates that spill out of the SGPR file
+        asm volatile("" : "+v"(mk), "+v"(bs));
         base[i] = bs;
         mask[i] = mk;
     }
     __syncthreads();
 
-    // ---- K loop: wave wv owns channel group wv (16 or 8 channels) of every tap
+    // ---- K loop: wave wv owns channel group wv (16 or 8 channels) of every tap.  Operand fragments of tap t+1
+    // are fetched while the MFMAs of tap t issue; consecutive MFMAs go to different accumulators.
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int coff = wv * 4 * VEC + (lane >> 4) * VEC;
     const float *sBl = sB + (size_t)(lane & 15) * PS + coff;
     const float *sAl = sA + coff;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    vec_t af[2][MT], bf[2];
+    auto fetch = [&](int t, int buf) {
         const int toff = ((t / 3 - 1) * a.Win + (t % 3 - 1)) * PS;
-        const vec_t bf = *reinterpret_cast<const vec_t *>(sBl + (size_t)t * 16 * PS);
+        bf[buf] = *reinterpret_cast<const vec_t *>(sBl + (size_t)t * 16 * PS);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const bool v = (mask[i] >> t) & 1;
-            const int off = v ? base[i] + toff : 0;
-            vec_t af = *reinterpret_cast<const vec_t *>(sAl + off);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float av = v ? vget(af, j) : 0.0f;
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vget(bf, j), acc[i], 0, 0, 0);
-            }
+            const int bit = (mask[i] >> t) & 1;
+            const int off = zoff + bit * (base[i] + toff - zoff);
+            af[buf][i] = *reinterpret_cast<const vec_t *>(sAl + off);
         }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < 9) fetch(t + 1, cur ^ 1);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[cur][i], j), vget(bf[cur], j), acc[i], 0, 0, 0);
     }
     // ---- cross-wave (split-K) reduction through LDS, fused epilogue
+    const int l = tid & 63, r = tid >> 6;
+    const int col = l & 15, row_in_tile = 4 * (l >> 4) + r;  // C/D layout of mfma_f32_16x16x4
+    const int co = n0 + col;
+    const float sc = a.scale[co], sh = a.shift[co];
+    float extra[MT];  // action-table and residual terms, fetched before the barrier so their latency overlaps it
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = min(m0 + i * 16 + row_in_tile, m1);
+        const int b = m / HWout, p = m - b * HWout;
+        float tab = 0.0f, res = 0.0f;
+        if (a.act_table) tab = a.act_table[((size_t)a.action[b] * HWout + p) * a.Cout + co];
+        if (a.residual) {
+            const float *rp = a.residual;
+            if (a.residual_gather) rp += (size_t)a.gather_ix[b] * a.slot_stride;
+            res = rp[(size_t)m * a.Cout + co];
+        }
+        extra[i] = tab * sc + res;  // (v + tab)*sc + sh + res  ==  v*sc + (tab*sc + res) + sh  up to rounding
+    }
     __syncthreads();
     float *red = smem;  // [4][MT][4][64]
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wv * MT + i) * 4 + r) * 64 + lane] = acc[i][r];
+        for (int q = 0; q < 4; ++q) red[((wv * MT + i) * 4 + q) * 64 + lane] = acc[i][q];
     __syncthreads();
-    const int l = tid & 63, r = tid >> 6;
-    const int col = l & 15, row_in_tile = 4 * (l >> 4) + r;  // C/D layout of mfma_f32_16x16x4
-    const int co = n0 + col;
-    const float sc = a.scale[co], sh = a.shift[co];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + i * 16 + row_in_tile;
         if (m > m1) continue;
         float v = red[((0 * MT + i) * 4 + r) * 64 + l] + red[((1 * MT + i) * 4 + r) * 64 + l] +
                   red[((2 * MT + i) * 4 + r) * 64 + l] + red[((3 * MT + i) * 4 + r) * 64 + l];
-        const int b = m / HWout, p = m - b * HWout;
-        if (a.act_table) v += a.act_table[((size_t)a.action[b] * HWout + p) * a.Cout + co];
-        v = v * sc + sh;
-        if (a.residual) {
-            const float *rp = a.residual;
-            if (a.residual_gather) rp += (size_t)a.gather_ix[b] * a.slot_stride;
-            v += rp[(size_t)m * a.Cout + co];
-        }
+        v = v * sc + sh + extra[i];
         if (a.relu) v = fmaxf(v, 0.0f);
         a.out[(size_t)m * a.Cout + co] = v;
     }
@@ -226,31 +262,214 @@ __global__ __launch_bounds__(256) void k_avgpool(const float *__restrict__ in, f
     *reinterpret_cast<float4 *>(out + (size_t)pix * C + c4 * 4) = s;
 }
 
-// conv1x1 + bias + BN + ReLU, NHWC; block = 256 threads handles 64 pixels x Cout (<= 32) outputs
-template <int CIN>
-__global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ in, const float *__restrict__ w,
-                                                 const float *__restrict__ bias, const float *__restrict__ scale,
-                                                 const float *__restrict__ shift, float *__restrict__ out, int npix,
-                                                 int Cout)
+// conv1x1 (64 -> 16) + bias + BN + ReLU as a small MFMA GEMM: 144 pixels x 16 channels per workgroup, the 4
+// waves split K = 64 into 16-channel groups (one operand fetch + 4 MFMAs per tile per wave).
+__global__ __launch_bounds__(256) void k_conv1x1(lz_c1_args a)
 {
-    __shared__ float sw[32 * (CIN + 1)];
-    __shared__ float sx[64 * (CIN + 1)];
-    for (int i = threadIdx.x; i < Cout * CIN; i += 256) sw[(i / CIN) * (CIN + 1) + i % CIN] = w[i];
-    const int p0 = blockIdx.x * 64;
-    for (int i = threadIdx.x; i < 64 * CIN; i += 256) {
-        const int p = p0 + i / CIN;
-        sx[(i / CIN) * (CIN + 1) + i % CIN] = p < npix ? in[(size_t)p * CIN + i % CIN] : 0.0f;
+    constexpr int CIN = 64, PS = CIN + 4, MT = 9, TM = 144;
+    __shared__ __attribute__((aligned(16))) float smem[(TM + 16) * PS];  // A [144][68] + W [16][68]; reused for the reduction
+    const lz_c1_job &jb = a.job[blockIdx.y];
+    float *sA = smem, *sB = smem + TM * PS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * TM, m1 = min(m0 + TM, a.npix) - 1;
+    {
+        float4 v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int idx = u * 256 + tid;
+            v[u] = vzero4();
+            if (idx < TM * 16) {
+                const int pix = idx >> 4, c4 = idx & 15;
+                if (m0 + pix <= m1) v[u] = *reinterpret_cast<const float4 *>(jb.in + (size_t)(m0 + pix) * CIN + c4 * 4);
+            } else if (idx < (TM + 16) * 16) {
+                v[u] = *reinterpret_cast<const float4 *>(jb.w + (size_t)(idx - TM * 16) * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int idx = u * 256 + tid;
+            if (idx < (TM + 16) * 16) *reinterpret_cast<float4 *>(smem + (size_t)(idx >> 4) * PS + (idx & 15) * 4) = v[u];
+        }
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < 64 * Cout; o += 256) {
-        const int pl = o / Cout, co = o - pl * Cout;
-        if (p0 + pl >= npix) continue;
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int c = 0; c < CIN; ++c) acc += sx[pl * (CIN + 1) + c] * sw[co * (CIN + 1) + c];
-        acc += bias[co];
-        acc = acc * scale[co] + shift[co];
-        out[(size_t)(p0 + pl) * Cout + co] = fmaxf(acc, 0.0f);
+    const int coff = wv * 16 + (lane >> 4) * 4;
+    const float4 bf = *reinterpret_cast<const float4 *>(sB + (lane & 15) * PS + coff);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const float4 af = *reinterpret_cast<const float4 *>(sA + (i * 16 + (lane & 15)) * PS + coff);
+        acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af, j), vget(bf, j), acc[i], 0, 0, 0);
+    }
+    __syncthreads();
+    float *red = smem;  // [4][MT][4][64] = 9216 floats <= (144+16)*68
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[((wv * MT + i) * 4 + q) * 64 + lane] = acc[i][q];
+    __syncthreads();
+    const int l = tid & 63, r = tid >> 6, col = l & 15, row_in_tile = 4 * (l >> 4) + r;
+    const float bi = jb.bias[col], sc = jb.scale[col], sh = jb.shift[col];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + i * 16 + row_in_tile;
+        if (m > m1) continue;
+        float v = red[((0 * MT + i) * 4 + r) * 64 + l] + red[((1 * MT + i) * 4 + r) * 64 + l] +
+                  red[((2 * MT + i) * 4 + r) * 64 + l] + red[((3 * MT + i) * 4 + r) * 64 + l];
+        v = (v + bi) * sc + sh;
+        jb.out[(size_t)m * jb.out_stride + jb.out_off + col] = fmaxf(v, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Convolution chain on the 6x6 latent: one workgroup per root, wave w owns output channels [16w, 16w+16) of every
+// layer (3 M-tiles of 16 pixels, the last 12 rows are padding), K = 9 taps x 64 channels = 36 steps of 12 MFMAs.
+// Activations ping-pong between four LDS buffers; weight fragments come straight from L2 into registers, four
+// steps ahead.  432 MFMAs per wave per layer = 5.8 us at the fp32-matrix issue rate.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
+{
+    constexpr int PS = 68, HW = 36, BUF = (HW + 1) * PS;  // 36 pixels + one all-zero pixel
+    __shared__ __attribute__((aligned(16))) float smem[4 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x;
+    {
+        const float *src = a.in + (size_t)b * HW * 64;
+        if (a.gather_ix) src += (size_t)a.gather_ix[b] * a.slot_stride;
+        float4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int idx = u * 256 + tid;
+            v[u] = vzero4();
+            if (idx < HW * 16) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int idx = u * 256 + tid;
+            if (idx < HW * 16) *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
+        }
+        if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
+    }
+    // geometry of this lane's row in each of the 3 M-tiles (the same for every layer)
+    const int zoff = HW * PS;
+    int base[3], mask[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int row = i * 16 + (lane & 15);
+        const int p = min(row, HW - 1), y = p / 6, x = p - y * 6;
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            mk |= ((iy >= 0) & (iy < 6) & (ix >= 0) & (ix < 6) & (row < HW)) << t;
+        }
+        int bs = p * PS;
+        asm volatile("" : "+v"(mk), "+v"(bs));
+        base[i] = bs;
+        mask[i] = mk;
+    }
+    const int kq4 = (lane >> 4) * 4;
+    __syncthreads();
+
+    // Weight fragments are requested R = 12 steps (~4.6k MFMA cycles) before use into a register ring, across layer
+    // boundaries (the next layer's first fragments are in flight during this layer's epilogue and barrier); the
+    // A fragments of step s+1 are read from LDS before the MFMAs of step s issue.  sched_barrier pins that order
+    // (left alone, the scheduler sinks the prefetches next to their uses and exposes the L2 latency).
+    constexpr int R = 12;
+    float4 wq[R];
+    {
+        const float4 *w0 = reinterpret_cast<const float4 *>(a.layer[0].wf) + (size_t)wv * 36 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < R; ++s) wq[s] = w0[s * 64];
+    }
+    auto fetch_a = [&](const float *sIn, int s, float4 (&af)[3]) {
+        const int t = s >> 2, g = s & 3;
+        const int toff = ((t / 3 - 1) * 6 + (t % 3 - 1)) * PS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int bit = (mask[i] >> t) & 1;
+            const int off = zoff + bit * (base[i] + toff - zoff);
+            af[i] = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+        }
+    };
+    for (int L = 0; L < a.nlayers; ++L) {
+        const lz_chain_layer &ly = a.layer[L];
+        const float *sIn = smem + ly.in * BUF + kq4;
+        float *sOut = smem + ly.out * BUF;
+        const bool more = L + 1 < a.nlayers;
+        const float4 *wc = reinterpret_cast<const float4 *>(ly.wf) + (size_t)wv * 36 * 64 + lane;
+        const float4 *wn = reinterpret_cast<const float4 *>(a.layer[more ? L + 1 : L].wf) + (size_t)wv * 36 * 64 + lane;
+        f32x4 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 af[2][3];
+        fetch_a(sIn, 0, af[0]);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            const float4 bfr = wq[s % R];
+            wq[s % R] = (s + R < 36) ? wc[(s + R) * 64] : wn[(s + R - 36) * 64];
+            if (s + 1 < 36) fetch_a(sIn, s + 1, af[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: BN (+ action table) (+ residual) (+ ReLU) -> LDS (and the latent pool)
+        const int col = wv * 16 + (lane & 15);
+        const float sc = ly.scale[col], sh = ly.shift[col];
+        const float *tab = ly.act ? a.act_table + (size_t)a.action[b] * HW * 64 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = i * 16 + 4 * (lane >> 4) + q;
+                if (row < HW) {
+                    float v = acc[i][q];
+                    if (tab) v += tab[row * 64 + col];
+                    v = v * sc + sh;
+                    if (ly.res >= 0) v += smem[ly.res * BUF + row * PS + col];
+                    if (ly.relu) v = fmaxf(v, 0.0f);
+                    sOut[row * PS + col] = v;
+                    if (ly.gout) ly.gout[((size_t)b * HW + row) * 64 + col] = v;
+                }
+            }
+        __syncthreads();
+    }
+    // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU: wave j runs job j
+    if (wv < a.nc1) {
+        const lz_c1_job &jb = a.c1[wv];
+        const float *sIn = smem + a.c1_in[wv] * BUF + kq4;
+        f32x4 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bfr = *reinterpret_cast<const float4 *>(jb.w + (size_t)(lane & 15) * 64 + g * 16 + kq4);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int row = i * 16 + (lane & 15);
+                const int off = (row < HW) ? row * PS : zoff;
+                const float4 af = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af, j), vget(bfr, j), acc[i], 0, 0, 0);
+            }
+        }
+        const int col = lane & 15;
+        const float bi = jb.bias[col], sc = jb.scale[col], sh = jb.shift[col];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = i * 16 + 4 * (lane >> 4) + q;
+                if (row < HW) {
+                    const float v = (acc[i][q] + bi) * sc + sh;
+                    jb.out[((size_t)b * HW + row) * jb.out_stride + jb.out_off + col] = fmaxf(v, 0.0f);
+                }
+            }
     }
 }
 
@@ -381,22 +600,32 @@ constexpr int EPB = 4;
 constexpr int MAXH = 4;
 struct head_pack { lz_head_desc h[MAXH]; };
 
-__device__ __forceinline__ float block_reduce(float v, float *scratch, bool is_max)
+// block-wide reduction of N values per thread (max or sum); result broadcast to every thread
+template <int N, bool IS_MAX>
+__device__ __forceinline__ void block_reduce_n(float (&v)[N], float *scratch)
 {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const float t = __shfl_xor(v, o);
-        v = is_max ? fmaxf(v, t) : v + t;
-    }
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float t = __shfl_xor(v[k], o);
+            v[k] = IS_MAX ? fmaxf(v[k], t) : v[k] + t;
+        }
     const int wv = threadIdx.x >> 6;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[wv] = v;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < N; ++k) scratch[wv * N + k] = v[k];
     __syncthreads();
-    const float a0 = scratch[0], a1 = scratch[1], a2 = scratch[2], a3 = scratch[3];
-    return is_max ? fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) : (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float a0 = scratch[k], a1 = scratch[N + k], a2 = scratch[2 * N + k], a3 = scratch[3 * N + k];
+        v[k] = IS_MAX ? fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) : (a0 + a1) + (a2 + a3);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_heads(head_pack hp, int B, int HW, int C, int HC, int HID)
+template <int HID>
+__global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const lz_head_desc &h = hp.h[blockIdx.y];
@@ -405,34 +634,15 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B, int HW, int 
     const int K1 = h.K1;
     float *xs = smem;                    // [EPB][K1]
     float *hid = xs + EPB * K1;          // [EPB][HID]
-    float *scr = hid + EPB * HID;        // [8]
-    float *lat = scr + 8;                // [EPB][HW][C+1] (conv heads only)
-    if (h.has_conv) {
-        const int CP = C + 1;
-        for (int i = tid; i < EPB * HW * C; i += 256) {
-            const int e = i / (HW * C), rem = i - e * HW * C;
-            const int b = b0 + e;
-            lat[(e * HW + rem / C) * CP + rem % C] = b < B ? h.in[(size_t)b * HW * C + rem] : 0.0f;
-        }
-        __syncthreads();
-        for (int o = tid; o < EPB * HW * HC; o += 256) {
-            const int e = o / (HW * HC), rem = o - e * HW * HC, p = rem / HC, co = rem - p * HC;
-            const float *lp = lat + (e * HW + p) * CP;
-            const float *wr = h.cw + (size_t)co * C;
-            float acc = 0.0f;
-            for (int c = 0; c < C; ++c) acc += lp[c] * wr[c];
-            acc += h.cb[co];
-            acc = acc * h.cscale[co] + h.cshift[co];
-            xs[e * K1 + rem] = fmaxf(acc, 0.0f);  // K1 index = pixel*HC + channel
-        }
-    } else {
-        for (int i = tid; i < EPB * K1; i += 256) {
-            const int e = i / K1, b = b0 + e;
-            xs[i] = b < B ? h.in[(size_t)b * K1 + (i - e * K1)] : 0.0f;
-        }
+    float *scr = hid + EPB * HID;        // [4 * 8]
+    for (int i = tid; i < EPB * (K1 / 4); i += 256) {  // 16-channel runs are contiguous: float4 loads
+        const int e = i / (K1 / 4), k = (i - e * (K1 / 4)) * 4, b = b0 + e;
+        float4 v = vzero4();
+        if (b < B) v = *reinterpret_cast<const float4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
+        *reinterpret_cast<float4 *>(xs + e * K1 + k) = v;
     }
     __syncthreads();
-    // ---- layer 1: HID(=32) units x 8 K-parts, float4 weight fetches (128 B contiguous per unit)
+    // ---- layer 1: HID units x 8 K-parts; a unit's row is read 128 B at a time by its 8 lanes
     {
         const int u = tid >> 3, part = tid & 7;
         float acc[EPB];
@@ -440,6 +650,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B, int HW, int 
         for (int e = 0; e < EPB; ++e) acc[e] = 0.0f;
         if (u < HID) {
             const float *wr = h.w1 + (size_t)u * K1;
+#pragma unroll 6
             for (int k = part * 4; k < K1; k += 32) {
                 const float4 wv4 = *reinterpret_cast<const float4 *>(wr + k);
 #pragma unroll
@@ -461,65 +672,69 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B, int HW, int 
         }
     }
     __syncthreads();
-    // ---- layer 2 (+ softmax expectation over the support, + h^-1)
+    // ---- layer 2 on the transposed weights: lane n reads w2t[k][n], fully coalesced
     constexpr int NPT = 3;  // outputs per thread: NOUT <= 768
     float lg[NPT][EPB];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int n = tid + i * 256;
+        const bool ok = n < h.NOUT;
+        float acc[EPB];
+        const float bias = ok ? h.b2[n] : 0.0f;
 #pragma unroll
-        for (int e = 0; e < EPB; ++e) lg[i][e] = -__builtin_inff();
-        if (n < h.NOUT) {
-            const float *wr = h.w2 + (size_t)n * HID;
-            float acc[EPB];
+        for (int e = 0; e < EPB; ++e) acc[e] = bias;
+        if (ok) {
+#pragma unroll 8
+            for (int k = 0; k < HID; ++k) {
+                const float wv = h.w2t[(size_t)k * h.NOUT + n];
 #pragma unroll
-            for (int e = 0; e < EPB; ++e) acc[e] = 0.0f;
-            for (int k = 0; k < HID; k += 4) {
-                const float4 wv4 = *reinterpret_cast<const float4 *>(wr + k);
-#pragma unroll
-                for (int e = 0; e < EPB; ++e) {
-                    const float4 hv = *reinterpret_cast<const float4 *>(hid + e * HID + k);
-                    acc[e] += wv4.x * hv.x + wv4.y * hv.y + wv4.z * hv.z + wv4.w * hv.w;
-                }
+                for (int e = 0; e < EPB; ++e) acc[e] += wv * hid[e * HID + k];
             }
+        }
 #pragma unroll
-            for (int e = 0; e < EPB; ++e) {
-                lg[i][e] = acc[e] + h.b2[n];
-                if (h.out_logits && b0 + e < B) h.out_logits[(size_t)(b0 + e) * h.NOUT + n] = lg[i][e];
-            }
+        for (int e = 0; e < EPB; ++e) {
+            lg[i][e] = ok ? acc[e] : -__builtin_inff();
+            if (ok && h.out_logits && b0 + e < B) h.out_logits[(size_t)(b0 + e) * h.NOUT + n] = acc[e];
         }
     }
     if (!h.categorical) return;
+    float m[EPB];
+#pragma unroll
+    for (int e = 0; e < EPB; ++e) m[e] = fmaxf(fmaxf(lg[0][e], lg[1][e]), lg[2][e]);
+    block_reduce_n<EPB, true>(m, scr);
+    float ss[2 * EPB];
 #pragma unroll
     for (int e = 0; e < EPB; ++e) {
-        float m = fmaxf(fmaxf(lg[0][e], lg[1][e]), lg[2][e]);
-        m = block_reduce(m, scr, true);
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int n = tid + i * 256;
             if (n < h.NOUT) {
-                const float ex = expf(lg[i][e] - m);
+                const float ex = expf(lg[i][e] - m[e]);
                 s0 += ex;
                 s1 += ex * (h.support_min + (float)n);
             }
         }
-        s0 = block_reduce(s0, scr, false);
-        s1 = block_reduce(s1, scr, false);
-        if (tid == 0 && b0 + e < B) {
-            // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
-            const float value = s1 / s0;
-            const float eps = 0.001f;
-            float t = fabsf(value) + 1.0f;
-            t = t + eps;
-            t = 0.004f * t;
-            t = 1.0f + t;
-            t = sqrtf(t);
-            t = t - 1.0f;
-            t = t / 0.002f;
-            const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
-            h.out_scalar[b0 + e] = sgn * (t * t - 1.0f);
-        }
+        ss[2 * e] = s0;
+        ss[2 * e + 1] = s1;
+    }
+    block_reduce_n<2 * EPB, false>(ss, scr);
+    if (tid < EPB && b0 + tid < B) {
+        // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
+        float s0 = ss[0], s1 = ss[1];
+#pragma unroll
+        for (int e = 1; e < EPB; ++e) if (tid == e) { s0 = ss[2 * e]; s1 = ss[2 * e + 1]; }
+        const float value = s1 / s0;
+        const float eps = 0.001f;
+        float t = fabsf(value) + 1.0f;
+        t = t + eps;
+        t = 0.004f * t;
+        t = 1.0f + t;
+        t = sqrtf(t);
+        t = t - 1.0f;
+        t = t / 0.002f;
+        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
+        h.out_scalar[b0 + tid] = sgn * (t * t - 1.0f);
     }
 }
 
@@ -540,7 +755,7 @@ void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s
     int npix = conv_npix_max(a, stride);
     npix = min(npix, a.B * a.Hin * a.Win);
     const int ps = cin + 4;
-    size_t lds = ((size_t)npix * ps + (size_t)9 * 16 * ps) * 4;
+    size_t lds = ((size_t)(npix + 1) * ps + (size_t)9 * 16 * ps) * 4;
     const size_t red = (size_t)4 * 9 * 4 * 64 * 4;
     if (lds < red) lds = red;
     dim3 grid((M + 143) / 144, a.Cout / 16), block(256);
@@ -568,11 +783,14 @@ void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, Hin, Win, C);
 }
 
-void lz_launch_conv1x1(const float *in, const float *w, const float *bias, const float *scale, const float *shift,
-                       float *out, int B, int HW, int CIN, int Cout, hipStream_t s)
+void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 {
-    const int npix = B * HW;
-    if (CIN == 64) hipLaunchKernelGGL((k_conv1x1<64>), dim3((npix + 63) / 64), dim3(256), 0, s, in, w, bias, scale, shift, out, npix, Cout);
+    hipLaunchKernelGGL(k_conv1x1, dim3((a.npix + 143) / 144, a.njobs), dim3(256), 0, s, a);
+}
+
+void lz_launch_chain(const lz_chain_args &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_chain, dim3(a.B), dim3(256), 0, s, a);
 }
 
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
@@ -582,16 +800,14 @@ void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
     hipLaunchKernelGGL(k_lstm, grid, block, lds, s, a);
 }
 
-void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HW, int C, int HC, int HID, hipStream_t s)
+void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s)
 {
     head_pack hp;
     int k1max = 0;
-    bool conv = false;
     for (int i = 0; i < nheads && i < MAXH; ++i) {
         hp.h[i] = heads[i];
         if (heads[i].K1 > k1max) k1max = heads[i].K1;
-        conv |= heads[i].has_conv != 0;
     }
-    size_t lds = ((size_t)EPB * k1max + (size_t)EPB * HID + 8 + (conv ? (size_t)EPB * HW * (C + 1) : 0)) * 4;
-    hipLaunchKernelGGL(k_heads, dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B, HW, C, HC, HID);
+    const size_t lds = ((size_t)EPB * k1max + (size_t)EPB * HID + 32) * 4;
+    if (HID == 32) hipLaunchKernelGGL((k_heads<32>), dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B);
 }

@@ -33,9 +33,46 @@ void lz_launch_conv_first(const float *obs_nchw, const float *w /*[9][C][Cout]*/
 // AvgPool2d(kernel 3, stride 2, pad 1, count_include_pad) on NHWC
 void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s);
 
-// conv1x1 (CIN -> Cout<=32) + BN + ReLU on NHWC [B][HW][CIN] -> [B][HW][Cout]
-void lz_launch_conv1x1(const float *in, const float *w /*[Cout][CIN]*/, const float *bias, const float *scale,
-                       const float *shift, float *out, int B, int HW, int CIN, int Cout, hipStream_t s);
+// conv1x1 (64 -> 16 channels per job) + bias + BN + ReLU on NHWC [npix][64] as a small MFMA GEMM; up to 4
+// independent jobs (e.g. reward / value / policy head convolutions) share one launch (blockIdx.y = job).
+struct lz_c1_job {
+    const float *in;      // [npix][64]
+    const float *w;       // [16][64]
+    const float *bias, *scale, *shift;  // [16]
+    float *out;           // out[pix * out_stride + out_off + c]
+    int out_stride, out_off;
+};
+struct lz_c1_args {
+    lz_c1_job job[4];
+    int njobs, npix;
+};
+void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s);
+
+// Chain of 3x3 convolutions on a 6x6x64 latent, one workgroup per root, activations resident in LDS across
+// layers (no HBM round trip, no kernel boundary between layers), weights streamed from L2 in MFMA-fragment order.
+// Used for the recurrent step (dynamics conv + residual block + prediction residual block + the 1x1 head convs)
+// and for the tail of the representation network.
+struct lz_chain_layer {
+    const float *wf;       // fragment-packed weights [4][9][4][64][4]  (N-tile, tap, 16-channel group, lane, 4 floats)
+    const float *scale, *shift;  // [64] folded BatchNorm
+    int in, out, res;      // LDS buffer indices (0..3); res < 0: no residual
+    int relu, act;         // act: add the one-hot-action table before BN (dynamics conv)
+    float *gout;           // optional global NHWC [B][36][64] copy of the output (latent pool slot)
+};
+struct lz_chain_args {
+    const float *in;             // NHWC [B][36][64], or a pool base when gather_ix != null
+    const int32_t *gather_ix;    // optional [B] pool slot per root
+    int64_t slot_stride;
+    const float *act_table;      // [A][36][64]
+    const int32_t *action;       // [B]
+    lz_chain_layer layer[6];
+    int nlayers;
+    lz_c1_job c1[3];             // 1x1 head convolutions on LDS buffers c1_in[j]; .in is ignored
+    int c1_in[3];
+    int nc1;
+    int B;
+};
+void lz_launch_chain(const lz_chain_args &a, hipStream_t s);
 
 // one LSTM step (nn.LSTM, 1 layer) fused with BatchNorm1d + ReLU of the output:
 //   gates = [x | h] . Wcat^T + bias ; c' = sig(f) c + sig(i) tanh(g) ; h' = sig(o) tanh(c')
@@ -54,17 +91,17 @@ struct lz_lstm_args {
 };
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s);
 
-// prediction / reward heads: (conv1x1 + BN + ReLU) -> Linear + BN + ReLU -> Linear [-> softmax.support -> h^-1]
+// heads: Linear + BN + ReLU -> Linear [-> softmax.support -> h^-1].  Input element k of root b is read at
+//   in[b * env_stride + (k / 16) * pix_stride + k % 16]   (k = pixel*16 + channel for the conv heads).
 struct lz_head_desc {
-    const float *in;       // conv head: NHWC latent [B][HW][C];  vector head: [B][K1]
-    int has_conv;          // 1: conv1x1 C -> HC first
-    const float *cw, *cb, *cscale, *cshift;  // conv1x1 [HC][C], bias, folded BN
-    const float *w1, *b1, *s1, *t1;  // Linear [HID][K1] (K1 index = pixel*HC + channel), bias, folded BN1d
-    const float *w2, *b2;            // Linear [NOUT][HID]
+    const float *in;
+    int env_stride, pix_stride;
+    const float *w1, *b1, *s1, *t1;  // Linear [HID][K1], bias, folded BN1d
+    const float *w2t, *b2;           // Linear transposed [HID][NOUT], bias [NOUT]
     int K1, NOUT;
     int categorical;       // 1: softmax . support -> inverse scalar transform -> out_scalar[B]
     float support_min;     // support = support_min + k (step 1)
     float *out_logits;     // optional [B][NOUT]
     float *out_scalar;     // [B] (categorical)
 };
-void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HW, int C, int HC, int HID, hipStream_t s);
+void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s);

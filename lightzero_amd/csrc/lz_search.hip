@@ -24,10 +24,11 @@ struct HostTensor {
 
 struct ConvW {
     float *w = nullptr, *scale = nullptr, *shift = nullptr;
+    float *wf = nullptr;  // MFMA-fragment order [cout/16][9][cin/16][64 lanes][4] for the LDS-resident conv chain
     int cin = 0, cout = 0;
 };
 struct MlpW {
-    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* transposed [HID][NOUT] */, *b2 = nullptr;
     int K1 = 0, NOUT = 0;
 };
 struct C1W {
@@ -156,6 +157,18 @@ struct Builder {
         c.w = upload(p);
         c.scale = upload(sc);
         c.shift = upload(sh);
+        if (cin == 64 && cout == 64) {
+            std::vector<float> f((size_t)cout * 9 * cin);
+            for (int nt = 0; nt < cout / 16; ++nt)
+                for (int t = 0; t < 9; ++t)
+                    for (int g = 0; g < cin / 16; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = lane & 15, kq = lane >> 4, ci = g * 16 + kq * 4 + j, co = nt * 16 + n;
+                                f[((((size_t)nt * 9 + t) * (cin / 16) + g) * 64 + lane) * 4 + j] = w->data[(((size_t)co * cin_total + ci) * 9) + t];
+                            }
+            c.wf = upload(f);
+        }
         return c;
     }
     ConvW resconv(const std::string &prefix, int idx, int cout, int cin)  // ding ResBlock convN = Sequential(conv, bn[, act])
@@ -198,7 +211,10 @@ struct Builder {
         o.b1 = upload(b1->data);
         o.s1 = upload(sc);
         o.t1 = upload(sh);
-        o.w2 = upload(w2->data);
+        std::vector<float> w2t((size_t)HID * NOUT);
+        for (int n = 0; n < NOUT; ++n)
+            for (int k = 0; k < HID; ++k) w2t[(size_t)k * NOUT + n] = w2->data[(size_t)n * HID + k];
+        o.w2 = upload(w2t);
         o.b2 = upload(b2->data);
         return o;
     }
@@ -327,7 +343,7 @@ static int ensure_pools(lz_roots *r)
     const size_t o_lat = take(NN * B * HW * C * 4), o_h = take(NN * B * H * 4), o_c = take(NN * B * H * 4),
                  o_vp = take(NN * B * 4), o_val = take(NN * B * 4), o_lg = take(NN * B * A * 4),
                  o_x1 = take(B * HW * C * 4), o_x2 = take(B * HW * C * 4), o_x3 = take(B * HW * C * 4),
-                 o_rx = take(B * HW * HC * 4), o_hbn = take(B * H * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
+                 o_rx = take(B * HW * HC * 4), o_pv = take(B * HW * 2 * HC * 4), o_hbn = take(B * H * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
                  o_tr = take(NN * 5 * B * 4), o_tp = take(B * 4), o_z = take(B * 4), o_nz = take(B * A * 4), o_no = take(B * 4);
     hipError_t err = hipMalloc(&r->pool_slab, off);
     if (err != hipSuccess) {
@@ -338,7 +354,7 @@ static int ensure_pools(lz_roots *r)
     r->latent_pool = (float *)(base + o_lat); r->h_pool = (float *)(base + o_h); r->c_pool = (float *)(base + o_c);
     r->sim_vp = (float *)(base + o_vp); r->sim_value = (float *)(base + o_val); r->sim_logits = (float *)(base + o_lg);
     r->t_x1 = (float *)(base + o_x1); r->t_x2 = (float *)(base + o_x2); r->t_x3 = (float *)(base + o_x3);
-    r->t_rx = (float *)(base + o_rx); r->t_hbn = (float *)(base + o_hbn);
+    r->t_rx = (float *)(base + o_rx); r->t_pv = (float *)(base + o_pv); r->t_hbn = (float *)(base + o_hbn);
     r->dbg_logits[0] = (float *)(base + o_d0); r->dbg_logits[1] = (float *)(base + o_d1);
     r->trace = (int32_t *)(base + o_tr); r->d_to_play = (int32_t *)(base + o_tp); r->d_zero_vp = (float *)(base + o_z);
     r->d_noise = (float *)(base + o_nz); r->d_noise_off = (int32_t *)(base + o_no);
@@ -358,43 +374,68 @@ static int ensure_ws(lz_model *m, int B)
 }
 
 static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
-                 int relu, hipStream_t s, lz_engine *prof = nullptr)
+                 int relu, hipStream_t s)
 {
-    const bool rec = prof && prof->prof_on && 2 * (prof->prof_used + 1) <= prof->prof_ev.size();
-    if (rec) (void)hipEventRecord(prof->prof_ev[2 * prof->prof_used], s);
-    struct Fin { lz_engine *p; bool rec; hipStream_t s; ~Fin() { if (rec) { (void)hipEventRecord(p->prof_ev[2 * p->prof_used + 1], s); p->prof_used++; } } } fin{prof, rec, s};
     lz_conv_args a{};
     a.in = in; a.w = w.w; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
 }
 
-static void prediction(lz_roots *r, const float *latent, float *out_value, float *out_logits, float *dbg_value_logits,
-                       const float *hbn, float *out_vp, float *dbg_vp_logits, hipStream_t s)
+static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu, int act, float *gout)
+{
+    lz_chain_layer l{};
+    l.wf = w.wf; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
+    return l;
+}
+
+static lz_c1_job c1job(const C1W &w, const float *in, float *out, int stride, int off)
+{
+    lz_c1_job j{};
+    j.in = in; j.w = w.w; j.bias = w.b; j.scale = w.s; j.shift = w.t; j.out = out; j.out_stride = stride; j.out_off = off;
+    return j;
+}
+
+static lz_head_desc headdesc(const MlpW &w, const float *in, int env_stride, int pix_stride, int categorical, float support_min,
+                             float *out_logits, float *out_scalar)
+{
+    lz_head_desc h{};
+    h.in = in; h.env_stride = env_stride; h.pix_stride = pix_stride;
+    h.w1 = w.w1; h.b1 = w.b1; h.s1 = w.s1; h.t1 = w.t1; h.w2t = w.w2; h.b2 = w.b2; h.K1 = w.K1; h.NOUT = w.NOUT;
+    h.categorical = categorical; h.support_min = support_min; h.out_logits = out_logits; h.out_scalar = out_scalar;
+    return h;
+}
+
+// the head MLPs (value, policy[, value prefix]) in one launch; inputs are the 1x1-conv outputs t_pv / the LSTM output
+static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_value_logits, bool with_vp, float *out_vp,
+                  float *dbg_vp_logits, hipStream_t s)
 {
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
-    const int B = r->t.B, HW = m->HWl, C = c.num_channels;
-    conv(m->pa, latent, r->t_x2, B, 6, 6, 1, nullptr, 1, s, r->eng);
-    conv(m->pb, r->t_x2, r->t_x3, B, 6, 6, 1, latent, 1, s, r->eng);
+    const int B = r->t.B, HW = m->HWl, HC = c.head_channels;
     lz_head_desc h[3];
-    memset(h, 0, sizeof(h));
     int n = 0;
-    h[n].in = r->t_x3; h[n].has_conv = 1; h[n].cw = m->val_c.w; h[n].cb = m->val_c.b; h[n].cscale = m->val_c.s; h[n].cshift = m->val_c.t;
-    h[n].w1 = m->fc_value.w1; h[n].b1 = m->fc_value.b1; h[n].s1 = m->fc_value.s1; h[n].t1 = m->fc_value.t1; h[n].w2 = m->fc_value.w2; h[n].b2 = m->fc_value.b2;
-    h[n].K1 = m->fc_value.K1; h[n].NOUT = m->fc_value.NOUT; h[n].categorical = 1; h[n].support_min = c.support_min;
-    h[n].out_logits = dbg_value_logits; h[n].out_scalar = out_value; n++;
-    h[n].in = r->t_x3; h[n].has_conv = 1; h[n].cw = m->pol_c.w; h[n].cb = m->pol_c.b; h[n].cscale = m->pol_c.s; h[n].cshift = m->pol_c.t;
-    h[n].w1 = m->fc_policy.w1; h[n].b1 = m->fc_policy.b1; h[n].s1 = m->fc_policy.s1; h[n].t1 = m->fc_policy.t1; h[n].w2 = m->fc_policy.w2; h[n].b2 = m->fc_policy.b2;
-    h[n].K1 = m->fc_policy.K1; h[n].NOUT = m->fc_policy.NOUT; h[n].categorical = 0; h[n].out_logits = out_logits; n++;
-    if (hbn) {
-        h[n].in = hbn; h[n].has_conv = 0;
-        h[n].w1 = m->fc_reward.w1; h[n].b1 = m->fc_reward.b1; h[n].s1 = m->fc_reward.s1; h[n].t1 = m->fc_reward.t1; h[n].w2 = m->fc_reward.w2; h[n].b2 = m->fc_reward.b2;
-        h[n].K1 = m->fc_reward.K1; h[n].NOUT = m->fc_reward.NOUT; h[n].categorical = 1; h[n].support_min = c.support_min;
-        h[n].out_logits = dbg_vp_logits; h[n].out_scalar = out_vp; n++;
-    }
-    lz_launch_heads(h, n, B, HW, C, c.head_channels, c.head_hidden, s);
+    h[n++] = headdesc(m->fc_value, r->t_pv, HW * 2 * HC, 2 * HC, 1, c.support_min, dbg_value_logits, out_value);
+    h[n++] = headdesc(m->fc_policy, r->t_pv + HC, HW * 2 * HC, 2 * HC, 0, 0.f, out_logits, nullptr);
+    if (with_vp) h[n++] = headdesc(m->fc_reward, r->t_hbn, c.lstm_hidden_size, 16, 1, c.support_min, dbg_vp_logits, out_vp);
+    lz_launch_heads(h, n, B, c.head_hidden, s);
 }
+
+// records a HIP-event pair around one launch when in-stream profiling is on (bench.py roofline)
+struct ProfScope {
+    lz_engine *e;
+    hipStream_t s;
+    bool rec;
+    ProfScope(lz_engine *e_, hipStream_t s_) : e(e_), s(s_)
+    {
+        rec = e && e->prof_on && 2 * (e->prof_used + 1) <= e->prof_ev.size();
+        if (rec) (void)hipEventRecord(e->prof_ev[2 * e->prof_used], s);
+    }
+    ~ProfScope()
+    {
+        if (rec) { (void)hipEventRecord(e->prof_ev[2 * e->prof_used + 1], s); e->prof_used++; }
+    }
+};
 
 extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
 {
@@ -439,14 +480,24 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     LZ_STAGE();
     lz_launch_avgpool(w2, w0, B, 12, 12, C, s);               // w0: 6x6x64
     LZ_STAGE();
-    // RepresentationNetwork.resblocks (common.py:775-776) -> latent pool slot 0
-    conv(m->rpa, w0, w1, B, 6, 6, 1, nullptr, 1, s);
-    LZ_STAGE();
-    conv(m->rpb, w1, r->latent_pool, B, 6, 6, 1, w0, 1, s);
 #undef LZ_STAGE
+    // RepresentationNetwork.resblocks (common.py:775-776) -> latent pool slot 0, then the prediction residual block
+    // and the value / policy 1x1 convs, all in one LDS-resident chain launch
+    {
+        lz_chain_args ca{};
+        ca.in = w0; ca.B = B;
+        ca.layer[ca.nlayers++] = chlayer(m->rpa, 0, 1, -1, 1, 0, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(m->rpb, 1, 2, 0, 1, 0, r->latent_pool);
+        ca.layer[ca.nlayers++] = chlayer(m->pa, 2, 3, -1, 1, 0, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(m->pb, 3, 0, 2, 1, 0, nullptr);
+        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = 0;
+        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = 0;
+        ca.nc1 = 2;
+        lz_launch_chain(ca, s);
+    }
     LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * H * 4, s));
     LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
-    prediction(r, r->latent_pool, r->sim_value, r->sim_logits, r->dbg_logits[0], nullptr, nullptr, nullptr, s);
+    heads(r, r->sim_value, r->sim_logits, r->dbg_logits[0], false, nullptr, nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
     r->inferred = true;
     return LZ_OK;
@@ -521,28 +572,36 @@ static void simulate(lz_roots *r, int sim, const lz_traverse_args &ta, float del
     const int slot = sim + 1;
     const size_t lat_slot = B * HW * C;
     lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
-    (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
-    // ---- dynamics (efficientzero_model.py:527-569): conv over [latent | one-hot action] + BN + latent, ReLU
-    lz_conv_args a{};
-    a.in = r->latent_pool; a.gather_ix = t.res_ix; a.slot_stride = (int64_t)lat_slot;
-    a.w = m->dyn.w; a.scale = m->dyn.scale; a.shift = m->dyn.shift; a.act_table = m->act_table; a.action = t.res_last_action;
-    a.residual = r->latent_pool; a.residual_gather = 1; a.out = r->t_x1;
-    a.B = (int)B; a.Hin = a.Win = a.Hout = a.Wout = 6; a.Cout = (int)C; a.relu = 1;
-    lz_launch_conv3x3(a, 64, 1, s);
+    if (r->trace_on) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
+    // ---- dynamics conv over [latent | one-hot action] + BN + latent + ReLU, dynamics residual block (-> latent pool
+    // slot), prediction residual block and the three 1x1 head convs (efficientzero_model.py:527-558, common.py:1189-1203):
+    // ONE launch, activations stay in LDS
     float *next_latent = r->latent_pool + (size_t)slot * lat_slot;
-    conv(m->dra, r->t_x1, r->t_x2, (int)B, 6, 6, 1, nullptr, 1, s, r->eng);
-    conv(m->drb, r->t_x2, next_latent, (int)B, 6, 6, 1, r->t_x1, 1, s, r->eng);
-    // ---- value prefix: conv1x1 + BN + ReLU -> LSTM -> BN1d + ReLU (-> MLP in the heads launch)
-    lz_launch_conv1x1(next_latent, m->rew_c.w, m->rew_c.b, m->rew_c.s, m->rew_c.t, r->t_rx, (int)B, (int)HW, (int)C, c.head_channels, s);
+    {
+        lz_chain_args ca{};
+        ca.in = r->latent_pool; ca.gather_ix = t.res_ix; ca.slot_stride = (int64_t)lat_slot;
+        ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B;
+        ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, 1, 1, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(m->dra, 1, 2, -1, 1, 0, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(m->drb, 2, 3, 1, 1, 0, next_latent);
+        ca.layer[ca.nlayers++] = chlayer(m->pa, 3, 0, -1, 1, 0, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(m->pb, 0, 2, 3, 1, 0, nullptr);
+        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = 2;
+        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = 2;
+        ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = 3;
+        ca.nc1 = 3;
+        ProfScope ps(r->eng, s);
+        lz_launch_chain(ca, s);
+    }
+    // ---- value prefix LSTM (+ BN1d + ReLU), then the three head MLPs with h^-1 fused
     lz_lstm_args l{};
     l.x = r->t_rx; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = m->lstm_w; l.bias = m->lstm_b;
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
     lz_launch_lstm(l, s);
-    // ---- prediction + the three heads, h^-1 fused
-    prediction(r, next_latent, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0],
-               r->t_hbn, r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
+    heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
+          r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
     // ---- expand + backup; is_reset = search_len % horizon == 0 derived on the device
     lz_tree_launch_backprop(t, slot, ta.discount, r->sim_vp + (size_t)slot * B, r->sim_value + (size_t)slot * B,
                             r->sim_logits + (size_t)slot * B * A, nullptr, horizon, nullptr, s);
@@ -574,9 +633,17 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
 }
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int lz_roots_enable_trace(lz_roots *r, int on)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    r->trace_on = on != 0;
+    return LZ_OK;
+}
+
 extern "C" int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out)
 {
     LZ_REQUIRE(r != nullptr && h_out != nullptr && r->trace != nullptr, "no trace");
+    LZ_REQUIRE(r->trace_on, "tracing is off: call lz_roots_enable_trace(roots, 1) before lz_search");
     LZ_REQUIRE(num_simulations >= 1 && num_simulations < r->t.NN, "num_simulations out of range");
     const size_t B = r->t.B;
     std::vector<int32_t> tmp((size_t)num_simulations * 5 * B);

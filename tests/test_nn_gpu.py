@@ -71,6 +71,7 @@ def test_recurrent_inference_matches_torch_teacher_forced():
     rng = np.random.default_rng(0)
     noises = rng.dirichlet([0.3] * A, size=B).astype(np.float32).reshape(-1)
     L.check(lib.lz_roots_prepare_from_inference(roots._h, 0.25, noises.ctypes.data, L.i32([-1] * B)))
+    L.check(lib.lz_roots_enable_trace(roots._h, 1))
     L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
     L.check(lib.lz_engine_synchronize(L.default_engine()))
     trace = np.zeros((S, B, 4), np.int32)
