@@ -111,7 +111,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     const size_t o_edge = take(nBNA * sizeof(float4)), o_child = take(nBNA * 4), o_vp = take(nBN * 4),
                  o_reset = take(nBN * 4), o_tp = take(nBN * 4), o_best = take(nBN * 4), o_rv = take((size_t)B * 4),
                  o_rs = take((size_t)B * 4), o_legal = take((size_t)B * A * 4), o_nl = take((size_t)B * 4),
-                 o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5);
+                 o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5),
+                 o_ep = take(256);
     hipError_t err = hipMalloc(&r->slab, off);
     if (err != hipSuccess) {
         delete r;
@@ -126,6 +127,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.legal = (int32_t *)(base + o_legal); t.n_legal = (int32_t *)(base + o_nl); t.minmax = (float *)(base + o_mm);
     t.path_node = (int32_t *)(base + o_pn); t.path_act = (int32_t *)(base + o_pa);
     int32_t *res = (int32_t *)(base + o_res);
+    t.rng_epoch = (uint32_t *)(base + o_ep);
+    (void)hipMemset(t.rng_epoch, 0, 4);
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
     *out = r;
     return LZ_OK;
@@ -189,6 +192,7 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     (void)hipSetDevice(r->eng->device);
     (void)hipStreamSynchronize(r->eng->stream);
     if (r->slab) (void)hipFree(r->slab);
+    if (r->graph_exec) (void)hipGraphExecDestroy(r->graph_exec);
     if (r->pool_slab) (void)hipFree(r->pool_slab);
     if (r->d_obs) (void)hipFree(r->d_obs);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
@@ -256,6 +260,7 @@ extern "C" int lz_roots_prepare(lz_roots *r, float root_noise_weight, const floa
     lz_tree_launch_prepare(t, root_noise_weight, h_noises_flat ? (const float *)(d + o_nz) : nullptr, 1,
                            (const int32_t *)(d + o_off), (const float *)(d + o_vp), (const float *)(d + o_lg),
                            (const int32_t *)(d + o_tp), s);
+    lz_tree_launch_bump_epoch(t, s);
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     r->players = players_of(h_to_play, B);
@@ -274,6 +279,7 @@ extern "C" int lz_roots_prepare_device(lz_roots *r, float root_noise_weight, con
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     lz_tree_launch_prepare(r->t, root_noise_weight, d_noises, 0, nullptr, d_value_prefix, d_policy_logits, d_to_play,
                            r->eng->stream);
+    lz_tree_launch_bump_epoch(r->t, r->eng->stream);
     LZ_HIP_CHECK(hipGetLastError());
     r->players = players;
     r->prepared = true;

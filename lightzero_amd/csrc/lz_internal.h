@@ -63,6 +63,16 @@ struct lz_tree_dev {
     int32_t *path_node;         // [B][NN]     expanded nodes on the search path, root first
     int32_t *path_act;          // [B][NN]     action taken at path_node[k]
     int32_t *res_ix, *res_iy, *res_last_action, *res_search_len, *res_vtp;  // [B] each
+    uint32_t *rng_epoch;        // [1] incremented by every prepare (stochastic tie-break stream)
+};
+
+struct lz_graph_key {
+    int sims, pb_c_base;
+    float pb_c_init, discount;
+    int horizon;
+    float delta;
+    int players, tiebreak;
+    uint64_t seed;
 };
 
 struct lz_roots {
@@ -100,6 +110,8 @@ struct lz_roots {
     float *d_noise = nullptr;       // [B][A]
     int32_t *d_noise_off = nullptr; // [B]
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
+    hipGraphExec_t graph_exec = nullptr;  // captured search (lz_search)
+    lz_graph_key graph_key{};
     bool inferred = false;
 };
 
@@ -123,5 +135,9 @@ void lz_tree_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, fl
 void lz_tree_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp,
                              const float *d_values, const float *d_logits, const int32_t *d_is_reset, int horizon,
                              const int32_t *d_to_play, hipStream_t s);
+void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp,
+                                      const float *d_values, const float *d_logits, int horizon,
+                                      const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
+void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s);
 void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s);
 void lz_tree_launch_trajectories(const lz_tree_dev &t, int32_t *d_out, int stride, hipStream_t s);

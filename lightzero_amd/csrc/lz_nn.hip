@@ -480,50 +480,59 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
+template <int NCHUNK>
+__global__ __launch_bounds__(256, 1) void k_lstm(lz_lstm_args a)
 {
-    constexpr int KC = 64, PS = KC + 4;
+    constexpr int KC = 64, PS = KC + 4, D = 4;  // D chunks of global loads in flight (register ring)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     auto sA = [&](int buf) -> float * { return smem + buf * 64 * PS; };
     auto sB = [&](int buf) -> float * { return smem + 2 * 64 * PS + buf * 32 * PS; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 32;
-    const int K = a.KX + a.H, nchunk = K / KC;
+    const int K = a.KX + a.H;
+    constexpr int nchunk = NCHUNK;  // K / 64, compile-time: the chunk loop is straight-line code so that the
+                                    // compiler's vmcnt bookkeeping keeps D chunks of loads in flight
     const size_t slot = (size_t)a.B * a.H;
 
-    float4 ra[4], rb[2];
-    auto load_chunk = [&](int c) {
-        const int k0 = c * KC;
+    // per-thread source rows (fixed across chunks): thread (row16 = tid >> 4, c4 = tid & 15) loads rows
+    // row16 + 16 i of the A chunk (i < 4) and of the B chunk (i < 2)
+    const int row16 = tid >> 4, c4 = tid & 15;
+    // rows past B are clamped to a valid row: the loads stay unconditional (a predicated load makes hipcc branch
+    // around it and drain the load queue at every join); their results are never written back.
+    size_t xoff[4], hoff[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // A chunk: 64 rows x 16 float4
-            const int idx = tid + i * 256, row = idx >> 4, c4 = idx & 15;
-            const int b = r0 + row;
-            float4 v = vzero4();
-            if (b < a.B) {
-                const float *src = (k0 < a.KX) ? a.x + (size_t)b * a.KX + k0
-                                               : a.h_pool + (size_t)a.gather_ix[b] * slot + (size_t)b * a.H + (k0 - a.KX);
-                v = *reinterpret_cast<const float4 *>(src + c4 * 4);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {  // B chunk: 32 gate rows x 16 float4
-            const int idx = tid + i * 256, row = idx >> 4, c4 = idx & 15;
-            rb[i] = *reinterpret_cast<const float4 *>(a.wcat + (size_t)(n0 + row) * K + k0 + c4 * 4);
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256, row = idx >> 4, c4 = idx & 15;
-            *reinterpret_cast<float4 *>(sA(buf) + row * PS + c4 * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256, row = idx >> 4, c4 = idx & 15;
-            *reinterpret_cast<float4 *>(sB(buf) + row * PS + c4 * 4) = rb[i];
-        }
-    };
+    for (int i = 0; i < 4; ++i) {
+        const int bb = min(r0 + row16 + 16 * i, a.B - 1);
+        xoff[i] = (size_t)bb * a.KX + c4 * 4;
+        hoff[i] = (size_t)a.gather_ix[bb] * slot + (size_t)bb * a.H + c4 * 4;
+    }
+    const float *w0p = a.wcat + (size_t)(n0 + row16) * K + c4 * 4;
+    const float *w1p = w0p + (size_t)16 * K;
+    // register ring: D = 4 chunks of loads in flight, as 24 named native vectors (indexed arrays / structs of
+    // HIP float4 are not promoted to registers by the compiler and end up in scratch)
+    f32x4 s0a0, s0a1, s0a2, s0a3, s0b0, s0b1, s1a0, s1a1, s1a2, s1a3, s1b0, s1b1;
+    f32x4 s2a0, s2a1, s2a2, s2a3, s2b0, s2b1, s3a0, s3a1, s3a2, s3a3, s3b0, s3b1;
+#define LZ_LSTM_LOAD(c, q)                                                                                    \
+    do {                                                                                                      \
+        const int k0_ = (c) * KC;                                                                             \
+        const bool inx_ = k0_ < a.KX;                                                                         \
+        const float *base_ = inx_ ? a.x + k0_ : a.h_pool + (k0_ - a.KX);                                      \
+        q##a0 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[0] : hoff[0]));                         \
+        q##a1 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[1] : hoff[1]));                         \
+        q##a2 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[2] : hoff[2]));                         \
+        q##a3 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[3] : hoff[3]));                         \
+        q##b0 = *reinterpret_cast<const f32x4 *>(w0p + k0_);                                                  \
+        q##b1 = *reinterpret_cast<const f32x4 *>(w1p + k0_);                                                  \
+    } while (0)
+#define LZ_LSTM_STORE(buf, q)                                                                                 \
+    do {                                                                                                      \
+        *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 0) * PS + c4 * 4) = q##a0;                              \
+        *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 16) * PS + c4 * 4) = q##a1;                             \
+        *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 32) * PS + c4 * 4) = q##a2;                             \
+        *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 48) * PS + c4 * 4) = q##a3;                             \
+        *reinterpret_cast<f32x4 *>(sB(buf) + (row16 + 0) * PS + c4 * 4) = q##b0;                              \
+        *reinterpret_cast<f32x4 *>(sB(buf) + (row16 + 16) * PS + c4 * 4) = q##b1;                             \
+    } while (0)
 
     f32x4 acc[4][2];
 #pragma unroll
@@ -531,27 +540,44 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int coff = wv * 16 + (lane >> 4) * 4;
-    load_chunk(0);
-    store_chunk(0);
+    // prologue: D chunks in flight, chunk 0 into LDS
+    LZ_LSTM_LOAD(0, s0);
+    if constexpr (1 < nchunk) LZ_LSTM_LOAD(1, s1);
+    if constexpr (2 < nchunk) LZ_LSTM_LOAD(2, s2);
+    if constexpr (3 < nchunk) LZ_LSTM_LOAD(3, s3);
+    __builtin_amdgcn_sched_barrier(0);
+    LZ_LSTM_STORE(0, s0);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) load_chunk(c + 1);
-        float4 bf[2], af[4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const float4 *>(sB(buf) + (j * 16 + (lane & 15)) * PS + coff);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const float4 *>(sA(buf) + (i * 16 + (lane & 15)) * PS + coff);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[i], q), vget(bf[j], q), acc[i][j], 0, 0, 0);
-        if (c + 1 < nchunk) store_chunk(buf ^ 1);
-        __syncthreads();
+    // chunk c: its ring slot CUR is free (already in LDS) -> refill it with chunk c + D; MFMAs from LDS buffer c & 1;
+    // then chunk c + 1 moves from slot NXT to the other LDS buffer.  sched_barrier keeps the refill ahead of the
+    // MFMAs (the scheduler would otherwise sink the loads next to their use and expose the L2 latency).
+#define LZ_LSTM_STEP(c, CUR, NXT)                                                                             \
+    if constexpr ((c) < nchunk) {                                                                             \
+        constexpr int buf_ = (c) & 1;                                                                         \
+        if constexpr ((c) + D < nchunk) LZ_LSTM_LOAD((c) + D, CUR);                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        float4 bf_[2], af_[4];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+            bf_[j] = *reinterpret_cast<const float4 *>(sB(buf_) + (j * 16 + (lane & 15)) * PS + coff);        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+            af_[i] = *reinterpret_cast<const float4 *>(sA(buf_) + (i * 16 + (lane & 15)) * PS + coff);        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af_[i], q), vget(bf_[j], q), acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if constexpr ((c) + 1 < nchunk) LZ_LSTM_STORE(buf_ ^ 1, NXT);                                         \
+        __syncthreads();                                                                                      \
     }
+    LZ_LSTM_STEP(0, s0, s1) LZ_LSTM_STEP(1, s1, s2) LZ_LSTM_STEP(2, s2, s3) LZ_LSTM_STEP(3, s3, s0)
+    LZ_LSTM_STEP(4, s0, s1) LZ_LSTM_STEP(5, s1, s2) LZ_LSTM_STEP(6, s2, s3) LZ_LSTM_STEP(7, s3, s0)
+    LZ_LSTM_STEP(8, s0, s1) LZ_LSTM_STEP(9, s1, s2) LZ_LSTM_STEP(10, s2, s3) LZ_LSTM_STEP(11, s3, s0)
+    LZ_LSTM_STEP(12, s0, s1) LZ_LSTM_STEP(13, s1, s2) LZ_LSTM_STEP(14, s2, s3) LZ_LSTM_STEP(15, s3, s0)
+    LZ_LSTM_STEP(16, s0, s1) LZ_LSTM_STEP(17, s1, s2) LZ_LSTM_STEP(18, s2, s3) LZ_LSTM_STEP(19, s3, s0)
+    static_assert(NCHUNK <= 20, "extend the LZ_LSTM_STEP list");
+#undef LZ_LSTM_STEP
+#undef LZ_LSTM_LOAD
+#undef LZ_LSTM_STORE
     // ---- split-K reduction, then the LSTM cell for 64 rows x 8 units
     float *red = smem;                       // [4][8][4][64]   (32 KB)
     float *csum = smem + 4 * 8 * 4 * 64;     // [64][33]
@@ -797,7 +823,10 @@ void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
 {
     const size_t lds = (size_t)(2 * 64 * 68 + 2 * 32 * 68) * 4;  // 52,224 B >= red (32 KB) + csum (8.4 KB)
     dim3 grid((a.B + 63) / 64, (4 * a.H) / 32), block(256);
-    hipLaunchKernelGGL(k_lstm, grid, block, lds, s, a);
+    const int nchunk = (a.KX + a.H) / 64;
+    if (nchunk == 17) hipLaunchKernelGGL((k_lstm<17>), grid, block, lds, s, a);
+    else if (nchunk == 13) hipLaunchKernelGGL((k_lstm<13>), grid, block, lds, s, a);
+    else if (nchunk == 9) hipLaunchKernelGGL((k_lstm<9>), grid, block, lds, s, a);
 }
 
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s)

@@ -6,6 +6,7 @@
 //   EfficientZeroMCTSCtree.search                lzero/mcts/tree_search/mcts_ctree.py:745-876
 //   EfficientZeroModel.initial/recurrent_inference  lzero/model/efficientzero_model.py:203-273
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -562,8 +563,9 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
     return LZ_OK;
 }
 
-// one simulation: traverse -> recurrent_inference -> backpropagate (mcts_ctree.py:782-876)
-static void simulate(lz_roots *r, int sim, const lz_traverse_args &ta, float delta, int horizon, hipStream_t s)
+// the network part of one simulation (mcts_ctree.py:834-847): recurrent_inference for the leaves selected by the
+// last traverse, outputs into slot sim + 1 of the pools
+static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
 {
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
@@ -571,7 +573,6 @@ static void simulate(lz_roots *r, int sim, const lz_traverse_args &ta, float del
     const size_t B = t.B, A = t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size;
     const int slot = sim + 1;
     const size_t lat_slot = B * HW * C;
-    lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
     if (r->trace_on) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     // ---- dynamics conv over [latent | one-hot action] + BN + latent + ReLU, dynamics residual block (-> latent pool
     // slot), prediction residual block and the three 1x1 head convs (efficientzero_model.py:527-558, common.py:1189-1203):
@@ -602,9 +603,28 @@ static void simulate(lz_roots *r, int sim, const lz_traverse_args &ta, float del
     lz_launch_lstm(l, s);
     heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
           r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
-    // ---- expand + backup; is_reset = search_len % horizon == 0 derived on the device
-    lz_tree_launch_backprop(t, slot, ta.discount, r->sim_vp + (size_t)slot * B, r->sim_value + (size_t)slot * B,
-                            r->sim_logits + (size_t)slot * B * A, nullptr, horizon, nullptr, s);
+}
+
+// the whole search: traverse, then per simulation [network, expand + backup fused with the next selection]
+static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta, float delta, int horizon, hipStream_t s)
+{
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
+    ta.counter = 0;
+    lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
+    for (int sim = 0; sim < num_simulations; ++sim) {
+        recurrent(r, sim, horizon, s);
+        const int slot = sim + 1;
+        const float *vp = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
+        // is_reset = search_len % horizon == 0 is derived on the device (mcts_ctree.py:859)
+        if (sim + 1 < num_simulations) {
+            ta.counter = (uint32_t)(sim + 1);
+            lz_tree_launch_backprop_traverse(t, slot, ta.discount, vp, val, lg, horizon, ta, delta, r->d_to_play, s);
+        } else {
+            lz_tree_launch_backprop(t, slot, ta.discount, vp, val, lg, nullptr, horizon, nullptr, s);
+        }
+    }
 }
 
 extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, float discount_factor,
@@ -620,15 +640,33 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
     r->delta = value_delta_max;
-    lz_tree_launch_minmax_reset(r->t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
     lz_traverse_args ta;
     ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
-    ta.tiebreak = r->tiebreak; ta.seed = r->seed;
-    for (int sim = 0; sim < num_simulations; ++sim) {
-        ta.counter = r->traverse_count++;
-        simulate(r, sim, ta, value_delta_max, lstm_horizon_len, s);
+    ta.tiebreak = r->tiebreak; ta.seed = r->seed; ta.counter = 0;
+    // The launch sequence of a search depends only on these parameters (every pointer is a fixed offset into the
+    // roots' slabs), so it is captured once into a HIP graph and replayed: ~5 launches per simulation become one
+    // graph launch, and the host leaves the loop.
+    const bool use_graph = !r->trace_on && !r->eng->prof_on && !getenv("LZ_NO_GRAPH");
+    if (!use_graph) {
+        enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
+        LZ_HIP_CHECK(hipGetLastError());
+        return LZ_OK;
     }
-    LZ_HIP_CHECK(hipGetLastError());
+    lz_graph_key key{num_simulations, pb_c_base, pb_c_init, discount_factor, lstm_horizon_len, value_delta_max, r->players,
+                     r->tiebreak, r->seed};
+    if (!r->graph_exec || memcmp(&key, &r->graph_key, sizeof(key)) != 0) {
+        if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        LZ_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
+        hipError_t e1 = hipStreamEndCapture(s, &g);
+        if (e1 != hipSuccess || !g) { lz_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e1)); return LZ_ERR_HIP; }
+        hipError_t e2 = hipGraphInstantiate(&r->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { r->graph_exec = nullptr; lz_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e2)); return LZ_ERR_HIP; }
+        r->graph_key = key;
+    }
+    LZ_HIP_CHECK(hipGraphLaunch(r->graph_exec, s));
     return LZ_OK;
 }
 

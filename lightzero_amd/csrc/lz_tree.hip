@@ -134,8 +134,8 @@ __global__ __launch_bounds__(64) void k_prepare(lz_tree_dev t, float noise_w, co
 // traverse: cbatch_traverse (cnode.cpp:886-963) -- select down to an unexpanded child
 // ------------------------------------------------------------------------------------------------
 template <int NC, int VARIANT>
-__global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args a, float delta_max,
-                                                 const int32_t *__restrict__ vtp_in)
+__device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta_max,
+                                             const int32_t *__restrict__ vtp_in)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args
     const float discount = a.discount;
     const float base = (float)a.pb_c_base;
     int vtp = vtp_in[b];
+    const uint32_t epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;  // bumped by every prepare: decorrelates env-steps
     int node = 0, depth = 0, is_root = 1, last_action = -1;
     int node_visit = t.root_visit[b];
     float parent_q = 0.0f;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args
                 masks[c] = __ballot(j == pos || (j > pos && score[c] >= thr));
                 cnt += __builtin_popcountll(masks[c]);
             }
-            const uint64_t h = mix64(a.seed ^ ((uint64_t)a.counter << 32) ^ ((uint64_t)b << 8) ^ (uint64_t)depth);
+            const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
             int r = (int)(h % (uint64_t)cnt);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -278,11 +279,11 @@ __global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args
 // backpropagate: cbatch_backpropagate (cnode.cpp:577-601) = expand the leaf, then cbackpropagate
 // ------------------------------------------------------------------------------------------------
 template <int NC, int VARIANT>
-__global__ __launch_bounds__(64) void k_backprop(lz_tree_dev t, int new_node, float discount,
-                                                 const float *__restrict__ vps, const float *__restrict__ values,
-                                                 const float *__restrict__ logits,
-                                                 const int32_t *__restrict__ is_reset, int horizon,
-                                                 const int32_t *__restrict__ to_play_in)
+__device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, int new_node, float discount,
+                                             const float *__restrict__ vps, const float *__restrict__ values,
+                                             const float *__restrict__ logits,
+                                             const int32_t *__restrict__ is_reset, int horizon,
+                                             const int32_t *__restrict__ to_play_in)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
@@ -399,6 +400,47 @@ __global__ __launch_bounds__(64) void k_backprop(lz_tree_dev t, int new_node, fl
     if (lane == 0) { t.minmax[2 * b] = mn; t.minmax[2 * b + 1] = mx; }
 }
 
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args a, float delta_max,
+                                                 const int32_t *__restrict__ vtp_in)
+{
+    dev_traverse<NC, VARIANT>(t, a, delta_max, vtp_in);
+}
+
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_backprop(lz_tree_dev t, int new_node, float discount,
+                                                 const float *__restrict__ vps, const float *__restrict__ values,
+                                                 const float *__restrict__ logits,
+                                                 const int32_t *__restrict__ is_reset, int horizon,
+                                                 const int32_t *__restrict__ to_play_in)
+{
+    dev_backprop<NC, VARIANT>(t, new_node, discount, vps, values, logits, is_reset, horizon, to_play_in);
+}
+
+// expand + backup of simulation s followed by the selection of simulation s + 1 for the same root, in one launch
+// (same wavefront owns the root in both phases; a workgroup-scope fence orders its stores before its loads).
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_backprop_traverse(lz_tree_dev t, int new_node, float discount,
+                                                          const float *__restrict__ vps,
+                                                          const float *__restrict__ values,
+                                                          const float *__restrict__ logits, int horizon,
+                                                          lz_traverse_args a, float delta_max,
+                                                          const int32_t *__restrict__ vtp_in)
+{
+    dev_backprop<NC, VARIANT>(t, new_node, discount, vps, values, logits, nullptr, horizon, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dev_traverse<NC, VARIANT>(t, a, delta_max, vtp_in);
+}
+
+// bumps the RNG epoch once per prepare (stochastic tie-break streams differ between env-steps even when the
+// whole search is replayed from a captured graph with identical kernel arguments)
+__global__ void k_bump_epoch(lz_tree_dev t)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && t.rng_epoch) t.rng_epoch[0] += 1u;
+}
+
 __global__ void k_minmax_reset(lz_tree_dev t)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,6 +539,30 @@ void lz_tree_launch_backprop(const lz_tree_dev &t, int latent_index, float disco
         launch_backprop_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s);
     else
         launch_backprop_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s);
+}
+
+template <int V>
+static void launch_bt_v(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val, const float *lg,
+                        int horizon, const lz_traverse_args &a, float delta, const int32_t *vtp, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_backprop_traverse<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp); break;
+    case 2: hipLaunchKernelGGL((k_backprop_traverse<2, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp); break;
+    default: hipLaunchKernelGGL((k_backprop_traverse<4, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp); break;
+    }
+}
+
+void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp,
+                                      const float *d_values, const float *d_logits, int horizon,
+                                      const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO) launch_bt_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s);
+    else launch_bt_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s);
+}
+
+void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(64), 0, s, t);
 }
 
 void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s)
