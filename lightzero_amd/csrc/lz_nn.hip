@@ -15,6 +15,8 @@
 // that every SIMD of every CU issues the same 324 MFMAs, and the partial tiles meet in LDS.  The input
 // halo and the 16-channel weight slice are staged in LDS once per workgroup with a +4-float pixel
 // pad, which makes every ds_read_b128 of an operand fragment bank-conflict free.
+#include <stdlib.h>
+
 #include "lz_nn_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -192,6 +194,124 @@ __global__ __launch_bounds__(256) void k_conv3x3(lz_conv_args a, int npix_max)
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 convolution for the large grids of the representation tower (48x48 .. 12x12): one workgroup = TM output
+// pixels x ALL output channels, wave = (16-channel N-tile, M-group), weight fragments streamed from L2 through a
+// register ring (no split-K, no LDS round trip for the result), halo staged once in LDS.  Several workgroups are
+// resident per CU so one's staging overlaps another's MFMAs.
+// grid = ceil(B*Hout*Wout / TM), block = 256.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int STRIDE, int TM>
+__global__ __launch_bounds__(256) void k_conv3x3_big(lz_conv_args a, int npix_max)
+{
+    constexpr int PS = CIN + 4, CH4 = CIN / 4, G = CIN / 16, NT = COUT / 16, MG = 4 / NT;
+    constexpr int MTW = TM / 16 / MG;      // M-tiles per wave
+    constexpr int STEPS = 9 * G, R = (STEPS >= 12) ? 12 : 6;
+    static_assert(TM % (16 * MG) == 0, "tile split");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sA = smem;  // [npix_max + 1][PS], last pixel all zeros
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nt = wv % NT, mg = wv / NT;
+    const int HWin = a.Hin * a.Win, HWout = a.Hout * a.Wout;
+    const int M = a.B * HWout;
+    const int m0 = blockIdx.x * TM;
+    const int m1 = min(m0 + TM, M) - 1;
+    auto centre = [&](int m) -> int {
+        if (STRIDE == 1) return m;
+        const int b = m / HWout, p = m - b * HWout, y = p / a.Wout, x = p - y * a.Wout;
+        return (b * a.Hin + STRIDE * y) * a.Win + STRIDE * x;
+    };
+    const int in_lo = max(0, centre(m0) - a.Win - 1);
+    const int in_hi = min(a.B * HWin, centre(m1) + a.Win + 2);
+    const int npix = in_hi - in_lo;
+    // weight ring prologue first: its latency overlaps the halo staging
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(a.wf) + (size_t)nt * STEPS * 64 + lane;
+    f32x4 wq[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) wq[s] = wl[s * 64];
+    {
+        const int nA = npix * CH4;
+        constexpr int UB = 8;
+        for (int base0 = 0; base0 < nA; base0 += UB * 256) {
+            f32x4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = min(base0 + u * 256 + tid, nA - 1);
+                v[u] = *reinterpret_cast<const f32x4 *>(a.in + ((size_t)in_lo * CIN) + (size_t)idx * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base0 + u * 256 + tid;
+                if (idx < nA) *reinterpret_cast<f32x4 *>(sA + (size_t)(idx / CH4) * PS + (idx % CH4) * 4) = v[u];
+            }
+        }
+        if (tid < CH4) *reinterpret_cast<f32x4 *>(sA + (size_t)npix_max * PS + tid * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int zoff = npix_max * PS;
+    int base[MTW], mask[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int m = m0 + (mg * MTW + i) * 16 + (lane & 15);
+        const int mm = min(m, m1);
+        const int b = mm / HWout, p = mm - b * HWout, y = p / a.Wout, x = p - y * a.Wout;
+        const int cy = STRIDE * y, cx = STRIDE * x;
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+            mk |= ((iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win) & (m <= m1)) << t;
+        }
+        int bs = ((b * a.Hin + cy) * a.Win + cx - in_lo) * PS;
+        asm volatile("" : "+v"(mk), "+v"(bs));
+        base[i] = bs;
+        mask[i] = mk;
+    }
+    __syncthreads();
+    const float *sAl = sA + (lane >> 4) * 4;
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto fetch_a = [&](int s, f32x4 (&af)[MTW]) {
+        const int t = s / G, g = s % G;
+        const int toff = ((t / 3 - 1) * a.Win + (t % 3 - 1)) * PS;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int bit = (mask[i] >> t) & 1;
+            const int off = zoff + bit * (base[i] + toff - zoff);
+            af[i] = *reinterpret_cast<const f32x4 *>(sAl + off + g * 16);
+        }
+    };
+    f32x4 af[2][MTW];
+    fetch_a(0, af[0]);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const f32x4 bfr = wq[s % R];
+        if (s + R < STEPS) wq[s % R] = wl[(s + R) * 64];
+        if (s + 1 < STEPS) fetch_a(s + 1, af[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][i][j], bfr[j], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int col = nt * 16 + (lane & 15);
+    const float sc = a.scale[col], sh = a.shift[col];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + (mg * MTW + i) * 16 + 4 * (lane >> 4) + q;
+            if (m <= m1) {
+                float v = acc[i][q] * sc + sh;
+                if (a.residual) v += a.residual[(size_t)m * COUT + col];
+                if (a.relu) v = fmaxf(v, 0.0f);
+                a.out[(size_t)m * COUT + col] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // first DownSample layer: conv3x3 / stride 2 from NCHW observations, + BN + ReLU.  One thread per
 // output pixel computes all Cout channels from the (<= 9*C)-value patch; weights broadcast from LDS.
 // ------------------------------------------------------------------------------------------------
@@ -334,6 +454,21 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
     __shared__ __attribute__((aligned(16))) float smem[4 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
+    // first weight fragments are requested before anything else so that their L2 round trip overlaps the staging
+    constexpr int R = 12;
+    float4 wq[R];
+    {
+        const float4 *w0 = reinterpret_cast<const float4 *>(a.layer[0].wf) + (size_t)wv * 36 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < R; ++s) wq[s] = w0[s * 64];
+    }
+    // 1x1 head-conv weights of this wave's job too (used after the last layer)
+    float4 c1w[4];
+    {
+        const float *cw = a.c1[min(wv, max(a.nc1 - 1, 0))].w;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(cw + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
+    }
     {
         const float *src = a.in + (size_t)b * HW * 64;
         if (a.gather_ix) src += (size_t)a.gather_ix[b] * a.slot_stride;
@@ -376,13 +511,6 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
     // boundaries (the next layer's first fragments are in flight during this layer's epilogue and barrier); the
     // A fragments of step s+1 are read from LDS before the MFMAs of step s issue.  sched_barrier pins that order
     // (left alone, the scheduler sinks the prefetches next to their uses and exposes the L2 latency).
-    constexpr int R = 12;
-    float4 wq[R];
-    {
-        const float4 *w0 = reinterpret_cast<const float4 *>(a.layer[0].wf) + (size_t)wv * 36 * 64 + lane;
-#pragma unroll
-        for (int s = 0; s < R; ++s) wq[s] = w0[s * 64];
-    }
     auto fetch_a = [&](const float *sIn, int s, float4 (&af)[3]) {
         const int t = s >> 2, g = s & 3;
         const int toff = ((t / 3 - 1) * 6 + (t % 3 - 1)) * PS;
@@ -448,7 +576,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bfr = *reinterpret_cast<const float4 *>(jb.w + (size_t)(lane & 15) * 64 + g * 16 + kq4);
+            const float4 bfr = c1w[g];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int row = i * 16 + (lane & 15);
@@ -480,35 +608,36 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int NCHUNK>
-__global__ __launch_bounds__(256, 1) void k_lstm(lz_lstm_args a)
+template <int NCHUNK, int MROWS>
+__global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 {
     constexpr int KC = 64, PS = KC + 4, D = 4;  // D chunks of global loads in flight (register ring)
+    constexpr int NA = MROWS / 16;              // float4 per thread per A chunk (= M-tiles per workgroup)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    auto sA = [&](int buf) -> float * { return smem + buf * 64 * PS; };
-    auto sB = [&](int buf) -> float * { return smem + 2 * 64 * PS + buf * 32 * PS; };
+    auto sA = [&](int buf) -> float * { return smem + buf * MROWS * PS; };
+    auto sB = [&](int buf) -> float * { return smem + 2 * MROWS * PS + buf * 32 * PS; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 32;
+    const int r0 = blockIdx.x * MROWS, n0 = blockIdx.y * 32;
     const int K = a.KX + a.H;
     constexpr int nchunk = NCHUNK;  // K / 64, compile-time: the chunk loop is straight-line code so that the
                                     // compiler's vmcnt bookkeeping keeps D chunks of loads in flight
     const size_t slot = (size_t)a.B * a.H;
 
     // per-thread source rows (fixed across chunks): thread (row16 = tid >> 4, c4 = tid & 15) loads rows
-    // row16 + 16 i of the A chunk (i < 4) and of the B chunk (i < 2)
+    // row16 + 16 i of the A chunk (i < NA) and of the B chunk (i < 2)
     const int row16 = tid >> 4, c4 = tid & 15;
     // rows past B are clamped to a valid row: the loads stay unconditional (a predicated load makes hipcc branch
     // around it and drain the load queue at every join); their results are never written back.
-    size_t xoff[4], hoff[4];
+    size_t xoff[NA], hoff[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int bb = min(r0 + row16 + 16 * i, a.B - 1);
         xoff[i] = (size_t)bb * a.KX + c4 * 4;
         hoff[i] = (size_t)a.gather_ix[bb] * slot + (size_t)bb * a.H + c4 * 4;
     }
     const float *w0p = a.wcat + (size_t)(n0 + row16) * K + c4 * 4;
     const float *w1p = w0p + (size_t)16 * K;
-    // register ring: D = 4 chunks of loads in flight, as 24 named native vectors (indexed arrays / structs of
+    // register ring: D = 4 chunks of loads in flight, as named native vectors (indexed arrays / structs of
     // HIP float4 are not promoted to registers by the compiler and end up in scratch)
     f32x4 s0a0, s0a1, s0a2, s0a3, s0b0, s0b1, s1a0, s1a1, s1a2, s1a3, s1b0, s1b1;
     f32x4 s2a0, s2a1, s2a2, s2a3, s2b0, s2b1, s3a0, s3a1, s3a2, s3a3, s3b0, s3b1;
@@ -519,8 +648,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm(lz_lstm_args a)
         const float *base_ = inx_ ? a.x + k0_ : a.h_pool + (k0_ - a.KX);                                      \
         q##a0 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[0] : hoff[0]));                         \
         q##a1 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[1] : hoff[1]));                         \
-        q##a2 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[2] : hoff[2]));                         \
-        q##a3 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[3] : hoff[3]));                         \
+        if constexpr (NA > 2) {                                                                               \
+            q##a2 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[NA > 2 ? 2 : 0] : hoff[NA > 2 ? 2 : 0])); \
+            q##a3 = *reinterpret_cast<const f32x4 *>(base_ + (inx_ ? xoff[NA > 2 ? 3 : 0] : hoff[NA > 2 ? 3 : 0])); \
+        }                                                                                                     \
         q##b0 = *reinterpret_cast<const f32x4 *>(w0p + k0_);                                                  \
         q##b1 = *reinterpret_cast<const f32x4 *>(w1p + k0_);                                                  \
     } while (0)
@@ -528,15 +659,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm(lz_lstm_args a)
     do {                                                                                                      \
         *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 0) * PS + c4 * 4) = q##a0;                              \
         *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 16) * PS + c4 * 4) = q##a1;                             \
-        *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 32) * PS + c4 * 4) = q##a2;                             \
-        *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 48) * PS + c4 * 4) = q##a3;                             \
+        if constexpr (NA > 2) {                                                                               \
+            *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 32) * PS + c4 * 4) = q##a2;                         \
+            *reinterpret_cast<f32x4 *>(sA(buf) + (row16 + 48) * PS + c4 * 4) = q##a3;                         \
+        }                                                                                                     \
         *reinterpret_cast<f32x4 *>(sB(buf) + (row16 + 0) * PS + c4 * 4) = q##b0;                              \
         *reinterpret_cast<f32x4 *>(sB(buf) + (row16 + 16) * PS + c4 * 4) = q##b1;                             \
     } while (0)
 
-    f32x4 acc[4][2];
+    f32x4 acc[NA][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int coff = wv * 16 + (lane >> 4) * 4;
@@ -556,13 +689,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm(lz_lstm_args a)
         constexpr int buf_ = (c) & 1;                                                                         \
         if constexpr ((c) + D < nchunk) LZ_LSTM_LOAD((c) + D, CUR);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        float4 bf_[2], af_[4];                                                                                \
+        float4 bf_[2], af_[NA];                                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
             bf_[j] = *reinterpret_cast<const float4 *>(sB(buf_) + (j * 16 + (lane & 15)) * PS + coff);        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                        \
             af_[i] = *reinterpret_cast<const float4 *>(sA(buf_) + (i * 16 + (lane & 15)) * PS + coff);        \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                    \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af_[i], q), vget(bf_[j], q), acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -578,28 +711,28 @@ __global__ __launch_bounds__(256, 1) void k_lstm(lz_lstm_args a)
 #undef LZ_LSTM_STEP
 #undef LZ_LSTM_LOAD
 #undef LZ_LSTM_STORE
-    // ---- split-K reduction, then the LSTM cell for 64 rows x 8 units
-    float *red = smem;                       // [4][8][4][64]   (32 KB)
-    float *csum = smem + 4 * 8 * 4 * 64;     // [64][33]
+    // ---- split-K reduction, then the LSTM cell for MROWS rows x 8 units
+    float *red = smem;                            // [4][NA*2][4][64]
+    float *csum = smem + 4 * NA * 2 * 4 * 64;     // [MROWS][33]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[((wv * 8 + i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) red[((wv * NA * 2 + i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
     __syncthreads();
     {
         const int l = tid & 63, r = tid >> 6;
 #pragma unroll
-        for (int tile = 0; tile < 8; ++tile) {
-            const float v = red[((0 * 8 + tile) * 4 + r) * 64 + l] + red[((1 * 8 + tile) * 4 + r) * 64 + l] +
-                            red[((2 * 8 + tile) * 4 + r) * 64 + l] + red[((3 * 8 + tile) * 4 + r) * 64 + l];
+        for (int tile = 0; tile < NA * 2; ++tile) {
+            const float v = red[((0 * NA * 2 + tile) * 4 + r) * 64 + l] + red[((1 * NA * 2 + tile) * 4 + r) * 64 + l] +
+                            red[((2 * NA * 2 + tile) * 4 + r) * 64 + l] + red[((3 * NA * 2 + tile) * 4 + r) * 64 + l];
             const int row = (tile >> 1) * 16 + 4 * (l >> 4) + r, col = (tile & 1) * 16 + (l & 15);
             csum[row * 33 + col] = v;
         }
     }
     __syncthreads();
-    for (int item = tid; item < 64 * 8; item += 256) {
+    for (int item = tid; item < MROWS * 8; item += 256) {
         const int row = item >> 3, u = item & 7;
         const int b = r0 + row;
         if (b >= a.B) continue;
@@ -676,7 +809,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
         for (int e = 0; e < EPB; ++e) acc[e] = 0.0f;
         if (u < HID) {
             const float *wr = h.w1 + (size_t)u * K1;
-#pragma unroll 6
+#pragma unroll 9
             for (int k = part * 4; k < K1; k += 32) {
                 const float4 wv4 = *reinterpret_cast<const float4 *>(wr + k);
 #pragma unroll
@@ -710,7 +843,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
 #pragma unroll
         for (int e = 0; e < EPB; ++e) acc[e] = bias;
         if (ok) {
-#pragma unroll 8
+#pragma unroll
             for (int k = 0; k < HID; ++k) {
                 const float wv = h.w2t[(size_t)k * h.NOUT + n];
 #pragma unroll
@@ -775,8 +908,23 @@ static int conv_npix_max(const lz_conv_args &a, int stride)
     return 2 * a.Win * (143 / a.Wout + 1) + 2 * (a.Wout - 1) + 2 * a.Win + 3;
 }
 
+template <int CIN, int COUT, int STRIDE, int TM>
+static void launch_big(const lz_conv_args &a, hipStream_t s)
+{
+    const int M = a.B * a.Hout * a.Wout;
+    int npix = (STRIDE == 1) ? TM + 2 * a.Win + 2 : 2 * a.Win * ((TM - 1) / a.Wout + 1) + 2 * (a.Wout - 1) + 2 * a.Win + 3;
+    npix = min(npix, a.B * a.Hin * a.Win);
+    const size_t lds = (size_t)(npix + 1) * (CIN + 4) * 4;
+    hipLaunchKernelGGL((k_conv3x3_big<CIN, COUT, STRIDE, TM>), dim3((M + TM - 1) / TM), dim3(256), lds, s, a, npix);
+}
+
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s)
 {
+    if (a.wf && !a.gather_ix && !a.act_table && a.Hout >= 12) {  // representation tower: big-grid kernel
+        if (cin == 32 && a.Cout == 32 && stride == 1) { launch_big<32, 32, 1, 128>(a, s); return; }
+        if (cin == 32 && a.Cout == 64 && stride == 2) { launch_big<32, 64, 2, 48>(a, s); return; }
+        if (cin == 64 && a.Cout == 64 && stride == 1) { launch_big<64, 64, 1, 144>(a, s); return; }
+    }
     const int M = a.B * a.Hout * a.Wout;
     int npix = conv_npix_max(a, stride);
     npix = min(npix, a.B * a.Hin * a.Win);
@@ -819,14 +967,28 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s)
     hipLaunchKernelGGL(k_chain, dim3(a.B), dim3(256), 0, s, a);
 }
 
+template <int MROWS>
+static void launch_lstm_m(const lz_lstm_args &a, hipStream_t s)
+{
+    // LDS: double-buffered A [MROWS][68] + B [32][68] chunks; reused for the split-K reduction + gate staging
+    size_t lds = (size_t)(2 * MROWS * 68 + 2 * 32 * 68) * 4;
+    const size_t red = (size_t)(4 * (MROWS / 16) * 2 * 4 * 64 + MROWS * 33) * 4;
+    if (lds < red) lds = red;
+    dim3 grid((a.B + MROWS - 1) / MROWS, (4 * a.H) / 32), block(256);
+    const int nchunk = (a.KX + a.H) / 64;
+    if (nchunk == 17) hipLaunchKernelGGL((k_lstm<17, MROWS>), grid, block, lds, s, a);
+    else if (nchunk == 13) hipLaunchKernelGGL((k_lstm<13, MROWS>), grid, block, lds, s, a);
+    else if (nchunk == 9) hipLaunchKernelGGL((k_lstm<9, MROWS>), grid, block, lds, s, a);
+}
+
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
 {
-    const size_t lds = (size_t)(2 * 64 * 68 + 2 * 32 * 68) * 4;  // 52,224 B >= red (32 KB) + csum (8.4 KB)
-    dim3 grid((a.B + 63) / 64, (4 * a.H) / 32), block(256);
-    const int nchunk = (a.KX + a.H) / 64;
-    if (nchunk == 17) hipLaunchKernelGGL((k_lstm<17>), grid, block, lds, s, a);
-    else if (nchunk == 13) hipLaunchKernelGGL((k_lstm<13>), grid, block, lds, s, a);
-    else if (nchunk == 9) hipLaunchKernelGGL((k_lstm<9>), grid, block, lds, s, a);
+    // 32-row tiles double the workgroup count (two resident per CU: one's chunk barrier overlaps the other's
+    // MFMAs) while the batch is small; 64-row tiles halve the operand traffic once there are enough rows
+    static const char *force = getenv("LZ_DEBUG_LSTM_ROWS");
+    const int rows = force ? atoi(force) : (a.B <= 512 ? 32 : 64);
+    if (rows == 32) launch_lstm_m<32>(a, s);
+    else launch_lstm_m<64>(a, s);
 }
 
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s)

@@ -158,7 +158,7 @@ struct Builder {
         c.w = upload(p);
         c.scale = upload(sc);
         c.shift = upload(sh);
-        if (cin == 64 && cout == 64) {
+        {
             std::vector<float> f((size_t)cout * 9 * cin);
             for (int nt = 0; nt < cout / 16; ++nt)
                 for (int t = 0; t < 9; ++t)
@@ -378,7 +378,7 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
                  int relu, hipStream_t s)
 {
     lz_conv_args a{};
-    a.in = in; a.w = w.w; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
+    a.in = in; a.w = w.w; a.wf = w.wf; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
 }
@@ -591,6 +591,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
         ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = 2;
         ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = 3;
         ca.nc1 = 3;
+        if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
         ProfScope ps(r->eng, s);
         lz_launch_chain(ca, s);
     }
@@ -600,6 +601,8 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
+    // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
+    // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
     lz_launch_lstm(l, s);
     heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
           r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
