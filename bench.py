@@ -149,6 +149,12 @@ def main():
     L.check(lib.lz_profile_read(eng, ctypes.byref(n_launch), ctypes.byref(tot_ms)))
     L.check(lib.lz_profile_enable(eng, 0))
 
+    traffic = None
+    try:  # HBM bytes per k_chain launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE), see profiles/r01_traffic.json
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f)["k_chain"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         value = world * ENVS * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
@@ -166,7 +172,8 @@ def main():
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "k_chain (per root: dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes of profiles/r01_traffic.json, not re-measured in this run)",
                          "avg_launch_us": avg_us, "launches_timed": n_launch.value,
                          "timing": "HIP event pairs on the engine stream around each launch, %d eager steps run right after the "
                                    "graph-replayed timed region" % prof_steps,

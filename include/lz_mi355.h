@@ -70,6 +70,9 @@ void *lz_engine_stream(lz_engine *e);
  * (max_simulations + 1) expanded nodes x action_space_size edges per root, resident in HBM. */
 int lz_roots_create(lz_engine *e, int variant, int root_num, int action_space_size, int max_simulations,
                     const int32_t *h_legal_flat, const int32_t *h_legal_count, lz_roots **out);
+/* Re-arm an existing batch of trees for the next env-step with new legal-action lists (same root_num and
+ * action space): what constructing a fresh Roots does in the reference, without re-allocating the HBM pools. */
+int lz_roots_reset(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count);
 int lz_roots_destroy(lz_roots *r);
 int lz_roots_num(const lz_roots *r);
 /* MinMaxStatsList.set_delta                      ez_tree.pyx:12-14 -> cminimax.cpp:61-65.

@@ -51,6 +51,7 @@ def lib():
         "lz_engine_stream": [P],
         "lz_roots_create": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(P)],
         "lz_roots_destroy": [P],
+        "lz_roots_reset": [P, c_i32p, c_i32p],
         "lz_roots_minmax_reset": [P, ctypes.c_float],
         "lz_roots_set_tiebreak": [P, ctypes.c_int, ctypes.c_uint64],
         "lz_roots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_i32p],

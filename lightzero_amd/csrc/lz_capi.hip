@@ -186,6 +186,19 @@ extern "C" int lz_roots_create(lz_engine *e, int variant, int root_num, int acti
     return LZ_OK;
 }
 
+extern "C" int lz_roots_reset(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = lz_roots_upload_legal(r, h_legal_flat, h_legal_count);
+    if (rc != LZ_OK) return rc;
+    r->prepared = false;
+    r->inferred = false;
+    r->traverse_count = 0;
+    lz_tree_launch_minmax_reset(r->t, r->eng->stream);
+    return LZ_OK;
+}
+
 extern "C" int lz_roots_destroy(lz_roots *r)
 {
     if (!r) return LZ_OK;

@@ -72,12 +72,12 @@ void lz_model_destroy(lz_model *m)
 extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
 {
     LZ_REQUIRE(e != nullptr && cfg != nullptr, "NULL argument");
-    LZ_REQUIRE(cfg->model_type == 0, "only model_type 0 (EfficientZeroModel conv, downsample) is implemented");
+    LZ_REQUIRE(cfg->model_type == 0 || cfg->model_type == 1, "model_type must be 0 (EfficientZeroModel) or 1 (MuZeroModel), conv + downsample");
     LZ_REQUIRE(cfg->num_channels == 64, "num_channels must be 64");
     LZ_REQUIRE(cfg->obs_h == 96 && cfg->obs_w == 96, "observation must be 96x96 (downsample path)");
     LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
-    LZ_REQUIRE(cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0, "lstm_hidden_size must be a multiple of 64");
+    LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
     if (e->model) lz_model_destroy(e->model);
@@ -287,6 +287,10 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->dra = b.resconv(d + "resblocks.0", 1, C, C);
         m->drb = b.resconv(d + "resblocks.0", 2, C, C);
         m->rew_c = b.conv1x1(d + "conv1x1_reward", d + "norm_reward", HC, C);
+        if (c.model_type == 1) {
+            // MuZero DynamicsNetwork (muzero_model.py:505-538): reward = MLP(flatten(relu(bn(conv1x1(next latent)))))
+            m->fc_reward = b.mlp(d + "fc_reward_head", HC * HW, HID, SUP, true, HC, HW);
+        } else {
         // LSTM: rows re-ordered to 4*unit + gate; the x columns permuted from the reference's
         // (channel, pixel) flatten order to (pixel, channel)
         const int KX = HC * HW, K = KX + H;
@@ -310,6 +314,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->vp_s = b.upload(sc);
         m->vp_t = b.upload(sh);
         m->fc_reward = b.mlp(d + "fc_reward_head", H, HID, SUP, false, HC, HW);
+        }
     }
     // ---- prediction (common.py:1081-1216)
     {
@@ -337,7 +342,7 @@ static int ensure_pools(lz_roots *r)
     if (r->pool_slab) return LZ_OK;
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
-    const size_t B = r->t.B, NN = r->t.NN, A = r->t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size,
+    const size_t B = r->t.B, NN = r->t.NN, A = r->t.A, C = c.num_channels, HW = m->HWl, H = c.model_type == 0 ? c.lstm_hidden_size : 0,
                  HC = c.head_channels, SUP = c.support_size;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -418,7 +423,10 @@ static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_v
     int n = 0;
     h[n++] = headdesc(m->fc_value, r->t_pv, HW * 2 * HC, 2 * HC, 1, c.support_min, dbg_value_logits, out_value);
     h[n++] = headdesc(m->fc_policy, r->t_pv + HC, HW * 2 * HC, 2 * HC, 0, 0.f, out_logits, nullptr);
-    if (with_vp) h[n++] = headdesc(m->fc_reward, r->t_hbn, c.lstm_hidden_size, 16, 1, c.support_min, dbg_vp_logits, out_vp);
+    if (with_vp) {
+        if (c.model_type == 1) h[n++] = headdesc(m->fc_reward, r->t_rx, HW * HC, HC, 1, c.support_min, dbg_vp_logits, out_vp);
+        else h[n++] = headdesc(m->fc_reward, r->t_hbn, c.lstm_hidden_size, 16, 1, c.support_min, dbg_vp_logits, out_vp);
+    }
     lz_launch_heads(h, n, B, c.head_hidden, s);
 }
 
@@ -444,7 +452,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     lz_model *m = r->eng->model;
     if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
     LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
-    LZ_REQUIRE(r->t.variant == LZ_TREE_EFFICIENTZERO, "model_type 0 needs an EfficientZero tree");
+    LZ_REQUIRE(r->t.variant == (m->cfg.model_type == 0 ? LZ_TREE_EFFICIENTZERO : LZ_TREE_MUZERO), "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree)");
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     int rc = ensure_pools(r);
     if (rc != LZ_OK) return rc;
@@ -452,7 +460,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     if (rc != LZ_OK) return rc;
     hipStream_t s = r->eng->stream;
     const lz_model_cfg &c = m->cfg;
-    const int B = r->t.B, C = c.num_channels, H = c.lstm_hidden_size;
+    const int B = r->t.B, C = c.num_channels, H = c.model_type == 0 ? c.lstm_hidden_size : 0;
     float *w0 = m->ws[0], *w1 = m->ws[1], *w2 = m->ws[2];
     // DownSample (common.py:266-365)
     int stage = 0;
@@ -496,8 +504,10 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
         ca.nc1 = 2;
         lz_launch_chain(ca, s);
     }
-    LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * H * 4, s));
-    LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
+    if (H > 0) {
+        LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * H * 4, s));
+        LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
+    }
     heads(r, r->sim_value, r->sim_logits, r->dbg_logits[0], false, nullptr, nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
     r->inferred = true;
@@ -603,7 +613,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
     // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
     // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
-    lz_launch_lstm(l, s);
+    if (c.model_type == 0) lz_launch_lstm(l, s);
     heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
           r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
 }
@@ -635,7 +645,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->inferred && r->prepared, "lz_search needs lz_initial_inference and a prepare call first");
-    LZ_REQUIRE(lstm_horizon_len > 0, "lstm_horizon_len must be positive (mcts_ctree.py:858)");
+    LZ_REQUIRE(lstm_horizon_len > 0 || r->eng->model->cfg.model_type == 1, "lstm_horizon_len must be positive (mcts_ctree.py:858)");
     if (num_simulations < 1 || num_simulations >= r->t.NN) {
         lz_set_error("num_simulations %d exceeds the node pool (max_simulations %d)", num_simulations, r->t.NN - 1);
         return LZ_ERR_STATE;

@@ -77,6 +77,19 @@ def make_module(variant, has_deterministic_flag):
             mode = self._tiebreak if self._tiebreak is not None else (0 if has_deterministic_flag else 1)
             L.check(L.lib().lz_roots_set_tiebreak(self._h, mode, self._seed))
 
+        def reset(self, legal_actions_list):
+            """Re-arm these roots for a new env-step (what building a fresh ``Roots`` does in the reference) while
+            keeping the HBM node / latent pools: same root_num and action space, new legal-action lists."""
+            if len(legal_actions_list) != self.root_num:
+                raise ValueError("legal_actions_list must have root_num entries")
+            self._legal = [[int(a) for a in l] for l in legal_actions_list]
+            self._inferred_by = None
+            if self._h is not None:
+                cnt = L.i32([len(l) for l in self._legal])
+                flat = L.i32([a for l in self._legal for a in l] or [0])
+                L.check(L.lib().lz_roots_reset(self._h, flat, cnt))
+            return self
+
         def set_tiebreak(self, mode, seed=None):
             """0: first arg-max (deterministic); 1: uniform over the reference's tie list."""
             self._tiebreak = int(mode)

@@ -144,8 +144,14 @@ class MuZeroMCTSCtree(object):
                                  max_simulations=max_simulations)
 
     def search(self, roots, model, latent_state_roots, to_play_batch, task_id=None):
-        import torch
         cfg = self._cfg
+        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+            # fused path: every simulation on the device (the reference runs recurrent_inference twice per
+            # simulation, mcts_ctree.py:338-345; once is enough)
+            L.check(L.lib().lz_search(roots._h, int(cfg["num_simulations"]), int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
+                                      float(cfg["discount_factor"]), 0, float(cfg["value_delta_max"])))
+            return
+        import torch
         device = _get(cfg, "device", "cpu")
         with torch.no_grad():
             model.eval()

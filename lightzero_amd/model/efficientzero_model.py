@@ -13,6 +13,8 @@ from .. import _lib as L
 
 
 class EfficientZeroModel(object):
+    _model_type = 0  # lz_model_cfg.model_type
+
     def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, lstm_hidden_size=512, num_res_blocks=1,
                  num_channels=64, reward_head_channels=16, value_head_channels=16, policy_head_channels=16,
                  reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
@@ -34,7 +36,7 @@ class EfficientZeroModel(object):
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
         self.reward_support_size = self.value_support_size
         self._engine = engine if engine is not None else L.default_engine()
-        cfg = L.ModelCfg(0, self.observation_shape[0], self.observation_shape[1], self.observation_shape[2],
+        cfg = L.ModelCfg(self._model_type, self.observation_shape[0], self.observation_shape[1], self.observation_shape[2],
                          self.action_space_size, self.num_channels, self.lstm_hidden_size, int(value_head_channels),
                          int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5)
         L.check(L.lib().lz_model_create(self._engine, ctypes.byref(cfg)))

@@ -1,0 +1,12 @@
+"""Engine-backed counterpart of lzero/model/muzero_model.py::MuZeroModel (inference graph): same network as the
+EfficientZero engine model without the value-prefix LSTM; the reward head is conv1x1 + BN + ReLU -> MLP
+(muzero_model.py:505-538).  Pair it with the MuZero tree (lightzero_amd.mcts.ctree.ctree_muzero.mz_tree)."""
+from .efficientzero_model import EfficientZeroModel
+
+
+class MuZeroModel(EfficientZeroModel):
+    _model_type = 1
+
+    def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, **kwargs):
+        kwargs.setdefault("lstm_hidden_size", 0)
+        super().__init__(observation_shape=observation_shape, action_space_size=action_space_size, **kwargs)

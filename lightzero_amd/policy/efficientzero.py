@@ -36,6 +36,7 @@ class EfficientZeroPolicy(object):
         self._mcts_eval = MCTSCtree(mcfg)
         self._collect_mcts_temperature = 1.
         self.collect_epsilon = 0.0
+        self._roots_cache = {}
         # "random": the reference's stochastic tie rule (rand() over the tie list, cnode.cpp:691);
         # "first": deterministic first arg-max (parity / reproducible evaluation)
         self._tiebreak = {"random": 1, "first": 0}[_g(cfg, "mcts_tiebreak", "random")]
@@ -44,10 +45,20 @@ class EfficientZeroPolicy(object):
         return self._forward_collect(*args, **kwargs)
 
     def _roots(self, n, legal_actions):
-        roots = MCTSCtree.roots(n, legal_actions, action_space_size=self._collect_model.action_space_size,
-                                max_simulations=int(self._mcfg["num_simulations"]))
-        roots.set_tiebreak(self._tiebreak)
+        # the reference builds a fresh Roots per forward (efficientzero.py:605); here the HBM pools of a batch size
+        # are allocated once and re-armed with the new legal-action lists
+        roots = self._roots_cache.get(n)
+        if roots is None:
+            roots = MCTSCtree.roots(n, legal_actions, action_space_size=self._collect_model.action_space_size,
+                                    max_simulations=int(self._mcfg["num_simulations"]))
+            roots.set_tiebreak(self._tiebreak)
+            self._roots_cache[n] = roots
+        else:
+            roots.reset(legal_actions)
         return roots
+
+    def _search(self, mcts, roots, model, network_output, to_play):
+        mcts.search(roots, model, network_output.latent_state, network_output.reward_hidden_state, to_play)
 
     def _forward_collect(self, data, action_mask=None, temperature=1, to_play=[-1], epsilon=0.25, ready_env_id=None,
                          **kwargs):
@@ -66,8 +77,7 @@ class EfficientZeroPolicy(object):
         noises = [np.random.dirichlet([alpha] * int(sum(action_mask[j]))).astype(np.float32).tolist()
                   for j in range(active_collect_env_num)]  # efficientzero.py:599-602
         roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
-        self._mcts_collect.search(roots, self._collect_model, network_output.latent_state,
-                                  network_output.reward_hidden_state, to_play)
+        self._search(self._mcts_collect, roots, self._collect_model, network_output, to_play)
         roots_visit_count_distributions = roots.get_distributions()
         roots_values = roots.get_values()
         eps_cfg = _g(self._cfg, "eps", {}) or {}
@@ -103,8 +113,7 @@ class EfficientZeroPolicy(object):
         network_output = self._eval_model.initial_inference(data, roots)
         pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
         roots.prepare_from_inference_no_noise(to_play)  # efficientzero.py:721
-        self._mcts_eval.search(roots, self._eval_model, network_output.latent_state,
-                               network_output.reward_hidden_state, to_play)
+        self._search(self._mcts_eval, roots, self._eval_model, network_output, to_play)
         roots_visit_count_distributions = roots.get_distributions()
         roots_values = roots.get_values()
         for i, env_id in enumerate(ready_env_id):

@@ -88,3 +88,53 @@ def ez_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
             roots.prepare_no_noise(list(out.value_prefix), policy_logits, list(to_play))
         ez_search(tree, roots, model, latent_state_roots, reward_hidden_state_roots, to_play, cfg, device, record)
         return roots.get_distributions(), roots.get_values(), pred_values.reshape(-1), policy_logits
+
+
+def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device="cpu", deterministic=None):
+    """MuZeroMCTSCtree.search  lzero/mcts/tree_search/mcts_ctree.py:267-368 (the reference calls
+    recurrent_inference twice per simulation, :338 and :340-345, and discards the first result; it is called once
+    here, which leaves the outputs unchanged)."""
+    ist = InverseScalarTransform(device=device)
+    with torch.no_grad():
+        model.eval()
+        batch_size = roots.num
+        pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+        latent_state_batch_in_search_path = [latent_state_roots]
+        min_max_stats_lst = tree.MinMaxStatsList(batch_size)
+        min_max_stats_lst.set_delta(cfg["value_delta_max"])
+        kw = {} if deterministic is None else dict(deterministic=deterministic)
+        for simulation_index in range(cfg["num_simulations"]):
+            latent_states = []
+            results = tree.ResultsWrapper(batch_size)
+            ix_l, iy_l, last_actions, virtual_to_play_batch = tree.batch_traverse(
+                roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, list(to_play_batch), **kw)
+            for ix, iy in zip(ix_l, iy_l):
+                latent_states.append(latent_state_batch_in_search_path[ix][iy])
+            latent_states = torch.from_numpy(np.asarray(latent_states)).to(device)
+            last_actions_t = torch.from_numpy(np.asarray(last_actions)).to(device).long()
+            out = model.recurrent_inference(latent_states, last_actions_t)
+            latent_state_batch_in_search_path.append(out.latent_state.detach().cpu().numpy())
+            value = ist(out.value).detach().cpu().numpy()
+            reward = ist(out.reward).detach().cpu().numpy()
+            tree.batch_backpropagate(simulation_index + 1, discount_factor, reward.reshape(-1).tolist(),
+                                     value.reshape(-1).tolist(), out.policy_logits.detach().cpu().numpy().tolist(),
+                                     min_max_stats_lst, results, virtual_to_play_batch)
+
+
+def mz_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, device="cpu", roots_kwargs=None,
+                       deterministic=None):
+    """MuZeroPolicy._forward_collect up to get_distributions/get_values  lzero/policy/muzero.py:745-790."""
+    ist = InverseScalarTransform(device=device)
+    with torch.no_grad():
+        model.eval()
+        out = model.initial_inference(obs)
+        pred_values = ist(out.value).detach().cpu().numpy()
+        latent_state_roots = out.latent_state.detach().cpu().numpy()
+        policy_logits = out.policy_logits.detach().cpu().numpy().tolist()
+        roots = tree.Roots(obs.shape[0], legal_actions, **(roots_kwargs or {}))
+        if noises is not None:
+            roots.prepare(cfg["root_noise_weight"], noises, list(out.reward), policy_logits, list(to_play))
+        else:
+            roots.prepare_no_noise(list(out.reward), policy_logits, list(to_play))
+        mz_search(tree, roots, model, latent_state_roots, to_play, cfg, device, deterministic)
+        return roots.get_distributions(), roots.get_values(), pred_values.reshape(-1), policy_logits

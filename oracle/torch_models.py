@@ -222,6 +222,76 @@ class EfficientZeroModel(nn.Module):  # efficientzero_model.py:20-382 (inference
         return EZNetworkOutput(value, value_prefix, policy_logits, next_latent_state, reward_hidden_state)
 
 
+class MZDynamicsNetwork(nn.Module):  # lzero/model/muzero_model.py:419-538
+    def __init__(self, action_encoding_dim, num_res_blocks, num_channels, reward_head_channels, reward_hidden,
+                 support_size, flat_reward):
+        super().__init__()
+        self.action_encoding_dim = action_encoding_dim
+        self.flat_reward = flat_reward
+        self.activation = nn.ReLU(inplace=True)
+        self.conv = nn.Conv2d(num_channels, num_channels - action_encoding_dim, 3, 1, 1, bias=False)
+        self.norm_common = nn.BatchNorm2d(num_channels - action_encoding_dim)
+        self.resblocks = nn.ModuleList([ResBlock(num_channels - action_encoding_dim) for _ in range(num_res_blocks)])
+        self.conv1x1_reward = nn.Conv2d(num_channels - action_encoding_dim, reward_head_channels, 1)
+        self.norm_reward = nn.BatchNorm2d(reward_head_channels)
+        self.fc_reward_head = mlp(flat_reward, reward_hidden, support_size)
+
+    def forward(self, state_action_encoding):
+        state_encoding = state_action_encoding[:, :-self.action_encoding_dim, :, :]
+        x = self.norm_common(self.conv(state_action_encoding))
+        x = x + state_encoding
+        x = self.activation(x)
+        for b in self.resblocks:
+            x = b(x)
+        next_latent_state = x
+        x = self.activation(self.norm_reward(self.conv1x1_reward(next_latent_state)))
+        reward = self.fc_reward_head(x.view(x.shape[0], -1))
+        return next_latent_state, reward
+
+
+class MuZeroModel(nn.Module):  # lzero/model/muzero_model.py:20-374 (inference graph only)
+    def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, num_res_blocks=1, num_channels=64,
+                 reward_head_channels=16, value_head_channels=16, policy_head_channels=16,
+                 reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
+                 reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True):
+        super().__init__()
+        self.action_space_size = action_space_size
+        self.reward_support_size = len(torch.arange(*reward_support_range))
+        self.value_support_size = len(torch.arange(*value_support_range))
+        if observation_shape[1] == 96:
+            latent_size = math.ceil(observation_shape[1] / 16) * math.ceil(observation_shape[2] / 16)
+        elif observation_shape[1] == 64:
+            latent_size = math.ceil(observation_shape[1] / 8) * math.ceil(observation_shape[2] / 8)
+        else:
+            latent_size = observation_shape[1] * observation_shape[2]
+        hw = latent_size if downsample else observation_shape[1] * observation_shape[2]
+        self.representation_network = RepresentationNetwork(observation_shape, num_res_blocks, num_channels, downsample)
+        self.dynamics_network = MZDynamicsNetwork(action_space_size, num_res_blocks, num_channels + action_space_size,
+                                                  reward_head_channels, reward_head_hidden_channels[0],
+                                                  self.reward_support_size, reward_head_channels * hw)
+        self.prediction_network = PredictionNetwork(action_space_size, num_res_blocks, num_channels, value_head_channels,
+                                                    policy_head_channels, value_head_hidden_channels[0],
+                                                    policy_head_hidden_channels[0], self.value_support_size,
+                                                    value_head_channels * hw, policy_head_channels * hw)
+
+    def initial_inference(self, obs):
+        batch_size = obs.size(0)
+        latent_state = self.representation_network(obs)
+        policy_logits, value = self.prediction_network(latent_state)
+        return MZNetworkOutput(value, [0. for _ in range(batch_size)], policy_logits, latent_state)
+
+    def recurrent_inference(self, latent_state, action):
+        if len(action.shape) == 1:
+            action = action.unsqueeze(-1)
+        action_one_hot = torch.zeros(action.shape[0], self.action_space_size, device=action.device)
+        action_one_hot.scatter_(1, action.long(), 1)
+        action_encoding = action_one_hot.unsqueeze(-1).unsqueeze(-1).expand(
+            latent_state.shape[0], self.action_space_size, latent_state.shape[2], latent_state.shape[3])
+        next_latent_state, reward = self.dynamics_network(torch.cat((latent_state, action_encoding), dim=1))
+        policy_logits, value = self.prediction_network(next_latent_state)
+        return MZNetworkOutput(value, reward, policy_logits, next_latent_state)
+
+
 class InverseScalarTransform(object):  # scaling_transform.py:64-92
     def __init__(self, support_range=(-300., 301., 1.), categorical_distribution=True, device="cpu"):
         self.value_support = torch.arange(*support_range, dtype=torch.float32).unsqueeze(0).to(device)

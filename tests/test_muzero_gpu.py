@@ -1,0 +1,96 @@
+"""GPU: MuZero conv model (lz_model_cfg.model_type 1) + MuZero tree, fused search, vs the oracle pipeline
+(torch restatement of lzero/model/muzero_model.py + CPU ctree oracle + restated MuZeroMCTSCtree.search)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(num_simulations=24, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
+           root_noise_weight=0.25, root_dirichlet_alpha=0.3)
+
+
+def _models(A, seed=0):
+    from oracle import torch_models as tm
+    from lightzero_amd.model.muzero_model import MuZeroModel
+    ref = tm.synthetic_init(tm.MuZeroModel(action_space_size=A), seed=seed)
+    dev = MuZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
+    return ref, dev
+
+
+def test_muzero_teacher_forced_and_end_to_end():
+    from oracle import ctree as octree, search as osearch, torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    B, A, S = 32, 4, CFG["num_simulations"]
+    ref, model = _models(A)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(11))
+    rng = np.random.default_rng(2)
+    noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    legal = [list(range(A))] * B
+    lib = L.lib()
+    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    out = model.initial_inference(obs.cuda().contiguous(), roots)
+    roots.prepare_from_inference(CFG["root_noise_weight"], noises, [-1] * B)
+    L.check(lib.lz_roots_enable_trace(roots._h, 1))
+    L.check(lib.lz_search(roots._h, S, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], 0, CFG["value_delta_max"]))
+    trace = np.zeros((S, B, 4), np.int32)
+    L.check(lib.lz_roots_read_trace(roots._h, S, trace.reshape(-1)))
+    lat = np.zeros((S + 1, B, 64, 6, 6), np.float32)
+    rew = np.zeros((S + 1, B), np.float32); val = np.zeros_like(rew); pol = np.zeros((S + 1, B, A), np.float32)
+    for s in range(S + 1):
+        L.check(lib.lz_roots_read_latent(roots._h, s, lat[s].reshape(-1)))
+        L.check(lib.lz_roots_read_sim_outputs(roots._h, s, rew[s], val[s], pol[s].reshape(-1)))
+    ist = tm.InverseScalarTransform()
+    ar = np.arange(B)
+    # tolerances relative to the magnitude: the h^-1 quantisation step grows like 1.3e-4 * (1 + |x|), and
+    # without the LSTM reset the random-weight latents / values drift upwards with depth
+    def rel(a, b):
+        return float((np.abs(a - b) / (1.0 + np.abs(b))).max())
+    worst = dict(lat=0.0, pol=0.0, rew=0.0, val=0.0)
+    for s in range(S):
+        ix, act = trace[s, :, 0], trace[s, :, 1]
+        with torch.no_grad():
+            o = ref.recurrent_inference(torch.from_numpy(lat[ix, ar]), torch.from_numpy(act).long())
+            r_rew = ist(o.reward).reshape(-1).numpy(); r_val = ist(o.value).reshape(-1).numpy()
+        worst["lat"] = max(worst["lat"], rel(lat[s + 1], o.latent_state.numpy()))
+        worst["pol"] = max(worst["pol"], rel(pol[s + 1], o.policy_logits.numpy()))
+        worst["rew"] = max(worst["rew"], rel(rew[s + 1], r_rew))
+        worst["val"] = max(worst["val"], rel(val[s + 1], r_val))
+    print("muzero worst |d| / (1 + |ref|):", worst, "max |value|", float(np.abs(val).max()))
+    assert worst["lat"] < 2e-5 and worst["pol"] < 2e-5 and worst["rew"] < 3e-4 and worst["val"] < 3e-4, worst
+    # end to end vs the oracle pipeline
+    o_dist, o_val, o_pred, o_logits = osearch.mz_forward_collect(
+        octree.mz_tree, ref, obs, legal, noises, [-1] * B, CFG, roots_kwargs=dict(action_space_size=A, max_simulations=S),
+        deterministic=True)
+    d_dist, d_val = roots.get_distributions(), np.array(roots.get_values())
+    same = np.array([a == b for a, b in zip(o_dist, d_dist)])
+    print("muzero identical visit distributions: %d / %d" % (same.sum(), B))
+    assert same.mean() >= 0.85
+    assert (np.abs(np.array(o_val) - d_val) / (1 + np.abs(d_val)))[same].max() < 2e-3
+    assert (np.abs(o_pred - out.value) / (1 + np.abs(o_pred))).max() < 3e-4
+
+
+def test_muzero_policy_contract():
+    from lightzero_amd.policy.muzero import MuZeroPolicy
+    B, A = 6, 4
+    ref, model = _models(A, seed=3)
+    policy = MuZeroPolicy(dict(CFG, num_simulations=8), model)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(4)).cuda()
+    mask = np.ones((B, A), np.float32)
+    mask[0, 1] = 0
+    out = policy._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B, epsilon=0.0)
+    assert sorted(out) == list(range(B))
+    assert len(out[0]["visit_count_distributions"]) == 3 and sum(out[1]["visit_count_distributions"]) == 8
+    out2 = policy._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B, epsilon=0.0)  # roots re-armed
+    assert sum(out2[2]["visit_count_distributions"]) == 8
+
+
+def test_mismatched_tree_and_model_is_loud():
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    ref, model = _models(4, seed=5)
+    roots = ez_tree.Roots(2, [[0, 1, 2, 3]] * 2, action_space_size=4, max_simulations=4)
+    with pytest.raises(L.LzError):
+        model.initial_inference(np.zeros((2, 4, 96, 96), np.float32), roots)
