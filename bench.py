@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the 256 envs of a GPU into this many independent sub-batches, each on its own engine "
+                         "(HIP stream): the MFMA-bound conv chain of one overlaps the latency-bound tree / LSTM / head "
+                         "kernels of the other")
     ap.add_argument("--tiebreak", choices=["first", "random"], default="random",
                     help="random = the reference's stochastic tie rule (default, like collection); first = parity mode")
     args = ap.parse_args()
@@ -83,19 +87,34 @@ def main():
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
     lib = L.lib()
     ref_model = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=ACTIONS), seed=0)
-    eng = L.default_engine(local_rank)
-    model = EfficientZeroModel(action_space_size=ACTIONS, engine=eng).load_state_dict(ref_model.state_dict())
+    NS = max(1, args.streams)
+    assert ENVS % NS == 0
+    EPS = ENVS // NS  # envs per sub-batch
+    engs, models = [], []
+    for k in range(NS):
+        if k == 0:
+            e = L.default_engine(local_rank)
+        else:
+            e = L.P()
+            L.check(lib.lz_engine_create(local_rank, ctypes.byref(e)))
+        engs.append(e)
+        models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e).load_state_dict(ref_model.state_dict()))
+    eng = engs[0]
     g = torch.Generator().manual_seed(1000 + rank)
     obs_cpu = torch.rand(ENVS, 4, 96, 96, generator=g)
     obs = obs_cpu.cuda().contiguous()
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
     noise_steps = [rng.dirichlet([0.3] * ACTIONS, size=ENVS).astype(np.float32) for _ in range(total)]
-    legal = [list(range(ACTIONS))] * ENVS
-    roots = ez_tree.Roots(ENVS, legal, action_space_size=ACTIONS, max_simulations=SIMS, engine=eng)
-    roots.set_tiebreak(0 if args.tiebreak == "first" else 1, seed=rank + 1)
-    roots._ensure(ACTIONS)
-    to_play = L.i32([-1] * ENVS)
+    legal = [list(range(ACTIONS))] * EPS
+    roots_l = []
+    for k in range(NS):
+        r = ez_tree.Roots(EPS, legal, action_space_size=ACTIONS, max_simulations=SIMS, engine=engs[k])
+        r.set_tiebreak(0 if args.tiebreak == "first" else 1, seed=rank * 16 + k + 1)
+        r._ensure(ACTIONS)
+        roots_l.append(r)
+    to_play = L.i32([-1] * EPS)
+    obs_parts = [obs[k * EPS:(k + 1) * EPS].contiguous() for k in range(NS)]
     dist_out = np.zeros((ENVS, ACTIONS), np.int32)
     cnt_out = np.zeros(ENVS, np.int32)
     val_out = np.zeros(ENVS, np.float32)
@@ -104,14 +123,20 @@ def main():
     rows_dev = torch.zeros(ENVS, 4 + ACTIONS, device="cuda")
 
     def step(i):
-        L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
-        L.check(lib.lz_roots_prepare_from_inference(roots._h, CFG["root_noise_weight"],
-                                                    noise_steps[i].ctypes.data, to_play))
-        L.check(lib.lz_search(roots._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"],
-                              CFG["lstm_horizon_len"], CFG["value_delta_max"]))
-        L.check(lib.lz_roots_get_distributions(roots._h, dist_out, cnt_out))
-        L.check(lib.lz_roots_get_values(roots._h, val_out))
-        L.check(lib.lz_roots_get_root_outputs(roots._h, pred_out, logit_out.reshape(-1)))
+        for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
+            L.check(lib.lz_initial_inference(r._h, obs_parts[k].data_ptr()))
+            nz = np.ascontiguousarray(noise_steps[i][k * EPS:(k + 1) * EPS])
+            L.check(lib.lz_roots_prepare_from_inference(r._h, CFG["root_noise_weight"], nz.ctypes.data, to_play))
+            L.check(lib.lz_search(r._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"],
+                                  CFG["lstm_horizon_len"], CFG["value_delta_max"]))
+        for k, r in enumerate(roots_l):
+            sl = slice(k * EPS, (k + 1) * EPS)
+            d = np.zeros((EPS, ACTIONS), np.int32); c = np.zeros(EPS, np.int32); v = np.zeros(EPS, np.float32)
+            p = np.zeros(EPS, np.float32); lg = np.zeros((EPS, ACTIONS), np.float32)
+            L.check(lib.lz_roots_get_distributions(r._h, d, c))
+            L.check(lib.lz_roots_get_values(r._h, v))
+            L.check(lib.lz_roots_get_root_outputs(r._h, p, lg.reshape(-1)))
+            dist_out[sl], cnt_out[sl], val_out[sl], pred_out[sl], logit_out[sl] = d, c, v, p, lg
         if world > 1:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI)
             rows = np.concatenate([np.zeros((ENVS, 1), np.float32), val_out[:, None], pred_out[:, None],
                                    cnt_out[:, None].astype(np.float32), dist_out.astype(np.float32)], 1)
@@ -121,13 +146,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    L.check(lib.lz_engine_synchronize(eng))
+    for e in engs:
+        L.check(lib.lz_engine_synchronize(e))
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-    L.check(lib.lz_engine_synchronize(eng))
+    for e in engs:
+        L.check(lib.lz_engine_synchronize(e))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -159,7 +186,7 @@ def main():
         value = world * ENVS * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         avg_us = tot_ms.value / max(n_launch.value, 1) * 1e3
-        achieved = (ENVS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
+        achieved = (EPS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
         out = {
             "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +195,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: Atari Pong EfficientZero, obs 4x96x96, 50 sims, "
                                    "256 envs per GPU, A=6, support 601, LSTM 512; synthetic obs, seed-0 random-init weights",
                        "envs_per_gpu": ENVS, "num_simulations": SIMS, "mcts_sims_per_s": value * SIMS,
-                       "tiebreak": args.tiebreak, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
+                       "tiebreak": args.tiebreak, "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "k_chain (per root: dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
@@ -177,7 +204,7 @@ def main():
                          "avg_launch_us": avg_us, "launches_timed": n_launch.value,
                          "timing": "HIP event pairs on the engine stream around each launch, %d eager steps run right after the "
                                    "graph-replayed timed region" % prof_steps,
-                         "algorithmic_flop_per_launch": ENVS * FLOP_CHAIN},
+                         "algorithmic_flop_per_launch": EPS * FLOP_CHAIN},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]])

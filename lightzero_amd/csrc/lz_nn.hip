@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
     auto sA = [&](int buf) -> float * { return smem + buf * MROWS * PS; };
     auto sB = [&](int buf) -> float * { return smem + 2 * MROWS * PS + buf * 32 * PS; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r0 = blockIdx.x * MROWS, n0 = blockIdx.y * 32;
+    // blockIdx.x walks the gate columns: consecutive workgroups land on different XCDs (block b -> XCD b % 8), so
+    // each XCD's L2 fetches only 1/8 of the 8.9 MB weight matrix instead of all of it (71 MB -> 18 MB of fabric reads)
+    const int r0 = blockIdx.y * MROWS, n0 = blockIdx.x * 32;
     const int K = a.KX + a.H;
     constexpr int nchunk = NCHUNK;  // K / 64, compile-time: the chunk loop is straight-line code so that the
                                     // compiler's vmcnt bookkeeping keeps D chunks of loads in flight
@@ -974,7 +976,7 @@ static void launch_lstm_m(const lz_lstm_args &a, hipStream_t s)
     size_t lds = (size_t)(2 * MROWS * 68 + 2 * 32 * 68) * 4;
     const size_t red = (size_t)(4 * (MROWS / 16) * 2 * 4 * 64 + MROWS * 33) * 4;
     if (lds < red) lds = red;
-    dim3 grid((a.B + MROWS - 1) / MROWS, (4 * a.H) / 32), block(256);
+    dim3 grid((4 * a.H) / 32, (a.B + MROWS - 1) / MROWS), block(256);
     const int nchunk = (a.KX + a.H) / 64;
     if (nchunk == 17) hipLaunchKernelGGL((k_lstm<17, MROWS>), grid, block, lds, s, a);
     else if (nchunk == 13) hipLaunchKernelGGL((k_lstm<13, MROWS>), grid, block, lds, s, a);

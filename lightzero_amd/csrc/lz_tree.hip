@@ -155,7 +155,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
         const float node_vp = t.node_vp[(size_t)b * NN + node];
         const int node_reset = t.node_reset[(size_t)b * NN + node];
         float prior[NC], val[NC], tr[NC], score[NC];
-        int vis[NC], act[NC];
+        int vis[NC], act[NC], chd[NC];  // chd: child node ids, fetched with the edges (one round trip per level)
         // ---- load the children (one 16-byte edge per lane) and compute_mean_q (cnode.cpp:173-212)
         float total = 0.0f;
         int nv = 0;
@@ -165,6 +165,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
             const bool valid = j < n;
             act[c] = valid ? (is_root ? t.legal[(size_t)b * A + j] : j) : 0;
             float4 e = valid ? edge_b[(size_t)node * A + act[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            chd[c] = valid ? child_b[(size_t)node * A + act[c]] : -1;
             prior[c] = e.x;
             vis[c] = __float_as_int(e.y);
             val[c] = (vis[c] == 0) ? 0.0f : e.z / (float)vis[c];  // CNode::value cnode.cpp:223-239
@@ -243,23 +244,24 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
                 }
             }
         }
-        int action = 0, sel_visit = 0;
+        int action = 0, sel_visit = 0, nxt = -3;
         if (pos >= 0 && best > LZ_FLOAT_MIN) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if ((pos >> 6) == c) {
                     action = rl_i(act[c], pos & 63);
                     sel_visit = rl_i(vis[c], pos & 63);
+                    nxt = rl_i(chd[c], pos & 63);
                 }
             }
         }
+        if (nxt == -3) nxt = uni(child_b[(size_t)node * A + action]);  // degenerate fallback (action 0 by default)
         if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
         if (lane == 0) {
             t.node_best[(size_t)b * NN + node] = action;
             t.path_node[(size_t)b * NN + depth] = node;
             t.path_act[(size_t)b * NN + depth] = action;
         }
-        const int nxt = uni(child_b[(size_t)node * A + action]);
         last_action = action;
         depth += 1;
         if (nxt < 0) break;  // reached an unexpanded child: the leaf
