@@ -122,7 +122,7 @@ int lz_roots_get_minmax(lz_roots *r, float *h_out);
  * (lzero/policy/scaling_transform.py:82-92) fused into the value / value-prefix heads.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct lz_model_cfg {
-    int model_type;         /* 0: EfficientZeroModel (conv, downsample=True)   1: MuZeroModel (conv, downsample=True) */
+    int model_type;         /* 0: EfficientZeroModel (conv)   1: MuZeroModel (conv) */
     int obs_c, obs_h, obs_w;/* observation_shape, e.g. 4, 96, 96 */
     int action_space_size;
     int num_channels;       /* 64 */
@@ -132,6 +132,8 @@ typedef struct lz_model_cfg {
     int support_size;       /* 601 */
     float support_min;      /* -300 */
     float bn_eps;           /* 1e-5 */
+    int downsample;         /* 1: DownSample tower, 96x96 obs -> 6x6 latent (Atari); 0: latent grid = obs grid (board games,
+                               e.g. Go 9x9: obs 17x9x9) */
 } lz_model_cfg;
 
 /* One model per engine.  Weights are ingested by their reference state_dict names

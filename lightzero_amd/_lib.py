@@ -18,7 +18,7 @@ class ModelCfg(ctypes.Structure):
     _fields_ = [("model_type", ctypes.c_int), ("obs_c", ctypes.c_int), ("obs_h", ctypes.c_int), ("obs_w", ctypes.c_int),
                 ("action_space_size", ctypes.c_int), ("num_channels", ctypes.c_int), ("lstm_hidden_size", ctypes.c_int),
                 ("head_channels", ctypes.c_int), ("head_hidden", ctypes.c_int), ("support_size", ctypes.c_int),
-                ("support_min", ctypes.c_float), ("bn_eps", ctypes.c_float)]
+                ("support_min", ctypes.c_float), ("bn_eps", ctypes.c_float), ("downsample", ctypes.c_int)]
 
 
 _lib = None

@@ -359,6 +359,37 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ ob
     }
 }
 
+// first layer of a no-downsample RepresentationNetwork (board games, common.py:735-741,768-771): conv3x3 stride 1 from
+// NCHW observations [B][C][H][W] to NHWC [B][H*W][64], + BN + ReLU.  thread = (pixel, 8 output channels).
+__global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ obs, const float *__restrict__ w,
+                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                 float *__restrict__ out, int B, int C, int H, int W)
+{
+    extern __shared__ float sw[];  // [9][C][64]
+    for (int i = threadIdx.x; i < 9 * C * 64; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const int g = threadIdx.x & 7;
+    const int64_t m = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (m >= (int64_t)B * H * W) return;
+    const int b = (int)(m / (H * W)), p = (int)(m - (int64_t)b * H * W), y = p / W, x = p - y * W;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        for (int ci = 0; ci < C; ++ci) {
+            const float xv = obs[(((size_t)b * C + ci) * H + iy) * W + ix];
+            const float *wr = sw + (t * C + ci) * 64 + g * 8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += xv * wr[c];
+        }
+    }
+    float *o = out + (size_t)m * 64 + g * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = fmaxf(acc[c] * scale[g * 8 + c] + shift[g * 8 + c], 0.0f);
+}
+
 // AvgPool2d(3, stride 2, pad 1), count_include_pad=True (divide by 9), NHWC, float4 per thread
 __global__ __launch_bounds__(256) void k_avgpool(const float *__restrict__ in, float *__restrict__ out, int B, int Hin,
                                                  int Win, int C)
@@ -448,10 +479,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(lz_c1_args a)
 // Activations ping-pong between four LDS buffers; weight fragments come straight from L2 into registers, four
 // steps ahead.  432 MFMAs per wave per layer = 5.8 us at the fp32-matrix issue rate.
 // ------------------------------------------------------------------------------------------------
+template <int GW, int GH>
 __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 {
-    constexpr int PS = 68, HW = 36, BUF = (HW + 1) * PS;  // 36 pixels + one all-zero pixel
-    __shared__ __attribute__((aligned(16))) float smem[4 * BUF];
+    constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS;  // HW pixels + one all-zero pixel
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
     // first weight fragments are requested before anything else so that their L2 round trip overlaps the staging
@@ -472,32 +504,33 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
     {
         const float *src = a.in + (size_t)b * HW * 64;
         if (a.gather_ix) src += (size_t)a.gather_ix[b] * a.slot_stride;
-        float4 v[3];
+        constexpr int NU = (HW * 16 + 255) / 256;
+        float4 v[NU];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int idx = u * 256 + tid;
             v[u] = vzero4();
             if (idx < HW * 16) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int idx = u * 256 + tid;
             if (idx < HW * 16) *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
         }
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
     }
-    // geometry of this lane's row in each of the 3 M-tiles (the same for every layer)
+    // geometry of this lane's row in each of the MT M-tiles (the same for every layer)
     const int zoff = HW * PS;
-    int base[3], mask[3];
+    int base[MT], mask[MT];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < MT; ++i) {
         const int row = i * 16 + (lane & 15);
-        const int p = min(row, HW - 1), y = p / 6, x = p - y * 6;
+        const int p = min(row, HW - 1), y = p / GW, x = p - y * GW;
         int mk = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            mk |= ((iy >= 0) & (iy < 6) & (ix >= 0) & (ix < 6) & (row < HW)) << t;
+            mk |= ((iy >= 0) & (iy < GH) & (ix >= 0) & (ix < GW) & (row < HW)) << t;
         }
         int bs = p * PS;
         asm volatile("" : "+v"(mk), "+v"(bs));
@@ -511,11 +544,11 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
     // boundaries (the next layer's first fragments are in flight during this layer's epilogue and barrier); the
     // A fragments of step s+1 are read from LDS before the MFMAs of step s issue.  sched_barrier pins that order
     // (left alone, the scheduler sinks the prefetches next to their uses and exposes the L2 latency).
-    auto fetch_a = [&](const float *sIn, int s, float4 (&af)[3]) {
+    auto fetch_a = [&](const float *sIn, int s, float4 (&af)[MT]) {
         const int t = s >> 2, g = s & 3;
-        const int toff = ((t / 3 - 1) * 6 + (t % 3 - 1)) * PS;
+        const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PS;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < MT; ++i) {
             const int bit = (mask[i] >> t) & 1;
             const int off = zoff + bit * (base[i] + toff - zoff);
             af[i] = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
@@ -528,10 +561,10 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         const bool more = L + 1 < a.nlayers;
         const float4 *wc = reinterpret_cast<const float4 *>(ly.wf) + (size_t)wv * 36 * 64 + lane;
         const float4 *wn = reinterpret_cast<const float4 *>(a.layer[more ? L + 1 : L].wf) + (size_t)wv * 36 * 64 + lane;
-        f32x4 acc[3];
+        f32x4 acc[MT];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4 af[2][3];
+        for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 af[2][MT];
         fetch_a(sIn, 0, af[0]);
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
@@ -542,7 +575,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < MT; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -551,7 +584,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         const float sc = ly.scale[col], sh = ly.shift[col];
         const float *tab = ly.act ? a.act_table + (size_t)a.action[b] * HW * 64 : nullptr;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = i * 16 + 4 * (lane >> 4) + q;
@@ -571,14 +604,14 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
     if (wv < a.nc1) {
         const lz_c1_job &jb = a.c1[wv];
         const float *sIn = smem + a.c1_in[wv] * BUF + kq4;
-        f32x4 acc[3];
+        f32x4 acc[MT];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 bfr = c1w[g];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 const int row = i * 16 + (lane & 15);
                 const int off = (row < HW) ? row * PS : zoff;
                 const float4 af = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
@@ -589,7 +622,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         const int col = lane & 15;
         const float bi = jb.bias[col], sc = jb.scale[col], sh = jb.shift[col];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = i * 16 + 4 * (lane >> 4) + q;
@@ -952,6 +985,13 @@ void lz_launch_conv_first(const float *obs, const float *w, const float *scale, 
     else if (C == 12 && Cout == 32) hipLaunchKernelGGL((k_conv_first<12, 32>), grid, block, 0, s, obs, w, scale, shift, out, B, H, W);
 }
 
+void lz_launch_conv_in(const float *obs, const float *w, const float *scale, const float *shift, float *out, int B, int C,
+                       int H, int W, hipStream_t s)
+{
+    const int64_t M = (int64_t)B * H * W;
+    hipLaunchKernelGGL(k_conv_in, dim3((unsigned)((M + 31) / 32)), dim3(256), (size_t)9 * C * 64 * 4, s, obs, w, scale, shift, out, B, C, H, W);
+}
+
 void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s)
 {
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
@@ -966,7 +1006,8 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_chain, dim3(a.B), dim3(256), 0, s, a);
+    if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)4 * 37 * 68 * 4, s, a);
+    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)4 * 82 * 68 * 4, s, a);
 }
 
 template <int MROWS>

@@ -31,6 +31,10 @@ void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s
 void lz_launch_conv_first(const float *obs_nchw, const float *w /*[9][C][Cout]*/, const float *scale,
                           const float *shift, float *out, int B, int C, int H, int W, int Cout, hipStream_t s);
 
+// first layer of a no-downsample representation network: conv3x3 stride 1 from NCHW obs to NHWC [B][H*W][64] + BN + ReLU
+void lz_launch_conv_in(const float *obs_nchw, const float *w /*[9][C][64]*/, const float *scale, const float *shift,
+                       float *out, int B, int C, int H, int W, hipStream_t s);
+
 // AvgPool2d(kernel 3, stride 2, pad 1, count_include_pad) on NHWC
 void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s);
 
@@ -72,6 +76,7 @@ struct lz_chain_args {
     int c1_in[3];
     int nc1;
     int B;
+    int gw, gh;                  // latent grid (6x6 Atari with downsample, 9x9 Go); compiled instances: 6x6, 9x9
 };
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s);
 

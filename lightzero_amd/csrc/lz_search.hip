@@ -41,7 +41,9 @@ struct lz_model {
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
     std::vector<void *> allocs;
-    int HWl = 0;  // latent pixels (6x6 = 36)
+    int HWl = 0;  // latent pixels (6x6 = 36 with downsample; obs_h*obs_w without)
+    int GW = 6, GH = 6;
+    ConvW rin;    // no-downsample input conv (weights [9][C][64] in rin.w)
     // representation
     float *first_w = nullptr, *first_s = nullptr, *first_t = nullptr;
     ConvW r1a, r1b, dn1, dn2, dn3, r2a, r2b, r3a, r3b, rpa, rpb;
@@ -74,8 +76,13 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(e != nullptr && cfg != nullptr, "NULL argument");
     LZ_REQUIRE(cfg->model_type == 0 || cfg->model_type == 1, "model_type must be 0 (EfficientZeroModel) or 1 (MuZeroModel), conv + downsample");
     LZ_REQUIRE(cfg->num_channels == 64, "num_channels must be 64");
-    LZ_REQUIRE(cfg->obs_h == 96 && cfg->obs_w == 96, "observation must be 96x96 (downsample path)");
-    LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
+    if (cfg->downsample) {
+        LZ_REQUIRE(cfg->obs_h == 96 && cfg->obs_w == 96, "observation must be 96x96 on the downsample path");
+        LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
+    } else {
+        LZ_REQUIRE(cfg->obs_h == 9 && cfg->obs_w == 9, "without downsample the compiled latent grid is 9x9 (Go)");
+        LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_c <= 64, "obs_c must be in [1, 64]");
+    }
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
@@ -85,7 +92,9 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
     e->model->cfg = *cfg;
     if (e->model->cfg.bn_eps <= 0) e->model->cfg.bn_eps = 1e-5f;
-    e->model->HWl = 36;
+    e->model->GW = cfg->downsample ? 6 : cfg->obs_w;
+    e->model->GH = cfg->downsample ? 6 : cfg->obs_h;
+    e->model->HWl = e->model->GW * e->model->GH;
     return LZ_OK;
 }
 
@@ -236,6 +245,21 @@ extern "C" int lz_model_finalize(lz_engine *e)
     Builder b{m, ""};
     // ---- representation (common.py:266-365, :706-787)
     {
+        if (!c.downsample) {
+            // board games: conv3x3(obs_c -> C) + BN + ReLU (common.py:735-741)
+            const HostTensor *w = b.get("representation_network.conv.weight", {C, c.obs_c, 3, 3});
+            std::vector<float> sc, sh;
+            b.bn("representation_network.norm", C, sc, sh);
+            if (w) {
+                std::vector<float> p((size_t)9 * c.obs_c * C);  // [tap][ci][co]
+                for (int co = 0; co < C; ++co)
+                    for (int ci = 0; ci < c.obs_c; ++ci)
+                        for (int t = 0; t < 9; ++t) p[((size_t)t * c.obs_c + ci) * C + co] = w->data[((size_t)co * c.obs_c + ci) * 9 + t];
+                m->rin.w = b.upload(p);
+                m->rin.scale = b.upload(sc);
+                m->rin.shift = b.upload(sh);
+            }
+        } else {
         const std::string d = "representation_network.downsample_net.";
         const HostTensor *w = b.get(d + "conv1.weight", {C2, c.obs_c, 3, 3});
         std::vector<float> sc, sh;
@@ -258,6 +282,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->r2b = b.resconv(d + "resblocks2.0", 2, C, C);
         m->r3a = b.resconv(d + "resblocks3.0", 1, C, C);
         m->r3b = b.resconv(d + "resblocks3.0", 2, C, C);
+        }
         m->rpa = b.resconv("representation_network.resblocks.0", 1, C, C);
         m->rpb = b.resconv("representation_network.resblocks.0", 2, C, C);
     }
@@ -269,18 +294,18 @@ extern "C" int lz_model_finalize(lz_engine *e)
         // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image
         const HostTensor *w = b.get(d + "conv.weight", {C, C + A, 3, 3});
         if (w) {
-            const int S = 6;
+            const int SW = m->GW, SH = m->GH;
             std::vector<float> tab((size_t)A * HW * C);
             for (int a = 0; a < A; ++a)
-                for (int y = 0; y < S; ++y)
-                    for (int x = 0; x < S; ++x)
+                for (int y = 0; y < SH; ++y)
+                    for (int x = 0; x < SW; ++x)
                         for (int co = 0; co < C; ++co) {
                             float acc = 0.0f;
                             for (int t = 0; t < 9; ++t) {
                                 const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-                                if (iy >= 0 && iy < S && ix >= 0 && ix < S) acc += w->data[((size_t)co * (C + A) + C + a) * 9 + t];
+                                if (iy >= 0 && iy < SH && ix >= 0 && ix < SW) acc += w->data[((size_t)co * (C + A) + C + a) * 9 + t];
                             }
-                            tab[((size_t)a * HW + y * S + x) * C + co] = acc;
+                            tab[((size_t)a * HW + y * SW + x) * C + co] = acc;
                         }
             m->act_table = b.upload(tab);
         }
@@ -373,7 +398,8 @@ static int ensure_ws(lz_model *m, int B)
     if (m->ws_B >= B) return LZ_OK;
     for (int i = 0; i < 3; ++i) { if (m->ws[i]) (void)hipFree(m->ws[i]); m->ws[i] = nullptr; }
     const lz_model_cfg &c = m->cfg;
-    const size_t n = (size_t)B * (c.obs_h / 2) * (c.obs_w / 2) * (c.num_channels / 2);  // largest activation
+    const size_t n = c.downsample ? (size_t)B * (c.obs_h / 2) * (c.obs_w / 2) * (c.num_channels / 2)  // largest activation
+                                  : (size_t)B * c.obs_h * c.obs_w * c.num_channels;
     for (int i = 0; i < 3; ++i) LZ_HIP_CHECK(hipMalloc((void **)&m->ws[i], n * 4));
     m->ws_B = B;
     return LZ_OK;
@@ -462,6 +488,9 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     const lz_model_cfg &c = m->cfg;
     const int B = r->t.B, C = c.num_channels, H = c.model_type == 0 ? c.lstm_hidden_size : 0;
     float *w0 = m->ws[0], *w1 = m->ws[1], *w2 = m->ws[2];
+    if (!c.downsample) {
+        lz_launch_conv_in(d_obs, m->rin.w, m->rin.scale, m->rin.shift, w0, B, c.obs_c, c.obs_h, c.obs_w, s);
+    } else {
     // DownSample (common.py:266-365)
     int stage = 0;
 #define LZ_STAGE() do { if (m->debug_stop == ++stage) { LZ_HIP_CHECK(hipStreamSynchronize(s)); return LZ_OK; } } while (0)
@@ -489,12 +518,13 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     LZ_STAGE();
     lz_launch_avgpool(w2, w0, B, 12, 12, C, s);               // w0: 6x6x64
     LZ_STAGE();
+    }
 #undef LZ_STAGE
     // RepresentationNetwork.resblocks (common.py:775-776) -> latent pool slot 0, then the prediction residual block
     // and the value / policy 1x1 convs, all in one LDS-resident chain launch
     {
         lz_chain_args ca{};
-        ca.in = w0; ca.B = B;
+        ca.in = w0; ca.B = B; ca.gw = m->GW; ca.gh = m->GH;
         ca.layer[ca.nlayers++] = chlayer(m->rpa, 0, 1, -1, 1, 0, nullptr);
         ca.layer[ca.nlayers++] = chlayer(m->rpb, 1, 2, 0, 1, 0, r->latent_pool);
         ca.layer[ca.nlayers++] = chlayer(m->pa, 2, 3, -1, 1, 0, nullptr);
@@ -591,7 +621,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     {
         lz_chain_args ca{};
         ca.in = r->latent_pool; ca.gather_ix = t.res_ix; ca.slot_stride = (int64_t)lat_slot;
-        ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B;
+        ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B; ca.gw = m->GW; ca.gh = m->GH;
         ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, 1, 1, nullptr);
         ca.layer[ca.nlayers++] = chlayer(m->dra, 1, 2, -1, 1, 0, nullptr);
         ca.layer[ca.nlayers++] = chlayer(m->drb, 2, 3, 1, 1, 0, next_latent);

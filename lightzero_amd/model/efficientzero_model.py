@@ -21,9 +21,9 @@ class EfficientZeroModel(object):
                  reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
                  categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
                  engine=None, **kwargs):
-        if num_res_blocks != 1 or not downsample or norm_type != 'BN' or not categorical_distribution \
+        if num_res_blocks != 1 or norm_type != 'BN' or not categorical_distribution \
                 or discrete_action_encoding_type != 'one_hot':
-            raise NotImplementedError("engine model: num_res_blocks=1, downsample=True, norm_type='BN', "
+            raise NotImplementedError("engine model: num_res_blocks=1, norm_type='BN', "
                                       "categorical_distribution=True, one_hot action encoding")
         if tuple(reward_support_range) != tuple(value_support_range) or value_support_range[2] != 1.:
             raise NotImplementedError("reward and value supports must be equal with step 1")
@@ -38,7 +38,8 @@ class EfficientZeroModel(object):
         self._engine = engine if engine is not None else L.default_engine()
         cfg = L.ModelCfg(self._model_type, self.observation_shape[0], self.observation_shape[1], self.observation_shape[2],
                          self.action_space_size, self.num_channels, self.lstm_hidden_size, int(value_head_channels),
-                         int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5)
+                         int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5,
+                         1 if downsample else 0)
         L.check(L.lib().lz_model_create(self._engine, ctypes.byref(cfg)))
         self._loaded = False
 
