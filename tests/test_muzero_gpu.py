@@ -94,3 +94,35 @@ def test_mismatched_tree_and_model_is_loud():
     roots = ez_tree.Roots(2, [[0, 1, 2, 3]] * 2, action_space_size=4, max_simulations=4)
     with pytest.raises(L.LzError):
         model.initial_inference(np.zeros((2, 4, 96, 96), np.float32), roots)
+
+
+def test_config3_full_size_properties():
+    """BASELINE configs[2]: Atari Breakout MuZero, 96x96x4, 400 simulations, 1024 roots on one GPU (latent pool 3.8 GB):
+    visit counts sum to S, deterministic tie-break => two runs identical, values finite; prints the wall time."""
+    import time
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    B, A, S = 1024, 4, 400
+    ref, model = _models(A, seed=7)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(8)).cuda().contiguous()
+    legal = [list(range(A))] * B
+    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    res = []
+    for it in range(3):
+        if it:
+            roots.reset(legal)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.initial_inference(obs, roots)
+        roots.prepare_from_inference_no_noise([-1] * B)
+        L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 0, 0.01))
+        d, v = roots.get_distributions(), roots.get_values()
+        dt = time.perf_counter() - t0
+        res.append((d, v))
+        print("config3 run %d: %.1f ms per env-step batch -> %.0f env-steps/s, %.2e sims/s" % (it, dt * 1e3, B / dt, B * S / dt))
+    assert res[1] == res[2] == res[0]
+    assert all(sum(d) == S for d in res[0][0])
+    assert np.isfinite(np.array(res[0][1])).all()
+    depth = max(len(t) for t in roots.get_trajectories())
+    print("config3 max best-action chain length:", depth)
