@@ -483,7 +483,10 @@ template <int GW, int GH>
 __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 {
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS;  // HW pixels + one all-zero pixel
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats, then the
+    float *sTab = smem + 4 * BUF;          // [HW][PS] one-hot-action table slice of this root's action
+    float *sSS = sTab + HW * PS;           // [6 layers][2][64] folded-BN scale / shift: the epilogues read LDS only,
+                                           // a global load there would make the compiler drain the weight ring (vmcnt(0))
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
     // first weight fragments are requested before anything else so that their L2 round trip overlaps the staging
@@ -518,6 +521,24 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
             if (idx < HW * 16) *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
         }
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
+        if (a.act_table) {
+            const float *tsrc = a.act_table + (size_t)a.action[b] * HW * 64;
+            float4 tv[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = min(u * 256 + tid, HW * 16 - 1);
+                tv[u] = *reinterpret_cast<const float4 *>(tsrc + (size_t)idx * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = u * 256 + tid;
+                if (idx < HW * 16) *reinterpret_cast<float4 *>(sTab + (idx >> 4) * PS + (idx & 15) * 4) = tv[u];
+            }
+        }
+        for (int i = tid; i < a.nlayers * 128; i += 256) {
+            const int L = i >> 7, r = i & 127;
+            sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+        }
     }
     // geometry of this lane's row in each of the MT M-tiles (the same for every layer)
     const int zoff = HW * PS;
@@ -581,8 +602,8 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         }
         // epilogue: BN (+ action table) (+ residual) (+ ReLU) -> LDS (and the latent pool)
         const int col = wv * 16 + (lane & 15);
-        const float sc = ly.scale[col], sh = ly.shift[col];
-        const float *tab = ly.act ? a.act_table + (size_t)a.action[b] * HW * 64 : nullptr;
+        const float sc = sSS[L * 128 + col], sh = sSS[L * 128 + 64 + col];
+        const bool tab = ly.act != 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
                 const int row = i * 16 + 4 * (lane >> 4) + q;
                 if (row < HW) {
                     float v = acc[i][q];
-                    if (tab) v += tab[row * 64 + col];
+                    if (tab) v += sTab[row * PS + col];
                     v = v * sc + sh;
                     if (ly.res >= 0) v += smem[ly.res * BUF + row * PS + col];
                     if (ly.relu) v = fmaxf(v, 0.0f);
@@ -829,29 +850,53 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
     float *xs = smem;                    // [EPB][K1]
     float *hid = xs + EPB * K1;          // [EPB][HID]
     float *scr = hid + EPB * HID;        // [4 * 8]
+    // Every weight this thread will need is requested up front (none depends on the activations): the kernel is
+    // a chain of three dependent stages, and each exposed L2 round trip costs as much as the arithmetic.
+    constexpr int NW1 = 18, NPT = 3;     // layer-1 float4 per thread kept in registers; outputs per thread (NOUT <= 768)
+    const int u = tid >> 3, part = tid & 7;
+    const float *wr = h.w1 + (size_t)min(u, HID - 1) * K1;
+    const int n1 = (K1 - part * 4 + 31) / 32;  // layer-1 iterations of this thread (k = part*4 + 32 i < K1)
+    f32x4 w1r[NW1];
+#pragma unroll
+    for (int i = 0; i < NW1; ++i) w1r[i] = *reinterpret_cast<const f32x4 *>(wr + min(part * 4 + 32 * i, K1 - 4));
+    float w2r[NPT][HID], b2r[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int n = min(tid + i * 256, h.NOUT - 1);
+        b2r[i] = h.b2[n];
+#pragma unroll
+        for (int k = 0; k < HID; ++k) w2r[i][k] = h.w2t[(size_t)k * h.NOUT + n];
+    }
+    const float b1v = h.b1[min(u, HID - 1)], s1v = h.s1[min(u, HID - 1)], t1v = h.t1[min(u, HID - 1)];
     for (int i = tid; i < EPB * (K1 / 4); i += 256) {  // 16-channel runs are contiguous: float4 loads
-        const int e = i / (K1 / 4), k = (i - e * (K1 / 4)) * 4, b = b0 + e;
-        float4 v = vzero4();
-        if (b < B) v = *reinterpret_cast<const float4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
-        *reinterpret_cast<float4 *>(xs + e * K1 + k) = v;
+        const int e = i / (K1 / 4), k = (i - e * (K1 / 4)) * 4, b = min(b0 + e, B - 1);
+        *reinterpret_cast<float4 *>(xs + e * K1 + k) =
+            *reinterpret_cast<const float4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
     }
     __syncthreads();
     // ---- layer 1: HID units x 8 K-parts; a unit's row is read 128 B at a time by its 8 lanes
     {
-        const int u = tid >> 3, part = tid & 7;
         float acc[EPB];
 #pragma unroll
         for (int e = 0; e < EPB; ++e) acc[e] = 0.0f;
-        if (u < HID) {
-            const float *wr = h.w1 + (size_t)u * K1;
-#pragma unroll 9
-            for (int k = part * 4; k < K1; k += 32) {
-                const float4 wv4 = *reinterpret_cast<const float4 *>(wr + k);
+#pragma unroll
+        for (int i = 0; i < NW1; ++i) {
+            if (i < n1) {
+                const int k = part * 4 + 32 * i;
 #pragma unroll
                 for (int e = 0; e < EPB; ++e) {
                     const float4 xv = *reinterpret_cast<const float4 *>(xs + e * K1 + k);
-                    acc[e] += wv4.x * xv.x + wv4.y * xv.y + wv4.z * xv.z + wv4.w * xv.w;
+                    acc[e] += w1r[i][0] * xv.x + w1r[i][1] * xv.y + w1r[i][2] * xv.z + w1r[i][3] * xv.w;
                 }
+            }
+        }
+        for (int i = NW1; i < n1; ++i) {  // K1 > 576 (board games): the tail streams from L2
+            const int k = part * 4 + 32 * i;
+            const f32x4 wv4 = *reinterpret_cast<const f32x4 *>(wr + k);
+#pragma unroll
+            for (int e = 0; e < EPB; ++e) {
+                const float4 xv = *reinterpret_cast<const float4 *>(xs + e * K1 + k);
+                acc[e] += wv4[0] * xv.x + wv4[1] * xv.y + wv4[2] * xv.z + wv4[3] * xv.w;
             }
         }
 #pragma unroll
@@ -862,28 +907,23 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
         }
         if (u < HID && part == 0) {
 #pragma unroll
-            for (int e = 0; e < EPB; ++e) hid[e * HID + u] = fmaxf((acc[e] + h.b1[u]) * h.s1[u] + h.t1[u], 0.0f);
+            for (int e = 0; e < EPB; ++e) hid[e * HID + u] = fmaxf((acc[e] + b1v) * s1v + t1v, 0.0f);
         }
     }
     __syncthreads();
-    // ---- layer 2 on the transposed weights: lane n reads w2t[k][n], fully coalesced
-    constexpr int NPT = 3;  // outputs per thread: NOUT <= 768
+    // ---- layer 2 on the transposed weights (already in registers)
     float lg[NPT][EPB];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int n = tid + i * 256;
         const bool ok = n < h.NOUT;
         float acc[EPB];
-        const float bias = ok ? h.b2[n] : 0.0f;
 #pragma unroll
-        for (int e = 0; e < EPB; ++e) acc[e] = bias;
-        if (ok) {
+        for (int e = 0; e < EPB; ++e) acc[e] = b2r[i];
 #pragma unroll
-            for (int k = 0; k < HID; ++k) {
-                const float wv = h.w2t[(size_t)k * h.NOUT + n];
+        for (int k = 0; k < HID; ++k) {
 #pragma unroll
-                for (int e = 0; e < EPB; ++e) acc[e] += wv * hid[e * HID + k];
-            }
+            for (int e = 0; e < EPB; ++e) acc[e] += w2r[i][k] * hid[e * HID + k];
         }
 #pragma unroll
         for (int e = 0; e < EPB; ++e) {
@@ -1006,8 +1046,8 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s)
 {
-    if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)4 * 37 * 68 * 4, s, a);
-    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)4 * 82 * 68 * 4, s, a);
+    if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a);
+    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)(4 * 82 * 68 + 81 * 68 + 6 * 128) * 4, s, a);
 }
 
 template <int MROWS>
