@@ -42,6 +42,21 @@ DET_HEADER = """\
 #define rand() (0)
 """
 
+CLOCK_CPP = """\
+// deterministic replacement of std::chrono::system_clock::now() for the reference's sampled ctree (test oracle only)
+#include <chrono>
+#include <cstdint>
+static uint64_t g_lz_clock = 1;
+extern "C" void oracle_set_clock(uint64_t v) { g_lz_clock = v; }
+extern "C" uint64_t oracle_get_clock(void) { return g_lz_clock; }
+namespace std { namespace chrono { inline namespace _V2 {
+system_clock::time_point system_clock::now() noexcept
+{
+    return time_point(duration(static_cast<rep>(g_lz_clock++)));
+}
+} } }
+"""
+
 SETUP = """\
 import sys
 from setuptools import setup, Extension
@@ -50,11 +65,18 @@ import os
 extra = ['-std=c++11', '-O2']
 if os.environ.get('LZ_ORACLE_DET_HEADER'):
     extra += ['-include', os.environ['LZ_ORACLE_DET_HEADER']]
+det = bool(os.environ.get('LZ_ORACLE_DET_HEADER'))
 exts = [
     Extension('lzero.mcts.ctree.ctree_efficientzero.ez_tree',
               ['lzero/mcts/ctree/ctree_efficientzero/ez_tree.pyx'], language='c++', extra_compile_args=extra),
     Extension('lzero.mcts.ctree.ctree_muzero.mz_tree',
               ['lzero/mcts/ctree/ctree_muzero/mz_tree.pyx'], language='c++', extra_compile_args=extra),
+    # Sampled EfficientZero: the deterministic flavour also links oracle_clock.cpp, which replaces
+    # std::chrono::system_clock::now() (the seed of the std::default_random_engine built inside CNode::expand,
+    # ctree_sampled_efficientzero/lib/cnode.cpp:251,336) by a settable counter
+    Extension('lzero.mcts.ctree.ctree_sampled_efficientzero.ezs_tree',
+              ['lzero/mcts/ctree/ctree_sampled_efficientzero/ezs_tree.pyx'] + (['oracle_clock.cpp'] if det else []),
+              language='c++', extra_compile_args=extra, extra_link_args=(['-Wl,-Bsymbolic-functions'] if det else [])),
 ]
 setup(ext_modules=cythonize(exts, language_level=3))
 """
@@ -65,8 +87,7 @@ def built(flavour):
     if not os.path.isdir(d):
         return False
     names = os.listdir(d)
-    return any(n.startswith("ez_tree") and n.endswith(".so") for n in names) and \
-        any(n.startswith("mz_tree") and n.endswith(".so") for n in names)
+    return all(any(n.startswith(stem) and n.endswith(".so") for n in names) for stem in ("ez_tree", "mz_tree", "ezs_tree"))
 
 
 def build(force=False):
@@ -95,11 +116,13 @@ def build(force=False):
                 hdr = os.path.join(tmp, "oracle_det.h")
                 with open(hdr, "w") as f:
                     f.write(DET_HEADER)
+                with open(os.path.join(tmp, "oracle_clock.cpp"), "w") as f:
+                    f.write(CLOCK_CPP)
                 env["LZ_ORACLE_DET_HEADER"] = hdr
             subprocess.run(cmd, cwd=tmp, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             odir = os.path.join(OUT, flavour)
             os.makedirs(odir, exist_ok=True)
-            for sub in ("ctree_efficientzero", "ctree_muzero"):
+            for sub in ("ctree_efficientzero", "ctree_muzero", "ctree_sampled_efficientzero"):
                 d = os.path.join(dst, "ctree", sub)
                 for n in os.listdir(d):
                     if n.endswith(".so"):
@@ -110,7 +133,8 @@ def build(force=False):
 
 
 def load(flavour="det"):
-    """Import (ez_tree, mz_tree) of the given flavour from oracle/_ref; None if not built."""
+    """Import (ez_tree, mz_tree) of the given flavour from oracle/_ref; None if not built.  ``load_sampled``
+    returns the Sampled-EfficientZero module."""
     import importlib.machinery
     import importlib.util
     d = os.path.join(OUT, flavour)
@@ -130,6 +154,30 @@ def load(flavour="det"):
         loader.exec_module(mod)
         mods.append(mod)
     return tuple(mods)
+
+
+def load_sampled(flavour="det"):
+    """(ezs_tree module, ctypes handle exposing oracle_set_clock / oracle_get_clock for the det flavour)."""
+    import ctypes
+    import importlib.machinery
+    import importlib.util
+    d = os.path.join(OUT, flavour)
+    if not os.path.isdir(d):
+        return None
+    cands = [n for n in os.listdir(d) if n.startswith("ezs_tree") and n.endswith(".so")]
+    if not cands:
+        return None
+    path = os.path.join(d, cands[0])
+    loader = importlib.machinery.ExtensionFileLoader("ezs_tree", path)
+    spec = importlib.util.spec_from_file_location("ezs_tree", path, loader=loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    handle = None
+    if flavour == "det":
+        handle = ctypes.CDLL(path)
+        handle.oracle_set_clock.argtypes = [ctypes.c_uint64]
+        handle.oracle_get_clock.restype = ctypes.c_uint64
+    return mod, handle
 
 
 if __name__ == "__main__":

@@ -14,11 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libctree_oracle.so")
 
 
+_SO_S = os.path.join(_HERE, "libctree_sampled_oracle.so")
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "ctree_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-B", "libctree_oracle.so"], check=True,
-                       stdout=subprocess.DEVNULL)
+    for so, src in ((_SO, "ctree_oracle.c"), (_SO_S, "ctree_sampled_oracle.c")):
+        srcp = os.path.join(_HERE, src)
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(srcp):
+            subprocess.run(["make", "-C", _HERE, "-B", os.path.basename(so)], check=True, stdout=subprocess.DEVNULL)
     return _SO
 
 
@@ -184,3 +187,146 @@ def _make(variant):
 
 ez_tree = _make(0)
 mz_tree = _make(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Sampled EfficientZero (continuous actions): ctypes face of oracle/ctree_sampled_oracle.c with the surface of
+# lzero/mcts/ctree/ctree_sampled_efficientzero/ezs_tree.pyx
+# ------------------------------------------------------------------------------------------------
+_slib = None
+
+
+def slib():
+    global _slib
+    if _slib is None:
+        build()
+        L = ctypes.CDLL(_SO_S)
+        P = ctypes.c_void_p
+        ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.stree_create.restype = P
+        L.stree_create.argtypes = [ctypes.c_int] * 4
+        L.stree_destroy.argtypes = [P]
+        L.stree_set_clock.argtypes = [P, ctypes.c_uint64]
+        L.stree_set_tiebreak.argtypes = [P, ctypes.c_int]
+        L.stree_set_delta.argtypes = [P, ctypes.c_float]
+        L.stree_prepare.argtypes = [P, ctypes.c_float, P, fp, fp, ip, P]
+        L.stree_traverse.argtypes = [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, ip, ip, ip, fp, ip]
+        L.stree_backpropagate.argtypes = [P, ctypes.c_int, ctypes.c_float, fp, fp, fp, ip, ip, P]
+        L.stree_get_distributions.argtypes = [P, ip]
+        L.stree_get_values.argtypes = [P, fp]
+        L.stree_get_minmax.argtypes = [P, fp]
+        L.stree_get_actions.argtypes = [P, ctypes.c_int, fp]
+        _slib = L
+    return _slib
+
+
+def _make_sampled():
+    class MinMaxStatsList(object):
+        def __init__(self, num):
+            self.num = num
+            self.delta = 0.0
+
+        def set_delta(self, value_delta_max):
+            self.delta = float(value_delta_max)
+
+    class ResultsWrapper(object):
+        def __init__(self, num):
+            self.num = num
+            self.search_lens = []
+
+        def get_search_len(self):
+            return self.search_lens
+
+    class Roots(object):
+        def __init__(self, root_num, legal_actions_list, action_space_size, num_of_sampled_actions,
+                     continuous_action_space=True, max_simulations=512):
+            assert continuous_action_space, "the oracle restates the continuous branch only"
+            self.root_num, self.D, self.K, self._S = root_num, action_space_size, num_of_sampled_actions, max_simulations
+            self._h = slib().stree_create(root_num, self.D, self.K, max_simulations)
+            self._mm_bound = None
+            self.given = None  # optional injected samples for the next expand: [B][K][D]
+
+        @property
+        def num(self):
+            return self.root_num
+
+        def set_clock(self, c):
+            slib().stree_set_clock(self._h, int(c))
+
+        def set_tiebreak(self, mode):
+            slib().stree_set_tiebreak(self._h, int(mode))
+
+        def _given_ptr(self):
+            if self.given is None:
+                return None
+            self._g = _f32(self.given)
+            self.given = None
+            return self._g.ctypes.data
+
+        def prepare(self, root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch):
+            nz = _f32(noises)
+            slib().stree_prepare(self._h, root_noise_weight, nz.ctypes.data, _f32(value_prefix_pool),
+                                 _f32(policy_logits_pool), _i32(to_play_batch), self._given_ptr())
+
+        def prepare_no_noise(self, value_prefix_pool, policy_logits_pool, to_play_batch):
+            slib().stree_prepare(self._h, 0.0, None, _f32(value_prefix_pool), _f32(policy_logits_pool),
+                                 _i32(to_play_batch), self._given_ptr())
+
+        def get_distributions(self):
+            out = np.zeros((self.root_num, self.K), np.int32)
+            slib().stree_get_distributions(self._h, out)
+            return out.tolist()
+
+        def get_values(self):
+            out = np.zeros(self.root_num, np.float32)
+            slib().stree_get_values(self._h, out)
+            return out.tolist()
+
+        def get_minmax(self):
+            out = np.zeros((self.root_num, 2), np.float32)
+            slib().stree_get_minmax(self._h, out)
+            return out
+
+        def get_sampled_actions(self, record=0):
+            out = np.zeros((self.root_num, self.K, self.D), np.float32)
+            slib().stree_get_actions(self._h, record, out)
+            return out.tolist()
+
+        def clear(self):
+            if self._h is not None:
+                slib().stree_destroy(self._h)
+                self._h = None
+
+        def __del__(self):
+            try:
+                self.clear()
+            except Exception:
+                pass
+
+    def batch_traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, virtual_to_play_batch,
+                       continuous_action_space=True):
+        B = roots.num
+        if roots._mm_bound is not min_max_stats_lst:
+            slib().stree_set_delta(roots._h, min_max_stats_lst.delta)
+            roots._mm_bound = min_max_stats_lst
+        vtp = _i32(virtual_to_play_batch).copy()
+        ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+        la = np.zeros((B, roots.D), np.float32)
+        slib().stree_traverse(roots._h, int(pb_c_base), pb_c_init, discount_factor, vtp, ix, iy, la, sl)
+        results.search_lens = sl.tolist()
+        results._roots = roots
+        return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+    def batch_backpropagate(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                            min_max_stats_lst, results, is_reset_list, to_play_batch):
+        roots = results._roots
+        slib().stree_backpropagate(roots._h, current_latent_state_index, discount_factor, _f32(value_prefixs),
+                                   _f32(values), _f32(policies), _i32(is_reset_list), _i32(to_play_batch),
+                                   roots._given_ptr())
+
+    return types.SimpleNamespace(MinMaxStatsList=MinMaxStatsList, ResultsWrapper=ResultsWrapper, Roots=Roots,
+                                 batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate)
+
+
+ezs_tree = _make_sampled()
