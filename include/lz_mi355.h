@@ -33,7 +33,8 @@ typedef enum lz_status {
 
 typedef enum lz_variant {
     LZ_TREE_EFFICIENTZERO = 0, /* lzero/mcts/ctree/ctree_efficientzero (value-prefix tree, is_reset) */
-    LZ_TREE_MUZERO = 1         /* lzero/mcts/ctree/ctree_muzero (reward tree) */
+    LZ_TREE_MUZERO = 1,        /* lzero/mcts/ctree/ctree_muzero (reward tree) */
+    LZ_TREE_SAMPLED_EFFICIENTZERO = 2 /* lzero/mcts/ctree/ctree_sampled_efficientzero, continuous actions */
 } lz_variant;
 
 typedef enum lz_tiebreak {
@@ -114,6 +115,32 @@ int lz_roots_get_values(lz_roots *r, float *h_out_values);
 int lz_roots_get_trajectories(lz_roots *r, int32_t *h_out, int stride);
 /* (minimum, maximum) per root [root_num][2] -- observability for tests */
 int lz_roots_get_minmax(lz_roots *r, float *h_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampled EfficientZero trees, continuous action space -- replaces ezs_tree.pyx (ctree_sampled_efficientzero).
+ * Every expanded node owns K actions drawn from tanh(N(mu, sigma)) (cnode.cpp:238-282).  The draws are made on the
+ * device with a counter-based RNG, or -- for bit-exact parity runs -- supplied by the caller (h_given [root_num][K][D]).
+ * The UCB prior is the shipped "uniform" branch pb_c / children.size() (cnode.cpp:1054-1079); actions whose every
+ * dimension prints identically with "%f" share one child (the reference keys children by a hash of to_string).
+ * lz_roots_get_values / lz_roots_minmax_reset / lz_roots_set_tiebreak / lz_roots_destroy apply to these handles too.
+ * ---------------------------------------------------------------------------------------------- */
+int lz_sroots_create(lz_engine *e, int root_num, int action_dim, int num_of_sampled_actions, int max_simulations,
+                     lz_roots **out);
+/* Roots.prepare / prepare_no_noise  ezs_tree.pyx -> CRoots::prepare cnode.cpp:671-702.  h_policy [root_num][2D] = (mu | sigma).
+ * h_noises [root_num][K] is accepted for signature parity; it only perturbs priors that the shipped score never reads. */
+int lz_sroots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises, const float *h_value_prefix,
+                      const float *h_policy, const int32_t *h_to_play, const float *h_given);
+/* batch_traverse  -> cbatch_traverse cnode.cpp:1110-1187; h_out_last_actions [root_num][D] floats */
+int lz_sbatch_traverse(lz_roots *r, int pb_c_base, float pb_c_init, float discount_factor, int32_t *h_virtual_to_play,
+                       int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch, float *h_out_last_actions,
+                       int32_t *h_out_search_lens);
+/* batch_backpropagate -> cbatch_backpropagate cnode.cpp:947-966 */
+int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_index, float discount_factor, const float *h_value_prefixs,
+                            const float *h_values, const float *h_policy, const int32_t *h_is_reset,
+                            const int32_t *h_to_play, const float *h_given);
+/* Roots.get_distributions ([root_num][K] visit counts) / get_sampled_actions ([root_num][K][D]) */
+int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out);
+int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
 
 
 /* ------------------------------------------------------------------------------------------------

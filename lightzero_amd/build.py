@@ -17,6 +17,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # exactly, so they are built without FMA contraction (see lz_tree.hip header).
 UNITS = [
     ("lz_tree.hip", ["-ffp-contract=off"]),
+    ("lz_tree_sampled.hip", ["-ffp-contract=off"]),
     ("lz_capi.hip", []),
     ("lz_nn.hip", []),
     ("lz_search.hip", []),

@@ -98,13 +98,13 @@ static int ensure_stage(lz_roots *r, size_t bytes)
     return LZ_OK;
 }
 
-int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roots **out)
+int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roots **out, int D = 0)
 {
     lz_roots *r = new (std::nothrow) lz_roots();
     if (!r) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
     r->eng = e;
     lz_tree_dev &t = r->t;
-    t.B = B; t.A = A; t.NN = max_sims + 1; t.variant = variant;
+    t.B = B; t.A = A; t.NN = max_sims + 1; t.variant = variant; t.D = D;
     const size_t nBNA = (size_t)B * t.NN * A, nBN = (size_t)B * t.NN;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -112,7 +112,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
                  o_reset = take(nBN * 4), o_tp = take(nBN * 4), o_best = take(nBN * 4), o_rv = take((size_t)B * 4),
                  o_rs = take((size_t)B * 4), o_legal = take((size_t)B * A * 4), o_nl = take((size_t)B * 4),
                  o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5),
-                 o_ep = take(256);
+                 o_ep = take(256), o_rep = take(D ? nBNA * 4 : 0), o_nch = take(D ? nBN * 4 : 0),
+                 o_act = take(D ? nBNA * D * 4 : 0), o_laf = take(D ? (size_t)B * D * 4 : 0);
     hipError_t err = hipMalloc(&r->slab, off);
     if (err != hipSuccess) {
         delete r;
@@ -127,6 +128,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.legal = (int32_t *)(base + o_legal); t.n_legal = (int32_t *)(base + o_nl); t.minmax = (float *)(base + o_mm);
     t.path_node = (int32_t *)(base + o_pn); t.path_act = (int32_t *)(base + o_pa);
     int32_t *res = (int32_t *)(base + o_res);
+    t.rep = D ? (int32_t *)(base + o_rep) : nullptr; t.nchild = D ? (int32_t *)(base + o_nch) : nullptr;
+    t.actions = D ? (float *)(base + o_act) : nullptr; t.res_last_action_f = D ? (float *)(base + o_laf) : nullptr;
     t.rng_epoch = (uint32_t *)(base + o_ep);
     (void)hipMemset(t.rng_epoch, 0, 4);
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
@@ -441,5 +444,176 @@ extern "C" int lz_roots_get_minmax(lz_roots *r, float *h_out)
     LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->t.minmax, (size_t)r->t.B * 8, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     memcpy(h_out, r->h_stage, (size_t)r->t.B * 8);
+    return LZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampled EfficientZero trees (continuous actions)
+// ------------------------------------------------------------------------------------------------
+extern "C" int lz_sroots_create(lz_engine *e, int root_num, int action_dim, int num_of_sampled_actions, int max_simulations,
+                                lz_roots **out)
+{
+    LZ_REQUIRE(e != nullptr && out != nullptr, "engine/out is NULL");
+    *out = nullptr;
+    LZ_REQUIRE(root_num > 0 && max_simulations > 0, "root_num and max_simulations must be positive");
+    LZ_REQUIRE(action_dim >= 1 && action_dim <= 64, "action_dim must be in [1, 64]");
+    LZ_REQUIRE(num_of_sampled_actions >= 1 && num_of_sampled_actions <= 64, "num_of_sampled_actions must be in [1, 64] (one lane per sampled action)");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    lz_roots *r = nullptr;
+    int rc = lz_roots_alloc(e, LZ_TREE_SAMPLED_EFFICIENTZERO, root_num, num_of_sampled_actions, max_simulations, &r, action_dim);
+    if (rc != LZ_OK) return rc;
+    lz_tree_launch_minmax_reset(r->t, e->stream);
+    *out = r;
+    return LZ_OK;
+}
+
+static int sampled_check(lz_roots *r)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO, "not a Sampled-EfficientZero roots handle (use lz_sroots_create)");
+    return LZ_OK;
+}
+
+extern "C" int lz_sroots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises, const float *h_value_prefix,
+                                 const float *h_policy, const int32_t *h_to_play, const float *h_given)
+{
+    int rc = sampled_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(h_value_prefix && h_policy && h_to_play, "NULL input");
+    (void)root_noise_weight; (void)h_noises;  // only perturb priors that the shipped uniform-prior score never reads
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, K = t.A, D = t.D;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    const size_t o_vp = 0, o_pol = o_vp + B * 4, o_tp = o_pol + B * 2 * D * 4, o_giv = o_tp + B * 4, need = o_giv + B * K * D * 4;
+    rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    memcpy(h + o_vp, h_value_prefix, B * 4);
+    memcpy(h + o_pol, h_policy, B * 2 * D * 4);
+    memcpy(h + o_tp, h_to_play, B * 4);
+    if (h_given) memcpy(h + o_giv, h_given, B * K * D * 4);
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, h_given ? need : o_giv, hipMemcpyHostToDevice, s));
+    lz_sample_args sa;
+    sa.given = h_given ? (const float *)(d + o_giv) : nullptr;
+    sa.policy = (const float *)(d + o_pol);
+    sa.seed = r->seed;
+    sa.counter = 0;
+    lz_stree_launch_prepare(t, sa, (const float *)(d + o_vp), (const int32_t *)(d + o_tp), s);
+    lz_tree_launch_bump_epoch(t, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    r->players = players_of(h_to_play, (int)B);
+    r->prepared = true;
+    r->traverse_count = 0;
+    return LZ_OK;
+}
+
+extern "C" int lz_sbatch_traverse(lz_roots *r, int pb_c_base, float pb_c_init, float discount_factor, int32_t *h_virtual_to_play,
+                                  int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch, float *h_out_last_actions,
+                                  int32_t *h_out_search_lens)
+{
+    int rc = sampled_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(r->prepared, "batch_traverse before Roots.prepare");
+    LZ_REQUIRE(h_virtual_to_play && h_out_index_in_search_path && h_out_index_in_batch && h_out_last_actions && h_out_search_lens, "NULL buffer");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, D = t.D;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    rc = ensure_stage(r, B * 4 * 6 + B * D * 4);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    memcpy(r->h_stage, h_virtual_to_play, B * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(r->d_stage, r->h_stage, B * 4, hipMemcpyHostToDevice, s));
+    lz_traverse_args a;
+    a.pb_c_base = pb_c_base; a.pb_c_init = pb_c_init; a.discount = discount_factor;
+    a.players = players_of(h_virtual_to_play, (int)B);
+    a.tiebreak = r->tiebreak; a.seed = r->seed; a.counter = r->traverse_count++;
+    r->players = a.players;
+    lz_stree_launch_traverse(t, a, r->delta, (const int32_t *)r->d_stage, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, t.res_ix, B * 4 * 5, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipMemcpyAsync((char *)r->h_stage + B * 4 * 5, t.res_last_action_f, B * D * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    const int32_t *h = (const int32_t *)r->h_stage;
+    memcpy(h_out_index_in_search_path, h, B * 4);
+    memcpy(h_out_index_in_batch, h + B, B * 4);
+    memcpy(h_out_search_lens, h + 3 * B, B * 4);
+    memcpy(h_virtual_to_play, h + 4 * B, B * 4);
+    memcpy(h_out_last_actions, (char *)r->h_stage + B * 4 * 5, B * D * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_index, float discount_factor,
+                                       const float *h_value_prefixs, const float *h_values, const float *h_policy,
+                                       const int32_t *h_is_reset, const int32_t *h_to_play, const float *h_given)
+{
+    int rc = sampled_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(r->prepared, "batch_backpropagate before Roots.prepare");
+    LZ_REQUIRE(h_value_prefixs && h_values && h_policy && h_is_reset && h_to_play, "NULL input");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, K = t.A, D = t.D;
+    if (current_latent_state_index < 1 || current_latent_state_index >= t.NN) {
+        lz_set_error("current_latent_state_index %d outside the node pool [1,%d]", current_latent_state_index, t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    const size_t o_vp = 0, o_v = B * 4, o_rst = 2 * B * 4, o_tp = 3 * B * 4, o_pol = 4 * B * 4, o_giv = o_pol + B * 2 * D * 4,
+                 need = o_giv + B * K * D * 4;
+    rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    memcpy(h + o_vp, h_value_prefixs, B * 4);
+    memcpy(h + o_v, h_values, B * 4);
+    memcpy(h + o_rst, h_is_reset, B * 4);
+    memcpy(h + o_tp, h_to_play, B * 4);
+    memcpy(h + o_pol, h_policy, B * 2 * D * 4);
+    if (h_given) memcpy(h + o_giv, h_given, B * K * D * 4);
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, h_given ? need : o_giv, hipMemcpyHostToDevice, s));
+    lz_sample_args sa;
+    sa.given = h_given ? (const float *)(d + o_giv) : nullptr;
+    sa.policy = (const float *)(d + o_pol);
+    sa.seed = r->seed;
+    sa.counter = (uint32_t)current_latent_state_index;
+    lz_stree_launch_backprop(t, current_latent_state_index, discount_factor, (const float *)(d + o_vp), (const float *)(d + o_v), sa,
+                             (const int32_t *)(d + o_rst), 0, (const int32_t *)(d + o_tp), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out)
+{
+    int rc = sampled_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(h_out != nullptr && r->prepared, "NULL output / roots not prepared");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, K = t.A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    rc = ensure_stage(r, B * K * 4);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    lz_stree_launch_readout(t, (int32_t *)r->d_stage, nullptr, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->d_stage, B * K * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_out, r->h_stage, B * K * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out)
+{
+    int rc = sampled_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(h_out != nullptr && r->prepared, "NULL output / roots not prepared");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, K = t.A, D = t.D, NN = t.NN;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    // actions of node 0 of every root: [B] strided blocks of K*D floats
+    LZ_HIP_CHECK(hipMemcpy2DAsync(h_out, K * D * 4, t.actions, NN * K * D * 4, K * D * 4, B, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
     return LZ_OK;
 }

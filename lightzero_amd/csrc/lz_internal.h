@@ -64,6 +64,12 @@ struct lz_tree_dev {
     int32_t *path_act;          // [B][NN]     action taken at path_node[k]
     int32_t *res_ix, *res_iy, *res_last_action, *res_search_len, *res_vtp;  // [B] each
     uint32_t *rng_epoch;        // [1] incremented by every prepare (stochastic tie-break stream)
+    // Sampled EfficientZero (variant 2, continuous actions): A == K sampled actions per node
+    int D;                      // action dimension
+    int32_t *rep;               // [B][NN][K]  position of the first legal action with the same "%f" key (shared child)
+    int32_t *nchild;            // [B][NN]     number of distinct keys == children.size()
+    float *actions;             // [B][NN][K][D] sampled actions (legal_actions of every expanded node)
+    float *res_last_action_f;   // [B][D]      last selected action of the latest traverse
 };
 
 struct lz_graph_key {
@@ -141,3 +147,15 @@ void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, fl
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s);
 void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s);
 void lz_tree_launch_trajectories(const lz_tree_dev &t, int32_t *d_out, int stride, hipStream_t s);
+// Sampled EfficientZero tree (lz_tree_sampled.hip)
+struct lz_sample_args {
+    const float *given;     // optional [B][K][D] already-sampled (post-tanh) actions; null => drawn on the device
+    const float *policy;    // [B][2D] (mu | sigma)
+    uint64_t seed;
+    uint32_t counter;
+};
+void lz_stree_launch_prepare(const lz_tree_dev &t, const lz_sample_args &sa, const float *d_vp, const int32_t *d_to_play, hipStream_t s);
+void lz_stree_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
+void lz_stree_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                              const lz_sample_args &sa, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play, hipStream_t s);
+void lz_stree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, float *d_values, hipStream_t s);

@@ -1,0 +1,139 @@
+"""Drop-in for lzero/mcts/ctree/ctree_sampled_efficientzero/ezs_tree.pyx (continuous action spaces): ``Roots``,
+``MinMaxStatsList``, ``ResultsWrapper``, ``batch_traverse``, ``batch_backpropagate`` -- trees in HBM, HIP kernels
+(lightzero_amd/csrc/lz_tree_sampled.hip).
+
+Same signatures as the reference.  Additions: ``Roots(..., max_simulations=None)`` sizes the node pool;
+``roots.given = array[B][K][D]`` injects the (post-tanh) actions of the NEXT expand instead of drawing them on the
+device (bit-exact parity runs); ``Roots.set_tiebreak(0|1)``.
+"""
+import ctypes
+
+import numpy as np
+
+from .... import _lib as L
+
+DEFAULT_MAX_SIMULATIONS = 512
+_seed = [0xC0FFEE]
+
+
+class MinMaxStatsList(object):
+    def __init__(self, num):
+        self.num = int(num)
+        self._delta = 0.0
+        self._bound = None
+
+    def set_delta(self, value_delta_max):
+        self._delta = float(value_delta_max)
+
+
+class ResultsWrapper(object):
+    def __init__(self, num):
+        self.num = int(num)
+        self._search_lens = []
+        self._roots = None
+
+    def get_search_len(self):
+        return self._search_lens
+
+
+class Roots(object):
+    def __init__(self, root_num, legal_actions_list, action_space_size, num_of_sampled_actions,
+                 continuous_action_space=True, max_simulations=None, engine=None):
+        if not continuous_action_space:
+            raise NotImplementedError("the device tree implements the continuous-action branch of ctree_sampled_efficientzero")
+        self.root_num, self.D, self.K = int(root_num), int(action_space_size), int(num_of_sampled_actions)
+        self._S = int(max_simulations) if max_simulations else DEFAULT_MAX_SIMULATIONS
+        h = L.P()
+        eng = engine if engine is not None else L.default_engine()
+        L.check(L.lib().lz_sroots_create(eng, self.root_num, self.D, self.K, self._S, ctypes.byref(h)))
+        self._h = h
+        _seed[0] += 1
+        self._seed = _seed[0]
+        L.check(L.lib().lz_roots_set_tiebreak(self._h, 1, self._seed))
+        self.given = None
+
+    @property
+    def num(self):
+        return self.root_num
+
+    def set_tiebreak(self, mode, seed=None):
+        if seed is not None:
+            self._seed = int(seed)
+        L.check(L.lib().lz_roots_set_tiebreak(self._h, int(mode), self._seed))
+
+    def _take_given(self):
+        if self.given is None:
+            return None
+        self._g = L.f32(self.given).reshape(self.root_num, self.K, self.D)
+        self.given = None
+        return self._g.ctypes.data
+
+    def prepare(self, root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch):
+        pol = L.f32(policy_logits_pool)
+        if pol.shape != (self.root_num, 2 * self.D):
+            raise ValueError("policy_logits_pool must be [root_num][2 * action_space_size] (mu | sigma)")
+        nz = L.f32(noises)
+        L.check(L.lib().lz_sroots_prepare(self._h, float(root_noise_weight), nz.ctypes.data, L.f32(value_prefix_pool), pol,
+                                          L.i32(to_play_batch), self._take_given()))
+
+    def prepare_no_noise(self, value_prefix_pool, policy_logits_pool, to_play_batch):
+        pol = L.f32(policy_logits_pool)
+        if pol.shape != (self.root_num, 2 * self.D):
+            raise ValueError("policy_logits_pool must be [root_num][2 * action_space_size] (mu | sigma)")
+        L.check(L.lib().lz_sroots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), pol, L.i32(to_play_batch),
+                                          self._take_given()))
+
+    def get_distributions(self):
+        out = np.zeros((self.root_num, self.K), np.int32)
+        L.check(L.lib().lz_sroots_get_distributions(self._h, out))
+        return out.tolist()
+
+    def get_sampled_actions(self):
+        out = np.zeros((self.root_num, self.K, self.D), np.float32)
+        L.check(L.lib().lz_sroots_get_sampled_actions(self._h, out.reshape(-1)))
+        return out.tolist()
+
+    def get_values(self):
+        out = np.zeros(self.root_num, np.float32)
+        L.check(L.lib().lz_roots_get_values(self._h, out))
+        return out.tolist()
+
+    def get_minmax(self):
+        out = np.zeros((self.root_num, 2), np.float32)
+        L.check(L.lib().lz_roots_get_minmax(self._h, out))
+        return out
+
+    def clear(self):
+        if self._h is not None:
+            L.lib().lz_roots_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.clear()
+        except Exception:
+            pass
+
+
+def batch_traverse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, virtual_to_play_batch,
+                   continuous_action_space=True):
+    if min_max_stats_lst._bound is not roots:
+        L.check(L.lib().lz_roots_minmax_reset(roots._h, min_max_stats_lst._delta))
+        min_max_stats_lst._bound = roots
+    B = roots.root_num
+    vtp = L.i32(virtual_to_play_batch).copy()
+    ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+    la = np.zeros((B, roots.D), np.float32)
+    L.check(L.lib().lz_sbatch_traverse(roots._h, int(pb_c_base), float(pb_c_init), float(discount_factor), vtp, ix, iy,
+                                       la.reshape(-1), sl))
+    results._search_lens = sl.tolist()
+    results._roots = roots
+    return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+
+def batch_backpropagate(current_latent_state_index, discount_factor, value_prefixs, values, policies, min_max_stats_lst,
+                        results, is_reset_list, to_play_batch):
+    roots = results._roots
+    L.check(L.lib().lz_sbatch_backpropagate(roots._h, int(current_latent_state_index), float(discount_factor),
+                                            L.f32(value_prefixs), L.f32(values), L.f32(policies), L.i32(is_reset_list),
+                                            L.i32(to_play_batch), roots._take_given()))
