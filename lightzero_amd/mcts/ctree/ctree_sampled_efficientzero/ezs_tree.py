@@ -50,7 +50,9 @@ class Roots(object):
         _seed[0] += 1
         self._seed = _seed[0]
         L.check(L.lib().lz_roots_set_tiebreak(self._h, 1, self._seed))
-        self.given = None
+        self.given = None            # draws of the NEXT expand, [B][K][D]
+        self.given_provider = None   # or: callable(record_index) -> draws (record 0 = prepare, s + 1 = simulation s)
+        self._record = 0
 
     @property
     def num(self):
@@ -62,6 +64,10 @@ class Roots(object):
         L.check(L.lib().lz_roots_set_tiebreak(self._h, int(mode), self._seed))
 
     def _take_given(self):
+        rec = self._record
+        self._record += 1
+        if self.given is None and self.given_provider is not None:
+            self.given = self.given_provider(rec)
         if self.given is None:
             return None
         self._g = L.f32(self.given).reshape(self.root_num, self.K, self.D)

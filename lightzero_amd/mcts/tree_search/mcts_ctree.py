@@ -177,3 +177,70 @@ class MuZeroMCTSCtree(object):
                 tree_muzero.batch_backpropagate(simulation_index + 1, discount_factor, reward.reshape(-1), value.reshape(-1),
                                                 out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
                                                 virtual_to_play_batch)
+
+
+class SampledEfficientZeroMCTSCtree(object):
+    """lzero/mcts/tree_search/mcts_ctree_sampled.py:394+ (continuous action spaces): the reference loop with the
+    HBM-resident Sampled-EfficientZero tree kernels doing batch_traverse / batch_backpropagate.  ``model`` is any
+    module with the SampledEfficientZeroModelMLP inference contract (``recurrent_inference(latent, (h, c), action)``
+    returning value / value_prefix logits, ``policy_logits`` = (mu | sigma), latent_state, reward_hidden_state)."""
+    config = dict(root_dirichlet_alpha=0.3, root_noise_weight=0.25, pb_c_base=19652, pb_c_init=1.25,
+                  value_delta_max=0.01)
+
+    @classmethod
+    def default_config(cls):
+        cfg = _Cfg(copy.deepcopy(cls.config))
+        cfg["cfg_type"] = cls.__name__ + "Dict"
+        return cfg
+
+    def __init__(self, cfg=None):
+        default_config = self.default_config()
+        if cfg is not None:
+            default_config.update(dict(cfg))
+        self._cfg = default_config
+        model_cfg = _get(self._cfg, "model", {}) or {}
+        self._support_min = float(_get(model_cfg, "value_support_range", (-300., 301., 1.))[0])
+
+    @classmethod
+    def roots(cls, active_collect_env_num, legal_actions, action_space_size, num_of_sampled_actions,
+              continuous_action_space=True, max_simulations=None):
+        from ..ctree.ctree_sampled_efficientzero import ezs_tree
+        return ezs_tree.Roots(active_collect_env_num, legal_actions, action_space_size, num_of_sampled_actions,
+                              continuous_action_space, max_simulations=max_simulations)
+
+    def search(self, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch):
+        import torch
+        from ..ctree.ctree_sampled_efficientzero import ezs_tree
+        cfg = self._cfg
+        device = _get(cfg, "device", "cpu")
+        with torch.no_grad():
+            model.eval()
+            batch_size = roots.num
+            pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+            latent_pool = [np.asarray(latent_state_roots)]
+            c_pool = [np.asarray(reward_hidden_state_roots[0])]
+            h_pool = [np.asarray(reward_hidden_state_roots[1])]
+            min_max_stats_lst = ezs_tree.MinMaxStatsList(batch_size)
+            min_max_stats_lst.set_delta(cfg["value_delta_max"])
+            for simulation_index in range(int(cfg["num_simulations"])):
+                results = ezs_tree.ResultsWrapper(num=batch_size)
+                tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
+                ix, iy, last_actions, virtual_to_play_batch = ezs_tree.batch_traverse(
+                    roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, tp, True)
+                search_lens = results.get_search_len()
+                ix = np.asarray(ix); iy = np.asarray(iy)
+                latent_states = torch.from_numpy(np.stack(latent_pool)[ix, iy]).to(device)
+                hc = torch.from_numpy(np.stack(c_pool)[ix, 0, iy]).to(device).unsqueeze(0)
+                hh = torch.from_numpy(np.stack(h_pool)[ix, 0, iy]).to(device).unsqueeze(0)
+                out = model.recurrent_inference(latent_states, (hc, hh), torch.from_numpy(np.asarray(last_actions, np.float32)).to(device))
+                latent_pool.append(out.latent_state.detach().cpu().numpy())
+                value = _inverse_scalar_transform(out.value, self._support_min)
+                value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min)
+                rhs = [out.reward_hidden_state[0].detach().cpu().numpy().copy(), out.reward_hidden_state[1].detach().cpu().numpy().copy()]
+                reset_idx = (np.array(search_lens) % int(cfg["lstm_horizon_len"]) == 0)
+                rhs[0][:, reset_idx, :] = 0
+                rhs[1][:, reset_idx, :] = 0
+                c_pool.append(rhs[0]); h_pool.append(rhs[1])
+                ezs_tree.batch_backpropagate(simulation_index + 1, discount_factor, value_prefix.reshape(-1), value.reshape(-1),
+                                             out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
+                                             reset_idx.astype(np.int32), virtual_to_play_batch)

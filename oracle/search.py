@@ -138,3 +138,44 @@ def mz_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
             roots.prepare_no_noise(list(out.reward), policy_logits, list(to_play))
         mz_search(tree, roots, model, latent_state_roots, to_play, cfg, device, deterministic)
         return roots.get_distributions(), roots.get_values(), pred_values.reshape(-1), policy_logits
+
+
+def sez_search(tree, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch, cfg, device="cpu"):
+    """SampledEfficientZeroMCTSCtree.search (continuous)  lzero/mcts/tree_search/mcts_ctree_sampled.py:480-600."""
+    ist = InverseScalarTransform(device=device)
+    with torch.no_grad():
+        model.eval()
+        batch_size = roots.num
+        pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+        latent_state_batch_in_search_path = [latent_state_roots]
+        reward_hidden_state_c_pool = [reward_hidden_state_roots[0]]
+        reward_hidden_state_h_pool = [reward_hidden_state_roots[1]]
+        min_max_stats_lst = tree.MinMaxStatsList(batch_size)
+        min_max_stats_lst.set_delta(cfg["value_delta_max"])
+        for simulation_index in range(cfg["num_simulations"]):
+            latent_states, hidden_states_c_reward, hidden_states_h_reward = [], [], []
+            results = tree.ResultsWrapper(batch_size)
+            ix_l, iy_l, last_actions, virtual_to_play_batch = tree.batch_traverse(
+                roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, list(to_play_batch), True)
+            search_lens = results.get_search_len()
+            for ix, iy in zip(ix_l, iy_l):
+                latent_states.append(latent_state_batch_in_search_path[ix][iy])
+                hidden_states_c_reward.append(reward_hidden_state_c_pool[ix][0][iy])
+                hidden_states_h_reward.append(reward_hidden_state_h_pool[ix][0][iy])
+            latent_states = torch.from_numpy(np.asarray(latent_states)).to(device)
+            hidden_states_c_reward = torch.from_numpy(np.asarray(hidden_states_c_reward)).to(device).unsqueeze(0)
+            hidden_states_h_reward = torch.from_numpy(np.asarray(hidden_states_h_reward)).to(device).unsqueeze(0)
+            last_actions_t = torch.from_numpy(np.asarray(last_actions, np.float32)).to(device)
+            out = model.recurrent_inference(latent_states, (hidden_states_c_reward, hidden_states_h_reward), last_actions_t)
+            latent_state_batch_in_search_path.append(out.latent_state.detach().cpu().numpy())
+            value = ist(out.value).detach().cpu().numpy()
+            value_prefix = ist(out.value_prefix).detach().cpu().numpy()
+            rhs = (out.reward_hidden_state[0].detach().cpu().numpy(), out.reward_hidden_state[1].detach().cpu().numpy())
+            reset_idx = (np.array(search_lens) % cfg["lstm_horizon_len"] == 0)
+            rhs[0][:, reset_idx, :] = 0
+            rhs[1][:, reset_idx, :] = 0
+            reward_hidden_state_c_pool.append(rhs[0])
+            reward_hidden_state_h_pool.append(rhs[1])
+            tree.batch_backpropagate(simulation_index + 1, discount_factor, value_prefix.reshape(-1).tolist(),
+                                     value.reshape(-1).tolist(), out.policy_logits.detach().cpu().numpy().tolist(),
+                                     min_max_stats_lst, results, reset_idx.astype(np.int32).tolist(), virtual_to_play_batch)

@@ -69,3 +69,84 @@ def test_device_side_sampling_distribution_and_invariants():
     # two roots must not share a random stream
     ra = np.asarray(roots.get_sampled_actions())
     assert not np.array_equal(ra[0], ra[1])
+
+
+class _StandInSampledModel(torch.nn.Module if (torch := __import__("torch")) else object):
+    """A small MLP + LSTM world model with the inference contract of SampledEfficientZeroModelMLP
+    (lzero/model/sampled_efficientzero_model_mlp.py): NOT a restatement of it (its policy head is DI-engine's
+    ReparameterizationHead); any model with this contract drives the same driver and tree."""
+
+    def __init__(self, obs_dim=5, action_dim=1, latent=64, hidden=64, support=601):
+        super().__init__()
+        nn = torch.nn
+        self.action_dim, self.hidden = action_dim, hidden
+        self.rep = nn.Sequential(nn.Linear(obs_dim, latent), nn.LayerNorm(latent), nn.GELU(approximate="tanh"))
+        self.dyn = nn.Sequential(nn.Linear(latent + action_dim, latent), nn.LayerNorm(latent), nn.GELU(approximate="tanh"))
+        self.lstm = nn.LSTM(latent, hidden)
+        self.vp = nn.Linear(hidden, support)
+        self.val = nn.Linear(latent, support)
+        self.mu = nn.Linear(latent, action_dim)
+        self.log_sigma = nn.Linear(latent, action_dim)
+
+    def _pred(self, z):
+        sigma = torch.exp(torch.clamp(self.log_sigma(z), -5, 1))
+        return torch.cat([self.mu(z), sigma], 1), self.val(z)
+
+    def initial_inference(self, obs):
+        from oracle.torch_models import EZNetworkOutput
+        z = self.rep(obs)
+        pol, val = self._pred(z)
+        B = obs.shape[0]
+        return EZNetworkOutput(val, [0. for _ in range(B)], pol, z, (torch.zeros(1, B, self.hidden), torch.zeros(1, B, self.hidden)))
+
+    def recurrent_inference(self, z, hc, action):
+        from oracle.torch_models import EZNetworkOutput
+        z2 = self.dyn(torch.cat([z, action.reshape(z.shape[0], -1)], 1)) + z
+        o, hc2 = self.lstm(z2.unsqueeze(0), hc)
+        pol, val = self._pred(z2)
+        return EZNetworkOutput(val, self.vp(o.squeeze(0)), pol, z2, hc2)
+
+
+def test_sampled_driver_and_policy_with_foreign_model():
+    """BASELINE configs[4] shape (DMC cartpole-swingup state obs 5, action dim 1, K = 20, 50 simulations): the reference
+    driver loop with the device tree must reproduce the oracle pipeline exactly when fed the oracle's draws."""
+    from oracle import ctree as octree, search as osearch
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    from lightzero_amd.policy.sampled_efficientzero import SampledEfficientZeroPolicy
+    torch.manual_seed(0)
+    B, D, K, S = 32, 1, 20, 50
+    model = _StandInSampledModel(obs_dim=5, action_dim=D).eval()
+    obs = torch.randn(B, 5)
+    cfg = dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
+               lstm_horizon_len=5, root_noise_weight=0.25, device="cpu",
+               model=dict(action_space_size=D, num_of_sampled_actions=K, continuous_action_space=True))
+    with torch.no_grad():
+        o = model.initial_inference(obs)
+    lat = o.latent_state.numpy(); rh = (o.reward_hidden_state[0].numpy(), o.reward_hidden_state[1].numpy())
+    pol = o.policy_logits.numpy().tolist()
+    noises = np.random.default_rng(0).dirichlet([0.3] * K, size=B).astype(np.float32).tolist()
+    # oracle pipeline, recording the draws of every expand
+    oroots = octree.ezs_tree.Roots(B, [[-1] * K] * B, D, K, True, max_simulations=S)
+    oroots.set_clock(424242)
+    oroots.prepare(0.25, noises, [0.] * B, pol, [-1] * B)
+    osearch.sez_search(octree.ezs_tree, oroots, model, lat, rh, [-1] * B, cfg)
+    draws = [np.asarray(oroots.get_sampled_actions(e), np.float32) for e in range(S + 1)]
+    # device tree behind the reference-style driver, same draws
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [[-1] * K] * B, D, K, True, max_simulations=S)
+    roots.set_tiebreak(0)
+    roots.given_provider = lambda e: draws[e]
+    roots.prepare(0.25, noises, [0.] * B, pol, [-1] * B)
+    mcts.search(roots, model, lat, rh, [-1] * B)
+    assert roots.get_distributions() == oroots.get_distributions()
+    assert np.array_equal(np.asarray(roots.get_values(), np.float32).view(np.uint32), np.asarray(oroots.get_values(), np.float32).view(np.uint32))
+    assert np.array_equal(np.asarray(roots.get_sampled_actions(), np.float32), draws[0])
+    # policy surface (device-side draws): output contract of sampled_efficientzero.py:917-925
+    policy = SampledEfficientZeroPolicy(cfg, model)
+    out = policy._forward_collect(obs, temperature=1.0, to_play=[-1] * B)
+    o0 = out[0]
+    assert set(o0) == {"action", "visit_count_distributions", "root_sampled_actions", "visit_count_distribution_entropy",
+                       "searched_value", "predicted_value", "predicted_policy_logits"}
+    assert o0["root_sampled_actions"].shape == (K, D) and len(o0["visit_count_distributions"]) == K
+    assert sum(o0["visit_count_distributions"]) == S and o0["action"].shape == (D,)
+    assert any(np.allclose(o0["action"], a) for a in o0["root_sampled_actions"])
