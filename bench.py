@@ -33,10 +33,15 @@ CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_facto
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
 
 
-def cpu_baseline(ref_model, obs_cpu, noises, budget_s=25.0):
+def cpu_baseline(ref_model, obs_cpu, noises, budget_s=25.0, device="cpu"):
     """The reference pipeline on the host cores: reference ctree (compiled from its own sources when
-    oracle/_ref is present, else the C restatement) + restated Python driver + torch fp32 model."""
+    oracle/_ref is present, else the C restatement) + restated Python driver + torch fp32 model.
+    device="cuda" is SURVEY.md 8d's second arm, the reference as deployed with cuda=True: same driver and
+    host ctree, torch model on the MI355X through stock PyTorch-ROCm (MIOpen / rocBLAS)."""
     import torch
+    if device != "cpu":
+        ref_model = ref_model.to(device)
+        obs_cpu = obs_cpu.to(device)
     from oracle import build_ref, ctree as octree, search as osearch
     mods = build_ref.load("stock")
     kind_tree = "reference ctree (oracle/_ref/stock)" if mods else "C restatement of the ctree (oracle/ctree_oracle.c)"
@@ -45,12 +50,20 @@ def cpu_baseline(ref_model, obs_cpu, noises, budget_s=25.0):
     cores = torch.get_num_threads()
     legal = [list(range(ACTIONS))] * ENVS
     n, t_used = 0, 0.0
+    kw["device"] = device
     osearch.ez_forward_collect(tree, ref_model, obs_cpu[:32], legal[:32], [z for z in noises[:32]], [-1] * 32, CFG, **kw)  # warm-up
+    if device != "cpu":
+        osearch.ez_forward_collect(tree, ref_model, obs_cpu, legal, noises, [-1] * ENVS, CFG, **kw)  # MIOpen solver search at B=256
     while t_used < budget_s * 0.5 and n < 3:
         t0 = time.perf_counter()
         osearch.ez_forward_collect(tree, ref_model, obs_cpu, legal, noises, [-1] * ENVS, CFG, **kw)
         t_used += time.perf_counter() - t0
         n += 1
+    if device != "cpu":
+        ref_model.to("cpu")
+        return dict(value=ENVS * n / t_used, unit="env-steps/s", cores=1, kind="port",
+                    sample="%d full env-step batches after warm-up; %s on 1 host thread + restated driver + torch fp32 model on "
+                           "the MI355X via stock PyTorch-ROCm (the reference with cuda=True); %.1f s" % (n, kind_tree, t_used))
     return dict(value=ENVS * n / t_used, unit="env-steps/s", cores=cores, kind="port",
                 sample="%d full env-step batches (256 envs x 50 sims) after a 32-env warm-up; %s + restated "
                        "EfficientZeroMCTSCtree.search driver + torch fp32 model on %d threads; %.1f s" %
@@ -209,6 +222,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]])
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            try:
+                out["deployed_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]], device="cuda")
+                out["config"]["speedup_vs_deployed_baseline"] = value / out["deployed_baseline"]["value"]
+            except Exception as e:  # the reported baselines never take the measured line down with them
+                out["deployed_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -131,7 +131,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.rep = D ? (int32_t *)(base + o_rep) : nullptr; t.nchild = D ? (int32_t *)(base + o_nch) : nullptr;
     t.actions = D ? (float *)(base + o_act) : nullptr; t.res_last_action_f = D ? (float *)(base + o_laf) : nullptr;
     t.rng_epoch = (uint32_t *)(base + o_ep);
-    (void)hipMemset(t.rng_epoch, 0, 4);
+    (void)hipMemset(r->slab, 0, off);  // no kernel may depend on what the allocator handed back (epoch, legal lists, results)
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
     *out = r;
     return LZ_OK;
@@ -408,7 +408,8 @@ extern "C" int lz_roots_get_values(lz_roots *r, float *h_out_values)
     hipStream_t s = r->eng->stream;
     int32_t *d = (int32_t *)r->d_stage;
     float *dv = (float *)(d + (size_t)B * A + B);
-    lz_tree_launch_readout(t, d, nullptr, dv, s);
+    if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) lz_stree_launch_readout(t, d, dv, s);  // no legal-action lists there
+    else lz_tree_launch_readout(t, d, nullptr, dv, s);
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, dv, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));
