@@ -138,6 +138,9 @@ int lz_sbatch_traverse(lz_roots *r, int pb_c_base, float pb_c_init, float discou
 int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_index, float discount_factor, const float *h_value_prefixs,
                             const float *h_values, const float *h_policy, const int32_t *h_is_reset,
                             const int32_t *h_to_play, const float *h_given);
+/* parity runs of the fused sampled search: inject the post-tanh draws of every expansion, [records][root_num][K][D]
+ * (record 0 = Roots.prepare, record s + 1 = simulation s); NULL / 0 returns to device-side sampling */
+int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records);
 /* Roots.get_distributions ([root_num][K] visit counts) / get_sampled_actions ([root_num][K][D]) */
 int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out);
 int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
@@ -149,10 +152,12 @@ int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
  * (lzero/policy/scaling_transform.py:82-92) fused into the value / value-prefix heads.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct lz_model_cfg {
-    int model_type;         /* 0: EfficientZeroModel (conv)   1: MuZeroModel (conv) */
-    int obs_c, obs_h, obs_w;/* observation_shape, e.g. 4, 96, 96 */
+    int model_type;         /* 0: EfficientZeroModel (conv)   1: MuZeroModel (conv)   2: MuZeroModelMLP (muzero_model_mlp.py)
+                               3: EfficientZeroModelMLP (efficientzero_model_mlp.py)   4: SampledEfficientZeroModelMLP, continuous
+                               actions (sampled_efficientzero_model_mlp.py) */
+    int obs_c, obs_h, obs_w;/* observation_shape, e.g. 4, 96, 96; MLP models: obs_c = vector length, obs_h = obs_w = 1 */
     int action_space_size;
-    int num_channels;       /* 64 */
+    int num_channels;       /* 64; MLP models: latent_state_dim */
     int lstm_hidden_size;   /* 512 (EfficientZero) */
     int head_channels;      /* reward/value/policy head channels (16) */
     int head_hidden;        /* hidden width of the head MLPs (32) */
@@ -161,6 +166,14 @@ typedef struct lz_model_cfg {
     float bn_eps;           /* 1e-5 */
     int downsample;         /* 1: DownSample tower, 96x96 obs -> 6x6 latent (Atari); 0: latent grid = obs grid (board games,
                                e.g. Go 9x9: obs 17x9x9) */
+    /* ---- MLP model family only (model_type >= 2); the layer widths are taken from the tensors themselves */
+    int activation;         /* 0 ReLU, 1 GELU(approximate='tanh') */
+    int res_connection_in_dynamics;
+    int action_encoding;    /* 0 one_hot, 1 not_one_hot (action / action_space_size), 2 continuous (the action vector) */
+    int num_of_sampled_actions;  /* K (model_type 4) */
+    int sigma_type;         /* 0 conditioned */
+    int bound_type;         /* 0 None, 1 tanh on mu */
+    float ln_eps;           /* 1e-5 */
 } lz_model_cfg;
 
 /* One model per engine.  Weights are ingested by their reference state_dict names

@@ -18,7 +18,10 @@ class ModelCfg(ctypes.Structure):
     _fields_ = [("model_type", ctypes.c_int), ("obs_c", ctypes.c_int), ("obs_h", ctypes.c_int), ("obs_w", ctypes.c_int),
                 ("action_space_size", ctypes.c_int), ("num_channels", ctypes.c_int), ("lstm_hidden_size", ctypes.c_int),
                 ("head_channels", ctypes.c_int), ("head_hidden", ctypes.c_int), ("support_size", ctypes.c_int),
-                ("support_min", ctypes.c_float), ("bn_eps", ctypes.c_float), ("downsample", ctypes.c_int)]
+                ("support_min", ctypes.c_float), ("bn_eps", ctypes.c_float), ("downsample", ctypes.c_int),
+                ("activation", ctypes.c_int), ("res_connection_in_dynamics", ctypes.c_int), ("action_encoding", ctypes.c_int),
+                ("num_of_sampled_actions", ctypes.c_int), ("sigma_type", ctypes.c_int), ("bound_type", ctypes.c_int),
+                ("ln_eps", ctypes.c_float)]
 
 
 _lib = None
@@ -68,6 +71,7 @@ def lib():
         "lz_sbatch_backpropagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, P],
         "lz_sroots_get_distributions": [P, c_i32p],
         "lz_sroots_get_sampled_actions": [P, c_f32p],
+        "lz_sroots_set_given": [P, P, ctypes.c_int],
         "lz_model_create": [P, ctypes.POINTER(ModelCfg)],
         "lz_model_set_tensor": [P, ctypes.c_char_p, c_f32p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
         "lz_model_finalize": [P],

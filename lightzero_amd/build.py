@@ -20,6 +20,8 @@ UNITS = [
     ("lz_tree_sampled.hip", ["-ffp-contract=off"]),
     ("lz_capi.hip", []),
     ("lz_nn.hip", []),
+    ("lz_dense.hip", []),
+    ("lz_mlp.hip", []),
     ("lz_search.hip", []),
 ]
 

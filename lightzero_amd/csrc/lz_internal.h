@@ -116,6 +116,9 @@ struct lz_roots {
     float *d_noise = nullptr;       // [B][A]
     int32_t *d_noise_off = nullptr; // [B]
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
+    float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
+    float *d_given = nullptr;       // Sampled-EZ parity runs: [records][B][K][D] injected draws (record 0 = roots, s + 1 = simulation s)
+    int given_records = 0;
     hipGraphExec_t graph_exec = nullptr;  // captured search (lz_search)
     lz_graph_key graph_key{};
     bool inferred = false;

@@ -1,0 +1,181 @@
+// lz_model.h -- device-side weight containers and the state_dict ingestion helpers shared by the convolutional
+// (lz_search.hip) and the vector-observation / MLP (lz_mlp.hip) model families.
+#pragma once
+#include <math.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lz_internal.h"
+#include "lz_nn_kernels.h"
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvW {
+    float *w = nullptr, *scale = nullptr, *shift = nullptr;
+    float *wf = nullptr;  // MFMA-fragment order [cout/16][9][cin/16][64 lanes][4] for the LDS-resident conv chain
+    int cin = 0, cout = 0;
+};
+struct MlpW {
+    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* transposed [HID][NOUT] */, *b2 = nullptr;
+    int K1 = 0, NOUT = 0;
+};
+struct C1W {
+    float *w = nullptr, *b = nullptr, *s = nullptr, *t = nullptr;
+};
+
+struct lz_model {
+    lz_model_cfg cfg{};
+    std::map<std::string, HostTensor> raw;
+    bool finalized = false;
+    std::vector<void *> allocs;
+    int HWl = 0;  // latent pixels (6x6 = 36 with downsample; obs_h*obs_w without)
+    int GW = 6, GH = 6;
+    ConvW rin;    // no-downsample input conv (weights [9][C][64] in rin.w)
+    // representation
+    float *first_w = nullptr, *first_s = nullptr, *first_t = nullptr;
+    ConvW r1a, r1b, dn1, dn2, dn3, r2a, r2b, r3a, r3b, rpa, rpb;
+    // dynamics
+    ConvW dyn, dra, drb;
+    float *act_table = nullptr;
+    C1W rew_c;
+    float *lstm_w = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
+    MlpW fc_reward;
+    // prediction
+    ConvW pa, pb;
+    C1W val_c, pol_c;
+    MlpW fc_value, fc_policy;
+    // workspaces for initial inference
+    int ws_B = 0;
+    float *ws[3] = {nullptr, nullptr, nullptr};
+    struct lz_mlp_model *mlp = nullptr;  // vector-observation family (model_type >= 2), see lz_mlp.hip
+    int debug_stop = 0;  // lz_debug_set("stop_stage"): leave lz_initial_inference after stage k
+};
+
+
+namespace {
+
+struct Builder {
+    lz_model *m;
+    std::string err;
+    const HostTensor *get(const std::string &name, std::initializer_list<int64_t> shape)
+    {
+        auto it = m->raw.find(name);
+        if (it == m->raw.end()) { if (err.empty()) err = "missing tensor '" + name + "'"; return nullptr; }
+        const HostTensor &t = it->second;
+        if (t.shape.size() != shape.size() || !std::equal(shape.begin(), shape.end(), t.shape.begin())) {
+            if (err.empty()) err = "tensor '" + name + "' has an unexpected shape";
+            return nullptr;
+        }
+        return &t;
+    }
+    float *upload(const std::vector<float> &v)
+    {
+        float *d = nullptr;
+        if (hipMalloc((void **)&d, v.size() * 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
+        m->allocs.push_back(d);
+        if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
+        return d;
+    }
+    // eval-mode BatchNorm -> y = x*scale + shift
+    void bn(const std::string &prefix, int n, std::vector<float> &scale, std::vector<float> &shift)
+    {
+        const HostTensor *w = get(prefix + ".weight", {n}), *b = get(prefix + ".bias", {n}),
+                         *mu = get(prefix + ".running_mean", {n}), *var = get(prefix + ".running_var", {n});
+        scale.assign(n, 1.0f);
+        shift.assign(n, 0.0f);
+        if (!w || !b || !mu || !var) return;
+        for (int i = 0; i < n; ++i) {
+            const float inv = 1.0f / sqrtf(var->data[i] + m->cfg.bn_eps);
+            scale[i] = w->data[i] * inv;
+            shift[i] = b->data[i] - mu->data[i] * scale[i];
+        }
+    }
+    // conv weight [cout][cin_total][3][3] -> packed [cout/16][9][16][cin] (first `cin` input channels)
+    ConvW conv(const std::string &wname, const std::string &bnprefix, int cout, int cin_total, int cin)
+    {
+        ConvW c;
+        c.cin = cin;
+        c.cout = cout;
+        const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
+        std::vector<float> sc(cout, 1.0f), sh(cout, 0.0f);
+        if (!bnprefix.empty()) bn(bnprefix, cout, sc, sh);
+        if (!w) return c;
+        std::vector<float> p((size_t)cout * 9 * cin);
+        for (int co = 0; co < cout; ++co)
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < cin; ++ci)
+                    p[(((size_t)(co / 16) * 9 + t) * 16 + co % 16) * cin + ci] = w->data[(((size_t)co * cin_total + ci) * 9) + t];
+        c.w = upload(p);
+        c.scale = upload(sc);
+        c.shift = upload(sh);
+        {
+            std::vector<float> f((size_t)cout * 9 * cin);
+            for (int nt = 0; nt < cout / 16; ++nt)
+                for (int t = 0; t < 9; ++t)
+                    for (int g = 0; g < cin / 16; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = lane & 15, kq = lane >> 4, ci = g * 16 + kq * 4 + j, co = nt * 16 + n;
+                                f[((((size_t)nt * 9 + t) * (cin / 16) + g) * 64 + lane) * 4 + j] = w->data[(((size_t)co * cin_total + ci) * 9) + t];
+                            }
+            c.wf = upload(f);
+        }
+        return c;
+    }
+    ConvW resconv(const std::string &prefix, int idx, int cout, int cin)  // ding ResBlock convN = Sequential(conv, bn[, act])
+    {
+        const std::string p = prefix + ".conv" + std::to_string(idx);
+        return conv(p + ".0.weight", p + ".1", cout, cin, cin);
+    }
+    C1W conv1x1(const std::string &cprefix, const std::string &bnprefix, int cout, int cin)
+    {
+        C1W c;
+        const HostTensor *w = get(cprefix + ".weight", {cout, cin, 1, 1}), *b = get(cprefix + ".bias", {cout});
+        std::vector<float> sc, sh;
+        bn(bnprefix, cout, sc, sh);
+        if (!w || !b) return c;
+        c.w = upload(w->data);
+        c.b = upload(b->data);
+        c.s = upload(sc);
+        c.t = upload(sh);
+        return c;
+    }
+    // Linear - BN1d - ReLU - Linear; conv_flat: K1 = HC*HW in the reference's (channel, pixel) order ->
+    // permute the columns to this engine's (pixel, channel) order
+    MlpW mlp(const std::string &prefix, int K1, int HID, int NOUT, bool conv_flat, int HC, int HW)
+    {
+        MlpW o;
+        o.K1 = K1;
+        o.NOUT = NOUT;
+        const HostTensor *w1 = get(prefix + ".0.weight", {HID, K1}), *b1 = get(prefix + ".0.bias", {HID}),
+                         *w2 = get(prefix + ".3.weight", {NOUT, HID}), *b2 = get(prefix + ".3.bias", {NOUT});
+        std::vector<float> sc, sh;
+        bn(prefix + ".1", HID, sc, sh);
+        if (!w1 || !b1 || !w2 || !b2) return o;
+        std::vector<float> w1p(w1->data);
+        if (conv_flat) {
+            for (int u = 0; u < HID; ++u)
+                for (int p = 0; p < HW; ++p)
+                    for (int c = 0; c < HC; ++c) w1p[(size_t)u * K1 + p * HC + c] = w1->data[(size_t)u * K1 + c * HW + p];
+        }
+        o.w1 = upload(w1p);
+        o.b1 = upload(b1->data);
+        o.s1 = upload(sc);
+        o.t1 = upload(sh);
+        std::vector<float> w2t((size_t)HID * NOUT);
+        for (int n = 0; n < NOUT; ++n)
+            for (int k = 0; k < HID; ++k) w2t[(size_t)k * NOUT + n] = w2->data[(size_t)n * HID + k];
+        o.w2 = upload(w2t);
+        o.b2 = upload(b2->data);
+        return o;
+    }
+};
+
+
+}  // namespace

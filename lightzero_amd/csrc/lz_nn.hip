@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
         if (a.search_len && a.horizon > 0) reset = (a.search_len[b] % a.horizon) == 0;  // mcts_ctree.py:859-863
         a.h_out[(size_t)b * a.H + unit] = reset ? 0.0f : hn;
         a.c_out[(size_t)b * a.H + unit] = reset ? 0.0f : cn;
-        a.hbn_out[(size_t)b * a.H + unit] = fmaxf(hn * a.bn_scale[unit] + a.bn_shift[unit], 0.0f);
+        // conv model: BatchNorm1d + ReLU feed the value-prefix head; MLP models (efficientzero_model_mlp.py) feed it h' itself
+        a.hbn_out[(size_t)b * a.H + unit] = a.bn_scale ? fmaxf(hn * a.bn_scale[unit] + a.bn_shift[unit], 0.0f) : hn;
     }
 }
 
@@ -1062,6 +1063,8 @@ static void launch_lstm_m(const lz_lstm_args &a, hipStream_t s)
     if (nchunk == 17) hipLaunchKernelGGL((k_lstm<17, MROWS>), grid, block, lds, s, a);
     else if (nchunk == 13) hipLaunchKernelGGL((k_lstm<13, MROWS>), grid, block, lds, s, a);
     else if (nchunk == 9) hipLaunchKernelGGL((k_lstm<9, MROWS>), grid, block, lds, s, a);
+    else if (nchunk == 12) hipLaunchKernelGGL((k_lstm<12, MROWS>), grid, block, lds, s, a);  // MLP models: latent 256 + hidden 512
+    else if (nchunk == 4) hipLaunchKernelGGL((k_lstm<4, MROWS>), grid, block, lds, s, a);    // latent 128 + hidden 128
 }
 
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)

@@ -88,7 +88,7 @@ struct lz_lstm_args {
     const int32_t *gather_ix;      // [B]
     const float *wcat;       // [4H][KX+H], row n = 4*unit + gate (gate order i,f,g,o)
     const float *bias;       // [4H] same order (b_ih + b_hh)
-    const float *bn_scale, *bn_shift;  // [H]
+    const float *bn_scale, *bn_shift;  // [H]; null => hbn_out = h' (no norm / activation)
     const int32_t *search_len;  // [B] (reset when search_len % horizon == 0); may be null => no reset
     int horizon;
     float *h_out, *c_out;    // [B][H] destination slot of the pools
@@ -111,3 +111,37 @@ struct lz_head_desc {
     float *out_scalar;     // [B] (categorical)
 };
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s);
+
+// Dense layer for the vector-observation (MLP) model family:
+//   y = [act]( [LN | BN]( [x | x2] . W^T + bias ) ) [+ residual]     (+ optional final transform)
+// One workgroup owns 16 rows x all N columns (so LayerNorm / softmax run in the epilogue); up to 4 independent layers
+// (jobs) share a launch (blockIdx.y = job).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
+struct lz_dense_job {
+    const float *x;            // [B][K1], or a pool base when x_gather != null (row b from slot x_gather[b])
+    const int32_t *x_gather;
+    int64_t x_slot_stride;
+    const float *x2;           // second input block (the action encoding); mode 1: float rows [B][K2]
+    const int32_t *x2_idx;     // mode 2: one-hot(x2_idx[b]) of width K2 ; mode 3: the scalar x2_idx[b] / x2_div
+    float x2_div;
+    int K1, K2, x2_mode;
+    const float *wf;           // MFMA-fragment order [Np/16][Kp/16][64 lanes][4]: lane (n = l%16, g = l/16) holds W[n0+n][k0+4g..4g+3]
+    const float *bias;         // [N]
+    const float *scale, *shift;  // optional [N] folded eval-mode BatchNorm1d
+    const float *ln_g, *ln_b;  // optional [N] LayerNorm affine
+    float ln_eps;
+    int N, act;                // act: 0 none, 1 ReLU, 2 GELU(tanh)
+    const float *res;          // optional residual rows [B][N] (a pool base with res_gather)
+    const int32_t *res_gather;
+    int64_t res_slot_stride;
+    float *out, *out2;         // [B][N] each, either may be null
+    int final;                 // 0 none ; 1 softmax . support -> h^-1 -> out_scalar[B] ; 2 columns >= final_split: exp(clamp(v, -20, 2)),
+                               //   columns < final_split: tanh when final_tanh
+    int final_split, final_tanh;
+    float support_min;
+    float *out_scalar;
+};
+struct lz_dense_args {
+    lz_dense_job job[4];
+    int njobs, B;
+};
+void lz_launch_dense(const lz_dense_args &a, hipStream_t s);

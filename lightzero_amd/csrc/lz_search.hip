@@ -18,63 +18,44 @@
 #include "lz_internal.h"
 #include "lz_nn_kernels.h"
 
-struct HostTensor {
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-};
-
-struct ConvW {
-    float *w = nullptr, *scale = nullptr, *shift = nullptr;
-    float *wf = nullptr;  // MFMA-fragment order [cout/16][9][cin/16][64 lanes][4] for the LDS-resident conv chain
-    int cin = 0, cout = 0;
-};
-struct MlpW {
-    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* transposed [HID][NOUT] */, *b2 = nullptr;
-    int K1 = 0, NOUT = 0;
-};
-struct C1W {
-    float *w = nullptr, *b = nullptr, *s = nullptr, *t = nullptr;
-};
-
-struct lz_model {
-    lz_model_cfg cfg{};
-    std::map<std::string, HostTensor> raw;
-    bool finalized = false;
-    std::vector<void *> allocs;
-    int HWl = 0;  // latent pixels (6x6 = 36 with downsample; obs_h*obs_w without)
-    int GW = 6, GH = 6;
-    ConvW rin;    // no-downsample input conv (weights [9][C][64] in rin.w)
-    // representation
-    float *first_w = nullptr, *first_s = nullptr, *first_t = nullptr;
-    ConvW r1a, r1b, dn1, dn2, dn3, r2a, r2b, r3a, r3b, rpa, rpb;
-    // dynamics
-    ConvW dyn, dra, drb;
-    float *act_table = nullptr;
-    C1W rew_c;
-    float *lstm_w = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
-    MlpW fc_reward;
-    // prediction
-    ConvW pa, pb;
-    C1W val_c, pol_c;
-    MlpW fc_value, fc_policy;
-    // workspaces for initial inference
-    int ws_B = 0;
-    float *ws[3] = {nullptr, nullptr, nullptr};
-    int debug_stop = 0;  // lz_debug_set("stop_stage"): leave lz_initial_inference after stage k
-};
+#include "lz_model.h"
+#include "lz_mlp.h"
 
 void lz_model_destroy(lz_model *m)
 {
     if (!m) return;
     for (void *p : m->allocs) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (m->ws[i]) (void)hipFree(m->ws[i]);
+    if (m->mlp) lz_mlp_model_destroy(m->mlp);
     delete m;
 }
 
 extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
 {
     LZ_REQUIRE(e != nullptr && cfg != nullptr, "NULL argument");
-    LZ_REQUIRE(cfg->model_type == 0 || cfg->model_type == 1, "model_type must be 0 (EfficientZeroModel) or 1 (MuZeroModel), conv + downsample");
+    LZ_REQUIRE(cfg->model_type >= 0 && cfg->model_type <= 4, "model_type must be 0 (EfficientZeroModel), 1 (MuZeroModel), 2 (MuZeroModelMLP), 3 (EfficientZeroModelMLP) or 4 (SampledEfficientZeroModelMLP)");
+    LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
+    if (cfg->model_type >= 2) {
+        // vector observations: obs_c = observation_shape, num_channels = latent_state_dim; the layer widths come from the tensors
+        LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_h == 1 && cfg->obs_w == 1, "MLP models take obs_c = observation_shape, obs_h = obs_w = 1");
+        LZ_REQUIRE(cfg->num_channels >= 16 && cfg->num_channels <= 1024, "latent_state_dim must be in [16, 1024]");
+        LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
+        LZ_REQUIRE(cfg->action_encoding >= 0 && cfg->action_encoding <= 2, "action_encoding must be 0 (one_hot), 1 (not_one_hot) or 2 (continuous)");
+        LZ_REQUIRE((cfg->action_encoding == 2) == (cfg->model_type == 4), "continuous actions <-> SampledEfficientZeroModelMLP (the discrete sampled tree is not compiled)");
+        if (cfg->model_type != 2) {
+            const int nchunk = (cfg->num_channels + cfg->lstm_hidden_size) / 64;
+            LZ_REQUIRE(cfg->num_channels % 64 == 0 && cfg->lstm_hidden_size % 64 == 0 && (nchunk == 4 || nchunk == 12 || nchunk == 9 || nchunk == 13 || nchunk == 17),
+                       "compiled LSTM shapes: (latent_state_dim + lstm_hidden_size) / 64 in {4, 9, 12, 13, 17}, both multiples of 64");
+        }
+        if (e->model) lz_model_destroy(e->model);
+        e->model = new (std::nothrow) lz_model();
+        if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+        e->model->cfg = *cfg;
+        if (e->model->cfg.bn_eps <= 0) e->model->cfg.bn_eps = 1e-5f;
+        if (e->model->cfg.ln_eps <= 0) e->model->cfg.ln_eps = 1e-5f;
+        e->model->GW = e->model->GH = e->model->HWl = 1;
+        return LZ_OK;
+    }
     LZ_REQUIRE(cfg->num_channels == 64, "num_channels must be 64");
     if (cfg->downsample) {
         LZ_REQUIRE(cfg->obs_h == 96 && cfg->obs_w == 96, "observation must be 96x96 on the downsample path");
@@ -85,7 +66,6 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     }
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
-    LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
     if (e->model) lz_model_destroy(e->model);
     e->model = new (std::nothrow) lz_model();
@@ -111,127 +91,6 @@ extern "C" int lz_model_set_tensor(lz_engine *e, const char *name, const float *
     return LZ_OK;
 }
 
-namespace {
-
-struct Builder {
-    lz_model *m;
-    std::string err;
-    const HostTensor *get(const std::string &name, std::initializer_list<int64_t> shape)
-    {
-        auto it = m->raw.find(name);
-        if (it == m->raw.end()) { if (err.empty()) err = "missing tensor '" + name + "'"; return nullptr; }
-        const HostTensor &t = it->second;
-        if (t.shape.size() != shape.size() || !std::equal(shape.begin(), shape.end(), t.shape.begin())) {
-            if (err.empty()) err = "tensor '" + name + "' has an unexpected shape";
-            return nullptr;
-        }
-        return &t;
-    }
-    float *upload(const std::vector<float> &v)
-    {
-        float *d = nullptr;
-        if (hipMalloc((void **)&d, v.size() * 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
-        m->allocs.push_back(d);
-        if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
-        return d;
-    }
-    // eval-mode BatchNorm -> y = x*scale + shift
-    void bn(const std::string &prefix, int n, std::vector<float> &scale, std::vector<float> &shift)
-    {
-        const HostTensor *w = get(prefix + ".weight", {n}), *b = get(prefix + ".bias", {n}),
-                         *mu = get(prefix + ".running_mean", {n}), *var = get(prefix + ".running_var", {n});
-        scale.assign(n, 1.0f);
-        shift.assign(n, 0.0f);
-        if (!w || !b || !mu || !var) return;
-        for (int i = 0; i < n; ++i) {
-            const float inv = 1.0f / sqrtf(var->data[i] + m->cfg.bn_eps);
-            scale[i] = w->data[i] * inv;
-            shift[i] = b->data[i] - mu->data[i] * scale[i];
-        }
-    }
-    // conv weight [cout][cin_total][3][3] -> packed [cout/16][9][16][cin] (first `cin` input channels)
-    ConvW conv(const std::string &wname, const std::string &bnprefix, int cout, int cin_total, int cin)
-    {
-        ConvW c;
-        c.cin = cin;
-        c.cout = cout;
-        const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
-        std::vector<float> sc(cout, 1.0f), sh(cout, 0.0f);
-        if (!bnprefix.empty()) bn(bnprefix, cout, sc, sh);
-        if (!w) return c;
-        std::vector<float> p((size_t)cout * 9 * cin);
-        for (int co = 0; co < cout; ++co)
-            for (int t = 0; t < 9; ++t)
-                for (int ci = 0; ci < cin; ++ci)
-                    p[(((size_t)(co / 16) * 9 + t) * 16 + co % 16) * cin + ci] = w->data[(((size_t)co * cin_total + ci) * 9) + t];
-        c.w = upload(p);
-        c.scale = upload(sc);
-        c.shift = upload(sh);
-        {
-            std::vector<float> f((size_t)cout * 9 * cin);
-            for (int nt = 0; nt < cout / 16; ++nt)
-                for (int t = 0; t < 9; ++t)
-                    for (int g = 0; g < cin / 16; ++g)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 4; ++j) {
-                                const int n = lane & 15, kq = lane >> 4, ci = g * 16 + kq * 4 + j, co = nt * 16 + n;
-                                f[((((size_t)nt * 9 + t) * (cin / 16) + g) * 64 + lane) * 4 + j] = w->data[(((size_t)co * cin_total + ci) * 9) + t];
-                            }
-            c.wf = upload(f);
-        }
-        return c;
-    }
-    ConvW resconv(const std::string &prefix, int idx, int cout, int cin)  // ding ResBlock convN = Sequential(conv, bn[, act])
-    {
-        const std::string p = prefix + ".conv" + std::to_string(idx);
-        return conv(p + ".0.weight", p + ".1", cout, cin, cin);
-    }
-    C1W conv1x1(const std::string &cprefix, const std::string &bnprefix, int cout, int cin)
-    {
-        C1W c;
-        const HostTensor *w = get(cprefix + ".weight", {cout, cin, 1, 1}), *b = get(cprefix + ".bias", {cout});
-        std::vector<float> sc, sh;
-        bn(bnprefix, cout, sc, sh);
-        if (!w || !b) return c;
-        c.w = upload(w->data);
-        c.b = upload(b->data);
-        c.s = upload(sc);
-        c.t = upload(sh);
-        return c;
-    }
-    // Linear - BN1d - ReLU - Linear; conv_flat: K1 = HC*HW in the reference's (channel, pixel) order ->
-    // permute the columns to this engine's (pixel, channel) order
-    MlpW mlp(const std::string &prefix, int K1, int HID, int NOUT, bool conv_flat, int HC, int HW)
-    {
-        MlpW o;
-        o.K1 = K1;
-        o.NOUT = NOUT;
-        const HostTensor *w1 = get(prefix + ".0.weight", {HID, K1}), *b1 = get(prefix + ".0.bias", {HID}),
-                         *w2 = get(prefix + ".3.weight", {NOUT, HID}), *b2 = get(prefix + ".3.bias", {NOUT});
-        std::vector<float> sc, sh;
-        bn(prefix + ".1", HID, sc, sh);
-        if (!w1 || !b1 || !w2 || !b2) return o;
-        std::vector<float> w1p(w1->data);
-        if (conv_flat) {
-            for (int u = 0; u < HID; ++u)
-                for (int p = 0; p < HW; ++p)
-                    for (int c = 0; c < HC; ++c) w1p[(size_t)u * K1 + p * HC + c] = w1->data[(size_t)u * K1 + c * HW + p];
-        }
-        o.w1 = upload(w1p);
-        o.b1 = upload(b1->data);
-        o.s1 = upload(sc);
-        o.t1 = upload(sh);
-        std::vector<float> w2t((size_t)HID * NOUT);
-        for (int n = 0; n < NOUT; ++n)
-            for (int k = 0; k < HID; ++k) w2t[(size_t)k * NOUT + n] = w2->data[(size_t)n * HID + k];
-        o.w2 = upload(w2t);
-        o.b2 = upload(b2->data);
-        return o;
-    }
-};
-
-}  // namespace
-
 extern "C" int lz_model_finalize(lz_engine *e)
 {
     LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
@@ -239,6 +98,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
     lz_model *m = e->model;
     for (void *p : m->allocs) (void)hipFree(p);
     m->allocs.clear();
+    if (m->cfg.model_type >= 2) return lz_mlp_finalize(e);
     const lz_model_cfg &c = m->cfg;
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
               H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size;
@@ -477,9 +337,15 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     LZ_REQUIRE(r != nullptr && d_obs != nullptr, "NULL argument");
     lz_model *m = r->eng->model;
     if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
-    LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
-    LZ_REQUIRE(r->t.variant == (m->cfg.model_type == 0 ? LZ_TREE_EFFICIENTZERO : LZ_TREE_MUZERO), "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree)");
+    {
+        const int mt = m->cfg.model_type;
+        const int want = (mt == 0 || mt == 3) ? LZ_TREE_EFFICIENTZERO : (mt == 4 ? LZ_TREE_SAMPLED_EFFICIENTZERO : LZ_TREE_MUZERO);
+        LZ_REQUIRE(r->t.variant == want, "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree, sampled model <-> sampled tree)");
+        if (mt == 4) LZ_REQUIRE(r->t.D == m->cfg.action_space_size && r->t.A == m->cfg.num_of_sampled_actions, "sampled roots (K, action dim) differ from the model's");
+        else LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
+    }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    if (m->cfg.model_type >= 2) return lz_mlp_initial_inference(r, d_obs);
     int rc = ensure_pools(r);
     if (rc != LZ_OK) return rc;
     rc = ensure_ws(m, r->t.B);
@@ -559,11 +425,26 @@ extern "C" int lz_initial_inference_host(lz_roots *r, const float *h_obs)
 extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits)
 {
     LZ_REQUIRE(r != nullptr && r->inferred, "lz_initial_inference has not run on these roots");
-    const size_t B = r->t.B, A = r->t.A;
+    const size_t B = r->t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)r->t.A;
     hipStream_t s = r->eng->stream;
     if (h_pred_values) LZ_HIP_CHECK(hipMemcpyAsync(h_pred_values, r->sim_value, B * 4, hipMemcpyDeviceToHost, s));
     if (h_policy_logits) LZ_HIP_CHECK(hipMemcpyAsync(h_policy_logits, r->sim_logits, B * A * 4, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records)
+{
+    LZ_REQUIRE(r != nullptr && r->t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO, "not a Sampled-EfficientZero roots handle");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    if (r->d_given) { (void)hipFree(r->d_given); r->d_given = nullptr; }
+    r->given_records = 0;
+    if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }  // the pointers are baked into the graph
+    if (!h_draws || records <= 0) return LZ_OK;
+    const size_t n = (size_t)records * r->t.B * r->t.A * r->t.D;
+    LZ_HIP_CHECK(hipMalloc((void **)&r->d_given, n * 4));
+    LZ_HIP_CHECK(hipMemcpy(r->d_given, h_draws, n * 4, hipMemcpyHostToDevice));
+    r->given_records = records;
     return LZ_OK;
 }
 
@@ -572,6 +453,29 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
 {
     LZ_REQUIRE(r != nullptr && r->inferred && h_to_play != nullptr, "lz_initial_inference must run first; to_play required");
     const lz_tree_dev &t = r->t;
+    if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
+        // Roots.prepare of the sampled tree (cnode.cpp:640-700): K actions per root drawn from the root (mu | sigma); the
+        // Dirichlet noise only perturbs priors that the shipped uniform-prior score never reads
+        const size_t B = t.B;
+        LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+        hipStream_t s = r->eng->stream;
+        int largest = h_to_play[0];
+        for (size_t i = 1; i < B; ++i) if (h_to_play[i] > largest) largest = h_to_play[i];
+        LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, h_to_play, B * 4, hipMemcpyHostToDevice, s));
+        LZ_HIP_CHECK(hipStreamSynchronize(s));
+        lz_sample_args sa;
+        sa.given = (r->d_given && r->given_records > 0) ? r->d_given : nullptr;
+        sa.policy = r->sim_logits;
+        sa.seed = r->seed;
+        sa.counter = 0;
+        lz_stree_launch_prepare(t, sa, r->d_zero_vp, r->d_to_play, s);
+        lz_tree_launch_bump_epoch(t, s);
+        LZ_HIP_CHECK(hipGetLastError());
+        r->players = largest == -1 ? 1 : 2;
+        r->prepared = true;
+        r->traverse_count = 0;
+        return LZ_OK;
+    }
     const size_t B = t.B, A = t.A;
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
@@ -608,6 +512,7 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
 static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
 {
     lz_model *m = r->eng->model;
+    if (m->cfg.model_type >= 2) { lz_mlp_recurrent(r, sim, horizon, s); return; }
     const lz_model_cfg &c = m->cfg;
     const lz_tree_dev &t = r->t;
     const size_t B = t.B, A = t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size;
@@ -652,9 +557,29 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
 static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta, float delta, int horizon, hipStream_t s)
 {
     const lz_tree_dev &t = r->t;
-    const size_t B = t.B, A = t.A;
+    const size_t B = t.B;
+    const size_t A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
     lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
     ta.counter = 0;
+    if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
+        // SampledEfficientZeroMCTSCtree.search (mcts_ctree_sampled.py:480-600): the leaf's K actions are drawn on the
+        // device from the (mu | sigma) the network just produced (or copied from the injected draws of a parity run)
+        const size_t KD = (size_t)t.A * t.D;
+        for (int sim = 0; sim < num_simulations; ++sim) {
+            ta.counter = (uint32_t)sim;
+            lz_stree_launch_traverse(t, ta, delta, r->d_to_play, s);
+            recurrent(r, sim, horizon, s);
+            const int slot = sim + 1;
+            lz_sample_args sa;
+            sa.given = (r->d_given && slot < r->given_records) ? r->d_given + (size_t)slot * B * KD : nullptr;
+            sa.policy = r->sim_logits + (size_t)slot * B * A;
+            sa.seed = r->seed;
+            sa.counter = (uint32_t)slot;
+            lz_stree_launch_backprop(t, slot, ta.discount, r->sim_vp + (size_t)slot * B, r->sim_value + (size_t)slot * B, sa, nullptr, horizon,
+                                     nullptr, s);
+        }
+        return;
+    }
     lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
     for (int sim = 0; sim < num_simulations; ++sim) {
         recurrent(r, sim, horizon, s);
@@ -675,7 +600,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->inferred && r->prepared, "lz_search needs lz_initial_inference and a prepare call first");
-    LZ_REQUIRE(lstm_horizon_len > 0 || r->eng->model->cfg.model_type == 1, "lstm_horizon_len must be positive (mcts_ctree.py:858)");
+    LZ_REQUIRE(lstm_horizon_len > 0 || r->eng->model->cfg.model_type == 1 || r->eng->model->cfg.model_type == 2, "lstm_horizon_len must be positive (mcts_ctree.py:858)");
     if (num_simulations < 1 || num_simulations >= r->t.NN) {
         lz_set_error("num_simulations %d exceeds the node pool (max_simulations %d)", num_simulations, r->t.NN - 1);
         return LZ_ERR_STATE;
@@ -744,7 +669,7 @@ extern "C" int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_p
 {
     LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr, "no pools");
     LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
-    const size_t B = r->t.B, A = r->t.A;
+    const size_t B = r->t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)r->t.A;
     hipStream_t s = r->eng->stream;
     if (h_value_prefix) LZ_HIP_CHECK(hipMemcpyAsync(h_value_prefix, r->sim_vp + slot * B, B * 4, hipMemcpyDeviceToHost, s));
     if (h_value) LZ_HIP_CHECK(hipMemcpyAsync(h_value, r->sim_value + slot * B, B * 4, hipMemcpyDeviceToHost, s));
@@ -758,7 +683,7 @@ extern "C" int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw)
     LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr && h_out_nchw != nullptr, "no pools");
     LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
     lz_model *m = r->eng->model;
-    const size_t B = r->t.B, C = m->cfg.num_channels, HW = m->HWl;
+    const size_t B = r->t.B, C = m->cfg.num_channels, HW = m->HWl;  // MLP models: HW = 1, C = latent_state_dim
     std::vector<float> tmp(B * HW * C);
     hipStream_t s = r->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(tmp.data(), r->latent_pool + slot * B * HW * C, tmp.size() * 4, hipMemcpyDeviceToHost, s));

@@ -89,6 +89,27 @@ class Roots(object):
         L.check(L.lib().lz_sroots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), pol, L.i32(to_play_batch),
                                           self._take_given()))
 
+    # ---- fused path (engine model): the root (mu | sigma) is already in HBM
+    def _ensure(self, action_space_size):
+        if int(action_space_size) != self.D:
+            raise ValueError("model action dimension %d != roots action_space_size %d" % (action_space_size, self.D))
+
+    def prepare_from_inference(self, root_noise_weight, noises, to_play_batch):
+        """Roots.prepare with the (mu | sigma) an engine model's initial_inference left in HBM.  The Dirichlet noise only
+        perturbs priors the shipped uniform-prior score never reads (cnode.cpp:1026-1108), so it is not uploaded."""
+        L.check(L.lib().lz_roots_prepare_from_inference(self._h, float(root_noise_weight), None, L.i32(to_play_batch)))
+
+    def prepare_from_inference_no_noise(self, to_play_batch):
+        L.check(L.lib().lz_roots_prepare_from_inference(self._h, 0.0, None, L.i32(to_play_batch)))
+
+    def set_given_records(self, draws):
+        """parity runs of the fused search: draws [records][B][K][D] (record 0 = roots, s + 1 = simulation s); None clears"""
+        if draws is None:
+            L.check(L.lib().lz_sroots_set_given(self._h, None, 0))
+            return
+        d = np.ascontiguousarray(draws, np.float32).reshape(-1, self.root_num, self.K, self.D)
+        L.check(L.lib().lz_sroots_set_given(self._h, d.ctypes.data, d.shape[0]))
+
     def get_distributions(self):
         out = np.zeros((self.root_num, self.K), np.int32)
         L.check(L.lib().lz_sroots_get_distributions(self._h, out))

@@ -212,6 +212,11 @@ class SampledEfficientZeroMCTSCtree(object):
         import torch
         from ..ctree.ctree_sampled_efficientzero import ezs_tree
         cfg = self._cfg
+        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+            # engine model: the whole loop (select, MLP + LSTM inference, sampling of the leaf's K actions, backup) on the device
+            L.check(L.lib().lz_search(roots._h, int(cfg["num_simulations"]), int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
+                                      float(cfg["discount_factor"]), int(cfg["lstm_horizon_len"]), float(cfg["value_delta_max"])))
+            return
         device = _get(cfg, "device", "cpu")
         with torch.no_grad():
             model.eval()

@@ -292,6 +292,258 @@ class MuZeroModel(nn.Module):  # lzero/model/muzero_model.py:20-374 (inference g
         return MZNetworkOutput(value, reward, policy_logits, next_latent_state)
 
 
+# ------------------------------------------------------------------------------------------------
+# vector-observation (MLP) model family
+# ------------------------------------------------------------------------------------------------
+def _norm1d(norm_type, n):
+    """ding.torch_utils.build_normalization(norm_type, dim=1): 'BN' -> BatchNorm1d, 'LN' -> LayerNorm."""
+    return {"BN": nn.BatchNorm1d, "LN": nn.LayerNorm}[norm_type](n)
+
+
+def mlp_v2(cin, hidden, cout, activation, norm_type, output_activation, output_norm):
+    """lzero/model/common.py:28-98 MLP_V2 (hidden is a list), and -- with hidden = [h] * (layer_num - 1) --
+    ding.torch_utils.MLP(in, h, out, layer_num, ...) restated from DI-engine's published source: every layer is
+    Linear [, norm] [, activation]; the last one takes norm / activation only when output_norm / output_activation."""
+    dims = [cin] + list(hidden) + [cout]
+    layers = []
+    for i in range(len(dims) - 1):
+        last = i == len(dims) - 2
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if norm_type and (not last or output_norm):
+            layers.append(_norm1d(norm_type, dims[i + 1]))
+        if activation is not None and (not last or output_activation):
+            layers.append(activation)
+    return nn.Sequential(*layers)
+
+
+class RepresentationNetworkMLP(nn.Module):  # common.py:790-851
+    def __init__(self, observation_shape, hidden_channels, activation=None, norm_type="BN"):
+        super().__init__()
+        activation = activation if activation is not None else nn.GELU(approximate="tanh")
+        self.fc_representation = mlp_v2(observation_shape, [hidden_channels], hidden_channels, activation, norm_type, False, False)
+        self.norm = nn.LayerNorm(hidden_channels)  # final_norm_option_in_encoder = 'LayerNorm'
+
+    def forward(self, x):
+        return self.norm(self.fc_representation(x.float()))
+
+
+class PredictionNetworkMLP(nn.Module):  # common.py:1218-1295 (discrete policy head)
+    def __init__(self, action_space_size, num_channels, value_hidden, policy_hidden, support, activation, norm_type):
+        super().__init__()
+        self.fc_prediction_common = mlp_v2(num_channels, [num_channels], num_channels, activation, norm_type, True, True)
+        self.fc_value_head = mlp_v2(num_channels, value_hidden, support, activation, norm_type, False, False)
+        self.fc_policy_head = mlp_v2(num_channels, policy_hidden, action_space_size, activation, norm_type, False, False)
+
+    def forward(self, z):
+        x = self.fc_prediction_common(z)
+        return self.fc_policy_head(x), self.fc_value_head(x)
+
+
+class ReparameterizationHead(nn.Module):
+    """ding.model.common.ReparameterizationHead (un-vendored DI-engine; restated from its published source, PARITY
+    UNPINNED): main = MLP(in, in, in, layer_num, activation, norm) ; mu = Linear ; sigma_type 'conditioned':
+    sigma = exp(clamp(Linear(x), -20, 2)) ; 'fixed': constant ; bound_type 'tanh' squashes mu."""
+
+    def __init__(self, input_size, output_size, layer_num=2, sigma_type="conditioned", fixed_sigma_value=0.3,
+                 activation=None, norm_type=None, bound_type=None):
+        super().__init__()
+        self.sigma_type, self.bound_type, self.fixed_sigma_value = sigma_type, bound_type, fixed_sigma_value
+        self.main = mlp_v2(input_size, [input_size] * (layer_num - 1), input_size, activation or nn.ReLU(), norm_type, True, True)
+        self.mu = nn.Linear(input_size, output_size)
+        if sigma_type == "conditioned":
+            self.log_sigma_layer = nn.Linear(input_size, output_size)
+
+    def forward(self, x):
+        x = self.main(x)
+        mu = self.mu(x)
+        if self.bound_type == "tanh":
+            mu = torch.tanh(mu)
+        if self.sigma_type == "conditioned":
+            sigma = torch.exp(torch.clamp(self.log_sigma_layer(x), -20, 2))
+        else:
+            sigma = torch.full_like(mu, self.fixed_sigma_value)
+        return {"mu": mu, "sigma": sigma}
+
+
+class SampledPredictionNetworkMLP(nn.Module):  # sampled_efficientzero_model_mlp.py: class PredictionNetworkMLP
+    def __init__(self, continuous, action_space_size, num_channels, value_hidden, policy_hidden, support, activation,
+                 norm_type, sigma_type, fixed_sigma_value, bound_type):
+        super().__init__()
+        self.continuous = continuous
+        self.fc_prediction_common = mlp_v2(num_channels, [num_channels], num_channels, activation, norm_type, True, True)
+        self.fc_value_head = mlp_v2(num_channels, [value_hidden[0]], support, activation, norm_type, False, False)
+        if continuous:
+            self.fc_policy_head = ReparameterizationHead(num_channels, action_space_size, 2, sigma_type, fixed_sigma_value,
+                                                         nn.ReLU(), None, bound_type)
+        else:
+            self.fc_policy_head = mlp_v2(num_channels, [policy_hidden[0]], action_space_size, activation, norm_type, False, False)
+
+    def forward(self, z):
+        x = self.fc_prediction_common(z)
+        value = self.fc_value_head(x)
+        policy = self.fc_policy_head(x)
+        if self.continuous:
+            policy = torch.cat([policy["mu"], policy["sigma"]], dim=-1)
+        return policy, value
+
+
+class MZDynamicsNetworkMLP(nn.Module):  # muzero_model_mlp.py:340-442
+    def __init__(self, action_encoding_dim, num_channels, reward_hidden, support, activation, norm_type, res):
+        super().__init__()
+        self.action_encoding_dim, self.res = action_encoding_dim, res
+        L = num_channels - action_encoding_dim
+        if res:
+            self.fc_dynamics_1 = mlp_v2(num_channels, [L], L, activation, norm_type, True, True)
+            self.fc_dynamics_2 = mlp_v2(L, [L], L, activation, norm_type, True, True)
+        else:
+            self.fc_dynamics = mlp_v2(num_channels, [L], L, activation, norm_type, True, True)
+        self.fc_reward_head = mlp_v2(L, reward_hidden, support, activation, norm_type, False, False)
+
+    def forward(self, sa):
+        if self.res:
+            nxt = self.fc_dynamics_1(sa) + sa[:, :-self.action_encoding_dim]
+            enc = self.fc_dynamics_2(nxt)
+        else:
+            nxt = self.fc_dynamics(sa)
+            enc = nxt
+        return nxt, self.fc_reward_head(enc)
+
+
+class EZDynamicsNetworkMLP(nn.Module):  # efficientzero_model_mlp.py: class DynamicsNetworkMLP
+    def __init__(self, action_encoding_dim, num_channels, lstm_hidden_size, reward_hidden, support, activation, norm_type, res):
+        super().__init__()
+        self.action_encoding_dim, self.res = action_encoding_dim, res
+        L = num_channels - action_encoding_dim
+        if res:
+            self.fc_dynamics_1 = mlp_v2(num_channels, [L], L, activation, norm_type, True, True)
+            self.fc_dynamics_2 = mlp_v2(L, [L], L, activation, norm_type, True, True)
+        else:
+            self.fc_dynamics = mlp_v2(num_channels, [L], L, activation, norm_type, True, True)
+        self.lstm = nn.LSTM(input_size=L, hidden_size=lstm_hidden_size)
+        self.fc_reward_head = mlp_v2(lstm_hidden_size, [reward_hidden[0]], support, activation, norm_type, False, False)
+
+    def forward(self, sa, reward_hidden_state):
+        if self.res:
+            nxt = self.fc_dynamics_1(sa) + sa[:, :-self.action_encoding_dim]
+            enc = self.fc_dynamics_2(nxt)
+        else:
+            nxt = self.fc_dynamics(sa)
+            enc = nxt
+        vp, hc = self.lstm(enc.unsqueeze(0), reward_hidden_state)
+        return nxt, hc, self.fc_reward_head(vp.squeeze(0))
+
+
+def _encode_action(action, latent, continuous, action_space_size, encoding):
+    """the action-encoding preamble of every MLP model's ``_dynamics`` (e.g. muzero_model_mlp.py:300-322)"""
+    if continuous:
+        if action.dim() == 1:
+            action = action.unsqueeze(-1)
+        elif action.dim() == 3:
+            action = action.squeeze(-1)
+        enc = action
+    elif encoding == "one_hot":
+        if action.dim() == 1:
+            action = action.unsqueeze(-1)
+        enc = torch.zeros(action.shape[0], action_space_size, device=action.device)
+        enc.scatter_(1, action.long(), 1)
+    else:
+        enc = action / action_space_size
+        if enc.dim() == 1:
+            enc = enc.unsqueeze(-1)
+    return torch.cat((latent, enc.to(latent.device).float()), dim=1)
+
+
+class MuZeroModelMLP(nn.Module):  # lzero/model/muzero_model_mlp.py:13-338 (inference graph only)
+    def __init__(self, observation_shape=4, action_space_size=2, latent_state_dim=128, reward_head_hidden_channels=(32,),
+                 value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,), support_range=(-300., 301., 1.),
+                 norm_type="BN", discrete_action_encoding_type="one_hot", res_connection_in_dynamics=False):
+        super().__init__()
+        self.action_space_size, self.encoding = action_space_size, discrete_action_encoding_type
+        self.support_size = len(torch.arange(*support_range))
+        enc = action_space_size if discrete_action_encoding_type == "one_hot" else 1
+        act = nn.ReLU(inplace=True)
+        self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, None, norm_type)
+        self.dynamics_network = MZDynamicsNetworkMLP(enc, latent_state_dim + enc, list(reward_head_hidden_channels),
+                                                     self.support_size, act, norm_type, res_connection_in_dynamics)
+        self.prediction_network = PredictionNetworkMLP(action_space_size, latent_state_dim, list(value_head_hidden_channels),
+                                                       list(policy_head_hidden_channels), self.support_size, act, norm_type)
+
+    def initial_inference(self, obs):
+        z = self.representation_network(obs)
+        policy_logits, value = self.prediction_network(z)
+        return MZNetworkOutput(value, [0. for _ in range(obs.size(0))], policy_logits, z)
+
+    def recurrent_inference(self, latent_state, action):
+        sa = _encode_action(action, latent_state, False, self.action_space_size, self.encoding)
+        nxt, reward = self.dynamics_network(sa)
+        policy_logits, value = self.prediction_network(nxt)
+        return MZNetworkOutput(value, reward, policy_logits, nxt)
+
+
+class EfficientZeroModelMLP(nn.Module):  # lzero/model/efficientzero_model_mlp.py (inference graph only)
+    def __init__(self, observation_shape=4, action_space_size=2, lstm_hidden_size=512, latent_state_dim=256,
+                 reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
+                 support_range=(-300., 301., 1.), norm_type="BN", discrete_action_encoding_type="one_hot",
+                 res_connection_in_dynamics=False):
+        super().__init__()
+        self.action_space_size, self.encoding, self.lstm_hidden_size = action_space_size, discrete_action_encoding_type, lstm_hidden_size
+        self.support_size = len(torch.arange(*support_range))
+        enc = action_space_size if discrete_action_encoding_type == "one_hot" else 1
+        act = nn.ReLU(inplace=True)
+        self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, None, norm_type)
+        self.dynamics_network = EZDynamicsNetworkMLP(enc, latent_state_dim + enc, lstm_hidden_size, list(reward_head_hidden_channels),
+                                                     self.support_size, act, norm_type, res_connection_in_dynamics)
+        self.prediction_network = PredictionNetworkMLP(action_space_size, latent_state_dim, list(value_head_hidden_channels),
+                                                       list(policy_head_hidden_channels), self.support_size, act, norm_type)
+
+    def initial_inference(self, obs):
+        z = self.representation_network(obs)
+        policy_logits, value = self.prediction_network(z)
+        B = obs.size(0)
+        hc = (torch.zeros(1, B, self.lstm_hidden_size).to(obs.device), torch.zeros(1, B, self.lstm_hidden_size).to(obs.device))
+        return EZNetworkOutput(value, [0. for _ in range(B)], policy_logits, z, hc)
+
+    def recurrent_inference(self, latent_state, reward_hidden_state, action):
+        sa = _encode_action(action, latent_state, False, self.action_space_size, self.encoding)
+        nxt, hc, vp = self.dynamics_network(sa, reward_hidden_state)
+        policy_logits, value = self.prediction_network(nxt)
+        return EZNetworkOutput(value, vp, policy_logits, nxt, hc)
+
+
+class SampledEfficientZeroModelMLP(nn.Module):  # lzero/model/sampled_efficientzero_model_mlp.py (inference graph only)
+    def __init__(self, observation_shape=5, action_space_size=1, latent_state_dim=256, lstm_hidden_size=512,
+                 reward_head_hidden_channels=(256,), value_head_hidden_channels=(256,), policy_head_hidden_channels=(256,),
+                 support_range=(-300., 301., 1.), continuous_action_space=True, num_of_sampled_actions=20,
+                 sigma_type="conditioned", fixed_sigma_value=0.3, bound_type=None, norm_type="LN",
+                 discrete_action_encoding_type="one_hot", res_connection_in_dynamics=True):
+        super().__init__()
+        self.action_space_size, self.encoding, self.lstm_hidden_size = action_space_size, discrete_action_encoding_type, lstm_hidden_size
+        self.continuous_action_space, self.num_of_sampled_actions = continuous_action_space, num_of_sampled_actions
+        self.support_size = len(torch.arange(*support_range))
+        enc = action_space_size if (continuous_action_space or discrete_action_encoding_type == "one_hot") else 1
+        act = nn.GELU(approximate="tanh")
+        self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, act, norm_type)
+        self.dynamics_network = EZDynamicsNetworkMLP(enc, latent_state_dim + enc, lstm_hidden_size, list(reward_head_hidden_channels),
+                                                     self.support_size, act, norm_type, res_connection_in_dynamics)
+        self.prediction_network = SampledPredictionNetworkMLP(continuous_action_space, action_space_size, latent_state_dim,
+                                                              list(value_head_hidden_channels), list(policy_head_hidden_channels),
+                                                              self.support_size, act, norm_type, sigma_type, fixed_sigma_value, bound_type)
+
+    def initial_inference(self, obs):
+        z = self.representation_network(obs)
+        policy_logits, value = self.prediction_network(z)
+        B = obs.size(0)
+        hc = (torch.zeros(1, B, self.lstm_hidden_size).to(obs.device), torch.zeros(1, B, self.lstm_hidden_size).to(obs.device))
+        return EZNetworkOutput(value, [0. for _ in range(B)], policy_logits, z, hc)
+
+    def recurrent_inference(self, latent_state, reward_hidden_state, action):
+        sa = _encode_action(action, latent_state, self.continuous_action_space, self.action_space_size, self.encoding)
+        nxt, hc, vp = self.dynamics_network(sa, reward_hidden_state)
+        policy_logits, value = self.prediction_network(nxt)
+        return EZNetworkOutput(value, vp, policy_logits, nxt, hc)
+
+
+
 class InverseScalarTransform(object):  # scaling_transform.py:64-92
     def __init__(self, support_range=(-300., 301., 1.), categorical_distribution=True, device="cpu"):
         self.value_support = torch.arange(*support_range, dtype=torch.float32).unsqueeze(0).to(device)
@@ -324,6 +576,8 @@ def synthetic_init(model, seed=0):
                 m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
                 m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
                 m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+            if isinstance(m, nn.LayerNorm):
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
         for head in ("fc_value", "fc_policy", "fc_reward_head"):
             for m in model.modules():
                 if hasattr(m, head):

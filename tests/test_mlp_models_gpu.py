@@ -1,0 +1,152 @@
+"""Vector-observation (MLP) model family on the device vs the torch fp32 restatement (oracle/torch_models.py) on shared
+seeded weights: MuZeroModelMLP (BASELINE configs[0] CartPole shape), EfficientZeroModelMLP, SampledEfficientZeroModelMLP
+(BASELINE configs[4] DMC state shape).  Tolerances: pre-h^-1 network outputs 2e-5 relative; scalars after h^-1
+3e-4 (1 + |x|) (the transform amplifies fp32 rounding of the softmax expectation)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_models as tm
+from oracle import ctree as octree, search as osearch
+from lightzero_amd import _lib as L
+
+CFG = dict(num_simulations=25, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
+           lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+
+
+def _ist(x):
+    return tm.InverseScalarTransform()(x).reshape(-1).numpy()
+
+
+def test_muzero_mlp_search_matches_oracle_pipeline():
+    from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    from lightzero_amd.mcts.tree_search.mcts_ctree import MuZeroMCTSCtree
+    B, A, S = 8, 2, 25
+    ref = tm.synthetic_init(tm.MuZeroModelMLP(observation_shape=4, action_space_size=A, latent_state_dim=128), seed=3)
+    model = MuZeroModelMLP(observation_shape=4, action_space_size=A, latent_state_dim=128, norm_type='BN').load_state_dict(ref.state_dict())
+    obs = torch.randn(B, 4, generator=torch.Generator().manual_seed(1))
+    legal = [list(range(A))] * B
+    noises = np.random.default_rng(0).dirichlet([0.3] * A, size=B).astype(np.float32).tolist()
+    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    out = model.initial_inference(obs, roots)
+    with torch.no_grad():
+        ro = ref.initial_inference(obs)
+    assert _rel(out.policy_logits, ro.policy_logits.numpy()) < 2e-5
+    assert _rel(out.value, _ist(ro.value)) < 3e-4
+    lat = np.zeros((B, 128), np.float32)
+    L.check(L.lib().lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
+    assert _rel(lat, ro.latent_state.numpy()) < 2e-5
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts = MuZeroMCTSCtree(dict(CFG, num_simulations=S))
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    mcts.search(roots, model, out.latent_state, [-1] * B)
+    dists, values = roots.get_distributions(), roots.get_values()
+    # oracle pipeline: C restatement of the reference tree + torch model
+    od, ov, _, _ = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, [-1] * B, dict(CFG, num_simulations=S),
+                                              roots_kwargs=dict(action_space_size=A, max_simulations=S), deterministic=True)
+    same = sum(int(a == b) for a, b in zip(dists, od))
+    assert same >= B - 1, "only %d / %d visit-count distributions identical" % (same, B)
+    if same == B:
+        assert _rel(values, ov) < 3e-4
+    # last simulation's network outputs vs torch on the latents the device itself produced
+    tr = np.zeros((S, B, 4), np.int32)  # (latent index in search path, last action, search length, virtual to_play)
+    L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+    s = S - 1
+    ix, la = tr[s, :, 0], tr[s, :, 1]
+    pool = np.zeros((S + 1, B, 128), np.float32)
+    for k in range(S + 1):
+        L.check(L.lib().lz_roots_read_latent(roots._h, k, pool[k].reshape(-1)))
+    with torch.no_grad():
+        r = ref.recurrent_inference(torch.from_numpy(pool[ix, np.arange(B)]), torch.from_numpy(la).long())
+    vp = np.zeros(B, np.float32); v = np.zeros(B, np.float32); lg = np.zeros((B, A), np.float32)
+    L.check(L.lib().lz_roots_read_sim_outputs(roots._h, s + 1, vp, v, lg.reshape(-1)))
+    assert _rel(pool[s + 1], r.latent_state.numpy()) < 2e-5
+    assert _rel(lg, r.policy_logits.numpy()) < 2e-5
+    assert _rel(v, _ist(r.value)) < 3e-4 and _rel(vp, _ist(r.reward)) < 3e-4
+
+
+@pytest.mark.parametrize("res", [False, True])
+def test_efficientzero_mlp_search_matches_oracle_pipeline(res):
+    from lightzero_amd.model.efficientzero_model_mlp import EfficientZeroModelMLP
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.mcts.tree_search.mcts_ctree import EfficientZeroMCTSCtree
+    B, A, S, Ld, H = 24, 3, 30, 128, 128
+    ref = tm.synthetic_init(tm.EfficientZeroModelMLP(observation_shape=6, action_space_size=A, lstm_hidden_size=H, latent_state_dim=Ld,
+                                                     res_connection_in_dynamics=res), seed=5)
+    model = EfficientZeroModelMLP(observation_shape=6, action_space_size=A, lstm_hidden_size=H, latent_state_dim=Ld,
+                                  res_connection_in_dynamics=res).load_state_dict(ref.state_dict())
+    obs = torch.randn(B, 6, generator=torch.Generator().manual_seed(2))
+    legal = [list(range(A))] * B
+    noises = np.random.default_rng(1).dirichlet([0.3] * A, size=B).astype(np.float32).tolist()
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    out = model.initial_inference(obs, roots)
+    with torch.no_grad():
+        ro = ref.initial_inference(obs)
+    assert _rel(out.policy_logits, ro.policy_logits.numpy()) < 2e-5
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    cfg = dict(CFG, num_simulations=S)
+    EfficientZeroMCTSCtree(cfg).search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    od, ov, _, _ = osearch.ez_forward_collect(octree.ez_tree, ref, obs, legal, noises, [-1] * B, cfg,
+                                              roots_kwargs=dict(action_space_size=A, max_simulations=S))
+    dists = roots.get_distributions()
+    same = sum(int(a == b) for a, b in zip(dists, od))
+    assert same >= B - 1, "only %d / %d visit-count distributions identical" % (same, B)
+    hh = np.zeros((B, H), np.float32); cc = np.zeros((B, H), np.float32)
+    L.check(L.lib().lz_roots_read_hidden(roots._h, 1, hh.reshape(-1), cc.reshape(-1)))
+    assert np.isfinite(hh).all() and np.abs(hh).max() > 0
+
+
+def test_sampled_mlp_fused_search_matches_oracle_pipeline():
+    """BASELINE configs[4] shape: obs 5, action dim 1, K = 20, latent 256, LSTM 512, LN + GELU, 50 simulations.
+    The oracle pipeline's draws are injected into the fused device search: visit counts must be identical."""
+    from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    B, D, K, S = 32, 1, 20, 50
+    ref = tm.synthetic_init(tm.SampledEfficientZeroModelMLP(observation_shape=5, action_space_size=D, num_of_sampled_actions=K), seed=7)
+    model = SampledEfficientZeroModelMLP(observation_shape=5, action_space_size=D, continuous_action_space=True,
+                                         num_of_sampled_actions=K).load_state_dict(ref.state_dict())
+    obs = torch.randn(B, 5, generator=torch.Generator().manual_seed(3))
+    cfg = dict(CFG, num_simulations=S, model=dict(action_space_size=D, num_of_sampled_actions=K, continuous_action_space=True))
+    with torch.no_grad():
+        o = ref.initial_inference(obs)
+    noises = np.random.default_rng(0).dirichlet([0.3] * K, size=B).astype(np.float32).tolist()
+    oroots = octree.ezs_tree.Roots(B, [[-1] * K] * B, D, K, True, max_simulations=S)
+    oroots.set_clock(77)
+    oroots.prepare(0.25, noises, [0.] * B, o.policy_logits.numpy().tolist(), [-1] * B)
+    osearch.sez_search(octree.ezs_tree, oroots, ref, o.latent_state.numpy(),
+                       (o.reward_hidden_state[0].numpy(), o.reward_hidden_state[1].numpy()), [-1] * B, cfg)
+    draws = np.stack([np.asarray(oroots.get_sampled_actions(e), np.float32).reshape(B, K, D) for e in range(S + 1)])
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [[-1] * K] * B, D, K, True, max_simulations=S)
+    roots.set_tiebreak(0)
+    out = model.initial_inference(obs, roots)
+    assert _rel(out.policy_logits, o.policy_logits.numpy()) < 2e-5
+    assert _rel(out.value, _ist(o.value)) < 3e-4
+    roots.set_given_records(draws)
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    od = oroots.get_distributions()
+    dists = roots.get_distributions()
+    same = sum(int(a == b) for a, b in zip(dists, od))
+    assert same >= B - 1, "only %d / %d visit-count distributions identical" % (same, B)
+    assert np.array_equal(np.asarray(roots.get_sampled_actions(), np.float32), draws[0])
+    # device-side sampling: a second search without injected draws still spends every simulation and replays from the graph
+    roots.set_given_records(None)
+    for _ in range(2):
+        out = model.initial_inference(obs, roots)
+        roots.prepare_from_inference(0.25, noises, [-1] * B)
+        mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+        d2 = np.asarray(roots.get_distributions())
+        assert (d2.sum(1) == S).all()
+        acts = np.asarray(roots.get_sampled_actions())
+        assert np.all(np.abs(acts) <= 1.0) and acts.std() > 0
