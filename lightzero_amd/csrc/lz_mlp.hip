@@ -103,7 +103,7 @@ struct MlpBuilder {
 
 int widest(const std::vector<DenseW> &v, int w)
 {
-    for (const DenseW &d : v) if (d.N > w && d.N < 600) w = d.N;  // the categorical outputs are reduced in the epilogue, never stored
+    for (const DenseW &d : v) if (d.N > w) w = d.N;
     return w;
 }
 
@@ -197,6 +197,9 @@ int lz_mlp_finalize(lz_engine *e)
         else if (M.pol.empty() || M.pol.back().N != M.PA) b.err = "policy head shape mismatch";
         else if (M.common.empty() || M.common.back().N != M.L) b.err = "fc_prediction_common shape mismatch";
     }
+    for (const auto *v : {&M.rep, &M.dyn1, &M.dyn2, &M.rew, &M.common, &M.val, &M.pol})
+        for (const DenseW &dw : *v)
+            if (b.err.empty() && (dw.K > 512 || dw.N > 640)) b.err = "dense layer beyond the compiled limits (in_features <= 512, out_features <= 640)";
     if (!b.err.empty()) { lz_set_error("lz_model_finalize: %s", b.err.c_str()); return LZ_ERR_STATE; }
     int w = std::max(M.L, M.H);
     for (const auto *v : {&M.rep, &M.dyn1, &M.dyn2, &M.rew, &M.common, &M.val, &M.pol}) w = widest(*v, w);
