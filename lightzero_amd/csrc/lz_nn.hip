@@ -541,11 +541,17 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         }
     }
     // geometry of this lane's row in each of the MT M-tiles (the same for every layer)
+    // 36 pixels = 2 full 16-row tiles + 4 rows (81 = 5 + 1 row): the remainder rows run on v_mfma_f32_4x4x1_f32
+    // (16 blocks of 4 rows x 4 channels; block = (k-quarter, channel quad) -- exactly the lane layout the 16x16x4 B
+    // fragment already has) at a quarter of the cost of a padded third tile.
+    constexpr int MF = HW / 16, REM = HW % 16;
+    constexpr bool SMALL_REM = REM > 0 && REM <= 4;
+    static_assert(MT == MF + (REM ? 1 : 0), "tile count");
     const int zoff = HW * PS;
     int base[MT], mask[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int row = i * 16 + (lane & 15);
+        const int row = (SMALL_REM && i == MF) ? i * 16 + (lane & 3) : i * 16 + (lane & 15);
         const int p = min(row, HW - 1), y = p / GW, x = p - y * GW;
         int mk = 0;
 #pragma unroll
@@ -596,9 +602,25 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) {
+                    if (SMALL_REM && i == MF) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
+                    else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SMALL_REM) {
+            // the 4x4x1 blocks hold partial sums per k-quarter (lane >> 4): add the four quarters, then lane group q keeps row q
+            f32x4 r = acc[MF];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = r[q];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                r[q] = v;
+            }
+            const int g = lane >> 4;
+            const float mine = g == 0 ? r[0] : g == 1 ? r[1] : g == 2 ? r[2] : r[3];
+            acc[MF] = (f32x4){mine, 0.f, 0.f, 0.f};
         }
         // epilogue: BN (+ action table) (+ residual) (+ ReLU) -> LDS (and the latent pool)
         const int col = wv * 16 + (lane & 15);
@@ -608,7 +630,8 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = i * 16 + 4 * (lane >> 4) + q;
+                if (SMALL_REM && i == MF && q > 0) continue;
+                const int row = (SMALL_REM && i == MF) ? i * 16 + (lane >> 4) : i * 16 + 4 * (lane >> 4) + q;
                 if (row < HW) {
                     float v = acc[i][q];
                     if (tab) v += sTab[row * PS + col];
