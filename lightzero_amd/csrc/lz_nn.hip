@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(lz_c1_args a)
 // Activations ping-pong between four LDS buffers; weight fragments come straight from L2 into registers, four
 // steps ahead.  432 MFMAs per wave per layer = 5.8 us at the fp32-matrix issue rate.
 // ------------------------------------------------------------------------------------------------
-template <int GW, int GH>
+template <int GW, int GH, bool TS = false>
 __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 {
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS;  // HW pixels + one all-zero pixel
@@ -565,7 +565,13 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         mask[i] = mk;
     }
     const int kq4 = (lane >> 4) * 4;
+    // TS instantiation only (debugging): s_memtime stamps of workgroup 0 / thread 0 into LDS, copied out at the end
+    unsigned long long *sTS = reinterpret_cast<unsigned long long *>(sSS + 6 * 128);
+    int nts = 0;
+#define LZ_TS() do { if constexpr (TS) { if (b == 0 && tid == 0) sTS[nts++] = __builtin_readcyclecounter(); } } while (0)
+    LZ_TS();
     __syncthreads();
+    LZ_TS();
 
     // Weight fragments are requested R = 12 steps (~4.6k MFMA cycles) before use into a register ring, across layer
     // boundaries (the next layer's first fragments are in flight during this layer's epilogue and barrier); the
@@ -591,8 +597,25 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         f32x4 acc[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the epilogue's operands do not depend on the accumulators: read them now, their LDS latency hides under the K loop
+        const int col = wv * 16 + (lane & 15);
+        const float sc = sSS[L * 128 + col], sh = sSS[L * 128 + 64 + col];
+        const bool tab = ly.act != 0, hasres = ly.res >= 0, relu = ly.relu != 0;
+        const float *sRes = smem + max(ly.res, 0) * BUF;
+        float tv[MT][4], rv[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (SMALL_REM && i == MF && q > 0) continue;
+                const int row = (SMALL_REM && i == MF) ? i * 16 + (lane >> 4) : i * 16 + 4 * (lane >> 4) + q;
+                const int rr = min(row, HW - 1);
+                tv[i][q] = sTab[rr * PS + col];
+                rv[i][q] = sRes[rr * PS + col];
+            }
         float4 af[2][MT];
         fetch_a(sIn, 0, af[0]);
+        LZ_TS();
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             const float4 bfr = wq[s % R];
@@ -608,6 +631,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        LZ_TS();
         if (SMALL_REM) {
             // the 4x4x1 blocks hold partial sums per k-quarter (lane >> 4): add the four quarters, then lane group q keeps row q
             f32x4 r = acc[MF];
@@ -622,27 +646,36 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
             const float mine = g == 0 ? r[0] : g == 1 ? r[1] : g == 2 ? r[2] : r[3];
             acc[MF] = (f32x4){mine, 0.f, 0.f, 0.f};
         }
-        // epilogue: BN (+ action table) (+ residual) (+ ReLU) -> LDS (and the latent pool)
-        const int col = wv * 16 + (lane & 15);
-        const float sc = sSS[L * 128 + col], sh = sSS[L * 128 + 64 + col];
-        const bool tab = ly.act != 0;
+        // epilogue: BN (+ action table) (+ residual) (+ ReLU) -> LDS (and the latent pool); branch-free, operands preloaded
+        float outv[MT][4];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (SMALL_REM && i == MF && q > 0) continue;
                 const int row = (SMALL_REM && i == MF) ? i * 16 + (lane >> 4) : i * 16 + 4 * (lane >> 4) + q;
-                if (row < HW) {
-                    float v = acc[i][q];
-                    if (tab) v += sTab[row * PS + col];
-                    v = v * sc + sh;
-                    if (ly.res >= 0) v += smem[ly.res * BUF + row * PS + col];
-                    if (ly.relu) v = fmaxf(v, 0.0f);
-                    sOut[row * PS + col] = v;
-                    if (ly.gout) ly.gout[((size_t)b * HW + row) * 64 + col] = v;
-                }
+                float v = acc[i][q];
+                v += tab ? tv[i][q] : 0.0f;
+                v = v * sc + sh;
+                v += hasres ? rv[i][q] : 0.0f;
+                v = relu ? fmaxf(v, 0.0f) : v;
+                outv[i][q] = v;
+                if (row < HW) sOut[row * PS + col] = v;
             }
+        if (ly.gout) {
+            float *go = ly.gout + (size_t)b * HW * 64 + col;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (SMALL_REM && i == MF && q > 0) continue;
+                    const int row = (SMALL_REM && i == MF) ? i * 16 + (lane >> 4) : i * 16 + 4 * (lane >> 4) + q;
+                    if (row < HW) go[(size_t)row * 64] = outv[i][q];
+                }
+        }
+        LZ_TS();
         __syncthreads();
+        LZ_TS();
     }
     // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU: wave j runs job j
     if (wv < a.nc1) {
@@ -676,6 +709,14 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
                 }
             }
     }
+    LZ_TS();
+    if constexpr (TS) {
+        if (b == 0 && tid == 0 && a.tstamp) {
+            a.tstamp[0] = (unsigned long long)nts;
+            for (int i = 0; i < nts && i < 30; ++i) a.tstamp[1 + i] = sTS[i];
+        }
+    }
+#undef LZ_TS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1070,7 +1111,8 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s)
 {
-    if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a);
+    if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 64) * 4, s, a);
+    else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a);
     else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)(4 * 82 * 68 + 81 * 68 + 6 * 128) * 4, s, a);
 }
 

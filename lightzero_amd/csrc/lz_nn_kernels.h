@@ -77,6 +77,7 @@ struct lz_chain_args {
     int nc1;
     int B;
     int gw, gh;                  // latent grid (6x6 Atari with downsample, 9x9 Go); compiled instances: 6x6, 9x9
+    unsigned long long *tstamp;  // debugging: s_memtime stamps of workgroup 0 / wave 0 (null in production)
 };
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s);
 

@@ -507,6 +507,15 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
     return LZ_OK;
 }
 
+static unsigned long long *g_chain_ts = nullptr;
+extern "C" int lz_debug_read_chain_ts(unsigned long long *h_out)
+{
+    LZ_REQUIRE(g_chain_ts != nullptr && h_out != nullptr, "LZ_DEBUG_CHAIN_TS was not set");
+    LZ_HIP_CHECK(hipDeviceSynchronize());
+    LZ_HIP_CHECK(hipMemcpy(h_out, g_chain_ts, 32 * 8, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}
+
 // the network part of one simulation (mcts_ctree.py:834-847): recurrent_inference for the leaves selected by the
 // last traverse, outputs into slot sim + 1 of the pools
 static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
@@ -537,6 +546,10 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
         ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = 3;
         ca.nc1 = 3;
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
+        if (getenv("LZ_DEBUG_CHAIN_TS")) {  // timing experiments only: stamps of the last launch, read with lz_debug_read_chain_ts
+            if (!g_chain_ts) (void)hipMalloc((void **)&g_chain_ts, 32 * 8);
+            ca.tstamp = g_chain_ts;
+        }
         ProfScope ps(r->eng, s);
         lz_launch_chain(ca, s);
     }

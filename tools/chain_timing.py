@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Debugging aid: per-phase time stamps (s_memtime, 100 MHz) of one k_chain workgroup during a search.
+    LZ_DEBUG_CHAIN_TS=1 LZ_NO_GRAPH=1 python tools/chain_timing.py"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LZ_DEBUG_CHAIN_TS", "1"); os.environ.setdefault("LZ_NO_GRAPH", "1")
+import torch
+from oracle import torch_models as tm
+from lightzero_amd import _lib as L
+from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+lib = L.lib()
+ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=6), seed=0)
+model = EfficientZeroModel(action_space_size=6).load_state_dict(ref.state_dict())
+B, S = 256, 50
+roots = ez_tree.Roots(B, [list(range(6))] * B, action_space_size=6, max_simulations=S); roots._ensure(6)
+obs = torch.rand(B, 4, 96, 96).cuda()
+for it in range(3):
+    L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
+    L.check(lib.lz_roots_prepare_from_inference(roots._h, 0.25, None, L.i32([-1] * B)))
+    L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+    L.check(lib.lz_engine_synchronize(L.default_engine()))
+lib.lz_debug_read_chain_ts.argtypes = [ctypes.c_void_p]
+out = np.zeros(32, np.uint64)
+L.check(lib.lz_debug_read_chain_ts(out.ctypes.data))
+n = int(out[0]); ts = out[1:1 + n].astype(np.int64)
+names = ["staged", "sync"] + [x for l in range(5) for x in ("L%d loop start" % l, "L%d loop end" % l, "L%d epilogue" % l, "L%d barrier" % l)] + ["end"]
+print("stamps:", n)
+for i in range(1, n):
+    print("%-16s +%6.2f us   (t=%6.2f)" % (names[i] if i < len(names) else i, (ts[i] - ts[i - 1]) / 100.0, (ts[i] - ts[0]) / 100.0))
