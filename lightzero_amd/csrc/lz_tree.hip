@@ -17,8 +17,11 @@
 // `r + gamma * v` must stay a rounded multiply followed by a rounded add.  expf/logf come from
 // lz_math.h (bit-identical to the host libm the reference links); division and sqrt are the
 // correctly rounded HIP defaults.
+#include <stdlib.h>
+
 #include "lz_internal.h"
 #include "lz_math.h"
+#include "lz_wave.h"
 
 #define LZ_FLOAT_MAX 1000000.0f  // cminimax.h:9
 #define LZ_FLOAT_MIN (-LZ_FLOAT_MAX)
@@ -32,19 +35,6 @@ __device__ __forceinline__ float rl_f(float v, int lane)
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
 {
@@ -131,29 +121,85 @@ __global__ __launch_bounds__(64) void k_prepare(lz_tree_dev t, float noise_w, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-root view of the tree arrays.  The kernels below are written once against this view and instantiated
+// twice: on the HBM arrays directly, and on an LDS copy of the root's tree (loads from LDS, stores written through to
+// HBM) -- a search step is a chain of dependent loads (node -> edges -> child -> ...), ~1 us each from HBM/L2.
+// ------------------------------------------------------------------------------------------------
+struct tview {
+    float4 *edge;            // [NN][A]   read / write here
+    int32_t *child;          // [NN][A]
+    float *node_vp;          // [NN]
+    int32_t *node_reset, *node_to_play;
+    const int32_t *path_node, *path_act;  // [NN] path of the previous traverse (read by the backup)
+    float4 *g_edge;          // write-through targets in HBM (WT instantiation), same indexing
+    int32_t *g_child;
+    float *g_node_vp;
+    int32_t *g_node_reset, *g_node_to_play;
+};
+
+// values that cross from the backup into the next selection in registers (fused kernel) or come from HBM
+template <int NC>
+struct tscal {
+    int n_root;        // number of legal root actions
+    int root_act[NC];  // this lane's root legal action(s)
+    int root_visit;
+    float root_vsum;
+    float mn, mx;      // CMinMaxStats
+    uint32_t epoch;
+};
+
+__device__ __forceinline__ tview global_view(const lz_tree_dev &t, int b)
+{
+    tview v;
+    const size_t e = (size_t)b * t.NN * t.A, n = (size_t)b * t.NN;
+    v.edge = v.g_edge = t.edge + e;
+    v.child = v.g_child = t.child + e;
+    v.node_vp = v.g_node_vp = t.node_vp + n;
+    v.node_reset = v.g_node_reset = t.node_reset + n;
+    v.node_to_play = v.g_node_to_play = t.node_to_play + n;
+    v.path_node = t.path_node + n;
+    v.path_act = t.path_act + n;
+    return v;
+}
+
+template <int NC>
+__device__ __forceinline__ void load_scalars(const lz_tree_dev &t, int b, tscal<NC> &sc)
+{
+    const int lane = threadIdx.x;
+    sc.n_root = uni(t.n_legal[b]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        sc.root_act[c] = (j < sc.n_root) ? t.legal[(size_t)b * t.A + j] : 0;
+    }
+    sc.root_visit = t.root_visit[b];
+    sc.root_vsum = t.root_vsum[b];
+    sc.mn = t.minmax[2 * b];
+    sc.mx = t.minmax[2 * b + 1];
+    sc.epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;  // bumped by every prepare: decorrelates env-steps
+}
+
+// ------------------------------------------------------------------------------------------------
 // traverse: cbatch_traverse (cnode.cpp:886-963) -- select down to an unexpanded child
 // ------------------------------------------------------------------------------------------------
 template <int NC, int VARIANT>
-__device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta_max,
-                                             const int32_t *__restrict__ vtp_in)
+__device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &v, const tscal<NC> &sc, const lz_traverse_args &a,
+                                             float delta_max, int vtp)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
-    const float4 *edge_b = t.edge + (size_t)b * NN * A;
-    const int32_t *child_b = t.child + (size_t)b * NN * A;
-    const float mn = t.minmax[2 * b], mx = t.minmax[2 * b + 1];
+    const float mn = sc.mn, mx = sc.mx;
     const float discount = a.discount;
     const float base = (float)a.pb_c_base;
-    int vtp = vtp_in[b];
-    const uint32_t epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;  // bumped by every prepare: decorrelates env-steps
+    const uint32_t epoch = sc.epoch;
     int node = 0, depth = 0, is_root = 1, last_action = -1;
-    int node_visit = t.root_visit[b];
+    int node_visit = sc.root_visit;
     float parent_q = 0.0f;
 
     for (;;) {
-        const int n = is_root ? uni(t.n_legal[b]) : A;
-        const float node_vp = t.node_vp[(size_t)b * NN + node];
-        const int node_reset = t.node_reset[(size_t)b * NN + node];
+        const int n = is_root ? sc.n_root : A;
+        const float node_vp = v.node_vp[node];
+        const int node_reset = v.node_reset[node];
         float prior[NC], val[NC], tr[NC], score[NC];
         int vis[NC], act[NC], chd[NC];  // chd: child node ids, fetched with the edges (one round trip per level)
         // ---- load the children (one 16-byte edge per lane) and compute_mean_q (cnode.cpp:173-212)
@@ -163,9 +209,9 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
         for (int c = 0; c < NC; ++c) {
             const int j = c * 64 + lane;
             const bool valid = j < n;
-            act[c] = valid ? (is_root ? t.legal[(size_t)b * A + j] : j) : 0;
-            float4 e = valid ? edge_b[(size_t)node * A + act[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
-            chd[c] = valid ? child_b[(size_t)node * A + act[c]] : -1;
+            act[c] = valid ? (is_root ? sc.root_act[c] : j) : 0;
+            float4 e = valid ? v.edge[(size_t)node * A + act[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            chd[c] = valid ? v.child[(size_t)node * A + act[c]] : -1;
             prior[c] = e.x;
             vis[c] = __float_as_int(e.y);
             val[c] = (vis[c] == 0) ? 0.0f : e.z / (float)vis[c];  // CNode::value cnode.cpp:223-239
@@ -229,8 +275,11 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
                 masks[c] = __ballot(j == pos || (j > pos && score[c] >= thr));
                 cnt += __builtin_popcountll(masks[c]);
             }
-            const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
-            int r = (int)(h % (uint64_t)cnt);
+            int r = 0;
+            if (cnt > 1) {  // a single candidate (the usual case once visits differ) needs no draw
+                const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
+                r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt) without a 64-bit division
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 uint64_t mk = masks[c];
@@ -255,7 +304,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
                 }
             }
         }
-        if (nxt == -3) nxt = uni(child_b[(size_t)node * A + action]);  // degenerate fallback (action 0 by default)
+        if (nxt == -3) nxt = uni(v.child[(size_t)node * A + action]);  // degenerate fallback (action 0 by default)
         if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
         if (lane == 0) {
             t.node_best[(size_t)b * NN + node] = action;
@@ -278,37 +327,22 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const lz_trav
 }
 
 // ------------------------------------------------------------------------------------------------
-// backpropagate: cbatch_backpropagate (cnode.cpp:577-601) = expand the leaf, then cbackpropagate
+// backpropagate: cbatch_backpropagate (cnode.cpp:577-601) = expand the leaf, then cbackpropagate.
+// d = search length of the path, lg[] = this lane's policy logits of the leaf, sc carries root visit / value sum and
+// the min-max statistics in and out.
 // ------------------------------------------------------------------------------------------------
-template <int NC, int VARIANT>
-__device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, int new_node, float discount,
-                                             const float *__restrict__ vps, const float *__restrict__ values,
-                                             const float *__restrict__ logits,
-                                             const int32_t *__restrict__ is_reset, int horizon,
-                                             const int32_t *__restrict__ to_play_in)
+template <int NC, int VARIANT, bool WT>
+__device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &v, tscal<NC> &sc, int new_node, float discount,
+                                             float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
-    float4 *edge_b = t.edge + (size_t)b * NN * A;
-    int32_t *child_b = t.child + (size_t)b * NN * A;
-    const int d = uni(t.res_search_len[b]);
-    const int to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
-    const float vp_b = vps[b];
-    int reset = 0;
-    if (VARIANT == LZ_TREE_EFFICIENTZERO) {
-        if (is_reset) reset = is_reset[b];
-        else if (horizon > 0) reset = (d % horizon == 0) ? 1 : 0;  // mcts_ctree.py:859
-    }
     // ---- CNode::expand (cnode.cpp:88-151): all A actions are legal below the root
     {
-        float lg[NC], e[NC];
+        float e[NC];
         float m = LZ_FLOAT_MIN;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int j = c * 64 + lane;
-            lg[c] = (j < A) ? logits[(size_t)b * A + j] : LZ_FLOAT_MIN;
-            m = fmaxf(m, lg[c]);
-        }
+        for (int c = 0; c < NC; ++c) m = fmaxf(m, lg[c]);
         m = wave_max(m);
 #pragma unroll
         for (int c = 0; c < NC; ++c) e[c] = lz_expf(lg[c] - m);
@@ -323,25 +357,33 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, int new_node,
             const int j = c * 64 + lane;
             if (j < A) {
                 const size_t o = (size_t)new_node * A + j;
-                edge_b[o] = make_float4(e[c] / sum, __int_as_float(0), 0.0f, 0.0f);
-                child_b[o] = -1;
+                const float4 ne = make_float4(e[c] / sum, __int_as_float(0), 0.0f, 0.0f);
+                v.edge[o] = ne;
+                v.child[o] = -1;
+                if (WT) { v.g_edge[o] = ne; v.g_child[o] = -1; }
             }
         }
     }
-    const int parent = uni(t.path_node[(size_t)b * NN + d - 1]);
-    const int pact = uni(t.path_act[(size_t)b * NN + d - 1]);
+    const int parent = uni(v.path_node[d - 1]);
+    const int pact = uni(v.path_act[d - 1]);
     if (lane == 0) {
-        child_b[(size_t)parent * A + pact] = new_node;
-        const size_t o = (size_t)b * NN + new_node;
-        t.node_vp[o] = vp_b;
-        t.node_reset[o] = reset;
-        t.node_to_play[o] = to_play;
-        t.node_best[o] = -1;
+        v.child[(size_t)parent * A + pact] = new_node;
+        v.node_vp[new_node] = vp_b;
+        v.node_reset[new_node] = reset;
+        v.node_to_play[new_node] = to_play;
+        if (WT) {
+            v.g_child[(size_t)parent * A + pact] = new_node;
+            v.g_node_vp[new_node] = vp_b;
+            v.g_node_reset[new_node] = reset;
+            v.g_node_to_play[new_node] = to_play;
+        }
+        t.node_best[(size_t)b * NN + new_node] = -1;
     }
+    if (WT) __builtin_amdgcn_wave_barrier();
     // ---- cbackpropagate (cnode.cpp:482-575): path node P_k, k = d (leaf) .. 0 (root); lane i of a
     // chunk owns k = d - (chunk*64 + i).  Gather is parallel, the bootstrap recurrence is a scalar chain.
-    float bootstrap = values[b];
-    float mn = t.minmax[2 * b], mx = t.minmax[2 * b + 1];
+    float bootstrap = value_b;
+    float mn = sc.mn, mx = sc.mx;
     for (int k0 = d; k0 >= 0; k0 -= 64) {
         const int k = k0 - lane;
         const bool valid = k >= 0;
@@ -349,21 +391,21 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, int new_node,
         float prior = 0.f, vsum = 0.f, own_vp = 0.f, parent_vp = 0.f;
         if (valid) {
             if (k >= 1) {
-                pn = t.path_node[(size_t)b * NN + k - 1];
-                pa = t.path_act[(size_t)b * NN + k - 1];
-                const float4 e = edge_b[(size_t)pn * A + pa];
+                pn = v.path_node[k - 1];
+                pa = v.path_act[k - 1];
+                const float4 e = v.edge[(size_t)pn * A + pa];
                 prior = e.x;
                 vis = __float_as_int(e.y);
                 vsum = e.z;
                 own_vp = (k == d) ? vp_b : e.w;
-                parent_vp = t.node_vp[(size_t)b * NN + pn];
-                parent_reset = t.node_reset[(size_t)b * NN + pn];
-                if (k < d) own_tp = t.node_to_play[(size_t)b * NN + t.path_node[(size_t)b * NN + k]];
+                parent_vp = v.node_vp[pn];
+                parent_reset = v.node_reset[pn];
+                if (k < d) own_tp = v.node_to_play[v.path_node[k]];
             } else {
-                vis = t.root_visit[b];
-                vsum = t.root_vsum[b];
-                own_vp = t.node_vp[(size_t)b * NN];
-                own_tp = t.node_to_play[(size_t)b * NN];
+                vis = sc.root_visit;
+                vsum = sc.root_vsum;
+                own_vp = v.node_vp[0];
+                own_tp = v.node_to_play[0];
             }
         }
         float true_reward, tr_eff;
@@ -384,6 +426,8 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, int new_node,
             else if (rl_i(same, i)) bootstrap = -tre + discount * bootstrap;
             else bootstrap = tre + discount * bootstrap;
         }
+        int new_root_visit = 0;
+        float new_root_vsum = 0.0f;
         if (valid) {
             vsum = same ? vsum + my_boot : vsum + (-my_boot);
             vis += 1;
@@ -393,20 +437,68 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, int new_node,
             else q = (to_play == -1) ? true_reward + discount * value : true_reward + discount * -value;
             mx = fmaxf(mx, q);
             mn = fminf(mn, q);
-            if (k >= 1) edge_b[(size_t)pn * A + pa] = make_float4(prior, __int_as_float(vis), vsum, own_vp);
-            else { t.root_visit[b] = vis; t.root_vsum[b] = vsum; }
+            if (k >= 1) {
+                const float4 ne = make_float4(prior, __int_as_float(vis), vsum, own_vp);
+                v.edge[(size_t)pn * A + pa] = ne;
+                if (WT) v.g_edge[(size_t)pn * A + pa] = ne;
+            } else {
+                t.root_visit[b] = vis;
+                t.root_vsum[b] = vsum;
+                new_root_visit = vis;
+                new_root_vsum = vsum;
+            }
+        }
+        // the root is lane k0 of the chunk that contains k == 0
+        if (k0 < 64) {
+            sc.root_visit = rl_i(new_root_visit, k0);
+            sc.root_vsum = rl_f(new_root_vsum, k0);
         }
     }
     mx = wave_max(mx);
     mn = wave_min(mn);
     if (lane == 0) { t.minmax[2 * b] = mn; t.minmax[2 * b + 1] = mx; }
+    sc.mn = mn;
+    sc.mx = mx;
 }
 
 template <int NC, int VARIANT>
 __global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args a, float delta_max,
                                                  const int32_t *__restrict__ vtp_in)
 {
-    dev_traverse<NC, VARIANT>(t, a, delta_max, vtp_in);
+    const int b = blockIdx.x;
+    const tview v = global_view(t, b);
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp_in[b]);
+}
+
+// leaf inputs of the backup: search length, player, value prefix, value, logits, is_reset
+template <int NC, int VARIANT>
+struct leaf_in {
+    int d, to_play, reset;
+    float vp, value;
+    float lg[NC];
+};
+template <int NC, int VARIANT>
+__device__ __forceinline__ void load_leaf(const lz_tree_dev &t, int b, const float *__restrict__ vps, const float *__restrict__ values,
+                                          const float *__restrict__ logits, const int32_t *__restrict__ is_reset, int horizon,
+                                          const int32_t *__restrict__ to_play_in, leaf_in<NC, VARIANT> &L)
+{
+    const int lane = threadIdx.x, A = t.A;
+    L.d = uni(t.res_search_len[b]);
+    L.to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
+    L.vp = vps[b];
+    L.value = values[b];
+    L.reset = 0;
+    if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+        if (is_reset) L.reset = is_reset[b];
+        else if (horizon > 0) L.reset = (L.d % horizon == 0) ? 1 : 0;  // mcts_ctree.py:859
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        L.lg[c] = (j < A) ? logits[(size_t)b * A + j] : LZ_FLOAT_MIN;
+    }
 }
 
 template <int NC, int VARIANT>
@@ -416,7 +508,13 @@ __global__ __launch_bounds__(64) void k_backprop(lz_tree_dev t, int new_node, fl
                                                  const int32_t *__restrict__ is_reset, int horizon,
                                                  const int32_t *__restrict__ to_play_in)
 {
-    dev_backprop<NC, VARIANT>(t, new_node, discount, vps, values, logits, is_reset, horizon, to_play_in);
+    const int b = blockIdx.x;
+    const tview v = global_view(t, b);
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    leaf_in<NC, VARIANT> L;
+    load_leaf<NC, VARIANT>(t, b, vps, values, logits, is_reset, horizon, to_play_in, L);
+    dev_backprop<NC, VARIANT, false>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
 }
 
 // expand + backup of simulation s followed by the selection of simulation s + 1 for the same root, in one launch
@@ -429,11 +527,67 @@ __global__ __launch_bounds__(64) void k_backprop_traverse(lz_tree_dev t, int new
                                                           lz_traverse_args a, float delta_max,
                                                           const int32_t *__restrict__ vtp_in)
 {
-    dev_backprop<NC, VARIANT>(t, new_node, discount, vps, values, logits, nullptr, horizon, nullptr);
+    const int b = blockIdx.x;
+    const tview v = global_view(t, b);
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    leaf_in<NC, VARIANT> L;
+    load_leaf<NC, VARIANT>(t, b, vps, values, logits, nullptr, horizon, nullptr, L);
+    const int vtp = vtp_in[b];
+    dev_backprop<NC, VARIANT, false>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    dev_traverse<NC, VARIANT>(t, a, delta_max, vtp_in);
+    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp);
+}
+
+// The same fused step on an LDS copy of the root's tree: every array the step reads is requested in the first
+// instructions (one HBM round trip for the whole tree: edges, child ids, node records, the previous path, the leaf's
+// network outputs and the root scalars), the backup and the selection then chase pointers inside LDS, and every store
+// is written through to HBM.  Used when the tree of one root fits the LDS budget (lz_tree_lds_bytes).
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_backprop_traverse_lds(lz_tree_dev t, int new_node, float discount,
+                                                              const float *__restrict__ vps,
+                                                              const float *__restrict__ values,
+                                                              const float *__restrict__ logits, int horizon,
+                                                              lz_traverse_args a, float delta_max,
+                                                              const int32_t *__restrict__ vtp_in)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_tree[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    const int nn = new_node + 1;        // nodes 0 .. new_node exist after this step
+    float4 *s_edge = s_tree;                                              // [nn][A]
+    int32_t *s_child = reinterpret_cast<int32_t *>(s_edge + (size_t)nn * A);   // [nn][A]
+    float *s_vp = reinterpret_cast<float *>(s_child + (size_t)nn * A);    // [nn]
+    int32_t *s_reset = reinterpret_cast<int32_t *>(s_vp + nn);
+    int32_t *s_tp = s_reset + nn;
+    int32_t *s_pn = s_tp + nn;
+    int32_t *s_pa = s_pn + nn;
+    const tview g = global_view(t, b);
+    // ---- one round trip: everything the step reads
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    leaf_in<NC, VARIANT> L;
+    load_leaf<NC, VARIANT>(t, b, vps, values, logits, nullptr, horizon, nullptr, L);
+    const int vtp = vtp_in[b];
+    const int ne = new_node * A;        // edges / child ids of the existing nodes 0 .. new_node - 1
+    for (int i = lane; i < ne; i += 64) { s_edge[i] = g.edge[i]; s_child[i] = g.child[i]; }
+    for (int i = lane; i < new_node; i += 64) {
+        s_vp[i] = g.node_vp[i]; s_reset[i] = g.node_reset[i]; s_tp[i] = g.node_to_play[i];
+        s_pn[i] = g.path_node[i]; s_pa[i] = g.path_act[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    tview v = g;
+    v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
+    v.path_node = s_pn; v.path_act = s_pa;
+    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp);
 }
 
 // bumps the RNG epoch once per prepare (stochastic tie-break streams differ between env-steps even when the
@@ -543,10 +697,21 @@ void lz_tree_launch_backprop(const lz_tree_dev &t, int latent_index, float disco
         launch_backprop_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s);
 }
 
+// LDS bytes of the staged tree of one root after `idx` nodes exist besides the new one (k_backprop_traverse_lds)
+static size_t tree_lds_bytes(const lz_tree_dev &t, int idx) { return (size_t)(idx + 1) * ((size_t)t.A * 20 + 20); }
+
 template <int V>
 static void launch_bt_v(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val, const float *lg,
                         int horizon, const lz_traverse_args &a, float delta, const int32_t *vtp, hipStream_t s)
 {
+    // path lengths are bounded by the node count, so the previous path fits the same [nn] arrays
+    const char *no_lds = getenv("LZ_TREE_NO_LDS");  // parity tests compare the two instantiations
+    const size_t lds = tree_lds_bytes(t, idx);
+    if (!no_lds && lds <= 16 * 1024 && nchunks(t.A) <= 2) {
+        if (nchunks(t.A) == 1) hipLaunchKernelGGL((k_backprop_traverse_lds<1, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
+        else hipLaunchKernelGGL((k_backprop_traverse_lds<2, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
+        return;
+    }
     switch (nchunks(t.A)) {
     case 1: hipLaunchKernelGGL((k_backprop_traverse<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp); break;
     case 2: hipLaunchKernelGGL((k_backprop_traverse<2, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp); break;

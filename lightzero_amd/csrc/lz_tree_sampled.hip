@@ -15,6 +15,7 @@
 // -- the reference itself seeds a std::default_random_engine from the wall clock in every expand.
 #include "lz_internal.h"
 #include "lz_math.h"
+#include "lz_wave.h"
 
 #define LZ_FLOAT_MAX 1000000.0f
 #define LZ_FLOAT_MIN (-LZ_FLOAT_MAX)
@@ -24,18 +25,6 @@ namespace {
 __device__ __forceinline__ float rl_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
 {
     z += 0x9e3779b97f4a7c15ull;

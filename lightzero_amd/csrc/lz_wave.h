@@ -1,0 +1,28 @@
+// lz_wave.h -- wave-wide reductions for the one-wavefront-per-root tree kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+// Wave-wide max / min on the DPP path (quad permutes, row mirrors, row broadcasts: ~8 VALU ops) instead of six
+// ds_bpermute round trips through the LDS crossbar: these kernels are one wavefront of strictly dependent
+// instructions, so every reduction sits on the critical path.  max / min are order independent, the result is exact.
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_red(float v)
+{
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); };
+    int x = __float_as_int(v);
+#define LZ_DPP(ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false))
+    v = op(v, LZ_DPP(0xB1, 0xf)); x = __float_as_int(v);   // quad_perm [1,0,3,2]
+    v = op(v, LZ_DPP(0x4E, 0xf)); x = __float_as_int(v);   // quad_perm [2,3,0,1]
+    v = op(v, LZ_DPP(0x141, 0xf)); x = __float_as_int(v);  // row_half_mirror
+    v = op(v, LZ_DPP(0x140, 0xf)); x = __float_as_int(v);  // row_mirror: every lane of a row holds the row result
+    v = op(v, LZ_DPP(0x142, 0xa)); x = __float_as_int(v);  // row_bcast:15 into rows 1 and 3
+    v = op(v, LZ_DPP(0x143, 0xc));                         // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef LZ_DPP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) { return wave_red<true>(v); }
+__device__ __forceinline__ float wave_min(float v) { return wave_red<false>(v); }
+
+}  // namespace

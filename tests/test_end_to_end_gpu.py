@@ -101,3 +101,44 @@ def test_foreign_torch_model_uses_device_tree():
     osearch.ez_search(octree.ez_tree, oroots, ref, lat, rh, [-1] * B, cfg)
     assert roots.get_distributions() == oroots.get_distributions()
     assert np.allclose(roots.get_values(), oroots.get_values(), atol=1e-6)
+
+
+@pytest.mark.parametrize("tiebreak", [0, 1])
+def test_lds_staged_tree_step_is_bit_identical_to_the_hbm_one(tiebreak):
+    """k_backprop_traverse_lds (tree of one root staged in LDS, stores written through) vs k_backprop_traverse (HBM):
+    same search, same network outputs -> identical per-simulation records, visit counts, root values (bitwise) and
+    min-max statistics."""
+    import os
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    B, A, S = 48, 6, 50
+    ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A))
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(11)).cuda().contiguous()
+    rng = np.random.default_rng(3)
+    mask = (rng.random((B, A)) < 0.7)
+    mask[:, 2] = True
+    legal = [np.nonzero(m)[0].tolist() for m in mask]
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    res = []
+    for no_lds in ("1", None):
+        if no_lds:
+            os.environ["LZ_TREE_NO_LDS"] = no_lds
+        else:
+            os.environ.pop("LZ_TREE_NO_LDS", None)
+        roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+        roots.set_tiebreak(tiebreak, seed=99)
+        model.initial_inference(obs, roots)
+        roots.prepare_from_inference(0.25, noises, [-1] * B)
+        L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+        L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+        tr = np.zeros((S, B, 4), np.int32)
+        L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+        res.append((tr, roots.get_distributions(), np.asarray(roots.get_values(), np.float32).view(np.uint32),
+                    roots.get_trajectories(), roots.get_minmax().view(np.uint32)))
+    os.environ.pop("LZ_TREE_NO_LDS", None)
+    assert np.array_equal(res[0][0], res[1][0]), "per-simulation records differ"
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+    assert np.array_equal(res[0][4], res[1][4])
