@@ -146,6 +146,13 @@ int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out);
 int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
 
 
+/* select_action (lzero/policy/utils.py:637-661) for every root on the device: p_i = N_i^(1/T) / sum over the root's legal
+ * positions (float64 like the original); h_action_pos[i] = arg-max of the visit counts (deterministic != 0, np.argmax:
+ * first maximum) or one draw from p (counter-based generator keyed by seed and root); h_entropy[i] in bits.
+ * Also valid on Sampled-EfficientZero roots (positions = the K sampled actions). */
+int lz_roots_select_action(lz_roots *r, double temperature, int deterministic, uint64_t seed, int32_t *h_action_pos,
+                           double *h_entropy);
+
 /* ------------------------------------------------------------------------------------------------
  * Network -- replaces lzero/model/efficientzero_model.py (EfficientZeroModel.initial_inference :203-238,
  * recurrent_inference :240-273) evaluated in eval() mode, with InverseScalarTransform

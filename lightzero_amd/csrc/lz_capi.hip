@@ -449,6 +449,75 @@ extern "C" int lz_roots_get_minmax(lz_roots *r, float *h_out)
 }
 
 // ------------------------------------------------------------------------------------------------
+// select_action on the device (lzero/policy/utils.py:637-661): p_i = N_i^(1/T) / sum, arg-max or one draw, entropy in bits.
+// float64 like the Python original; one thread per root (A is small).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ uint64_t sel_mix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void k_select_action(lz_tree_dev t, double inv_temperature, int deterministic, uint64_t seed,
+                                int32_t *__restrict__ pos_out, double *__restrict__ ent_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= t.B) return;
+    const bool sampled = t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO;
+    const int A = t.A, n = sampled ? A : t.n_legal[b];
+    const float4 *edge0 = t.edge + (size_t)b * t.NN * A;
+    auto count = [&](int j) -> int {
+        const int slot = sampled ? t.rep[(size_t)b * t.NN * A + j] : t.legal[(size_t)b * A + j];
+        return __float_as_int(edge0[slot].y);
+    };
+    double sum = 0.0;
+    int best = -1, arg = 0;
+    for (int j = 0; j < n; ++j) {
+        const int c = count(j);
+        sum += pow((double)c, inv_temperature);
+        if (c > best) { best = c; arg = j; }  // np.argmax: first maximum
+    }
+    const double u = (double)(sel_mix64(sel_mix64(seed) ^ (uint64_t)b) >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+    double acc = 0.0, H = 0.0;
+    int pick = -1, last = 0;
+    for (int j = 0; j < n; ++j) {
+        const double p = pow((double)count(j), inv_temperature) / sum;
+        if (p > 0.0) { H -= p * log2(p); last = j; }
+        acc += p;
+        if (pick < 0 && u < acc) pick = j;  // searchsorted(cumsum(p), u, side='right') like np.random.choice
+    }
+    if (pick < 0) pick = last;
+    pos_out[b] = deterministic ? arg : pick;
+    ent_out[b] = H;
+}
+}  // namespace
+
+extern "C" int lz_roots_select_action(lz_roots *r, double temperature, int deterministic, uint64_t seed, int32_t *h_action_pos,
+                                      double *h_entropy)
+{
+    LZ_REQUIRE(r != nullptr && h_action_pos != nullptr && h_entropy != nullptr, "NULL argument");
+    LZ_REQUIRE(r->prepared, "select_action before Roots.prepare");
+    LZ_REQUIRE(temperature > 0.0, "temperature must be positive");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = ensure_stage(r, B * 16);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    double *d_ent = (double *)r->d_stage;
+    int32_t *d_pos = (int32_t *)((char *)r->d_stage + B * 8);
+    hipLaunchKernelGGL(k_select_action, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, t, 1.0 / temperature, deterministic, seed, d_pos, d_ent);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->d_stage, B * 12, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_entropy, r->h_stage, B * 8);
+    memcpy(h_action_pos, (char *)r->h_stage + B * 8, B * 4);
+    return LZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sampled EfficientZero trees (continuous actions)
 // ------------------------------------------------------------------------------------------------
 extern "C" int lz_sroots_create(lz_engine *e, int root_num, int action_dim, int num_of_sampled_actions, int max_simulations,

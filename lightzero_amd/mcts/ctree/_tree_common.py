@@ -155,6 +155,17 @@ def make_module(variant, has_deterministic_flag):
                 res.append(row[:row.index(-1)])
             return res
 
+        def select_action(self, temperature=1, deterministic=True, seed=None):
+            """select_action (lzero/policy/utils.py:637-661) for every root on the device: returns (action positions
+            [root_num], entropies in bits [root_num]).  deterministic=False draws from N^(1/T) with the engine's
+            counter-based generator (``seed``; a fresh one per call when None) instead of np.random."""
+            pos = np.zeros(self.root_num, np.int32)
+            ent = np.zeros(self.root_num, np.float64)
+            if seed is None:
+                seed = int(np.random.randint(0, 2 ** 62))
+            L.check(L.lib().lz_roots_select_action(self._h, float(temperature), 1 if deterministic else 0, int(seed), pos, ent))
+            return pos, ent
+
         def get_minmax(self):
             out = np.zeros((self.root_num, 2), np.float32)
             L.check(L.lib().lz_roots_get_minmax(self._h, out))

@@ -40,6 +40,9 @@ class EfficientZeroPolicy(object):
         # "random": the reference's stochastic tie rule (rand() over the tie list, cnode.cpp:691);
         # "first": deterministic first arg-max (parity / reproducible evaluation)
         self._tiebreak = {"random": 1, "first": 0}[_g(cfg, "mcts_tiebreak", "random")]
+        # True: select_action (temperature sampling / arg-max + entropy) runs as one device kernel over all roots
+        # (lz_roots_select_action) instead of the reference's per-env Python loop with np.random.choice
+        self._device_select = bool(_g(cfg, "device_select_action", False))
 
     def forward(self, *args, **kwargs):
         return self._forward_collect(*args, **kwargs)
@@ -82,9 +85,16 @@ class EfficientZeroPolicy(object):
         roots_values = roots.get_values()
         eps_cfg = _g(self._cfg, "eps", {}) or {}
         eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
+        if self._device_select:
+            dev_pos, dev_ent = roots.select_action(self._collect_mcts_temperature, deterministic=eps_greedy)
         for i, env_id in enumerate(ready_env_id):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]
-            if eps_greedy:
+            if self._device_select:
+                idx, entropy = int(dev_pos[i]), float(dev_ent[i])
+                action = legal_actions[i][idx]
+                if eps_greedy and np.random.rand() < self.collect_epsilon:
+                    action = np.random.choice(legal_actions[i])
+            elif eps_greedy:
                 idx, entropy = select_action(distributions, temperature=self._collect_mcts_temperature, deterministic=True)
                 action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
                 if np.random.rand() < self.collect_epsilon:
@@ -116,9 +126,14 @@ class EfficientZeroPolicy(object):
         self._search(self._mcts_eval, roots, self._eval_model, network_output, to_play)
         roots_visit_count_distributions = roots.get_distributions()
         roots_values = roots.get_values()
+        if self._device_select:
+            dev_pos, dev_ent = roots.select_action(1, deterministic=True)
         for i, env_id in enumerate(ready_env_id):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]
-            idx, entropy = select_action(distributions, temperature=1, deterministic=True)  # efficientzero.py:733
+            if self._device_select:
+                idx, entropy = int(dev_pos[i]), float(dev_ent[i])
+            else:
+                idx, entropy = select_action(distributions, temperature=1, deterministic=True)  # efficientzero.py:733
             action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
             output[env_id] = {
                 'action': action,

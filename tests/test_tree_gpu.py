@@ -125,3 +125,43 @@ def test_error_paths_are_loud():
     with pytest.raises(L.LzError):
         bad = ez_tree.Roots(1, [[5]], action_space_size=2, max_simulations=3)
         bad.prepare_no_noise([0.0], [[0.0, 0.0]], [-1])
+
+
+def test_device_select_action_matches_python_original():
+    """lz_roots_select_action vs lzero/policy/utils.py:637-661 (restated in lightzero_amd.policy.utils): arg-max position
+    identical, entropy (float64) within 1e-12, sampled positions follow N^(1/T)."""
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.policy.utils import select_action
+    rng = np.random.default_rng(0)
+    B, A, S = 64, 9, 40
+    legal = []
+    for i in range(B):
+        k = int(rng.integers(1, A + 1))
+        legal.append(sorted(rng.choice(A, size=k, replace=False).tolist()))
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    roots.prepare(0.25, noises, [0.0] * B, rng.normal(size=(B, A)).astype(np.float32).tolist(), [-1] * B)
+    mm = ez_tree.MinMaxStatsList(B); mm.set_delta(0.01)
+    for s in range(S):
+        res = ez_tree.ResultsWrapper(B)
+        ix, iy, la, vtp = ez_tree.batch_traverse(roots, 19652, 1.25, 0.997, mm, res, [-1] * B)
+        sl = res.get_search_len()
+        ez_tree.batch_backpropagate(s + 1, 0.997, rng.normal(size=B).astype(np.float32).tolist(), rng.normal(size=B).astype(np.float32).tolist(),
+                                    rng.normal(size=(B, A)).astype(np.float32).tolist(), mm, res, [int(l % 5 == 0) for l in sl], vtp)
+    dists = roots.get_distributions()
+    for T in (1.0, 0.5, 0.25):
+        pos, ent = roots.select_action(T, deterministic=True)
+        for i in range(B):
+            p_ref, e_ref = select_action(dists[i], temperature=T, deterministic=True)
+            assert pos[i] == p_ref
+            assert abs(ent[i] - e_ref) <= 1e-12 * max(1.0, abs(e_ref))
+    # sampling: empirical frequencies of root 0 over many seeds vs N^(1/T)
+    T = 1.0
+    i = int(np.argmax([len(d) for d in dists]))
+    p = np.asarray(dists[i], np.float64) ** (1 / T); p /= p.sum()
+    draws = np.stack([roots.select_action(T, deterministic=False, seed=1000 + k)[0] for k in range(400)])
+    freq = np.bincount(draws[:, i], minlength=len(p)) / draws.shape[0]
+    assert np.abs(freq - p).max() < 0.08
+    for b in range(B):
+        assert draws[:, b].max() < len(dists[b]) and all(dists[b][j] > 0 for j in np.unique(draws[:, b]))
