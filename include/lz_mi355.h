@@ -146,6 +146,23 @@ int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out);
 int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
 
 
+/* ReZero (search_with_reuse, https://arxiv.org/abs/2404.16364) -- replaces batch_traverse_with_reuse /
+ * batch_backpropagate_with_reuse (ez_tree.pyx:94-121, mz_tree.pyx:84-110; cnode.cpp:603-649, 697-754, 816-884, 965-1072).
+ * h_true_action[B]: the trajectory's action at each root, h_reuse_value[B]: the value found by the search of the next state.
+ * The root scores the true action with carm_score and the walk stops right below the root when it is selected;
+ * h_out_index_in_search_path[i] = -1 when the node reached is already expanded (no inference for root i this simulation). */
+int lz_batch_traverse_with_reuse(lz_roots *r, int pb_c_base, float pb_c_init, float discount_factor,
+                                 int32_t *h_virtual_to_play, const int32_t *h_true_action, const float *h_reuse_value,
+                                 int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch,
+                                 int32_t *h_out_last_actions, int32_t *h_out_search_lens);
+/* value_prefixs / values / policy_logits hold n_infer rows: one per root that needed inference, in root order (the
+ * reference's packed batch); h_no_inference_lst / h_reuse_lst are ascending root indices terminated by -1 (the driver's
+ * lists, mcts_ctree.py:920-990); h_is_reset[B] per ROOT (NULL for the MuZero tree). */
+int lz_batch_backpropagate_with_reuse(lz_roots *r, int current_latent_state_index, float discount_factor,
+                                      const float *h_value_prefixs, const float *h_values, const float *h_policy_logits,
+                                      int n_infer, const int32_t *h_is_reset, const int32_t *h_to_play,
+                                      const int32_t *h_no_inference_lst, const int32_t *h_reuse_lst, const float *h_reuse_value);
+
 /* select_action (lzero/policy/utils.py:637-661) for every root on the device: p_i = N_i^(1/T) / sum over the root's legal
  * positions (float64 like the original); h_action_pos[i] = arg-max of the visit counts (deterministic != 0, np.argmax:
  * first maximum) or one draw from p (counter-based generator keyed by seed and root); h_entropy[i] in bits.

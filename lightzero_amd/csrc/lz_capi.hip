@@ -6,6 +6,8 @@
 
 #include <new>
 
+#include <vector>
+
 #include "lz_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -113,7 +115,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
                  o_rs = take((size_t)B * 4), o_legal = take((size_t)B * A * 4), o_nl = take((size_t)B * 4),
                  o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5),
                  o_ep = take(256), o_rep = take(D ? nBNA * 4 : 0), o_nch = take(D ? nBN * 4 : 0),
-                 o_act = take(D ? nBNA * D * 4 : 0), o_laf = take(D ? (size_t)B * D * 4 : 0);
+                 o_act = take(D ? nBNA * D * 4 : 0), o_laf = take(D ? (size_t)B * D * 4 : 0),
+                 o_bidx = take(nBN * 4), o_noinf = take((size_t)B * 4);
     hipError_t err = hipMalloc(&r->slab, off);
     if (err != hipSuccess) {
         delete r;
@@ -131,6 +134,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.rep = D ? (int32_t *)(base + o_rep) : nullptr; t.nchild = D ? (int32_t *)(base + o_nch) : nullptr;
     t.actions = D ? (float *)(base + o_act) : nullptr; t.res_last_action_f = D ? (float *)(base + o_laf) : nullptr;
     t.rng_epoch = (uint32_t *)(base + o_ep);
+    t.node_bidx = (int32_t *)(base + o_bidx); t.res_noinf = (int32_t *)(base + o_noinf);
     (void)hipMemset(r->slab, 0, off);  // no kernel may depend on what the allocator handed back (epoch, legal lists, results)
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
     *out = r;
@@ -367,6 +371,99 @@ extern "C" int lz_batch_backpropagate(lz_roots *r, int current_latent_state_inde
     LZ_HIP_CHECK(hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, s));
     lz_tree_launch_backprop(t, current_latent_state_index, discount_factor, (const float *)(d + o_vp), (const float *)(d + o_v),
                             (const float *)(d + o_lg), (const int32_t *)(d + o_rst), 0, (const int32_t *)(d + o_tp), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// ---- ReZero: batch_traverse_with_reuse / batch_backpropagate_with_reuse (ez_tree.pyx:94-121, mz_tree.pyx:84-110)
+extern "C" int lz_batch_traverse_with_reuse(lz_roots *r, int pb_c_base, float pb_c_init, float discount_factor,
+                                            int32_t *h_virtual_to_play, const int32_t *h_true_action, const float *h_reuse_value,
+                                            int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch,
+                                            int32_t *h_out_last_actions, int32_t *h_out_search_lens)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->prepared, "batch_traverse_with_reuse before Roots.prepare");
+    LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "the sampled tree has no reuse variant");
+    LZ_REQUIRE(h_virtual_to_play && h_true_action && h_reuse_value && h_out_index_in_search_path && h_out_index_in_batch &&
+               h_out_last_actions && h_out_search_lens, "NULL buffer");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = ensure_stage(r, B * 4 * 6);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    memcpy(h, h_virtual_to_play, B * 4);
+    memcpy(h + B * 4, h_true_action, B * 4);
+    memcpy(h + B * 8, h_reuse_value, B * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, B * 12, hipMemcpyHostToDevice, s));
+    lz_traverse_args a;
+    a.pb_c_base = pb_c_base; a.pb_c_init = pb_c_init; a.discount = discount_factor;
+    a.players = players_of(h_virtual_to_play, (int)B);
+    a.tiebreak = r->tiebreak; a.seed = r->seed; a.counter = r->traverse_count++;
+    r->players = a.players;
+    lz_tree_launch_traverse_reuse(t, a, r->delta, (const int32_t *)d, (const int32_t *)(d + B * 4), (const float *)(d + B * 8), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(h, t.res_ix, B * 4 * 5, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(h + B * 20, t.res_noinf, B * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    const int32_t *hi = (const int32_t *)h;
+    for (size_t i = 0; i < B; ++i) h_out_index_in_search_path[i] = hi[5 * B + i] ? -1 : hi[i];  // cnode.cpp:1049
+    memcpy(h_out_index_in_batch, hi + B, B * 4);
+    memcpy(h_out_last_actions, hi + 2 * B, B * 4);
+    memcpy(h_out_search_lens, hi + 3 * B, B * 4);
+    memcpy(h_virtual_to_play, hi + 4 * B, B * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_batch_backpropagate_with_reuse(lz_roots *r, int current_latent_state_index, float discount_factor,
+                                                 const float *h_value_prefixs, const float *h_values, const float *h_policy_logits,
+                                                 int n_infer, const int32_t *h_is_reset, const int32_t *h_to_play,
+                                                 const int32_t *h_no_inference_lst, const int32_t *h_reuse_lst,
+                                                 const float *h_reuse_value)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->prepared, "batch_backpropagate_with_reuse before Roots.prepare");
+    LZ_REQUIRE(h_to_play && h_no_inference_lst && h_reuse_lst && h_reuse_value && n_infer >= 0, "NULL input");
+    LZ_REQUIRE(n_infer == 0 || (h_value_prefixs && h_values && h_policy_logits), "network outputs missing");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    if (current_latent_state_index < 1 || current_latent_state_index >= t.NN) {
+        lz_set_error("current_latent_state_index %d outside the node pool [1,%d]", current_latent_state_index, t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    LZ_REQUIRE(t.variant == LZ_TREE_MUZERO || h_is_reset != nullptr, "is_reset_list is required for the EfficientZero tree");
+    // the reference walks the two ascending, -1 terminated lists with running counters (cnode.cpp:622-641)
+    std::vector<int32_t> mode(B), row(B);
+    size_t ca = 0, cb = 0, cc = 0;
+    for (size_t i = 0; i < B; ++i) {
+        if ((int32_t)i == h_no_inference_lst[ca]) { ++ca; mode[i] = 1; row[i] = 0; }
+        else {
+            mode[i] = 0;
+            if ((int32_t)i == h_reuse_lst[cc]) { mode[i] = 2; ++cc; }
+            row[i] = (int32_t)cb++;
+        }
+    }
+    if ((int)cb != n_infer) { lz_set_error("%zu roots need network outputs but %d rows were passed", cb, n_infer); return LZ_ERR_INVALID; }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    const size_t n = (size_t)n_infer;
+    const size_t o_vp = 0, o_v = o_vp + (n + 1) * 4, o_lg = o_v + (n + 1) * 4, o_rst = o_lg + (n + 1) * A * 4, o_tp = o_rst + B * 4,
+                 o_md = o_tp + B * 4, o_row = o_md + B * 4, o_rv = o_row + B * 4, need = o_rv + B * 4;
+    int rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    if (n) { memcpy(h + o_vp, h_value_prefixs, n * 4); memcpy(h + o_v, h_values, n * 4); memcpy(h + o_lg, h_policy_logits, n * A * 4); }
+    if (h_is_reset) memcpy(h + o_rst, h_is_reset, B * 4); else memset(h + o_rst, 0, B * 4);
+    memcpy(h + o_tp, h_to_play, B * 4);
+    memcpy(h + o_md, mode.data(), B * 4);
+    memcpy(h + o_row, row.data(), B * 4);
+    memcpy(h + o_rv, h_reuse_value, B * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, s));
+    lz_tree_launch_backprop_reuse(t, current_latent_state_index, discount_factor, (const float *)(d + o_vp), (const float *)(d + o_v),
+                                  (const float *)(d + o_lg), (const int32_t *)(d + o_rst), 0, (const int32_t *)(d + o_tp),
+                                  (const int32_t *)(d + o_md), (const int32_t *)(d + o_row), (const float *)(d + o_rv), nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     return LZ_OK;

@@ -64,6 +64,8 @@ struct lz_tree_dev {
     int32_t *path_act;          // [B][NN]     action taken at path_node[k]
     int32_t *res_ix, *res_iy, *res_last_action, *res_search_len, *res_vtp;  // [B] each
     uint32_t *rng_epoch;        // [1] incremented by every prepare (stochastic tie-break stream)
+    int32_t *node_bidx;         // [B][NN]     CNode::batch_index (== b except under ReZero's packed inference batches)
+    int32_t *res_noinf;         // [B]         ReZero: the last traverse ended on an already expanded node (reference index -1)
     // Sampled EfficientZero (variant 2, continuous actions): A == K sampled actions per node
     int D;                      // action dimension
     int32_t *rep;               // [B][NN][K]  position of the first legal action with the same "%f" key (shared child)
@@ -148,6 +150,13 @@ void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, fl
                                       const float *d_values, const float *d_logits, int horizon,
                                       const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s);
+// ReZero search_with_reuse (cnode.cpp:603-649, 697-754, 816-884, 965-1072)
+void lz_tree_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
+                                   const int32_t *d_true_action, const float *d_reuse_value, hipStream_t s);
+void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                   const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play,
+                                   const int32_t *d_mode, const int32_t *d_row, const float *d_reuse_value,
+                                   const int32_t *d_true_action, hipStream_t s);
 void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s);
 void lz_tree_launch_trajectories(const lz_tree_dev &t, int32_t *d_out, int stride, hipStream_t s);
 // Sampled EfficientZero tree (lz_tree_sampled.hip)

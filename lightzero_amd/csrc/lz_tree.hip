@@ -115,6 +115,7 @@ __global__ __launch_bounds__(64) void k_prepare(lz_tree_dev t, float noise_w, co
         t.node_reset[o] = 0;
         t.node_to_play[o] = to_play[b];
         t.node_best[o] = -1;
+        t.node_bidx[o] = b;   // CNode::batch_index of the root (cnode.cpp:334)
         t.root_visit[b] = 1;  // visit_count += 1 (cnode.cpp:341)
         t.root_vsum[b] = 0.0f;
     }
@@ -182,9 +183,12 @@ __device__ __forceinline__ void load_scalars(const lz_tree_dev &t, int b, tscal<
 // ------------------------------------------------------------------------------------------------
 // traverse: cbatch_traverse (cnode.cpp:886-963) -- select down to an unexpanded child
 // ------------------------------------------------------------------------------------------------
-template <int NC, int VARIANT>
+// REUSE (ReZero, cnode.cpp:697-754, 816-884, 965-1072): at the root the trajectory's true action is scored by carm_score
+// (its value term is the reuse value and, once visited, it gets no prior term), and the walk stops right below the root
+// when that action is selected; res_noinf marks roots whose reached node is already expanded (reference index -1).
+template <int NC, int VARIANT, bool REUSE = false>
 __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &v, const tscal<NC> &sc, const lz_traverse_args &a,
-                                             float delta_max, int vtp)
+                                             float delta_max, int vtp, int true_action = -1, float reuse_value = 0.0f)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
@@ -192,7 +196,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
     const float discount = a.discount;
     const float base = (float)a.pb_c_base;
     const uint32_t epoch = sc.epoch;
-    int node = 0, depth = 0, is_root = 1, last_action = -1;
+    int node = 0, depth = 0, is_root = 1, last_action = -1, noinf = 0;
     int node_visit = sc.root_visit;
     float parent_q = 0.0f;
 
@@ -233,6 +237,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
         float mean_q;
         if (is_root && nv > 0) mean_q = total / (float)nv;
         else mean_q = (parent_q + total) / (float)(nv + 1);
+        const int was_root = is_root;
         is_root = 0;
         parent_q = mean_q;
 
@@ -246,14 +251,18 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
             const int j = c * 64 + lane;
             float pb_c = pbc0 * (sq / (float)(vis[c] + 1));
             const float prior_score = pb_c * prior[c];
+            const bool arm = REUSE && was_root && act[c] == true_action;  // carm_score instead of cucb_score
+            const float vchild = arm ? reuse_value : val[c];
             float value_score;
             if (vis[c] == 0) value_score = mean_q;
-            else if (a.players == 1) value_score = tr[c] + discount * val[c];
-            else value_score = tr[c] + discount * (-val[c]);
+            else if (a.players == 1) value_score = tr[c] + discount * vchild;
+            else value_score = tr[c] + discount * (-vchild);
             value_score = mm_normalize(value_score, mn, mx, delta_max);
             if (value_score < 0) value_score = 0;
             else if (value_score > 1) value_score = 1;
-            score[c] = (j < n) ? prior_score + value_score : -__builtin_inff();
+            float ucb = prior_score + value_score;
+            if (arm && vis[c] != 0) ucb = value_score;
+            score[c] = (j < n) ? ucb : -__builtin_inff();
             best = fmaxf(best, score[c]);
         }
         best = wave_max(best);
@@ -313,16 +322,18 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
         }
         last_action = action;
         depth += 1;
+        if (REUSE && was_root && action == true_action) { noinf = nxt >= 0 ? 1 : 0; break; }  // cnode.cpp:1041-1044
         if (nxt < 0) break;  // reached an unexpanded child: the leaf
         node = nxt;
         node_visit = sel_visit;
     }
     if (lane == 0) {
-        t.res_ix[b] = node;  // parent->current_latent_state_index (cnode.cpp:955)
-        t.res_iy[b] = b;     // parent->batch_index
+        t.res_ix[b] = node;  // parent->current_latent_state_index (cnode.cpp:955); stays a valid slot when noinf
+        t.res_iy[b] = REUSE ? (noinf ? b : t.node_bidx[(size_t)b * NN + node]) : b;  // parent->batch_index
         t.res_last_action[b] = last_action;
         t.res_search_len[b] = depth;
         t.res_vtp[b] = vtp;
+        if (REUSE) t.res_noinf[b] = noinf;
     }
 }
 
@@ -331,14 +342,17 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
 // d = search length of the path, lg[] = this lane's policy logits of the leaf, sc carries root visit / value sum and
 // the min-max statistics in and out.
 // ------------------------------------------------------------------------------------------------
+// no_expand (ReZero, cnode.cpp:626-630): the leaf is an already expanded node -- nothing is expanded, its own value prefix
+// stays, only is_reset is refreshed and value_b (the reuse value) is backed up.  bidx = the leaf's batch_index.
 template <int NC, int VARIANT, bool WT>
 __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &v, tscal<NC> &sc, int new_node, float discount,
-                                             float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset)
+                                             float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset,
+                                             bool no_expand = false, int bidx = -1)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
     // ---- CNode::expand (cnode.cpp:88-151): all A actions are legal below the root
-    {
+    if (!no_expand) {
         float e[NC];
         float m = LZ_FLOAT_MIN;
 #pragma unroll
@@ -366,7 +380,14 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &
     }
     const int parent = uni(v.path_node[d - 1]);
     const int pact = uni(v.path_act[d - 1]);
-    if (lane == 0) {
+    if (no_expand) {
+        if (VARIANT == LZ_TREE_EFFICIENTZERO && lane == 0) {
+            const int leaf = v.child[(size_t)parent * A + pact];
+            v.node_reset[leaf] = reset;
+            if (WT) v.g_node_reset[leaf] = reset;
+        }
+    } else if (lane == 0) {
+        t.node_bidx[(size_t)b * NN + new_node] = bidx < 0 ? b : bidx;
         v.child[(size_t)parent * A + pact] = new_node;
         v.node_vp[new_node] = vp_b;
         v.node_reset[new_node] = reset;
@@ -397,7 +418,7 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &
                 prior = e.x;
                 vis = __float_as_int(e.y);
                 vsum = e.z;
-                own_vp = (k == d) ? vp_b : e.w;
+                own_vp = (k == d && !no_expand) ? vp_b : e.w;
                 parent_vp = v.node_vp[pn];
                 parent_reset = v.node_reset[pn];
                 if (k < d) own_tp = v.node_to_play[v.path_node[k]];
@@ -539,6 +560,57 @@ __global__ __launch_bounds__(64) void k_backprop_traverse(lz_tree_dev t, int new
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp);
+}
+
+// ReZero (search_with_reuse): cbatch_traverse_with_reuse / cbatch_backpropagate_with_reuse (cnode.cpp:603-649, 965-1072)
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_traverse_reuse(lz_tree_dev t, lz_traverse_args a, float delta_max,
+                                                       const int32_t *__restrict__ vtp_in, const int32_t *__restrict__ true_action,
+                                                       const float *__restrict__ reuse_value)
+{
+    const int b = blockIdx.x;
+    const tview v = global_view(t, b);
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    dev_traverse<NC, VARIANT, true>(t, v, sc, a, delta_max, vtp_in[b], true_action[b], reuse_value[b]);
+}
+
+// mode[b]: 0 expand + back up the network value, 1 no inference (leaf already expanded; back up the reuse value),
+// 2 expand + back up the reuse value; null => derived from the last traverse (fused path).  row[b]: row of this root in
+// the packed network outputs (the reference packs the roots that needed inference); null => b.
+template <int NC, int VARIANT>
+__global__ __launch_bounds__(64) void k_backprop_reuse(lz_tree_dev t, int new_node, float discount,
+                                                       const float *__restrict__ vps, const float *__restrict__ values,
+                                                       const float *__restrict__ logits, const int32_t *__restrict__ is_reset,
+                                                       int horizon, const int32_t *__restrict__ to_play_in,
+                                                       const int32_t *__restrict__ mode, const int32_t *__restrict__ row,
+                                                       const float *__restrict__ reuse_value,
+                                                       const int32_t *__restrict__ true_action)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, A = t.A;
+    const tview v = global_view(t, b);
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    const int d = uni(t.res_search_len[b]);
+    int m;
+    if (mode) m = uni(mode[b]);
+    else m = uni(t.res_noinf[b]) ? 1 : ((uni(t.res_ix[b]) == 0 && uni(t.res_last_action[b]) == uni(true_action[b])) ? 2 : 0);
+    const int r = row ? uni(row[b]) : b;
+    const int to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
+    int reset = 0;
+    if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+        if (is_reset) reset = is_reset[b];
+        else if (horizon > 0) reset = (d % horizon == 0) ? 1 : 0;
+    }
+    float lg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        lg[c] = (m != 1 && j < A) ? logits[(size_t)r * A + j] : LZ_FLOAT_MIN;
+    }
+    const float vp = (m != 1) ? vps[r] : 0.0f;
+    const float value = (m != 0) ? reuse_value[b] : values[r];
+    dev_backprop<NC, VARIANT, false>(t, v, sc, new_node, discount, vp, value, lg, d, to_play, reset, m == 1, r);
 }
 
 // The same fused step on an LDS copy of the root's tree: every array the step reads is requested in the first
@@ -725,6 +797,45 @@ void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, fl
 {
     if (t.variant == LZ_TREE_EFFICIENTZERO) launch_bt_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s);
     else launch_bt_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s);
+}
+
+template <int V>
+static void launch_reuse_v(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *vtp, const int32_t *ta,
+                           const float *rv, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_traverse_reuse<1, V>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp, ta, rv); break;
+    case 2: hipLaunchKernelGGL((k_traverse_reuse<2, V>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp, ta, rv); break;
+    default: hipLaunchKernelGGL((k_traverse_reuse<4, V>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp, ta, rv); break;
+    }
+}
+void lz_tree_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
+                                   const int32_t *d_true_action, const float *d_reuse_value, hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO) launch_reuse_v<LZ_TREE_EFFICIENTZERO>(t, a, delta, d_vtp_in, d_true_action, d_reuse_value, s);
+    else launch_reuse_v<LZ_TREE_MUZERO>(t, a, delta, d_vtp_in, d_true_action, d_reuse_value, s);
+}
+
+template <int V>
+static void launch_bpreuse_v(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val, const float *lg,
+                             const int32_t *rst, int horizon, const int32_t *tp, const int32_t *mode, const int32_t *row,
+                             const float *rv, const int32_t *ta, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_backprop_reuse<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta); break;
+    case 2: hipLaunchKernelGGL((k_backprop_reuse<2, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta); break;
+    default: hipLaunchKernelGGL((k_backprop_reuse<4, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta); break;
+    }
+}
+void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                   const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play,
+                                   const int32_t *d_mode, const int32_t *d_row, const float *d_reuse_value,
+                                   const int32_t *d_true_action, hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO)
+        launch_bpreuse_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, s);
+    else
+        launch_bpreuse_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, s);
 }
 
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s)

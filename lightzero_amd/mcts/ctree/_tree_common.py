@@ -230,5 +230,45 @@ def make_module(variant, has_deterministic_flag):
                                                    L.f32(value_prefixs), L.f32(values), L.f32(policies),
                                                    rst.ctypes.data, L.i32(to_play_batch)))
 
+    # ---- ReZero (ez_tree.pyx:94-121, mz_tree.pyx:84-110)
+    def batch_traverse_with_reuse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results,
+                                  virtual_to_play_batch, true_action, reuse_value):
+        if roots._h is None:
+            raise L.LzError("batch_traverse_with_reuse before Roots.prepare")
+        _bind(roots, min_max_stats_lst)
+        B = roots.root_num
+        vtp = L.i32(virtual_to_play_batch).copy()
+        ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); la = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+        L.check(L.lib().lz_batch_traverse_with_reuse(roots._h, int(pb_c_base), float(pb_c_init), float(discount_factor), vtp,
+                                                     L.i32(true_action), L.f32(reuse_value), ix, iy, la, sl))
+        results._search_lens = sl.tolist()
+        results._roots = roots
+        return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+    def _backprop_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies, results, is_reset_list,
+                        to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst):
+        roots = results._roots
+        n = len(value_prefixs)
+        vp, v, pol = L.f32(value_prefixs if n else [0.0]), L.f32(values if n else [0.0]), L.f32(policies if n else [[0.0]])
+        rst = L.i32(is_reset_list) if is_reset_list is not None else None
+        L.check(L.lib().lz_batch_backpropagate_with_reuse(
+            roots._h, int(current_latent_state_index), float(discount_factor), vp.ctypes.data, v.ctypes.data, pol.ctypes.data, n,
+            rst.ctypes.data if rst is not None else None, L.i32(to_play_batch), L.i32(no_inference_lst), L.i32(reuse_lst),
+            L.f32(reuse_value_lst)))
+
+    if has_deterministic_flag:
+        def batch_backpropagate_with_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                                           min_max_stats_lst, results, to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst):
+            _backprop_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies, results, None,
+                            to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst)
+    else:
+        def batch_backpropagate_with_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                                           min_max_stats_lst, results, is_reset_list, to_play_batch, no_inference_lst, reuse_lst,
+                                           reuse_value_lst):
+            _backprop_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies, results, is_reset_list,
+                            to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst)
+
     return dict(MinMaxStatsList=MinMaxStatsList, ResultsWrapper=ResultsWrapper, Roots=Roots,
-                batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate)
+                batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate,
+                batch_traverse_with_reuse=batch_traverse_with_reuse,
+                batch_backpropagate_with_reuse=batch_backpropagate_with_reuse)

@@ -44,6 +44,8 @@ def lib():
         L.otree_prepare.argtypes = [P, ctypes.c_float, P, fp, fp, ip]
         L.otree_traverse.argtypes = [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, ip, ip, ip, ip, ip]
         L.otree_backpropagate.argtypes = [P, ctypes.c_int, ctypes.c_float, fp, fp, fp, ip, ip]
+        L.otree_traverse_with_reuse.argtypes = [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, ip, ip, fp, ip, ip, ip, ip]
+        L.otree_backpropagate_with_reuse.argtypes = [P, ctypes.c_int, ctypes.c_float, fp, fp, fp, ip, ip, ip, ip, fp]
         L.otree_get_distributions.argtypes = [P, ip, ip]
         L.otree_get_values.argtypes = [P, fp]
         L.otree_get_minmax.argtypes = [P, fp]
@@ -180,8 +182,48 @@ def _make(variant):
             lib().otree_backpropagate(roots._h, current_latent_state_index, discount_factor, _f32(rewards),
                                       _f32(values), _f32(policies), _i32([0] * roots.num), _i32(to_play_batch))
 
+    # ReZero (ez_tree.pyx:94-121, mz_tree.pyx:84-110)
+    def batch_traverse_with_reuse(roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results,
+                                  virtual_to_play_batch, true_action, reuse_value):
+        B = roots.num
+        if roots._mm_bound is not min_max_stats_lst:
+            lib().otree_set_delta(roots._h, min_max_stats_lst.delta)
+            roots._mm_bound = min_max_stats_lst
+        vtp = _i32(virtual_to_play_batch).copy()
+        ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); la = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+        lib().otree_traverse_with_reuse(roots._h, int(pb_c_base), pb_c_init, discount_factor, vtp, _i32(true_action),
+                                        _f32(reuse_value), ix, iy, la, sl)
+        results.search_lens = sl.tolist()
+        results._roots = roots
+        return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+    def _bp_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies, results, is_reset_list,
+                  to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst):
+        roots = results._roots
+        A = roots._A
+        pol = _f32(policies).reshape(-1, A) if len(policies) else np.zeros((1, A), np.float32)
+        lib().otree_backpropagate_with_reuse(roots._h, current_latent_state_index, discount_factor,
+                                             _f32(value_prefixs if len(value_prefixs) else [0.0]),
+                                             _f32(values if len(values) else [0.0]), pol, _i32(is_reset_list),
+                                             _i32(to_play_batch), _i32(no_inference_lst), _i32(reuse_lst), _f32(reuse_value_lst))
+
+    if variant == 0:
+        def batch_backpropagate_with_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                                           min_max_stats_lst, results, is_reset_list, to_play_batch, no_inference_lst,
+                                           reuse_lst, reuse_value_lst):
+            _bp_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies, results, is_reset_list,
+                      to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst)
+    else:
+        def batch_backpropagate_with_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies,
+                                           min_max_stats_lst, results, to_play_batch, no_inference_lst, reuse_lst,
+                                           reuse_value_lst):
+            _bp_reuse(current_latent_state_index, discount_factor, value_prefixs, values, policies, results,
+                      [0] * results._roots.num, to_play_batch, no_inference_lst, reuse_lst, reuse_value_lst)
+
     ns = types.SimpleNamespace(MinMaxStatsList=MinMaxStatsList, ResultsWrapper=ResultsWrapper, Roots=Roots,
-                               batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate)
+                               batch_traverse=batch_traverse, batch_backpropagate=batch_backpropagate,
+                               batch_traverse_with_reuse=batch_traverse_with_reuse,
+                               batch_backpropagate_with_reuse=batch_backpropagate_with_reuse)
     return ns
 
 

@@ -369,6 +369,147 @@ void otree_backpropagate(OTree *t, int latent_index, float discount, const float
     }
 }
 
+/* ---- ReZero: search_with_reuse (https://arxiv.org/abs/2404.16364) ------------------------------------------------ */
+/* carm_score  cnode.cpp:816-884 (EZ) / ctree_muzero cnode.cpp:701-752 (MZ) */
+static float arm_score(const OTree *t, const ONode *child, const OMinMax *mm, float parent_mean_q, int is_reset,
+                       float reuse_value, float total_children_visit_counts, float parent_value_prefix, float pb_c_base,
+                       float pb_c_init, float discount, int players)
+{
+    float pb_c = 0.0f, prior_score = 0.0f, value_score = 0.0f;
+    pb_c = logf((total_children_visit_counts + pb_c_base + 1) / pb_c_base) + pb_c_init;
+    pb_c *= (sqrtf(total_children_visit_counts) / (child->visit_count + 1));
+    prior_score = pb_c * child->prior;
+    if (child->visit_count == 0) {
+        value_score = parent_mean_q;
+    } else {
+        float true_reward;
+        if (t->variant == 0) {
+            true_reward = child->value_prefix - parent_value_prefix;
+            if (is_reset == 1) true_reward = child->value_prefix;
+        } else {
+            true_reward = child->value_prefix;
+        }
+        if (players == 1) value_score = true_reward + discount * reuse_value;
+        else if (players == 2) value_score = true_reward + discount * (-reuse_value);
+    }
+    value_score = mm_normalize(mm, value_score);
+    if (value_score < 0) value_score = 0;
+    else if (value_score > 1) value_score = 1;
+    return (child->visit_count == 0) ? prior_score + value_score : value_score;
+}
+
+/* cselect_root_child  cnode.cpp:697-754 (EZ) / ctree_muzero cnode.cpp:597-652 (MZ) */
+static int select_root_child(const OTree *t, int env, const ONode *n, const OMinMax *mm, int pb_c_base, float pb_c_init,
+                             float discount, float mean_q, int players, int true_action, float reuse_value)
+{
+    const ONode *pool = &t->nodes[(size_t)env * t->cap];
+    float max_score = O_FLOAT_MIN;
+    const float epsilon = 0.000001f;
+    int max_index_lst[t->A];
+    int n_max = 0;
+    for (int j = 0; j < n->n_legal; ++j) {
+        int a = legal_at(t, env, n, j);
+        const ONode *child = &pool[n->first_child + a];
+        float temp_score;
+        if (a == true_action)
+            temp_score = arm_score(t, child, mm, mean_q, n->is_reset, reuse_value, (float)(n->visit_count - 1), n->value_prefix,
+                                   (float)pb_c_base, pb_c_init, discount, players);
+        else
+            temp_score = ucb_score(t, child, mm, mean_q, n->is_reset, (float)(n->visit_count - 1), n->value_prefix,
+                                   (float)pb_c_base, pb_c_init, discount, players);
+        if (max_score < temp_score) {
+            max_score = temp_score;
+            n_max = 0;
+            max_index_lst[n_max++] = a;
+        } else if (temp_score >= max_score - epsilon) {
+            max_index_lst[n_max++] = a;
+        }
+    }
+    int action = 0;
+    if (n_max > 0) {
+        int rand_index = t->tiebreak ? (rand() % n_max) : 0;
+        action = max_index_lst[rand_index];
+    }
+    return action;
+}
+
+/* cbatch_traverse_with_reuse  cnode.cpp:965-1072 (EZ) / ctree_muzero cnode.cpp:828-930 (MZ):
+ * the search stops below the root when the root picks the trajectory's true action; out_ix = -1 when the node reached
+ * is already expanded (no inference needed for this root in this simulation). */
+void otree_traverse_with_reuse(OTree *t, int pb_c_base, float pb_c_init, float discount, int *virtual_to_play,
+                               const int *true_action, const float *reuse_value, int *out_ix, int *out_iy,
+                               int *out_last_action, int *out_search_len)
+{
+    int last_action = -1;
+    int players;
+    int largest = virtual_to_play[0];
+    for (int i = 1; i < t->B; ++i) if (virtual_to_play[i] > largest) largest = virtual_to_play[i];
+    players = (largest == -1) ? 1 : 2;
+    for (int i = 0; i < t->B; ++i) {
+        ONode *pool = &t->nodes[(size_t)i * t->cap];
+        int *path = &t->path[(size_t)i * t->cap];
+        float parent_q = 0.0f;
+        int ni = 0, is_root = 1, search_len = 0, plen = 0;
+        path[plen++] = ni;
+        while (pool[ni].expanded) {
+            ONode *node = &pool[ni];
+            float mean_q = compute_mean_q(t, i, node, is_root, parent_q, discount);
+            parent_q = mean_q;
+            int action;
+            if (is_root) action = select_root_child(t, i, node, &t->mm[i], pb_c_base, pb_c_init, discount, mean_q, players, true_action[i], reuse_value[i]);
+            else action = select_child(t, i, node, &t->mm[i], pb_c_base, pb_c_init, discount, mean_q, players);
+            if (players > 1) virtual_to_play[i] = (virtual_to_play[i] == 1) ? 2 : 1;
+            node->best_action = action;
+            ni = node->first_child + action;
+            last_action = action;
+            path[plen++] = ni;
+            search_len += 1;
+            if (is_root && action == true_action[i]) break;
+            is_root = 0;
+        }
+        if (pool[ni].expanded) {
+            out_ix[i] = -1;
+            out_iy[i] = i;
+        } else {
+            const ONode *parent = &pool[path[plen - 2]];
+            out_ix[i] = parent->latent_index;
+            out_iy[i] = parent->batch_index;
+        }
+        out_last_action[i] = last_action;
+        out_search_len[i] = search_len;
+        t->path_len[i] = plen;
+    }
+}
+
+/* cbatch_backpropagate_with_reuse  cnode.cpp:603-649 (EZ) / ctree_muzero cnode.cpp:502-549 (MZ).
+ * value_prefixs / values / logits hold one row per root that needed inference, in root order (the reference's compacted
+ * batch); no_inference_lst / reuse_lst are ascending root indices terminated by -1. */
+void otree_backpropagate_with_reuse(OTree *t, int latent_index, float discount, const float *value_prefixs,
+                                    const float *values, const float *logits, const int *is_reset, const int *to_play,
+                                    const int *no_inference_lst, const int *reuse_lst, const float *reuse_value)
+{
+    int count_a = 0, count_b = 0, count_c = 0;
+    float value_propagate = 0;
+    for (int i = 0; i < t->B; ++i) {
+        int leaf = t->path[(size_t)i * t->cap + t->path_len[i] - 1];
+        if (i == no_inference_lst[count_a]) {
+            count_a = count_a + 1;
+            value_propagate = reuse_value[i];
+        } else {
+            node_expand(t, i, leaf, to_play[i], latent_index, count_b, value_prefixs[count_b], logits + (size_t)count_b * t->A);
+            if (i == reuse_lst[count_c]) {
+                value_propagate = reuse_value[i];
+                count_c = count_c + 1;
+            } else {
+                value_propagate = values[count_b];
+            }
+            count_b = count_b + 1;
+        }
+        if (t->variant == 0) t->nodes[(size_t)i * t->cap + leaf].is_reset = is_reset[i];
+        backpropagate(t, i, to_play[i], value_propagate, discount);
+    }
+}
+
 /* CRoots::get_distributions cnode.cpp:389-405, CNode::get_children_distribution :263-281 */
 void otree_get_distributions(const OTree *t, int *out /* [B][A], -1 padded */, int *out_cnt)
 {

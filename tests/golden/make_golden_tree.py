@@ -31,3 +31,16 @@ for name in sorted(td.CASES):
     np.savez_compressed(os.path.join(HERE, "tree_%s.npz" % name), records=rec.astype(dt), distributions=dist,
                         values=out["values"])
     print(name, "ok", rec.shape, "max depth", rec[:, :, 3].max())
+
+# ReZero search_with_reuse
+for name in sorted(td.REUSE_CASES):
+    c = td.make_reuse_inputs(td.REUSE_CASES[name])
+    out = td.run_tree_reuse(ez_ref if c["variant"] == "ez" else mz_ref, c)
+    dist = np.full((c["B"], c["A"]), -1, np.int32)
+    for i, d in enumerate(out["distributions"]):
+        dist[i, :len(d)] = d
+    rec = out["records"]
+    dt = np.int8 if rec.max() < 127 and rec.min() >= -128 else np.int16
+    np.savez_compressed(os.path.join(HERE, "tree_%s.npz" % name), records=rec.astype(dt), distributions=dist,
+                        values=out["values"])
+    print(name, "ok", rec.shape, "inferences", out["inferences"], "of", c["B"] * c["S"])

@@ -69,3 +69,29 @@ def test_reference_stochastic_tie_breaking_mode():
         res = mz.ResultsWrapper(1)
         sel.append(mz.batch_traverse(roots, 19652, 1.25, 0.997, mm, res, [-1])[2][0])
     assert len(set(sel)) > 1
+
+
+# ---- ReZero search_with_reuse ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(td.REUSE_CASES))
+def test_oracle_reuse_matches_compiled_reference(name):
+    if not build_ref.build():
+        pytest.skip("reference sources not present (GPU box)")
+    ez_ref, mz_ref = build_ref.load("det")
+    c = td.make_reuse_inputs(td.REUSE_CASES[name])
+    ref = td.run_tree_reuse(ez_ref if c["variant"] == "ez" else mz_ref, c)
+    ora = td.run_tree_reuse(_mod(c["variant"]), c, roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
+    td.assert_same(ref, ora, name)
+    assert ref["inferences"] == ora["inferences"] and ref["inferences"] < c["B"] * c["S"]  # some roots did skip inference
+
+
+@pytest.mark.parametrize("name", sorted(td.REUSE_CASES))
+def test_oracle_reuse_matches_golden(name):
+    g = np.load(os.path.join(GOLD, "tree_%s.npz" % name))
+    c = td.make_reuse_inputs(td.REUSE_CASES[name])
+    ora = td.run_tree_reuse(_mod(c["variant"]), c, roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
+    assert np.array_equal(ora["records"], g["records"])
+    dist = np.full((c["B"], c["A"]), -1, np.int32)
+    for i, d in enumerate(ora["distributions"]):
+        dist[i, :len(d)] = d
+    assert np.array_equal(dist, g["distributions"])
+    assert np.array_equal(ora["values"].view(np.uint32), g["values"].view(np.uint32))

@@ -165,3 +165,29 @@ def test_device_select_action_matches_python_original():
     assert np.abs(freq - p).max() < 0.08
     for b in range(B):
         assert draws[:, b].max() < len(dists[b]) and all(dists[b][j] > 0 for j in np.unique(draws[:, b]))
+
+
+@pytest.mark.parametrize("name", sorted(td.REUSE_CASES))
+def test_device_reuse_tree_matches_oracle_and_golden(name):
+    """ReZero batch_traverse_with_reuse / batch_backpropagate_with_reuse on the device: bit-exact vs the C oracle and vs
+    the goldens generated from the reference's own compiled code (incl. the packed batch_index bookkeeping)."""
+    from oracle import ctree as octree
+    c = td.make_reuse_inputs(td.REUSE_CASES[name])
+    mod = _dev_mod(c["variant"])
+    orig = mod.Roots
+
+    def mk(n, legal, **kw):
+        r = orig(n, legal, action_space_size=c["A"], max_simulations=c["S"])
+        r.set_tiebreak(0)
+        return r
+    ns = type("M", (), dict(Roots=staticmethod(mk), MinMaxStatsList=mod.MinMaxStatsList, ResultsWrapper=mod.ResultsWrapper,
+                            batch_traverse_with_reuse=staticmethod(mod.batch_traverse_with_reuse),
+                            batch_backpropagate_with_reuse=staticmethod(mod.batch_backpropagate_with_reuse)))
+    dev = td.run_tree_reuse(ns, c)
+    omod = octree.ez_tree if c["variant"] == "ez" else octree.mz_tree
+    ora = td.run_tree_reuse(omod, c, roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
+    td.assert_same(ora, dev, name)
+    assert dev["inferences"] == ora["inferences"]
+    g = np.load(os.path.join(GOLD, "tree_%s.npz" % name))
+    assert np.array_equal(dev["records"], g["records"])
+    assert np.array_equal(dev["values"].view(np.uint32), g["values"].view(np.uint32))

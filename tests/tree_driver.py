@@ -119,3 +119,72 @@ def assert_same(a, b, what=""):
     assert a["distributions"] == b["distributions"], "%s: visit-count distributions differ" % what
     # bit-exact: same float32 op order on both sides
     assert np.array_equal(a["values"].view(np.uint32), b["values"].view(np.uint32)), "%s: root values differ" % what
+
+
+# ------------------------------------------------------------------------------------------------
+# ReZero: search_with_reuse (lzero/mcts/tree_search/mcts_ctree.py:878-1002 EZ, :370-470 MZ)
+# ------------------------------------------------------------------------------------------------
+REUSE_CASES = {
+    "ez_reuse_b32": dict(variant="ez", B=32, A=6, S=40, seed=20),
+    "ez_reuse_fixture16": dict(variant="ez", B=16, A=9, S=30, seed=21, legal="fixture", to_play=[-1] * 16),
+    "ez_reuse_fixture16_2p": dict(variant="ez", B=16, A=9, S=30, seed=22, legal="fixture", to_play=FIXTURE_TO_PLAY, discount=1.0),
+    "mz_reuse_b24": dict(variant="mz", B=24, A=4, S=60, seed=23),
+    "mz_reuse_fixture16_2p": dict(variant="mz", B=16, A=9, S=30, seed=24, legal="fixture", to_play=FIXTURE_TO_PLAY),
+}
+
+
+def make_reuse_inputs(case):
+    c = make_inputs(case)
+    rng = np.random.default_rng(1000 + c["seed"])
+    # the trajectory's true action (a legal one) and the value found by the search of the next state
+    c["true_action"] = [int(l[rng.integers(0, len(l))]) for l in c["legal_list"]]
+    c["reuse_value"] = rng.standard_normal(c["B"]).astype(np.float32)
+    return c
+
+
+def run_tree_reuse(mod, c, roots_kwargs=None):
+    """The reference driver's bookkeeping (compaction of the roots that need inference, no_inference / reuse lists with
+    the -1 sentinel) around batch_traverse_with_reuse / batch_backpropagate_with_reuse, with recorded network outputs:
+    sims[s] holds one row per ROOT; the rows of the roots that need inference are packed in root order.
+    is_reset is computed per root from its own search length (the reference indexes a compacted list by root there,
+    mcts_ctree.py:968-971 vs cnode.cpp:645, which reads out of bounds whenever a root skips inference)."""
+    B, S = c["B"], c["S"]
+    ez = c["variant"] == "ez"
+    roots = mod.Roots(B, c["legal_list"], **(roots_kwargs or {}))
+    if c["noises"] is not None:
+        roots.prepare(c["noise_w"], c["noises"], c["root_vp"].tolist(), c["root_logits"].tolist(), list(c["to_play_list"]))
+    else:
+        roots.prepare_no_noise(c["root_vp"].tolist(), c["root_logits"].tolist(), list(c["to_play_list"]))
+    mm = mod.MinMaxStatsList(B)
+    mm.set_delta(c["delta"])
+    rec = np.zeros((S, B, 5), np.int32)
+    infer = 0
+    for s in range(S):
+        res = mod.ResultsWrapper(B)
+        ix, iy, la, vtp = mod.batch_traverse_with_reuse(roots, c["pb_c_base"], c["pb_c_init"], c["discount"], mm, res,
+                                                        list(c["to_play_list"]), list(c["true_action"]), c["reuse_value"].tolist())
+        sl = res.get_search_len()
+        rec[s, :, 0], rec[s, :, 1], rec[s, :, 2], rec[s, :, 3], rec[s, :, 4] = ix, iy, la, sl, vtp
+        need, no_inference_lst, reuse_lst = [], [], []
+        for count in range(B):
+            if ix[count] != -1:
+                need.append(count)
+            else:
+                no_inference_lst.append(iy[count])
+            if ix[count] == 0 and la[count] == c["true_action"][count]:
+                reuse_lst.append(count)
+        infer += len(need)
+        sim = c["sims"][s]
+        no_inference_lst.append(-1)
+        reuse_lst.append(-1)
+        vp, v, lg = sim["vp"][need].tolist(), sim["v"][need].tolist(), sim["logits"][need].tolist()
+        if ez:
+            reset = [int(l % c["horizon"] == 0) for l in sl]
+            mod.batch_backpropagate_with_reuse(s + 1, c["discount"], vp, v, lg, mm, res, reset, vtp, no_inference_lst, reuse_lst,
+                                               c["reuse_value"].tolist())
+        else:
+            mod.batch_backpropagate_with_reuse(s + 1, c["discount"], vp, v, lg, mm, res, vtp, no_inference_lst, reuse_lst,
+                                               c["reuse_value"].tolist())
+    out = dict(records=rec, distributions=roots.get_distributions(), values=np.asarray(roots.get_values(), np.float32),
+               inferences=infer)
+    return out
