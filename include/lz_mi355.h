@@ -163,6 +163,13 @@ int lz_batch_backpropagate_with_reuse(lz_roots *r, int current_latent_state_inde
                                       int n_infer, const int32_t *h_is_reset, const int32_t *h_to_play,
                                       const int32_t *h_no_inference_lst, const int32_t *h_reuse_lst, const float *h_reuse_value);
 
+/* the whole ReZero search on the device with an engine model (replaces EfficientZeroMCTSCtree.search_with_reuse /
+ * MuZeroMCTSCtree.search_with_reuse, mcts_ctree.py:878-1002, 370-470); returns the reference's (length of the last
+ * simulation's inference batch, average inference batch size). */
+int lz_search_with_reuse(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, float discount_factor,
+                         int lstm_horizon_len, float value_delta_max, const int32_t *h_true_action,
+                         const float *h_reuse_value, int *out_last_length, double *out_average_infer);
+
 /* select_action (lzero/policy/utils.py:637-661) for every root on the device: p_i = N_i^(1/T) / sum over the root's legal
  * positions (float64 like the original); h_action_pos[i] = arg-max of the visit counts (deterministic != 0, np.argmax:
  * first maximum) or one draw from p (counter-based generator keyed by seed and root); h_entropy[i] in bits.

@@ -72,6 +72,7 @@ def lib():
         "lz_sroots_get_distributions": [P, c_i32p],
         "lz_sroots_get_sampled_actions": [P, c_f32p],
         "lz_sroots_set_given": [P, P, ctypes.c_int],
+        "lz_search_with_reuse": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float, c_i32p, c_f32p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
         "lz_batch_traverse_with_reuse": [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "lz_batch_backpropagate_with_reuse": [P, ctypes.c_int, ctypes.c_float, P, P, P, ctypes.c_int, P, c_i32p, c_i32p, c_i32p, c_f32p],
         "lz_roots_select_action": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, c_i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")],

@@ -215,6 +215,8 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     if (r->graph_exec) (void)hipGraphExecDestroy(r->graph_exec);
     if (r->pool_slab) (void)hipFree(r->pool_slab);
     if (r->d_obs) (void)hipFree(r->d_obs);
+    if (r->d_given) (void)hipFree(r->d_given);
+    if (r->d_reuse) (void)hipFree(r->d_reuse);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);
     delete r;
@@ -463,7 +465,7 @@ extern "C" int lz_batch_backpropagate_with_reuse(lz_roots *r, int current_latent
     LZ_HIP_CHECK(hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, s));
     lz_tree_launch_backprop_reuse(t, current_latent_state_index, discount_factor, (const float *)(d + o_vp), (const float *)(d + o_v),
                                   (const float *)(d + o_lg), (const int32_t *)(d + o_rst), 0, (const int32_t *)(d + o_tp),
-                                  (const int32_t *)(d + o_md), (const int32_t *)(d + o_row), (const float *)(d + o_rv), nullptr, s);
+                                  (const int32_t *)(d + o_md), (const int32_t *)(d + o_row), (const float *)(d + o_rv), nullptr, nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     return LZ_OK;

@@ -119,6 +119,7 @@ struct lz_roots {
     int32_t *d_noise_off = nullptr; // [B]
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
+    void *d_reuse = nullptr;        // ReZero fused search: true_action [B] | reuse_value [B] | per-simulation inference counts [NN]
     float *d_given = nullptr;       // Sampled-EZ parity runs: [records][B][K][D] injected draws (record 0 = roots, s + 1 = simulation s)
     int given_records = 0;
     hipGraphExec_t graph_exec = nullptr;  // captured search (lz_search)
@@ -156,7 +157,7 @@ void lz_tree_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args 
 void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
                                    const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play,
                                    const int32_t *d_mode, const int32_t *d_row, const float *d_reuse_value,
-                                   const int32_t *d_true_action, hipStream_t s);
+                                   const int32_t *d_true_action, int32_t *d_infer_counter, hipStream_t s);
 void lz_tree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, int32_t *d_cnt, float *d_values, hipStream_t s);
 void lz_tree_launch_trajectories(const lz_tree_dev &t, int32_t *d_out, int stride, hipStream_t s);
 // Sampled EfficientZero tree (lz_tree_sampled.hip)

@@ -651,6 +651,58 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     return LZ_OK;
 }
 
+// ReZero: EfficientZeroMCTSCtree.search_with_reuse / MuZeroMCTSCtree.search_with_reuse (mcts_ctree.py:878-1002, 370-470) with an
+// engine model.  Every root goes through the network kernels each simulation (a root that needs no inference only wastes
+// its lane of the batch; its outputs land in a pool slot no node refers to), the tree kernels implement the reuse rules.
+extern "C" int lz_search_with_reuse(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, float discount_factor,
+                                    int lstm_horizon_len, float value_delta_max, const int32_t *h_true_action,
+                                    const float *h_reuse_value, int *out_last_length, double *out_average_infer)
+{
+    LZ_REQUIRE(r != nullptr && h_true_action != nullptr && h_reuse_value != nullptr, "NULL argument");
+    LZ_REQUIRE(r->inferred && r->prepared, "lz_search_with_reuse needs lz_initial_inference and a prepare call first");
+    LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "the sampled tree has no reuse variant");
+    const int mt = r->eng->model->cfg.model_type;
+    LZ_REQUIRE(lstm_horizon_len > 0 || mt == 1 || mt == 2, "lstm_horizon_len must be positive (mcts_ctree.py:967)");
+    if (num_simulations < 1 || num_simulations >= r->t.NN) {
+        lz_set_error("num_simulations %d exceeds the node pool (max_simulations %d)", num_simulations, r->t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = mt >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
+    if (!r->d_reuse) LZ_HIP_CHECK(hipMalloc(&r->d_reuse, (2 * B + (size_t)t.NN) * 4));
+    int32_t *d_ta = (int32_t *)r->d_reuse;
+    float *d_rv = (float *)(d_ta + B);
+    int32_t *d_cnt = (int32_t *)(d_rv + B);
+    LZ_HIP_CHECK(hipMemcpyAsync(d_ta, h_true_action, B * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(d_rv, h_reuse_value, B * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipMemsetAsync(d_cnt, 0, (size_t)t.NN * 4, s));
+    r->delta = value_delta_max;
+    lz_traverse_args ta;
+    ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
+    ta.tiebreak = r->tiebreak; ta.seed = r->seed; ta.counter = 0;
+    lz_tree_launch_minmax_reset(t, s);
+    for (int sim = 0; sim < num_simulations; ++sim) {
+        ta.counter = (uint32_t)sim;
+        lz_tree_launch_traverse_reuse(t, ta, value_delta_max, r->d_to_play, d_ta, d_rv, s);
+        recurrent(r, sim, lstm_horizon_len, s);
+        const int slot = sim + 1;
+        lz_tree_launch_backprop_reuse(t, slot, discount_factor, r->sim_vp + (size_t)slot * B, r->sim_value + (size_t)slot * B,
+                                      r->sim_logits + (size_t)slot * B * A, nullptr, lstm_horizon_len, nullptr, nullptr, nullptr, d_rv,
+                                      d_ta, d_cnt + sim, s);
+    }
+    LZ_HIP_CHECK(hipGetLastError());
+    std::vector<int32_t> cnt(num_simulations);
+    LZ_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)num_simulations * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    long long sum = 0;
+    for (int v : cnt) sum += v;
+    if (out_last_length) *out_last_length = cnt.back();
+    if (out_average_infer) *out_average_infer = (double)sum / num_simulations;
+    return LZ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int lz_roots_enable_trace(lz_roots *r, int on)
 {

@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) void k_backprop_reuse(lz_tree_dev t, int new_no
                                                        int horizon, const int32_t *__restrict__ to_play_in,
                                                        const int32_t *__restrict__ mode, const int32_t *__restrict__ row,
                                                        const float *__restrict__ reuse_value,
-                                                       const int32_t *__restrict__ true_action)
+                                                       const int32_t *__restrict__ true_action, int32_t *infer_counter)
 {
     const int b = blockIdx.x, lane = threadIdx.x, A = t.A;
     const tview v = global_view(t, b);
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(64) void k_backprop_reuse(lz_tree_dev t, int new_no
     }
     const float vp = (m != 1) ? vps[r] : 0.0f;
     const float value = (m != 0) ? reuse_value[b] : values[r];
+    if (infer_counter && lane == 0 && m != 1) atomicAdd(infer_counter, 1);  // roots that used a network evaluation
     dev_backprop<NC, VARIANT, false>(t, v, sc, new_node, discount, vp, value, lg, d, to_play, reset, m == 1, r);
 }
 
@@ -819,23 +820,23 @@ void lz_tree_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args 
 template <int V>
 static void launch_bpreuse_v(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val, const float *lg,
                              const int32_t *rst, int horizon, const int32_t *tp, const int32_t *mode, const int32_t *row,
-                             const float *rv, const int32_t *ta, hipStream_t s)
+                             const float *rv, const int32_t *ta, int32_t *ic, hipStream_t s)
 {
     switch (nchunks(t.A)) {
-    case 1: hipLaunchKernelGGL((k_backprop_reuse<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta); break;
-    case 2: hipLaunchKernelGGL((k_backprop_reuse<2, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta); break;
-    default: hipLaunchKernelGGL((k_backprop_reuse<4, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta); break;
+    case 1: hipLaunchKernelGGL((k_backprop_reuse<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta, ic); break;
+    case 2: hipLaunchKernelGGL((k_backprop_reuse<2, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta, ic); break;
+    default: hipLaunchKernelGGL((k_backprop_reuse<4, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta, ic); break;
     }
 }
 void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
                                    const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play,
                                    const int32_t *d_mode, const int32_t *d_row, const float *d_reuse_value,
-                                   const int32_t *d_true_action, hipStream_t s)
+                                   const int32_t *d_true_action, int32_t *d_infer_counter, hipStream_t s)
 {
     if (t.variant == LZ_TREE_EFFICIENTZERO)
-        launch_bpreuse_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, s);
+        launch_bpreuse_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, d_infer_counter, s);
     else
-        launch_bpreuse_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, s);
+        launch_bpreuse_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, d_infer_counter, s);
 }
 
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s)

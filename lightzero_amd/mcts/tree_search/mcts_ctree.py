@@ -118,6 +118,71 @@ class EfficientZeroMCTSCtree(object):
                     reset_idx.astype(np.int32), virtual_to_play_batch)
 
 
+    def search_with_reuse(self, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch,
+                          true_action_list=None, reuse_value_list=None):
+        """EfficientZeroMCTSCtree.search_with_reuse (mcts_ctree.py:878-1002, ReZero): returns the reference's
+        ``(length, average_infer)``.  Engine model: the whole loop on the device (lz_search_with_reuse).  Foreign model:
+        the reference loop with the device tree; ``is_reset`` is computed per root from its own search length (the
+        reference indexes a packed list by root there, which reads out of bounds whenever a root skips inference)."""
+        cfg = self._cfg
+        S = int(cfg["num_simulations"])
+        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+            import ctypes
+            length, avg = ctypes.c_int(0), ctypes.c_double(0.0)
+            L.check(L.lib().lz_search_with_reuse(roots._h, S, int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
+                                                 float(cfg["discount_factor"]), int(cfg["lstm_horizon_len"]),
+                                                 float(cfg["value_delta_max"]), L.i32(true_action_list), L.f32(reuse_value_list),
+                                                 ctypes.byref(length), ctypes.byref(avg)))
+            return length.value, avg.value
+        import torch
+        T = tree_efficientzero
+        device = _get(cfg, "device", "cpu")
+        with torch.no_grad():
+            model.eval()
+            batch_size = roots.num
+            pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+            latent_pool = [np.asarray(latent_state_roots)]
+            c_pool = [np.asarray(reward_hidden_state_roots[0])]
+            h_pool = [np.asarray(reward_hidden_state_roots[1])]
+            mm = T.MinMaxStatsList(batch_size)
+            mm.set_delta(cfg["value_delta_max"])
+            infer_sum, length = 0, 0
+            for simulation_index in range(S):
+                results = T.ResultsWrapper(num=batch_size)
+                tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
+                ix, iy, last_actions, vtp = T.batch_traverse_with_reuse(roots, pb_c_base, pb_c_init, discount_factor, mm, results, tp,
+                                                                        true_action_list, reuse_value_list)
+                search_lens = results.get_search_len()
+                need = [k for k in range(batch_size) if ix[k] != -1]
+                no_inference_lst = [iy[k] for k in range(batch_size) if ix[k] == -1] + [-1]
+                reuse_lst = [k for k in range(batch_size) if ix[k] == 0 and last_actions[k] == true_action_list[k]] + [-1]
+                length = len(need)
+                if length:
+                    lat = np.stack([latent_pool[ix[k]][iy[k]] for k in need])
+                    hc = np.stack([c_pool[ix[k]][0][iy[k]] for k in need])
+                    hh = np.stack([h_pool[ix[k]][0][iy[k]] for k in need])
+                    out = model.recurrent_inference(torch.from_numpy(lat).to(device),
+                                                    (torch.from_numpy(hc).to(device).unsqueeze(0), torch.from_numpy(hh).to(device).unsqueeze(0)),
+                                                    torch.from_numpy(np.asarray([last_actions[k] for k in need])).to(device).long())
+                    latent_pool.append(out.latent_state.detach().cpu().numpy())
+                    value = _inverse_scalar_transform(out.value, self._support_min).reshape(-1)
+                    value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min).reshape(-1)
+                    policy = out.policy_logits.detach().cpu().numpy()
+                    rhs = [out.reward_hidden_state[0].detach().cpu().numpy().copy(), out.reward_hidden_state[1].detach().cpu().numpy().copy()]
+                    reset_packed = (np.array([search_lens[k] for k in need]) % int(cfg["lstm_horizon_len"]) == 0)
+                    rhs[0][:, reset_packed, :] = 0
+                    rhs[1][:, reset_packed, :] = 0
+                    c_pool.append(rhs[0]); h_pool.append(rhs[1])
+                else:
+                    latent_pool.append([]); c_pool.append([]); h_pool.append([])
+                    value, value_prefix, policy = [], [], []
+                is_reset_list = (np.array(search_lens) % int(cfg["lstm_horizon_len"]) == 0).astype(np.int32)
+                T.batch_backpropagate_with_reuse(simulation_index + 1, discount_factor, value_prefix, value, policy, mm, results,
+                                                 is_reset_list, vtp, no_inference_lst, reuse_lst, reuse_value_list)
+                infer_sum += length
+        return length, infer_sum / S
+
+
 class MuZeroMCTSCtree(object):
     """lzero/mcts/tree_search/mcts_ctree.py:211-368 (reference loop; tree kernels on the device)."""
     config = dict(root_dirichlet_alpha=0.3, root_noise_weight=0.25, pb_c_base=19652, pb_c_init=1.25,
@@ -177,6 +242,56 @@ class MuZeroMCTSCtree(object):
                 tree_muzero.batch_backpropagate(simulation_index + 1, discount_factor, reward.reshape(-1), value.reshape(-1),
                                                 out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
                                                 virtual_to_play_batch)
+
+    def search_with_reuse(self, roots, model, latent_state_roots, to_play_batch, true_action_list=None, reuse_value_list=None):
+        """MuZeroMCTSCtree.search_with_reuse (mcts_ctree.py:370-470, ReZero): returns ``(length, average_infer)``."""
+        cfg = self._cfg
+        S = int(cfg["num_simulations"])
+        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+            import ctypes
+            length, avg = ctypes.c_int(0), ctypes.c_double(0.0)
+            L.check(L.lib().lz_search_with_reuse(roots._h, S, int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
+                                                 float(cfg["discount_factor"]), 0, float(cfg["value_delta_max"]),
+                                                 L.i32(true_action_list), L.f32(reuse_value_list), ctypes.byref(length), ctypes.byref(avg)))
+            return length.value, avg.value
+        import torch
+        T = tree_muzero
+        device = _get(cfg, "device", "cpu")
+        with torch.no_grad():
+            model.eval()
+            batch_size = roots.num
+            pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+            latent_pool = [np.asarray(latent_state_roots)]
+            mm = T.MinMaxStatsList(batch_size)
+            mm.set_delta(cfg["value_delta_max"])
+            infer_sum, length = 0, 0
+            for simulation_index in range(S):
+                results = T.ResultsWrapper(num=batch_size)
+                tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
+                ix, iy, last_actions, vtp = T.batch_traverse_with_reuse(roots, pb_c_base, pb_c_init, discount_factor, mm, results, tp,
+                                                                        true_action_list, reuse_value_list)
+                need = [k for k in range(batch_size) if ix[k] != -1]
+                no_inference_lst = [iy[k] for k in range(batch_size) if ix[k] == -1] + [-1]
+                reuse_lst = [k for k in range(batch_size) if ix[k] == 0 and last_actions[k] == true_action_list[k]] + [-1]
+                length = len(need)
+                if length:
+                    lat = np.stack([latent_pool[ix[k]][iy[k]] for k in need])
+                    out = model.recurrent_inference(torch.from_numpy(lat).to(device),
+                                                    torch.from_numpy(np.asarray([last_actions[k] for k in need])).to(device).long())
+                    latent_pool.append(out.latent_state.detach().cpu().numpy())
+                    if self._categorical:
+                        value = _inverse_scalar_transform(out.value, self._support_min).reshape(-1)
+                        reward = _inverse_scalar_transform(out.reward, self._support_min).reshape(-1)
+                    else:
+                        value = out.value.detach().cpu().numpy().reshape(-1); reward = out.reward.detach().cpu().numpy().reshape(-1)
+                    policy = out.policy_logits.detach().cpu().numpy()
+                else:
+                    latent_pool.append([])
+                    value, reward, policy = [], [], []
+                T.batch_backpropagate_with_reuse(simulation_index + 1, discount_factor, reward, value, policy, mm, results, vtp,
+                                                 no_inference_lst, reuse_lst, reuse_value_list)
+                infer_sum += length
+        return length, infer_sum / S
 
 
 class SampledEfficientZeroMCTSCtree(object):

@@ -179,3 +179,70 @@ def sez_search(tree, roots, model, latent_state_roots, reward_hidden_state_roots
             tree.batch_backpropagate(simulation_index + 1, discount_factor, value_prefix.reshape(-1).tolist(),
                                      value.reshape(-1).tolist(), out.policy_logits.detach().cpu().numpy().tolist(),
                                      min_max_stats_lst, results, reset_idx.astype(np.int32).tolist(), virtual_to_play_batch)
+
+
+def ez_search_with_reuse(tree, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch, cfg, true_action_list,
+                         reuse_value_list, device="cpu"):
+    """EfficientZeroMCTSCtree.search_with_reuse  lzero/mcts/tree_search/mcts_ctree.py:878-1002 (ReZero).  One deviation:
+    is_reset_list is computed per ROOT from its own search length; the reference builds it from the packed search lengths
+    (:968-971) and cnode.cpp:645 indexes it by root, which reads past its end whenever a root skips inference."""
+    ist = InverseScalarTransform(device=device)
+    with torch.no_grad():
+        model.eval()
+        batch_size = roots.num
+        pb_c_base, pb_c_init, discount_factor = cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"]
+        latent_state_batch_in_search_path = [latent_state_roots]
+        reward_hidden_state_c_batch = [reward_hidden_state_roots[0]]
+        reward_hidden_state_h_batch = [reward_hidden_state_roots[1]]
+        min_max_stats_lst = tree.MinMaxStatsList(batch_size)
+        min_max_stats_lst.set_delta(cfg["value_delta_max"])
+        infer_sum = 0
+        for simulation_index in range(cfg["num_simulations"]):
+            latent_states, hidden_states_c_reward, hidden_states_h_reward = [], [], []
+            temp_actions, temp_search_lens, no_inference_lst, reuse_lst = [], [], [], []
+            results = tree.ResultsWrapper(batch_size)
+            ix_l, iy_l, last_actions, virtual_to_play_batch = tree.batch_traverse_with_reuse(
+                roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, list(to_play_batch),
+                list(true_action_list), list(reuse_value_list))
+            search_lens = results.get_search_len()
+            for count, (ix, iy) in enumerate(zip(ix_l, iy_l)):
+                if ix != -1:
+                    latent_states.append(latent_state_batch_in_search_path[ix][iy])
+                    hidden_states_c_reward.append(reward_hidden_state_c_batch[ix][0][iy])
+                    hidden_states_h_reward.append(reward_hidden_state_h_batch[ix][0][iy])
+                    temp_actions.append(last_actions[count])
+                    temp_search_lens.append(search_lens[count])
+                else:
+                    no_inference_lst.append(iy)
+                if ix == 0 and last_actions[count] == true_action_list[count]:
+                    reuse_lst.append(count)
+            length = len(temp_actions)
+            if length != 0:
+                out = model.recurrent_inference(
+                    torch.from_numpy(np.asarray(latent_states)).to(device),
+                    (torch.from_numpy(np.asarray(hidden_states_c_reward)).to(device).unsqueeze(0),
+                     torch.from_numpy(np.asarray(hidden_states_h_reward)).to(device).unsqueeze(0)),
+                    torch.from_numpy(np.asarray(temp_actions)).to(device).long())
+                latent_state_batch_in_search_path.append(out.latent_state.detach().cpu().numpy())
+                value_batch = ist(out.value).detach().cpu().numpy().reshape(-1).tolist()
+                value_prefix_batch = ist(out.value_prefix).detach().cpu().numpy().reshape(-1).tolist()
+                policy_logits_batch = out.policy_logits.detach().cpu().numpy().tolist()
+                rhs = (out.reward_hidden_state[0].detach().cpu().numpy(), out.reward_hidden_state[1].detach().cpu().numpy())
+                reset_idx = (np.array(temp_search_lens) % cfg["lstm_horizon_len"] == 0)
+                rhs[0][:, reset_idx, :] = 0
+                rhs[1][:, reset_idx, :] = 0
+                reward_hidden_state_c_batch.append(rhs[0])
+                reward_hidden_state_h_batch.append(rhs[1])
+            else:
+                latent_state_batch_in_search_path.append([])
+                value_batch, policy_logits_batch, value_prefix_batch = [], [], []
+                reward_hidden_state_c_batch.append([])
+                reward_hidden_state_h_batch.append([])
+            is_reset_list = (np.array(search_lens) % cfg["lstm_horizon_len"] == 0).astype(np.int32).tolist()
+            no_inference_lst.append(-1)
+            reuse_lst.append(-1)
+            tree.batch_backpropagate_with_reuse(simulation_index + 1, discount_factor, value_prefix_batch, value_batch,
+                                                policy_logits_batch, min_max_stats_lst, results, is_reset_list,
+                                                virtual_to_play_batch, no_inference_lst, reuse_lst, list(reuse_value_list))
+            infer_sum += length
+        return length, infer_sum / cfg["num_simulations"]

@@ -176,3 +176,49 @@ def test_policy_with_device_select_action_and_reanalyze_shaped_batch():
     # the first B rows of a bigger batch search exactly like a batch of their own (roots are independent)
     sub = pol_host._forward_eval(obs_r[:B].contiguous(), action_mask=np.ones((B, A), np.float32), to_play=[-1] * B)
     assert all(sub[i]["visit_count_distributions"] == out[i]["visit_count_distributions"] for i in range(B))
+
+
+def test_search_with_reuse_fused_and_foreign_vs_oracle_pipeline():
+    """ReZero: EfficientZeroMCTSCtree.search_with_reuse with (a) the engine model, whole loop on the
+    device, and (b) a torch model driving the device tree through the reference loop, vs the oracle pipeline
+    (C restatement of the reference tree + restated driver + torch model)."""
+    from oracle import ctree as octree, search as osearch, torch_models as tm
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.mcts.tree_search.mcts_ctree import EfficientZeroMCTSCtree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    B, A, S = 32, 6, 24
+    cfg = dict(CFG, num_simulations=S)
+    ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A))
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(31))
+    rng = np.random.default_rng(7)
+    legal = [list(range(A))] * B
+    true_action = rng.integers(0, A, size=B).tolist()
+    reuse_value = rng.standard_normal(B).astype(np.float32).tolist()
+    with torch.no_grad():
+        o = ref.initial_inference(obs)
+    lat = o.latent_state.numpy(); rh = (o.reward_hidden_state[0].numpy(), o.reward_hidden_state[1].numpy())
+    pol = o.policy_logits.numpy().tolist()
+    # oracle pipeline
+    oroots = octree.ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    oroots.prepare_no_noise([0.0] * B, pol, [-1] * B)
+    o_len, o_avg = osearch.ez_search_with_reuse(octree.ez_tree, oroots, ref, lat, rh, [-1] * B, cfg, true_action, reuse_value)
+    assert o_avg < B  # some roots skipped inference
+    mcts = EfficientZeroMCTSCtree(cfg)
+    # (b) foreign torch model + device tree
+    roots_b = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots_b.set_tiebreak(0)
+    roots_b.prepare_no_noise([0.0] * B, pol, [-1] * B)
+    b_len, b_avg = mcts.search_with_reuse(roots_b, ref, lat, rh, [-1] * B, true_action, reuse_value)
+    assert roots_b.get_distributions() == oroots.get_distributions() and (b_len, b_avg) == (o_len, o_avg)
+    # (a) engine model, fused
+    roots_a = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots_a.set_tiebreak(0)
+    out = model.initial_inference(obs.cuda().contiguous(), roots_a)
+    roots_a.prepare_from_inference_no_noise([-1] * B)
+    a_len, a_avg = mcts.search_with_reuse(roots_a, model, out.latent_state, out.reward_hidden_state, [-1] * B, true_action, reuse_value)
+    same = sum(int(x == y) for x, y in zip(roots_a.get_distributions(), oroots.get_distributions()))
+    assert same >= int(0.9 * B), "only %d / %d visit-count distributions identical" % (same, B)
+    if same == B:
+        assert (a_len, a_avg) == (o_len, o_avg)
+    assert abs(a_avg - o_avg) < 0.1 * B
