@@ -23,7 +23,7 @@ struct lz_mlp_model {
     bool lstm = false, res = false, continuous = false;
     int enc_mode = 2;  // lz_dense_job.x2_mode of the action encoding
     std::vector<DenseW> rep, dyn1, dyn2, rew, common, val, pol;
-    float *lstm_w = nullptr, *lstm_b = nullptr;
+    float *lstm_w = nullptr, *lstm_wf = nullptr, *lstm_b = nullptr;
 };
 
 void lz_mlp_model_destroy(lz_mlp_model *mm) { delete mm; }
@@ -185,6 +185,11 @@ int lz_mlp_finalize(lz_engine *e)
                 }
             M.lstm_w = b.upload(wc);
             M.lstm_b = b.upload(bc);
+            if (K % 16 == 0 && H % 16 == 0) {
+                std::vector<float> wf(wc.size());
+                lz_lstm_pack_fragments(wc.data(), H, K, wf.data());
+                M.lstm_wf = b.upload(wf);
+            }
         }
     }
     if (b.err.empty()) {
@@ -372,7 +377,7 @@ void lz_mlp_recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     const float *rin = enc;
     if (M.lstm) {
         lz_lstm_args &l = P.lstm;
-        l.x = enc; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = M.lstm_w; l.bias = M.lstm_b;
+        l.x = enc; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = M.lstm_w; l.wf = M.lstm_wf; l.bias = M.lstm_b;
         l.bn_scale = nullptr; l.bn_shift = nullptr; l.search_len = t.res_search_len; l.horizon = horizon;
         l.h_out = r->h_pool + (size_t)slot * B * M.H; l.c_out = r->c_pool + (size_t)slot * B * M.H; l.hbn_out = r->t_hbn;
         l.B = (int)B; l.KX = M.L; l.H = M.H;

@@ -44,7 +44,7 @@ struct lz_model {
     ConvW dyn, dra, drb;
     float *act_table = nullptr;
     C1W rew_c;
-    float *lstm_w = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
+    float *lstm_w = nullptr, *lstm_wf = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
     MlpW fc_reward;
     // prediction
     ConvW pa, pb;

@@ -874,6 +874,114 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM step, barrier-free variant.  One workgroup = 32 rows x 16 hidden units (x 4 gates: wave g owns gate g).  The 32
+// [x | h] rows are staged ONCE in LDS (32 x K floats, <= 140 KB), the weights stream from L2 straight into registers in
+// MFMA-fragment order through a 12-deep ring, so the K loop is ds_read + MFMA only (no per-chunk barrier, no LDS
+// stores) -- the structure of k_chain's inner loop.  grid = (H/16, ceil(B/32)): blockIdx.x walks the column tiles so
+// that the workgroups sharing a weight slice sit on the same XCD (block id % 8).
+// ------------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
+{
+    constexpr int K = NKB * 16, PS = K + 4, MR = 32, R = 12;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [32][PS]; reused for the gate exchange
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x, r0 = blockIdx.y * MR;
+    const int H = a.H, KX = a.KX;
+    const size_t slot = (size_t)a.B * H;
+    // weight ring first: its L2 round trip overlaps the staging
+    const float4 *wp = reinterpret_cast<const float4 *>(a.wf) + ((size_t)(tile * 4 + wv) * NKB) * 64 + lane;
+    float4 wq[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)min(s, NKB - 1) * 64];
+    // previous cell state of this thread's two (row, unit) pairs
+    float c_prev[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = tid + 256 * q, row = p >> 4, u = p & 15;
+        const int b = min(r0 + row, a.B - 1);
+        c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + tile * 16 + u];
+    }
+    // stage the rows: [x (KX) | h (H)] per row; 8 threads per row, batches of 12 float4 loads in flight per thread
+    constexpr int K4 = K / 4, NI = (K4 + 7) / 8, NBATCH = 12;
+    {
+        const int row = tid >> 3, part = tid & 7;
+        const int b = min(r0 + row, a.B - 1);
+        const int kx4 = KX >> 2;
+        const float *xrow = a.x + (size_t)b * KX;
+        const float *hrow = a.h_pool + (size_t)a.gather_ix[b] * slot + (size_t)b * H - KX;
+        float *dst = smem + row * PS;
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += NBATCH) {
+            float4 v[NBATCH];
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) {
+                const int k4 = min(part + 8 * (i0 + i), K4 - 1);
+                v[i] = *reinterpret_cast<const float4 *>((k4 < kx4 ? xrow : hrow) + k4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NBATCH; ++i) {
+                const int k4 = part + 8 * (i0 + i);
+                if (i0 + i < NI && k4 < K4) *reinterpret_cast<float4 *>(dst + k4 * 4) = v[i];
+            }
+        }
+    }
+    __syncthreads();
+    const float *sA0 = smem + (lane & 15) * PS + (lane >> 4) * 4;
+    const float *sA1 = sA0 + 16 * PS;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    float4 a0 = *reinterpret_cast<const float4 *>(sA0), a1 = *reinterpret_cast<const float4 *>(sA1);
+#pragma unroll
+    for (int s = 0; s < NKB; ++s) {
+        const float4 bfr = wq[s % R];
+        if (s + R < NKB) wq[s % R] = wp[(size_t)(s + R) * 64];
+        float4 n0 = a0, n1 = a1;
+        if (s + 1 < NKB) {
+            n0 = *reinterpret_cast<const float4 *>(sA0 + (s + 1) * 16);
+            n1 = *reinterpret_cast<const float4 *>(sA1 + (s + 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a0, j), vget(bfr, j), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a1, j), vget(bfr, j), acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0;
+        a1 = n1;
+    }
+    __syncthreads();  // every wave is done reading the staged rows: the buffer becomes the gate exchange [4][32][17]
+    float *sG = smem;
+    {
+        const int col = lane & 15, rq = 4 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sG[(wv * MR + rq + q) * 17 + col] = acc0[q];
+            sG[(wv * MR + 16 + rq + q) * 17 + col] = acc1[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = tid + 256 * q, row = p >> 4, u = p & 15;
+        const int b = r0 + row;
+        if (b >= a.B) continue;
+        const int unit = tile * 16 + u;
+        const float gi = sG[(0 * MR + row) * 17 + u] + a.bias[4 * unit + 0];
+        const float gf = sG[(1 * MR + row) * 17 + u] + a.bias[4 * unit + 1];
+        const float gg = sG[(2 * MR + row) * 17 + u] + a.bias[4 * unit + 2];
+        const float go = sG[(3 * MR + row) * 17 + u] + a.bias[4 * unit + 3];
+        const float cn = sigmoidf_(gf) * c_prev[q] + sigmoidf_(gi) * tanhf(gg);
+        const float hn = sigmoidf_(go) * tanhf(cn);
+        bool reset = false;
+        if (a.search_len && a.horizon > 0) reset = (a.search_len[b] % a.horizon) == 0;  // mcts_ctree.py:859-863
+        a.h_out[(size_t)b * H + unit] = reset ? 0.0f : hn;
+        a.c_out[(size_t)b * H + unit] = reset ? 0.0f : cn;
+        a.hbn_out[(size_t)b * H + unit] = a.bn_scale ? fmaxf(hn * a.bn_scale[unit] + a.bn_shift[unit], 0.0f) : hn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // heads.  grid = (ceil(B/4), nheads), block = 256: four roots share every weight fetch.
 // ------------------------------------------------------------------------------------------------
 constexpr int EPB = 4;
@@ -1132,8 +1240,37 @@ static void launch_lstm_m(const lz_lstm_args &a, hipStream_t s)
     else if (nchunk == 4) hipLaunchKernelGGL((k_lstm<4, MROWS>), grid, block, lds, s, a);    // latent 128 + hidden 128
 }
 
+void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out)
+{
+    const int NKB = K / 16;
+    for (int t = 0; t < H / 16; ++t)
+        for (int g = 0; g < 4; ++g)
+            for (int kb = 0; kb < NKB; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = lane & 15, kq = lane >> 4;
+                        out[((((size_t)(t * 4 + g) * NKB + kb) * 64) + lane) * 4 + j] =
+                            wcat[(size_t)(4 * (16 * t + n) + g) * K + 16 * kb + 4 * kq + j];
+                    }
+}
+
+static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
+{
+    static const char *off = getenv("LZ_LSTM_CHUNKED");
+    if (off || !a.wf || (a.H & 15) || (a.KX & 15)) return false;
+    const int nkb = (a.KX + a.H) / 16;
+    dim3 grid(a.H / 16, (a.B + 31) / 32), block(256);
+    const size_t lds = (size_t)32 * ((size_t)nkb * 16 + 4) * 4;
+    if (nkb == 68) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)
+    else if (nkb == 48) hipLaunchKernelGGL((k_lstm2<48>), grid, block, lds, s, a);  // 256 + 512 (MLP models)
+    else if (nkb == 16) hipLaunchKernelGGL((k_lstm2<16>), grid, block, lds, s, a);  // 128 + 128
+    else return false;
+    return true;
+}
+
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
 {
+    if (launch_lstm2(a, s)) return;
     // 32-row tiles double the workgroup count (two resident per CU: one's chunk barrier overlaps the other's
     // MFMAs) while the batch is small; 64-row tiles halve the operand traffic once there are enough rows
     static const char *force = getenv("LZ_DEBUG_LSTM_ROWS");

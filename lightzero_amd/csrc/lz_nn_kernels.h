@@ -88,6 +88,8 @@ struct lz_lstm_args {
     const float *h_pool, *c_pool;  // pools [NN][B][H]; row b read from slot gather_ix[b]
     const int32_t *gather_ix;      // [B]
     const float *wcat;       // [4H][KX+H], row n = 4*unit + gate (gate order i,f,g,o)
+    const float *wf;         // the same matrix in MFMA-fragment order [H/16][4 gates][(KX+H)/16][64 lanes][4] (lz_lstm_pack_fragments);
+                             // null => only the chunked kernel can run
     const float *bias;       // [4H] same order (b_ih + b_hh)
     const float *bn_scale, *bn_shift;  // [H]; null => hbn_out = h' (no norm / activation)
     const int32_t *search_len;  // [B] (reset when search_len % horizon == 0); may be null => no reset
@@ -97,6 +99,8 @@ struct lz_lstm_args {
     int B, KX, H;
 };
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s);
+// host: wcat [4H][K] (row 4*unit + gate) -> fragment order for lz_lstm_args::wf (4*H*K floats)
+void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out);
 
 // heads: Linear + BN + ReLU -> Linear [-> softmax.support -> h^-1].  Input element k of root b is read at
 //   in[b * env_stride + (k / 16) * pix_stride + k % 16]   (k = pixel*16 + channel for the conv heads).

@@ -193,6 +193,11 @@ extern "C" int lz_model_finalize(lz_engine *e)
                 }
             m->lstm_w = b.upload(wc);
             m->lstm_b = b.upload(bc);
+            if (K % 16 == 0 && H % 16 == 0) {
+                std::vector<float> wf(wc.size());
+                lz_lstm_pack_fragments(wc.data(), H, K, wf.data());
+                m->lstm_wf = b.upload(wf);
+            }
         }
         std::vector<float> sc, sh;
         b.bn(d + "norm_value_prefix", H, sc, sh);
@@ -555,7 +560,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     }
     // ---- value prefix LSTM (+ BN1d + ReLU), then the three head MLPs with h^-1 fused
     lz_lstm_args l{};
-    l.x = r->t_rx; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = m->lstm_w; l.bias = m->lstm_b;
+    l.x = r->t_rx; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = m->lstm_w; l.wf = m->lstm_wf; l.bias = m->lstm_b;
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
