@@ -5,6 +5,8 @@
 // sampled_efficientzero_model_mlp.py), DynamicsNetwork (muzero_model_mlp.py:340-442), DynamicsNetworkMLP
 // (efficientzero_model_mlp.py) and ReparameterizationHead, with eval-mode BatchNorm1d / LayerNorm, ReLU / GELU(tanh),
 // the residual connection of the dynamics network and InverseScalarTransform (scaling_transform.py:82-92) in the epilogue.
+#include <algorithm>
+
 #include "lz_nn_kernels.h"
 
 namespace {
@@ -24,86 +26,141 @@ __device__ __forceinline__ float red_max(float v)
     return v;
 }
 
-// grid = (ceil(B/16), njobs), block = 1024: 16 waves; wave w owns the 16-column tiles w, w+16, ... in the GEMM and row w
-// in the epilogue.  These layers are tiny (<= 0.6 MB of weights, 16 rows): a launch costs a handful of dependent memory
-// round trips, not arithmetic.  So everything that does not depend on the GEMM is requested in the first instructions --
-// the wave's first 16-k-block chunk of weight fragments (64 VGPRs), the input rows, the residual row, and the epilogue
-// vectors (bias / BN / LN) -- and is in flight together; the four waves of a SIMD cover each other's later waits.
-constexpr int KCH = 16;   // k-blocks (of 16) per chunk
-constexpr int XPT = 8;    // staged input elements per thread: 16 * Kp <= 1024 * XPT  (Kp <= 512)
-constexpr int RPT = 10;   // residual / output columns per lane: N <= 64 * RPT
+__device__ __forceinline__ float red16_sum(float v)  // over the 16 lanes that share a row while staging
+{
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+// GELU(approximate='tanh') with tanh(y) = 1 - 2 / (1 + e^{2y}) on the hardware exp / rcp (a libm tanhf is ~60 instructions
+// with range branches; these kernels are a few thousand instructions in total).  |error| < 3e-7 absolute.
+__device__ __forceinline__ float gelu_tanh(float u)
+{
+    const float y = 0.7978845608028654f * (u + 0.044715f * u * u * u);
+    const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * y));
+    return 0.5f * u * (1.0f + t);
+}
+// branch-free: relu / gelu / identity selected with v_cndmask
+__device__ __forceinline__ float act_fn(float u, int act)
+{
+    const float r = fmaxf(u, 0.0f), g = gelu_tanh(u);
+    return act == 1 ? r : (act == 2 ? g : u);
+}
 
-__global__ __launch_bounds__(1024) void k_dense(lz_dense_args a)
+constexpr int KCH = 16;  // k-blocks (of 16) per weight chunk held in registers
+
+// grid = (ceil(B/16), ceil(Np/64), njobs), block = 256: wave w owns the 16-column tile 4 * blockIdx.y + w.
+// MAXV = float4 per lane while staging a row (16 lanes per row): 4 covers K1 <= 256, 10 covers K1 <= 640.
+// XF = some job of the launch carries a deferred transform (otherwise the gamma / beta / residual loads are not even issued).
+template <int MAXV, bool XF>
+__global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const lz_dense_job &j = a.job[blockIdx.y];
+    const lz_dense_job &j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r0 = blockIdx.x * 16, B = a.B;
-    const int K1 = j.K1, K = j.K1 + j.K2, Kp = (K + 15) & ~15, PS = Kp + 4;
-    const int N = j.N, Np = (N + 15) & ~15, NPS = Np + 4;
-    const int KB = Kp >> 4, NT = Np >> 4;
-    float *sX = smem;              // [16][PS]
-    float *sY = sX + 16 * PS;      // [16][NPS]
-    float *sP = sY + 16 * NPS;     // [5][Np]: bias, scale, shift, ln_g, ln_b
-    const f32x4 *wf4 = reinterpret_cast<const f32x4 *>(j.wf);
-    // ---- (1) first weight chunk of this wave
+    const int K1 = j.K1, K = j.K1 + j.K2, Kp = (K + 15) & ~15, PS = Kp + 4, KB = Kp >> 4;
+    const int N = j.N, NT = (N + 15) >> 4;
+    if ((int)blockIdx.y * 4 >= NT) return;  // jobs of one launch differ in width
+    const int ct = blockIdx.y * 4 + wv;     // this wave's column tile (may be past the end: the wave then only helps staging)
+    float *sX = smem;                       // [16][PS]
+    // ---- first weight chunk: in flight while the input rows are staged
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(j.wf) + (size_t)min(ct, NT - 1) * KB * 64 + lane;
     f32x4 bf[KCH];
-    int t = wv, k0 = 0;
+#pragma unroll
+    for (int q = 0; q < KCH; ++q) bf[q] = wp[(size_t)min(q, KB - 1) * 64];
+    // ---- stage 16 input rows: 16 lanes per row (same wavefront), producer's LayerNorm / activation / residual on the fly.
+    // Every global load of the pass is issued before anything is consumed (straight-line, float4 granularity): a loop of
+    // load -> use iterations would pay one memory round trip per element.
     {
-        const f32x4 *p = wf4 + (size_t)min(t, NT - 1) * KB * 64 + lane;
+        const int row = tid >> 4, part = tid & 15;
+        const int b = min(r0 + row, B - 1);
+        const float *src = j.x + (j.x_gather ? (size_t)j.x_gather[b] * (size_t)j.x_slot_stride : 0) + (size_t)b * K1;
+        float *dst = sX + row * PS;
+        if ((K1 & 3) == 0) {
+            // unconditional, clamped loads (a predicated load makes the compiler branch around it and drain the load queue);
+            // absent transforms read the row itself as a dummy and are switched off with selects
+            const int nv = K1 >> 2;
+            const bool has_ln = j.in_ln_g != nullptr, has_res = j.in_res != nullptr;
+            const float *gp = has_ln ? j.in_ln_g : src, *bp = has_ln ? j.in_ln_b : src;
+            const float *rp = has_res ? j.in_res + (j.in_res_gather ? (size_t)j.in_res_gather[b] * (size_t)j.in_res_slot_stride : 0) + (size_t)b * K1 : src;
+            f32x4 xv[MAXV], gv[XF ? MAXV : 1], bv[XF ? MAXV : 1], rv[XF ? MAXV : 1];
 #pragma unroll
-        for (int q = 0; q < KCH; ++q) bf[q] = p[(size_t)min(q, KB - 1) * 64];
-    }
-    // ---- (2) epilogue vectors, residual row (row = wave), input rows
-    float pv[5] = {0.f, 1.f, 0.f, 1.f, 0.f};
-    if (tid < N) {
-        pv[0] = j.bias[tid];
-        if (j.scale) { pv[1] = j.scale[tid]; pv[2] = j.shift[tid]; }
-        if (j.ln_g) { pv[3] = j.ln_g[tid]; pv[4] = j.ln_b[tid]; }
-    }
-    const int brow = min(r0 + wv, B - 1);
-    float rres[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) rres[i] = 0.0f;
-    if (j.res) {
-        const size_t rbase = (j.res_gather ? (size_t)j.res_gather[brow] * (size_t)j.res_slot_stride : 0) + (size_t)brow * N;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) if (lane + 64 * i < N) rres[i] = j.res[rbase + lane + 64 * i];
-    }
-    float xv[XPT];
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-        const int e = tid + 1024 * i;
-        xv[i] = 0.0f;
-        if (e < 16 * Kp) {
-            const int row = e / Kp, k = e - row * Kp;
-            const int b = min(r0 + row, B - 1);
-            if (k < K1) {
-                const size_t base = j.x_gather ? (size_t)j.x_gather[b] * (size_t)j.x_slot_stride : 0;
-                xv[i] = j.x[base + (size_t)b * K1 + k];
-            } else if (k < K) {
-                const int kk = k - K1;
-                if (j.x2_mode == 1) xv[i] = j.x2[(size_t)b * j.K2 + kk];
-                else if (j.x2_mode == 2) xv[i] = (j.x2_idx[b] == kk) ? 1.0f : 0.0f;
-                else xv[i] = (float)j.x2_idx[b] / j.x2_div;
+            for (int i = 0; i < MAXV; ++i) {
+                const int ic = 4 * min(part + 16 * i, nv - 1);
+                xv[i] = *reinterpret_cast<const f32x4 *>(src + ic);
+                if constexpr (XF) {
+                    gv[i] = *reinterpret_cast<const f32x4 *>(gp + ic);
+                    bv[i] = *reinterpret_cast<const f32x4 *>(bp + ic);
+                    rv[i] = *reinterpret_cast<const f32x4 *>(rp + ic);
+                }
             }
+            if constexpr (!XF) {
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int idx = part + 16 * i;
+                    if (idx < nv) *reinterpret_cast<f32x4 *>(dst + 4 * idx) = xv[i];
+                }
+            } else {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const float s4 = (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+                sum += (part + 16 * i < nv) ? s4 : 0.0f;
+            }
+            const float mean_ln = red16_sum(sum) / (float)K1;
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                float q4 = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float d = xv[i][q] - mean_ln; q4 += d * d; }
+                sq += (part + 16 * i < nv) ? q4 : 0.0f;
+            }
+            const float rstd_ln = 1.0f / sqrtf(red16_sum(sq) / (float)K1 + j.in_ln_eps);
+            const float mean = has_ln ? mean_ln : 0.0f, rstd = has_ln ? rstd_ln : 1.0f;
+            const bool wr = j.in_out && blockIdx.y == 0 && r0 + row < B;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int idx = part + 16 * i;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float u = (xv[i][q] - mean) * rstd;
+                    u = has_ln ? u * gv[i][q] + bv[i][q] : u;
+                    u = act_fn(u, j.in_act);
+                    u += has_res ? rv[i][q] : 0.0f;
+                    v[q] = u;
+                }
+                if (idx < nv) {
+                    *reinterpret_cast<f32x4 *>(dst + 4 * idx) = v;
+                    if (wr) *reinterpret_cast<f32x4 *>(j.in_out + (size_t)(r0 + row) * K1 + 4 * idx) = v;
+                }
+            }
+            }
+        } else {  // tiny odd widths (raw observations): no transform is ever attached to them
+            for (int k = part; k < K1; k += 16) dst[k] = src[k];
+        }
+        for (int k = K1 + part; k < Kp; k += 16) {
+            float v = 0.0f;
+            if (k < K) {
+                const int kk = k - K1;
+                if (j.x2_mode == 1) v = j.x2[(size_t)b * j.K2 + kk];
+                else if (j.x2_mode == 2) v = (j.x2_idx[b] == kk) ? 1.0f : 0.0f;
+                else v = (float)j.x2_idx[b] / j.x2_div;
+            }
+            dst[k] = v;
         }
     }
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-        const int e = tid + 1024 * i;
-        if (e < 16 * Kp) { const int row = e / Kp, k = e - row * Kp; sX[row * PS + k] = xv[i]; }
-    }
-    if (tid < N) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) sP[q * Np + tid] = pv[q];
-    }
     __syncthreads();
-    // ---- (3) GEMM
+    if (ct >= NT) return;
+    // ---- GEMM: one 16 x 16 tile per wave
     const float *sAf = sX + (lane & 15) * PS + (lane >> 4) * 4;
-    const int col = lane & 15, rq = 4 * (lane >> 4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    while (t < NT) {
+    for (int k0 = 0; k0 < KB; k0 += KCH) {
+        if (k0 > 0) {
+#pragma unroll
+            for (int q = 0; q < KCH; ++q) bf[q] = wp[(size_t)min(k0 + q, KB - 1) * 64];
+        }
 #pragma unroll
         for (int q = 0; q < KCH; ++q) {
             if (k0 + q < KB) {
@@ -112,84 +169,45 @@ __global__ __launch_bounds__(1024) void k_dense(lz_dense_args a)
                 for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[q][i], acc, 0, 0, 0);
             }
         }
-        k0 += KCH;
-        if (k0 >= KB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sY[(rq + q) * NPS + t * 16 + col] = acc[q];
-            acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            k0 = 0;
-            t += 16;
-        }
-        if (t < NT) {
-            const f32x4 *p = wf4 + (size_t)t * KB * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < KCH; ++q) bf[q] = p[(size_t)min(k0 + q, KB - 1) * 64];
-        }
     }
-    __syncthreads();
-    // ---- (4) row epilogue: one wave per row
-    const int b = r0 + wv;
-    const bool live = b < B;
-    float *y = sY + wv * NPS;
-    float v[RPT];
-    float sum = 0.0f;
+    // ---- epilogue: bias (+ BN) (+ activation when nothing is deferred) (+ the reparameterisation head's transforms)
+    const int n = ct * 16 + (lane & 15);
+    if (n >= N) return;
+    const float bias = j.bias[n];
+    const float sc = j.scale ? j.scale[n] : 1.0f, sh = j.scale ? j.shift[n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = 0.0f;
-        if (c < N) {
-            v[i] = (y[c] + sP[c]) * sP[Np + c] + sP[2 * Np + c];
-            sum += v[i];
+    for (int q = 0; q < 4; ++q) {
+        const int b = r0 + 4 * (lane >> 4) + q;
+        if (b >= B) continue;
+        float u = act_fn((acc[q] + bias) * sc + sh, j.act);
+        if (j.final == 2) {
+            if (n >= j.final_split) u = expf(fminf(fmaxf(u, -20.0f), 2.0f));
+            else if (j.final_tanh) u = tanhf(u);
         }
+        j.out[(size_t)b * N + n] = u;
     }
-    if (j.ln_g) {
-        const float mean = red_sum(sum) / (float)N;
-        float sq = 0.0f;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) if (lane + 64 * i < N) { const float d = v[i] - mean; sq += d * d; }
-        const float rstd = 1.0f / sqrtf(red_sum(sq) / (float)N + j.ln_eps);
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int c = lane + 64 * i;
-            if (c < N) v[i] = (v[i] - mean) * rstd * sP[3 * Np + c] + sP[4 * Np + c];
-        }
-    }
+}
+
+// grid = (ceil(B/4), njobs), block = 256: one wave per row
+__global__ __launch_bounds__(256) void k_rowfinal(lz_rowfinal_args a)
+{
+    const lz_rowfinal_job &j = a.job[blockIdx.y];
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const int N = j.N;
+    const float *y = j.logits + (size_t)b * N;
     float mx = -__builtin_inff();
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int c = lane + 64 * i;
-        if (c < N) {
-            float u = v[i];
-            if (j.act == 1) u = fmaxf(u, 0.0f);
-            else if (j.act == 2) u = 0.5f * u * (1.0f + tanhf(0.7978845608028654f * (u + 0.044715f * u * u * u)));
-            u += rres[i];
-            if (j.final == 2) {
-                if (c >= j.final_split) u = expf(fminf(fmaxf(u, -20.0f), 2.0f));
-                else if (j.final_tanh) u = tanhf(u);
-            }
-            v[i] = u;
-            mx = fmaxf(mx, u);
-            if (live) {
-                if (j.out) j.out[(size_t)b * N + c] = u;
-                if (j.out2) j.out2[(size_t)b * N + c] = u;
-            }
-        }
-    }
-    if (j.final != 1) return;
+    for (int c = lane; c < N; c += 64) mx = fmaxf(mx, y[c]);
     mx = red_max(mx);
     float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int c = lane + 64 * i;
-        if (c < N) {
-            const float ex = expf(v[i] - mx);
-            s0 += ex;
-            s1 += ex * (j.support_min + (float)c);
-        }
+    for (int c = lane; c < N; c += 64) {
+        const float ex = expf(y[c] - mx);
+        s0 += ex;
+        s1 += ex * (j.support_min + (float)c);
     }
     s0 = red_sum(s0);
     s1 = red_sum(s1);
-    if (lane == 0 && live) {
+    if (lane == 0) {
         // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
         const float value = s1 / s0;
         const float eps = 0.001f;
@@ -210,10 +228,27 @@ __global__ __launch_bounds__(1024) void k_dense(lz_dense_args a)
 void lz_launch_dense(const lz_dense_args &a, hipStream_t s)
 {
     size_t lds = 0;
+    int ncg = 1;
     for (int i = 0; i < a.njobs; ++i) {
-        const int Kp = (a.job[i].K1 + a.job[i].K2 + 15) & ~15, Np = (a.job[i].N + 15) & ~15;
-        const size_t need = (size_t)(16 * (Kp + 4) + 16 * (Np + 4) + 5 * Np) * 4;
-        if (need > lds) lds = need;
+        const int Kp = (a.job[i].K1 + a.job[i].K2 + 15) & ~15, cg = (a.job[i].N + 63) / 64;
+        lds = std::max(lds, (size_t)16 * (Kp + 4) * 4);
+        ncg = std::max(ncg, cg);
     }
-    hipLaunchKernelGGL(k_dense, dim3((a.B + 15) / 16, a.njobs), dim3(1024), lds, s, a);
+    int k1max = 0;
+    for (int i = 0; i < a.njobs; ++i) k1max = std::max(k1max, a.job[i].K1);
+    bool xf = false;
+    for (int i = 0; i < a.njobs; ++i) xf = xf || a.job[i].in_ln_g || a.job[i].in_act || a.job[i].in_res || a.job[i].in_out;
+    const dim3 grid((a.B + 15) / 16, ncg, a.njobs), block(256);
+    if (k1max <= 256) {
+        if (xf) hipLaunchKernelGGL((k_dense<4, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_dense<4, false>), grid, block, lds, s, a);
+    } else {
+        if (xf) hipLaunchKernelGGL((k_dense<10, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_dense<10, false>), grid, block, lds, s, a);
+    }
+}
+
+void lz_launch_rowfinal(const lz_rowfinal_args &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rowfinal, dim3((a.B + 3) / 4, a.njobs), dim3(256), 0, s, a);
 }

@@ -171,4 +171,7 @@ void lz_stree_launch_prepare(const lz_tree_dev &t, const lz_sample_args &sa, con
 void lz_stree_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
 void lz_stree_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
                               const lz_sample_args &sa, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play, hipStream_t s);
+void lz_stree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                       const lz_sample_args &sa, int horizon, const lz_traverse_args &a, float delta,
+                                       const int32_t *d_vtp_in, hipStream_t s);
 void lz_stree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, float *d_values, hipStream_t s);

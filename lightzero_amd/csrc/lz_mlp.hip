@@ -205,6 +205,13 @@ int lz_mlp_finalize(lz_engine *e)
     for (const auto *v : {&M.rep, &M.dyn1, &M.dyn2, &M.rew, &M.common, &M.val, &M.pol})
         for (const DenseW &dw : *v)
             if (b.err.empty() && (dw.K > 512 || dw.N > 640)) b.err = "dense layer beyond the compiled limits (in_features <= 512, out_features <= 640)";
+    if (b.err.empty() && M.lstm) {
+        // the LSTM input may carry a deferred LayerNorm / activation, which only the k_lstm2 instantiations below apply
+        const std::vector<DenseW> &src = M.res ? M.dyn2 : M.dyn1;
+        const bool deferred = !src.empty() && src.back().ln_g;
+        const bool compiled = (M.L == 256 && M.H == 512) || (M.L == 128 && M.H == 128);
+        if (deferred && !compiled) b.err = "LayerNorm MLP models are compiled for (latent_state_dim, lstm_hidden_size) = (256, 512) and (128, 128)";
+    }
     if (!b.err.empty()) { lz_set_error("lz_model_finalize: %s", b.err.c_str()); return LZ_ERR_STATE; }
     int w = std::max(M.L, M.H);
     for (const auto *v : {&M.rep, &M.dyn1, &M.dyn2, &M.rew, &M.common, &M.val, &M.pol}) w = widest(*v, w);
@@ -248,19 +255,42 @@ int lz_mlp_ensure_pools(lz_roots *r)
 
 namespace {
 
-// one inference as dependency levels of dense jobs (+ the LSTM after the jobs of `lstm_level`)
+// a [B][K] activation in HBM plus the transform its consumers apply while loading it (the producer's deferred
+// LayerNorm + activation, then an optional residual); `materialise`: where one consumer writes the transformed rows
+struct Act {
+    const float *x = nullptr;
+    const int32_t *gather = nullptr;
+    int64_t slot_stride = 0;
+    int K = 0;
+    const float *ln_g = nullptr, *ln_b = nullptr;
+    int act = 0;
+    const float *res = nullptr;
+    const int32_t *res_gather = nullptr;
+    int64_t res_slot_stride = 0;
+    float *materialise = nullptr;
+};
+
+// one inference as dependency levels of dense jobs (+ row finishers, + the LSTM after the jobs of `lstm_level`)
 struct Program {
     std::vector<std::vector<lz_dense_job>> levels;
+    std::vector<std::vector<lz_rowfinal_job>> finals;
     int lstm_level = -1;
     lz_lstm_args lstm{};
-    void add(int level, const lz_dense_job &j)
+    float ln_eps = 1e-5f;
+    lz_dense_job &add(int level, const lz_dense_job &j)
     {
         if ((int)levels.size() <= level) levels.resize(level + 1);
         levels[level].push_back(j);
+        return levels[level].back();
+    }
+    void add_final(int level, const lz_rowfinal_job &j)
+    {
+        if ((int)finals.size() <= level) finals.resize(level + 1);
+        finals[level].push_back(j);
     }
     void run(int B, hipStream_t s)
     {
-        const int n = std::max((int)levels.size(), lstm_level + 1);
+        const int n = std::max(std::max((int)levels.size(), (int)finals.size()), lstm_level + 1);
         for (int l = 0; l < n; ++l) {
             if (l < (int)levels.size()) {
                 const auto &v = levels[l];
@@ -272,46 +302,82 @@ struct Program {
                     lz_launch_dense(a, s);
                 }
             }
+            if (l < (int)finals.size() && !finals[l].empty()) {
+                lz_rowfinal_args a{};
+                a.B = B;
+                a.njobs = (int)std::min<size_t>(4, finals[l].size());
+                for (int k = 0; k < a.njobs; ++k) a.job[k] = finals[l][k];
+                lz_launch_rowfinal(a, s);
+            }
             if (l == lstm_level) lz_launch_lstm(lstm, s);
         }
     }
+    // layer `w` reading `in` at `level`; returns the job (already added) -- its output activation is out_of(job, w)
+    lz_dense_job &layer(int level, const DenseW &w, Act &in, float *out)
+    {
+        lz_dense_job j{};
+        j.x = in.x; j.x_gather = in.gather; j.x_slot_stride = in.slot_stride; j.K1 = in.K;
+        j.in_ln_g = in.ln_g; j.in_ln_b = in.ln_b; j.in_ln_eps = ln_eps; j.in_act = in.act;
+        j.in_res = in.res; j.in_res_gather = in.res_gather; j.in_res_slot_stride = in.res_slot_stride;
+        j.in_out = in.materialise;
+        in.materialise = nullptr;  // one writer is enough
+        j.wf = w.wf; j.bias = w.bias; j.scale = w.scale; j.shift = w.shift; j.N = w.N;
+        j.act = w.ln_g ? 0 : w.act;  // with a LayerNorm the activation is deferred to the consumers together with it
+        j.out = out;
+        return add(level, j);
+    }
+    static Act out_of(const lz_dense_job &j, const DenseW &w)
+    {
+        Act o;
+        o.x = j.out; o.K = w.N;
+        if (w.ln_g) { o.ln_g = w.ln_g; o.ln_b = w.ln_b; o.act = w.act; }
+        return o;
+    }
+    // layers as a chain from `level`; intermediate activations alternate between t0 / t1 (the last one lands in `last_out`
+    // when given).  Returns the level of the last layer; `out` = the chain's output activation.
+    int chain(int level, const std::vector<DenseW> &layers, Act in, float *t0, float *t1, float *last_out, Act *out,
+              lz_dense_job **last_job = nullptr)
+    {
+        Act cur = in;
+        for (size_t i = 0; i < layers.size(); ++i) {
+            const bool last = i + 1 == layers.size();
+            float *dst = (last && last_out) ? last_out : ((i & 1) ? t1 : t0);
+            lz_dense_job &j = layer(level, layers[i], cur, dst);
+            if (last && last_job) *last_job = &j;
+            cur = out_of(j, layers[i]);
+            ++level;
+        }
+        if (out) *out = cur;
+        return level - 1;
+    }
 };
 
-lz_dense_job job_of(const DenseW &w, const float *x, float *out, float ln_eps)
+// prediction network on `latent`: trunk, then the value chain (-> row finisher) and the policy chain off the trunk
+// returns the level after which the value logits are complete; `value_final` = the row finisher the caller schedules
+int prediction(Program &P, int level, const lz_mlp_model &M, lz_roots *r, Act &latent, float support_min, float *out_value,
+               float *out_policy, float *value_logits, lz_rowfinal_job *value_final)
 {
-    lz_dense_job j{};
-    j.x = x; j.K1 = w.K; j.wf = w.wf; j.bias = w.bias; j.scale = w.scale; j.shift = w.shift; j.ln_g = w.ln_g; j.ln_b = w.ln_b;
-    j.ln_eps = ln_eps; j.N = w.N; j.act = w.act; j.out = out;
-    return j;
-}
-
-// appends layers[from..] as a chain starting at `level` reading `x`; intermediate activations ping-pong between t0 / t1;
-// the last layer's job is returned (already added) so that the caller can patch its outputs: returns its level
-int chain(Program &P, int level, const std::vector<DenseW> &layers, size_t from, const float *x, float *t0, float *t1, float ln_eps,
-          lz_dense_job **last)
-{
-    const float *in = x;
-    for (size_t i = from; i < layers.size(); ++i) {
-        float *out = ((i - from) & 1) ? t1 : t0;
-        P.add(level, job_of(layers[i], in, out, ln_eps));
-        *last = &P.levels[level].back();
-        in = out;
-        ++level;
+    Act pc;
+    lz_dense_job *first = nullptr;
+    // the first trunk layer may have to materialise its (transformed) input: chain() hands `latent` by value, so do layer 0 here
+    {
+        lz_dense_job &j = P.layer(level, M.common[0], latent, r->mt[4]);
+        first = &j;
+        pc = Program::out_of(j, M.common[0]);
+        (void)first;
     }
-    return level - 1;
-}
-
-void prediction(Program &P, int level, const lz_mlp_model &M, lz_roots *r, const float *latent, float ln_eps, float support_min,
-                float *out_value, float *out_policy, float *dbg_value_logits)
-{
-    lz_dense_job *last = nullptr;
-    const int lc = chain(P, level, M.common, 0, latent, r->mt[4], r->mt[5], ln_eps, &last);
-    const float *pc = last->out;
-    chain(P, lc + 1, M.val, 0, pc, r->mt[6], r->mt[7], ln_eps, &last);
-    last->out = dbg_value_logits; last->final = 1; last->support_min = support_min; last->out_scalar = out_value;
-    chain(P, lc + 1, M.pol, 0, pc, r->mt[8], r->mt[9], ln_eps, &last);
-    last->out = out_policy;
-    if (M.continuous) { last->final = 2; last->final_split = M.A; last->final_tanh = r->eng->model->cfg.bound_type == 1; }
+    int lc = level;
+    if (M.common.size() > 1) {
+        std::vector<DenseW> rest(M.common.begin() + 1, M.common.end());
+        lc = P.chain(level + 1, rest, pc, r->mt[5], r->mt[4], nullptr, &pc);
+    }
+    Act vout;
+    const int lv = P.chain(lc + 1, M.val, pc, r->mt[6], r->mt[7], value_logits, &vout);
+    value_final->logits = value_logits; value_final->N = M.SUP; value_final->support_min = support_min; value_final->out_scalar = out_value;
+    lz_dense_job *pl = nullptr;
+    P.chain(lc + 1, M.pol, pc, r->mt[8], r->mt[9], out_policy, nullptr, &pl);
+    if (M.continuous) { pl->final = 2; pl->final_split = M.A; pl->final_tanh = r->eng->model->cfg.bound_type == 1; }
+    return lv;
 }
 
 }  // namespace
@@ -325,12 +391,16 @@ int lz_mlp_initial_inference(lz_roots *r, const float *d_obs)
     if (rc != LZ_OK) return rc;
     hipStream_t s = r->eng->stream;
     const int B = r->t.B;
-    const float eps = c.ln_eps > 0 ? c.ln_eps : 1e-5f;
     Program P;
-    lz_dense_job *last = nullptr;
-    const int lr = chain(P, 0, M.rep, 0, d_obs, r->mt[0], r->mt[1], eps, &last);
-    last->out = r->latent_pool;  // slot 0
-    prediction(P, lr + 1, M, r, r->latent_pool, eps, c.support_min, r->sim_value, r->sim_logits, r->dbg_logits[0]);
+    P.ln_eps = c.ln_eps > 0 ? c.ln_eps : 1e-5f;
+    Act obs;
+    obs.x = d_obs; obs.K = M.OBS;
+    Act latent;
+    const int lr = P.chain(0, M.rep, obs, r->mt[0], r->mt[1], r->mt[2], &latent);
+    latent.materialise = r->latent_pool;  // slot 0: written by the first consumer with the encoder's final LayerNorm applied
+    lz_rowfinal_job vf{};
+    const int lvv = prediction(P, lr + 1, M, r, latent, c.support_min, r->sim_value, r->sim_logits, r->dbg_logits[0], &vf);
+    P.add_final(lvv + 1, vf);
     P.run(B, s);
     if (M.lstm) {
         LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * M.H * 4, s));
@@ -351,43 +421,59 @@ void lz_mlp_recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     const lz_tree_dev &t = r->t;
     const size_t B = t.B;
     const int slot = sim + 1;
-    const float eps = c.ln_eps > 0 ? c.ln_eps : 1e-5f;
     const size_t lat_slot = B * M.L;
     float *next_latent = r->latent_pool + (size_t)slot * lat_slot;
     if (r->trace_on) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     Program P;
-    lz_dense_job *last = nullptr;
-    // dynamics: [latent | action encoding] -> next latent (+ latent with res_connection_in_dynamics)
-    int lv = chain(P, 0, M.dyn1, 0, r->latent_pool, r->mt[0], r->mt[1], eps, &last);
+    P.ln_eps = c.ln_eps > 0 ? c.ln_eps : 1e-5f;
+    // dynamics trunk: [latent | action encoding] -> next latent (+ latent with res_connection_in_dynamics)
+    Act z;
+    z.x = r->latent_pool; z.gather = t.res_ix; z.slot_stride = (int64_t)lat_slot; z.K = M.L;
+    Act next;
+    const int lv = P.chain(0, M.dyn1, z, r->mt[0], r->mt[1], r->mt[2], &next);
     {
         lz_dense_job &first = P.levels[0][0];
-        first.x_gather = t.res_ix; first.x_slot_stride = (int64_t)lat_slot; first.K1 = M.L; first.K2 = M.ENC; first.x2_mode = M.enc_mode;
+        first.K2 = M.ENC; first.x2_mode = M.enc_mode;
         first.x2 = t.res_last_action_f; first.x2_idx = t.res_last_action; first.x2_div = (float)M.A;
     }
-    last->out = next_latent;
-    if (M.res) { last->res = r->latent_pool; last->res_gather = t.res_ix; last->res_slot_stride = (int64_t)lat_slot; }
-    const float *enc = next_latent;
-    int le = lv;
-    if (M.res) {
-        le = chain(P, lv + 1, M.dyn2, 0, next_latent, r->mt[2], r->mt[3], eps, &last);
-        enc = last->out;
+    if (M.res) { next.res = r->latent_pool; next.res_gather = t.res_ix; next.res_slot_stride = (int64_t)lat_slot; }
+    // the pool must hold the finished next latent (deferred norm / activation / residual applied): its first consumer writes
+    // it; without any deferred transform the trunk's last layer writes the pool slot itself
+    const bool deferred = next.ln_g || next.act || next.res;
+    if (deferred) next.materialise = next_latent;
+    else {
+        P.levels[lv].back().out = next_latent;
+        next.x = next_latent;
     }
+    // prediction first: it is the consumer that materialises the next latent
+    Act enc = next;
+    lz_rowfinal_job vf{};
+    const int lvv = prediction(P, lv + 1, M, r, next, c.support_min, r->sim_value + (size_t)slot * B,
+                               r->sim_logits + (size_t)slot * B * M.PA, r->dbg_logits[0], &vf);
+    enc.materialise = nullptr;
+    int le = lv;
+    if (M.res) le = P.chain(lv + 1, M.dyn2, enc, r->mt[10], r->mt[11], r->mt[3], &enc);
     // reward / value prefix
-    int lrw = le + 1;
-    const float *rin = enc;
+    Act rin = enc;
     if (M.lstm) {
         lz_lstm_args &l = P.lstm;
-        l.x = enc; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = M.lstm_w; l.wf = M.lstm_wf; l.bias = M.lstm_b;
+        l.x = enc.x; l.x_ln_g = enc.ln_g; l.x_ln_b = enc.ln_b; l.x_ln_eps = P.ln_eps; l.x_act = enc.act;
+        l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = M.lstm_w; l.wf = M.lstm_wf; l.bias = M.lstm_b;
         l.bn_scale = nullptr; l.bn_shift = nullptr; l.search_len = t.res_search_len; l.horizon = horizon;
         l.h_out = r->h_pool + (size_t)slot * B * M.H; l.c_out = r->c_pool + (size_t)slot * B * M.H; l.hbn_out = r->t_hbn;
         l.B = (int)B; l.KX = M.L; l.H = M.H;
         P.lstm_level = le;  // after the dense jobs of the level that produced `enc`
-        rin = r->t_hbn;
+        rin = Act{};
+        rin.x = r->t_hbn; rin.K = M.H;
     }
-    chain(P, lrw, M.rew, 0, rin, r->mt[10], r->mt[11], eps, &last);
-    last->out = r->dbg_logits[1]; last->final = 1; last->support_min = c.support_min; last->out_scalar = r->sim_vp + (size_t)slot * B;
-    prediction(P, lv + 1, M, r, next_latent, eps, c.support_min, r->sim_value + (size_t)slot * B,
-               r->sim_logits + (size_t)slot * B * M.PA, r->dbg_logits[0]);
+    Act rout;
+    const int lrw = P.chain(le + 1, M.rew, rin, r->mt[12], r->mt[1], r->dbg_logits[1], &rout);
+    lz_rowfinal_job rf{};
+    rf.logits = r->dbg_logits[1]; rf.N = M.SUP; rf.support_min = c.support_min; rf.out_scalar = r->sim_vp + (size_t)slot * B;
+    // both row finishers (value, value prefix / reward) share the last launch
+    const int lfin = std::max(lrw, lvv) + 1;
+    P.add_final(lfin, vf);
+    P.add_final(lfin, rf);
     P.run((int)B, s);
 }
 

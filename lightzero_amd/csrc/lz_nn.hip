@@ -880,7 +880,8 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // stores) -- the structure of k_chain's inner loop.  grid = (H/16, ceil(B/32)): blockIdx.x walks the column tiles so
 // that the workgroups sharing a weight slice sit on the same XCD (block id % 8).
 // ------------------------------------------------------------------------------------------------
-template <int NKB>
+// XV = float4 per lane of the optional input transform (8 lanes per row): KX = 32 * XV; 0 = no transform compiled in
+template <int NKB, int XV = 0>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
     constexpr int K = NKB * 16, PS = K + 4, MR = 32, R = 12;
@@ -923,6 +924,45 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
             for (int i = 0; i < NBATCH; ++i) {
                 const int k4 = part + 8 * (i0 + i);
                 if (i0 + i < NI && k4 < K4) *reinterpret_cast<float4 *>(dst + k4 * 4) = v[i];
+            }
+        }
+        if constexpr (XV > 0) {
+            // x's producer left its LayerNorm / activation to us (vector-observation models): the 8 lanes that staged the row
+            // finish it in place; float4 granularity, straight-line, every load issued before the first use
+            const bool has_ln = a.x_ln_g != nullptr;
+            const float *gp = has_ln ? a.x_ln_g : a.bias, *bp = has_ln ? a.x_ln_b : a.bias;  // dummies are valid memory
+            float4 xv[XV], gv[XV], bv[XV];
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                const int k = 4 * (part + 8 * i);
+                xv[i] = *reinterpret_cast<const float4 *>(dst + k);
+                gv[i] = *reinterpret_cast<const float4 *>(gp + k);
+                bv[i] = *reinterpret_cast<const float4 *>(bp + k);
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XV; ++i) sum += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+            sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
+            const float mean_ln = sum / (float)KX;
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                const float d0 = xv[i].x - mean_ln, d1 = xv[i].y - mean_ln, d2 = xv[i].z - mean_ln, d3 = xv[i].w - mean_ln;
+                sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 1);
+            const float mean = has_ln ? mean_ln : 0.0f, rstd = has_ln ? 1.0f / sqrtf(sq / (float)KX + a.x_ln_eps) : 1.0f;
+            auto fin = [&](float u, float g, float be) {
+                u = (u - mean) * rstd;
+                u = has_ln ? u * g + be : u;
+                const float y = 0.7978845608028654f * (u + 0.044715f * u * u * u);
+                const float gl = 0.5f * u * (2.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * y)));  // GELU(tanh), hardware exp / rcp
+                return a.x_act == 1 ? fmaxf(u, 0.0f) : (a.x_act == 2 ? gl : u);
+            };
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                *reinterpret_cast<float4 *>(dst + 4 * (part + 8 * i)) =
+                    make_float4(fin(xv[i].x, gv[i].x, bv[i].x), fin(xv[i].y, gv[i].y, bv[i].y), fin(xv[i].z, gv[i].z, bv[i].z), fin(xv[i].w, gv[i].w, bv[i].w));
             }
         }
     }
@@ -1257,14 +1297,20 @@ void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out)
 static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
 {
     static const char *off = getenv("LZ_LSTM_CHUNKED");
-    if (off || !a.wf || (a.H & 15) || (a.KX & 15)) return false;
+    if (!a.wf || (a.H & 15) || (a.KX & 15)) return false;
+    if (off && !a.x_ln_g && !a.x_act) return false;  // the chunked kernel has no input transform
     const int nkb = (a.KX + a.H) / 16;
     dim3 grid(a.H / 16, (a.B + 31) / 32), block(256);
     const size_t lds = (size_t)32 * ((size_t)nkb * 16 + 4) * 4;
-    if (nkb == 68) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)
-    else if (nkb == 48) hipLaunchKernelGGL((k_lstm2<48>), grid, block, lds, s, a);  // 256 + 512 (MLP models)
-    else if (nkb == 16) hipLaunchKernelGGL((k_lstm2<16>), grid, block, lds, s, a);  // 128 + 128
-    else return false;
+    const bool xf = a.x_ln_g || a.x_act;
+    if (nkb == 68 && !xf) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)
+    else if (nkb == 48 && a.KX == 256) {                                                    // 256 + 512 (MLP models)
+        if (xf) hipLaunchKernelGGL((k_lstm2<48, 8>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_lstm2<48>), grid, block, lds, s, a);
+    } else if (nkb == 16 && a.KX == 128) {                                                  // 128 + 128
+        if (xf) hipLaunchKernelGGL((k_lstm2<16, 4>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_lstm2<16>), grid, block, lds, s, a);
+    } else return false;
     return true;
 }
 

@@ -85,6 +85,9 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s);
 //   gates = [x | h] . Wcat^T + bias ; c' = sig(f) c + sig(i) tanh(g) ; h' = sig(o) tanh(c')
 struct lz_lstm_args {
     const float *x;          // [B][KX]
+    const float *x_ln_g, *x_ln_b;  // optional deferred LayerNorm + activation of x's producer, applied while staging (k_lstm2 only)
+    float x_ln_eps;
+    int x_act;               // 0 none, 1 ReLU, 2 GELU(tanh)
     const float *h_pool, *c_pool;  // pools [NN][B][H]; row b read from slot gather_ix[b]
     const int32_t *gather_ix;      // [B]
     const float *wcat;       // [4H][KX+H], row n = 4*unit + gate (gate order i,f,g,o)
@@ -117,36 +120,52 @@ struct lz_head_desc {
 };
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s);
 
-// Dense layer for the vector-observation (MLP) model family:
-//   y = [act]( [LN | BN]( [x | x2] . W^T + bias ) ) [+ residual]     (+ optional final transform)
-// One workgroup owns 16 rows x all N columns (so LayerNorm / softmax run in the epilogue); up to 4 independent layers
-// (jobs) share a launch (blockIdx.y = job).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
+// Dense layer for the vector-observation (MLP) model family, split over the chip in both dimensions:
+//   out = epilogue( T(x) . W^T + bias ),   T = the PRODUCER's deferred LayerNorm / activation / residual, applied on load
+// A workgroup owns 16 rows x 64 columns (4 waves x one 16-column MFMA tile), so a 256 x 256 layer at B = 256 is 64
+// workgroups that each pull 64 KB of weights (a workgroup that owned whole rows would pull the entire matrix through one
+// CU at ~10 B/clk: 13 us per layer, measured).  LayerNorm needs whole rows, so a layer with a LayerNorm stores its raw
+// output and its consumers normalise while they stage their input; one consumer can also write the transformed rows
+// back (the next latent state of the pool).  Up to 4 independent layers per launch (blockIdx.z).
 struct lz_dense_job {
-    const float *x;            // [B][K1], or a pool base when x_gather != null (row b from slot x_gather[b])
+    const float *x;            // [B][K1] raw rows, or a pool base when x_gather != null (row b from slot x_gather[b])
     const int32_t *x_gather;
     int64_t x_slot_stride;
+    int K1;
+    const float *in_ln_g, *in_ln_b;  // deferred LayerNorm of the producer over the K1 columns (null: none)
+    float in_ln_eps;
+    int in_act;                // deferred activation of the producer: 0 none, 1 ReLU, 2 GELU(tanh)
+    const float *in_res;       // residual rows [B][K1] added after the activation (a pool base with in_res_gather)
+    const int32_t *in_res_gather;
+    int64_t in_res_slot_stride;
+    float *in_out;             // optional: the transformed rows, written by the column-group-0 workgroups ([B][K1])
     const float *x2;           // second input block (the action encoding); mode 1: float rows [B][K2]
     const int32_t *x2_idx;     // mode 2: one-hot(x2_idx[b]) of width K2 ; mode 3: the scalar x2_idx[b] / x2_div
     float x2_div;
-    int K1, K2, x2_mode;
+    int K2, x2_mode;
     const float *wf;           // MFMA-fragment order [Np/16][Kp/16][64 lanes][4]: lane (n = l%16, g = l/16) holds W[n0+n][k0+4g..4g+3]
     const float *bias;         // [N]
     const float *scale, *shift;  // optional [N] folded eval-mode BatchNorm1d
-    const float *ln_g, *ln_b;  // optional [N] LayerNorm affine
-    float ln_eps;
-    int N, act;                // act: 0 none, 1 ReLU, 2 GELU(tanh)
-    const float *res;          // optional residual rows [B][N] (a pool base with res_gather)
-    const int32_t *res_gather;
-    int64_t res_slot_stride;
-    float *out, *out2;         // [B][N] each, either may be null
-    int final;                 // 0 none ; 1 softmax . support -> h^-1 -> out_scalar[B] ; 2 columns >= final_split: exp(clamp(v, -20, 2)),
-                               //   columns < final_split: tanh when final_tanh
+    int N, act;                // act: applied here only when this layer has no LayerNorm (otherwise deferred to the consumers)
+    int final;                 // 2: columns >= final_split: exp(clamp(v, -20, 2)), columns < final_split: tanh when final_tanh
     int final_split, final_tanh;
-    float support_min;
-    float *out_scalar;
+    float *out;                // [B][N]
 };
 struct lz_dense_args {
     lz_dense_job job[4];
     int njobs, B;
 };
 void lz_launch_dense(const lz_dense_args &a, hipStream_t s);
+
+// row finisher: softmax(logits) . support -> InverseScalarTransform (scaling_transform.py:82-92), one wave per row
+struct lz_rowfinal_job {
+    const float *logits;       // [B][N]
+    int N;
+    float support_min;
+    float *out_scalar;         // [B]
+};
+struct lz_rowfinal_args {
+    lz_rowfinal_job job[4];
+    int njobs, B;
+};
+void lz_launch_rowfinal(const lz_rowfinal_args &a, hipStream_t s);

@@ -583,9 +583,9 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
         // SampledEfficientZeroMCTSCtree.search (mcts_ctree_sampled.py:480-600): the leaf's K actions are drawn on the
         // device from the (mu | sigma) the network just produced (or copied from the injected draws of a parity run)
         const size_t KD = (size_t)t.A * t.D;
+        ta.counter = 0;
+        lz_stree_launch_traverse(t, ta, delta, r->d_to_play, s);
         for (int sim = 0; sim < num_simulations; ++sim) {
-            ta.counter = (uint32_t)sim;
-            lz_stree_launch_traverse(t, ta, delta, r->d_to_play, s);
             recurrent(r, sim, horizon, s);
             const int slot = sim + 1;
             lz_sample_args sa;
@@ -593,8 +593,13 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
             sa.policy = r->sim_logits + (size_t)slot * B * A;
             sa.seed = r->seed;
             sa.counter = (uint32_t)slot;
-            lz_stree_launch_backprop(t, slot, ta.discount, r->sim_vp + (size_t)slot * B, r->sim_value + (size_t)slot * B, sa, nullptr, horizon,
-                                     nullptr, s);
+            const float *vp = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B;
+            if (sim + 1 < num_simulations) {
+                ta.counter = (uint32_t)(sim + 1);
+                lz_stree_launch_backprop_traverse(t, slot, ta.discount, vp, val, sa, horizon, ta, delta, r->d_to_play, s);
+            } else {
+                lz_stree_launch_backprop(t, slot, ta.discount, vp, val, sa, nullptr, horizon, nullptr, s);
+            }
         }
         return;
     }

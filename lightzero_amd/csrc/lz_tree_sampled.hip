@@ -302,6 +302,20 @@ __global__ __launch_bounds__(64) void k_sbackprop(lz_tree_dev t, int new_node, f
     dev_sbackprop(t, new_node, discount, vps, values, sa, is_reset, horizon, to_play_in, s_act);
 }
 
+// expand + backup of simulation s followed by the selection of simulation s + 1 for the same root, in one launch
+__global__ __launch_bounds__(64) void k_sbackprop_straverse(lz_tree_dev t, int new_node, float discount,
+                                                            const float *__restrict__ vps, const float *__restrict__ values,
+                                                            lz_sample_args sa, int horizon, lz_traverse_args a, float delta_max,
+                                                            const int32_t *__restrict__ vtp_in)
+{
+    extern __shared__ float s_act[];
+    dev_sbackprop(t, new_node, discount, vps, values, sa, nullptr, horizon, nullptr, s_act);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dev_straverse(t, a, delta_max, vtp_in);
+}
+
 // get_children_distribution (cnode.cpp:570-590): the visit count of every legal position's (possibly shared) child
 __global__ void k_sreadout(lz_tree_dev t, int32_t *__restrict__ dist, float *__restrict__ values)
 {
@@ -329,6 +343,13 @@ void lz_stree_launch_backprop(const lz_tree_dev &t, int latent_index, float disc
 {
     hipLaunchKernelGGL(k_sbackprop, dim3(t.B), dim3(64), (size_t)t.A * t.D * 4, s, t, latent_index, discount, d_vp, d_values, sa,
                        d_is_reset, horizon, d_to_play);
+}
+void lz_stree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                       const lz_sample_args &sa, int horizon, const lz_traverse_args &a, float delta,
+                                       const int32_t *d_vtp_in, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sbackprop_straverse, dim3(t.B), dim3(64), (size_t)t.A * t.D * 4, s, t, latent_index, discount, d_vp, d_values, sa,
+                       horizon, a, delta, d_vtp_in);
 }
 void lz_stree_launch_readout(const lz_tree_dev &t, int32_t *d_dist, float *d_values, hipStream_t s)
 {
