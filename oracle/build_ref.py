@@ -5,6 +5,7 @@ repository history; oracle/_ref/ is git-ignored), the reference Cython/C++ tree 
 
     lzero/mcts/ctree/ctree_efficientzero/ez_tree.pyx  (+ lib/cnode.cpp, common_lib/cminimax.cpp)
     lzero/mcts/ctree/ctree_muzero/mz_tree.pyx         (+ lib/cnode.cpp, common_lib/cminimax.cpp)
+    lzero/mcts/ctree/ctree_sampled_efficientzero/ezs_tree.pyx, lzero/mcts/ctree/ctree_gumbel_muzero/gmz_tree.pyx
 
 exactly the way the reference's setup.py:67-96 does (cythonize, language=c++, -std=c++11), in
 two flavours:
@@ -77,6 +78,9 @@ exts = [
     Extension('lzero.mcts.ctree.ctree_sampled_efficientzero.ezs_tree',
               ['lzero/mcts/ctree/ctree_sampled_efficientzero/ezs_tree.pyx'] + (['oracle_clock.cpp'] if det else []),
               language='c++', extra_compile_args=extra, extra_link_args=(['-Wl,-Bsymbolic-functions'] if det else [])),
+    # Gumbel MuZero: deterministic by construction (every node's Gumbel vector comes from std::mt19937(0), cnode.cpp:1133-1151)
+    Extension('lzero.mcts.ctree.ctree_gumbel_muzero.gmz_tree',
+              ['lzero/mcts/ctree/ctree_gumbel_muzero/gmz_tree.pyx'], language='c++', extra_compile_args=extra),
 ]
 setup(ext_modules=cythonize(exts, language_level=3))
 """
@@ -87,7 +91,7 @@ def built(flavour):
     if not os.path.isdir(d):
         return False
     names = os.listdir(d)
-    return all(any(n.startswith(stem) and n.endswith(".so") for n in names) for stem in ("ez_tree", "mz_tree", "ezs_tree"))
+    return all(any(n.startswith(stem) and n.endswith(".so") for n in names) for stem in ("ez_tree", "mz_tree", "ezs_tree", "gmz_tree"))
 
 
 def build(force=False):
@@ -122,7 +126,7 @@ def build(force=False):
             subprocess.run(cmd, cwd=tmp, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             odir = os.path.join(OUT, flavour)
             os.makedirs(odir, exist_ok=True)
-            for sub in ("ctree_efficientzero", "ctree_muzero", "ctree_sampled_efficientzero"):
+            for sub in ("ctree_efficientzero", "ctree_muzero", "ctree_sampled_efficientzero", "ctree_gumbel_muzero"):
                 d = os.path.join(dst, "ctree", sub)
                 for n in os.listdir(d):
                     if n.endswith(".so"):
@@ -178,6 +182,24 @@ def load_sampled(flavour="det"):
         handle.oracle_set_clock.argtypes = [ctypes.c_uint64]
         handle.oracle_get_clock.restype = ctypes.c_uint64
     return mod, handle
+
+
+def load_gumbel(flavour="stock"):
+    """gmz_tree module of the reference (lzero/mcts/ctree/ctree_gumbel_muzero); None if not built."""
+    import importlib.machinery
+    import importlib.util
+    d = os.path.join(OUT, flavour)
+    if not os.path.isdir(d):
+        return None
+    cands = [n for n in os.listdir(d) if n.startswith("gmz_tree") and n.endswith(".so")]
+    if not cands:
+        return None
+    path = os.path.join(d, cands[0])
+    loader = importlib.machinery.ExtensionFileLoader("gmz_tree", path)
+    spec = importlib.util.spec_from_file_location("gmz_tree", path, loader=loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
 
 
 if __name__ == "__main__":

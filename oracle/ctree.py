@@ -15,10 +15,11 @@ _SO = os.path.join(_HERE, "libctree_oracle.so")
 
 
 _SO_S = os.path.join(_HERE, "libctree_sampled_oracle.so")
+_SO_G = os.path.join(_HERE, "libctree_gumbel_oracle.so")
 
 
 def build(force=False):
-    for so, src in ((_SO, "ctree_oracle.c"), (_SO_S, "ctree_sampled_oracle.c")):
+    for so, src in ((_SO, "ctree_oracle.c"), (_SO_S, "ctree_sampled_oracle.c"), (_SO_G, "ctree_gumbel_oracle.c")):
         srcp = os.path.join(_HERE, src)
         if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(srcp):
             subprocess.run(["make", "-C", _HERE, "-B", os.path.basename(so)], check=True, stdout=subprocess.DEVNULL)
@@ -372,3 +373,147 @@ def _make_sampled():
 
 
 ezs_tree = _make_sampled()
+
+
+# ------------------------------------------------------------------------------------------------
+# Gumbel MuZero: ctypes face of oracle/ctree_gumbel_oracle.c with the surface of
+# lzero/mcts/ctree/ctree_gumbel_muzero/gmz_tree.pyx
+# ------------------------------------------------------------------------------------------------
+_glib = None
+
+
+def glib():
+    global _glib
+    if _glib is None:
+        build()
+        L = ctypes.CDLL(_SO_G)
+        P = ctypes.c_void_p
+        ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.gtree_create.restype = P
+        L.gtree_create.argtypes = [ctypes.c_int] * 3 + [ip, ip]
+        L.gtree_destroy.argtypes = [P]
+        L.gtree_set_delta.argtypes = [P, ctypes.c_float]
+        L.gtree_prepare.argtypes = [P, ctypes.c_float, P, fp, fp, fp, ip]
+        L.gtree_traverse.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ip, ip, ip, ip, ip]
+        L.gtree_backpropagate.argtypes = [P, ctypes.c_int, ctypes.c_float, fp, fp, fp, ip]
+        L.gtree_get_distributions.argtypes = [P, ip, ip]
+        L.gtree_get_values.argtypes = [P, fp]
+        L.gtree_get_children_values.argtypes = [P, ctypes.c_float, fp]
+        L.gtree_get_policies.argtypes = [P, ctypes.c_float, fp]
+        L.gtree_get_trajectories.argtypes = [P, ip, ctypes.c_int]
+        L.gtree_generate_gumbel.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_int, fp]
+        L.gtree_considered_visits.argtypes = [ctypes.c_int, ctypes.c_int, ip]
+        L.gtree_softmax.argtypes = [fp, ctypes.c_int]
+        _glib = L
+    return _glib
+
+
+def _make_gumbel():
+    class MinMaxStatsList(object):
+        def __init__(self, num):
+            self.num = num
+            self.delta = 0.0
+
+        def set_delta(self, value_delta_max):
+            self.delta = float(value_delta_max)
+
+    class ResultsWrapper(object):
+        def __init__(self, num):
+            self.num = num
+            self.search_lens = []
+
+        def get_search_len(self):
+            return self.search_lens
+
+    class Roots(object):
+        def __init__(self, root_num, legal_actions_list, action_space_size=None, max_simulations=512):
+            self.root_num = root_num
+            self._legal = [list(map(int, l)) for l in legal_actions_list]
+            self._A = action_space_size
+            self._S = max_simulations
+            self._h = None
+
+        @property
+        def num(self):
+            return self.root_num
+
+        def _ensure(self, A):
+            if self._h is None:
+                if self._A is None:
+                    self._A = A
+                cnt = _i32([len(l) for l in self._legal])
+                flat = _i32([a for l in self._legal for a in l] or [0])
+                self._h = glib().gtree_create(self.root_num, self._A, self._S, flat, cnt)
+
+        def prepare(self, root_noise_weight, noises, value_prefix_pool, value_pool, policy_logits_pool, to_play_batch):
+            logits = _f32(policy_logits_pool)
+            self._ensure(logits.shape[1])
+            nz = _f32([x for row in noises for x in row] or [0.0])
+            glib().gtree_prepare(self._h, root_noise_weight, nz.ctypes.data, _f32(value_prefix_pool), _f32(value_pool), logits,
+                                 _i32(to_play_batch))
+
+        def prepare_no_noise(self, value_prefix_pool, value_pool, policy_logits_pool, to_play_batch):
+            logits = _f32(policy_logits_pool)
+            self._ensure(logits.shape[1])
+            glib().gtree_prepare(self._h, 0.0, None, _f32(value_prefix_pool), _f32(value_pool), logits, _i32(to_play_batch))
+
+        def get_distributions(self):
+            out = np.zeros((self.root_num, self._A), np.int32)
+            cnt = np.zeros(self.root_num, np.int32)
+            glib().gtree_get_distributions(self._h, out, cnt)
+            return [out[i, :cnt[i]].tolist() for i in range(self.root_num)]
+
+        def get_values(self):
+            out = np.zeros(self.root_num, np.float32)
+            glib().gtree_get_values(self._h, out)
+            return out.tolist()
+
+        def get_children_values(self, discount, action_space_size):
+            out = np.zeros((self.root_num, self._A), np.float32)
+            glib().gtree_get_children_values(self._h, discount, out)
+            return out.tolist()
+
+        def get_policies(self, discount, action_space_size):
+            out = np.zeros((self.root_num, self._A), np.float32)
+            glib().gtree_get_policies(self._h, discount, out)
+            return out.tolist()
+
+        def get_trajectories(self):
+            stride = self._S + 2
+            out = np.zeros((self.root_num, stride), np.int32)
+            glib().gtree_get_trajectories(self._h, out, stride)
+            return [row[:row.index(-1)] for row in out.tolist()]
+
+        def clear(self):
+            if self._h is not None:
+                glib().gtree_destroy(self._h)
+                self._h = None
+
+        def __del__(self):
+            try:
+                self.clear()
+            except Exception:
+                pass
+
+    def batch_traverse(roots, num_simulations, max_num_considered_actions, discount, results, virtual_to_play_batch):
+        B = roots.num
+        vtp = _i32(virtual_to_play_batch)
+        ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); la = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
+        glib().gtree_traverse(roots._h, int(num_simulations), int(max_num_considered_actions), discount, vtp, ix, iy, la, sl)
+        results.search_lens = sl.tolist()
+        results._roots = roots
+        return ix.tolist(), iy.tolist(), la.tolist(), vtp.tolist()
+
+    def batch_back_propagate(current_latent_state_index, discount, value_prefixs, values, policies, min_max_stats_lst, results,
+                             to_play_batch):
+        roots = results._roots
+        glib().gtree_set_delta(roots._h, min_max_stats_lst.delta)
+        glib().gtree_backpropagate(roots._h, current_latent_state_index, discount, _f32(value_prefixs), _f32(values), _f32(policies),
+                                   _i32(to_play_batch))
+
+    return types.SimpleNamespace(MinMaxStatsList=MinMaxStatsList, ResultsWrapper=ResultsWrapper, Roots=Roots,
+                                 batch_traverse=batch_traverse, batch_back_propagate=batch_back_propagate)
+
+
+gmz_tree = _make_gumbel()
