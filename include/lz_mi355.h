@@ -34,7 +34,8 @@ typedef enum lz_status {
 typedef enum lz_variant {
     LZ_TREE_EFFICIENTZERO = 0, /* lzero/mcts/ctree/ctree_efficientzero (value-prefix tree, is_reset) */
     LZ_TREE_MUZERO = 1,        /* lzero/mcts/ctree/ctree_muzero (reward tree) */
-    LZ_TREE_SAMPLED_EFFICIENTZERO = 2 /* lzero/mcts/ctree/ctree_sampled_efficientzero, continuous actions */
+    LZ_TREE_SAMPLED_EFFICIENTZERO = 2, /* lzero/mcts/ctree/ctree_sampled_efficientzero, continuous actions */
+    LZ_TREE_GUMBEL_MUZERO = 3          /* lzero/mcts/ctree/ctree_gumbel_muzero */
 } lz_variant;
 
 typedef enum lz_tiebreak {
@@ -145,6 +146,20 @@ int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records);
 int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out);
 int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
 
+
+/* Gumbel MuZero -- replaces lzero/mcts/ctree/ctree_gumbel_muzero/gmz_tree.pyx (lib/cnode.cpp): roots created with
+ * lz_roots_create(..., LZ_TREE_GUMBEL_MUZERO, ...); Roots.prepare / prepare_no_noise take the root rewards AND values
+ * (gmz_tree.pyx:36-40); batch_traverse selects with sequential halving at the root (cselect_root_child :701-745) and the
+ * completed-Q improved policy below it (cselect_interior_child :747-790); get_policies / get_children_values are
+ * CRoots::get_policies / get_children_values (:506-541).  Distributions / values / trajectories: the generic getters. */
+int lz_groots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises_flat, const float *h_rewards,
+                      const float *h_values, const float *h_policy_logits, const int32_t *h_to_play);
+int lz_gbatch_traverse(lz_roots *r, int num_simulations, int max_num_considered_actions, float discount_factor,
+                       int32_t *h_virtual_to_play, int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch,
+                       int32_t *h_out_last_actions, int32_t *h_out_search_lens);
+int lz_gbatch_back_propagate(lz_roots *r, int current_latent_state_index, float discount_factor, const float *h_rewards,
+                             const float *h_values, const float *h_policy_logits);
+int lz_groots_get_policies(lz_roots *r, float discount_factor, float *h_out_policies, float *h_out_children_values);
 
 /* ReZero (search_with_reuse, https://arxiv.org/abs/2404.16364) -- replaces batch_traverse_with_reuse /
  * batch_backpropagate_with_reuse (ez_tree.pyx:94-121, mz_tree.pyx:84-110; cnode.cpp:603-649, 697-754, 816-884, 965-1072).

@@ -6,6 +6,9 @@
 
 #include <new>
 
+#include <algorithm>
+#include <cmath>
+#include <random>
 #include <vector>
 
 #include "lz_internal.h"
@@ -116,7 +119,9 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
                  o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5),
                  o_ep = take(256), o_rep = take(D ? nBNA * 4 : 0), o_nch = take(D ? nBN * 4 : 0),
                  o_act = take(D ? nBNA * D * 4 : 0), o_laf = take(D ? (size_t)B * D * 4 : 0),
-                 o_bidx = take(nBN * 4), o_noinf = take((size_t)B * 4);
+                 o_bidx = take(nBN * 4), o_noinf = take((size_t)B * 4),
+                 o_raw = take(variant == LZ_TREE_GUMBEL_MUZERO ? nBN * 4 : 0), o_gum = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)A * 4 : 0),
+                 o_cons = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)t.NN * 4 : 0);
     hipError_t err = hipMalloc(&r->slab, off);
     if (err != hipSuccess) {
         delete r;
@@ -136,6 +141,17 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.rng_epoch = (uint32_t *)(base + o_ep);
     t.node_bidx = (int32_t *)(base + o_bidx); t.res_noinf = (int32_t *)(base + o_noinf);
     (void)hipMemset(r->slab, 0, off);  // no kernel may depend on what the allocator handed back (epoch, legal lists, results)
+    t.node_raw = nullptr; t.gumbel = nullptr; t.considered = nullptr;
+    if (variant == LZ_TREE_GUMBEL_MUZERO) {
+        t.node_raw = (float *)(base + o_raw); t.gumbel = (float *)(base + o_gum); t.considered = (int32_t *)(base + o_cons);
+        // every CNode draws its Gumbel vector from std::mt19937(gumbel_rng = 0) scaled by gumbel_scale = 10 (cnode.cpp:58-59,86-89,
+        // 1133-1151): one constant prefix, computed with the same libstdc++ distribution the reference uses
+        std::mt19937 gen(static_cast<unsigned int>(0.0f));
+        std::extreme_value_distribution<float> dist(0, 1);
+        std::vector<float> g((size_t)A);
+        for (int i = 0; i < A; ++i) g[i] = 10.0f * dist(gen);
+        (void)hipMemcpy(t.gumbel, g.data(), (size_t)A * 4, hipMemcpyHostToDevice);
+    }
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
     *out = r;
     return LZ_OK;
@@ -179,7 +195,7 @@ extern "C" int lz_roots_create(lz_engine *e, int variant, int root_num, int acti
 {
     LZ_REQUIRE(e != nullptr && out != nullptr, "engine/out is NULL");
     *out = nullptr;
-    LZ_REQUIRE(variant == LZ_TREE_EFFICIENTZERO || variant == LZ_TREE_MUZERO, "unknown tree variant");
+    LZ_REQUIRE(variant == LZ_TREE_EFFICIENTZERO || variant == LZ_TREE_MUZERO || variant == LZ_TREE_GUMBEL_MUZERO, "unknown tree variant");
     LZ_REQUIRE(root_num > 0 && action_space_size > 0 && max_simulations > 0, "root_num, action_space_size, max_simulations must be positive");
     LZ_REQUIRE(action_space_size <= 256, "action_space_size > 256 is not supported by the wave-per-root tree kernels");
     LZ_HIP_CHECK(hipSetDevice(e->device));
@@ -375,6 +391,173 @@ extern "C" int lz_batch_backpropagate(lz_roots *r, int current_latent_state_inde
                             (const float *)(d + o_lg), (const int32_t *)(d + o_rst), 0, (const int32_t *)(d + o_tp), s);
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// ---- Gumbel MuZero (gmz_tree.pyx): Roots.prepare / prepare_no_noise, batch_traverse, batch_back_propagate, get_policies,
+// get_children_values.  Create the roots with lz_roots_create(..., LZ_TREE_GUMBEL_MUZERO, ...).
+static int gumbel_check(lz_roots *r)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->t.variant == LZ_TREE_GUMBEL_MUZERO, "not a Gumbel MuZero roots handle (lz_roots_create with LZ_TREE_GUMBEL_MUZERO)");
+    return LZ_OK;
+}
+
+// get_sequence_of_considered_visits (cnode.cpp:1041-1076)
+static std::vector<int32_t> considered_visits(int max_num_considered_actions, int num_simulations)
+{
+    std::vector<int32_t> seq;
+    if (max_num_considered_actions <= 1) {
+        for (int i = 0; i < num_simulations; ++i) seq.push_back(i);
+        return seq;
+    }
+    const int log2max = (int)std::ceil(std::log2((double)max_num_considered_actions));
+    std::vector<int32_t> visits((size_t)max_num_considered_actions, 0);
+    int num_considered = max_num_considered_actions;
+    while ((int)seq.size() < num_simulations) {
+        const int num_extra = std::max(1, num_simulations / (log2max * num_considered));
+        for (int i = 0; i < num_extra; ++i) {
+            seq.insert(seq.end(), visits.begin(), visits.begin() + num_considered);
+            for (int j = 0; j < num_considered; ++j) visits[j] += 1;
+        }
+        num_considered = std::max(2, num_considered / 2);
+    }
+    seq.resize((size_t)num_simulations);
+    return seq;
+}
+
+int lz_groots_set_considered(lz_roots *r, int num_simulations, int max_num_considered_actions, hipStream_t s)
+{
+    if (r->g_sims == num_simulations && r->g_m == max_num_considered_actions) return LZ_OK;
+    if (num_simulations < 1 || num_simulations >= r->t.NN) {
+        lz_set_error("num_simulations %d exceeds the node pool (max_simulations %d)", num_simulations, r->t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    const std::vector<int32_t> seq = considered_visits(std::min(max_num_considered_actions, num_simulations), num_simulations);
+    LZ_HIP_CHECK(hipMemcpyAsync(r->t.considered, seq.data(), seq.size() * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    r->g_sims = num_simulations;
+    r->g_m = max_num_considered_actions;
+    return LZ_OK;
+}
+
+extern "C" int lz_groots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises_flat, const float *h_rewards,
+                                 const float *h_values, const float *h_policy_logits, const int32_t *h_to_play)
+{
+    int rc = gumbel_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(h_rewards && h_values && h_policy_logits && h_to_play, "NULL input");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    size_t n_noise = 0;
+    std::vector<int32_t> off(B);
+    if (h_noises_flat) {
+        std::vector<int32_t> nl(B);
+        LZ_HIP_CHECK(hipMemcpyAsync(nl.data(), t.n_legal, B * 4, hipMemcpyDeviceToHost, s));
+        LZ_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < B; ++i) { off[i] = (int32_t)n_noise; n_noise += nl[i]; }
+    }
+    const size_t o_r = 0, o_v = B * 4, o_tp = 2 * B * 4, o_off = 3 * B * 4, o_lg = 4 * B * 4, o_nz = o_lg + B * A * 4, need = o_nz + (n_noise + 1) * 4;
+    rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    memcpy(h + o_r, h_rewards, B * 4);
+    memcpy(h + o_v, h_values, B * 4);
+    memcpy(h + o_tp, h_to_play, B * 4);
+    memcpy(h + o_off, off.data(), B * 4);
+    memcpy(h + o_lg, h_policy_logits, B * A * 4);
+    if (h_noises_flat) memcpy(h + o_nz, h_noises_flat, n_noise * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, s));
+    lz_gtree_launch_prepare(t, root_noise_weight, h_noises_flat ? (const float *)(d + o_nz) : nullptr, 1, (const int32_t *)(d + o_off),
+                            (const float *)(d + o_r), (const float *)(d + o_v), (const float *)(d + o_lg), (const int32_t *)(d + o_tp), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    r->players = 1;
+    r->prepared = true;
+    r->traverse_count = 0;
+    return LZ_OK;
+}
+
+extern "C" int lz_gbatch_traverse(lz_roots *r, int num_simulations, int max_num_considered_actions, float discount_factor,
+                                  int32_t *h_virtual_to_play, int32_t *h_out_index_in_search_path, int32_t *h_out_index_in_batch,
+                                  int32_t *h_out_last_actions, int32_t *h_out_search_lens)
+{
+    int rc = gumbel_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(r->prepared, "batch_traverse before Roots.prepare");
+    LZ_REQUIRE(h_virtual_to_play && h_out_index_in_search_path && h_out_index_in_batch && h_out_last_actions && h_out_search_lens, "NULL buffer");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B;
+    for (size_t i = 0; i < B; ++i) LZ_REQUIRE(h_virtual_to_play[i] == -1, "the Gumbel MuZero tree is single-player (cnode.cpp:618)");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    rc = lz_groots_set_considered(r, num_simulations, max_num_considered_actions, s);
+    if (rc != LZ_OK) return rc;
+    rc = ensure_stage(r, B * 4 * 5);
+    if (rc != LZ_OK) return rc;
+    lz_gtree_launch_traverse(t, discount_factor, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, t.res_ix, B * 4 * 5, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    const int32_t *h = (const int32_t *)r->h_stage;
+    memcpy(h_out_index_in_search_path, h, B * 4);
+    memcpy(h_out_index_in_batch, h + B, B * 4);
+    memcpy(h_out_last_actions, h + 2 * B, B * 4);
+    memcpy(h_out_search_lens, h + 3 * B, B * 4);
+    return LZ_OK;
+}
+
+extern "C" int lz_gbatch_back_propagate(lz_roots *r, int current_latent_state_index, float discount_factor, const float *h_rewards,
+                                        const float *h_values, const float *h_policy_logits)
+{
+    int rc = gumbel_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(r->prepared, "batch_back_propagate before Roots.prepare");
+    LZ_REQUIRE(h_rewards && h_values && h_policy_logits, "NULL input");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    if (current_latent_state_index < 1 || current_latent_state_index >= t.NN) {
+        lz_set_error("current_latent_state_index %d outside the node pool [1,%d]", current_latent_state_index, t.NN - 1);
+        return LZ_ERR_STATE;
+    }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    const size_t o_r = 0, o_v = B * 4, o_lg = 2 * B * 4, need = o_lg + B * A * 4;
+    rc = ensure_stage(r, need);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
+    memcpy(h + o_r, h_rewards, B * 4);
+    memcpy(h + o_v, h_values, B * 4);
+    memcpy(h + o_lg, h_policy_logits, B * A * 4);
+    LZ_HIP_CHECK(hipMemcpyAsync(d, h, need, hipMemcpyHostToDevice, s));
+    lz_gtree_launch_backprop(t, current_latent_state_index, discount_factor, (const float *)(d + o_r), (const float *)(d + o_v),
+                             (const float *)(d + o_lg), s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// Roots.get_policies / get_children_values: [root_num][action_space_size] each; either output may be NULL
+extern "C" int lz_groots_get_policies(lz_roots *r, float discount_factor, float *h_out_policies, float *h_out_children_values)
+{
+    int rc = gumbel_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(r->prepared && (h_out_policies || h_out_children_values), "roots not prepared / no output");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    rc = ensure_stage(r, 2 * B * A * 4);
+    if (rc != LZ_OK) return rc;
+    hipStream_t s = r->eng->stream;
+    float *dp = (float *)r->d_stage, *dv = dp + B * A;
+    lz_gtree_launch_policies(t, discount_factor, h_out_policies ? dp : nullptr, h_out_children_values ? dv : nullptr, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->d_stage, 2 * B * A * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_out_policies) memcpy(h_out_policies, r->h_stage, B * A * 4);
+    if (h_out_children_values) memcpy(h_out_children_values, (float *)r->h_stage + B * A, B * A * 4);
     return LZ_OK;
 }
 

@@ -64,6 +64,10 @@ struct lz_tree_dev {
     int32_t *path_act;          // [B][NN]     action taken at path_node[k]
     int32_t *res_ix, *res_iy, *res_last_action, *res_search_len, *res_vtp;  // [B] each
     uint32_t *rng_epoch;        // [1] incremented by every prepare (stochastic tie-break stream)
+    // Gumbel MuZero (variant 3)
+    float *node_raw;            // [B][NN]     CNode::raw_value: the value head's output at the node
+    float *gumbel;              // [A]         gumbel_scale * extreme_value(mt19937(0)): the same prefix for every node (cnode.cpp:86-89)
+    int32_t *considered;        // [NN]        get_sequence_of_considered_visits(min(m, S), S) of the current search
     int32_t *node_bidx;         // [B][NN]     CNode::batch_index (== b except under ReZero's packed inference batches)
     int32_t *res_noinf;         // [B]         ReZero: the last traverse ended on an already expanded node (reference index -1)
     // Sampled EfficientZero (variant 2, continuous actions): A == K sampled actions per node
@@ -119,6 +123,7 @@ struct lz_roots {
     int32_t *d_noise_off = nullptr; // [B]
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
+    int g_sims = -1, g_m = -1;      // Gumbel MuZero: (num_simulations, max_num_considered_actions) of the uploaded visit table
     void *d_reuse = nullptr;        // ReZero fused search: true_action [B] | reuse_value [B] | per-simulation inference counts [NN]
     float *d_given = nullptr;       // Sampled-EZ parity runs: [records][B][K][D] injected draws (record 0 = roots, s + 1 = simulation s)
     int given_records = 0;
@@ -151,6 +156,17 @@ void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, fl
                                       const float *d_values, const float *d_logits, int horizon,
                                       const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s);
+// Gumbel MuZero (ctree_gumbel_muzero/lib/cnode.cpp): selection by sequential halving at the root and by the completed-Q
+// improved policy below it; expand / backup are the MuZero kernels (+ raw value), readout adds get_policies / get_children_values
+int lz_groots_set_considered(lz_roots *r, int num_simulations, int max_num_considered_actions, hipStream_t s);
+void lz_gtree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int noises_ragged, const int32_t *d_noise_off,
+                             const float *d_rewards, const float *d_values, const float *d_logits, const int32_t *d_to_play, hipStream_t s);
+void lz_gtree_launch_traverse(const lz_tree_dev &t, float discount, hipStream_t s);
+void lz_gtree_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_rewards, const float *d_values,
+                              const float *d_logits, hipStream_t s);
+void lz_gtree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_rewards,
+                                       const float *d_values, const float *d_logits, hipStream_t s);
+void lz_gtree_launch_policies(const lz_tree_dev &t, float discount, float *d_policies, float *d_children_values, hipStream_t s);
 // ReZero search_with_reuse (cnode.cpp:603-649, 697-754, 816-884, 965-1072)
 void lz_tree_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
                                    const int32_t *d_true_action, const float *d_reuse_value, hipStream_t s);

@@ -663,6 +663,261 @@ __global__ __launch_bounds__(64) void k_backprop_traverse_lds(lz_tree_dev t, int
     dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gumbel MuZero (lzero/mcts/ctree/ctree_gumbel_muzero/lib/cnode.cpp).  Lane = legal position of the current node.
+// ------------------------------------------------------------------------------------------------
+// sum of v over the lanes of `mask`, added in lane order (the reference accumulates in index order)
+__device__ __forceinline__ float ordered_add(float acc, float v, uint64_t mask)
+{
+    while (mask) {
+        const int j = __builtin_ctzll(mask);
+        acc += rl_f(v, j);
+        mask &= mask - 1;
+    }
+    return acc;
+}
+
+// csoftmax (cnode.cpp:903-928) over the first n positions: x[c] holds position c*64 + lane
+template <int NC>
+__device__ __forceinline__ void dev_csoftmax(float (&x)[NC], int n)
+{
+    const int lane = threadIdx.x;
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if (c * 64 + lane < n) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float e = lz_expf(x[c] - m);
+        sum = ordered_add(sum, e, __ballot(c * 64 + lane < n));
+    }
+    const float ls = lz_logf(sum);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) x[c] = lz_expf(x[c] - m - ls);
+}
+
+// qtransform_completed_by_mix_value (cnode.cpp:984-1037) with the header defaults (maxvisit_init 50, value_scale 0.1,
+// rescale_values, epsilon 1e-8); CNode::get_q :181-197, compute_mixed_value :930-966, rescale_qvalues :968-982
+template <int NC>
+__device__ __forceinline__ void dev_completed_q(const float (&prior)[NC], const int (&vis)[NC], const float (&q)[NC], int n, float raw_value,
+                                                float (&cq)[NC])
+{
+    const int lane = threadIdx.x;
+    float ptmp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ptmp[c] = prior[c];
+    dev_csoftmax<NC>(ptmp, n);
+    float visit_count_sum = 0.0f, probs_sum = 0.0f, weighted_q_sum = 0.0f;
+    const float min_num = -10e7f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const uint64_t valid = __ballot(c * 64 + lane < n);
+        visit_count_sum = ordered_add(visit_count_sum, (float)vis[c], valid);
+        ptmp[c] = fmaxf(ptmp[c], min_num);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) probs_sum = ordered_add(probs_sum, ptmp[c], __ballot(c * 64 + lane < n && vis[c] > 0));
+#pragma unroll
+    for (int c = 0; c < NC; ++c) weighted_q_sum = ordered_add(weighted_q_sum, ptmp[c] * q[c] / probs_sum, __ballot(c * 64 + lane < n && vis[c] > 0));
+    const float value = (raw_value + visit_count_sum * weighted_q_sum) / (visit_count_sum + 1);
+    float mx = -__builtin_inff(), mn = __builtin_inff(), max_visit = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cq[c] = vis[c] > 0 ? q[c] : value;
+        if (c * 64 + lane < n) { mx = fmaxf(mx, cq[c]); mn = fminf(mn, cq[c]); max_visit = fmaxf(max_visit, (float)vis[c]); }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    max_visit = wave_max(max_visit);
+    const float gap = fmaxf(mx - mn, 1e-8f);
+    const float visit_scale = 50.0f + max_visit;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cq[c] = (cq[c] - mn) / gap * visit_scale * 0.1f;
+}
+
+// children of `node` as seen by cselect_root_child / cselect_interior_child: prior, visit, q = reward + discount * value()
+template <int NC>
+__device__ __forceinline__ void dev_gchildren(const lz_tree_dev &t, int b, int node, int n, bool is_root, float discount, float (&prior)[NC],
+                                              int (&vis)[NC], float (&q)[NC], int (&act)[NC], int (&chd)[NC])
+{
+    const int lane = threadIdx.x, A = t.A, NN = t.NN;
+    const float4 *edge_b = t.edge + (size_t)b * NN * A;
+    const int32_t *child_b = t.child + (size_t)b * NN * A;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        const bool valid = j < n;
+        act[c] = valid ? (is_root ? t.legal[(size_t)b * A + j] : j) : 0;
+        const float4 e = valid ? edge_b[(size_t)node * A + act[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        chd[c] = valid ? child_b[(size_t)node * A + act[c]] : -1;
+        prior[c] = e.x;
+        vis[c] = __float_as_int(e.y);
+        const float val = (vis[c] == 0) ? 0.0f : e.z / (float)vis[c];
+        q[c] = e.w + discount * val;
+    }
+}
+
+// first position (legal-list order) whose score equals the wave maximum; all -inf => position 0 (cnode.cpp:724-733)
+template <int NC>
+__device__ __forceinline__ int dev_first_argmax(const float (&score)[NC])
+{
+    float best = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) best = fmaxf(best, score[c]);
+    best = wave_max(best);
+    if (!(best > -__builtin_inff())) return 0;
+    int pos = -1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const uint64_t mask = __ballot(score[c] == best);
+        if (pos < 0 && mask) pos = c * 64 + __builtin_ctzll(mask);
+    }
+    return pos;
+}
+
+// cbatch_traverse (cnode.cpp:834-897)
+template <int NC>
+__device__ __forceinline__ void dev_gtraverse(const lz_tree_dev &t, float discount)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    int node = 0, depth = 0, is_root = 1, last_action = -1;
+    for (;;) {
+        const int n = is_root ? uni(t.n_legal[b]) : A;
+        float prior[NC], q[NC], cq[NC], score[NC];
+        int vis[NC], act[NC], chd[NC];
+        dev_gchildren<NC>(t, b, node, n, is_root != 0, discount, prior, vis, q, act, chd);
+        dev_completed_q<NC>(prior, vis, q, n, t.node_raw[(size_t)b * NN + node], cq);
+        if (is_root) {
+            // cselect_root_child :701-745 + score_considered :1096-1131
+            int sim_index = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint64_t valid = __ballot(c * 64 + lane < n);
+                while (valid) { const int j = __builtin_ctzll(valid); sim_index += rl_i(vis[c], j); valid &= valid - 1; }
+            }
+            const int considered_visit = t.considered[min(sim_index, NN - 1)];
+            float max_logit = -__builtin_inff();
+#pragma unroll
+            for (int c = 0; c < NC; ++c) if (c * 64 + lane < n) max_logit = fmaxf(max_logit, prior[c]);
+            max_logit = wave_max(max_logit);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int j = c * 64 + lane;
+                const float g = t.gumbel[min(j, A - 1)];
+                const float sc = fmaxf(-1e9f, g + (prior[c] - max_logit) + cq[c]);
+                score[c] = (j < n && vis[c] == considered_visit) ? sc : -__builtin_inff();
+            }
+        } else {
+            // cselect_interior_child :747-790
+            float probs[NC];
+            int vsum = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                probs[c] = prior[c] + cq[c];
+                uint64_t valid = __ballot(c * 64 + lane < n);
+                while (valid) { const int j = __builtin_ctzll(valid); vsum += rl_i(vis[c], j); valid &= valid - 1; }
+            }
+            dev_csoftmax<NC>(probs, n);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) score[c] = (c * 64 + lane < n) ? probs[c] - (float)vis[c] / (float)(1 + vsum) : -__builtin_inff();
+        }
+        const int pos = dev_first_argmax<NC>(score);
+        int action = 0, nxt = -1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if ((pos >> 6) == c) { action = rl_i(act[c], pos & 63); nxt = rl_i(chd[c], pos & 63); }
+        is_root = 0;
+        if (lane == 0) {
+            t.node_best[(size_t)b * NN + node] = action;
+            t.path_node[(size_t)b * NN + depth] = node;
+            t.path_act[(size_t)b * NN + depth] = action;
+        }
+        last_action = action;
+        depth += 1;
+        if (nxt < 0) break;
+        node = nxt;
+    }
+    if (lane == 0) {
+        t.res_ix[b] = node;
+        t.res_iy[b] = b;
+        t.res_last_action[b] = last_action;
+        t.res_search_len[b] = depth;
+        t.res_vtp[b] = -1;
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(64) void k_gtraverse(lz_tree_dev t, float discount)
+{
+    dev_gtraverse<NC>(t, discount);
+}
+
+// cbatch_back_propagate (cnode.cpp:633-652): CNode::expand + cback_propagate == the MuZero expand / one-player backup, plus the raw value
+template <int NC, bool THEN_TRAVERSE>
+__global__ __launch_bounds__(64) void k_gbackprop(lz_tree_dev t, int new_node, float discount, const float *__restrict__ rewards,
+                                                  const float *__restrict__ values, const float *__restrict__ logits)
+{
+    const int b = blockIdx.x;
+    const tview v = global_view(t, b);
+    tscal<NC> sc;
+    load_scalars<NC>(t, b, sc);
+    leaf_in<NC, LZ_TREE_MUZERO> L;
+    load_leaf<NC, LZ_TREE_MUZERO>(t, b, rewards, values, logits, nullptr, 0, nullptr, L);
+    if (threadIdx.x == 0) t.node_raw[(size_t)b * t.NN + new_node] = L.value;
+    dev_backprop<NC, LZ_TREE_MUZERO, false>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, -1, 0);
+    if (THEN_TRAVERSE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        dev_gtraverse<NC>(t, discount);
+    }
+}
+
+// CRoots::prepare (cnode.cpp:418-455): the MuZero root expansion + raw value
+__global__ void k_graw_root(lz_tree_dev t, const float *__restrict__ values)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < t.B) t.node_raw[(size_t)b * t.NN] = values[b];
+}
+
+// CNode::get_policy :350-375 and CNode::get_children_value :309-338 of every root: [B][A] each (either may be null)
+template <int NC>
+__global__ __launch_bounds__(64) void k_gpolicies(lz_tree_dev t, float discount, float *__restrict__ policies, float *__restrict__ children_values)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, A = t.A;
+    const int n = uni(t.n_legal[b]);
+    float prior[NC], q[NC], cq[NC];
+    int vis[NC], act[NC], chd[NC];
+    dev_gchildren<NC>(t, b, 0, n, true, discount, prior, vis, q, act, chd);
+    dev_completed_q<NC>(prior, vis, q, n, t.node_raw[(size_t)b * t.NN], cq);
+    if (children_values) {
+        for (int a = lane; a < A; a += 64) children_values[(size_t)b * A + a] = -__builtin_inff();
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (c * 64 + lane < n) children_values[(size_t)b * A + act[c]] = cq[c];
+    }
+    if (policies) {
+        // probs over the whole action space: -inf for illegal actions, csoftmax over all A entries in action order
+        extern __shared__ float s_p[];
+        for (int a = lane; a < A; a += 64) s_p[a] = -__builtin_inff();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (c * 64 + lane < n) s_p[act[c]] = prior[c] + cq[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c] = (c * 64 + lane < A) ? s_p[c * 64 + lane] : -__builtin_inff();
+        dev_csoftmax<NC>(x, A);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (c * 64 + lane < A) policies[(size_t)b * A + c * 64 + lane] = x[c];
+    }
+}
+
 // bumps the RNG epoch once per prepare (stochastic tie-break streams differ between env-steps even when the
 // whole search is replayed from a captured graph with identical kernel arguments)
 __global__ void k_bump_epoch(lz_tree_dev t)
@@ -837,6 +1092,47 @@ void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float
         launch_bpreuse_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, d_infer_counter, s);
     else
         launch_bpreuse_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, d_infer_counter, s);
+}
+
+void lz_gtree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int ragged, const int32_t *d_noise_off,
+                             const float *d_rewards, const float *d_values, const float *d_logits, const int32_t *d_to_play, hipStream_t s)
+{
+    lz_tree_launch_prepare(t, noise_w, d_noises, ragged, d_noise_off, d_rewards, d_logits, d_to_play, s);
+    hipLaunchKernelGGL(k_graw_root, dim3((t.B + 255) / 256), dim3(256), 0, s, t, d_values);
+}
+void lz_gtree_launch_traverse(const lz_tree_dev &t, float discount, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL(k_gtraverse<1>, dim3(t.B), dim3(64), 0, s, t, discount); break;
+    case 2: hipLaunchKernelGGL(k_gtraverse<2>, dim3(t.B), dim3(64), 0, s, t, discount); break;
+    default: hipLaunchKernelGGL(k_gtraverse<4>, dim3(t.B), dim3(64), 0, s, t, discount); break;
+    }
+}
+void lz_gtree_launch_backprop(const lz_tree_dev &t, int idx, float discount, const float *r, const float *v, const float *lg, hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_gbackprop<1, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
+    case 2: hipLaunchKernelGGL((k_gbackprop<2, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
+    default: hipLaunchKernelGGL((k_gbackprop<4, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
+    }
+}
+void lz_gtree_launch_backprop_traverse(const lz_tree_dev &t, int idx, float discount, const float *r, const float *v, const float *lg,
+                                       hipStream_t s)
+{
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_gbackprop<1, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
+    case 2: hipLaunchKernelGGL((k_gbackprop<2, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
+    default: hipLaunchKernelGGL((k_gbackprop<4, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
+    }
+}
+void lz_gtree_launch_policies(const lz_tree_dev &t, float discount, float *d_policies, float *d_children_values, hipStream_t s)
+{
+    const size_t sh = (size_t)t.A * 4;
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL(k_gpolicies<1>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values); break;
+    case 2: hipLaunchKernelGGL(k_gpolicies<2>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values); break;
+    default: hipLaunchKernelGGL(k_gpolicies<4>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values); break;
+    }
 }
 
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s)
