@@ -160,6 +160,9 @@ int lz_gbatch_traverse(lz_roots *r, int num_simulations, int max_num_considered_
 int lz_gbatch_back_propagate(lz_roots *r, int current_latent_state_index, float discount_factor, const float *h_rewards,
                              const float *h_values, const float *h_policy_logits);
 int lz_groots_get_policies(lz_roots *r, float discount_factor, float *h_out_policies, float *h_out_children_values);
+/* GumbelMuZeroMCTSCtree.search (mcts_ctree.py:1067-1172) with an engine MuZero model, whole loop on the device; prepare the
+ * roots with lz_roots_prepare_from_inference (rewards 0, values and logits of lz_initial_inference, gumbel_muzero.py:562) */
+int lz_gsearch(lz_roots *r, int num_simulations, int max_num_considered_actions, float discount_factor);
 
 /* ReZero (search_with_reuse, https://arxiv.org/abs/2404.16364) -- replaces batch_traverse_with_reuse /
  * batch_backpropagate_with_reuse (ez_tree.pyx:94-121, mz_tree.pyx:84-110; cnode.cpp:603-649, 697-754, 816-884, 965-1072).

@@ -76,6 +76,7 @@ def lib():
         "lz_gbatch_traverse": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "lz_gbatch_back_propagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p],
         "lz_groots_get_policies": [P, ctypes.c_float, P, P],
+        "lz_gsearch": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float],
         "lz_search_with_reuse": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float, c_i32p, c_f32p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
         "lz_batch_traverse_with_reuse": [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "lz_batch_backpropagate_with_reuse": [P, ctypes.c_int, ctypes.c_float, P, P, P, ctypes.c_int, P, c_i32p, c_i32p, c_i32p, c_f32p],

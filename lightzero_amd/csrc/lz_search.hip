@@ -345,7 +345,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     {
         const int mt = m->cfg.model_type;
         const int want = (mt == 0 || mt == 3) ? LZ_TREE_EFFICIENTZERO : (mt == 4 ? LZ_TREE_SAMPLED_EFFICIENTZERO : LZ_TREE_MUZERO);
-        LZ_REQUIRE(r->t.variant == want, "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree, sampled model <-> sampled tree)");
+        LZ_REQUIRE(r->t.variant == want || (want == LZ_TREE_MUZERO && r->t.variant == LZ_TREE_GUMBEL_MUZERO), "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree, sampled model <-> sampled tree)");
         if (mt == 4) LZ_REQUIRE(r->t.D == m->cfg.action_space_size && r->t.A == m->cfg.num_of_sampled_actions, "sampled roots (K, action dim) differ from the model's");
         else LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
     }
@@ -504,7 +504,10 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
         LZ_HIP_CHECK(hipStreamSynchronize(s));
         d_noise = r->d_noise;
     }
-    lz_tree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_logits, r->d_to_play, s);
+    if (t.variant == LZ_TREE_GUMBEL_MUZERO)  // roots.prepare(noise_w, noises, reward_roots = 0, pred_values, policy_logits, to_play), gumbel_muzero.py:562
+        lz_gtree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_value, r->sim_logits, r->d_to_play, s);
+    else
+        lz_tree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_logits, r->d_to_play, s);
     LZ_HIP_CHECK(hipGetLastError());
     r->players = players;
     r->prepared = true;
@@ -658,6 +661,33 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
         r->graph_key = key;
     }
     LZ_HIP_CHECK(hipGraphLaunch(r->graph_exec, s));
+    return LZ_OK;
+}
+
+// GumbelMuZeroMCTSCtree.search (mcts_ctree.py:1067-1172) with an engine MuZero model: sequential-halving selection, MuZero
+// recurrent inference, expand + backup fused with the next selection, all on the device
+extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_considered_actions, float discount_factor)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_REQUIRE(r->t.variant == LZ_TREE_GUMBEL_MUZERO, "not a Gumbel MuZero roots handle");
+    LZ_REQUIRE(r->inferred && r->prepared, "lz_gsearch needs lz_initial_inference and a prepare call first");
+    LZ_REQUIRE(r->players == 1, "the Gumbel MuZero tree is single-player (cnode.cpp:618)");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    int rc = lz_groots_set_considered(r, num_simulations, max_num_considered_actions, s);
+    if (rc != LZ_OK) return rc;
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
+    lz_tree_launch_minmax_reset(t, s);
+    lz_gtree_launch_traverse(t, discount_factor, s);
+    for (int sim = 0; sim < num_simulations; ++sim) {
+        recurrent(r, sim, 0, s);
+        const int slot = sim + 1;
+        const float *rew = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
+        if (sim + 1 < num_simulations) lz_gtree_launch_backprop_traverse(t, slot, discount_factor, rew, val, lg, s);
+        else lz_gtree_launch_backprop(t, slot, discount_factor, rew, val, lg, s);
+    }
+    LZ_HIP_CHECK(hipGetLastError());
     return LZ_OK;
 }
 

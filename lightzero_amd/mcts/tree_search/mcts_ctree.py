@@ -364,3 +364,56 @@ class SampledEfficientZeroMCTSCtree(object):
                 ezs_tree.batch_backpropagate(simulation_index + 1, discount_factor, value_prefix.reshape(-1), value.reshape(-1),
                                              out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
                                              reset_idx.astype(np.int32), virtual_to_play_batch)
+
+
+class GumbelMuZeroMCTSCtree(object):
+    """lzero/mcts/tree_search/mcts_ctree.py:1004-1172 (Gumbel MuZero): engine MuZero model -> lz_gsearch, whole loop on the device;
+    any other model -> the reference loop with the device tree (gmz_tree drop-in)."""
+    config = dict(root_dirichlet_alpha=0.3, root_noise_weight=0.25, pb_c_base=19652, pb_c_init=1.25, value_delta_max=0.01,
+                  max_num_considered_actions=4)
+
+    @classmethod
+    def default_config(cls):
+        cfg = _Cfg(copy.deepcopy(cls.config))
+        cfg["cfg_type"] = cls.__name__ + "Dict"
+        return cfg
+
+    def __init__(self, cfg=None):
+        default_config = self.default_config()
+        if cfg is not None:
+            default_config.update(dict(cfg))
+        self._cfg = default_config
+        model_cfg = _get(self._cfg, "model", {}) or {}
+        self._support_min = float(_get(model_cfg, "value_support_range", (-300., 301., 1.))[0])
+
+    @classmethod
+    def roots(cls, active_collect_env_num, legal_actions, action_space_size=None, max_simulations=None):
+        from ..ctree.ctree_gumbel_muzero import gmz_tree
+        return gmz_tree.Roots(active_collect_env_num, legal_actions, action_space_size=action_space_size, max_simulations=max_simulations)
+
+    def search(self, roots, model, latent_state_roots, to_play_batch):
+        from ..ctree.ctree_gumbel_muzero import gmz_tree
+        cfg = self._cfg
+        S, m, discount_factor = int(cfg["num_simulations"]), int(cfg["max_num_considered_actions"]), cfg["discount_factor"]
+        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+            L.check(L.lib().lz_gsearch(roots._h, S, m, float(discount_factor)))
+            return
+        import torch
+        device = _get(cfg, "device", "cpu")
+        with torch.no_grad():
+            model.eval()
+            batch_size = roots.num
+            latent_pool = [np.asarray(latent_state_roots)]
+            mm = gmz_tree.MinMaxStatsList(batch_size)
+            mm.set_delta(cfg["value_delta_max"])
+            for simulation_index in range(S):
+                results = gmz_tree.ResultsWrapper(num=batch_size)
+                tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
+                ix, iy, last_actions, vtp = gmz_tree.batch_traverse(roots, S, m, discount_factor, results, tp)
+                lat = np.stack(latent_pool)[np.asarray(ix), np.asarray(iy)]
+                out = model.recurrent_inference(torch.from_numpy(lat).to(device), torch.from_numpy(np.asarray(last_actions)).to(device).long())
+                latent_pool.append(out.latent_state.detach().cpu().numpy())
+                value = _inverse_scalar_transform(out.value, self._support_min).reshape(-1)
+                reward = _inverse_scalar_transform(out.reward, self._support_min).reshape(-1)
+                gmz_tree.batch_back_propagate(simulation_index + 1, discount_factor, reward, value,
+                                              out.policy_logits.detach().cpu().numpy(), mm, results, vtp)

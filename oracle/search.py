@@ -246,3 +246,31 @@ def ez_search_with_reuse(tree, roots, model, latent_state_roots, reward_hidden_s
                                                 virtual_to_play_batch, no_inference_lst, reuse_lst, list(reuse_value_list))
             infer_sum += length
         return length, infer_sum / cfg["num_simulations"]
+
+
+def gmz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device="cpu"):
+    """GumbelMuZeroMCTSCtree.search  lzero/mcts/tree_search/mcts_ctree.py:1067-1172."""
+    ist = InverseScalarTransform(device=device)
+    with torch.no_grad():
+        model.eval()
+        batch_size = roots.num
+        discount_factor = cfg["discount_factor"]
+        latent_state_batch_in_search_path = [latent_state_roots]
+        min_max_stats_lst = tree.MinMaxStatsList(batch_size)
+        min_max_stats_lst.set_delta(cfg["value_delta_max"])
+        for simulation_index in range(cfg["num_simulations"]):
+            latent_states = []
+            results = tree.ResultsWrapper(batch_size)
+            ix_l, iy_l, last_actions, virtual_to_play_batch = tree.batch_traverse(
+                roots, cfg["num_simulations"], cfg["max_num_considered_actions"], discount_factor, results, list(to_play_batch))
+            for ix, iy in zip(ix_l, iy_l):
+                latent_states.append(latent_state_batch_in_search_path[ix][iy])
+            latent_states = torch.from_numpy(np.asarray(latent_states)).to(device)
+            last_actions_t = torch.from_numpy(np.asarray(last_actions)).to(device).long()
+            out = model.recurrent_inference(latent_states, last_actions_t)
+            latent_state_batch_in_search_path.append(out.latent_state.detach().cpu().numpy())
+            value = ist(out.value).detach().cpu().numpy()
+            reward = ist(out.reward).detach().cpu().numpy()
+            tree.batch_back_propagate(simulation_index + 1, discount_factor, reward.reshape(-1).tolist(), value.reshape(-1).tolist(),
+                                      out.policy_logits.detach().cpu().numpy().tolist(), min_max_stats_lst, results,
+                                      virtual_to_play_batch)
