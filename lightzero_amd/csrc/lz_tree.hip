@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64) void k_backprop_traverse_lds(lz_tree_dev t, int
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_tree[];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int A = t.A, NN = t.NN;
+    const int A = t.A;
     const int nn = new_node + 1;        // nodes 0 .. new_node exist after this step
     float4 *s_edge = s_tree;                                              // [nn][A]
     int32_t *s_child = reinterpret_cast<int32_t *>(s_edge + (size_t)nn * A);   // [nn][A]
