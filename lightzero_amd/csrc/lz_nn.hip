@@ -1029,7 +1029,7 @@ constexpr int MAXH = 4;
 struct head_pack { lz_head_desc h[MAXH]; };
 
 // block-wide reduction of N values per thread (max or sum); result broadcast to every thread
-template <int N, bool IS_MAX>
+template <int N, bool IS_MAX, int NWAVES>
 __device__ __forceinline__ void block_reduce_n(float (&v)[N], float *scratch)
 {
 #pragma unroll
@@ -1047,13 +1047,22 @@ __device__ __forceinline__ void block_reduce_n(float (&v)[N], float *scratch)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const float a0 = scratch[k], a1 = scratch[N + k], a2 = scratch[2 * N + k], a3 = scratch[3 * N + k];
-        v[k] = IS_MAX ? fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) : (a0 + a1) + (a2 + a3);
+        float r[NWAVES / 4];
+#pragma unroll
+        for (int g = 0; g < NWAVES / 4; ++g) {
+            const float a0 = scratch[(4 * g) * N + k], a1 = scratch[(4 * g + 1) * N + k], a2 = scratch[(4 * g + 2) * N + k], a3 = scratch[(4 * g + 3) * N + k];
+            r[g] = IS_MAX ? fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) : (a0 + a1) + (a2 + a3);
+        }
+        v[k] = r[0];
+#pragma unroll
+        for (int g = 1; g < NWAVES / 4; ++g) v[k] = IS_MAX ? fmaxf(v[k], r[g]) : v[k] + r[g];
     }
 }
 
-template <int HID>
-__global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
+// NTHR threads: HID units x (NTHR / HID) K-parts in layer 1, ceil(768 / NTHR) outputs per thread in layer 2.  512 threads
+// (8 waves) halve the per-thread load and FMA chains of the 256-thread version.
+template <int HID, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const lz_head_desc &h = hp.h[blockIdx.y];
@@ -1062,26 +1071,29 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
     const int K1 = h.K1;
     float *xs = smem;                    // [EPB][K1]
     float *hid = xs + EPB * K1;          // [EPB][HID]
-    float *scr = hid + EPB * HID;        // [4 * 8]
+    float *scr = hid + EPB * HID;        // [NWAVES * 8]
+    constexpr int NWAVES = NTHR / 64, PARTS = NTHR / HID;  // PARTS lanes (a power of two) share one hidden unit's row
     // Every weight this thread will need is requested up front (none depends on the activations): the kernel is
     // a chain of three dependent stages, and each exposed L2 round trip costs as much as the arithmetic.
-    constexpr int NW1 = 18, NPT = 3;     // layer-1 float4 per thread kept in registers; outputs per thread (NOUT <= 768)
-    const int u = tid >> 3, part = tid & 7;
+    constexpr int NW1 = 144 / PARTS, NPT = (768 + NTHR - 1) / NTHR;  // layer-1 float4 per thread kept in registers (K1 = 576
+                                                                     // fits exactly); outputs per thread (NOUT <= 768)
+    const int u = tid / PARTS, part = tid % PARTS;
     const float *wr = h.w1 + (size_t)min(u, HID - 1) * K1;
-    const int n1 = (K1 - part * 4 + 31) / 32;  // layer-1 iterations of this thread (k = part*4 + 32 i < K1)
+    constexpr int KSTEP = 4 * PARTS;
+    const int n1 = (K1 - part * 4 + KSTEP - 1) / KSTEP;  // layer-1 iterations of this thread (k = part*4 + KSTEP i < K1)
     f32x4 w1r[NW1];
 #pragma unroll
-    for (int i = 0; i < NW1; ++i) w1r[i] = *reinterpret_cast<const f32x4 *>(wr + min(part * 4 + 32 * i, K1 - 4));
+    for (int i = 0; i < NW1; ++i) w1r[i] = *reinterpret_cast<const f32x4 *>(wr + min(part * 4 + KSTEP * i, K1 - 4));
     float w2r[NPT][HID], b2r[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const int n = min(tid + i * 256, h.NOUT - 1);
+        const int n = min(tid + i * NTHR, h.NOUT - 1);
         b2r[i] = h.b2[n];
 #pragma unroll
         for (int k = 0; k < HID; ++k) w2r[i][k] = h.w2t[(size_t)k * h.NOUT + n];
     }
     const float b1v = h.b1[min(u, HID - 1)], s1v = h.s1[min(u, HID - 1)], t1v = h.t1[min(u, HID - 1)];
-    for (int i = tid; i < EPB * (K1 / 4); i += 256) {  // 16-channel runs are contiguous: float4 loads
+    for (int i = tid; i < EPB * (K1 / 4); i += NTHR) {  // 16-channel runs are contiguous: float4 loads
         const int e = i / (K1 / 4), k = (i - e * (K1 / 4)) * 4, b = min(b0 + e, B - 1);
         *reinterpret_cast<float4 *>(xs + e * K1 + k) =
             *reinterpret_cast<const float4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
@@ -1095,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
 #pragma unroll
         for (int i = 0; i < NW1; ++i) {
             if (i < n1) {
-                const int k = part * 4 + 32 * i;
+                const int k = part * 4 + KSTEP * i;
 #pragma unroll
                 for (int e = 0; e < EPB; ++e) {
                     const float4 xv = *reinterpret_cast<const float4 *>(xs + e * K1 + k);
@@ -1104,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
             }
         }
         for (int i = NW1; i < n1; ++i) {  // K1 > 576 (board games): the tail streams from L2
-            const int k = part * 4 + 32 * i;
+            const int k = part * 4 + KSTEP * i;
             const f32x4 wv4 = *reinterpret_cast<const f32x4 *>(wr + k);
 #pragma unroll
             for (int e = 0; e < EPB; ++e) {
@@ -1114,9 +1126,8 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
         }
 #pragma unroll
         for (int e = 0; e < EPB; ++e) {
-            acc[e] += __shfl_xor(acc[e], 1);
-            acc[e] += __shfl_xor(acc[e], 2);
-            acc[e] += __shfl_xor(acc[e], 4);
+#pragma unroll
+            for (int o = 1; o < PARTS; o <<= 1) acc[e] += __shfl_xor(acc[e], o);
         }
         if (u < HID && part == 0) {
 #pragma unroll
@@ -1128,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
     float lg[NPT][EPB];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const int n = tid + i * 256;
+        const int n = tid + i * NTHR;
         const bool ok = n < h.NOUT;
         float acc[EPB];
 #pragma unroll
@@ -1147,15 +1158,19 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
     if (!h.categorical) return;
     float m[EPB];
 #pragma unroll
-    for (int e = 0; e < EPB; ++e) m[e] = fmaxf(fmaxf(lg[0][e], lg[1][e]), lg[2][e]);
-    block_reduce_n<EPB, true>(m, scr);
+    for (int e = 0; e < EPB; ++e) {
+        m[e] = lg[0][e];
+#pragma unroll
+        for (int i = 1; i < NPT; ++i) m[e] = fmaxf(m[e], lg[i][e]);
+    }
+    block_reduce_n<EPB, true, NWAVES>(m, scr);
     float ss[2 * EPB];
 #pragma unroll
     for (int e = 0; e < EPB; ++e) {
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int n = tid + i * 256;
+            const int n = tid + i * NTHR;
             if (n < h.NOUT) {
                 const float ex = expf(lg[i][e] - m[e]);
                 s0 += ex;
@@ -1165,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_heads(head_pack hp, int B)
         ss[2 * e] = s0;
         ss[2 * e + 1] = s1;
     }
-    block_reduce_n<2 * EPB, false>(ss, scr);
+    block_reduce_n<2 * EPB, false, NWAVES>(ss, scr);
     if (tid < EPB && b0 + tid < B) {
         // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
         float s0 = ss[0], s1 = ss[1];
@@ -1333,6 +1348,9 @@ void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipS
         hp.h[i] = heads[i];
         if (heads[i].K1 > k1max) k1max = heads[i].K1;
     }
-    const size_t lds = ((size_t)EPB * k1max + (size_t)EPB * HID + 32) * 4;
-    if (HID == 32) hipLaunchKernelGGL((k_heads<32>), dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B);
+    const size_t lds = ((size_t)EPB * k1max + (size_t)EPB * HID + 8 * 8) * 4;
+    static const char *narrow = getenv("LZ_HEADS_256");
+    if (HID != 32) return;
+    if (narrow) hipLaunchKernelGGL((k_heads<32, 256>), dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B);
+    else hipLaunchKernelGGL((k_heads<32, 512>), dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds, s, hp, B);
 }
