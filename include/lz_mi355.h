@@ -139,6 +139,10 @@ int lz_sbatch_traverse(lz_roots *r, int pb_c_base, float pb_c_init, float discou
 int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_index, float discount_factor, const float *h_value_prefixs,
                             const float *h_values, const float *h_policy, const int32_t *h_is_reset,
                             const int32_t *h_to_play, const float *h_given);
+/* discrete action spaces (continuous_action_space = False, cnode.cpp:288-327): each node samples K of the action_space_size
+ * actions without replacement from its policy logits; an action is the float of its index, policies are [root_num][A] logits */
+int lz_sroots_create_discrete(lz_engine *e, int root_num, int action_space_size, int num_of_sampled_actions,
+                              int max_simulations, lz_roots **out);
 /* parity runs of the fused sampled search: inject the post-tanh draws of every expansion, [records][root_num][K][D]
  * (record 0 = Roots.prepare, record s + 1 = simulation s); NULL / 0 returns to device-side sampling */
 int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records);

@@ -66,6 +66,7 @@ def lib():
         "lz_roots_get_trajectories": [P, c_i32p, ctypes.c_int],
         "lz_roots_get_minmax": [P, c_f32p],
         "lz_sroots_create": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)],
+        "lz_sroots_create_discrete": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)],
         "lz_sroots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_i32p, P],
         "lz_sbatch_traverse": [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_i32p, c_i32p, c_i32p, c_f32p, c_i32p],
         "lz_sbatch_backpropagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, P],

@@ -109,7 +109,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     if (!r) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
     r->eng = e;
     lz_tree_dev &t = r->t;
-    t.B = B; t.A = A; t.NN = max_sims + 1; t.variant = variant; t.D = D;
+    t.B = B; t.A = A; t.NN = max_sims + 1; t.variant = variant; t.D = D; t.disc_A = 0;
     const size_t nBNA = (size_t)B * t.NN * A, nBN = (size_t)B * t.NN;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -819,6 +819,18 @@ extern "C" int lz_sroots_create(lz_engine *e, int root_num, int action_dim, int 
     return LZ_OK;
 }
 
+// discrete action space (continuous_action_space = False): K of the action_space_size actions per node, policy = logits
+extern "C" int lz_sroots_create_discrete(lz_engine *e, int root_num, int action_space_size, int num_of_sampled_actions,
+                                         int max_simulations, lz_roots **out)
+{
+    LZ_REQUIRE(action_space_size >= 1 && action_space_size <= 64, "action_space_size must be in [1, 64] (one lane per action)");
+    LZ_REQUIRE(num_of_sampled_actions <= action_space_size, "num_of_sampled_actions must not exceed action_space_size (sampling is without replacement)");
+    int rc = lz_sroots_create(e, root_num, 1, num_of_sampled_actions, max_simulations, out);
+    if (rc != LZ_OK) return rc;
+    (*out)->t.disc_A = action_space_size;
+    return LZ_OK;
+}
+
 static int sampled_check(lz_roots *r)
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
@@ -836,12 +848,13 @@ extern "C" int lz_sroots_prepare(lz_roots *r, float root_noise_weight, const flo
     const lz_tree_dev &t = r->t;
     const size_t B = t.B, K = t.A, D = t.D;
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
-    const size_t o_vp = 0, o_pol = o_vp + B * 4, o_tp = o_pol + B * 2 * D * 4, o_giv = o_tp + B * 4, need = o_giv + B * K * D * 4;
+    const size_t PSZ = t.disc_A > 0 ? (size_t)t.disc_A : 2 * D;  // floats per root in the policy array
+    const size_t o_vp = 0, o_pol = o_vp + B * 4, o_tp = o_pol + B * PSZ * 4, o_giv = o_tp + B * 4, need = o_giv + B * K * D * 4;
     rc = ensure_stage(r, need);
     if (rc != LZ_OK) return rc;
     char *h = (char *)r->h_stage, *d = (char *)r->d_stage;
     memcpy(h + o_vp, h_value_prefix, B * 4);
-    memcpy(h + o_pol, h_policy, B * 2 * D * 4);
+    memcpy(h + o_pol, h_policy, B * PSZ * 4);
     memcpy(h + o_tp, h_to_play, B * 4);
     if (h_given) memcpy(h + o_giv, h_given, B * K * D * 4);
     hipStream_t s = r->eng->stream;
@@ -911,7 +924,8 @@ extern "C" int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_ind
         return LZ_ERR_STATE;
     }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
-    const size_t o_vp = 0, o_v = B * 4, o_rst = 2 * B * 4, o_tp = 3 * B * 4, o_pol = 4 * B * 4, o_giv = o_pol + B * 2 * D * 4,
+    const size_t PSZ = t.disc_A > 0 ? (size_t)t.disc_A : 2 * D;
+    const size_t o_vp = 0, o_v = B * 4, o_rst = 2 * B * 4, o_tp = 3 * B * 4, o_pol = 4 * B * 4, o_giv = o_pol + B * PSZ * 4,
                  need = o_giv + B * K * D * 4;
     rc = ensure_stage(r, need);
     if (rc != LZ_OK) return rc;
@@ -920,7 +934,7 @@ extern "C" int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_ind
     memcpy(h + o_v, h_values, B * 4);
     memcpy(h + o_rst, h_is_reset, B * 4);
     memcpy(h + o_tp, h_to_play, B * 4);
-    memcpy(h + o_pol, h_policy, B * 2 * D * 4);
+    memcpy(h + o_pol, h_policy, B * PSZ * 4);
     if (h_given) memcpy(h + o_giv, h_given, B * K * D * 4);
     hipStream_t s = r->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(d, h, h_given ? need : o_giv, hipMemcpyHostToDevice, s));

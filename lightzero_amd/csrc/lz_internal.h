@@ -72,6 +72,7 @@ struct lz_tree_dev {
     int32_t *res_noinf;         // [B]         ReZero: the last traverse ended on an already expanded node (reference index -1)
     // Sampled EfficientZero (variant 2, continuous actions): A == K sampled actions per node
     int D;                      // action dimension
+    int disc_A;                 // > 0: discrete action space of that size (D == 1, an action is the float of its index; policy = logits)
     int32_t *rep;               // [B][NN][K]  position of the first legal action with the same "%f" key (shared child)
     int32_t *nchild;            // [B][NN]     number of distinct keys == children.size()
     float *actions;             // [B][NN][K][D] sampled actions (legal_actions of every expanded node)

@@ -41,7 +41,7 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
         LZ_REQUIRE(cfg->num_channels >= 16 && cfg->num_channels <= 1024, "latent_state_dim must be in [16, 1024]");
         LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
         LZ_REQUIRE(cfg->action_encoding >= 0 && cfg->action_encoding <= 2, "action_encoding must be 0 (one_hot), 1 (not_one_hot) or 2 (continuous)");
-        LZ_REQUIRE((cfg->action_encoding == 2) == (cfg->model_type == 4), "continuous actions <-> SampledEfficientZeroModelMLP (the discrete sampled tree is not compiled)");
+        LZ_REQUIRE(cfg->action_encoding != 2 || cfg->model_type == 4, "continuous actions need the SampledEfficientZeroModelMLP");
         if (cfg->model_type != 2) {
             const int nchunk = (cfg->num_channels + cfg->lstm_hidden_size) / 64;
             LZ_REQUIRE(cfg->num_channels % 64 == 0 && cfg->lstm_hidden_size % 64 == 0 && (nchunk == 4 || nchunk == 12 || nchunk == 9 || nchunk == 13 || nchunk == 17),
@@ -346,7 +346,12 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
         const int mt = m->cfg.model_type;
         const int want = (mt == 0 || mt == 3) ? LZ_TREE_EFFICIENTZERO : (mt == 4 ? LZ_TREE_SAMPLED_EFFICIENTZERO : LZ_TREE_MUZERO);
         LZ_REQUIRE(r->t.variant == want || (want == LZ_TREE_MUZERO && r->t.variant == LZ_TREE_GUMBEL_MUZERO), "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree, sampled model <-> sampled tree)");
-        if (mt == 4) LZ_REQUIRE(r->t.D == m->cfg.action_space_size && r->t.A == m->cfg.num_of_sampled_actions, "sampled roots (K, action dim) differ from the model's");
+        if (mt == 4) {
+            const bool cont = m->cfg.action_encoding == 2;
+            LZ_REQUIRE(r->t.A == m->cfg.num_of_sampled_actions, "sampled roots: num_of_sampled_actions differs from the model's");
+            LZ_REQUIRE(cont ? (r->t.disc_A == 0 && r->t.D == m->cfg.action_space_size) : (r->t.disc_A == m->cfg.action_space_size),
+                       "sampled roots: action space (continuous dimension / discrete size) differs from the model's");
+        }
         else LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
     }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));

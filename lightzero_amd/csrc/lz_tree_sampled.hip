@@ -53,7 +53,30 @@ __device__ __forceinline__ void expand_sampled(const lz_tree_dev &t, int b, int 
 {
     const int lane = threadIdx.x, K = t.A, D = t.D, NN = t.NN;
     float *gact = t.actions + (((size_t)b * NN + node) * K) * D;
-    if (lane < K) {
+    if (t.disc_A > 0 && !sa.given) {
+        // discrete action space (cnode.cpp:288-327): K of the A actions without replacement -- the reference sorts the keys
+        // u_a^(1/p_a) in descending order and keeps the first K; log(u_a) / p_a orders the same way.  Lane = action (A <= 64).
+        const int A = t.disc_A;
+        const uint32_t epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;
+        const float lg = lane < A ? sa.policy[(size_t)b * A + lane] : -__builtin_inff();
+        const float ex = lane < A ? expf(lg) : 0.0f;
+        float sum = ex;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float p = ex / (sum + 1e-6f);
+        const uint64_t st = mix64(mix64(sa.seed ^ 0x5a3c1e0fu ^ ((uint64_t)epoch << 24) ^ (uint64_t)sa.counter) ^ ((uint64_t)b << 20) ^
+                                  ((uint64_t)node << 8) ^ (uint64_t)lane);
+        const float u = ((float)((st >> 40) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
+        const float key = lane < A ? logf(u) / fmaxf(p, 1e-30f) : -__builtin_inff();
+        int rank = 0;
+        for (int a2 = 0; a2 < A; ++a2) {
+            const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key), a2));
+            rank += (k2 > key || (k2 == key && a2 < lane)) ? 1 : 0;
+        }
+        if (lane < A && rank < K) s_act[rank] = (float)lane;
+        __syncthreads();
+        if (lane < K) gact[lane] = s_act[lane];
+    } else if (lane < K) {
         if (sa.given) {
             for (int j = 0; j < D; ++j) s_act[lane * D + j] = sa.given[((size_t)b * K + lane) * D + j];
         } else {
@@ -200,7 +223,8 @@ __device__ __forceinline__ void dev_straverse(const lz_tree_dev &t, const lz_tra
     if (lane == 0) {
         t.res_ix[b] = node;
         t.res_iy[b] = b;
-        t.res_last_action[b] = last_pos;
+        // discrete action spaces: the network wants the action index (one-hot encoding), not its position among the K samples
+        t.res_last_action[b] = t.disc_A > 0 ? (int)t.actions[(((size_t)b * NN + node) * K + last_pos) * D] : last_pos;
         t.res_search_len[b] = depth;
         t.res_vtp[b] = vtp;
     }

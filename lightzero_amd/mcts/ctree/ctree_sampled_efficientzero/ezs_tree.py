@@ -39,13 +39,17 @@ class ResultsWrapper(object):
 class Roots(object):
     def __init__(self, root_num, legal_actions_list, action_space_size, num_of_sampled_actions,
                  continuous_action_space=True, max_simulations=None, engine=None):
-        if not continuous_action_space:
-            raise NotImplementedError("the device tree implements the continuous-action branch of ctree_sampled_efficientzero")
-        self.root_num, self.D, self.K = int(root_num), int(action_space_size), int(num_of_sampled_actions)
+        self.root_num, self.K = int(root_num), int(num_of_sampled_actions)
+        self.continuous = bool(continuous_action_space)
         self._S = int(max_simulations) if max_simulations else DEFAULT_MAX_SIMULATIONS
         h = L.P()
         eng = engine if engine is not None else L.default_engine()
-        L.check(L.lib().lz_sroots_create(eng, self.root_num, self.D, self.K, self._S, ctypes.byref(h)))
+        if self.continuous:
+            self.D, self._pw = int(action_space_size), 2 * int(action_space_size)   # policy = (mu | sigma)
+            L.check(L.lib().lz_sroots_create(eng, self.root_num, self.D, self.K, self._S, ctypes.byref(h)))
+        else:  # discrete: an action is the float of its index (cnode.cpp:436-441), policy = action_space_size logits
+            self.D, self._pw = 1, int(action_space_size)
+            L.check(L.lib().lz_sroots_create_discrete(eng, self.root_num, self._pw, self.K, self._S, ctypes.byref(h)))
         self._h = h
         _seed[0] += 1
         self._seed = _seed[0]
@@ -76,22 +80,22 @@ class Roots(object):
 
     def prepare(self, root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch):
         pol = L.f32(policy_logits_pool)
-        if pol.shape != (self.root_num, 2 * self.D):
-            raise ValueError("policy_logits_pool must be [root_num][2 * action_space_size] (mu | sigma)")
+        if pol.shape != (self.root_num, self._pw):
+            raise ValueError("policy_logits_pool must be [root_num][2 * action_space_size] (mu | sigma), or [root_num][action_space_size] logits for discrete actions")
         nz = L.f32(noises)
         L.check(L.lib().lz_sroots_prepare(self._h, float(root_noise_weight), nz.ctypes.data, L.f32(value_prefix_pool), pol,
                                           L.i32(to_play_batch), self._take_given()))
 
     def prepare_no_noise(self, value_prefix_pool, policy_logits_pool, to_play_batch):
         pol = L.f32(policy_logits_pool)
-        if pol.shape != (self.root_num, 2 * self.D):
-            raise ValueError("policy_logits_pool must be [root_num][2 * action_space_size] (mu | sigma)")
+        if pol.shape != (self.root_num, self._pw):
+            raise ValueError("policy_logits_pool has the wrong width")
         L.check(L.lib().lz_sroots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), pol, L.i32(to_play_batch),
                                           self._take_given()))
 
     # ---- fused path (engine model): the root (mu | sigma) is already in HBM
     def _ensure(self, action_space_size):
-        if int(action_space_size) != self.D:
+        if int(action_space_size) != (self.D if self.continuous else self._pw):
             raise ValueError("model action dimension %d != roots action_space_size %d" % (action_space_size, self.D))
 
     def prepare_from_inference(self, root_noise_weight, noises, to_play_batch):

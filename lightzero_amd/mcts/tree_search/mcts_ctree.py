@@ -346,13 +346,16 @@ class SampledEfficientZeroMCTSCtree(object):
                 results = ezs_tree.ResultsWrapper(num=batch_size)
                 tp = to_play_batch if _get(cfg, "env_type", "not_board_games") == "not_board_games" else copy.deepcopy(to_play_batch)
                 ix, iy, last_actions, virtual_to_play_batch = ezs_tree.batch_traverse(
-                    roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, tp, True)
+                    roots, pb_c_base, pb_c_init, discount_factor, min_max_stats_lst, results, tp, roots.continuous)
                 search_lens = results.get_search_len()
                 ix = np.asarray(ix); iy = np.asarray(iy)
                 latent_states = torch.from_numpy(np.stack(latent_pool)[ix, iy]).to(device)
                 hc = torch.from_numpy(np.stack(c_pool)[ix, 0, iy]).to(device).unsqueeze(0)
                 hh = torch.from_numpy(np.stack(h_pool)[ix, 0, iy]).to(device).unsqueeze(0)
-                out = model.recurrent_inference(latent_states, (hc, hh), torch.from_numpy(np.asarray(last_actions, np.float32)).to(device))
+                la = torch.from_numpy(np.asarray(last_actions, np.float32)).to(device)
+                if not roots.continuous:
+                    la = la.long()  # mcts_ctree_sampled.py: discrete actions are fed as indices
+                out = model.recurrent_inference(latent_states, (hc, hh), la)
                 latent_pool.append(out.latent_state.detach().cpu().numpy())
                 value = _inverse_scalar_transform(out.value, self._support_min)
                 value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min)

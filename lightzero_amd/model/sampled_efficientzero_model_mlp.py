@@ -1,5 +1,6 @@
 """``SampledEfficientZeroModelMLP``  lzero/model/sampled_efficientzero_model_mlp.py (inference graph, continuous action
-spaces; BASELINE configs[4]): LayerNorm + GELU(tanh) stacks, value-prefix LSTM, ReparameterizationHead (mu | sigma).
+spaces, BASELINE configs[4]; or discrete ones with an MLP policy head): LayerNorm + GELU(tanh) stacks, value-prefix LSTM,
+ReparameterizationHead (mu | sigma).
 Pair it with ezs_tree.Roots.  See muzero_model_mlp.py for the engine mechanics."""
 from .muzero_model_mlp import _EngineModelMLP
 
@@ -12,9 +13,7 @@ class SampledEfficientZeroModelMLP(_EngineModelMLP):
     def __init__(self, observation_shape=2, action_space_size=6, latent_state_dim=256, lstm_hidden_size=512,
                  continuous_action_space=False, num_of_sampled_actions=6, norm_type='LN', res_connection_in_dynamics=True,
                  **kwargs):
-        if not continuous_action_space:
-            raise NotImplementedError("the device tree implements the continuous-action branch of Sampled EfficientZero")
         super().__init__(observation_shape=observation_shape, action_space_size=action_space_size,
                          latent_state_dim=latent_state_dim, lstm_hidden_size=lstm_hidden_size,
-                         continuous_action_space=True, num_of_sampled_actions=num_of_sampled_actions, norm_type=norm_type,
-                         res_connection_in_dynamics=res_connection_in_dynamics, **kwargs)
+                         continuous_action_space=bool(continuous_action_space), num_of_sampled_actions=num_of_sampled_actions,
+                         norm_type=norm_type, res_connection_in_dynamics=res_connection_in_dynamics, **kwargs)

@@ -20,8 +20,7 @@ class SampledEfficientZeroPolicy(object):
         mc = _g(cfg, "model", {}) or {}
         self._A = int(_g(mc, "action_space_size"))
         self._K = int(_g(mc, "num_of_sampled_actions", 20))
-        if not _g(mc, "continuous_action_space", True):
-            raise NotImplementedError("the device tree implements the continuous-action branch of Sampled EfficientZero")
+        self._continuous = bool(_g(mc, "continuous_action_space", True))
         self._support_min = float(_g(mc, "value_support_range", (-300., 301., 1.))[0])
         self._mcfg = dict(num_simulations=_g(cfg, "num_simulations", 50), discount_factor=_g(cfg, "discount_factor", 0.997),
                           lstm_horizon_len=_g(cfg, "lstm_horizon_len", 5), pb_c_base=_g(cfg, "pb_c_base", 19652),
@@ -42,8 +41,9 @@ class SampledEfficientZeroPolicy(object):
         # the reference builds a fresh Roots per forward (sampled_efficientzero.py:876); prepare() re-arms the same pools
         roots = self._roots_cache.get(n)
         if roots is None:
+            # the reference passes the action mask's indices for discrete spaces; its CRoots ignores them (cnode.cpp:653-659)
             legal_actions = [[-1 for _ in range(self._K)] for _ in range(n)]
-            roots = MCTSCtree.roots(n, legal_actions, self._A, self._K, True, max_simulations=int(self._mcfg["num_simulations"]))
+            roots = MCTSCtree.roots(n, legal_actions, self._A, self._K, self._continuous, max_simulations=int(self._mcfg["num_simulations"]))
             roots.set_tiebreak(self._tiebreak)
             self._roots_cache[n] = roots
         return roots
@@ -87,8 +87,11 @@ class SampledEfficientZeroPolicy(object):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]
             root_sampled_actions = np.array([a for a in roots_sampled_actions[i]])
             idx, entropy = select_action(distributions, temperature=temperature, deterministic=deterministic)
+            action = np.array(roots_sampled_actions[i][idx])
+            if not self._continuous:  # sampled_efficientzero.py:908-913
+                action = int(action) if len(action.shape) == 0 else int(action[0])
             output[env_id] = {
-                'action': np.array(roots_sampled_actions[i][idx]),
+                'action': action,
                 'visit_count_distributions': distributions,
                 'root_sampled_actions': root_sampled_actions,
                 'visit_count_distribution_entropy': entropy,

@@ -249,6 +249,8 @@ def slib():
         fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.stree_create.restype = P
         L.stree_create.argtypes = [ctypes.c_int] * 4
+        L.stree_create_discrete.restype = P
+        L.stree_create_discrete.argtypes = [ctypes.c_int] * 4
         L.stree_destroy.argtypes = [P]
         L.stree_set_clock.argtypes = [P, ctypes.c_uint64]
         L.stree_set_tiebreak.argtypes = [P, ctypes.c_int]
@@ -284,9 +286,14 @@ def _make_sampled():
     class Roots(object):
         def __init__(self, root_num, legal_actions_list, action_space_size, num_of_sampled_actions,
                      continuous_action_space=True, max_simulations=512):
-            assert continuous_action_space, "the oracle restates the continuous branch only"
-            self.root_num, self.D, self.K, self._S = root_num, action_space_size, num_of_sampled_actions, max_simulations
-            self._h = slib().stree_create(root_num, self.D, self.K, max_simulations)
+            self.root_num, self.K, self._S = root_num, num_of_sampled_actions, max_simulations
+            self.continuous = bool(continuous_action_space)
+            if self.continuous:
+                self.D = action_space_size
+                self._h = slib().stree_create(root_num, self.D, self.K, max_simulations)
+            else:  # an action is the float of its index (cnode.cpp:436-441); the policy is `action_space_size` logits
+                self.D = 1
+                self._h = slib().stree_create_discrete(root_num, action_space_size, self.K, max_simulations)
             self._mm_bound = None
             self.given = None  # optional injected samples for the next expand: [B][K][D]
 

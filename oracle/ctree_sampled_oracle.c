@@ -1,6 +1,7 @@
 /*
- * TEST INFRASTRUCTURE ONLY -- CPU restatement (plain C11, scalar) of the reference's Sampled-EfficientZero tree for
- * CONTINUOUS action spaces.  Nothing on the product path may include, link or call this file.
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement (plain C11, scalar) of the reference's Sampled-EfficientZero tree: continuous
+ * action spaces (K actions ~ tanh(N(mu, sigma))) and discrete ones (K of the A actions drawn without replacement by sorting
+ * u_i^(1/p_i), cnode.cpp:290-327).  Nothing on the product path may include, link or call this file.
  *
  * Restates (reference = /root/reference, LightZero v0.2.0):
  *   lzero/mcts/ctree/ctree_sampled_efficientzero/lib/cnode.cpp
@@ -47,6 +48,8 @@ typedef struct { float maximum, minimum, value_delta_max; } SMinMax;
 
 typedef struct {
     int B, D, K, cap, tiebreak;
+    int A_disc;        /* > 0: discrete action space of that size (D == 1, an action is the float of its index) */
+    int pstride;       /* floats per root in the policy arrays: 2 D (mu | sigma) or A_disc (logits) */
     uint64_t clock;    /* what system_clock::now().time_since_epoch().count() returns next */
     SNode *nodes;      /* [B][cap] */
     int *n_nodes;      /* [B] */
@@ -85,11 +88,25 @@ static float normal_fresh(uint64_t *x, float mean, float stddev) /* normal_distr
     return ret;
 }
 
+/* generate_canonical<double, 53>(minstd_rand0): two engine draws (log2 of the range is 30), libstdc++ random.tcc */
+static double canonical53(uint64_t *x)
+{
+    const long double r = 2147483646.0L;  /* max() - min() + 1 */
+    double sum = 0, tmp = 1;
+    for (int k = 2; k != 0; --k) {
+        sum += (double)(lcg_next(x) - 1u) * tmp;
+        tmp = (double)((long double)tmp * r);
+    }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+    return ret;
+}
+
 /* ---- tree ---- */
 STree *stree_create(int B, int D, int K, int max_sims)
 {
     STree *t = (STree *)calloc(1, sizeof(STree));
-    t->B = B; t->D = D; t->K = K; t->tiebreak = 0; t->clock = 1;
+    t->B = B; t->D = D; t->K = K; t->tiebreak = 0; t->clock = 1; t->A_disc = 0; t->pstride = 2 * D;
     t->cap_exp = max_sims + 1;
     t->cap = 1 + t->cap_exp * K;
     t->nodes = (SNode *)calloc((size_t)B * t->cap, sizeof(SNode));
@@ -109,6 +126,14 @@ STree *stree_create(int B, int D, int K, int max_sims)
         t->n_nodes[i] = 1;
         t->mm[i].maximum = S_FLOAT_MIN; t->mm[i].minimum = S_FLOAT_MAX; t->mm[i].value_delta_max = 0.0f;
     }
+    return t;
+}
+
+/* discrete action space of size A: D == 1, policy = A logits */
+STree *stree_create_discrete(int B, int A, int K, int max_sims)
+{
+    STree *t = stree_create(B, 1, K, max_sims);
+    t->A_disc = A; t->pstride = A;
     return t;
 }
 
@@ -155,7 +180,32 @@ static void node_expand(STree *t, int env, int ni, int to_play, int latent_index
         x = seed % 2147483647ull;
         if (x == 0) x = 1;
     }
-    for (int i = 0; i < K; ++i) {
+    if (t->A_disc) {
+        /* discrete branch (cnode.cpp:288-327, 434-447): probs = exp(l) / (sum exp(l) + 1e-6), keys u^(1/p) sorted in
+         * descending order, the first K indices are the sampled actions, prior = probs[action] */
+        const int A = t->A_disc;
+        float probs[A];
+        float logits_exp_sum = 0;
+        for (int a = 0; a < A; ++a) logits_exp_sum += expf(policy[a]);
+        for (int a = 0; a < A; ++a) probs[a] = (float)((double)expf(policy[a]) / ((double)logits_exp_sum + 1e-6));
+        if (given) {
+            for (int i = 0; i < K; ++i) { act[i] = given[i]; logp_after[i] = probs[(int)given[i]]; }
+        } else {
+            int idx[A];
+            double key[A];
+            for (int a = 0; a < A; ++a) { idx[a] = a; key[a] = pow(canonical53(&x), 1. / (double)probs[a]); }
+            /* std::sort(begin, end, cmp) with cmp(x, y) = x.second > y.second: for n <= 16 libstdc++ runs its insertion sort
+             * (bits/stl_algo.h __insertion_sort); equal keys keep their order there.  Larger n go through introsort, whose
+             * order among EQUAL keys is not restated (distinct keys sort identically under any algorithm). */
+            for (int i = 1; i < A; ++i) {
+                const int vi = idx[i]; const double vk = key[i];
+                if (vk > key[0]) { memmove(&idx[1], &idx[0], sizeof(int) * i); memmove(&key[1], &key[0], sizeof(double) * i); idx[0] = vi; key[0] = vk; }
+                else { int j = i; while (vk > key[j - 1]) { idx[j] = idx[j - 1]; key[j] = key[j - 1]; --j; } idx[j] = vi; key[j] = vk; }
+            }
+            for (int i = 0; i < K; ++i) { act[i] = (float)idx[i]; logp_after[i] = probs[idx[i]]; }
+        }
+    }
+    for (int i = 0; i < K && !t->A_disc; ++i) {
         float prob_before = 1;
         double ysum = 0.;
         for (int j = 0; j < D; ++j) {
@@ -209,14 +259,15 @@ void stree_prepare(STree *t, float noise_w, const float *noises /* [B][K] or NUL
 {
     for (int i = 0; i < t->B; ++i) {
         SNode *pool = &t->nodes[(size_t)i * t->cap];
-        node_expand(t, i, 0, to_play[i], 0, i, value_prefixs[i], policies + (size_t)i * 2 * t->D,
+        node_expand(t, i, 0, to_play[i], 0, i, value_prefixs[i], policies + (size_t)i * t->pstride,
                     given ? given + (size_t)i * t->K * t->D : NULL);
         if (noises) {
             const int *rep = &t->rep[(((size_t)i * t->cap_exp) + 0) * t->K];
             for (int k = 0; k < t->K; ++k) {
                 SNode *child = &pool[pool[0].first_child + rep[k]];
                 const float prior = child->prior, noise = noises[(size_t)i * t->K + k];
-                child->prior = (float)log((double)(expf(prior) * (1 - noise_w) + noise * noise_w) + 1e-6);
+                if (t->A_disc) child->prior = prior * (1 - noise_w) + noise * noise_w;  /* prior is a probability (:474-477) */
+                else child->prior = (float)log((double)(expf(prior) * (1 - noise_w) + noise * noise_w) + 1e-6);
             }
         }
         pool[0].visit_count += 1;
@@ -355,7 +406,7 @@ void stree_backpropagate(STree *t, int latent_index, float discount, const float
 {
     for (int i = 0; i < t->B; ++i) {
         const int leaf = t->path[(size_t)i * t->cap + t->path_len[i] - 1];
-        node_expand(t, i, leaf, to_play[i], latent_index, i, value_prefixs[i], policies + (size_t)i * 2 * t->D,
+        node_expand(t, i, leaf, to_play[i], latent_index, i, value_prefixs[i], policies + (size_t)i * t->pstride,
                     given ? given + (size_t)i * t->K * t->D : NULL);
         t->nodes[(size_t)i * t->cap + leaf].is_reset = is_reset[i];
         backpropagate(t, i, to_play[i], values[i], discount);

@@ -20,7 +20,7 @@ ezs, h = build_ref.load_sampled("det")
 for name in sorted(sd.CASES):
     c = sd.make_inputs(sd.CASES[name])
     h.oracle_set_clock(CLOCK0)
-    out = sd.run_tree(ezs, c, lambda: ezs.Roots(c["B"], [[-1] * 5 for _ in range(c["B"])], c["D"], c["K"], True))
+    out = sd.run_tree(ezs, c, lambda: ezs.Roots(c["B"], [[-1] * 5 for _ in range(c["B"])], c.get("A") or c["D"], c["K"], not c.get("A")))
     np.savez_compressed(os.path.join(HERE, "sampled_%s.npz" % name), records=out["records"].astype(np.int16),
                         distributions=out["distributions"].astype(np.int16), values=out["values"],
                         root_actions=out["root_actions"], last_actions=out["last_actions"])

@@ -10,6 +10,10 @@ CASES = {
     "sez_collide": dict(B=4, D=1, K=12, S=30, seed=2, sigma_scale=1e-7),  # tiny sigma: duplicate "%f" keys
     "sez_2p": dict(B=6, D=3, K=8, S=40, seed=3, to_play="random12", discount=1.0),
     "sez_cfg5_b256": dict(B=256, D=1, K=20, S=50, seed=4),
+    # discrete action spaces (continuous_action_space=False): K of the A actions, policy = A logits, D = 1 (the action index)
+    "sez_disc_a6_k4": dict(B=8, D=1, K=4, S=40, seed=5, A=6),
+    "sez_disc_pendulum_a11_k5": dict(B=6, D=1, K=5, S=50, seed=6, A=11),  # pendulum_cont_disc_sampled_efficientzero_config.py
+    "sez_disc_k_eq_a": dict(B=4, D=1, K=4, S=30, seed=7, A=4),
 }
 
 
@@ -21,6 +25,8 @@ def make_inputs(case):
     B, D, K, S = c["B"], c["D"], c["K"], c["S"]
 
     def policy():
+        if c.get("A"):
+            return rng.standard_normal((B, c["A"])).astype(np.float32)
         mu = 0.5 * rng.standard_normal((B, D))
         sigma = (0.3 + rng.random((B, D))) * c["sigma_scale"]
         return np.concatenate([mu, sigma], 1).astype(np.float32)
@@ -52,7 +58,7 @@ def run_tree(mod, c, make_roots, before_expand=None, after_expand=None):
     for s in range(S):
         res = mod.ResultsWrapper(B)
         ix, iy, la, vtp = mod.batch_traverse(roots, c["pb_c_base"], c["pb_c_init"], c["discount"], mm, res,
-                                             list(c["to_play_list"]), True)
+                                             list(c["to_play_list"]), not c.get("A"))
         sl = res.get_search_len()
         rec[s, :, 0], rec[s, :, 1], rec[s, :, 2], rec[s, :, 3] = ix, iy, sl, vtp
         last[s] = np.asarray(la, np.float32).reshape(B, c["D"])

@@ -203,3 +203,51 @@ def test_policies_on_mlp_engine_models_full_size():
     assert np.abs(((z - mu[:, None]) / sig[:, None]).mean()) < 0.1
     ev = pol._forward_eval(obs, to_play=[-1] * B)
     assert all(sum(ev[i]["visit_count_distributions"]) >= S for i in range(B))
+
+
+def test_discrete_sampled_efficientzero_fused_and_policy():
+    """Sampled EfficientZero on a DISCRETE action space (cartpole_sampled_efficientzero_config.py shape: A = 2, K = 2 is degenerate;
+    use A = 7, K = 4): engine model + fused search with the oracle's draws injected reproduces the oracle pipeline; policy surface."""
+    from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    from lightzero_amd.policy.sampled_efficientzero import SampledEfficientZeroPolicy
+    B, A, K, S = 32, 7, 4, 30
+    ref = tm.synthetic_init(tm.SampledEfficientZeroModelMLP(observation_shape=6, action_space_size=A, continuous_action_space=False,
+                                                            num_of_sampled_actions=K), seed=11)
+    model = SampledEfficientZeroModelMLP(observation_shape=6, action_space_size=A, continuous_action_space=False,
+                                         num_of_sampled_actions=K).load_state_dict(ref.state_dict())
+    obs = torch.randn(B, 6, generator=torch.Generator().manual_seed(8))
+    cfg = dict(CFG, num_simulations=S, model=dict(action_space_size=A, num_of_sampled_actions=K, continuous_action_space=False))
+    with torch.no_grad():
+        o = ref.initial_inference(obs)
+    noises = np.random.default_rng(0).dirichlet([0.3] * K, size=B).astype(np.float32).tolist()
+    oroots = octree.ezs_tree.Roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
+    oroots.set_clock(99)
+    oroots.prepare(0.25, noises, [0.] * B, o.policy_logits.numpy().tolist(), [-1] * B)
+
+    class _Disc(object):  # the oracle driver feeds float last_actions; a discrete model wants indices
+        def eval(self):
+            return self
+
+        def recurrent_inference(self, z, hc, a):
+            return ref.recurrent_inference(z, hc, a.reshape(-1).long())
+    osearch.sez_search(octree.ezs_tree, oroots, _Disc(), o.latent_state.numpy(),
+                       (o.reward_hidden_state[0].numpy(), o.reward_hidden_state[1].numpy()), [-1] * B, cfg)
+    draws = np.stack([np.asarray(oroots.get_sampled_actions(e), np.float32).reshape(B, K, 1) for e in range(S + 1)])
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
+    roots.set_tiebreak(0)
+    out = model.initial_inference(obs, roots)
+    assert _rel(out.policy_logits, o.policy_logits.numpy()) < 2e-5
+    roots.set_given_records(draws)
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    same = sum(int(a == b) for a, b in zip(roots.get_distributions(), oroots.get_distributions()))
+    assert same >= B - 2, "only %d / %d visit-count distributions identical" % (same, B)
+    roots.set_given_records(None)
+    policy = SampledEfficientZeroPolicy(cfg, model)
+    res = policy._forward_collect(obs, temperature=1.0, to_play=[-1] * B)
+    for i in range(B):
+        assert isinstance(res[i]["action"], int) and 0 <= res[i]["action"] < A
+        acts = res[i]["root_sampled_actions"].reshape(-1)
+        assert len(set(acts.tolist())) == K and sum(res[i]["visit_count_distributions"]) == S

@@ -23,13 +23,13 @@ def test_device_sampled_tree_matches_oracle_with_injected_draws(name):
     draws = {}
 
     def mk_o():
-        r = octree.ezs_tree.Roots(c["B"], [[-1] * 5] * c["B"], c["D"], c["K"], True, max_simulations=c["S"])
+        r = octree.ezs_tree.Roots(c["B"], [[-1] * 5] * c["B"], c.get("A") or c["D"], c["K"], not c.get("A"), max_simulations=c["S"])
         r.set_clock(CLOCK0)
         return r
     ora = sd.run_tree(octree.ezs_tree, c, mk_o, after_expand=lambda r, e: draws.__setitem__(e, np.asarray(r.get_sampled_actions(e), np.float32)))
 
     def mk_d():
-        r = ezs_tree.Roots(c["B"], [[-1] * 5] * c["B"], c["D"], c["K"], True, max_simulations=c["S"])
+        r = ezs_tree.Roots(c["B"], [[-1] * 5] * c["B"], c.get("A") or c["D"], c["K"], not c.get("A"), max_simulations=c["S"])
         r.set_tiebreak(0)
         return r
     dev = sd.run_tree(ezs_tree, c, mk_d, before_expand=lambda r, e: setattr(r, "given", draws[e]))
@@ -150,3 +150,31 @@ def test_sampled_driver_and_policy_with_foreign_model():
     assert o0["root_sampled_actions"].shape == (K, D) and len(o0["visit_count_distributions"]) == K
     assert sum(o0["visit_count_distributions"]) == S and o0["action"].shape == (D,)
     assert any(np.allclose(o0["action"], a) for a in o0["root_sampled_actions"])
+
+
+def test_device_side_discrete_sampling_without_replacement():
+    """continuous_action_space=False (cnode.cpp:288-327): every node holds K DISTINCT action indices; sampling K of A without
+    replacement through the keys u^(1/p) is the Efraimidis-Spirakis scheme, whose first draw follows p exactly."""
+    from lightzero_amd.mcts.ctree.ctree_sampled_efficientzero import ezs_tree
+    B, A, K, S = 2048, 11, 5, 12
+    rng = np.random.default_rng(3)
+    logits = np.tile(rng.standard_normal((1, A)).astype(np.float32), (B, 1))
+    roots = ezs_tree.Roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
+    roots.prepare_no_noise([0.0] * B, logits.tolist(), [-1] * B)
+    acts = np.asarray(roots.get_sampled_actions(), np.float32).reshape(B, K)
+    assert np.array_equal(acts, np.rint(acts)) and acts.min() >= 0 and acts.max() < A
+    assert all(len(set(row.tolist())) == K for row in acts)
+    p = np.exp(logits[0].astype(np.float64)); p /= p.sum()
+    first = np.bincount(acts[:, 0].astype(int), minlength=A) / B
+    assert np.abs(first - p).max() < 0.04
+    mm = ezs_tree.MinMaxStatsList(B)
+    mm.set_delta(0.01)
+    for s in range(S):
+        res = ezs_tree.ResultsWrapper(B)
+        ix, iy, la, vtp = ezs_tree.batch_traverse(roots, 19652, 1.25, 0.997, mm, res, [-1] * B, False)
+        la = np.asarray(la).reshape(B)
+        assert np.array_equal(la, np.rint(la)) and la.min() >= 0 and la.max() < A
+        ezs_tree.batch_backpropagate(s + 1, 0.997, rng.standard_normal(B).astype(np.float32).tolist(),
+                                     rng.standard_normal(B).astype(np.float32).tolist(), rng.standard_normal((B, A)).astype(np.float32).tolist(),
+                                     mm, res, [0] * B, vtp)
+    assert (np.asarray(roots.get_distributions()).sum(1) == S).all()

@@ -15,7 +15,7 @@ CLOCK0 = 123456789
 
 def _run_oracle(c):
     def mk():
-        r = octree.ezs_tree.Roots(c["B"], [[-1] * 5] * c["B"], c["D"], c["K"], True, max_simulations=c["S"])
+        r = octree.ezs_tree.Roots(c["B"], [[-1] * 5] * c["B"], c.get("A") or c["D"], c["K"], not c.get("A"), max_simulations=c["S"])
         r.set_clock(CLOCK0)
         return r
     return sd.run_tree(octree.ezs_tree, c, mk)
@@ -28,7 +28,7 @@ def test_sampled_oracle_matches_compiled_reference(name):
     ezs, h = build_ref.load_sampled("det")
     c = sd.make_inputs(sd.CASES[name])
     h.oracle_set_clock(CLOCK0)
-    ref = sd.run_tree(ezs, c, lambda: ezs.Roots(c["B"], [[-1] * 5 for _ in range(c["B"])], c["D"], c["K"], True))
+    ref = sd.run_tree(ezs, c, lambda: ezs.Roots(c["B"], [[-1] * 5 for _ in range(c["B"])], c.get("A") or c["D"], c["K"], not c.get("A")))
     ora = _run_oracle(c)
     sd.assert_same(ref, ora, name)
     if name == "sez_collide":  # the duplicate-key path must actually be exercised
