@@ -33,12 +33,23 @@ CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_facto
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
 
 
-def cpu_baseline(ref_model, obs_cpu, noises, budget_s=25.0, device="cpu"):
+def _reference_model(weights):
+    """the oracle's torch restatement of EfficientZeroModel carrying the benchmark's weights (baseline legs only)"""
+    import torch
+    from oracle import torch_models as tm
+    m = tm.EfficientZeroModel(action_space_size=ACTIONS)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    return m.eval()
+
+
+def cpu_baseline(weights, obs_cpu, noises, budget_s=25.0, device="cpu"):
     """The reference pipeline on the host cores: reference ctree (compiled from its own sources when
     oracle/_ref is present, else the C restatement) + restated Python driver + torch fp32 model.
     device="cuda" is SURVEY.md 8d's second arm, the reference as deployed with cuda=True: same driver and
     host ctree, torch model on the MI355X through stock PyTorch-ROCm (MIOpen / rocBLAS)."""
     import torch
+    ref_model = _reference_model(weights)
     if device != "cpu":
         ref_model = ref_model.to(device)
         obs_cpu = obs_cpu.to(device)
@@ -60,7 +71,6 @@ def cpu_baseline(ref_model, obs_cpu, noises, budget_s=25.0, device="cpu"):
         t_used += time.perf_counter() - t0
         n += 1
     if device != "cpu":
-        ref_model.to("cpu")
         return dict(value=ENVS * n / t_used, unit="env-steps/s", cores=1, kind="port",
                     sample="%d full env-step batches after warm-up; %s on 1 host thread + restated driver + torch fp32 model on "
                            "the MI355X via stock PyTorch-ROCm (the reference with cuda=True); %.1f s" % (n, kind_tree, t_used))
@@ -94,12 +104,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from oracle import torch_models as tm  # synthetic weights of the named architecture (no checkpoints offline)
     from lightzero_amd import _lib as L, shard
+    from lightzero_amd.model.synthetic import efficientzero_state_dict  # seeded random-init weights (no checkpoints offline)
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
     lib = L.lib()
-    ref_model = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=ACTIONS), seed=0)
+    weights = efficientzero_state_dict(seed=0, action_space_size=ACTIONS)
     NS = max(1, args.streams)
     assert ENVS % NS == 0
     EPS = ENVS // NS  # envs per sub-batch
@@ -111,7 +121,7 @@ def main():
             e = L.P()
             L.check(lib.lz_engine_create(local_rank, ctypes.byref(e)))
         engs.append(e)
-        models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e).load_state_dict(ref_model.state_dict()))
+        models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e).load_state_dict(weights))
     eng = engs[0]
     g = torch.Generator().manual_seed(1000 + rank)
     obs_cpu = torch.rand(ENVS, 4, 96, 96, generator=g)
@@ -220,10 +230,10 @@ def main():
                          "algorithmic_flop_per_launch": EPS * FLOP_CHAIN},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]])
+            out["cpu_baseline"] = cpu_baseline(weights, obs_cpu, [z.tolist() for z in noise_steps[0]])
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             try:
-                out["deployed_baseline"] = cpu_baseline(ref_model, obs_cpu, [z.tolist() for z in noise_steps[0]], device="cuda")
+                out["deployed_baseline"] = cpu_baseline(weights, obs_cpu, [z.tolist() for z in noise_steps[0]], device="cuda")
                 out["config"]["speedup_vs_deployed_baseline"] = value / out["deployed_baseline"]["value"]
             except Exception as e:  # the reported baselines never take the measured line down with them
                 out["deployed_baseline"] = {"error": repr(e)}

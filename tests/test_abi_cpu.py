@@ -37,3 +37,12 @@ def test_no_gpu_means_loud_failure_not_fallback():
     roots = ez_tree.Roots(1, [[0, 1]])
     with pytest.raises(L.LzError):
         roots.prepare_no_noise([0.0], [[0.0, 0.0]], [-1])
+
+
+def test_synthetic_state_dict_matches_reference_layout():
+    """the benchmark's seeded weights (product code, no oracle import) carry exactly the reference model's tensor names / shapes"""
+    from oracle import torch_models as tm
+    from lightzero_amd.model.synthetic import efficientzero_state_dict
+    sd = efficientzero_state_dict(seed=0, action_space_size=6)
+    ref = {k: tuple(v.shape) for k, v in tm.EfficientZeroModel(action_space_size=6).state_dict().items() if "num_batches" not in k}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == ref

@@ -2,7 +2,8 @@
 """Timing of the vector-observation configurations of BASELINE.json on one MI355X (not the headline bench line):
 configs[0] CartPole MuZero MLP (8 envs x 25 sims) and configs[4] Sampled EfficientZero DMC state (K = 20, 64 envs per GPU
 x 50 sims; --envs 256 for the whole 4-GPU batch on one device).  Search only (initial inference -> prepare -> fused
-search -> read-back), inputs resident in HBM, synthetic seeded weights.
+search -> read-back), inputs resident in HBM, synthetic seeded weights (development tool: it borrows the torch restatements under
+oracle/ to produce reference-format state_dicts for these architectures; nothing of oracle/ runs in the timed loop).
 
     python tools/bench_mlp_configs.py --config 4 --envs 256 --steps 50
 """

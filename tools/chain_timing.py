@@ -6,13 +6,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("LZ_DEBUG_CHAIN_TS", "1"); os.environ.setdefault("LZ_NO_GRAPH", "1")
 import torch
-from oracle import torch_models as tm
 from lightzero_amd import _lib as L
 from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
 from lightzero_amd.model.efficientzero_model import EfficientZeroModel
 lib = L.lib()
-ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=6), seed=0)
-model = EfficientZeroModel(action_space_size=6).load_state_dict(ref.state_dict())
+from lightzero_amd.model.synthetic import efficientzero_state_dict
+model = EfficientZeroModel(action_space_size=6).load_state_dict(efficientzero_state_dict(seed=0, action_space_size=6))
 B, S = 256, 50
 roots = ez_tree.Roots(B, [list(range(6))] * B, action_space_size=6, max_simulations=S); roots._ensure(6)
 obs = torch.rand(B, 4, 96, 96).cuda()
