@@ -183,6 +183,7 @@ int lz_roots_upload_legal(lz_roots *r, const int32_t *h_legal_flat, const int32_
             off += n;
         }
     }
+    r->h_n_legal.assign(hn, hn + B);
     hipStream_t s = r->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(t.legal, hl, (size_t)B * A * 4, hipMemcpyHostToDevice, s));
     LZ_HIP_CHECK(hipMemcpyAsync(t.n_legal, hn, (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -232,6 +233,8 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     if (r->pool_slab) (void)hipFree(r->pool_slab);
     if (r->d_obs) (void)hipFree(r->d_obs);
     if (r->d_given) (void)hipFree(r->d_given);
+    if (r->h_prep) (void)hipHostFree(r->h_prep);
+    if (r->prep_done) (void)hipEventDestroy(r->prep_done);
     if (r->d_reuse) (void)hipFree(r->d_reuse);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);

@@ -124,6 +124,10 @@ struct lz_roots {
     int32_t *d_noise_off = nullptr; // [B]
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
+    std::vector<int32_t> h_n_legal;  // host copy of n_legal (noise offsets without a device round trip)
+    void *h_prep = nullptr;          // pinned staging of prepare_from_inference (noise | offsets | to_play), own buffer so that the
+    size_t prep_bytes = 0;           // upload can stay asynchronous
+    hipEvent_t prep_done = nullptr;  // recorded after that upload: the buffer is rewritten only once it has fired
     int g_sims = -1, g_m = -1;      // Gumbel MuZero: (num_simulations, max_num_considered_actions) of the uploaded visit table
     void *d_reuse = nullptr;        // ReZero fused search: true_action [B] | reuse_value [B] | per-simulation inference counts [NN]
     float *d_given = nullptr;       // Sampled-EZ parity runs: [records][B][K][D] injected draws (record 0 = roots, s + 1 = simulation s)

@@ -495,19 +495,39 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
         for (size_t i = 1; i < B; ++i) if (h_to_play[i] > largest) largest = h_to_play[i];
         players = largest == -1 ? 1 : 2;
     }
-    LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, h_to_play, B * 4, hipMemcpyHostToDevice, s));
+    // everything the kernel needs from the host goes through one pinned buffer and one asynchronous copy: no host-device
+    // synchronisation between lz_initial_inference and lz_search (the next graph launch queues behind the network kernels)
     const float *d_noise = nullptr;
-    if (h_noises_flat) {
-        std::vector<int32_t> nl(B), off(B);
-        LZ_HIP_CHECK(hipMemcpyAsync(nl.data(), t.n_legal, B * 4, hipMemcpyDeviceToHost, s));
-        LZ_HIP_CHECK(hipStreamSynchronize(s));
-        size_t acc = 0;
-        for (size_t i = 0; i < B; ++i) { off[i] = (int32_t)acc; acc += nl[i]; }
-        if (acc > B * A) { lz_set_error("noise count exceeds root_num * action_space_size"); return LZ_ERR_INVALID; }
-        LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise, h_noises_flat, acc * 4, hipMemcpyHostToDevice, s));
-        LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise_off, off.data(), B * 4, hipMemcpyHostToDevice, s));
-        LZ_HIP_CHECK(hipStreamSynchronize(s));
-        d_noise = r->d_noise;
+    {
+        size_t n_noise = 0;
+        if (h_noises_flat) {
+            if (r->h_n_legal.size() != B) { lz_set_error("legal-action counts of these roots are unknown"); return LZ_ERR_STATE; }
+            for (size_t i = 0; i < B; ++i) n_noise += (size_t)r->h_n_legal[i];
+            if (n_noise > B * A) { lz_set_error("noise count exceeds root_num * action_space_size"); return LZ_ERR_INVALID; }
+        }
+        const size_t need = (2 * B + n_noise) * 4;
+        if (need > r->prep_bytes) {
+            if (r->prep_done) LZ_HIP_CHECK(hipEventSynchronize(r->prep_done));
+            if (r->h_prep) (void)hipHostFree(r->h_prep);
+            r->h_prep = nullptr; r->prep_bytes = 0;
+            LZ_HIP_CHECK(hipHostMalloc(&r->h_prep, need + 4096, hipHostMallocDefault));
+            r->prep_bytes = need + 4096;
+        }
+        if (!r->prep_done) LZ_HIP_CHECK(hipEventCreateWithFlags(&r->prep_done, hipEventDisableTiming));
+        else LZ_HIP_CHECK(hipEventSynchronize(r->prep_done));  // the previous upload has left the buffer
+        int32_t *hp = (int32_t *)r->h_prep;
+        memcpy(hp, h_to_play, B * 4);
+        LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, hp, B * 4, hipMemcpyHostToDevice, s));
+        if (h_noises_flat) {
+            int32_t *ho = hp + B;
+            size_t acc = 0;
+            for (size_t i = 0; i < B; ++i) { ho[i] = (int32_t)acc; acc += (size_t)r->h_n_legal[i]; }
+            memcpy(hp + 2 * B, h_noises_flat, n_noise * 4);
+            LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise_off, ho, B * 4, hipMemcpyHostToDevice, s));
+            LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise, hp + 2 * B, n_noise * 4, hipMemcpyHostToDevice, s));
+            d_noise = r->d_noise;
+        }
+        LZ_HIP_CHECK(hipEventRecord(r->prep_done, s));
     }
     if (t.variant == LZ_TREE_GUMBEL_MUZERO)  // roots.prepare(noise_w, noises, reward_roots = 0, pred_values, policy_logits, to_play), gumbel_muzero.py:562
         lz_gtree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_value, r->sim_logits, r->d_to_play, s);
