@@ -156,9 +156,7 @@ def main():
             sl = slice(k * EPS, (k + 1) * EPS)
             d = np.zeros((EPS, ACTIONS), np.int32); c = np.zeros(EPS, np.int32); v = np.zeros(EPS, np.float32)
             p = np.zeros(EPS, np.float32); lg = np.zeros((EPS, ACTIONS), np.float32)
-            L.check(lib.lz_roots_get_distributions(r._h, d, c))
-            L.check(lib.lz_roots_get_values(r._h, v))
-            L.check(lib.lz_roots_get_root_outputs(r._h, p, lg.reshape(-1)))
+            L.check(lib.lz_roots_get_search_results(r._h, d, c, v, p.ctypes.data, lg.ctypes.data))
             dist_out[sl], cnt_out[sl], val_out[sl], pred_out[sl], logit_out[sl] = d, c, v, p, lg
         if world > 1:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI)
             rows = np.concatenate([np.zeros((ENVS, 1), np.float32), val_out[:, None], pred_out[:, None],

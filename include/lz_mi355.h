@@ -245,6 +245,11 @@ int lz_initial_inference(lz_roots *r, const float *d_obs);
 /* same from a HOST observation batch (staged through HBM; the PCIe copy is on the engine stream) */
 int lz_initial_inference_host(lz_roots *r, const float *h_obs);
 int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits);
+/* everything _forward_collect reads back after a fused search (efficientzero.py:616-643) in one readout launch, one
+ * device-to-host copy and one synchronisation: get_distributions (+ counts), get_values, and the root predictions of
+ * lz_initial_inference (h_pred_values / h_policy_logits may be NULL) */
+int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
+                                float *h_pred_values, float *h_policy_logits);
 /* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
  * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
 int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,

@@ -73,6 +73,7 @@ def lib():
         "lz_sroots_get_distributions": [P, c_i32p],
         "lz_sroots_get_sampled_actions": [P, c_f32p],
         "lz_sroots_set_given": [P, P, ctypes.c_int],
+        "lz_roots_get_search_results": [P, c_i32p, c_i32p, c_f32p, P, P],
         "lz_groots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_f32p, c_i32p],
         "lz_gbatch_traverse": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "lz_gbatch_back_propagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p],

@@ -234,6 +234,8 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     if (r->d_obs) (void)hipFree(r->d_obs);
     if (r->d_given) (void)hipFree(r->d_given);
     if (r->h_prep) (void)hipHostFree(r->h_prep);
+    if (r->d_results) (void)hipFree(r->d_results);
+    if (r->h_results) (void)hipHostFree(r->h_results);
     if (r->prep_done) (void)hipEventDestroy(r->prep_done);
     if (r->d_reuse) (void)hipFree(r->d_reuse);
     if (r->h_stage) (void)hipHostFree(r->h_stage);

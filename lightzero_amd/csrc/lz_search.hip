@@ -443,6 +443,43 @@ extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, floa
     return LZ_OK;
 }
 
+// everything _forward_collect reads back after a search, in ONE readout launch, one device-to-host copy and one
+// synchronisation: visit-count distributions (+ counts), root values, and the root predictions of lz_initial_inference
+extern "C" int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
+                                           float *h_pred_values, float *h_policy_logits)
+{
+    LZ_REQUIRE(r != nullptr && h_out_dist != nullptr && h_out_count != nullptr && h_out_values != nullptr, "NULL argument");
+    LZ_REQUIRE(r->prepared && r->inferred && r->pool_slab != nullptr, "roots not searched through the fused path");
+    LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "use the lz_sroots_* getters for sampled roots");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, A = t.A;
+    const size_t PA = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : A;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    // layout of the result block: dist [B][A] | count [B] | values [B] | pred values [B] | logits [B][PA]
+    const size_t n_i = B * A + B, n_f = 2 * B + B * PA, bytes = (n_i + n_f) * 4;
+    if (!r->d_results) {
+        LZ_HIP_CHECK(hipMalloc(&r->d_results, bytes));
+        LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
+    }
+    int32_t *d_dist = (int32_t *)r->d_results, *d_cnt = d_dist + B * A;
+    float *d_val = (float *)(d_cnt + B), *d_pred = d_val + B, *d_lg = d_pred + B;
+    lz_tree_launch_readout(t, d_dist, d_cnt, d_val, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    if (h_pred_values) LZ_HIP_CHECK(hipMemcpyAsync(d_pred, r->sim_value, B * 4, hipMemcpyDeviceToDevice, s));
+    if (h_policy_logits) LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_results, r->d_results, bytes, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    const int32_t *hi = (const int32_t *)r->h_results;
+    const float *hf = (const float *)(hi + n_i);
+    memcpy(h_out_dist, hi, B * A * 4);
+    memcpy(h_out_count, hi + B * A, B * 4);
+    memcpy(h_out_values, hf, B * 4);
+    if (h_pred_values) memcpy(h_pred_values, hf + B, B * 4);
+    if (h_policy_logits) memcpy(h_policy_logits, hf + 2 * B, B * PA * 4);
+    return LZ_OK;
+}
+
 extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records)
 {
     LZ_REQUIRE(r != nullptr && r->t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO, "not a Sampled-EfficientZero roots handle");

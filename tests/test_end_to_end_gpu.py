@@ -222,3 +222,25 @@ def test_search_with_reuse_fused_and_foreign_vs_oracle_pipeline():
     if same == B:
         assert (a_len, a_avg) == (o_len, o_avg)
     assert abs(a_avg - o_avg) < 0.1 * B
+
+
+def test_packed_search_results_equal_the_individual_getters():
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    B, A, S = 16, 6, 12
+    ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A))
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(2)).cuda().contiguous()
+    legal = [[0, 2, 5]] * 4 + [list(range(A))] * (B - 4)
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    out = model.initial_inference(obs, roots)
+    roots.prepare_from_inference_no_noise([-1] * B)
+    L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+    d = np.zeros((B, A), np.int32); c = np.zeros(B, np.int32); v = np.zeros(B, np.float32); p = np.zeros(B, np.float32)
+    lg = np.zeros((B, A), np.float32)
+    L.check(L.lib().lz_roots_get_search_results(roots._h, d, c, v, p.ctypes.data, lg.ctypes.data))
+    assert [d[i, :c[i]].tolist() for i in range(B)] == roots.get_distributions()
+    assert np.array_equal(v, np.asarray(roots.get_values(), np.float32))
+    assert np.array_equal(p, out.value) and np.array_equal(lg, out.policy_logits)
