@@ -623,12 +623,16 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
             if (s + 1 < 36) fetch_a(sIn, s + 1, af[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     if (SMALL_REM && i == MF) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
                     else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af[s & 1][i], j), vget(bfr, j), acc[i], 0, 0, 0);
                 }
+                // keep the short 4x4x1 instructions spread between the 16x16x4 ones: grouped at the end of the step (where
+                // the scheduler puts them) each waits on its predecessor (s_nop), interleaved none does
+                if (SMALL_REM) __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         LZ_TS();
