@@ -121,7 +121,10 @@ def make_module(variant, has_deterministic_flag):
         def prepare_from_inference(self, root_noise_weight, noises, to_play_batch):
             """Roots.prepare with the policy logits an engine model's initial_inference left in HBM
             (value prefix 0, efficientzero_model.py:238); noises: one list per root over its legal actions."""
-            nz = L.f32([x for row in noises for x in row] or [0.0])
+            if isinstance(noises, np.ndarray):  # [root_num][n_legal] rows of equal length
+                nz = np.ascontiguousarray(noises, np.float32).reshape(-1)
+            else:
+                nz = np.concatenate([np.asarray(row, np.float32).reshape(-1) for row in noises]) if len(noises) else np.zeros(1, np.float32)
             L.check(L.lib().lz_roots_prepare_from_inference(self._h, float(root_noise_weight), nz.ctypes.data,
                                                             L.i32(to_play_batch)))
 
@@ -154,6 +157,15 @@ def make_module(variant, has_deterministic_flag):
                 row = out[i].tolist()
                 res.append(row[:row.index(-1)])
             return res
+
+        def get_search_results(self, policy_width=None):
+            """After a fused search: (visit counts [B][A] int32, -1 padded; legal counts [B]; root values [B]; predicted root values
+            [B]; root policy logits [B][policy_width]) in ONE read-back (lz_roots_get_search_results)."""
+            B, A = self.root_num, self._A
+            dist = np.zeros((B, A), np.int32); cnt = np.zeros(B, np.int32); val = np.zeros(B, np.float32)
+            pred = np.zeros(B, np.float32); lg = np.zeros((B, policy_width or A), np.float32)
+            L.check(L.lib().lz_roots_get_search_results(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data))
+            return dist, cnt, val, pred, lg
 
         def select_action(self, temperature=1, deterministic=True, seed=None):
             """select_action (lzero/policy/utils.py:637-661) for every root on the device: returns (action positions

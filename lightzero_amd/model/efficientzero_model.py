@@ -62,14 +62,15 @@ class EfficientZeroModel(object):
 
     _is_lz_engine_model = True
 
-    def initial_inference(self, obs, roots):
+    def initial_inference(self, obs, roots, fetch=True):
         """EfficientZeroModel.initial_inference (efficientzero_model.py:203-238) for the batch held by ``roots``
         (a lightzero_amd ez_tree.Roots): the latent state and the zero LSTM state are written into the roots'
         HBM pools (slot 0) instead of being returned.  ``obs``: [B,C,H,W] fp32 -- a device tensor exposing
         ``data_ptr()`` (used in place) or a host numpy array (staged over PCIe).
         Returns an ``EZNetworkOutput``-like namespace: ``value`` is already passed through
         InverseScalarTransform (shape [B]), ``value_prefix`` is ``[0.]*B``, ``policy_logits`` is [B,A] numpy;
-        ``latent_state`` / ``reward_hidden_state`` are opaque tokens bound to ``roots``."""
+        ``latent_state`` / ``reward_hidden_state`` are opaque tokens bound to ``roots``.  ``fetch=False`` skips the read-back
+        (and its synchronisation) and returns None."""
         if not self._loaded:
             raise L.LzError("EfficientZeroModel: load_state_dict has not been called")
         B = roots.num
@@ -89,6 +90,10 @@ class EfficientZeroModel(object):
                 raise ValueError("obs must be [B,C,H,W]")
             L.check(L.lib().lz_initial_inference_host(roots._h, arr.reshape(-1)))
         roots._inferred_by = self
+        if not fetch:
+            # the caller reads the root predictions after the search (Roots.get_search_results): no host-device
+            # synchronisation between the representation network and the search
+            return None
         values = np.zeros(B, np.float32)
         logits = np.zeros((B, self.action_space_size), np.float32)
         L.check(L.lib().lz_roots_get_root_outputs(roots._h, values, logits.reshape(-1)))

@@ -45,7 +45,7 @@ class _EngineModelMLP(EfficientZeroModel):
         L.check(L.lib().lz_model_create(self._engine, ctypes.byref(cfg)))
         self._loaded = False
 
-    def initial_inference(self, obs, roots):
+    def initial_inference(self, obs, roots, fetch=True):
         """initial_inference for the batch held by ``roots``; ``obs``: [B, observation_shape] fp32 (device tensor or host
         array).  Same return contract as the convolutional engine models; ``policy_logits`` is [B, A] (or [B, 2 D] =
         (mu | sigma) for continuous actions)."""
@@ -67,6 +67,8 @@ class _EngineModelMLP(EfficientZeroModel):
                 raise ValueError("obs must be [B, observation_shape]")
             L.check(L.lib().lz_initial_inference_host(roots._h, arr.reshape(-1)))
         roots._inferred_by = self
+        if not fetch:
+            return None
         values = np.zeros(B, np.float32)
         logits = np.zeros((B, self._policy_width), np.float32)
         L.check(L.lib().lz_roots_get_root_outputs(roots._h, values, logits.reshape(-1)))

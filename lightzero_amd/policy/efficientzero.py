@@ -17,6 +17,14 @@ def _g(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
+class _HbmTokens(object):
+    """stands in for the network output of an engine model whose latent / LSTM state stayed in HBM"""
+
+    def __init__(self, roots):
+        self.latent_state = ("hbm-pool", roots)
+        self.reward_hidden_state = ("hbm-pool", roots)
+
+
 class EfficientZeroPolicy(object):
     def __init__(self, cfg, model):
         """cfg: the reference policy config (dict / EasyDict-like): num_simulations, discount_factor,
@@ -74,15 +82,28 @@ class EfficientZeroPolicy(object):
         to_play = list(to_play) if len(to_play) == active_collect_env_num else [to_play[0]] * active_collect_env_num
         legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_collect_env_num)]
         roots = self._roots(active_collect_env_num, legal_actions)
-        network_output = self._collect_model.initial_inference(data, roots)
-        pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
         alpha = self._mcfg["root_dirichlet_alpha"]
-        noises = [np.random.dirichlet([alpha] * int(sum(action_mask[j]))).astype(np.float32).tolist()
-                  for j in range(active_collect_env_num)]  # efficientzero.py:599-602
-        roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
-        self._search(self._mcts_collect, roots, self._collect_model, network_output, to_play)
-        roots_visit_count_distributions = roots.get_distributions()
-        roots_values = roots.get_values()
+        counts = [len(l) for l in legal_actions]
+        if len(set(counts)) == 1:  # one vectorised draw instead of one np.random.dirichlet call per env (efficientzero.py:599-602)
+            noises = np.random.dirichlet([alpha] * counts[0], size=active_collect_env_num).astype(np.float32)
+        else:
+            noises = [np.random.dirichlet([alpha] * c).astype(np.float32) for c in counts]
+        fused = getattr(self._collect_model, "_is_lz_engine_model", False) and hasattr(roots, "get_search_results")
+        if fused:
+            # no read-back (and no synchronisation) before the search: predictions come back with the search results
+            self._collect_model.initial_inference(data, roots, fetch=False)
+            roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
+            self._search(self._mcts_collect, roots, self._collect_model, _HbmTokens(roots), to_play)
+            dist, cnt, roots_values, pred_values, logits = roots.get_search_results()
+            roots_visit_count_distributions = [dist[i, :cnt[i]].tolist() for i in range(active_collect_env_num)]
+            policy_logits = logits.tolist()
+        else:
+            network_output = self._collect_model.initial_inference(data, roots)
+            pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
+            roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
+            self._search(self._mcts_collect, roots, self._collect_model, network_output, to_play)
+            roots_visit_count_distributions = roots.get_distributions()
+            roots_values = roots.get_values()
         eps_cfg = _g(self._cfg, "eps", {}) or {}
         eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
         if self._device_select:

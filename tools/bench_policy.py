@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Wall time of the POLICY surface (EfficientZeroPolicy._forward_collect: what a collector calls once per env-step) at
+BASELINE configs[1] -- search plus the host-side glue (noise draws, read-back, select_action, output dict)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from lightzero_amd.model.efficientzero_model import EfficientZeroModel  # noqa: E402
+from lightzero_amd.model.synthetic import efficientzero_state_dict  # noqa: E402
+from lightzero_amd.policy.efficientzero import EfficientZeroPolicy  # noqa: E402
+
+B, A = 256, 6
+model = EfficientZeroModel(action_space_size=A).load_state_dict(efficientzero_state_dict(seed=0, action_space_size=A))
+obs = torch.rand(B, 4, 96, 96).cuda()
+mask = np.ones((B, A), np.float32)
+for dev_sel in (False, True):
+    pol = EfficientZeroPolicy(dict(num_simulations=50, discount_factor=0.997, lstm_horizon_len=5, device_select_action=dev_sel), model)
+    for _ in range(3):
+        pol._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B)
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        out = pol._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B)
+    dt = (time.perf_counter() - t0) / n
+    print("device_select_action=%s: %.2f ms per _forward_collect (%d envs) -> %.0f env-steps/s" % (dev_sel, dt * 1e3, B, B / dt))
