@@ -280,6 +280,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_big(lz_conv_args a, int npix_ma
             af[i] = *reinterpret_cast<const f32x4 *>(sAl + off + g * 16);
         }
     };
+    // the epilogue's operands do not depend on the accumulators: request them before the K loop (unconditional, clamped
+    // loads; a load inside the epilogue's per-element conditions costs one exposed memory round trip each)
+    const int col = nt * 16 + (lane & 15);
+    const float sc = a.scale[col], sh = a.shift[col];
+    const float *resp = a.residual ? a.residual : a.out;  // dummy: valid memory, switched off by a select
+    const bool has_res = a.residual != nullptr, relu = a.relu != 0;
+    float rv[MTW][4];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = min(m0 + (mg * MTW + i) * 16 + 4 * (lane >> 4) + q, m1);
+            rv[i][q] = resp[(size_t)m * COUT + col];
+        }
     f32x4 af[2][MTW];
     fetch_a(0, af[0]);
 #pragma unroll
@@ -295,19 +309,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_big(lz_conv_args a, int npix_ma
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][i][j], bfr[j], acc[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    const int col = nt * 16 + (lane & 15);
-    const float sc = a.scale[col], sh = a.shift[col];
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m = m0 + (mg * MTW + i) * 16 + 4 * (lane >> 4) + q;
-            if (m <= m1) {
-                float v = acc[i][q] * sc + sh;
-                if (a.residual) v += a.residual[(size_t)m * COUT + col];
-                if (a.relu) v = fmaxf(v, 0.0f);
-                a.out[(size_t)m * COUT + col] = v;
-            }
+            float v = acc[i][q] * sc + sh;
+            v += has_res ? rv[i][q] : 0.0f;
+            v = relu ? fmaxf(v, 0.0f) : v;
+            if (m <= m1) a.out[(size_t)m * COUT + col] = v;
         }
 }
 
