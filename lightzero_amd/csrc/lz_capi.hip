@@ -98,7 +98,7 @@ static int ensure_stage(lz_roots *r, size_t bytes)
     r->stage_bytes = 0;
     bytes = align_up(bytes, 4096);
     LZ_HIP_CHECK(hipHostMalloc(&r->h_stage, bytes, hipHostMallocDefault));
-    LZ_HIP_CHECK(hipMalloc(&r->d_stage, bytes));
+    LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_stage, bytes));
     r->stage_bytes = bytes;
     return LZ_OK;
 }
@@ -122,7 +122,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
                  o_bidx = take(nBN * 4), o_noinf = take((size_t)B * 4),
                  o_raw = take(variant == LZ_TREE_GUMBEL_MUZERO ? nBN * 4 : 0), o_gum = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)A * 4 : 0),
                  o_cons = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)t.NN * 4 : 0);
-    hipError_t err = hipMalloc(&r->slab, off);
+    hipError_t err = lz_dev_malloc((void **)&r->slab, off);
     if (err != hipSuccess) {
         delete r;
         lz_set_error("hipMalloc(%zu bytes) for the node pool failed: %s", off, hipGetErrorString(err));
@@ -140,7 +140,10 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.actions = D ? (float *)(base + o_act) : nullptr; t.res_last_action_f = D ? (float *)(base + o_laf) : nullptr;
     t.rng_epoch = (uint32_t *)(base + o_ep);
     t.node_bidx = (int32_t *)(base + o_bidx); t.res_noinf = (int32_t *)(base + o_noinf);
-    (void)hipMemset(r->slab, 0, off);  // no kernel may depend on what the allocator handed back (epoch, legal lists, results)
+    // no kernel may depend on what the allocator handed back (epoch, legal lists, results).  On the engine's own stream: that
+    // stream is non-blocking, so a null-stream memset queued behind another library's work (torch's default stream) could land
+    // AFTER the first prepare and wipe it.
+    LZ_HIP_CHECK(hipMemsetAsync(r->slab, 0, off, e->stream));
     t.node_raw = nullptr; t.gumbel = nullptr; t.considered = nullptr;
     if (variant == LZ_TREE_GUMBEL_MUZERO) {
         t.node_raw = (float *)(base + o_raw); t.gumbel = (float *)(base + o_gum); t.considered = (int32_t *)(base + o_cons);
@@ -150,7 +153,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
         std::extreme_value_distribution<float> dist(0, 1);
         std::vector<float> g((size_t)A);
         for (int i = 0; i < A; ++i) g[i] = 10.0f * dist(gen);
-        (void)hipMemcpy(t.gumbel, g.data(), (size_t)A * 4, hipMemcpyHostToDevice);
+        LZ_HIP_CHECK(hipMemcpyAsync(t.gumbel, g.data(), (size_t)A * 4, hipMemcpyHostToDevice, e->stream));
+        LZ_HIP_CHECK(hipStreamSynchronize(e->stream));  // g is a stack vector
     }
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
     *out = r;

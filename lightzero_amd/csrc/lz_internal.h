@@ -26,6 +26,22 @@ void lz_set_error(const char *fmt, ...);
         }                                        \
     } while (0)
 
+// Every device allocation of the library goes through here.  LZ_POISON=<byte> (debug) fills fresh allocations with
+// that byte so that a kernel depending on what the allocator handed back shows up as a parity failure
+// (tests/test_poison_gpu.py runs the search under 0x00, 0x7f and 0xff and requires identical results).
+#include <stdlib.h>
+static inline hipError_t lz_dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+    const char *v = getenv("LZ_POISON");
+    if (v && *v) {
+        e = hipMemset(*p, (int)strtol(v, nullptr, 0) & 0xff, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // the engine stream does not order against the null stream
+    }
+    return e;
+}
+
 struct lz_model;  // network weights + workspaces (lz_nn.hip)
 
 struct lz_engine {

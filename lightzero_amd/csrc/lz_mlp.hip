@@ -216,6 +216,7 @@ int lz_mlp_finalize(lz_engine *e)
     int w = std::max(M.L, M.H);
     for (const auto *v : {&M.rep, &M.dyn1, &M.dyn2, &M.rew, &M.common, &M.val, &M.pol}) w = widest(*v, w);
     M.Wmax = w;
+    LZ_HIP_CHECK(hipDeviceSynchronize());  // weight uploads went through the null stream; the engine stream does not order against it
     m->finalized = true;
     return LZ_OK;
 }
@@ -236,7 +237,7 @@ int lz_mlp_ensure_pools(lz_roots *r)
                  o_no = take(B * 4);
     size_t o_mt[14];
     for (int i = 0; i < 14; ++i) o_mt[i] = take(B * W * 4);
-    hipError_t err = hipMalloc(&r->pool_slab, off);
+    hipError_t err = lz_dev_malloc((void **)&r->pool_slab, off);
     if (err != hipSuccess) {
         lz_set_error("hipMalloc(%zu bytes) for the latent/LSTM pools failed: %s", off, hipGetErrorString(err));
         return err == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP;

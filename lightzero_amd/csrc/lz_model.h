@@ -77,7 +77,7 @@ struct Builder {
     float *upload(const std::vector<float> &v)
     {
         float *d = nullptr;
-        if (hipMalloc((void **)&d, v.size() * 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
+        if (lz_dev_malloc((void **)&d, v.size() * 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
         m->allocs.push_back(d);
         if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
         return d;

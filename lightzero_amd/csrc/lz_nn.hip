@@ -909,13 +909,21 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     float4 wq[R];
 #pragma unroll
     for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)min(s, NKB - 1) * 64];
-    // previous cell state of this thread's two (row, unit) pairs
-    float c_prev[2];
+    // everything the cell epilogue needs for this thread's two (row, unit) pairs is requested now: previous cell state, gate
+    // biases, BatchNorm scale / shift, reset flag (unconditional loads; dummies where a pointer is null)
+    float c_prev[2], gb[2][4], bns[2], bnt[2];
+    int slen[2];
+    const float *bnsp = a.bn_scale ? a.bn_scale : a.bias, *bntp = a.bn_scale ? a.bn_shift : a.bias;
+    const int32_t *slp = a.search_len ? a.search_len : a.gather_ix;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int p = tid + 256 * q, row = p >> 4, u = p & 15;
-        const int b = min(r0 + row, a.B - 1);
-        c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + tile * 16 + u];
+        const int b = min(r0 + row, a.B - 1), unit = tile * 16 + u;
+        c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + 4 * unit);
+        gb[q][0] = b4.x; gb[q][1] = b4.y; gb[q][2] = b4.z; gb[q][3] = b4.w;
+        bns[q] = bnsp[unit]; bnt[q] = bntp[unit];
+        slen[q] = slp[b];
     }
     // stage the rows: [x (KX) | h (H)] per row; 8 threads per row, batches of 12 float4 loads in flight per thread
     constexpr int K4 = K / 4, NI = (K4 + 7) / 8, NBATCH = 12;
@@ -1021,17 +1029,16 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         const int b = r0 + row;
         if (b >= a.B) continue;
         const int unit = tile * 16 + u;
-        const float gi = sG[(0 * MR + row) * 17 + u] + a.bias[4 * unit + 0];
-        const float gf = sG[(1 * MR + row) * 17 + u] + a.bias[4 * unit + 1];
-        const float gg = sG[(2 * MR + row) * 17 + u] + a.bias[4 * unit + 2];
-        const float go = sG[(3 * MR + row) * 17 + u] + a.bias[4 * unit + 3];
+        const float gi = sG[(0 * MR + row) * 17 + u] + gb[q][0];
+        const float gf = sG[(1 * MR + row) * 17 + u] + gb[q][1];
+        const float gg = sG[(2 * MR + row) * 17 + u] + gb[q][2];
+        const float go = sG[(3 * MR + row) * 17 + u] + gb[q][3];
         const float cn = sigmoidf_(gf) * c_prev[q] + sigmoidf_(gi) * tanhf(gg);
         const float hn = sigmoidf_(go) * tanhf(cn);
-        bool reset = false;
-        if (a.search_len && a.horizon > 0) reset = (a.search_len[b] % a.horizon) == 0;  // mcts_ctree.py:859-863
+        const bool reset = a.search_len && a.horizon > 0 && (slen[q] % a.horizon) == 0;  // mcts_ctree.py:859-863
         a.h_out[(size_t)b * H + unit] = reset ? 0.0f : hn;
         a.c_out[(size_t)b * H + unit] = reset ? 0.0f : cn;
-        a.hbn_out[(size_t)b * H + unit] = a.bn_scale ? fmaxf(hn * a.bn_scale[unit] + a.bn_shift[unit], 0.0f) : hn;
+        a.hbn_out[(size_t)b * H + unit] = a.bn_scale ? fmaxf(hn * bns[q] + bnt[q], 0.0f) : hn;
     }
 }
 

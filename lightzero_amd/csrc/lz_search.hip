@@ -220,6 +220,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
         lz_set_error("lz_model_finalize: %s", b.err.c_str());
         return LZ_ERR_STATE;
     }
+    LZ_HIP_CHECK(hipDeviceSynchronize());  // weight uploads went through the null stream; the engine stream does not order against it
     m->finalized = true;
     return LZ_OK;
 }
@@ -241,7 +242,7 @@ static int ensure_pools(lz_roots *r)
                  o_x1 = take(B * HW * C * 4), o_x2 = take(B * HW * C * 4), o_x3 = take(B * HW * C * 4),
                  o_rx = take(B * HW * HC * 4), o_pv = take(B * HW * 2 * HC * 4), o_hbn = take(B * H * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
                  o_tr = take(NN * 5 * B * 4), o_tp = take(B * 4), o_z = take(B * 4), o_nz = take(B * A * 4), o_no = take(B * 4);
-    hipError_t err = hipMalloc(&r->pool_slab, off);
+    hipError_t err = lz_dev_malloc((void **)&r->pool_slab, off);
     if (err != hipSuccess) {
         lz_set_error("hipMalloc(%zu bytes) for the latent/LSTM pools failed: %s", off, hipGetErrorString(err));
         return err == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP;
@@ -265,7 +266,7 @@ static int ensure_ws(lz_model *m, int B)
     const lz_model_cfg &c = m->cfg;
     const size_t n = c.downsample ? (size_t)B * (c.obs_h / 2) * (c.obs_w / 2) * (c.num_channels / 2)  // largest activation
                                   : (size_t)B * c.obs_h * c.obs_w * c.num_channels;
-    for (int i = 0; i < 3; ++i) LZ_HIP_CHECK(hipMalloc((void **)&m->ws[i], n * 4));
+    for (int i = 0; i < 3; ++i) LZ_HIP_CHECK(lz_dev_malloc((void **)&m->ws[i], n * 4));
     m->ws_B = B;
     return LZ_OK;
 }
@@ -427,7 +428,7 @@ extern "C" int lz_initial_inference_host(lz_roots *r, const float *h_obs)
     if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     const size_t n = (size_t)r->t.B * m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
-    if (!r->d_obs) LZ_HIP_CHECK(hipMalloc((void **)&r->d_obs, n * 4));
+    if (!r->d_obs) LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_obs, n * 4));
     LZ_HIP_CHECK(hipMemcpyAsync(r->d_obs, h_obs, n * 4, hipMemcpyHostToDevice, r->eng->stream));
     return lz_initial_inference(r, r->d_obs);
 }
@@ -459,7 +460,7 @@ extern "C" int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int
     // layout of the result block: dist [B][A] | count [B] | values [B] | pred values [B] | logits [B][PA]
     const size_t n_i = B * A + B, n_f = 2 * B + B * PA, bytes = (n_i + n_f) * 4;
     if (!r->d_results) {
-        LZ_HIP_CHECK(hipMalloc(&r->d_results, bytes));
+        LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes));
         LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
     }
     int32_t *d_dist = (int32_t *)r->d_results, *d_cnt = d_dist + B * A;
@@ -489,8 +490,9 @@ extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int record
     if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }  // the pointers are baked into the graph
     if (!h_draws || records <= 0) return LZ_OK;
     const size_t n = (size_t)records * r->t.B * r->t.A * r->t.D;
-    LZ_HIP_CHECK(hipMalloc((void **)&r->d_given, n * 4));
-    LZ_HIP_CHECK(hipMemcpy(r->d_given, h_draws, n * 4, hipMemcpyHostToDevice));
+    LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_given, n * 4));
+    LZ_HIP_CHECK(hipMemcpyAsync(r->d_given, h_draws, n * 4, hipMemcpyHostToDevice, r->eng->stream));
+    LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
     r->given_records = records;
     return LZ_OK;
 }
@@ -617,7 +619,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
         ca.nc1 = 3;
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
         if (getenv("LZ_DEBUG_CHAIN_TS")) {  // timing experiments only: stamps of the last launch, read with lz_debug_read_chain_ts
-            if (!g_chain_ts) (void)hipMalloc((void **)&g_chain_ts, 32 * 8);
+            if (!g_chain_ts) (void)lz_dev_malloc((void **)&g_chain_ts, 32 * 8);
             ca.tstamp = g_chain_ts;
         }
         ProfScope ps(r->eng, s);
@@ -773,7 +775,7 @@ extern "C" int lz_search_with_reuse(lz_roots *r, int num_simulations, int pb_c_b
     hipStream_t s = r->eng->stream;
     const lz_tree_dev &t = r->t;
     const size_t B = t.B, A = mt >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
-    if (!r->d_reuse) LZ_HIP_CHECK(hipMalloc(&r->d_reuse, (2 * B + (size_t)t.NN) * 4));
+    if (!r->d_reuse) LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_reuse, (2 * B + (size_t)t.NN) * 4));
     int32_t *d_ta = (int32_t *)r->d_reuse;
     float *d_rv = (float *)(d_ta + B);
     int32_t *d_cnt = (int32_t *)(d_rv + B);
@@ -894,6 +896,7 @@ extern "C" int lz_debug_set(lz_engine *e, const char *key, int value)
 extern "C" int lz_debug_read_ws(lz_engine *e, int which, float *h_out, int64_t n)
 {
     LZ_REQUIRE(e && e->model && which >= 0 && which < 3 && e->model->ws[which] && h_out, "bad argument");
+    LZ_HIP_CHECK(hipDeviceSynchronize());
     LZ_HIP_CHECK(hipMemcpy(h_out, e->model->ws[which], (size_t)n * 4, hipMemcpyDeviceToHost));
     return LZ_OK;
 }
