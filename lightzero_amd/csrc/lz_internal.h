@@ -163,6 +163,18 @@ struct lz_traverse_args {
     uint64_t seed;
     uint32_t counter;
 };
+// one expand + backup + next-selection step for every root (dev_step_lds in lz_tree_dev.h), as run by k_backprop_traverse_lds
+// or by the convolution chain's prologue (lz_launch_chain with a step)
+struct lz_tree_step {
+    lz_tree_dev t;
+    int new_node;              // = latent slot of the leaf being expanded
+    float discount;
+    const float *vps, *values, *logits;  // the leaf's network outputs [B], [B], [B][A]
+    int horizon;
+    lz_traverse_args a;
+    float delta;
+    const int32_t *vtp;
+};
 void lz_tree_launch_minmax_reset(const lz_tree_dev &t, hipStream_t s);
 void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int noises_ragged,
                             const int32_t *d_noise_off, const float *d_vp, const float *d_logits,

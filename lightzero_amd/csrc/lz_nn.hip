@@ -18,6 +18,8 @@
 #include <stdlib.h>
 
 #include "lz_nn_kernels.h"
+#define LZ_TREE_DEV_RESTORE_FAST_CONTRACT
+#include "lz_tree_dev.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -489,8 +491,15 @@ __global__ __launch_bounds__(256) void k_conv1x1(lz_c1_args a)
 // Activations ping-pong between four LDS buffers; weight fragments come straight from L2 into registers, four
 // steps ahead.  432 MFMAs per wave per layer = 5.8 us at the fp32-matrix issue rate.
 // ------------------------------------------------------------------------------------------------
-template <int GW, int GH, bool TS = false>
-__global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
+// TREE != 0: wave 0 first runs the root's tree step (dev_step_lds, variant TREE - 1) on an LDS copy of the tree placed in
+// the still unused activation buffers -- the per-simulation tree launch disappears, and the weight prefetch of the first
+// layer is in flight meanwhile.
+struct no_step {};
+template <int TREE> struct step_arg { typedef lz_tree_step type; };
+template <> struct step_arg<0> { typedef no_step type; };
+
+template <int GW, int GH, bool TS = false, int TREE = 0>
+__global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_arg<TREE>::type step)
 {
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS;  // HW pixels + one all-zero pixel
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats, then the
@@ -514,9 +523,21 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(cw + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
     }
+    int g_slot = 0, g_action = 0;
+    if constexpr (TREE != 0) {
+        int32_t *s_sel = reinterpret_cast<int32_t *>(sSS + 6 * 128 + (TS ? 64 : 0));
+        if (wv == 0)
+            dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel);
+        __syncthreads();
+        g_slot = s_sel[0];
+        g_action = s_sel[1];
+    } else {
+        if (a.gather_ix) g_slot = a.gather_ix[b];
+        if (a.act_table) g_action = a.action[b];
+    }
     {
-        const float *src = a.in + (size_t)b * HW * 64;
-        if (a.gather_ix) src += (size_t)a.gather_ix[b] * a.slot_stride;
+        const float *src = a.in + (size_t)b * HW * 64 + (size_t)g_slot * a.slot_stride;
         constexpr int NU = (HW * 16 + 255) / 256;
         float4 v[NU];
 #pragma unroll
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a)
         }
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
         if (a.act_table) {
-            const float *tsrc = a.act_table + (size_t)a.action[b] * HW * 64;
+            const float *tsrc = a.act_table + (size_t)g_action * HW * 64;
             float4 tv[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -1293,11 +1314,27 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
     hipLaunchKernelGGL(k_conv1x1, dim3((a.npix + 143) / 144, a.njobs), dim3(256), 0, s, a);
 }
 
-void lz_launch_chain(const lz_chain_args &a, hipStream_t s)
+// the tree step can ride in the chain's prologue when the root's tree fits the (still unused) activation buffers, one lane
+// per action covers the node, and a gather / action table is what the chain would have read anyway
+bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
 {
-    if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 64) * 4, s, a);
-    else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a);
-    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)(4 * 82 * 68 + 81 * 68 + 6 * 128) * 4, s, a);
+    if (!(a.gw == 6 && a.gh == 6) || a.tstamp || !a.gather_ix || !a.act_table) return false;
+    if (step.t.A > 64 || step.t.B != a.B) return false;
+    if (step.t.variant != LZ_TREE_EFFICIENTZERO && step.t.variant != LZ_TREE_MUZERO) return false;
+    return lz_tree_lds_bytes(step.t, step.new_node) <= 16 * 1024;
+}
+
+void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step)
+{
+    if (step) {
+        const size_t lds = (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 4) * 4;
+        if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain<6, 6, false, 1>), dim3(a.B), dim3(256), lds, s, a, *step);
+        else hipLaunchKernelGGL((k_chain<6, 6, false, 2>), dim3(a.B), dim3(256), lds, s, a, *step);
+        return;
+    }
+    if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 64) * 4, s, a, no_step{});
+    else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a, no_step{});
+    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)(4 * 82 * 68 + 81 * 68 + 6 * 128) * 4, s, a, no_step{});
 }
 
 template <int MROWS>

@@ -79,7 +79,12 @@ struct lz_chain_args {
     int gw, gh;                  // latent grid (6x6 Atari with downsample, 9x9 Go); compiled instances: 6x6, 9x9
     unsigned long long *tstamp;  // debugging: s_memtime stamps of workgroup 0 / wave 0 (null in production)
 };
-void lz_launch_chain(const lz_chain_args &a, hipStream_t s);
+// step != null: the tree step of every root (expand + backup of the previous simulation, selection of this one) runs as the
+// prologue of the root's workgroup, and the chain reads the selected (slot, action) from LDS instead of gather_ix / action
+// (which the step still writes for the kernels that follow).  Requires lz_chain_fusable(step).
+struct lz_tree_step;
+bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step);
+void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step = nullptr);
 
 // one LSTM step (nn.LSTM, 1 layer) fused with BatchNorm1d + ReLU of the output:
 //   gates = [x | h] . Wcat^T + bias ; c' = sig(f) c + sig(i) tanh(g) ; h' = sig(o) tanh(c')

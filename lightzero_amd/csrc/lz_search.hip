@@ -588,9 +588,18 @@ extern "C" int lz_debug_read_chain_ts(unsigned long long *h_out)
     return LZ_OK;
 }
 
+// timing experiments only: LZ_DEBUG_SKIP=<letters> drops launches from the search (t tree step, c chain, l LSTM, h heads) so
+// that the marginal in-graph cost of each kernel can be read off the step time; results are then meaningless
+static bool dbg_skip(char k)
+{
+    const char *v = getenv("LZ_DEBUG_SKIP");
+    return v && strchr(v, k);
+}
+
 // the network part of one simulation (mcts_ctree.py:834-847): recurrent_inference for the leaves selected by the
 // last traverse, outputs into slot sim + 1 of the pools
-static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
+// `step` (conv models only): the tree step that selects this simulation's leaves, run inside the chain launch
+static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz_tree_step *step = nullptr)
 {
     lz_model *m = r->eng->model;
     if (m->cfg.model_type >= 2) { lz_mlp_recurrent(r, sim, horizon, s); return; }
@@ -623,7 +632,12 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
             ca.tstamp = g_chain_ts;
         }
         ProfScope ps(r->eng, s);
-        lz_launch_chain(ca, s);
+        if (step && !lz_chain_fusable(ca, *step)) {  // decided by the caller with chain_takes_step(); kept as a guard
+            lz_tree_launch_backprop_traverse(step->t, step->new_node, step->discount, step->vps, step->values, step->logits,
+                                             step->horizon, step->a, step->delta, step->vtp, s);
+            step = nullptr;
+        }
+        if (!dbg_skip('c')) lz_launch_chain(ca, s, step);
     }
     // ---- value prefix LSTM (+ BN1d + ReLU), then the three head MLPs with h^-1 fused
     lz_lstm_args l{};
@@ -633,8 +647,8 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
     // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
     // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
-    if (c.model_type == 0) lz_launch_lstm(l, s);
-    heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
+    if (c.model_type == 0 && !dbg_skip('l')) lz_launch_lstm(l, s);
+    if (!dbg_skip('h')) heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
           r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
 }
 
@@ -671,14 +685,27 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
         return;
     }
     lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
+    // The expand + backup of simulation s and the selection of simulation s + 1 are one tree step per root; for the conv
+    // models it runs in the prologue of simulation s + 1's chain launch (same workgroup-per-root mapping) while the tree
+    // of a root still fits the LDS budget, else as its own launch.  LZ_NO_TREE_FUSE=1 keeps it separate (parity tests).
+    const bool fuse = r->eng->model->cfg.model_type < 2 && !r->trace_on && !getenv("LZ_NO_TREE_FUSE");
+    lz_tree_step step{};
+    bool pending = false;  // a step that the next chain launch has to run
     for (int sim = 0; sim < num_simulations; ++sim) {
-        recurrent(r, sim, horizon, s);
+        recurrent(r, sim, horizon, s, pending ? &step : nullptr);
+        pending = false;
         const int slot = sim + 1;
         const float *vp = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
         // is_reset = search_len % horizon == 0 is derived on the device (mcts_ctree.py:859)
         if (sim + 1 < num_simulations) {
             ta.counter = (uint32_t)(sim + 1);
-            lz_tree_launch_backprop_traverse(t, slot, ta.discount, vp, val, lg, horizon, ta, delta, r->d_to_play, s);
+            if (fuse) {
+                step.t = t; step.new_node = slot; step.discount = ta.discount; step.vps = vp; step.values = val; step.logits = lg;
+                step.horizon = horizon; step.a = ta; step.delta = delta; step.vtp = r->d_to_play;
+                pending = true;
+            } else if (!dbg_skip('t')) {
+                lz_tree_launch_backprop_traverse(t, slot, ta.discount, vp, val, lg, horizon, ta, delta, r->d_to_play, s);
+            }
         } else {
             lz_tree_launch_backprop(t, slot, ta.discount, vp, val, lg, nullptr, horizon, nullptr, s);
         }

@@ -1,0 +1,543 @@
+// lz_tree_dev.h -- device-side tree code shared by the tree kernels (lz_tree.hip) and the convolution chain that runs a
+// root's tree step as its prologue (lz_nn.hip): per-root view, selection (cbatch_traverse), expansion + backup
+// (cbatch_backpropagate), and the step on an LDS copy of the tree.  See lz_tree.hip for the reference citations.
+//
+// Everything here reproduces the reference's float arithmetic bit for bit, so FMA contraction is switched off for this
+// header whatever the including translation unit is built with (restored at the end when the includer asks for it).
+#pragma once
+#include "lz_internal.h"
+#include "lz_wave.h"
+
+#pragma clang fp contract(off)
+#include "lz_math.h"  // below the pragma: its polynomial evaluations must stay individually rounded too
+
+#define LZ_FLOAT_MAX 1000000.0f  // cminimax.h:9
+#define LZ_FLOAT_MIN (-LZ_FLOAT_MAX)
+
+namespace {
+
+
+__device__ __forceinline__ float rl_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float mm_normalize(float v, float mn, float mx, float delta_max)
+{
+    const float d = mx - mn;  // cminimax.cpp:33-45
+    if (d > 0) {
+        if (d < delta_max) v = (v - mn) / delta_max;
+        else v = (v - mn) / d;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-root view of the tree arrays.  The kernels below are written once against this view and instantiated
+// twice: on the HBM arrays directly, and on an LDS copy of the root's tree (loads from LDS, stores written through to
+// HBM) -- a search step is a chain of dependent loads (node -> edges -> child -> ...), ~1 us each from HBM/L2.
+// ------------------------------------------------------------------------------------------------
+struct tview {
+    float4 *edge;            // [NN][A]   read / write here
+    int32_t *child;          // [NN][A]
+    float *node_vp;          // [NN]
+    int32_t *node_reset, *node_to_play;
+    const int32_t *path_node, *path_act;  // [NN] path of the previous traverse (read by the backup)
+    float4 *g_edge;          // write-through targets in HBM (WT instantiation), same indexing
+    int32_t *g_child;
+    float *g_node_vp;
+    int32_t *g_node_reset, *g_node_to_play;
+};
+
+// values that cross from the backup into the next selection in registers (fused kernel) or come from HBM
+template <int NC>
+struct tscal {
+    int n_root;        // number of legal root actions
+    int root_act[NC];  // this lane's root legal action(s)
+    int root_visit;
+    float root_vsum;
+    float mn, mx;      // CMinMaxStats
+    uint32_t epoch;
+};
+
+__device__ __forceinline__ tview global_view(const lz_tree_dev &t, int b)
+{
+    tview v;
+    const size_t e = (size_t)b * t.NN * t.A, n = (size_t)b * t.NN;
+    v.edge = v.g_edge = t.edge + e;
+    v.child = v.g_child = t.child + e;
+    v.node_vp = v.g_node_vp = t.node_vp + n;
+    v.node_reset = v.g_node_reset = t.node_reset + n;
+    v.node_to_play = v.g_node_to_play = t.node_to_play + n;
+    v.path_node = t.path_node + n;
+    v.path_act = t.path_act + n;
+    return v;
+}
+
+template <int NC>
+__device__ __forceinline__ void load_scalars(const lz_tree_dev &t, int b, tscal<NC> &sc)
+{
+    const int lane = threadIdx.x;
+    sc.n_root = uni(t.n_legal[b]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        sc.root_act[c] = (j < sc.n_root) ? t.legal[(size_t)b * t.A + j] : 0;
+    }
+    sc.root_visit = t.root_visit[b];
+    sc.root_vsum = t.root_vsum[b];
+    sc.mn = t.minmax[2 * b];
+    sc.mx = t.minmax[2 * b + 1];
+    sc.epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;  // bumped by every prepare: decorrelates env-steps
+}
+
+// ------------------------------------------------------------------------------------------------
+// traverse: cbatch_traverse (cnode.cpp:886-963) -- select down to an unexpanded child
+// ------------------------------------------------------------------------------------------------
+// REUSE (ReZero, cnode.cpp:697-754, 816-884, 965-1072): at the root the trajectory's true action is scored by carm_score
+// (its value term is the reuse value and, once visited, it gets no prior term), and the walk stops right below the root
+// when that action is selected; res_noinf marks roots whose reached node is already expanded (reference index -1).
+template <int NC, int VARIANT, bool REUSE = false>
+__device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &v, const tscal<NC> &sc, const lz_traverse_args &a,
+                                             float delta_max, int vtp, int true_action = -1, float reuse_value = 0.0f,
+                                             int32_t *s_out = nullptr)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    const float mn = sc.mn, mx = sc.mx;
+    const float discount = a.discount;
+    const float base = (float)a.pb_c_base;
+    const uint32_t epoch = sc.epoch;
+    int node = 0, depth = 0, is_root = 1, last_action = -1, noinf = 0;
+    int node_visit = sc.root_visit;
+    float parent_q = 0.0f;
+
+    for (;;) {
+        const int n = is_root ? sc.n_root : A;
+        const float node_vp = v.node_vp[node];
+        const int node_reset = v.node_reset[node];
+        float prior[NC], val[NC], tr[NC], score[NC];
+        int vis[NC], act[NC], chd[NC];  // chd: child node ids, fetched with the edges (one round trip per level)
+        // ---- load the children (one 16-byte edge per lane) and compute_mean_q (cnode.cpp:173-212)
+        float total = 0.0f;
+        int nv = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            const bool valid = j < n;
+            act[c] = valid ? (is_root ? sc.root_act[c] : j) : 0;
+            float4 e = valid ? v.edge[(size_t)node * A + act[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            chd[c] = valid ? v.child[(size_t)node * A + act[c]] : -1;
+            prior[c] = e.x;
+            vis[c] = __float_as_int(e.y);
+            val[c] = (vis[c] == 0) ? 0.0f : e.z / (float)vis[c];  // CNode::value cnode.cpp:223-239
+            if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+                tr[c] = e.w - node_vp;
+                if (node_reset == 1) tr[c] = e.w;
+            } else {
+                tr[c] = e.w;
+            }
+            const float qsa = tr[c] + discount * val[c];
+            uint64_t mask = __ballot(valid && vis[c] > 0);
+            while (mask) {  // total_unsigned_q += qsa in legal-list order
+                const int j2 = __builtin_ctzll(mask);
+                total += rl_f(qsa, j2);
+                nv += 1;
+                mask &= mask - 1;
+            }
+        }
+        float mean_q;
+        if (is_root && nv > 0) mean_q = total / (float)nv;
+        else mean_q = (parent_q + total) / (float)(nv + 1);
+        const int was_root = is_root;
+        is_root = 0;
+        parent_q = mean_q;
+
+        // ---- cucb_score (cnode.cpp:756-814) for every child
+        const float N = (float)(node_visit - 1);
+        const float pbc0 = lz_logf((N + base + 1) / base) + a.pb_c_init;
+        const float sq = sqrtf(N);
+        float best = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            float pb_c = pbc0 * (sq / (float)(vis[c] + 1));
+            const float prior_score = pb_c * prior[c];
+            const bool arm = REUSE && was_root && act[c] == true_action;  // carm_score instead of cucb_score
+            const float vchild = arm ? reuse_value : val[c];
+            float value_score;
+            if (vis[c] == 0) value_score = mean_q;
+            else if (a.players == 1) value_score = tr[c] + discount * vchild;
+            else value_score = tr[c] + discount * (-vchild);
+            value_score = mm_normalize(value_score, mn, mx, delta_max);
+            if (value_score < 0) value_score = 0;
+            else if (value_score > 1) value_score = 1;
+            float ucb = prior_score + value_score;
+            if (arm && vis[c] != 0) ucb = value_score;
+            score[c] = (j < n) ? ucb : -__builtin_inff();
+            best = fmaxf(best, score[c]);
+        }
+        best = wave_max(best);
+        // ---- cselect_child (cnode.cpp:651-695): front of the tie list == first arg-max in list order
+        int pos = -1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const uint64_t mask = __ballot(score[c] == best);
+            if (pos < 0 && mask) pos = c * 64 + __builtin_ctzll(mask);
+        }
+        if (a.tiebreak == LZ_TIE_RANDOM && pos >= 0) {
+            // tie list = [first arg-max] + later entries with score >= max - 1e-6 (cnode.cpp:675-685)
+            const float thr = best - 0.000001f;
+            uint64_t masks[NC];
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int j = c * 64 + lane;
+                masks[c] = __ballot(j == pos || (j > pos && score[c] >= thr));
+                cnt += __builtin_popcountll(masks[c]);
+            }
+            int r = 0;
+            if (cnt > 1) {  // a single candidate (the usual case once visits differ) needs no draw
+                const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
+                r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt) without a 64-bit division
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                uint64_t mk = masks[c];
+                const int pc = __builtin_popcountll(mk);
+                if (r >= 0 && r < pc) {
+                    for (int q = 0; q < r; ++q) mk &= mk - 1;
+                    pos = c * 64 + __builtin_ctzll(mk);
+                    r = -1;
+                } else if (r >= pc) {
+                    r -= pc;
+                }
+            }
+        }
+        int action = 0, sel_visit = 0, nxt = -3;
+        if (pos >= 0 && best > LZ_FLOAT_MIN) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if ((pos >> 6) == c) {
+                    action = rl_i(act[c], pos & 63);
+                    sel_visit = rl_i(vis[c], pos & 63);
+                    nxt = rl_i(chd[c], pos & 63);
+                }
+            }
+        }
+        if (nxt == -3) nxt = uni(v.child[(size_t)node * A + action]);  // degenerate fallback (action 0 by default)
+        if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
+        if (lane == 0) {
+            t.node_best[(size_t)b * NN + node] = action;
+            t.path_node[(size_t)b * NN + depth] = node;
+            t.path_act[(size_t)b * NN + depth] = action;
+        }
+        last_action = action;
+        depth += 1;
+        if (REUSE && was_root && action == true_action) { noinf = nxt >= 0 ? 1 : 0; break; }  // cnode.cpp:1041-1044
+        if (nxt < 0) break;  // reached an unexpanded child: the leaf
+        node = nxt;
+        node_visit = sel_visit;
+    }
+    if (lane == 0) {
+        t.res_ix[b] = node;  // parent->current_latent_state_index (cnode.cpp:955); stays a valid slot when noinf
+        t.res_iy[b] = REUSE ? (noinf ? b : t.node_bidx[(size_t)b * NN + node]) : b;  // parent->batch_index
+        t.res_last_action[b] = last_action;
+        t.res_search_len[b] = depth;
+        t.res_vtp[b] = vtp;
+        if (REUSE) t.res_noinf[b] = noinf;
+        if (s_out) { s_out[0] = node; s_out[1] = last_action; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backpropagate: cbatch_backpropagate (cnode.cpp:577-601) = expand the leaf, then cbackpropagate.
+// d = search length of the path, lg[] = this lane's policy logits of the leaf, sc carries root visit / value sum and
+// the min-max statistics in and out.
+// ------------------------------------------------------------------------------------------------
+// no_expand (ReZero, cnode.cpp:626-630): the leaf is an already expanded node -- nothing is expanded, its own value prefix
+// stays, only is_reset is refreshed and value_b (the reuse value) is backed up.  bidx = the leaf's batch_index.
+template <int NC, int VARIANT, bool WT>
+__device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &v, tscal<NC> &sc, int new_node, float discount,
+                                             float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset,
+                                             bool no_expand = false, int bidx = -1)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    // ---- CNode::expand (cnode.cpp:88-151): all A actions are legal below the root
+    if (!no_expand) {
+        float e[NC];
+        float m = LZ_FLOAT_MIN;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) m = fmaxf(m, lg[c]);
+        m = wave_max(m);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) e[c] = lz_expf(lg[c] - m);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cnt = min(64, A - c * 64);
+            for (int j = 0; j < cnt; ++j) sum += rl_f(e[c], j);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = c * 64 + lane;
+            if (j < A) {
+                const size_t o = (size_t)new_node * A + j;
+                const float4 ne = make_float4(e[c] / sum, __int_as_float(0), 0.0f, 0.0f);
+                v.edge[o] = ne;
+                v.child[o] = -1;
+                if (WT) { v.g_edge[o] = ne; v.g_child[o] = -1; }
+            }
+        }
+    }
+    const int parent = uni(v.path_node[d - 1]);
+    const int pact = uni(v.path_act[d - 1]);
+    if (no_expand) {
+        if (VARIANT == LZ_TREE_EFFICIENTZERO && lane == 0) {
+            const int leaf = v.child[(size_t)parent * A + pact];
+            v.node_reset[leaf] = reset;
+            if (WT) v.g_node_reset[leaf] = reset;
+        }
+    } else if (lane == 0) {
+        t.node_bidx[(size_t)b * NN + new_node] = bidx < 0 ? b : bidx;
+        v.child[(size_t)parent * A + pact] = new_node;
+        v.node_vp[new_node] = vp_b;
+        v.node_reset[new_node] = reset;
+        v.node_to_play[new_node] = to_play;
+        if (WT) {
+            v.g_child[(size_t)parent * A + pact] = new_node;
+            v.g_node_vp[new_node] = vp_b;
+            v.g_node_reset[new_node] = reset;
+            v.g_node_to_play[new_node] = to_play;
+        }
+        t.node_best[(size_t)b * NN + new_node] = -1;
+    }
+    if (WT) __builtin_amdgcn_wave_barrier();
+    // ---- cbackpropagate (cnode.cpp:482-575): path node P_k, k = d (leaf) .. 0 (root); lane i of a
+    // chunk owns k = d - (chunk*64 + i).  Gather is parallel, the bootstrap recurrence is a scalar chain.
+    float bootstrap = value_b;
+    float mn = sc.mn, mx = sc.mx;
+    for (int k0 = d; k0 >= 0; k0 -= 64) {
+        const int k = k0 - lane;
+        const bool valid = k >= 0;
+        int pn = 0, pa = 0, vis = 0, own_tp = to_play, parent_reset = 0;
+        float prior = 0.f, vsum = 0.f, own_vp = 0.f, parent_vp = 0.f;
+        if (valid) {
+            if (k >= 1) {
+                pn = v.path_node[k - 1];
+                pa = v.path_act[k - 1];
+                const float4 e = v.edge[(size_t)pn * A + pa];
+                prior = e.x;
+                vis = __float_as_int(e.y);
+                vsum = e.z;
+                own_vp = (k == d && !no_expand) ? vp_b : e.w;
+                parent_vp = v.node_vp[pn];
+                parent_reset = v.node_reset[pn];
+                if (k < d) own_tp = v.node_to_play[v.path_node[k]];
+            } else {
+                vis = sc.root_visit;
+                vsum = sc.root_vsum;
+                own_vp = v.node_vp[0];
+                own_tp = v.node_to_play[0];
+            }
+        }
+        float true_reward, tr_eff;
+        if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+            true_reward = own_vp - parent_vp;
+            tr_eff = (parent_reset == 1) ? own_vp : true_reward;
+        } else {
+            true_reward = own_vp;
+            tr_eff = own_vp;
+        }
+        const int same = (to_play == -1) ? 1 : (own_tp == to_play ? 1 : 0);
+        const int cnt = min(64, k0 + 1);
+        float my_boot = 0.0f;
+        for (int i = 0; i < cnt; ++i) {
+            if (lane == i) my_boot = bootstrap;
+            const float tre = rl_f(tr_eff, i);
+            if (to_play == -1) bootstrap = tre + discount * bootstrap;
+            else if (rl_i(same, i)) bootstrap = -tre + discount * bootstrap;
+            else bootstrap = tre + discount * bootstrap;
+        }
+        int new_root_visit = 0;
+        float new_root_vsum = 0.0f;
+        if (valid) {
+            vsum = same ? vsum + my_boot : vsum + (-my_boot);
+            vis += 1;
+            const float value = vsum / (float)vis;
+            float q;
+            if (VARIANT == LZ_TREE_EFFICIENTZERO) q = true_reward + discount * value;  // cnode.cpp:516/:558
+            else q = (to_play == -1) ? true_reward + discount * value : true_reward + discount * -value;
+            mx = fmaxf(mx, q);
+            mn = fminf(mn, q);
+            if (k >= 1) {
+                const float4 ne = make_float4(prior, __int_as_float(vis), vsum, own_vp);
+                v.edge[(size_t)pn * A + pa] = ne;
+                if (WT) v.g_edge[(size_t)pn * A + pa] = ne;
+            } else {
+                t.root_visit[b] = vis;
+                t.root_vsum[b] = vsum;
+                new_root_visit = vis;
+                new_root_vsum = vsum;
+            }
+        }
+        // the root is lane k0 of the chunk that contains k == 0
+        if (k0 < 64) {
+            sc.root_visit = rl_i(new_root_visit, k0);
+            sc.root_vsum = rl_f(new_root_vsum, k0);
+        }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    if (lane == 0) { t.minmax[2 * b] = mn; t.minmax[2 * b + 1] = mx; }
+    sc.mn = mn;
+    sc.mx = mx;
+}
+
+// leaf inputs of the backup: search length, player, value prefix, value, logits, is_reset
+template <int NC, int VARIANT>
+struct leaf_in {
+    int d, to_play, reset;
+    float vp, value;
+    float lg[NC];
+};
+template <int NC, int VARIANT>
+__device__ __forceinline__ void load_leaf(const lz_tree_dev &t, int b, const float *__restrict__ vps, const float *__restrict__ values,
+                                          const float *__restrict__ logits, const int32_t *__restrict__ is_reset, int horizon,
+                                          const int32_t *__restrict__ to_play_in, leaf_in<NC, VARIANT> &L)
+{
+    const int lane = threadIdx.x, A = t.A;
+    L.d = uni(t.res_search_len[b]);
+    L.to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
+    L.vp = vps[b];
+    L.value = values[b];
+    L.reset = 0;
+    if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+        if (is_reset) L.reset = is_reset[b];
+        else if (horizon > 0) L.reset = (L.d % horizon == 0) ? 1 : 0;  // mcts_ctree.py:859
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        L.lg[c] = (j < A) ? logits[(size_t)b * A + j] : LZ_FLOAT_MIN;
+    }
+}
+
+// expand + backup of the previous simulation followed by the selection of the next one, on an LDS copy of the root's tree:
+// every array the step reads is requested in the first instructions (one HBM round trip for the whole tree: edges, child
+// ids, node records, the previous path, the leaf's network outputs and the root scalars), the backup and the selection
+// then chase pointers inside LDS, and every store is written through to HBM.  One wavefront; s_tree needs
+// lz_tree_lds_bytes(t, new_node) bytes.  s_out (optional, LDS): [0] = selected parent slot (res_ix), [1] = last action.
+template <int NC, int VARIANT>
+__device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int new_node, float discount,
+                                             const float *__restrict__ vps, const float *__restrict__ values,
+                                             const float *__restrict__ logits, int horizon, const lz_traverse_args &a,
+                                             float delta_max, const int32_t *__restrict__ vtp_in, float4 *s_tree,
+                                             int32_t *s_out = nullptr)
+{
+    const int lane = threadIdx.x;
+    const int A = t.A;
+    const int nn = new_node + 1;        // nodes 0 .. new_node exist after this step
+    float4 *s_edge = s_tree;                                              // [nn][A]
+    int32_t *s_child = reinterpret_cast<int32_t *>(s_edge + (size_t)nn * A);   // [nn][A]
+    float *s_vp = reinterpret_cast<float *>(s_child + (size_t)nn * A);    // [nn]
+    int32_t *s_reset = reinterpret_cast<int32_t *>(s_vp + nn);
+    int32_t *s_tp = s_reset + nn;
+    int32_t *s_pn = s_tp + nn;
+    int32_t *s_pa = s_pn + nn;
+    const tview g = global_view(t, b);
+    // ---- one round trip: everything the step reads.  All requests are unconditional (clamped indices) and issued before
+    // the first use: a predicated load, or a wave-uniform read of a loaded value in between, would split this into
+    // several dependent HBM/L2 round trips (~0.6 us each).
+    const int r_nroot = t.n_legal[b], r_visit = t.root_visit[b], r_d = t.res_search_len[b], r_tp = t.res_vtp[b];
+    const float r_vsum = t.root_vsum[b], r_mn = t.minmax[2 * b], r_mx = t.minmax[2 * b + 1], r_vp = vps[b], r_val = values[b];
+    const uint32_t r_epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;
+    const int vtp = vtp_in[b];
+    int r_act[NC];
+    float r_lg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = min(c * 64 + lane, A - 1);
+        r_act[c] = t.legal[(size_t)b * A + j];
+        r_lg[c] = logits[(size_t)b * A + j];
+    }
+    const int ne = new_node * A;        // edges / child ids of the existing nodes 0 .. new_node - 1 (ne >= 1)
+    constexpr int UE = 8;
+    for (int i0 = 0; i0 < ne; i0 += UE * 64) {
+        float4 e[UE];
+        int32_t ch[UE];
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            const int i = min(i0 + u * 64 + lane, ne - 1);
+            e[u] = g.edge[i];
+            ch[u] = g.child[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            const int i = i0 + u * 64 + lane;
+            if (i < ne) { s_edge[i] = e[u]; s_child[i] = ch[u]; }
+        }
+    }
+    constexpr int UN = 2;
+    for (int i0 = 0; i0 < new_node; i0 += UN * 64) {
+        float nv[UN];
+        int32_t nr[UN], nt[UN], pn[UN], pa[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = min(i0 + u * 64 + lane, new_node - 1);
+            nv[u] = g.node_vp[i]; nr[u] = g.node_reset[i]; nt[u] = g.node_to_play[i]; pn[u] = g.path_node[i]; pa[u] = g.path_act[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * 64 + lane;
+            if (i < new_node) { s_vp[i] = nv[u]; s_reset[i] = nr[u]; s_tp[i] = nt[u]; s_pn[i] = pn[u]; s_pa[i] = pa[u]; }
+        }
+    }
+    // the same values load_scalars / load_leaf produce
+    tscal<NC> sc;
+    sc.n_root = uni(r_nroot);
+    sc.root_visit = r_visit; sc.root_vsum = r_vsum; sc.mn = r_mn; sc.mx = r_mx; sc.epoch = r_epoch;
+    leaf_in<NC, VARIANT> L;
+    L.d = uni(r_d);
+    L.to_play = uni(r_tp);
+    L.vp = r_vp; L.value = r_val;
+    L.reset = (VARIANT == LZ_TREE_EFFICIENTZERO && horizon > 0) ? ((L.d % horizon == 0) ? 1 : 0) : 0;  // mcts_ctree.py:859
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        sc.root_act[c] = (j < sc.n_root) ? r_act[c] : 0;
+        L.lg[c] = (j < A) ? r_lg[c] : LZ_FLOAT_MIN;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    tview v = g;
+    v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
+    v.path_node = s_pn; v.path_act = s_pa;
+    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out);
+}
+
+}  // namespace
+
+// LDS bytes of the staged tree of one root after `idx` nodes exist besides the new one (dev_step_lds)
+static inline size_t lz_tree_lds_bytes(const lz_tree_dev &t, int idx) { return (size_t)(idx + 1) * ((size_t)t.A * 20 + 20); }
+
+#ifdef LZ_TREE_DEV_RESTORE_FAST_CONTRACT  // defined by includers that are NOT built with -ffp-contract=off (lz_nn.hip)
+#pragma clang fp contract(fast)          // hipcc's default for device code
+#endif

@@ -244,3 +244,48 @@ def test_packed_search_results_equal_the_individual_getters():
     assert [d[i, :c[i]].tolist() for i in range(B)] == roots.get_distributions()
     assert np.array_equal(v, np.asarray(roots.get_values(), np.float32))
     assert np.array_equal(p, out.value) and np.array_equal(lg, out.policy_logits)
+
+
+@pytest.mark.parametrize("tiebreak", [0, 1])
+@pytest.mark.parametrize("family", ["ez", "mz"])
+def test_tree_step_in_the_chain_prologue_is_bit_identical_to_the_separate_launch(family, tiebreak):
+    """the graph-captured search runs a root's expand + backup + next selection as the prologue of the root's chain
+    workgroup (k_chain<..., TREE>, tree code from lz_tree_dev.h compiled into a translation unit with FMA contraction
+    on); LZ_NO_TREE_FUSE=1 keeps the separate k_backprop_traverse_lds launch.  Same distributions, root values
+    (bitwise), trajectories and min-max statistics."""
+    import os
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    B, A, S = 67, 6, 50
+    if family == "ez":
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+        from lightzero_amd.model.efficientzero_model import EfficientZeroModel as M
+        ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A))
+    else:
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as tree
+        from lightzero_amd.model.muzero_model import MuZeroModel as M
+        ref = tm.synthetic_init(tm.MuZeroModel(action_space_size=A))
+    model = M(action_space_size=A).load_state_dict(ref.state_dict())
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(12)).cuda().contiguous()
+    rng = np.random.default_rng(4)
+    mask = (rng.random((B, A)) < 0.7)
+    mask[:, 1] = True
+    legal = [np.nonzero(m)[0].tolist() for m in mask]
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    res = []
+    for no_fuse in ("1", None):
+        if no_fuse:
+            os.environ["LZ_NO_TREE_FUSE"] = no_fuse
+        else:
+            os.environ.pop("LZ_NO_TREE_FUSE", None)
+        roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+        roots.set_tiebreak(tiebreak, seed=77)
+        model.initial_inference(obs, roots)
+        roots.prepare_from_inference(0.25, noises, [-1] * B)
+        L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+        res.append((roots.get_distributions(), np.asarray(roots.get_values(), np.float32).view(np.uint32),
+                    roots.get_trajectories(), roots.get_minmax().view(np.uint32)))
+    os.environ.pop("LZ_NO_TREE_FUSE", None)
+    assert all(sum(d) == S for d in res[1][0])
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    assert np.array_equal(res[0][3], res[1][3])
