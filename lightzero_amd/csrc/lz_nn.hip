@@ -1321,7 +1321,10 @@ bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
     if (!(a.gw == 6 && a.gh == 6) || a.tstamp || !a.gather_ix || !a.act_table) return false;
     if (step.t.A > 64 || step.t.B != a.B) return false;
     if (step.t.variant != LZ_TREE_EFFICIENTZERO && step.t.variant != LZ_TREE_MUZERO) return false;
-    return lz_tree_lds_bytes(step.t, step.new_node) <= 16 * 1024;
+    // the staged tree lives in the four activation buffers (4 x 37 x 68 floats = 40 KB) until the latent is loaded over it;
+    // staging more than 16 KB per root and simulation was measured slower than walking the HBM arrays (configs[2], 400 sims)
+    const size_t room = (size_t)4 * 37 * 68 * 4, lim = lz_tree_lds_limit(16 * 1024);
+    return lz_tree_lds_bytes(step.t, step.new_node) <= (lim < room ? lim : room);
 }
 
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step)

@@ -577,7 +577,7 @@ static void launch_bt_v(const lz_tree_dev &t, int idx, float discount, const flo
     // path lengths are bounded by the node count, so the previous path fits the same [nn] arrays
     const char *no_lds = getenv("LZ_TREE_NO_LDS");  // parity tests compare the two instantiations
     const size_t lds = lz_tree_lds_bytes(t, idx);
-    if (!no_lds && lds <= 16 * 1024 && nchunks(t.A) <= 2) {
+    if (!no_lds && lds <= lz_tree_lds_limit(16 * 1024) && lds <= 64 * 1024 && nchunks(t.A) <= 2) {
         if (nchunks(t.A) == 1) hipLaunchKernelGGL((k_backprop_traverse_lds<1, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
         else hipLaunchKernelGGL((k_backprop_traverse_lds<2, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
         return;

@@ -538,6 +538,15 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
 // LDS bytes of the staged tree of one root after `idx` nodes exist besides the new one (dev_step_lds)
 static inline size_t lz_tree_lds_bytes(const lz_tree_dev &t, int idx) { return (size_t)(idx + 1) * ((size_t)t.A * 20 + 20); }
 
+// Largest staged tree (bytes per root) the LDS step is used for; beyond it the step walks the HBM arrays.  Staging costs
+// O(tree) per simulation but every level of the walk then costs an LDS instead of an HBM round trip.
+// LZ_TREE_LDS_LIMIT overrides (experiments).
+static inline size_t lz_tree_lds_limit(size_t dflt)
+{
+    const char *v = getenv("LZ_TREE_LDS_LIMIT");
+    return v && *v ? (size_t)strtoul(v, nullptr, 0) : dflt;
+}
+
 #ifdef LZ_TREE_DEV_RESTORE_FAST_CONTRACT  // defined by includers that are NOT built with -ffp-contract=off (lz_nn.hip)
 #pragma clang fp contract(fast)          // hipcc's default for device code
 #endif

@@ -8,7 +8,9 @@ import numpy as np
 
 
 def efficientzero_state_dict(seed=0, observation_channels=4, action_space_size=6, num_channels=64, lstm_hidden_size=512,
-                             head_channels=16, head_hidden=32, support_size=601, latent_pixels=36):
+                             head_channels=16, head_hidden=32, support_size=601, latent_pixels=36, muzero=False):
+    """muzero=True: lzero/model/muzero_model.py's layout instead (no LSTM / norm_value_prefix; the reward MLP reads the
+    flattened conv1x1 features, muzero_model.py:505-538)."""
     rng = np.random.default_rng(seed)
     sd = {}
     C, C2, A, H, HC, HID, SUP, HW = num_channels, num_channels // 2, action_space_size, lstm_hidden_size, head_channels, head_hidden, support_size, latent_pixels
@@ -48,10 +50,13 @@ def efficientzero_state_dict(seed=0, observation_channels=4, action_space_size=6
     w(d + "conv.weight", C, C + A, 3, 3); bn(d + "norm_common", C)
     resblock(d + "resblocks.0", C, C)
     w(d + "conv1x1_reward.weight", HC, C, 1, 1); b(d + "conv1x1_reward.bias", HC); bn(d + "norm_reward", HC)
-    w(d + "lstm.weight_ih_l0", 4 * H, HC * HW); w(d + "lstm.weight_hh_l0", 4 * H, H)
-    b(d + "lstm.bias_ih_l0", 4 * H); b(d + "lstm.bias_hh_l0", 4 * H)
-    bn(d + "norm_value_prefix", H)
-    mlp(d + "fc_reward_head", H, SUP)
+    if muzero:
+        mlp(d + "fc_reward_head", HC * HW, SUP)
+    else:
+        w(d + "lstm.weight_ih_l0", 4 * H, HC * HW); w(d + "lstm.weight_hh_l0", 4 * H, H)
+        b(d + "lstm.bias_ih_l0", 4 * H); b(d + "lstm.bias_hh_l0", 4 * H)
+        bn(d + "norm_value_prefix", H)
+        mlp(d + "fc_reward_head", H, SUP)
     d = "prediction_network."
     resblock(d + "resblocks.0", C, C)
     w(d + "conv1x1_value.weight", HC, C, 1, 1); b(d + "conv1x1_value.bias", HC)
@@ -60,3 +65,7 @@ def efficientzero_state_dict(seed=0, observation_channels=4, action_space_size=6
     mlp(d + "fc_value", HC * HW, SUP)
     mlp(d + "fc_policy", HC * HW, A)
     return sd
+
+
+def muzero_state_dict(seed=0, **kw):
+    return efficientzero_state_dict(seed=seed, muzero=True, **kw)

@@ -1,0 +1,76 @@
+"""Search-only timing of BASELINE.json configs[2] on one MI355X: Atari MuZero (conv model, obs 4x96x96, A = 4), 1024 envs x
+400 simulations -- the deep-tree stress case.  obs already in HBM -> distributions / root values on the host.  Synthetic
+seed-0 weights (lightzero_amd.model.synthetic), random obs.
+
+    python tools/bench_conv_configs.py [--envs 1024] [--sims 400] [--steps 5] [--warmup 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--actions", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1, help="independent sub-batches, each on its own engine / HIP stream: the "
+                    "latency-bound tree step of one overlaps the MFMA-bound network step of another")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    from lightzero_amd.model.muzero_model import MuZeroModel
+    from lightzero_amd.model.synthetic import muzero_state_dict
+    import ctypes
+    B, A, S, NS = a.envs, a.actions, a.sims, max(1, a.streams)
+    assert B % NS == 0
+    EPS = B // NS
+    weights = muzero_state_dict(seed=0, action_space_size=A)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
+    torch.cuda.synchronize()
+    legal = [list(range(A))] * EPS
+    rng = np.random.default_rng(0)
+    noises = rng.dirichlet([0.3] * A, size=B).astype(np.float32)
+    parts = []
+    for k in range(NS):
+        if k == 0:
+            e = L.default_engine(0)
+        else:
+            e = L.P()
+            L.check(L.lib().lz_engine_create(0, ctypes.byref(e)))
+        model = MuZeroModel(action_space_size=A, engine=e).load_state_dict(weights)
+        roots = mz_tree.Roots(EPS, legal, action_space_size=A, max_simulations=S, engine=e)
+        parts.append((model, roots, obs[k * EPS:(k + 1) * EPS].contiguous(), np.ascontiguousarray(noises[k * EPS:(k + 1) * EPS])))
+
+    def step():
+        for model, roots, o, nz in parts:  # enqueue every sub-batch before reading anything back
+            roots.reset(legal)
+            model.initial_inference(o, roots, fetch=False)
+            roots.prepare_from_inference(0.25, nz, [-1] * EPS)
+            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 0, 0.01))
+        res = [roots.get_search_results() for _, roots, _, _ in parts]
+        return [np.concatenate([r[i] for r in res]) for i in range(5)]
+
+    for _ in range(a.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    assert (np.asarray(res[0]).sum(1) == S).all()
+    print(json.dumps({"workload": "configs[2] Atari MuZero conv, deep-tree stress", "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS,
+                      "ms_per_step": dt * 1e3, "env_steps_per_s": B / dt, "mcts_sims_per_s": B * S / dt}))
+
+
+if __name__ == "__main__":
+    main()
