@@ -218,7 +218,7 @@ def main():
                        "envs_per_gpu": ENVS, "num_simulations": SIMS, "mcts_sims_per_s": value * SIMS,
                        "tiebreak": args.tiebreak, "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
                        "parallelism": "env-shard x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_chain (per root: dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation)",
+            "roofline": {"bound": "mfma", "kernel": "k_chain (per root: [tree step of the root: expand + backup + next selection, one wave, prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation; achieved counts only the convolution FLOPs over the whole launch)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes of profiles/r01_traffic.json, not re-measured in this run)",
