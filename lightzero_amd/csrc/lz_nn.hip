@@ -916,11 +916,14 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // that the workgroups sharing a weight slice sit on the same XCD (block id % 8).
 // ------------------------------------------------------------------------------------------------
 // XV = float4 per lane of the optional input transform (8 lanes per row): KX = 32 * XV; 0 = no transform compiled in
-template <int NKB, int XV = 0>
+// MR = rows per workgroup: 32, or 16 when 32 staged rows would not fit the 160 KB of LDS (K = 1536: 64x64 observations)
+template <int NKB, int XV = 0, int MR = 32>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
-    constexpr int K = NKB * 16, PS = K + 4, MR = 32, R = 12;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [32][PS]; reused for the gate exchange
+    constexpr int K = NKB * 16, PS = K + 4, R = 12;
+    constexpr int NQ = MR / 16, TPR = 256 / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
+    static_assert(MR == 32 || (MR == 16 && XV == 0), "the input transform is written for 8 staging lanes per row");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [MR][PS]; reused for the gate exchange
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile = blockIdx.x, r0 = blockIdx.y * MR;
     const int H = a.H, KX = a.KX;
@@ -932,12 +935,12 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)min(s, NKB - 1) * 64];
     // everything the cell epilogue needs for this thread's two (row, unit) pairs is requested now: previous cell state, gate
     // biases, BatchNorm scale / shift, reset flag (unconditional loads; dummies where a pointer is null)
-    float c_prev[2], gb[2][4], bns[2], bnt[2];
-    int slen[2];
+    float c_prev[NQ], gb[NQ][4], bns[NQ], bnt[NQ];
+    int slen[NQ];
     const float *bnsp = a.bn_scale ? a.bn_scale : a.bias, *bntp = a.bn_scale ? a.bn_shift : a.bias;
     const int32_t *slp = a.search_len ? a.search_len : a.gather_ix;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int p = tid + 256 * q, row = p >> 4, u = p & 15;
         const int b = min(r0 + row, a.B - 1), unit = tile * 16 + u;
         c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
@@ -946,10 +949,10 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         bns[q] = bnsp[unit]; bnt[q] = bntp[unit];
         slen[q] = slp[b];
     }
-    // stage the rows: [x (KX) | h (H)] per row; 8 threads per row, batches of 12 float4 loads in flight per thread
-    constexpr int K4 = K / 4, NI = (K4 + 7) / 8, NBATCH = 12;
+    // stage the rows: [x (KX) | h (H)] per row; TPR (8) threads per row, batches of 12 float4 loads in flight per thread
+    constexpr int K4 = K / 4, NI = (K4 + TPR - 1) / TPR, NBATCH = 12;
     {
-        const int row = tid >> 3, part = tid & 7;
+        const int row = tid / TPR, part = tid % TPR;
         const int b = min(r0 + row, a.B - 1);
         const int kx4 = KX >> 2;
         const float *xrow = a.x + (size_t)b * KX;
@@ -960,12 +963,12 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
             float4 v[NBATCH];
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
-                const int k4 = min(part + 8 * (i0 + i), K4 - 1);
+                const int k4 = min(part + TPR * (i0 + i), K4 - 1);
                 v[i] = *reinterpret_cast<const float4 *>((k4 < kx4 ? xrow : hrow) + k4 * 4);
             }
 #pragma unroll
             for (int i = 0; i < NBATCH; ++i) {
-                const int k4 = part + 8 * (i0 + i);
+                const int k4 = part + TPR * (i0 + i);
                 if (i0 + i < NI && k4 < K4) *reinterpret_cast<float4 *>(dst + k4 * 4) = v[i];
             }
         }
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     }
     __syncthreads();
     const float *sA0 = smem + (lane & 15) * PS + (lane >> 4) * 4;
-    const float *sA1 = sA0 + 16 * PS;
+    const float *sA1 = sA0 + (MR == 32 ? 16 : 0) * PS;  // MR == 16: the second tile is not computed
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     float4 a0 = *reinterpret_cast<const float4 *>(sA0), a1 = *reinterpret_cast<const float4 *>(sA1);
 #pragma unroll
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a0, j), vget(bfr, j), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a1, j), vget(bfr, j), acc1, 0, 0, 0);
+            if constexpr (MR == 32) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a1, j), vget(bfr, j), acc1, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         a0 = n0;
@@ -1040,12 +1043,12 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             sG[(wv * MR + rq + q) * 17 + col] = acc0[q];
-            sG[(wv * MR + 16 + rq + q) * 17 + col] = acc1[q];
+            if constexpr (MR == 32) sG[(wv * MR + 16 + rq + q) * 17 + col] = acc1[q];
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int p = tid + 256 * q, row = p >> 4, u = p & 15;
         const int b = r0 + row;
         if (b >= a.B) continue;
@@ -1318,23 +1321,30 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 // per action covers the node, and a gather / action table is what the chain would have read anyway
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
 {
-    if (!(a.gw == 6 && a.gh == 6) || a.tstamp || !a.gather_ix || !a.act_table) return false;
+    if (!((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) || a.tstamp || !a.gather_ix || !a.act_table) return false;
     if (step.t.A > 64 || step.t.B != a.B) return false;
     if (step.t.variant != LZ_TREE_EFFICIENTZERO && step.t.variant != LZ_TREE_MUZERO) return false;
     // the staged tree lives in the four activation buffers (4 x 37 x 68 floats = 40 KB) until the latent is loaded over it;
     // staging more than 16 KB per root and simulation was measured slower than walking the HBM arrays (configs[2], 400 sims)
-    const size_t room = (size_t)4 * 37 * 68 * 4, lim = lz_tree_lds_limit(16 * 1024);
+    const size_t room = (size_t)4 * (a.gw * a.gh + 1) * 68 * 4, lim = lz_tree_lds_limit(16 * 1024);
     return lz_tree_lds_bytes(step.t, step.new_node) <= (lim < room ? lim : room);
 }
 
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step)
 {
+    auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + 6 * 128 + extra) * 4; };
     if (step) {
-        const size_t lds = (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 4) * 4;
-        if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain<6, 6, false, 1>), dim3(a.B), dim3(256), lds, s, a, *step);
-        else hipLaunchKernelGGL((k_chain<6, 6, false, 2>), dim3(a.B), dim3(256), lds, s, a, *step);
+        const bool ez = step->t.variant == LZ_TREE_EFFICIENTZERO;
+        if (a.gw == 8) {
+            if (ez) hipLaunchKernelGGL((k_chain<8, 8, false, 1>), dim3(a.B), dim3(256), lds_of(64, 4), s, a, *step);
+            else hipLaunchKernelGGL((k_chain<8, 8, false, 2>), dim3(a.B), dim3(256), lds_of(64, 4), s, a, *step);
+        } else {
+            if (ez) hipLaunchKernelGGL((k_chain<6, 6, false, 1>), dim3(a.B), dim3(256), lds_of(36, 4), s, a, *step);
+            else hipLaunchKernelGGL((k_chain<6, 6, false, 2>), dim3(a.B), dim3(256), lds_of(36, 4), s, a, *step);
+        }
         return;
     }
+    if (a.gw == 8 && a.gh == 8) { hipLaunchKernelGGL((k_chain<8, 8>), dim3(a.B), dim3(256), lds_of(64, 0), s, a, no_step{}); return; }
     if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 64) * 4, s, a, no_step{});
     else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a, no_step{});
     else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)(4 * 82 * 68 + 81 * 68 + 6 * 128) * 4, s, a, no_step{});
@@ -1379,6 +1389,10 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     dim3 grid(a.H / 16, (a.B + 31) / 32), block(256);
     const size_t lds = (size_t)32 * ((size_t)nkb * 16 + 4) * 4;
     const bool xf = a.x_ln_g || a.x_act;
+    if (nkb == 96 && !xf) {  // 1024 + 512 (EfficientZero conv on 64x64 observations: 8x8 latent): 16-row tiles, 98.5 KB of LDS
+        hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        return true;
+    }
     if (nkb == 68 && !xf) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)
     else if (nkb == 48 && a.KX == 256) {                                                    // 256 + 512 (MLP models)
         if (xf) hipLaunchKernelGGL((k_lstm2<48, 8>), grid, block, lds, s, a);

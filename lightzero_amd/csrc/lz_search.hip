@@ -58,7 +58,11 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     }
     LZ_REQUIRE(cfg->num_channels == 64, "num_channels must be 64");
     if (cfg->downsample) {
-        LZ_REQUIRE(cfg->obs_h == 96 && cfg->obs_w == 96, "observation must be 96x96 on the downsample path");
+        // the two sizes the reference models define a latent size for (efficientzero_model.py:121-124): 96x96 ends on a 6x6
+        // latent; 64x64 (the shipped Atari configs, zoo/atari/config/atari_efficientzero_config.py:29) skips DownSample's
+        // last pooling (common.py:355-359) and ends on 8x8
+        LZ_REQUIRE(cfg->obs_h == cfg->obs_w && (cfg->obs_h == 96 || cfg->obs_h == 64),
+                   "observation must be 96x96 or 64x64 on the downsample path (efficientzero_model.py:121-124)");
         LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
     } else {
         LZ_REQUIRE(cfg->obs_h == 9 && cfg->obs_w == 9, "without downsample the compiled latent grid is 9x9 (Go)");
@@ -67,13 +71,19 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
+    if (cfg->model_type == 0) {  // the value-prefix LSTM reads [16 channels x latent pixels | hidden]: compiled K shapes
+        const int g = cfg->downsample ? (cfg->obs_h == 64 ? 8 : 6) : cfg->obs_h;
+        const int K = cfg->head_channels * g * g + cfg->lstm_hidden_size;
+        const bool frag = K / 16 == 68 || K / 16 == 96, chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 9);
+        LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): 6x6 latent with hidden 512 | 256, 8x8 latent (64x64 observations) with hidden 512");
+    }
     if (e->model) lz_model_destroy(e->model);
     e->model = new (std::nothrow) lz_model();
     if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
     e->model->cfg = *cfg;
     if (e->model->cfg.bn_eps <= 0) e->model->cfg.bn_eps = 1e-5f;
-    e->model->GW = cfg->downsample ? 6 : cfg->obs_w;
-    e->model->GH = cfg->downsample ? 6 : cfg->obs_h;
+    e->model->GW = cfg->downsample ? (cfg->obs_w == 64 ? 8 : 6) : cfg->obs_w;
+    e->model->GH = cfg->downsample ? (cfg->obs_h == 64 ? 8 : 6) : cfg->obs_h;
     e->model->HWl = e->model->GW * e->model->GH;
     return LZ_OK;
 }
@@ -371,29 +381,35 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     // DownSample (common.py:266-365)
     int stage = 0;
 #define LZ_STAGE() do { if (m->debug_stop == ++stage) { LZ_HIP_CHECK(hipStreamSynchronize(s)); return LZ_OK; } } while (0)
-    lz_launch_conv_first(d_obs, m->first_w, m->first_s, m->first_t, w0, B, c.obs_c, c.obs_h, c.obs_w, C / 2, s);  // 48x48x32
+    // grid sizes for 96 | 64 observations: S1 = 48 | 32, S2 = 24 | 16, S3 = 12 | 8, then 6 | (no second pooling)
+    const int S1 = c.obs_h / 2, S2 = (S1 + 1) / 2, S3 = (S2 + 1) / 2;
+    lz_launch_conv_first(d_obs, m->first_w, m->first_s, m->first_t, w0, B, c.obs_c, c.obs_h, c.obs_w, C / 2, s);  // S1 x S1 x 32
     LZ_STAGE();
-    conv(m->r1a, w0, w1, B, 48, 48, 1, nullptr, 1, s);
+    conv(m->r1a, w0, w1, B, S1, S1, 1, nullptr, 1, s);
     LZ_STAGE();
-    conv(m->r1b, w1, w2, B, 48, 48, 1, w0, 1, s);            // w2: 48x48x32
+    conv(m->r1b, w1, w2, B, S1, S1, 1, w0, 1, s);            // w2: S1 x S1 x 32
     LZ_STAGE();
-    conv(m->dn1, w2, w0, B, 48, 24, 2, nullptr, 1, s);       // w0: 24x24x64
+    conv(m->dn1, w2, w0, B, S1, S2, 2, nullptr, 1, s);       // w0: S2 x S2 x 64
     LZ_STAGE();
-    conv(m->dn3, w2, w1, B, 48, 24, 2, nullptr, 0, s);       // w1: identity path (no norm, no act)
+    conv(m->dn3, w2, w1, B, S1, S2, 2, nullptr, 0, s);       // w1: identity path (no norm, no act)
     LZ_STAGE();
-    conv(m->dn2, w0, w2, B, 24, 24, 1, w1, 1, s);            // w2: 24x24x64
+    conv(m->dn2, w0, w2, B, S2, S2, 1, w1, 1, s);            // w2: S2 x S2 x 64
     LZ_STAGE();
-    conv(m->r2a, w2, w0, B, 24, 24, 1, nullptr, 1, s);
+    conv(m->r2a, w2, w0, B, S2, S2, 1, nullptr, 1, s);
     LZ_STAGE();
-    conv(m->r2b, w0, w1, B, 24, 24, 1, w2, 1, s);            // w1
+    conv(m->r2b, w0, w1, B, S2, S2, 1, w2, 1, s);            // w1
     LZ_STAGE();
-    lz_launch_avgpool(w1, w0, B, 24, 24, C, s);               // w0: 12x12x64
+    lz_launch_avgpool(w1, w0, B, S2, S2, C, s);               // w0: S3 x S3 x 64
     LZ_STAGE();
-    conv(m->r3a, w0, w1, B, 12, 12, 1, nullptr, 1, s);
+    conv(m->r3a, w0, w1, B, S3, S3, 1, nullptr, 1, s);
     LZ_STAGE();
-    conv(m->r3b, w1, w2, B, 12, 12, 1, w0, 1, s);            // w2
+    conv(m->r3b, w1, w2, B, S3, S3, 1, w0, 1, s);            // w2
     LZ_STAGE();
-    lz_launch_avgpool(w2, w0, B, 12, 12, C, s);               // w0: 6x6x64
+    if (c.obs_h == 64) {                                      // common.py:358-359: no second pooling
+        LZ_HIP_CHECK(hipMemcpyAsync(w0, w2, (size_t)B * S3 * S3 * C * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        lz_launch_avgpool(w2, w0, B, S3, S3, C, s);           // w0: 6x6x64
+    }
     LZ_STAGE();
     }
 #undef LZ_STAGE

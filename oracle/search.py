@@ -20,7 +20,7 @@ from .torch_models import InverseScalarTransform
 def ez_search(tree, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch, cfg, device="cpu",
               record=None):
     """cfg: dict(num_simulations, pb_c_base, pb_c_init, discount_factor, value_delta_max, lstm_horizon_len)."""
-    ist = InverseScalarTransform(device=device)
+    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         batch_size = roots.num
@@ -72,7 +72,7 @@ def ez_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
                        record=None):
     """obs: torch [B,C,H,W] on ``device``.  Returns (visit-count distributions, root values, predicted values,
     policy logits) like efficientzero.py:582-615."""
-    ist = InverseScalarTransform(device=device)
+    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         out = model.initial_inference(obs)
@@ -94,7 +94,7 @@ def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device
     """MuZeroMCTSCtree.search  lzero/mcts/tree_search/mcts_ctree.py:267-368 (the reference calls
     recurrent_inference twice per simulation, :338 and :340-345, and discards the first result; it is called once
     here, which leaves the outputs unchanged)."""
-    ist = InverseScalarTransform(device=device)
+    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         batch_size = roots.num
@@ -124,7 +124,7 @@ def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device
 def mz_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, device="cpu", roots_kwargs=None,
                        deterministic=None):
     """MuZeroPolicy._forward_collect up to get_distributions/get_values  lzero/policy/muzero.py:745-790."""
-    ist = InverseScalarTransform(device=device)
+    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         out = model.initial_inference(obs)

@@ -1,0 +1,128 @@
+"""GPU: the reference's shipped Atari configuration (zoo/atari/config/atari_efficientzero_config.py:29-49,
+atari_muzero_config.py): observations 4x64x64, DownSample without its last pooling (common.py:355-359) -> 8x8x64 latent,
+supports (-50, 51, 1).  Network kernels vs the torch restatement (teacher-forced, tolerances of tests/test_nn_gpu.py) and
+the fused search vs the oracle pipeline."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SUP = (-50., 51., 1.)
+CFG = dict(num_simulations=20, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
+           lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3, support_range=SUP)
+
+
+def _maxdiff(a, b):
+    """max |a - b| / max(1, |b|): absolute below magnitude 1, relative above (the 8x8 latents of the synthetic weights reach
+    a few hundred, where one fp32 ulp is already 3e-5)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def _models(family, A, seed=0):
+    from oracle import torch_models as tm
+    kw = dict(observation_shape=(4, 64, 64), action_space_size=A, reward_support_range=SUP, value_support_range=SUP)
+    if family == "ez":
+        from lightzero_amd.model.efficientzero_model import EfficientZeroModel as M
+        ref = tm.synthetic_init(tm.EfficientZeroModel(**kw), seed=seed)
+    else:
+        from lightzero_amd.model.muzero_model import MuZeroModel as M
+        ref = tm.synthetic_init(tm.MuZeroModel(**kw), seed=seed)
+    return ref, M(**kw).load_state_dict(ref.state_dict())
+
+
+def test_efficientzero_64x64_networks_match_torch_teacher_forced():
+    from lightzero_amd import _lib as L
+    from oracle import torch_models as tm
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    B, A, S = 19, 6, 10
+    ref, dev = _models("ez", A)
+    obs = torch.rand(B, 4, 64, 64, generator=torch.Generator().manual_seed(3))
+    roots = ez_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    lib = L.lib()
+    out = dev.initial_inference(obs.cuda().contiguous(), roots)
+    ist = tm.InverseScalarTransform(SUP)
+    with torch.no_grad():
+        o = ref.initial_inference(obs)
+    lat0 = np.zeros((B, 64, 8, 8), np.float32)
+    L.check(lib.lz_roots_read_latent(roots._h, 0, lat0.reshape(-1)))
+    assert _maxdiff(lat0, o.latent_state.numpy()) < 2e-5
+    assert _maxdiff(out.policy_logits, o.policy_logits.numpy()) < 2e-5
+    assert _maxdiff(out.value, ist(o.value).reshape(-1).numpy()) < 3e-4
+    rng = np.random.default_rng(0)
+    noises = rng.dirichlet([0.3] * A, size=B).astype(np.float32)
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    L.check(lib.lz_roots_enable_trace(roots._h, 1))
+    L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+    trace = np.zeros((S, B, 4), np.int32)
+    L.check(lib.lz_roots_read_trace(roots._h, S, trace.reshape(-1)))
+    lat = np.zeros((S + 1, B, 64, 8, 8), np.float32); hh = np.zeros((S + 1, B, 512), np.float32); cc = np.zeros_like(hh)
+    vp = np.zeros((S + 1, B), np.float32); val = np.zeros_like(vp); pol = np.zeros((S + 1, B, A), np.float32)
+    for s in range(S + 1):
+        L.check(lib.lz_roots_read_latent(roots._h, s, lat[s].reshape(-1)))
+        L.check(lib.lz_roots_read_hidden(roots._h, s, hh[s].reshape(-1), cc[s].reshape(-1)))
+        L.check(lib.lz_roots_read_sim_outputs(roots._h, s, vp[s], val[s], pol[s].reshape(-1)))
+    ar = np.arange(B)
+    worst = dict(lat=0.0, h=0.0, c=0.0, pol=0.0, vp=0.0, val=0.0)
+    for s in range(S):
+        ix, act, slen = trace[s, :, 0], trace[s, :, 1], trace[s, :, 2]
+        with torch.no_grad():
+            o = ref.recurrent_inference(torch.from_numpy(lat[ix, ar]),
+                                        (torch.from_numpy(hh[ix, ar]).unsqueeze(0), torch.from_numpy(cc[ix, ar]).unsqueeze(0)),
+                                        torch.from_numpy(act).long())
+            r_vp = ist(o.value_prefix).reshape(-1).numpy(); r_val = ist(o.value).reshape(-1).numpy()
+            rh = o.reward_hidden_state[0][0].numpy().copy(); rc = o.reward_hidden_state[1][0].numpy().copy()
+        reset = (slen % 5 == 0)
+        rh[reset] = 0; rc[reset] = 0  # mcts_ctree.py:859-863
+        worst["lat"] = max(worst["lat"], _maxdiff(lat[s + 1], o.latent_state.numpy()))
+        worst["h"] = max(worst["h"], _maxdiff(hh[s + 1], rh)); worst["c"] = max(worst["c"], _maxdiff(cc[s + 1], rc))
+        worst["pol"] = max(worst["pol"], _maxdiff(pol[s + 1], o.policy_logits.numpy()))
+        worst["vp"] = max(worst["vp"], _maxdiff(vp[s + 1], r_vp)); worst["val"] = max(worst["val"], _maxdiff(val[s + 1], r_val))
+    print("worst abs diffs:", worst)
+    assert worst["lat"] < 2e-5 and worst["h"] < 2e-5 and worst["c"] < 2e-5 and worst["pol"] < 2e-5, worst
+    assert worst["vp"] < 3e-4 and worst["val"] < 3e-4, worst
+    assert (np.array(roots.get_distributions()).sum(1) == S).all()
+
+
+@pytest.mark.parametrize("family", ["ez", "mz"])
+def test_64x64_fused_search_vs_oracle_pipeline(family):
+    """the graph-captured search (tree step in the 8x8 chain's prologue) vs reference-style driver + torch model + CPU ctree
+    oracle: >= 90 % of the roots with identical visit distributions, root values within 2e-3 on those."""
+    from oracle import ctree as octree, search as osearch, torch_models as tm
+    from lightzero_amd import _lib as L
+    B, A, S = 48, 6, CFG["num_simulations"]
+    ref, model = _models(family, A, seed=1)
+    obs = torch.rand(B, 4, 64, 64, generator=torch.Generator().manual_seed(6))
+    rng = np.random.default_rng(1)
+    noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    legal = [list(range(A))] * B
+    kw = dict(roots_kwargs=dict(action_space_size=A, max_simulations=S))
+    if family == "ez":
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as dtree
+        o_dist, o_val, o_pred, o_logits = osearch.ez_forward_collect(octree.ez_tree, ref, obs, legal, noises, [-1] * B, CFG, **kw)
+        horizon = CFG["lstm_horizon_len"]
+    else:
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as dtree
+        o_dist, o_val, o_pred, o_logits = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, [-1] * B, CFG, **kw)
+        horizon = 0
+    roots = dtree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    out = model.initial_inference(obs.cuda().contiguous(), roots)
+    roots.prepare_from_inference(CFG["root_noise_weight"], noises, [-1] * B)
+    L.check(L.lib().lz_search(roots._h, S, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], horizon, CFG["value_delta_max"]))
+    d_dist, d_val = roots.get_distributions(), np.array(roots.get_values())
+    same = np.array([a == b for a, b in zip(o_dist, d_dist)])
+    print("identical visit distributions: %d / %d" % (same.sum(), B))
+    assert same.mean() >= 0.9
+    assert np.abs(np.array(o_val) - d_val)[same].max() < 2e-3
+    assert np.abs(o_pred - out.value).max() < 3e-4
+    assert np.abs(np.array(o_logits) - out.policy_logits).max() < 2e-5
+
+
+def test_unsupported_observation_size_is_refused():
+    from lightzero_amd import _lib as L
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    with pytest.raises(L.LzError):
+        EfficientZeroModel(observation_shape=(4, 84, 84), action_space_size=6)

@@ -1,8 +1,10 @@
-"""Search-only timing of BASELINE.json configs[2] on one MI355X: Atari MuZero (conv model, obs 4x96x96, A = 4), 1024 envs x
-400 simulations -- the deep-tree stress case.  obs already in HBM -> distributions / root values on the host.  Synthetic
-seed-0 weights (lightzero_amd.model.synthetic), random obs.
+"""Search-only timing of the conv-model configurations on one MI355X.  Default: BASELINE.json configs[2], Atari MuZero (obs
+4x96x96, A = 4), 1024 envs x 400 simulations -- the deep-tree stress case.  obs already in HBM -> distributions / root
+values on the host.  Synthetic seed-0 weights (lightzero_amd.model.synthetic), random obs.
 
-    python tools/bench_conv_configs.py [--envs 1024] [--sims 400] [--steps 5] [--warmup 2]
+    python tools/bench_conv_configs.py [--envs 1024] [--sims 400] [--steps 5] [--warmup 2] [--streams 2]
+    python tools/bench_conv_configs.py --family ez --obs 64 --envs 256 --sims 50 --actions 6 --steps 20
+        (the reference's shipped Atari EfficientZero configuration: 64x64 observations, 8x8 latent, support (-50, 51, 1))
 """
 import argparse
 import json
@@ -20,21 +22,30 @@ def main():
     ap.add_argument("--actions", type=int, default=4)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--family", choices=["mz", "ez"], default="mz")
+    ap.add_argument("--obs", type=int, choices=[96, 64], default=96)
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches, each on its own engine / HIP stream: the "
                     "latency-bound tree step of one overlaps the MFMA-bound network step of another")
     a = ap.parse_args()
     import numpy as np
     import torch
     from lightzero_amd import _lib as L
-    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
-    from lightzero_amd.model.muzero_model import MuZeroModel
-    from lightzero_amd.model.synthetic import muzero_state_dict
+    from lightzero_amd.model.synthetic import efficientzero_state_dict
+    if a.family == "mz":
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as tree
+        from lightzero_amd.model.muzero_model import MuZeroModel as Model
+    else:
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+        from lightzero_amd.model.efficientzero_model import EfficientZeroModel as Model
     import ctypes
     B, A, S, NS = a.envs, a.actions, a.sims, max(1, a.streams)
     assert B % NS == 0
     EPS = B // NS
-    weights = muzero_state_dict(seed=0, action_space_size=A)
-    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
+    sup = (-300., 301., 1.) if a.obs == 96 else (-50., 51., 1.)
+    weights = efficientzero_state_dict(seed=0, action_space_size=A, muzero=a.family == "mz", latent_pixels=36 if a.obs == 96 else 64,
+                                       support_size=int(sup[1] - sup[0]))
+    mkw = dict(observation_shape=(4, a.obs, a.obs), action_space_size=A, reward_support_range=sup, value_support_range=sup)
+    obs = torch.rand(B, 4, a.obs, a.obs, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
     torch.cuda.synchronize()
     legal = [list(range(A))] * EPS
     rng = np.random.default_rng(0)
@@ -46,8 +57,8 @@ def main():
         else:
             e = L.P()
             L.check(L.lib().lz_engine_create(0, ctypes.byref(e)))
-        model = MuZeroModel(action_space_size=A, engine=e).load_state_dict(weights)
-        roots = mz_tree.Roots(EPS, legal, action_space_size=A, max_simulations=S, engine=e)
+        model = Model(engine=e, **mkw).load_state_dict(weights)
+        roots = tree.Roots(EPS, legal, action_space_size=A, max_simulations=S, engine=e)
         parts.append((model, roots, obs[k * EPS:(k + 1) * EPS].contiguous(), np.ascontiguousarray(noises[k * EPS:(k + 1) * EPS])))
 
     def step():
@@ -55,7 +66,7 @@ def main():
             roots.reset(legal)
             model.initial_inference(o, roots, fetch=False)
             roots.prepare_from_inference(0.25, nz, [-1] * EPS)
-            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 0, 0.01))
+            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5 if a.family == "ez" else 0, 0.01))
         res = [roots.get_search_results() for _, roots, _, _ in parts]
         return [np.concatenate([r[i] for r in res]) for i in range(5)]
 
@@ -68,7 +79,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     assert (np.asarray(res[0]).sum(1) == S).all()
-    print(json.dumps({"workload": "configs[2] Atari MuZero conv, deep-tree stress", "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS,
+    print(json.dumps({"workload": "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS,
                       "ms_per_step": dt * 1e3, "env_steps_per_s": B / dt, "mcts_sims_per_s": B * S / dt}))
 
 
