@@ -65,15 +65,16 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
                    "observation must be 96x96 or 64x64 on the downsample path (efficientzero_model.py:121-124)");
         LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
     } else {
-        LZ_REQUIRE(cfg->obs_h == 9 && cfg->obs_w == 9, "without downsample the compiled latent grid is 9x9 (Go)");
+        LZ_REQUIRE((cfg->obs_h == 9 && cfg->obs_w == 9) || (cfg->obs_h == 6 && cfg->obs_w == 7),
+                   "without downsample the compiled latent grids are 9x9 (Go) and 6x7 (Connect4, zoo/board_games/connect4/config)");
         LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_c <= 64, "obs_c must be in [1, 64]");
     }
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
     if (cfg->model_type == 0) {  // the value-prefix LSTM reads [16 channels x latent pixels | hidden]: compiled K shapes
-        const int g = cfg->downsample ? (cfg->obs_h == 64 ? 8 : 6) : cfg->obs_h;
-        const int K = cfg->head_channels * g * g + cfg->lstm_hidden_size;
+        const int gpix = cfg->downsample ? (cfg->obs_h == 64 ? 64 : 36) : cfg->obs_h * cfg->obs_w;
+        const int K = cfg->head_channels * gpix + cfg->lstm_hidden_size;
         const bool frag = K / 16 == 68 || K / 16 == 96, chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 9);
         LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): 6x6 latent with hidden 512 | 256, 8x8 latent (64x64 observations) with hidden 512");
     }

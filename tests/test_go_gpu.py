@@ -10,16 +10,20 @@ pytestmark = pytest.mark.gpu
 CFG = dict(num_simulations=30, pb_c_base=19652, pb_c_init=1.25, discount_factor=1.0, value_delta_max=0.01,
            root_noise_weight=0.25, root_dirichlet_alpha=0.3)
 A = 82
+# (observation_shape, action space): Go 9x9, and Connect4 (zoo/board_games/connect4/config/connect4_muzero_bot_mode_config.py:
+# 31-35: obs 3x6x7, 7 columns, 64 channels) -- a non-square grid with a padded last M-tile (42 = 2 x 16 + 10 pixels)
+GAMES = {"go": ((17, 9, 9), 82), "connect4": ((3, 6, 7), 7)}
 
 
-def _setup(B, seed=0):
+def _setup(B, seed=0, game="go"):
     from oracle import torch_models as tm
     from lightzero_amd.model.muzero_model import MuZeroModel
-    kw = dict(observation_shape=(17, 9, 9), action_space_size=A, downsample=False)
+    shape, A = GAMES[game]
+    kw = dict(observation_shape=shape, action_space_size=A, downsample=False)
     ref = tm.synthetic_init(tm.MuZeroModel(**kw), seed=seed)
     dev = MuZeroModel(**kw).load_state_dict(ref.state_dict())
     g = torch.Generator().manual_seed(seed + 1)
-    obs = (torch.rand(B, 17, 9, 9, generator=g) < 0.3).float()
+    obs = (torch.rand(B, *shape, generator=g) < 0.3).float()
     rng = np.random.default_rng(seed)
     legal = []
     for _ in range(B):
@@ -31,19 +35,21 @@ def _setup(B, seed=0):
     return ref, dev, obs, legal, to_play, noises
 
 
-def test_go_fused_search_vs_oracle():
+@pytest.mark.parametrize("game", sorted(GAMES))
+def test_go_fused_search_vs_oracle(game):
     from oracle import ctree as octree, search as osearch, torch_models as tm
     from lightzero_amd import _lib as L
     from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
     B, S = 16, CFG["num_simulations"]
-    ref, model, obs, legal, to_play, noises = _setup(B)
+    (_, GH, GW), A = GAMES[game]
+    ref, model, obs, legal, to_play, noises = _setup(B, game=game)
     lib = L.lib()
     roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
     roots.set_tiebreak(0)
     out = model.initial_inference(obs.cuda().contiguous(), roots)
     with torch.no_grad():
         o = ref.initial_inference(obs)
-    lat0 = np.zeros((B, 64, 9, 9), np.float32)
+    lat0 = np.zeros((B, 64, GH, GW), np.float32)
     L.check(lib.lz_roots_read_latent(roots._h, 0, lat0.reshape(-1)))
     assert np.abs(lat0 - o.latent_state.numpy()).max() < 2e-5
     assert np.abs(out.policy_logits - o.policy_logits.numpy()).max() < 2e-5
@@ -52,7 +58,7 @@ def test_go_fused_search_vs_oracle():
     L.check(lib.lz_search(roots._h, S, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], 0, CFG["value_delta_max"]))
     trace = np.zeros((S, B, 4), np.int32)
     L.check(lib.lz_roots_read_trace(roots._h, S, trace.reshape(-1)))
-    lat = np.zeros((S + 1, B, 64, 9, 9), np.float32)
+    lat = np.zeros((S + 1, B, 64, GH, GW), np.float32)
     rew = np.zeros((S + 1, B), np.float32); val = np.zeros_like(rew); pol = np.zeros((S + 1, B, A), np.float32)
     for s in range(S + 1):
         L.check(lib.lz_roots_read_latent(roots._h, s, lat[s].reshape(-1)))
