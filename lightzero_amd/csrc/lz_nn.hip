@@ -1077,13 +1077,10 @@ struct head_pack { lz_head_desc h[MAXH]; };
 template <int N, bool IS_MAX, int NWAVES>
 __device__ __forceinline__ void block_reduce_n(float (&v)[N], float *scratch)
 {
+    // per-wave part on the DPP path (lz_wave.h): six ds_bpermute round trips per value otherwise sit on the kernel's
+    // critical path (three dependent reductions per launch)
 #pragma unroll
-    for (int k = 0; k < N; ++k)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float t = __shfl_xor(v[k], o);
-            v[k] = IS_MAX ? fmaxf(v[k], t) : v[k] + t;
-        }
+    for (int k = 0; k < N; ++k) v[k] = IS_MAX ? wave_max(v[k]) : wave_sum(v[k]);
     const int wv = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
@@ -1170,10 +1167,7 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
             }
         }
 #pragma unroll
-        for (int e = 0; e < EPB; ++e) {
-#pragma unroll
-            for (int o = 1; o < PARTS; o <<= 1) acc[e] += __shfl_xor(acc[e], o);
-        }
+        for (int e = 0; e < EPB; ++e) acc[e] = group_sum<PARTS>(acc[e]);  // PARTS lanes of one DPP row share a hidden unit
         if (u < HID && part == 0) {
 #pragma unroll
             for (int e = 0; e < EPB; ++e) hid[e * HID + u] = fmaxf((acc[e] + b1v) * s1v + t1v, 0.0f);

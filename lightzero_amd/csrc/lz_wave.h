@@ -22,6 +22,31 @@ __device__ __forceinline__ float wave_red(float v)
 #undef LZ_DPP
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// Wave-wide sum on the same path (fixed pairing order: quads, half rows, rows, then rows 0+1, 2+3, all).  Rows that a
+// row_bcast step does not write add 0.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#define LZ_DPP0(ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+    v += LZ_DPP0(0xB1, 0xf);
+    v += LZ_DPP0(0x4E, 0xf);
+    v += LZ_DPP0(0x141, 0xf);
+    v += LZ_DPP0(0x140, 0xf);
+    v += LZ_DPP0(0x142, 0xa);
+    v += LZ_DPP0(0x143, 0xc);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// sum over aligned groups of N = 4 | 8 | 16 consecutive lanes (every lane of the group gets it)
+template <int N>
+__device__ __forceinline__ float group_sum(float v)
+{
+    static_assert(N == 4 || N == 8 || N == 16, "DPP rows are 16 lanes");
+    v += LZ_DPP0(0xB1, 0xf);
+    v += LZ_DPP0(0x4E, 0xf);
+    if (N >= 8) v += LZ_DPP0(0x141, 0xf);
+    if (N >= 16) v += LZ_DPP0(0x140, 0xf);
+#undef LZ_DPP0
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) { return wave_red<true>(v); }
 __device__ __forceinline__ float wave_min(float v) { return wave_red<false>(v); }
 
