@@ -5,6 +5,7 @@
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the working tree.
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -43,10 +44,27 @@ def build(force=False, verbose=False):
             continue
         op = sp[:-4] + ".o"
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
-            cmd = [HIPCC] + COMMON + extra + ["-c", sp, "-o", op]
+            # -Rpass-analysis=kernel-resource-usage: per-kernel registers / scratch as compiler remarks.  A kernel that falls
+            # back to scratch memory (an array the optimiser could not keep in registers) costs a round trip per access on
+            # these latency-bound kernels and was once a silent 5 % regression: refuse it.
+            cmd = [HIPCC] + COMMON + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            res = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+            diag = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l and not re.match(r"^\s*(\d+ \|.*|\| +\^)\s*$", l))
+            if diag.strip():
+                sys.stderr.write(diag + "\n")
+            if res.returncode != 0:
+                raise subprocess.CalledProcessError(res.returncode, cmd)
+            name = None
+            for line in res.stderr.splitlines():
+                m = re.search(r"remark: Function Name: (\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+                if m and int(m.group(1)) > 0:
+                    os.remove(op)
+                    raise RuntimeError("%s: kernel %s uses %s bytes of scratch per lane" % (src, name, m.group(1)))
             relink = True
         objs.append(op)
     if relink or any(_newer(o, LIB) for o in objs):

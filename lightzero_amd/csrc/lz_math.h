@@ -41,7 +41,8 @@ LZ_HD uint64_t lz_exp2f_tab(unsigned i)
     return T[i];
 }
 
-LZ_HD float lz_expf(float x)
+// tab: optional copy of the 32-entry table somewhere faster than the constant segment (LDS); NULL = lz_exp2f_tab
+LZ_HD float lz_expf_core(float x, const uint64_t *tab)
 {
     const double InvLn2N = 0x1.71547652b82fep+5;  // 32/ln2
     const double SHIFT = 0x1.8p+52;
@@ -63,7 +64,7 @@ LZ_HD float lz_expf(float x)
     // contracts r and the polynomial.  The contracted form below is the one that matches it on all
     // 2^32 inputs; the uncontracted form differs for 2 inputs near x = -63.1 (tests/test_lz_math.py).
     const double r = __builtin_fma(InvLn2N, xd, -kd);
-    uint64_t t = lz_exp2f_tab((unsigned)(ki & 31));
+    uint64_t t = tab ? tab[ki & 31] : lz_exp2f_tab((unsigned)(ki & 31));
     t += ki << 47;
     const double s = lz_asdouble(t);
     z = __builtin_fma(C0, r, C1);
@@ -73,6 +74,7 @@ LZ_HD float lz_expf(float x)
     y = y * s;
     return (float)y;
 }
+LZ_HD float lz_expf(float x) { return lz_expf_core(x, 0); }
 
 LZ_HD float lz_logf(float x)
 {

@@ -14,6 +14,9 @@
 #define LZ_FLOAT_MAX 1000000.0f  // cminimax.h:9
 #define LZ_FLOAT_MIN (-LZ_FLOAT_MAX)
 
+// bytes of the staged arrays of dev_step_lds for `idx` + 1 nodes, rounded up to 16
+__host__ __device__ static inline size_t lz_tree_lds_bytes_raw(int A, int idx) { return (((size_t)(idx + 1) * ((size_t)A * 20 + 20)) + 15) / 16 * 16; }
+
 namespace {
 
 
@@ -111,7 +114,7 @@ __device__ __forceinline__ void load_scalars(const lz_tree_dev &t, int b, tscal<
 template <int NC, int VARIANT, bool REUSE = false>
 __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &v, const tscal<NC> &sc, const lz_traverse_args &a,
                                              float delta_max, int vtp, int true_action = -1, float reuse_value = 0.0f,
-                                             int32_t *s_out = nullptr)
+                                             int32_t *s_out = nullptr, bool use_tab = false, float tab_pbc = 0.0f, float tab_sq = 0.0f)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
@@ -165,9 +168,17 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
         parent_q = mean_q;
 
         // ---- cucb_score (cnode.cpp:756-814) for every child
+        // use_tab: lane n holds both factors for N = n (computed once per launch, while the tree is being staged): the
+        // software logf with its table fetch and the sqrt leave the per-level dependent chain.  Same expressions, same bits.
         const float N = (float)(node_visit - 1);
-        const float pbc0 = lz_logf((N + base + 1) / base) + a.pb_c_init;
-        const float sq = sqrtf(N);
+        float pbc0, sq;
+        if (use_tab) {
+            pbc0 = rl_f(tab_pbc, node_visit - 1);
+            sq = rl_f(tab_sq, node_visit - 1);
+        } else {
+            pbc0 = lz_logf((N + base + 1) / base) + a.pb_c_init;
+            sq = sqrtf(N);
+        }
         float best = -__builtin_inff();
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -271,7 +282,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
 template <int NC, int VARIANT, bool WT>
 __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &v, tscal<NC> &sc, int new_node, float discount,
                                              float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset,
-                                             bool no_expand = false, int bidx = -1)
+                                             bool no_expand = false, int bidx = -1, const uint64_t *exptab = nullptr)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
@@ -283,7 +294,7 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &
         for (int c = 0; c < NC; ++c) m = fmaxf(m, lg[c]);
         m = wave_max(m);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) e[c] = lz_expf(lg[c] - m);
+        for (int c = 0; c < NC; ++c) e[c] = lz_expf_core(lg[c] - m, exptab);
         float sum = 0.0f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -457,6 +468,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     int32_t *s_tp = s_reset + nn;
     int32_t *s_pn = s_tp + nn;
     int32_t *s_pa = s_pn + nn;
+    uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_tree + lz_tree_lds_bytes_raw(A, new_node) / 16);  // 32 entries, 16-byte aligned
     const tview g = global_view(t, b);
     // ---- one round trip: everything the step reads.  All requests are unconditional (clamped indices) and issued before
     // the first use: a predicated load, or a wave-uniform read of a loaded value in between, would split this into
@@ -474,24 +486,57 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
         r_lg[c] = logits[(size_t)b * A + j];
     }
     const int ne = new_node * A;        // edges / child ids of the existing nodes 0 .. new_node - 1 (ne >= 1)
-    constexpr int UE = 8;
-    for (int i0 = 0; i0 < ne; i0 += UE * 64) {
-        float4 e[UE];
+    // first batch of every array: all requests, then the table arithmetic (it runs while they are in flight), then the LDS stores;
+    // two separate load-then-store loops would be two dependent round trips
+    constexpr int UE = 8, UN = 2;
+    typedef float v4f __attribute__((ext_vector_type(4)));  // native vectors: arrays of HIP's float4 struct end up in scratch here
+    v4f e0[UE];
+    int32_t ch0[UE];
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+        const int i = min(u * 64 + lane, ne - 1);
+        e0[u] = *reinterpret_cast<const v4f *>(g.edge + i);
+        ch0[u] = g.child[i];
+    }
+    float nv0[UN];
+    int32_t nr0[UN], nt0[UN], pn0[UN], pa0[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int i = min(u * 64 + lane, new_node - 1);
+        nv0[u] = g.node_vp[i]; nr0[u] = g.node_reset[i]; nt0[u] = g.node_to_play[i]; pn0[u] = g.path_node[i]; pa0[u] = g.path_act[i];
+    }
+    // tables that take software exp / log table fetches and the sqrt out of the dependent chains below: the 2^(i/32) table of
+    // lz_expf goes to LDS, and lane n computes the exploration factors of a node with visit count n + 1 (N = n <= new_node)
+    if (lane < 32) s_exp[lane] = lz_exp2f_tab((unsigned)lane);
+    const bool use_tab = new_node < 64;
+    const float nf = (float)lane, tab_pbc = lz_logf((nf + (float)a.pb_c_base + 1) / (float)a.pb_c_base) + a.pb_c_init, tab_sq = sqrtf(nf);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+        const int i = u * 64 + lane;
+        if (i < ne) { *reinterpret_cast<v4f *>(s_edge + i) = e0[u]; s_child[i] = ch0[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int i = u * 64 + lane;
+        if (i < new_node) { s_vp[i] = nv0[u]; s_reset[i] = nr0[u]; s_tp[i] = nt0[u]; s_pn[i] = pn0[u]; s_pa[i] = pa0[u]; }
+    }
+    for (int i0 = UE * 64; i0 < ne; i0 += UE * 64) {  // trees beyond 512 edges / 128 nodes: further batches
+        v4f e[UE];
         int32_t ch[UE];
 #pragma unroll
         for (int u = 0; u < UE; ++u) {
             const int i = min(i0 + u * 64 + lane, ne - 1);
-            e[u] = g.edge[i];
+            e[u] = *reinterpret_cast<const v4f *>(g.edge + i);
             ch[u] = g.child[i];
         }
 #pragma unroll
         for (int u = 0; u < UE; ++u) {
             const int i = i0 + u * 64 + lane;
-            if (i < ne) { s_edge[i] = e[u]; s_child[i] = ch[u]; }
+            if (i < ne) { *reinterpret_cast<v4f *>(s_edge + i) = e[u]; s_child[i] = ch[u]; }
         }
     }
-    constexpr int UN = 2;
-    for (int i0 = 0; i0 < new_node; i0 += UN * 64) {
+    for (int i0 = UN * 64; i0 < new_node; i0 += UN * 64) {
         float nv[UN];
         int32_t nr[UN], nt[UN], pn[UN], pa[UN];
 #pragma unroll
@@ -526,17 +571,18 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     tview v = g;
     v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
     v.path_node = s_pn; v.path_act = s_pa;
-    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
+    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset, false, -1, s_exp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out);
+    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
 }
 
 }  // namespace
 
-// LDS bytes of the staged tree of one root after `idx` nodes exist besides the new one (dev_step_lds)
-static inline size_t lz_tree_lds_bytes(const lz_tree_dev &t, int idx) { return (size_t)(idx + 1) * ((size_t)t.A * 20 + 20); }
+// LDS bytes of the staged tree of one root after `idx` nodes exist besides the new one (dev_step_lds): the arrays, rounded up to
+// 16 bytes, then the 32-entry exp table
+static inline size_t lz_tree_lds_bytes(const lz_tree_dev &t, int idx) { return lz_tree_lds_bytes_raw(t.A, idx) + 32 * 8; }
 
 // Largest staged tree (bytes per root) the LDS step is used for; beyond it the step walks the HBM arrays.  Staging costs
 // O(tree) per simulation but every level of the walk then costs an LDS instead of an HBM round trip.
