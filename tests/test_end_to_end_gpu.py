@@ -289,3 +289,40 @@ def test_tree_step_in_the_chain_prologue_is_bit_identical_to_the_separate_launch
     assert all(sum(d) == S for d in res[1][0])
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
     assert np.array_equal(res[0][3], res[1][3])
+
+
+def test_config2_full_size_deep_trees_properties():
+    """BASELINE.json configs[2] at full size: Atari MuZero (conv), 1024 roots x 400 simulations, A = 4 -- the trees outgrow
+    the LDS budget part-way through the search (tree step in the chain prologue -> separate HBM launch).  Size-independent
+    properties: visit counts sum to S, every root value is finite, the search is idempotent (deterministic tie-break), and the
+    run with the tree step kept out of the chain launch (LZ_NO_TREE_FUSE=1, LDS tree kernel -> HBM tree kernel) is
+    bit-identical."""
+    import os
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    from lightzero_amd.model.muzero_model import MuZeroModel
+    from lightzero_amd.model.synthetic import muzero_state_dict
+    B, A, S = 1024, 4, 400
+    model = MuZeroModel(action_space_size=A).load_state_dict(muzero_state_dict(seed=0, action_space_size=A))
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(2)).cuda().contiguous()
+    rng = np.random.default_rng(2)
+    noises = rng.dirichlet([0.3] * A, size=B).astype(np.float32)
+    legal = [list(range(A))] * B
+    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    res = []
+    for env in (None, None, "1"):
+        if env:
+            os.environ["LZ_NO_TREE_FUSE"] = env
+        roots.reset(legal)
+        roots.set_tiebreak(0)
+        model.initial_inference(obs, roots, fetch=False)
+        roots.prepare_from_inference(0.25, noises, [-1] * B)
+        L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 0, 0.01))
+        dist, cnt, val, pred, lg = roots.get_search_results()
+        res.append((dist.copy(), val.copy().view(np.uint32)))
+    os.environ.pop("LZ_NO_TREE_FUSE", None)
+    d0, v0 = res[0]
+    assert (d0.sum(1) == S).all() and (d0 >= 0).all()
+    assert np.isfinite(v0.view(np.float32)).all()
+    for d, v in res[1:]:
+        assert np.array_equal(d, d0) and np.array_equal(v, v0)
