@@ -346,16 +346,26 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ ob
     float acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-#pragma unroll 1
+    // all 9 x C input values are requested before the first use, unconditionally (clamped coordinates, zeroed by a select
+    // afterwards): a predicated load per tap is a branch plus a full wait each, i.e. nine dependent HBM round trips
+    float xv[9][C];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = 2 * y + t / 3 - 1, ix = 2 * x + t % 3 - 1;
+        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) xv[t][ci] = obs[(((size_t)b * C + ci) * H + cy) * W + cx];
+    }
+#pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int iy = 2 * y + t / 3 - 1, ix = 2 * x + t % 3 - 1;
         const bool v = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
         for (int ci = 0; ci < C; ++ci) {
-            const float xv = v ? obs[(((size_t)b * C + ci) * H + iy) * W + ix] : 0.0f;
+            const float xs = v ? xv[t][ci] : 0.0f;
             const float *wr = sw + (t * C + ci) * COUT + g * 8;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] += xv * wr[c];
+            for (int c = 0; c < 8; ++c) acc[c] += xs * wr[c];
         }
     }
     float *o = out + (size_t)m * COUT + g * 8;
