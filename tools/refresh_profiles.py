@@ -1,0 +1,87 @@
+"""Copies the judged summaries of a profiling run into profiles/ (tracked):
+
+    gpurun -- '<the rocprofv3 commands in DESIGN.md section 4, outputs under gpurun_out/<run>/{stats,pmc_sq,pmc_fetch,pmc_write},
+               plus python bench.py > gpurun_out/<run>/bench_n1.json>'
+    python tools/refresh_profiles.py gpurun_out/<run> r01
+
+writes profiles/<tag>_final_kernel_stats.csv, <tag>_bench_n1.json, <tag>_traffic.json, <tag>_pmc_summary.txt.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    run, tag = sys.argv[1], sys.argv[2]
+    prof = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(run, "stats", "*", "*kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(prof, "%s_final_kernel_stats.csv" % tag))
+    line = open(os.path.join(run, "bench_n1.json")).read().strip().splitlines()[-1]
+    bench = json.loads(line)
+    open(os.path.join(prof, "%s_bench_n1.json" % tag), "w").write(line + "\n")
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        for f in glob.glob(os.path.join(run, d, "*", "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(stats))}
+
+    def find(key, table):
+        for name in table:
+            if key in name:
+                return table[name]
+        return None
+
+    def mean(key, counter):
+        t = find(key, acc)
+        v = t.get(counter) if t else None
+        return round(sum(v) / len(v), 2) if v else None
+
+    fused = "k_chain<6, 6, false, 1>"
+    f, w = mean(fused, "FETCH_SIZE"), mean(fused, "WRITE_SIZE")
+    out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and rocprofv3 --kernel-trace --pmc WRITE_SIZE (two separate passes) -- "
+                   "python bench.py --steps 1 --warmup 1 --no-cpu-baseline, MI355X; per-dispatch means in KB as reported "
+                   "(tools/refresh_profiles.py). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B "
+                   "request of a wide coalesced read, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE taken as reported (uncalibrated).",
+           "k_chain": {"fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": int(round((2 * f + w) * 1024)),
+                       "note": "k_chain<6,6,false,1> = the root's tree step (prologue) + the convolution chain. reads: latent gather "
+                               "2.36 MB + 0.74 MB of weights once per XCD L2 (8 x) + the staged trees / leaf outputs of the tree step; "
+                               "writes: next latent 2.36 MB + head-conv outputs 1.77 MB + tree write-through. Algorithmic bytes of "
+                               "the chain 7.2 MB."}}
+    for key in ("k_chain<6, 6, false, 0>", "k_heads<32, 512>", "k_lstm2<68, 0, 32>", "k_conv3x3_big<64, 64, 1, 144>",
+                "k_conv3x3_big<32, 32, 1, 128>", "k_conv3x3_big<32, 64, 2, 48>", "k_conv_first", "k_avgpool"):
+        out[key] = {"fetch_size_kb": mean(key, "FETCH_SIZE"), "write_size_kb": mean(key, "WRITE_SIZE")}
+    json.dump(out, open(os.path.join(prof, "%s_traffic.json" % tag), "w"), indent=1)
+    # MFMA utilisation of the roofline kernel: busy cycles per SIMD over the launch duration at the sustained clock
+    busy = mean(fused, "SQ_VALU_MFMA_BUSY_CYCLES")
+    d_us = find(fused, dur)
+    hdr = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY",
+           "#   + separate passes --pmc FETCH_SIZE / --pmc WRITE_SIZE   -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline   (MI355X)",
+           "# per-dispatch means.  Counters are summed over the 8 XCDs / 1024 SIMDs; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY count quad-cycles;",
+           "# SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (32 per v_mfma_f32_16x16x4_f32, 8 per v_mfma_f32_4x4x1_16b_f32);",
+           "# FETCH_SIZE / WRITE_SIZE in KB (FETCH_SIZE x 2 = bytes read on gfx950, see %s_traffic.json)." % tag]
+    if busy and d_us:
+        per_simd = busy / 1024.0
+        hdr.append("# %s: %.2f M MFMA-busy cycles / 1024 SIMDs = %.1f k cycles per SIMD; launch %.1f us (%s_final_kernel_stats.csv) x ~2.0 GHz"
+                   % (fused, busy / 1e6, per_simd / 1e3, d_us, tag))
+        hdr.append("#   = %.0f k cycles -> MFMA pipe busy %.0f %% of the launch (which includes the tree-step prologue)."
+                   % (d_us * 2.0, 100.0 * per_simd / (d_us * 2000.0)))
+    body = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py")] +
+                          [os.path.join(run, d) for d in ("pmc_sq", "pmc_fetch", "pmc_write")],
+                          stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+    open(os.path.join(prof, "%s_pmc_summary.txt" % tag), "w").write("\n".join(hdr) + "\n" + body)
+    r = bench["roofline"]
+    print("value %.0f env-steps/s, %.3f ms/step; roofline %.1f TFLOP/s frac %.3f (%.1f us/launch); cpu_baseline %.1f; chain %.2f us, traffic %d B"
+          % (bench["value"], bench["ms_per_step"], r["achieved"], r["frac"], r["avg_launch_us"], bench["cpu_baseline"]["value"], d_us or 0,
+             out["k_chain"]["hbm_bytes_per_launch"]))
+
+
+if __name__ == "__main__":
+    main()
