@@ -87,28 +87,31 @@ __device__ __forceinline__ void expand_sampled(const lz_tree_dev &t, int b, int 
                 st = mix64(st);
                 const float u1 = ((float)((st >> 40) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
                 const float u2 = ((float)((st >> 16) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
-                const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+                // hardware log / cos / exp / rcp (~1e-6): these draws are compared with nothing bit for bit (the reference seeds
+                // its generator from the clock; parity runs inject the draws)
+                const float z = __fsqrt_rn(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
                 const float mu = sa.policy[(size_t)b * 2 * D + j], sigma = sa.policy[(size_t)b * 2 * D + D + j];
-                s_act[lane * D + j] = tanhf(mu + sigma * z);
+                s_act[lane * D + j] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * (mu + sigma * z)));
             }
         }
         for (int j = 0; j < D; ++j) gact[lane * D + j] = s_act[lane * D + j];
     }
     __syncthreads();
-    int rp = lane;
-    if (lane < K) {
-        for (int i2 = 0; i2 < lane; ++i2) {
-            bool same = true;
-            for (int j = 0; j < D && same; ++j) same = fkey(s_act[lane * D + j]) == fkey(s_act[i2 * D + j]);
-            if (same) { rp = i2; break; }  // first earlier position with the same key; its own rep is itself or earlier...
+    // rep = the first position whose D keys all equal this lane's (a key class is represented by its first member).  The keys
+    // travel by v_readlane: per dimension one fkey per lane and K uniform steps, instead of a per-lane double loop over LDS
+    // with two fkeys per comparison.
+    uint64_t eq = ~0ull;  // bit i2: position i2 matches this lane on every dimension so far
+    for (int j = 0; j < D; ++j) {
+        const uint64_t kj = fkey(s_act[min(lane, K - 1) * D + j]);
+        const int klo = (int)(uint32_t)kj, khi = (int)(uint32_t)(kj >> 32);
+        uint64_t m = 0;
+        for (int i2 = 0; i2 < K; ++i2) {
+            const int lo2 = __builtin_amdgcn_readlane(klo, i2), hi2 = __builtin_amdgcn_readlane(khi, i2);
+            m |= (uint64_t)((lo2 == klo) & (hi2 == khi)) << i2;
         }
-        // ...so chase once: the first position of a key class always represents itself
-        for (int i2 = 0; i2 < rp; ++i2) {
-            bool same = true;
-            for (int j = 0; j < D && same; ++j) same = fkey(s_act[rp * D + j]) == fkey(s_act[i2 * D + j]);
-            if (same) { rp = i2; break; }
-        }
+        eq &= m;
     }
+    const int rp = lane < K ? __builtin_ctzll(eq | (1ull << lane)) : lane;  // eq always contains the lane itself
     const uint64_t firsts = __ballot(lane < K && rp == lane);
     if (lane < K) {
         const size_t o = ((size_t)b * NN + node) * K + lane;
@@ -156,9 +159,17 @@ __device__ __forceinline__ void dev_straverse(const lz_tree_dev &t, const lz_tra
         const float node_vp = t.node_vp[(size_t)b * NN + node];
         const int node_reset = t.node_reset[(size_t)b * NN + node];
         const int nch = t.nchild[(size_t)b * NN + node];
-        const int rp = valid ? rep_b[(size_t)node * K + lane] : 0;
-        const float4 e = valid ? edge_b[(size_t)node * K + rp] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int chd = valid ? child_b[(size_t)node * K + rp] : -1;
+        // one round trip per level: every lane fetches its OWN slot (unconditional, clamped) next to rep[], then takes the
+        // representative's record from lane rep through the LDS crossbar -- edge[rep[lane]] as a dependent load was a second one
+        const int lc = min(lane, K - 1);
+        const int rp_raw = rep_b[(size_t)node * K + lc];
+        const float4 e_own = edge_b[(size_t)node * K + lc];
+        const int chd_own = child_b[(size_t)node * K + lc];
+        const int rp = valid ? rp_raw : 0;
+        float4 e;
+        e.x = __shfl(e_own.x, rp); e.y = __shfl(e_own.y, rp); e.z = __shfl(e_own.z, rp); e.w = __shfl(e_own.w, rp);
+        int chd = __shfl(chd_own, rp);
+        if (!valid) { e = make_float4(0.f, 0.f, 0.f, 0.f); chd = -1; }
         const int vis = __float_as_int(e.y);
         const float val = (vis == 0) ? 0.0f : e.z / (float)vis;
         float tr = e.w - node_vp;
@@ -198,10 +209,13 @@ __device__ __forceinline__ void dev_straverse(const lz_tree_dev &t, const lz_tra
         if (a.tiebreak == LZ_TIE_RANDOM) {
             const float thr = best - 0.000001f;
             uint64_t mk = __ballot(lane == pos || (lane > pos && score >= thr));
-            const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
-            int r = (int)(h % (uint64_t)__builtin_popcountll(mk));
-            for (int q = 0; q < r; ++q) mk &= mk - 1;
-            pos = __builtin_ctzll(mk);
+            const int cnt = __builtin_popcountll(mk);
+            if (cnt > 1) {  // a single candidate (the usual case once visits differ) needs no draw
+                const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
+                const int r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt) without a 64-bit division
+                for (int q = 0; q < r; ++q) mk &= mk - 1;
+                pos = __builtin_ctzll(mk);
+            }
         }
         const int rpos = rl_i(rp, pos);
         const int nxt = rl_i(chd, pos);
@@ -239,48 +253,88 @@ __device__ __forceinline__ void dev_sbackprop(const lz_tree_dev &t, int new_node
     const int K = t.A, NN = t.NN;
     float4 *edge_b = t.edge + (size_t)b * NN * K;
     int32_t *child_b = t.child + (size_t)b * NN * K;
-    const int d = uni(t.res_search_len[b]);
-    const int to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
+    // Everything that does not depend on another load is requested here, unconditionally, before the first wave-uniform read:
+    // leaf scalars, statistics, the root record and the WHOLE previous path (position = lane).  The backup then needs one
+    // more round trip (the edge / node records of the path entries) instead of five dependent ones.
+    const size_t nb = (size_t)b * NN;
+    const int d_raw = t.res_search_len[b];
+    const int tp_raw = to_play_in ? to_play_in[b] : t.res_vtp[b];
     const float vp_b = vps[b];
-    int reset = 0;
-    if (is_reset) reset = is_reset[b];
-    else if (horizon > 0) reset = (d % horizon == 0) ? 1 : 0;
+    const float value_b = values[b];
+    const int rst_raw = is_reset ? is_reset[b] : 0;
+    float mn = t.minmax[2 * b], mx = t.minmax[2 * b + 1];
+    const int root_visit = t.root_visit[b];
+    const float root_vsum = t.root_vsum[b], root_vp = t.node_vp[nb];
+    const int root_tp = t.node_to_play[nb];
+    const int pl = min(lane, NN - 1);
+    const int pnode_l = t.path_node[nb + pl], pact_l = t.path_act[nb + pl];
     expand_sampled(t, b, new_node, sa, s_act);
-    const int parent = uni(t.path_node[(size_t)b * NN + d - 1]);
-    const int pact = uni(t.path_act[(size_t)b * NN + d - 1]);
+    const int d = uni(d_raw);
+    const int to_play = uni(tp_raw);
+    int reset = 0;
+    if (is_reset) reset = rst_raw;
+    else if (horizon > 0) reset = (d % horizon == 0) ? 1 : 0;
+    const bool short_path = d <= 64;  // every path position sits in a lane (always, unless a search is deeper than 64)
+    const int parent = short_path ? rl_i(pnode_l, d - 1) : uni(t.path_node[nb + d - 1]);
+    const int pact = short_path ? rl_i(pact_l, d - 1) : uni(t.path_act[nb + d - 1]);
     if (lane == 0) {
         child_b[(size_t)parent * K + pact] = new_node;
-        const size_t o = (size_t)b * NN + new_node;
+        const size_t o = nb + new_node;
         t.node_vp[o] = vp_b;
         t.node_reset[o] = reset;
         t.node_to_play[o] = to_play;
         t.node_best[o] = -1;
     }
     // cbackpropagate (cnode.cpp:860-945): identical to the EfficientZero tree
-    float bootstrap = values[b];
-    float mn = t.minmax[2 * b], mx = t.minmax[2 * b + 1];
+    float bootstrap = value_b;
     for (int k0 = d; k0 >= 0; k0 -= 64) {
         const int k = k0 - lane;
         const bool valid = k >= 0;
         int pn = 0, pa = 0, vis = 0, own_tp = to_play, parent_reset = 0;
         float prior = 0.f, vsum = 0.f, own_vp = 0.f, parent_vp = 0.f;
-        if (valid) {
+        if (short_path) {
+            // path entries by lane exchange, then ONE batch of unconditional loads (clamped to entry 0 where k < 1)
+            const bool inner = valid && k >= 1;
+            pn = __shfl(pnode_l, max(k - 1, 0));
+            pa = __shfl(pact_l, max(k - 1, 0));
+            const int pnk = __shfl(pnode_l, min(max(k, 0), 63));
+            pn = inner ? pn : 0;
+            pa = inner ? pa : 0;
+            const float4 e = edge_b[(size_t)pn * K + pa];
+            const float pvp = t.node_vp[nb + pn];
+            const int prs = t.node_reset[nb + pn];
+            const int otp = t.node_to_play[nb + ((inner && k < d) ? pnk : 0)];
+            if (inner) {
+                prior = e.x;
+                vis = __float_as_int(e.y);
+                vsum = e.z;
+                own_vp = (k == d) ? vp_b : e.w;
+                parent_vp = pvp;
+                parent_reset = prs;
+                if (k < d) own_tp = otp;
+            } else if (valid) {
+                vis = root_visit;
+                vsum = root_vsum;
+                own_vp = root_vp;
+                own_tp = root_tp;
+            }
+        } else if (valid) {
             if (k >= 1) {
-                pn = t.path_node[(size_t)b * NN + k - 1];
-                pa = t.path_act[(size_t)b * NN + k - 1];
+                pn = t.path_node[nb + k - 1];
+                pa = t.path_act[nb + k - 1];
                 const float4 e = edge_b[(size_t)pn * K + pa];
                 prior = e.x;
                 vis = __float_as_int(e.y);
                 vsum = e.z;
                 own_vp = (k == d) ? vp_b : e.w;
-                parent_vp = t.node_vp[(size_t)b * NN + pn];
-                parent_reset = t.node_reset[(size_t)b * NN + pn];
-                if (k < d) own_tp = t.node_to_play[(size_t)b * NN + t.path_node[(size_t)b * NN + k]];
+                parent_vp = t.node_vp[nb + pn];
+                parent_reset = t.node_reset[nb + pn];
+                if (k < d) own_tp = t.node_to_play[nb + t.path_node[nb + k]];
             } else {
-                vis = t.root_visit[b];
-                vsum = t.root_vsum[b];
-                own_vp = t.node_vp[(size_t)b * NN];
-                own_tp = t.node_to_play[(size_t)b * NN];
+                vis = root_visit;
+                vsum = root_vsum;
+                own_vp = root_vp;
+                own_tp = root_tp;
             }
         }
         const float true_reward = own_vp - parent_vp;
