@@ -2,8 +2,8 @@
 """Timing of the vector-observation configurations of BASELINE.json on one MI355X (not the headline bench line):
 configs[0] CartPole MuZero MLP (8 envs x 25 sims) and configs[4] Sampled EfficientZero DMC state (K = 20, 64 envs per GPU
 x 50 sims; --envs 256 for the whole 4-GPU batch on one device).  Search only (initial inference -> prepare -> fused
-search -> read-back), inputs resident in HBM, synthetic seeded weights (development tool: it borrows the torch restatements under
-oracle/ to produce reference-format state_dicts for these architectures; nothing of oracle/ runs in the timed loop).
+search -> read-back), inputs resident in HBM, synthetic seeded weights in the reference's state_dict layout
+(lightzero_amd.model.synthetic.mlp_state_dict; tensor shapes committed in lightzero_amd/model/synthetic_mlp_specs.json).
 
     python tools/bench_mlp_configs.py --config 4 --envs 256 --steps 50
 """
@@ -26,15 +26,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     args = ap.parse_args()
     import torch
-    from oracle import torch_models as tm
+    from lightzero_amd.model.synthetic import mlp_state_dict
     from lightzero_amd import _lib as L
     lib = L.lib()
     if args.config == 0:
         from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP
         from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
         B, S, A, OBS = args.envs or 8, 25, 2, 4
-        ref = tm.synthetic_init(tm.MuZeroModelMLP(observation_shape=OBS, action_space_size=A, latent_state_dim=128), seed=0)
-        model = MuZeroModelMLP(observation_shape=OBS, action_space_size=A, latent_state_dim=128).load_state_dict(ref.state_dict())
+        model = MuZeroModelMLP(observation_shape=OBS, action_space_size=A, latent_state_dim=128).load_state_dict(mlp_state_dict("muzero_mlp_cartpole"))
         roots = mz_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S)
         roots.set_tiebreak(1, seed=1)
         roots._ensure(A)
@@ -43,9 +42,8 @@ def main():
         from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
         from lightzero_amd.mcts.ctree.ctree_sampled_efficientzero import ezs_tree
         B, S, A, OBS, K = args.envs or 64, 50, 1, 5, 20
-        ref = tm.synthetic_init(tm.SampledEfficientZeroModelMLP(observation_shape=OBS, action_space_size=A, num_of_sampled_actions=K), seed=0)
         model = SampledEfficientZeroModelMLP(observation_shape=OBS, action_space_size=A, continuous_action_space=True,
-                                             num_of_sampled_actions=K).load_state_dict(ref.state_dict())
+                                             num_of_sampled_actions=K).load_state_dict(mlp_state_dict("sampled_efficientzero_mlp_dmc"))
         roots = ezs_tree.Roots(B, [[-1] * K] * B, A, K, True, max_simulations=S)
         horizon, name = 5, "configs[4] DMC-state SampledEfficientZeroModelMLP K=20"
     obs = torch.rand(B, OBS, generator=torch.Generator().manual_seed(0)).cuda().contiguous()
