@@ -102,6 +102,7 @@ struct lz_graph_key {
     float delta;
     int players, tiebreak;
     uint64_t seed;
+    uint64_t knobs;   // the debugging switches that change the captured launch sequence (so that toggling one re-captures)
 };
 
 struct lz_roots {

@@ -754,8 +754,19 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
         LZ_HIP_CHECK(hipGetLastError());
         return LZ_OK;
     }
-    lz_graph_key key{num_simulations, pb_c_base, pb_c_init, discount_factor, lstm_horizon_len, value_delta_max, r->players,
-                     r->tiebreak, r->seed};
+    uint64_t knobs = 0;
+    {
+        const char *names[] = {"LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256", "LZ_DEBUG_SKIP"};
+        for (const char *n : names) {
+            const char *v = getenv(n);
+            knobs = knobs * 1000003ull + 7;
+            for (; v && *v; ++v) knobs = knobs * 131ull + (unsigned char)*v;
+        }
+    }
+    lz_graph_key key{};  // value-initialised: the padding takes part in the memcmp below
+    key.sims = num_simulations; key.pb_c_base = pb_c_base; key.pb_c_init = pb_c_init; key.discount = discount_factor;
+    key.horizon = lstm_horizon_len; key.delta = value_delta_max; key.players = r->players; key.tiebreak = r->tiebreak;
+    key.seed = r->seed; key.knobs = knobs;
     if (!r->graph_exec || memcmp(&key, &r->graph_key, sizeof(key)) != 0) {
         if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
         hipGraph_t g = nullptr;
