@@ -75,6 +75,11 @@ int lz_roots_create(lz_engine *e, int variant, int root_num, int action_space_si
 /* Re-arm an existing batch of trees for the next env-step with new legal-action lists (same root_num and
  * action space): what constructing a fresh Roots does in the reference, without re-allocating the HBM pools. */
 int lz_roots_reset(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count);
+/* The same re-arm for a batch whose root inference (lz_initial_inference) is ALREADY enqueued for this env-step: the
+ * legal-action lists may arrive after the representation network was launched, so that the host work that builds them
+ * (efficientzero.py:579: one np.nonzero per env) overlaps the network instead of preceding it.  Keeps the root latent /
+ * predictions; everything else as lz_roots_reset. */
+int lz_roots_reset_keep_inference(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count);
 int lz_roots_destroy(lz_roots *r);
 int lz_roots_num(const lz_roots *r);
 /* MinMaxStatsList.set_delta                      ez_tree.pyx:12-14 -> cminimax.cpp:61-65.
@@ -250,6 +255,12 @@ int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy
  * lz_initial_inference (h_pred_values / h_policy_logits may be NULL) */
 int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
                                 float *h_pred_values, float *h_policy_logits);
+/* The same read-back with lz_roots_select_action (select_action, lzero/policy/utils.py:637-661) for every root computed on
+ * the device before it, so that a collect forward has ONE device-host synchronisation after the search: h_action_pos
+ * [root_num] positions in the legal list, h_entropy [root_num] bits. */
+int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
+                                       float *h_pred_values, float *h_policy_logits, double temperature, int deterministic,
+                                       uint64_t seed, int32_t *h_action_pos, double *h_entropy);
 /* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
  * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
 int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,

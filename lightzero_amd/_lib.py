@@ -55,6 +55,7 @@ def lib():
         "lz_roots_create": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(P)],
         "lz_roots_destroy": [P],
         "lz_roots_reset": [P, c_i32p, c_i32p],
+        "lz_roots_reset_keep_inference": [P, c_i32p, c_i32p],
         "lz_roots_minmax_reset": [P, ctypes.c_float],
         "lz_roots_set_tiebreak": [P, ctypes.c_int, ctypes.c_uint64],
         "lz_roots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_i32p],
@@ -74,6 +75,7 @@ def lib():
         "lz_sroots_get_sampled_actions": [P, c_f32p],
         "lz_sroots_set_given": [P, P, ctypes.c_int],
         "lz_roots_get_search_results": [P, c_i32p, c_i32p, c_f32p, P, P],
+        "lz_roots_get_search_results_select": [P, c_i32p, c_i32p, c_f32p, P, P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, c_i32p, P],
         "lz_groots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_f32p, c_i32p],
         "lz_gbatch_traverse": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
         "lz_gbatch_back_propagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p],

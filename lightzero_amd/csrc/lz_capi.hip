@@ -214,17 +214,26 @@ extern "C" int lz_roots_create(lz_engine *e, int variant, int root_num, int acti
     return LZ_OK;
 }
 
-extern "C" int lz_roots_reset(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count)
+static int roots_rearm(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count, bool keep_inference)
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     int rc = lz_roots_upload_legal(r, h_legal_flat, h_legal_count);
     if (rc != LZ_OK) return rc;
     r->prepared = false;
-    r->inferred = false;
+    if (!keep_inference) { r->inferred = false; r->inference_fresh = false; }
     r->traverse_count = 0;
     lz_tree_launch_minmax_reset(r->t, r->eng->stream);
     return LZ_OK;
+}
+extern "C" int lz_roots_reset(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count)
+{
+    return roots_rearm(r, h_legal_flat, h_legal_count, false);
+}
+extern "C" int lz_roots_reset_keep_inference(lz_roots *r, const int32_t *h_legal_flat, const int32_t *h_legal_count)
+{
+    LZ_REQUIRE(r != nullptr && r->inferred && r->inference_fresh, "lz_roots_reset_keep_inference needs lz_initial_inference for this env-step first");
+    return roots_rearm(r, h_legal_flat, h_legal_count, true);
 }
 
 extern "C" int lz_roots_destroy(lz_roots *r)
@@ -785,6 +794,12 @@ __global__ void k_select_action(lz_tree_dev t, double inv_temperature, int deter
 }
 }  // namespace
 
+void lz_launch_select_action(const lz_tree_dev &t, double inv_temperature, int deterministic, uint64_t seed, int32_t *d_pos,
+                             double *d_ent, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_select_action, dim3((unsigned)((t.B + 63) / 64)), dim3(64), 0, s, t, inv_temperature, deterministic, seed, d_pos, d_ent);
+}
+
 extern "C" int lz_roots_select_action(lz_roots *r, double temperature, int deterministic, uint64_t seed, int32_t *h_action_pos,
                                       double *h_entropy)
 {
@@ -799,7 +814,7 @@ extern "C" int lz_roots_select_action(lz_roots *r, double temperature, int deter
     hipStream_t s = r->eng->stream;
     double *d_ent = (double *)r->d_stage;
     int32_t *d_pos = (int32_t *)((char *)r->d_stage + B * 8);
-    hipLaunchKernelGGL(k_select_action, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, t, 1.0 / temperature, deterministic, seed, d_pos, d_ent);
+    lz_launch_select_action(t, 1.0 / temperature, deterministic, seed, d_pos, d_ent, s);
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->d_stage, B * 12, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));

@@ -153,6 +153,7 @@ struct lz_roots {
     hipGraphExec_t graph_exec = nullptr;  // captured search (lz_search)
     lz_graph_key graph_key{};
     bool inferred = false;
+    bool inference_fresh = false;   // lz_initial_inference ran and no prepare has used it yet
 };
 
 // lz_tree.hip launchers (all asynchronous on `stream`)
@@ -176,6 +177,9 @@ struct lz_tree_step {
     float delta;
     const int32_t *vtp;
 };
+// select_action for every root (lz_capi.hip): d_pos [B] int32, d_ent [B] float64
+void lz_launch_select_action(const lz_tree_dev &t, double inv_temperature, int deterministic, uint64_t seed, int32_t *d_pos,
+                             double *d_ent, hipStream_t s);
 void lz_tree_launch_minmax_reset(const lz_tree_dev &t, hipStream_t s);
 void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int noises_ragged,
                             const int32_t *d_noise_off, const float *d_vp, const float *d_logits,

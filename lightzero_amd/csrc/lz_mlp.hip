@@ -409,6 +409,7 @@ int lz_mlp_initial_inference(lz_roots *r, const float *d_obs)
     }
     LZ_HIP_CHECK(hipGetLastError());
     r->inferred = true;
+    r->inference_fresh = true;  // no prepare has consumed it yet (lz_roots_reset_keep_inference)
     return LZ_OK;
 }
 

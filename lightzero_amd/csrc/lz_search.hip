@@ -435,6 +435,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     heads(r, r->sim_value, r->sim_logits, r->dbg_logits[0], false, nullptr, nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
     r->inferred = true;
+    r->inference_fresh = true;  // no prepare has consumed it yet (lz_roots_reset_keep_inference)
     return LZ_OK;
 }
 
@@ -463,39 +464,62 @@ extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, floa
 
 // everything _forward_collect reads back after a search, in ONE readout launch, one device-to-host copy and one
 // synchronisation: visit-count distributions (+ counts), root values, and the root predictions of lz_initial_inference
-extern "C" int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
-                                           float *h_pred_values, float *h_policy_logits)
+static int search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values, float *h_pred_values,
+                          float *h_policy_logits, bool select, double temperature, int deterministic, uint64_t seed,
+                          int32_t *h_action_pos, double *h_entropy)
 {
     LZ_REQUIRE(r != nullptr && h_out_dist != nullptr && h_out_count != nullptr && h_out_values != nullptr, "NULL argument");
     LZ_REQUIRE(r->prepared && r->inferred && r->pool_slab != nullptr, "roots not searched through the fused path");
     LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "use the lz_sroots_* getters for sampled roots");
+    LZ_REQUIRE(!select || (temperature > 0.0 && h_action_pos != nullptr && h_entropy != nullptr), "select_action needs a positive temperature and output arrays");
     const lz_tree_dev &t = r->t;
     const size_t B = t.B, A = t.A;
     const size_t PA = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : A;
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
-    // layout of the result block: dist [B][A] | count [B] | values [B] | pred values [B] | logits [B][PA]
-    const size_t n_i = B * A + B, n_f = 2 * B + B * PA, bytes = (n_i + n_f) * 4;
+    // layout of the result block: entropy [B] f64 | dist [B][A] | count [B] | action pos [B] | values [B] | pred values [B] | logits [B][PA]
+    const size_t n_i = B * A + 2 * B, n_f = 2 * B + B * PA, bytes = B * 8 + (n_i + n_f) * 4;
     if (!r->d_results) {
         LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes));
         LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
     }
-    int32_t *d_dist = (int32_t *)r->d_results, *d_cnt = d_dist + B * A;
-    float *d_val = (float *)(d_cnt + B), *d_pred = d_val + B, *d_lg = d_pred + B;
+    double *d_ent = (double *)r->d_results;
+    int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B;
+    float *d_val = (float *)(d_pos + B), *d_pred = d_val + B, *d_lg = d_pred + B;
     lz_tree_launch_readout(t, d_dist, d_cnt, d_val, s);
+    if (select) lz_launch_select_action(t, 1.0 / temperature, deterministic, seed, d_pos, d_ent, s);
     LZ_HIP_CHECK(hipGetLastError());
     if (h_pred_values) LZ_HIP_CHECK(hipMemcpyAsync(d_pred, r->sim_value, B * 4, hipMemcpyDeviceToDevice, s));
     if (h_policy_logits) LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
     LZ_HIP_CHECK(hipMemcpyAsync(r->h_results, r->d_results, bytes, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));
-    const int32_t *hi = (const int32_t *)r->h_results;
+    const double *he = (const double *)r->h_results;
+    const int32_t *hi = (const int32_t *)(he + B);
     const float *hf = (const float *)(hi + n_i);
     memcpy(h_out_dist, hi, B * A * 4);
     memcpy(h_out_count, hi + B * A, B * 4);
     memcpy(h_out_values, hf, B * 4);
     if (h_pred_values) memcpy(h_pred_values, hf + B, B * 4);
     if (h_policy_logits) memcpy(h_policy_logits, hf + 2 * B, B * PA * 4);
+    if (select) {
+        memcpy(h_action_pos, hi + B * A + B, B * 4);
+        memcpy(h_entropy, he, B * 8);
+    }
     return LZ_OK;
+}
+
+extern "C" int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
+                                           float *h_pred_values, float *h_policy_logits)
+{
+    return search_results(r, h_out_dist, h_out_count, h_out_values, h_pred_values, h_policy_logits, false, 1.0, 1, 0, nullptr, nullptr);
+}
+
+extern "C" int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
+                                                  float *h_pred_values, float *h_policy_logits, double temperature,
+                                                  int deterministic, uint64_t seed, int32_t *h_action_pos, double *h_entropy)
+{
+    return search_results(r, h_out_dist, h_out_count, h_out_values, h_pred_values, h_policy_logits, true, temperature, deterministic,
+                          seed, h_action_pos, h_entropy);
 }
 
 extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records)
@@ -518,6 +542,7 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
                                                const int32_t *h_to_play)
 {
     LZ_REQUIRE(r != nullptr && r->inferred && h_to_play != nullptr, "lz_initial_inference must run first; to_play required");
+    r->inference_fresh = false;
     const lz_tree_dev &t = r->t;
     if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
         // Roots.prepare of the sampled tree (cnode.cpp:640-700): K actions per root drawn from the root (mu | sigma); the

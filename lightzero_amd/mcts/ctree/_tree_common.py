@@ -77,17 +77,21 @@ def make_module(variant, has_deterministic_flag):
             mode = self._tiebreak if self._tiebreak is not None else (0 if has_deterministic_flag else 1)
             L.check(L.lib().lz_roots_set_tiebreak(self._h, mode, self._seed))
 
-        def reset(self, legal_actions_list):
+        def reset(self, legal_actions_list, keep_inference=False):
             """Re-arm these roots for a new env-step (what building a fresh ``Roots`` does in the reference) while
-            keeping the HBM node / latent pools: same root_num and action space, new legal-action lists."""
+            keeping the HBM node / latent pools: same root_num and action space, new legal-action lists.
+            ``keep_inference=True``: the engine model's initial_inference for THIS env-step was already launched on these
+            roots (the host builds the legal lists while the representation network runs)."""
             if len(legal_actions_list) != self.root_num:
                 raise ValueError("legal_actions_list must have root_num entries")
             self._legal = [[int(a) for a in l] for l in legal_actions_list]
-            self._inferred_by = None
+            if not keep_inference:
+                self._inferred_by = None
             if self._h is not None:
                 cnt = L.i32([len(l) for l in self._legal])
                 flat = L.i32([a for l in self._legal for a in l] or [0])
-                L.check(L.lib().lz_roots_reset(self._h, flat, cnt))
+                fn = L.lib().lz_roots_reset_keep_inference if keep_inference else L.lib().lz_roots_reset
+                L.check(fn(self._h, flat, cnt))
             return self
 
         def set_tiebreak(self, mode, seed=None):
@@ -158,14 +162,23 @@ def make_module(variant, has_deterministic_flag):
                 res.append(row[:row.index(-1)])
             return res
 
-        def get_search_results(self, policy_width=None):
+        def get_search_results(self, policy_width=None, select=None):
             """After a fused search: (visit counts [B][A] int32, -1 padded; legal counts [B]; root values [B]; predicted root values
-            [B]; root policy logits [B][policy_width]) in ONE read-back (lz_roots_get_search_results)."""
+            [B]; root policy logits [B][policy_width]) in ONE read-back (lz_roots_get_search_results).
+            ``select=(temperature, deterministic[, seed])`` also runs select_action for every root on the device before the
+            read-back and appends (action positions [B], entropies [B]) to the returned tuple -- still one synchronisation."""
             B, A = self.root_num, self._A
             dist = np.zeros((B, A), np.int32); cnt = np.zeros(B, np.int32); val = np.zeros(B, np.float32)
             pred = np.zeros(B, np.float32); lg = np.zeros((B, policy_width or A), np.float32)
-            L.check(L.lib().lz_roots_get_search_results(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data))
-            return dist, cnt, val, pred, lg
+            if select is None:
+                L.check(L.lib().lz_roots_get_search_results(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data))
+                return dist, cnt, val, pred, lg
+            temperature, deterministic = select[0], select[1]
+            seed = select[2] if len(select) > 2 and select[2] is not None else int(np.random.randint(0, 2 ** 62))
+            pos = np.zeros(B, np.int32); ent = np.zeros(B, np.float64)
+            L.check(L.lib().lz_roots_get_search_results_select(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data,
+                                                               float(temperature), 1 if deterministic else 0, int(seed), pos, ent.ctypes.data))
+            return dist, cnt, val, pred, lg, pos, ent
 
         def select_action(self, temperature=1, deterministic=True, seed=None):
             """select_action (lzero/policy/utils.py:637-661) for every root on the device: returns (action positions

@@ -80,8 +80,17 @@ class EfficientZeroPolicy(object):
             ready_env_id = np.arange(active_collect_env_num)
         output = {i: None for i in ready_env_id}
         to_play = list(to_play) if len(to_play) == active_collect_env_num else [to_play[0]] * active_collect_env_num
+        # engine model + cached roots: the representation network is launched first, and the host work below (legal lists,
+        # re-arming the roots, noise draws) runs while it computes
+        early = None
+        if getattr(self._collect_model, "_is_lz_engine_model", False):
+            early = self._roots_cache.get(active_collect_env_num)
+            if early is not None and hasattr(early, "get_search_results"):
+                self._collect_model.initial_inference(data, early, fetch=False)
+            else:
+                early = None
         legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_collect_env_num)]
-        roots = self._roots(active_collect_env_num, legal_actions)
+        roots = early.reset(legal_actions, keep_inference=True) if early is not None else self._roots(active_collect_env_num, legal_actions)
         alpha = self._mcfg["root_dirichlet_alpha"]
         counts = [len(l) for l in legal_actions]
         if len(set(counts)) == 1:  # one vectorised draw instead of one np.random.dirichlet call per env (efficientzero.py:599-602)
@@ -91,10 +100,16 @@ class EfficientZeroPolicy(object):
         fused = getattr(self._collect_model, "_is_lz_engine_model", False) and hasattr(roots, "get_search_results")
         if fused:
             # no read-back (and no synchronisation) before the search: predictions come back with the search results
-            self._collect_model.initial_inference(data, roots, fetch=False)
+            if early is None:
+                self._collect_model.initial_inference(data, roots, fetch=False)
             roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
             self._search(self._mcts_collect, roots, self._collect_model, _HbmTokens(roots), to_play)
-            dist, cnt, roots_values, pred_values, logits = roots.get_search_results()
+            eps_cfg0 = _g(self._cfg, "eps", {}) or {}
+            if self._device_select:  # select_action on the device, inside the same read-back
+                dist, cnt, roots_values, pred_values, logits, dev_pos, dev_ent = roots.get_search_results(
+                    select=(self._collect_mcts_temperature, bool(_g(eps_cfg0, "eps_greedy_exploration_in_collect", False))))
+            else:
+                dist, cnt, roots_values, pred_values, logits = roots.get_search_results()
             roots_visit_count_distributions = [dist[i, :cnt[i]].tolist() for i in range(active_collect_env_num)]
             policy_logits = logits.tolist()
         else:
@@ -106,7 +121,7 @@ class EfficientZeroPolicy(object):
             roots_values = roots.get_values()
         eps_cfg = _g(self._cfg, "eps", {}) or {}
         eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
-        if self._device_select:
+        if self._device_select and not fused:
             dev_pos, dev_ent = roots.select_action(self._collect_mcts_temperature, deterministic=eps_greedy)
         for i, env_id in enumerate(ready_env_id):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]

@@ -244,6 +244,12 @@ def test_packed_search_results_equal_the_individual_getters():
     assert [d[i, :c[i]].tolist() for i in range(B)] == roots.get_distributions()
     assert np.array_equal(v, np.asarray(roots.get_values(), np.float32))
     assert np.array_equal(p, out.value) and np.array_equal(lg, out.policy_logits)
+    # the same read-back with select_action folded in == the separate calls (same temperature / mode / seed)
+    for det, seed in ((True, 7), (False, 1234)):
+        res = roots.get_search_results(select=(0.5, det, seed))
+        pos, ent = roots.select_action(0.5, deterministic=det, seed=seed)
+        assert np.array_equal(res[0], d) and np.array_equal(res[1], c) and np.array_equal(res[2], v)
+        assert np.array_equal(res[5], pos) and np.array_equal(res[6], ent)
 
 
 @pytest.mark.parametrize("tiebreak", [0, 1])
