@@ -1402,6 +1402,14 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
         hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
         return true;
     }
+    // 16-row tiles (70 KB of LDS, 512 workgroups at 256 roots): two workgroups per CU, so one's staging and cell epilogue run
+    // under the other's MFMAs; measured 0.6 us per launch faster than 32-row tiles (LZ_LSTM_ROWS32=1) although the gate weights
+    // are streamed twice as often
+    static const char *big_rows = getenv("LZ_LSTM_ROWS32");
+    if (nkb == 68 && !xf && !big_rows) {
+        hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        return true;
+    }
     if (nkb == 68 && !xf) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)
     else if (nkb == 48 && a.KX == 256) {                                                    // 256 + 512 (MLP models)
         if (xf) hipLaunchKernelGGL((k_lstm2<48, 8>), grid, block, lds, s, a);
