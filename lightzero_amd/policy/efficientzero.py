@@ -156,14 +156,26 @@ class EfficientZeroPolicy(object):
         to_play = list(to_play) if len(to_play) == active_eval_env_num else [to_play[0]] * active_eval_env_num
         legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_eval_env_num)]
         roots = self._roots(active_eval_env_num, legal_actions)
-        network_output = self._eval_model.initial_inference(data, roots)
-        pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
-        roots.prepare_from_inference_no_noise(to_play)  # efficientzero.py:721
-        self._search(self._mcts_eval, roots, self._eval_model, network_output, to_play)
-        roots_visit_count_distributions = roots.get_distributions()
-        roots_values = roots.get_values()
-        if self._device_select:
-            dev_pos, dev_ent = roots.select_action(1, deterministic=True)
+        fused = getattr(self._eval_model, "_is_lz_engine_model", False) and hasattr(roots, "get_search_results")
+        if fused:  # like the collect forward: nothing is read back before the search, one synchronisation after it
+            self._eval_model.initial_inference(data, roots, fetch=False)
+            roots.prepare_from_inference_no_noise(to_play)  # efficientzero.py:721
+            self._search(self._mcts_eval, roots, self._eval_model, _HbmTokens(roots), to_play)
+            res = roots.get_search_results(select=(1, True)) if self._device_select else roots.get_search_results()
+            dist, cnt, roots_values, pred_values, logits = res[:5]
+            if self._device_select:
+                dev_pos, dev_ent = res[5], res[6]
+            roots_visit_count_distributions = [dist[i, :cnt[i]].tolist() for i in range(active_eval_env_num)]
+            policy_logits = logits.tolist()
+        else:
+            network_output = self._eval_model.initial_inference(data, roots)
+            pred_values, policy_logits = network_output.value, network_output.policy_logits.tolist()
+            roots.prepare_from_inference_no_noise(to_play)  # efficientzero.py:721
+            self._search(self._mcts_eval, roots, self._eval_model, network_output, to_play)
+            roots_visit_count_distributions = roots.get_distributions()
+            roots_values = roots.get_values()
+            if self._device_select:
+                dev_pos, dev_ent = roots.select_action(1, deterministic=True)
         for i, env_id in enumerate(ready_env_id):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]
             if self._device_select:
