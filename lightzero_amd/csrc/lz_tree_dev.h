@@ -124,6 +124,16 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
     const uint32_t epoch = sc.epoch;
     int node = 0, depth = 0, is_root = 1, last_action = -1, noinf = 0;
     int node_visit = sc.root_visit;
+    // the path record of level d stays in lane d & 63 and is written once after the walk (coalesced), not by three
+    // single-lane stores per level
+    int my_node = 0, my_act = 0;
+    auto flush_path = [&](int base, int count) {
+        if (lane < count) {
+            t.path_node[(size_t)b * NN + base + lane] = my_node;
+            t.path_act[(size_t)b * NN + base + lane] = my_act;
+            t.node_best[(size_t)b * NN + my_node] = my_act;
+        }
+    };
     float parent_q = 0.0f;
 
     for (;;) {
@@ -199,7 +209,7 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
             score[c] = (j < n) ? ucb : -__builtin_inff();
             best = fmaxf(best, score[c]);
         }
-        best = wave_max(best);
+        best = (NC == 1 && n <= 16) ? row0_max(best) : wave_max(best);
         // ---- cselect_child (cnode.cpp:651-695): front of the tie list == first arg-max in list order
         int pos = -1;
 #pragma unroll
@@ -249,18 +259,16 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
         }
         if (nxt == -3) nxt = uni(v.child[(size_t)node * A + action]);  // degenerate fallback (action 0 by default)
         if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
-        if (lane == 0) {
-            t.node_best[(size_t)b * NN + node] = action;
-            t.path_node[(size_t)b * NN + depth] = node;
-            t.path_act[(size_t)b * NN + depth] = action;
-        }
+        if (lane == (depth & 63)) { my_node = node; my_act = action; }
         last_action = action;
         depth += 1;
+        if ((depth & 63) == 0) flush_path(depth - 64, 64);
         if (REUSE && was_root && action == true_action) { noinf = nxt >= 0 ? 1 : 0; break; }  // cnode.cpp:1041-1044
         if (nxt < 0) break;  // reached an unexpanded child: the leaf
         node = nxt;
         node_visit = sel_visit;
     }
+    flush_path((depth - 1) & ~63, depth - ((depth - 1) & ~63));
     if (lane == 0) {
         t.res_ix[b] = node;  // parent->current_latent_state_index (cnode.cpp:955); stays a valid slot when noinf
         t.res_iy[b] = REUSE ? (noinf ? b : t.node_bidx[(size_t)b * NN + node]) : b;  // parent->batch_index
