@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--family", choices=["mz", "ez"], default="mz")
     ap.add_argument("--obs", type=int, choices=[96, 64], default=96)
+    ap.add_argument("--go", action="store_true", help="BASELINE configs[3] per-GPU share instead: Go 9x9 MuZero (obs 17x9x9, no downsample, "
+                    "A = 82, two players); use with --envs 64 --sims 200")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches, each on its own engine / HIP stream: the "
                     "latency-bound tree step of one overlaps the MFMA-bound network step of another")
     a = ap.parse_args()
@@ -42,12 +44,20 @@ def main():
     assert B % NS == 0
     EPS = B // NS
     sup = (-300., 301., 1.) if a.obs == 96 else (-50., 51., 1.)
-    weights = efficientzero_state_dict(seed=0, action_space_size=A, muzero=a.family == "mz", latent_pixels=36 if a.obs == 96 else 64,
-                                       support_size=int(sup[1] - sup[0]))
-    mkw = dict(observation_shape=(4, a.obs, a.obs), action_space_size=A, reward_support_range=sup, value_support_range=sup)
-    obs = torch.rand(B, 4, a.obs, a.obs, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
+    if a.go:
+        A = 82
+        weights = efficientzero_state_dict(seed=0, action_space_size=A, muzero=a.family == "mz", latent_pixels=81, observation_channels=17,
+                                           downsample=False)
+        mkw = dict(observation_shape=(17, 9, 9), action_space_size=A, downsample=False)
+        obs = (torch.rand(B, 17, 9, 9, generator=torch.Generator().manual_seed(1)) < 0.3).float().cuda().contiguous()
+    else:
+        weights = efficientzero_state_dict(seed=0, action_space_size=A, muzero=a.family == "mz", latent_pixels=36 if a.obs == 96 else 64,
+                                           support_size=int(sup[1] - sup[0]))
+        mkw = dict(observation_shape=(4, a.obs, a.obs), action_space_size=A, reward_support_range=sup, value_support_range=sup)
+        obs = torch.rand(B, 4, a.obs, a.obs, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
     torch.cuda.synchronize()
     legal = [list(range(A))] * EPS
+    to_play = ([1, 2] * EPS)[:EPS] if a.go else [-1] * EPS
     rng = np.random.default_rng(0)
     noises = rng.dirichlet([0.3] * A, size=B).astype(np.float32)
     parts = []
@@ -65,8 +75,8 @@ def main():
         for model, roots, o, nz in parts:  # enqueue every sub-batch before reading anything back
             roots.reset(legal)
             model.initial_inference(o, roots, fetch=False)
-            roots.prepare_from_inference(0.25, nz, [-1] * EPS)
-            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5 if a.family == "ez" else 0, 0.01))
+            roots.prepare_from_inference(0.25, nz, to_play)
+            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 1.0 if a.go else 0.997, 5 if a.family == "ez" else 0, 0.01))
         res = [roots.get_search_results() for _, roots, _, _ in parts]
         return [np.concatenate([r[i] for r in res]) for i in range(5)]
 
@@ -79,7 +89,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     assert (np.asarray(res[0]).sum(1) == S).all()
-    print(json.dumps({"workload": "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS,
+    print(json.dumps({"workload": "Go 9x9 MuZero conv (configs[3] share)" if a.go else "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS,
                       "ms_per_step": dt * 1e3, "env_steps_per_s": B / dt, "mcts_sims_per_s": B * S / dt}))
 
 
