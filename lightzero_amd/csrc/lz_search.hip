@@ -754,6 +754,43 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     }
 }
 
+// the debugging switches that change a captured launch sequence (so that toggling one re-captures)
+static uint64_t graph_knobs()
+{
+    uint64_t knobs = 0;
+    const char *names[] = {"LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256", "LZ_DEBUG_SKIP",
+                           "LZ_LSTM_ROWS32"};
+    for (const char *n : names) {
+        const char *v = getenv(n);
+        knobs = knobs * 1000003ull + 7;
+        for (; v && *v; ++v) knobs = knobs * 131ull + (unsigned char)*v;
+    }
+    return knobs;
+}
+
+// The launch sequence of a fused search depends only on its parameters (every pointer is a fixed offset into the roots'
+// slabs), so it is captured once into a HIP graph per (roots, key) and replayed: the launches of all simulations become one
+// graph launch, and the host leaves the loop.
+template <class F>
+static int launch_captured(lz_roots *r, const lz_graph_key &key, F enqueue)
+{
+    hipStream_t s = r->eng->stream;
+    if (!r->graph_exec || memcmp(&key, &r->graph_key, sizeof(key)) != 0) {
+        if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        LZ_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        enqueue();
+        hipError_t e1 = hipStreamEndCapture(s, &g);
+        if (e1 != hipSuccess || !g) { lz_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e1)); return LZ_ERR_HIP; }
+        hipError_t e2 = hipGraphInstantiate(&r->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { r->graph_exec = nullptr; lz_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e2)); return LZ_ERR_HIP; }
+        r->graph_key = key;
+    }
+    LZ_HIP_CHECK(hipGraphLaunch(r->graph_exec, s));
+    return LZ_OK;
+}
+
 extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, float discount_factor,
                          int lstm_horizon_len, float value_delta_max)
 {
@@ -770,42 +807,17 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     lz_traverse_args ta;
     ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
     ta.tiebreak = r->tiebreak; ta.seed = r->seed; ta.counter = 0;
-    // The launch sequence of a search depends only on these parameters (every pointer is a fixed offset into the
-    // roots' slabs), so it is captured once into a HIP graph and replayed: ~5 launches per simulation become one
-    // graph launch, and the host leaves the loop.
     const bool use_graph = !r->trace_on && !r->eng->prof_on && !getenv("LZ_NO_GRAPH");
     if (!use_graph) {
         enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
         LZ_HIP_CHECK(hipGetLastError());
         return LZ_OK;
     }
-    uint64_t knobs = 0;
-    {
-        const char *names[] = {"LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256", "LZ_DEBUG_SKIP"};
-        for (const char *n : names) {
-            const char *v = getenv(n);
-            knobs = knobs * 1000003ull + 7;
-            for (; v && *v; ++v) knobs = knobs * 131ull + (unsigned char)*v;
-        }
-    }
-    lz_graph_key key{};  // value-initialised: the padding takes part in the memcmp below
+    lz_graph_key key{};  // value-initialised: the padding takes part in the memcmp
     key.sims = num_simulations; key.pb_c_base = pb_c_base; key.pb_c_init = pb_c_init; key.discount = discount_factor;
     key.horizon = lstm_horizon_len; key.delta = value_delta_max; key.players = r->players; key.tiebreak = r->tiebreak;
-    key.seed = r->seed; key.knobs = knobs;
-    if (!r->graph_exec || memcmp(&key, &r->graph_key, sizeof(key)) != 0) {
-        if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
-        hipGraph_t g = nullptr;
-        LZ_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
-        hipError_t e1 = hipStreamEndCapture(s, &g);
-        if (e1 != hipSuccess || !g) { lz_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e1)); return LZ_ERR_HIP; }
-        hipError_t e2 = hipGraphInstantiate(&r->graph_exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e2 != hipSuccess) { r->graph_exec = nullptr; lz_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e2)); return LZ_ERR_HIP; }
-        r->graph_key = key;
-    }
-    LZ_HIP_CHECK(hipGraphLaunch(r->graph_exec, s));
-    return LZ_OK;
+    key.seed = r->seed; key.knobs = graph_knobs();
+    return launch_captured(r, key, [&]() { enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s); });
 }
 
 // GumbelMuZeroMCTSCtree.search (mcts_ctree.py:1067-1172) with an engine MuZero model: sequential-halving selection, MuZero
@@ -822,17 +834,27 @@ extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_consider
     if (rc != LZ_OK) return rc;
     const lz_tree_dev &t = r->t;
     const size_t B = t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
-    lz_tree_launch_minmax_reset(t, s);
-    lz_gtree_launch_traverse(t, discount_factor, s);
-    for (int sim = 0; sim < num_simulations; ++sim) {
-        recurrent(r, sim, 0, s);
-        const int slot = sim + 1;
-        const float *rew = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
-        if (sim + 1 < num_simulations) lz_gtree_launch_backprop_traverse(t, slot, discount_factor, rew, val, lg, s);
-        else lz_gtree_launch_backprop(t, slot, discount_factor, rew, val, lg, s);
+    auto enqueue = [&]() {
+        lz_tree_launch_minmax_reset(t, s);
+        lz_gtree_launch_traverse(t, discount_factor, s);
+        for (int sim = 0; sim < num_simulations; ++sim) {
+            recurrent(r, sim, 0, s);
+            const int slot = sim + 1;
+            const float *rew = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
+            if (sim + 1 < num_simulations) lz_gtree_launch_backprop_traverse(t, slot, discount_factor, rew, val, lg, s);
+            else lz_gtree_launch_backprop(t, slot, discount_factor, rew, val, lg, s);
+        }
+    };
+    if (r->trace_on || r->eng->prof_on || getenv("LZ_NO_GRAPH")) {
+        enqueue();
+        LZ_HIP_CHECK(hipGetLastError());
+        return LZ_OK;
     }
-    LZ_HIP_CHECK(hipGetLastError());
-    return LZ_OK;
+    lz_graph_key key{};
+    key.sims = num_simulations; key.pb_c_base = max_num_considered_actions; key.discount = discount_factor;
+    key.horizon = -7;  // marks a Gumbel search (a roots handle is either Gumbel or not, so the slot is never shared)
+    key.players = r->players; key.tiebreak = r->tiebreak; key.seed = r->seed; key.knobs = graph_knobs();
+    return launch_captured(r, key, enqueue);
 }
 
 // ReZero: EfficientZeroMCTSCtree.search_with_reuse / MuZeroMCTSCtree.search_with_reuse (mcts_ctree.py:878-1002, 370-470) with an
