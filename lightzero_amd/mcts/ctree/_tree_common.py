@@ -84,6 +84,8 @@ def make_module(variant, has_deterministic_flag):
             roots (the host builds the legal lists while the representation network runs)."""
             if len(legal_actions_list) != self.root_num:
                 raise ValueError("legal_actions_list must have root_num entries")
+            if keep_inference and self._h is None:
+                raise L.LzError("reset(keep_inference=True) needs an engine model's initial_inference on these roots first")
             self._legal = [[int(a) for a in l] for l in legal_actions_list]
             if not keep_inference:
                 self._inferred_by = None

@@ -332,3 +332,36 @@ def test_config2_full_size_deep_trees_properties():
     assert np.isfinite(v0.view(np.float32)).all()
     for d, v in res[1:]:
         assert np.array_equal(d, d0) and np.array_equal(v, v0)
+
+
+def test_reset_keep_inference_needs_a_fresh_root_inference():
+    """lz_roots_reset_keep_inference re-arms roots whose representation network was ALREADY launched for this env-step; it is
+    refused when no inference is pending (first use, or the last one was consumed by a prepare), and the reordered sequence
+    inference -> reset(keep) -> prepare -> search gives the same result as reset -> inference -> prepare -> search."""
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.model.synthetic import efficientzero_state_dict
+    B, A, S = 24, 6, 16
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(efficientzero_state_dict(seed=0, action_space_size=A))
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(9)).cuda().contiguous()
+    legal = [[0, 1, 4]] * 5 + [list(range(A))] * (B - 5)
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    with pytest.raises(L.LzError):
+        roots.reset(legal, keep_inference=True)          # nothing inferred yet
+    res = []
+    for early in (False, True):
+        if early:
+            model.initial_inference(obs, roots, fetch=False)
+            roots.reset(legal, keep_inference=True)
+        else:
+            roots.reset(legal)
+            model.initial_inference(obs, roots, fetch=False)
+        roots.prepare_from_inference_no_noise([-1] * B)
+        L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+        d, c, v, p, lg = roots.get_search_results()
+        res.append((d.copy(), v.copy().view(np.uint32), p.copy().view(np.uint32)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    with pytest.raises(L.LzError):
+        roots.reset(legal, keep_inference=True)          # the inference was consumed by the prepare above
