@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
     f32x4 bf[KCH];
 #pragma unroll
     for (int q = 0; q < KCH; ++q) bf[q] = wp[(size_t)min(q, KB - 1) * 64];
+    // ---- the epilogue's operands do not depend on the GEMM: requested now (unconditional; dummies where a pointer is null) --
+    // loaded after the K loop they are one more exposed memory round trip per launch
+    const int n_ep = min(min(ct, NT - 1) * 16 + (lane & 15), N - 1);
+    const float bias_ep = j.bias[n_ep];
+    const float *scp = j.scale ? j.scale : j.bias, *shp = j.scale ? j.shift : j.bias;
+    const float sc_ep = scp[n_ep], sh_ep = shp[n_ep];
     // ---- stage 16 input rows: 16 lanes per row (same wavefront), producer's LayerNorm / activation / residual on the fly.
     // Every global load of the pass is issued before anything is consumed (straight-line, float4 granularity): a loop of
     // load -> use iterations would pay one memory round trip per element.
@@ -76,6 +82,14 @@ __global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
         const int b = min(r0 + row, B - 1);
         const float *src = j.x + (j.x_gather ? (size_t)j.x_gather[b] * (size_t)j.x_slot_stride : 0) + (size_t)b * K1;
         float *dst = sX + row * PS;
+        // second input (the action encoding, K2 <= 16 in every model): its value for this lane's first tail column is requested
+        // with the row, not after it
+        float x2_first = 0.0f;
+        if (j.K2 > 0) {
+            const int kk0 = min(part, j.K2 - 1);
+            if (j.x2_mode == 1) x2_first = j.x2[(size_t)b * j.K2 + kk0];
+            else x2_first = (float)j.x2_idx[b];
+        }
         if ((K1 & 3) == 0) {
             // unconditional, clamped loads (a predicated load makes the compiler branch around it and drain the load queue);
             // absent transforms read the row itself as a dummy and are switched off with selects
@@ -144,7 +158,11 @@ __global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
             float v = 0.0f;
             if (k < K) {
                 const int kk = k - K1;
-                if (j.x2_mode == 1) v = j.x2[(size_t)b * j.K2 + kk];
+                if (kk == part && part < j.K2) {  // first tail column of this lane: preloaded
+                    if (j.x2_mode == 1) v = x2_first;
+                    else if (j.x2_mode == 2) v = ((int)x2_first == kk) ? 1.0f : 0.0f;
+                    else v = x2_first / j.x2_div;
+                } else if (j.x2_mode == 1) v = j.x2[(size_t)b * j.K2 + kk];
                 else if (j.x2_mode == 2) v = (j.x2_idx[b] == kk) ? 1.0f : 0.0f;
                 else v = (float)j.x2_idx[b] / j.x2_div;
             }
@@ -173,8 +191,8 @@ __global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
     // ---- epilogue: bias (+ BN) (+ activation when nothing is deferred) (+ the reparameterisation head's transforms)
     const int n = ct * 16 + (lane & 15);
     if (n >= N) return;
-    const float bias = j.bias[n];
-    const float sc = j.scale ? j.scale[n] : 1.0f, sh = j.scale ? j.shift[n] : 0.0f;
+    const float bias = bias_ep;
+    const float sc = j.scale ? sc_ep : 1.0f, sh = j.scale ? sh_ep : 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int b = r0 + 4 * (lane >> 4) + q;
