@@ -8,29 +8,16 @@
 #include <algorithm>
 
 #include "lz_nn_kernels.h"
+#include "lz_wave.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float red_sum(float v)  // over the wave that owns the row
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float red_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
-__device__ __forceinline__ float red16_sum(float v)  // over the 16 lanes that share a row while staging
-{
-    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-    return v;
-}
+// reductions on the DPP path (lz_wave.h) instead of ds_bpermute round trips: these kernels are a few thousand cycles long
+__device__ __forceinline__ float red_sum(float v) { return wave_sum(v); }    // over the wave that owns the row
+__device__ __forceinline__ float red_max(float v) { return wave_max(v); }
+__device__ __forceinline__ float red16_sum(float v) { return group_sum<16>(v); }  // the 16 lanes (one DPP row) that share a row while staging
 // GELU(approximate='tanh') with tanh(y) = 1 - 2 / (1 + e^{2y}) on the hardware exp / rcp (a libm tanhf is ~60 instructions
 // with range branches; these kernels are a few thousand instructions in total).  |error| < 3e-7 absolute.
 __device__ __forceinline__ float gelu_tanh(float u)

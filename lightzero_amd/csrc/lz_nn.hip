@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
             float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < XV; ++i) sum += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
-            sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
+            sum = group_sum<8>(sum);  // the 8 lanes that staged the row
             const float mean_ln = sum / (float)KX;
             float sq = 0.0f;
 #pragma unroll
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
                 const float d0 = xv[i].x - mean_ln, d1 = xv[i].y - mean_ln, d2 = xv[i].z - mean_ln, d3 = xv[i].w - mean_ln;
                 sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
-            sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 1);
+            sq = group_sum<8>(sq);
             const float mean = has_ln ? mean_ln : 0.0f, rstd = has_ln ? 1.0f / sqrtf(sq / (float)KX + a.x_ln_eps) : 1.0f;
             auto fin = [&](float u, float g, float be) {
                 u = (u - mean) * rstd;
