@@ -682,10 +682,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_ar
             f32x4 r = acc[MF];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float v = r[q];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                r[q] = v;
+                r[q] = xor32_sum(xor16_sum(r[q]));
             }
             const int g = lane >> 4;
             const float mine = g == 0 ? r[0] : g == 1 ? r[1] : g == 2 ? r[2] : r[3];

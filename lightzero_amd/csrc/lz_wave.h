@@ -59,6 +59,21 @@ __device__ __forceinline__ float row0_max(float v)
 #undef LZ_DPPM
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
+// v + v[lane ^ 16] and v + v[lane ^ 32] on gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap): two VALU
+// instructions instead of a ds_bpermute round trip; the operands of each addition are the same as with __shfl_xor, so the
+// sums are bit-identical
+__device__ __forceinline__ float xor16_sum(float v)
+{
+    const unsigned x = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // {r0 r0 r2 r2}, {r1 r1 r3 r3}
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v)
+{
+    const unsigned x = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // {lo lo}, {hi hi}
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_max(float v) { return wave_red<true>(v); }
 __device__ __forceinline__ float wave_min(float v) { return wave_red<false>(v); }
 
