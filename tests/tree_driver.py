@@ -35,13 +35,17 @@ CASES = {
     "mz_go82_2p": dict(variant="mz", B=16, A=82, S=200, seed=8, legal="random", to_play="random12", discount=1.0),
     "mz_fixture16_2p": dict(variant="mz", B=16, A=9, S=40, seed=9, legal="fixture", to_play=FIXTURE_TO_PLAY),
     "mz_zero_ties": dict(variant="mz", B=4, A=3, S=12, seed=10, zero=True, noise_w=None),
+    # values that grow with the simulation index: the newest leaf always looks best, so the search keeps extending ONE path
+    # (search depth well beyond 64: path records longer than a wavefront, deep backups)
+    "ez_deep_chain": dict(variant="ez", B=4, A=2, S=150, seed=11, deep=True),
+    "mz_deep_chain": dict(variant="mz", B=3, A=3, S=200, seed=12, deep=True),
 }
 
 
 def make_inputs(case):
     """Seeded synthetic 'network outputs' for every simulation of a case (all float32)."""
     c = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.997, delta=0.01, noise_w=0.25, horizon=5, legal=None,
-             to_play=None, zero=False, scale=1.0)
+             to_play=None, zero=False, scale=1.0, deep=False)
     c.update(case)
     rng = np.random.default_rng(c["seed"])
     B, A, S = c["B"], c["A"], c["S"]
@@ -63,6 +67,8 @@ def make_inputs(case):
         to_play = list(c["to_play"])
     z = 0.0 if c["zero"] else 1.0
     root_logits = (z * c["scale"] * rng.standard_normal((B, A))).astype(np.float32)
+    if c["deep"]:
+        root_logits[:, 0] += 12.0
     root_vp = np.zeros(B, np.float32)  # initial_inference: value_prefix = [0.]*B (efficientzero_model.py:238)
     if c["variant"] == "mz":
         root_vp = (z * 0.1 * rng.standard_normal(B)).astype(np.float32)  # MuZero roots carry a reward
@@ -70,12 +76,18 @@ def make_inputs(case):
     if c["noise_w"] is not None:
         noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
     sims = []
-    for _ in range(S):
+    for si in range(S):
         sims.append(dict(
             vp=(z * 0.5 * rng.standard_normal(B)).astype(np.float32),
             v=(z * rng.standard_normal(B)).astype(np.float32),
             logits=(z * c["scale"] * rng.standard_normal((B, A))).astype(np.float32),
         ))
+        if c["deep"]:
+            sims[-1]["vp"] = (0.01 * rng.random(B)).astype(np.float32)
+            sims[-1]["v"] = (1.0 + 0.5 * si + 0.01 * rng.random(B)).astype(np.float32)
+            lg = (0.01 * rng.standard_normal((B, A))).astype(np.float32)
+            lg[:, 0] += 12.0   # one overwhelmingly likely action per node
+            sims[-1]["logits"] = lg
     c.update(legal_list=legal, to_play_list=to_play, root_logits=root_logits, root_vp=root_vp, noises=noises, sims=sims)
     return c
 
