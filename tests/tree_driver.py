@@ -37,6 +37,9 @@ CASES = {
     "mz_zero_ties": dict(variant="mz", B=4, A=3, S=12, seed=10, zero=True, noise_w=None),
     # values that grow with the simulation index: the newest leaf always looks best, so the search keeps extending ONE path
     # (search depth well beyond 64: path records longer than a wavefront, deep backups)
+    # action spaces beyond 128: four 64-lane chunks per node in the device kernels
+    "ez_wide_a150": dict(variant="ez", B=6, A=150, S=60, seed=13, legal="random"),
+    "mz_wide_a200_2p": dict(variant="mz", B=5, A=200, S=80, seed=14, legal="random", to_play="random12", discount=1.0),
     "ez_deep_chain": dict(variant="ez", B=4, A=2, S=150, seed=11, deep=True),
     "mz_deep_chain": dict(variant="mz", B=3, A=3, S=200, seed=12, deep=True),
 }
