@@ -121,7 +121,8 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
                  o_act = take(D ? nBNA * D * 4 : 0), o_laf = take(D ? (size_t)B * D * 4 : 0),
                  o_bidx = take(nBN * 4), o_noinf = take((size_t)B * 4),
                  o_raw = take(variant == LZ_TREE_GUMBEL_MUZERO ? nBN * 4 : 0), o_gum = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)A * 4 : 0),
-                 o_cons = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)t.NN * 4 : 0);
+                 o_cons = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)t.NN * 4 : 0),
+                 o_gsoft = take(variant == LZ_TREE_GUMBEL_MUZERO ? nBNA * 4 : 0);
     hipError_t err = lz_dev_malloc((void **)&r->slab, off);
     if (err != hipSuccess) {
         delete r;
@@ -144,9 +145,10 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     // stream is non-blocking, so a null-stream memset queued behind another library's work (torch's default stream) could land
     // AFTER the first prepare and wipe it.
     LZ_HIP_CHECK(hipMemsetAsync(r->slab, 0, off, e->stream));
-    t.node_raw = nullptr; t.gumbel = nullptr; t.considered = nullptr;
+    t.node_raw = nullptr; t.gumbel = nullptr; t.considered = nullptr; t.gsoft = nullptr;
     if (variant == LZ_TREE_GUMBEL_MUZERO) {
         t.node_raw = (float *)(base + o_raw); t.gumbel = (float *)(base + o_gum); t.considered = (int32_t *)(base + o_cons);
+        t.gsoft = (float *)(base + o_gsoft);
         // every CNode draws its Gumbel vector from std::mt19937(gumbel_rng = 0) scaled by gumbel_scale = 10 (cnode.cpp:58-59,86-89,
         // 1133-1151): one constant prefix, computed with the same libstdc++ distribution the reference uses
         std::mt19937 gen(static_cast<unsigned int>(0.0f));

@@ -82,6 +82,8 @@ struct lz_tree_dev {
     uint32_t *rng_epoch;        // [1] incremented by every prepare (stochastic tie-break stream)
     // Gumbel MuZero (variant 3)
     float *node_raw;            // [B][NN]     CNode::raw_value: the value head's output at the node
+    float *gsoft;               // [B][NN][A]  Gumbel tree: csoftmax of a node's child priors by legal position, computed once when the
+                                //             node is expanded (root: after the noise) instead of at every visit
     float *gumbel;              // [A]         gumbel_scale * extreme_value(mt19937(0)): the same prefix for every node (cnode.cpp:86-89)
     int32_t *considered;        // [NN]        get_sequence_of_considered_visits(min(m, S), S) of the current search
     int32_t *node_bidx;         // [B][NN]     CNode::batch_index (== b except under ReZero's packed inference batches)

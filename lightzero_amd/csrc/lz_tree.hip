@@ -243,15 +243,15 @@ __device__ __forceinline__ void dev_csoftmax(float (&x)[NC], int n)
 
 // qtransform_completed_by_mix_value (cnode.cpp:984-1037) with the header defaults (maxvisit_init 50, value_scale 0.1,
 // rescale_values, epsilon 1e-8); CNode::get_q :181-197, compute_mixed_value :930-966, rescale_qvalues :968-982
+// psoft = csoftmax of the node's child priors (compute_mixed_value's first step), cached per node in t.gsoft
 template <int NC>
-__device__ __forceinline__ void dev_completed_q(const float (&prior)[NC], const int (&vis)[NC], const float (&q)[NC], int n, float raw_value,
+__device__ __forceinline__ void dev_completed_q(const float (&psoft)[NC], const int (&vis)[NC], const float (&q)[NC], int n, float raw_value,
                                                 float (&cq)[NC])
 {
     const int lane = threadIdx.x;
     float ptmp[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) ptmp[c] = prior[c];
-    dev_csoftmax<NC>(ptmp, n);
+    for (int c = 0; c < NC; ++c) ptmp[c] = psoft[c];
     float visit_count_sum = 0.0f, probs_sum = 0.0f, weighted_q_sum = 0.0f;
     const float min_num = -10e7f;
 #pragma unroll
@@ -302,6 +302,34 @@ __device__ __forceinline__ void dev_gchildren(const lz_tree_dev &t, int b, int n
     }
 }
 
+// csoftmax of the child priors of `node` by legal position -> t.gsoft (once per node: the priors never change after the
+// expansion, the root's after its noise)
+template <int NC>
+__device__ __forceinline__ void dev_store_gsoft(const lz_tree_dev &t, int b, int node, int n, bool is_root)
+{
+    const int lane = threadIdx.x, A = t.A, NN = t.NN;
+    float p[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        const int a = (j < n) ? (is_root ? t.legal[(size_t)b * A + j] : j) : 0;
+        p[c] = (j < n) ? t.edge[((size_t)b * NN + node) * A + a].x : 0.0f;
+    }
+    dev_csoftmax<NC>(p, n);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = c * 64 + lane;
+        if (j < n) t.gsoft[((size_t)b * NN + node) * A + j] = p[c];
+    }
+}
+template <int NC>
+__device__ __forceinline__ void dev_load_gsoft(const lz_tree_dev &t, int b, int node, int n, float (&p)[NC])
+{
+    const int lane = threadIdx.x, A = t.A, NN = t.NN;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = t.gsoft[((size_t)b * NN + node) * A + min(c * 64 + lane, A - 1)];
+}
+
 // first position (legal-list order) whose score equals the wave maximum; all -inf => position 0 (cnode.cpp:724-733)
 template <int NC>
 __device__ __forceinline__ int dev_first_argmax(const float (&score)[NC])
@@ -331,8 +359,10 @@ __device__ __forceinline__ void dev_gtraverse(const lz_tree_dev &t, float discou
         const int n = is_root ? uni(t.n_legal[b]) : A;
         float prior[NC], q[NC], cq[NC], score[NC];
         int vis[NC], act[NC], chd[NC];
+        float psoft[NC];
+        dev_load_gsoft<NC>(t, b, node, n, psoft);
         dev_gchildren<NC>(t, b, node, n, is_root != 0, discount, prior, vis, q, act, chd);
-        dev_completed_q<NC>(prior, vis, q, n, t.node_raw[(size_t)b * NN + node], cq);
+        dev_completed_q<NC>(psoft, vis, q, n, t.node_raw[(size_t)b * NN + node], cq);
         if (is_root) {
             // cselect_root_child :701-745 + score_considered :1096-1131
             int sim_index = 0;
@@ -411,6 +441,10 @@ __global__ __launch_bounds__(64) void k_gbackprop(lz_tree_dev t, int new_node, f
     load_leaf<NC, LZ_TREE_MUZERO>(t, b, rewards, values, logits, nullptr, 0, nullptr, L);
     if (threadIdx.x == 0) t.node_raw[(size_t)b * t.NN + new_node] = L.value;
     dev_backprop<NC, LZ_TREE_MUZERO, false>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, -1, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dev_store_gsoft<NC>(t, b, new_node, t.A, false);
     if (THEN_TRAVERSE) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
@@ -426,6 +460,13 @@ __global__ void k_graw_root(lz_tree_dev t, const float *__restrict__ values)
     if (b < t.B) t.node_raw[(size_t)b * t.NN] = values[b];
 }
 
+template <int NC>
+__global__ __launch_bounds__(64) void k_gsoft_root(lz_tree_dev t)
+{
+    const int b = blockIdx.x;
+    dev_store_gsoft<NC>(t, b, 0, uni(t.n_legal[b]), true);
+}
+
 // CNode::get_policy :350-375 and CNode::get_children_value :309-338 of every root: [B][A] each (either may be null)
 template <int NC>
 __global__ __launch_bounds__(64) void k_gpolicies(lz_tree_dev t, float discount, float *__restrict__ policies, float *__restrict__ children_values)
@@ -434,8 +475,10 @@ __global__ __launch_bounds__(64) void k_gpolicies(lz_tree_dev t, float discount,
     const int n = uni(t.n_legal[b]);
     float prior[NC], q[NC], cq[NC];
     int vis[NC], act[NC], chd[NC];
+    float psoft[NC];
+    dev_load_gsoft<NC>(t, b, 0, n, psoft);
     dev_gchildren<NC>(t, b, 0, n, true, discount, prior, vis, q, act, chd);
-    dev_completed_q<NC>(prior, vis, q, n, t.node_raw[(size_t)b * t.NN], cq);
+    dev_completed_q<NC>(psoft, vis, q, n, t.node_raw[(size_t)b * t.NN], cq);
     if (children_values) {
         for (int a = lane; a < A; a += 64) children_values[(size_t)b * A + a] = -__builtin_inff();
         __builtin_amdgcn_wave_barrier();
@@ -641,6 +684,11 @@ void lz_gtree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d
 {
     lz_tree_launch_prepare(t, noise_w, d_noises, ragged, d_noise_off, d_rewards, d_logits, d_to_play, s);
     hipLaunchKernelGGL(k_graw_root, dim3((t.B + 255) / 256), dim3(256), 0, s, t, d_values);
+    switch (nchunks(t.A)) {
+    case 1: hipLaunchKernelGGL((k_gsoft_root<1>), dim3(t.B), dim3(64), 0, s, t); break;
+    case 2: hipLaunchKernelGGL((k_gsoft_root<2>), dim3(t.B), dim3(64), 0, s, t); break;
+    default: hipLaunchKernelGGL((k_gsoft_root<4>), dim3(t.B), dim3(64), 0, s, t); break;
+    }
 }
 void lz_gtree_launch_traverse(const lz_tree_dev &t, float discount, hipStream_t s)
 {
