@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Debugging aid: per-phase time stamps (s_memtime, 100 MHz) of one k_chain workgroup during a search.
+"""Debugging aid: per-phase time stamps (s_memtime = shader cycles on gfx950, ~2.0 GHz under this load) of one k_chain workgroup during a search.
     LZ_DEBUG_CHAIN_TS=1 LZ_NO_GRAPH=1 python tools/chain_timing.py"""
 import ctypes, os, sys
 import numpy as np
@@ -27,4 +27,4 @@ n = int(out[0]); ts = out[1:1 + n].astype(np.int64)
 names = ["staged", "sync"] + [x for l in range(5) for x in ("L%d loop start" % l, "L%d loop end" % l, "L%d epilogue" % l, "L%d barrier" % l)] + ["end"]
 print("stamps:", n)
 for i in range(1, n):
-    print("%-16s +%6.2f us   (t=%6.2f)" % (names[i] if i < len(names) else i, (ts[i] - ts[i - 1]) / 100.0, (ts[i] - ts[0]) / 100.0))
+    print("%-16s +%7d cycles   (t=%7d, ~%5.1f us at 2.0 GHz)" % (names[i] if i < len(names) else i, ts[i] - ts[i - 1], ts[i] - ts[0], (ts[i] - ts[0]) / 2000.0))
