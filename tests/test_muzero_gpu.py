@@ -2,6 +2,7 @@
 (torch restatement of lzero/model/muzero_model.py + CPU ctree oracle + restated MuZeroMCTSCtree.search)."""
 import numpy as np
 import pytest
+from parity_util import assert_root_values_close
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +69,7 @@ def test_muzero_teacher_forced_and_end_to_end():
     same = np.array([a == b for a, b in zip(o_dist, d_dist)])
     print("muzero identical visit distributions: %d / %d" % (same.sum(), B))
     assert same.mean() >= 0.85
-    assert (np.abs(np.array(o_val) - d_val) / (1 + np.abs(d_val)))[same].max() < 2e-3
+    assert_root_values_close(o_val, d_val, same, relative=True)
     assert (np.abs(o_pred - out.value) / (1 + np.abs(o_pred))).max() < 3e-4
 
 

@@ -4,6 +4,7 @@ supports (-50, 51, 1).  Network kernels vs the torch restatement (teacher-forced
 the fused search vs the oracle pipeline."""
 import numpy as np
 import pytest
+from parity_util import assert_root_values_close
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -116,7 +117,7 @@ def test_64x64_fused_search_vs_oracle_pipeline(family):
     same = np.array([a == b for a, b in zip(o_dist, d_dist)])
     print("identical visit distributions: %d / %d" % (same.sum(), B))
     assert same.mean() >= 0.9
-    assert np.abs(np.array(o_val) - d_val)[same].max() < 2e-3
+    assert_root_values_close(o_val, d_val, same)
     assert np.abs(o_pred - out.value).max() < 3e-4
     assert np.abs(np.array(o_logits) - out.policy_logits).max() < 2e-5
 
