@@ -234,13 +234,18 @@ typedef struct lz_model_cfg {
     float ln_eps;           /* 1e-5 */
 } lz_model_cfg;
 
-/* One model per engine.  Weights are ingested by their reference state_dict names
+/* One model per engine (creating another replaces it: roots of the old one re-size their pools on the next inference).
+ * Calling lz_model_set_tensor + lz_model_finalize again on a live engine is a WEIGHT REFRESH (collector after a learner
+ * update): tensors of unchanged shape are overwritten in place, captured search graphs stay valid.  Weights are ingested by their reference state_dict names
  * (e.g. "dynamics_network.lstm.weight_ih_l0", "prediction_network.fc_value.3.bias"), fp32, C-contiguous,
  * host memory; lz_model_finalize folds the eval-mode BatchNorms, re-lays the tensors out for the
  * kernels and uploads them.  Replaces policy._collect_model.load_state_dict (muzero.py:1036-1058 format). */
 int lz_model_create(lz_engine *e, const lz_model_cfg *cfg);
 int lz_model_set_tensor(lz_engine *e, const char *name, const float *h_data, const int64_t *shape, int ndim);
 int lz_model_finalize(lz_engine *e);
+/* Identity of the model an engine currently holds: incremented by every lz_model_create.  A host-side model object records
+ * it and refuses to run once another model took its engine (one model per engine). */
+uint64_t lz_engine_model_uid(lz_engine *e);
 
 /* initial_inference for the roots' batch: d_obs is NCHW fp32 [root_num][obs_c][obs_h][obs_w] in HBM.
  * The latent state goes to slot 0 of the roots' latent pool, LSTM state slot 0 is zeroed
@@ -273,12 +278,24 @@ int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, 
               int lstm_horizon_len, float value_delta_max);
 
 /* observability for parity tests: per-simulation records and pools (host copies)                  */
-/* tracing is off by default (one extra D2D copy per simulation when on) */
+/* tracing is off by default; when on, the captured search graph carries one extra D2D copy per simulation and the head
+ * kernels also write their support-wide logits (lz_roots_read_debug_logits) */
 int lz_roots_enable_trace(lz_roots *r, int on);
 int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out /* [S][B][4] ix, action, search_len, to_play */);
 int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_prefix, float *h_value, float *h_policy_logits);
 int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw);
 int lz_roots_read_hidden(lz_roots *r, int slot, float *h_h, float *h_c);
+/* teacher-forced / foreign-driver access: put a caller-provided latent state (NCHW [root_num][C][H][W]; MLP models [root_num][L])
+ * and LSTM state ([root_num][H] each) into pool slot `slot` */
+int lz_roots_write_latent(lz_roots *r, int slot, const float *h_in_nchw);
+int lz_roots_write_hidden(lz_roots *r, int slot, const float *h_h, const float *h_c);
+/* Model.recurrent_inference(latent_state, reward_hidden_state, action)   efficientzero_model.py:240-273, muzero_model.py:240-272
+ * on pool slots: root i reads the state of slot h_parent_slot[i] and takes h_actions[i] (h_actions_f [root_num][D] for
+ * Sampled-EfficientZero roots); next latent / LSTM state / value prefix|reward / value / policy logits land in out_slot
+ * (lz_roots_read_latent / _hidden / _sim_outputs).  h_search_len (may be NULL) and lstm_horizon_len reproduce the driver's LSTM
+ * reset rule search_len % lstm_horizon_len == 0 (mcts_ctree.py:859-863). */
+int lz_recurrent_inference(lz_roots *r, const int32_t *h_parent_slot, const int32_t *h_actions, const float *h_actions_f,
+                           const int32_t *h_search_len, int lstm_horizon_len, int out_slot);
 /* optional debug logits of the last head launch: which = 0 value [B][support], 1 value_prefix/reward [B][support] */
 int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out);
 /* in-stream timing (HIP events on the engine stream) of the 64->64 3x3 convolution on the latent grid --

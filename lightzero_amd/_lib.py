@@ -7,7 +7,8 @@ import sys
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblz_mi355.so")
+# LZ_MI355_LIB: tools/ point this at liblz_mi355_dbg.so (the -DLZ_DEBUG_KNOBS build); everything else loads the release library
+LIB_PATH = os.environ.get("LZ_MI355_LIB") or os.path.join(_PKG, "liblz_mi355.so")
 
 
 class LzError(RuntimeError):
@@ -47,6 +48,7 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.lz_last_error.restype = ctypes.c_char_p
     L.lz_engine_stream.restype = P
+    L.lz_engine_model_uid.restype = ctypes.c_uint64
     sig = {
         "lz_engine_create": [ctypes.c_int, ctypes.POINTER(P)],
         "lz_engine_destroy": [P],
@@ -101,6 +103,10 @@ def lib():
         "lz_roots_read_latent": [P, ctypes.c_int, c_f32p],
         "lz_roots_read_hidden": [P, ctypes.c_int, c_f32p, c_f32p],
         "lz_roots_read_debug_logits": [P, ctypes.c_int, c_f32p],
+        "lz_roots_write_latent": [P, ctypes.c_int, c_f32p],
+        "lz_roots_write_hidden": [P, ctypes.c_int, c_f32p, c_f32p],
+        "lz_recurrent_inference": [P, c_i32p, P, P, P, ctypes.c_int, ctypes.c_int],
+        "lz_engine_model_uid": [P],
     }
     for name, argtypes in sig.items():
         getattr(L, name).argtypes = argtypes
@@ -125,6 +131,32 @@ def default_engine(device_index=None):
         check(lib().lz_engine_create(device_index, ctypes.byref(h)))
         _engines[device_index] = h
     return _engines[device_index]
+
+
+def new_engine(device_index=None):
+    """a fresh engine (its own HIP stream, room for one model) on the device"""
+    if device_index is None:
+        device_index = int(os.environ.get("LOCAL_RANK", "0"))
+    h = P()
+    check(lib().lz_engine_create(device_index, ctypes.byref(h)))
+    return h
+
+
+def engine_for_new_model(device_index=None):
+    """An engine holds ONE model (lz_model_create replaces the previous one).  The first model of a process gets the default
+    engine, every further one its own engine, so that two live model objects never share -- and silently overwrite -- weights."""
+    e = default_engine(device_index)
+    if lib().lz_engine_model_uid(e) == 0:
+        return e
+    return new_engine(device_index)
+
+
+def process_seed():
+    """Default seed of the device-side random streams (stochastic tie-breaks, sampled actions, select_action): drawn from
+    np.random -- so ``np.random.seed`` / the config seed govern it like they govern the reference's Dirichlet noise -- and mixed
+    with the rank, so that data-parallel collectors do not explore in lock-step."""
+    rank = int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")))
+    return (int(np.random.randint(0, 2 ** 62)) ^ ((rank + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1)
 
 
 def f32(x):

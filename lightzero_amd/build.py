@@ -31,9 +31,18 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
+DBG_LIB = os.path.join(PKG, "liblz_mi355_dbg.so")
+
+
+def build(force=False, verbose=False, debug_knobs=False):
+    """debug_knobs=True builds liblz_mi355_dbg.so instead: the same sources with -DLZ_DEBUG_KNOBS, i.e. WITH the skip-work timing
+    switches (LZ_DEBUG_SKIP, LZ_DEBUG_CHAIN_LAYERS, LZ_DEBUG_CHAIN_TS, LZ_DEBUG_LSTM_ROWS) that the release library does not
+    contain.  Only tools/ load it (LZ_MI355_LIB=<path>)."""
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s" % HIPCC)
+    LIB = DBG_LIB if debug_knobs else globals()["LIB"]
+    osuffix = ".dbg.o" if debug_knobs else ".o"
+    dflags = ["-DLZ_DEBUG_KNOBS"] if debug_knobs else []
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(PKG), "include", "lz_mi355.h"))
     objs = []
@@ -42,12 +51,12 @@ def build(force=False, verbose=False):
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        op = sp[:-4] + ".o"
+        op = sp[:-4] + osuffix
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
             # -Rpass-analysis=kernel-resource-usage: per-kernel registers / scratch as compiler remarks.  A kernel that falls
             # back to scratch memory (an array the optimiser could not keep in registers) costs a round trip per access on
             # these latency-bound kernels and was once a silent 5 % regression: refuse it.
-            cmd = [HIPCC] + COMMON + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", op]
+            cmd = [HIPCC] + COMMON + dflags + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
@@ -76,4 +85,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug_knobs="--debug-knobs" in sys.argv))

@@ -48,6 +48,8 @@ struct lz_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     lz_model *model = nullptr;
+    uint64_t model_uid = 0;      // bumped by lz_model_create: a different network (shapes) now lives on this engine
+    uint64_t weights_gen = 0;    // bumped whenever a device weight pointer changed (lz_model_finalize that had to re-allocate)
     // optional in-stream timing of one kernel class (bench.py roofline): HIP event pairs recorded on the
     // engine stream around every launch of the tagged kernel while enabled
     bool prof_on = false;
@@ -105,6 +107,9 @@ struct lz_graph_key {
     int players, tiebreak;
     uint64_t seed;
     uint64_t knobs;   // the debugging switches that change the captured launch sequence (so that toggling one re-captures)
+    uint64_t model_uid, weights_gen;  // the kernel arguments hold weight pointers: a re-created model or re-allocated weights re-capture
+    int trace;        // tracing adds one device-to-device copy per simulation to the captured sequence
+    int pad_;
 };
 
 struct lz_roots {
@@ -124,6 +129,8 @@ struct lz_roots {
     size_t stage_bytes = 0;
     // ---- fused search state (allocated on first lz_initial_inference), all in HBM
     void *pool_slab = nullptr;
+    uint64_t pool_model_uid = 0;    // the model (lz_engine::model_uid) whose shapes sized pool_slab / d_obs / d_results
+    size_t d_obs_bytes = 0, results_bytes = 0;
     float *latent_pool = nullptr;   // [NN][B][HW][C]   NHWC latent of every expanded node
     float *h_pool = nullptr;        // [NN][B][H]       LSTM state pools (EfficientZero)
     float *c_pool = nullptr;

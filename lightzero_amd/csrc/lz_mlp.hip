@@ -224,8 +224,11 @@ int lz_mlp_finalize(lz_engine *e)
 // ------------------------------------------------------------------------------------------------
 static size_t align_up_(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+int lz_roots_release_pools_if_stale(lz_roots *r);  // lz_search.hip
+
 int lz_mlp_ensure_pools(lz_roots *r)
 {
+    if (int rc = lz_roots_release_pools_if_stale(r)) return rc;
     if (r->pool_slab) return LZ_OK;
     const lz_mlp_model &M = *r->eng->model->mlp;
     const size_t B = r->t.B, NN = r->t.NN, L = M.L, H = M.H, PA = M.PA, W = M.Wmax, SUP = M.SUP;

@@ -33,7 +33,10 @@ struct lz_model {
     lz_model_cfg cfg{};
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
-    std::vector<void *> allocs;
+    std::vector<void *> allocs;          // device weight buffers in upload order
+    std::vector<size_t> alloc_bytes;     // their sizes: a re-finalize with the same shapes copies in place (pointers stay valid,
+    size_t alloc_cursor = 0;             // captured graphs stay valid); `realloc_happened` tells the engine to bump weights_gen
+    bool realloc_happened = false;
     int HWl = 0;  // latent pixels (6x6 = 36 with downsample; obs_h*obs_w without)
     int GW = 6, GH = 6;
     ConvW rin;    // no-downsample input conv (weights [9][C][64] in rin.w)
@@ -74,12 +77,26 @@ struct Builder {
         }
         return &t;
     }
+    // The upload order of a finalize is a function of the model configuration and tensor shapes only, so a weight refresh
+    // (lz_model_set_tensor + lz_model_finalize on a live engine, e.g. after a learner update) finds every buffer of the
+    // previous finalize at the same position with the same size and overwrites it in place.
     float *upload(const std::vector<float> &v)
     {
+        const size_t bytes = v.size() * 4;
         float *d = nullptr;
-        if (lz_dev_malloc((void **)&d, v.size() * 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
-        m->allocs.push_back(d);
-        if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
+        if (m->alloc_cursor < m->allocs.size() && m->alloc_bytes[m->alloc_cursor] == bytes) {
+            d = (float *)m->allocs[m->alloc_cursor];
+        } else {
+            for (size_t i = m->alloc_cursor; i < m->allocs.size(); ++i) (void)hipFree(m->allocs[i]);  // shapes changed from here on
+            m->allocs.resize(m->alloc_cursor);
+            m->alloc_bytes.resize(m->alloc_cursor);
+            if (lz_dev_malloc((void **)&d, bytes ? bytes : 4) != hipSuccess) { if (err.empty()) err = "hipMalloc failed for weights"; return nullptr; }
+            m->allocs.push_back(d);
+            m->alloc_bytes.push_back(bytes);
+            m->realloc_happened = true;
+        }
+        m->alloc_cursor++;
+        if (bytes && hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
         return d;
     }
     // eval-mode BatchNorm -> y = x*scale + shift

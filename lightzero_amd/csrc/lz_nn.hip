@@ -1423,8 +1423,12 @@ void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
     if (launch_lstm2(a, s)) return;
     // 32-row tiles double the workgroup count (two resident per CU: one's chunk barrier overlaps the other's
     // MFMAs) while the batch is small; 64-row tiles halve the operand traffic once there are enough rows
+#ifdef LZ_DEBUG_KNOBS
     static const char *force = getenv("LZ_DEBUG_LSTM_ROWS");
     const int rows = force ? atoi(force) : (a.B <= 512 ? 32 : 64);
+#else
+    const int rows = a.B <= 512 ? 32 : 64;
+#endif
     if (rows == 32) launch_lstm_m<32>(a, s);
     else launch_lstm_m<64>(a, s);
 }

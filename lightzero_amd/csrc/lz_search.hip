@@ -30,6 +30,22 @@ void lz_model_destroy(lz_model *m)
     delete m;
 }
 
+// An engine holds one model; creating another one replaces it.  model_uid tells every roots handle and every host-side model
+// object that what they were sized for / bound to is gone (lz_engine_model_uid; the pools are re-allocated, stale users fail).
+static int replace_model(lz_engine *e)
+{
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    if (e->model) lz_model_destroy(e->model);
+    e->model = new (std::nothrow) lz_model();
+    if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+    e->model_uid++;
+    e->weights_gen++;
+    return LZ_OK;
+}
+
+extern "C" uint64_t lz_engine_model_uid(lz_engine *e) { return e ? e->model_uid : 0; }
+
 extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
 {
     LZ_REQUIRE(e != nullptr && cfg != nullptr, "NULL argument");
@@ -47,9 +63,7 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
             LZ_REQUIRE(cfg->num_channels % 64 == 0 && cfg->lstm_hidden_size % 64 == 0 && (nchunk == 4 || nchunk == 12 || nchunk == 9 || nchunk == 13 || nchunk == 17),
                        "compiled LSTM shapes: (latent_state_dim + lstm_hidden_size) / 64 in {4, 9, 12, 13, 17}, both multiples of 64");
         }
-        if (e->model) lz_model_destroy(e->model);
-        e->model = new (std::nothrow) lz_model();
-        if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+        if (int rc = replace_model(e)) return rc;
         e->model->cfg = *cfg;
         if (e->model->cfg.bn_eps <= 0) e->model->cfg.bn_eps = 1e-5f;
         if (e->model->cfg.ln_eps <= 0) e->model->cfg.ln_eps = 1e-5f;
@@ -78,9 +92,7 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
         const bool frag = K / 16 == 68 || K / 16 == 96, chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 9);
         LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): 6x6 latent with hidden 512 | 256, 8x8 latent (64x64 observations) with hidden 512");
     }
-    if (e->model) lz_model_destroy(e->model);
-    e->model = new (std::nothrow) lz_model();
-    if (!e->model) { lz_set_error("out of host memory"); return LZ_ERR_NOMEM; }
+    if (int rc = replace_model(e)) return rc;
     e->model->cfg = *cfg;
     if (e->model->cfg.bn_eps <= 0) e->model->cfg.bn_eps = 1e-5f;
     e->model->GW = cfg->downsample ? (cfg->obs_w == 64 ? 8 : 6) : cfg->obs_w;
@@ -107,8 +119,23 @@ extern "C" int lz_model_finalize(lz_engine *e)
     LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
     LZ_HIP_CHECK(hipSetDevice(e->device));
     lz_model *m = e->model;
-    for (void *p : m->allocs) (void)hipFree(p);
-    m->allocs.clear();
+    // a weight refresh on a live engine: nothing of this engine may still be reading the buffers that are about to be
+    // overwritten in place (Builder::upload)
+    LZ_HIP_CHECK(hipStreamSynchronize(e->stream));
+    m->alloc_cursor = 0;
+    m->realloc_happened = false;
+    struct GenBump {  // on every exit path: re-allocated weights invalidate the captured graphs of this engine's roots
+        lz_engine *e; lz_model *m;
+        ~GenBump()
+        {
+            if (m->alloc_cursor < m->allocs.size()) {  // fewer buffers than last time
+                for (size_t i = m->alloc_cursor; i < m->allocs.size(); ++i) (void)hipFree(m->allocs[i]);
+                m->allocs.resize(m->alloc_cursor); m->alloc_bytes.resize(m->alloc_cursor);
+                m->realloc_happened = true;
+            }
+            if (m->realloc_happened) e->weights_gen++;
+        }
+    } gen_bump{e, m};
     if (m->cfg.model_type >= 2) return lz_mlp_finalize(e);
     const lz_model_cfg &c = m->cfg;
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
@@ -239,8 +266,27 @@ extern "C" int lz_model_finalize(lz_engine *e)
 // ------------------------------------------------------------------------------------------------
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// the pools are sized by the model's shapes: a roots handle that outlives its model (another lz_model_create on the engine)
+// gets fresh pools, result blocks and observation staging for the new one
+int lz_roots_release_pools_if_stale(lz_roots *r)
+{
+    if (r->pool_slab && r->pool_model_uid == r->eng->model_uid) return LZ_OK;
+    if (!r->pool_slab && !r->d_obs && !r->d_results) { r->pool_model_uid = r->eng->model_uid; return LZ_OK; }
+    LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
+    if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
+    if (r->pool_slab) { (void)hipFree(r->pool_slab); r->pool_slab = nullptr; }
+    if (r->d_obs) { (void)hipFree(r->d_obs); r->d_obs = nullptr; r->d_obs_bytes = 0; }
+    if (r->d_results) { (void)hipFree(r->d_results); r->d_results = nullptr; }
+    if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
+    r->results_bytes = 0;
+    r->inferred = false; r->inference_fresh = false;
+    r->pool_model_uid = r->eng->model_uid;
+    return LZ_OK;
+}
+
 static int ensure_pools(lz_roots *r)
 {
+    if (int rc = lz_roots_release_pools_if_stale(r)) return rc;
     if (r->pool_slab) return LZ_OK;
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
@@ -324,6 +370,8 @@ static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_v
     const int B = r->t.B, HW = m->HWl, HC = c.head_channels;
     lz_head_desc h[3];
     int n = 0;
+    // the support-wide logits are observability for the parity tests (lz_roots_read_debug_logits): written only while tracing is on
+    if (!r->trace_on) dbg_value_logits = dbg_vp_logits = nullptr;
     h[n++] = headdesc(m->fc_value, r->t_pv, HW * 2 * HC, 2 * HC, 1, c.support_min, dbg_value_logits, out_value);
     h[n++] = headdesc(m->fc_policy, r->t_pv + HC, HW * 2 * HC, 2 * HC, 0, 0.f, out_logits, nullptr);
     if (with_vp) {
@@ -445,8 +493,13 @@ extern "C" int lz_initial_inference_host(lz_roots *r, const float *h_obs)
     lz_model *m = r->eng->model;
     if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    if (int rc = lz_roots_release_pools_if_stale(r)) return rc;
     const size_t n = (size_t)r->t.B * m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
-    if (!r->d_obs) LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_obs, n * 4));
+    if (r->d_obs_bytes < n * 4) {
+        if (r->d_obs) { LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream)); (void)hipFree(r->d_obs); r->d_obs = nullptr; }
+        LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_obs, n * 4));
+        r->d_obs_bytes = n * 4;
+    }
     LZ_HIP_CHECK(hipMemcpyAsync(r->d_obs, h_obs, n * 4, hipMemcpyHostToDevice, r->eng->stream));
     return lz_initial_inference(r, r->d_obs);
 }
@@ -479,9 +532,12 @@ static int search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count
     hipStream_t s = r->eng->stream;
     // layout of the result block: entropy [B] f64 | dist [B][A] | count [B] | action pos [B] | values [B] | pred values [B] | logits [B][PA]
     const size_t n_i = B * A + 2 * B, n_f = 2 * B + B * PA, bytes = B * 8 + (n_i + n_f) * 4;
-    if (!r->d_results) {
+    if (r->results_bytes < bytes) {
+        if (r->d_results) { LZ_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(r->d_results); r->d_results = nullptr; }
+        if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
         LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes));
         LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
+        r->results_bytes = bytes;
     }
     double *d_ent = (double *)r->d_results;
     int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B;
@@ -621,6 +677,11 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
     return LZ_OK;
 }
 
+// Timing experiments that SKIP WORK (results are then meaningless) exist only in the -DLZ_DEBUG_KNOBS build
+// (liblz_mi355_dbg.so, `python -m lightzero_amd.build --debug-knobs`, used by tools/): LZ_DEBUG_SKIP=<letters> drops launches
+// from the search (t tree step, c chain, l LSTM, h heads), LZ_DEBUG_CHAIN_LAYERS cuts the chain short, LZ_DEBUG_CHAIN_TS
+// stamps its phases.  The release library contains none of them (tests/test_abi_cpu.py greps the binary).
+#ifdef LZ_DEBUG_KNOBS
 static unsigned long long *g_chain_ts = nullptr;
 extern "C" int lz_debug_read_chain_ts(unsigned long long *h_out)
 {
@@ -629,14 +690,14 @@ extern "C" int lz_debug_read_chain_ts(unsigned long long *h_out)
     LZ_HIP_CHECK(hipMemcpy(h_out, g_chain_ts, 32 * 8, hipMemcpyDeviceToHost));
     return LZ_OK;
 }
-
-// timing experiments only: LZ_DEBUG_SKIP=<letters> drops launches from the search (t tree step, c chain, l LSTM, h heads) so
-// that the marginal in-graph cost of each kernel can be read off the step time; results are then meaningless
 static bool dbg_skip(char k)
 {
     const char *v = getenv("LZ_DEBUG_SKIP");
     return v && strchr(v, k);
 }
+#else
+static constexpr bool dbg_skip(char) { return false; }
+#endif
 
 // the network part of one simulation (mcts_ctree.py:834-847): recurrent_inference for the leaves selected by the
 // last traverse, outputs into slot sim + 1 of the pools
@@ -650,7 +711,9 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     const size_t B = t.B, A = t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size;
     const int slot = sim + 1;
     const size_t lat_slot = B * HW * C;
-    if (r->trace_on) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
+    // trace: the selection this simulation's network launches consume.  With the tree step fused into the chain launch the
+    // res_* arrays are written by that launch's prologue, so the copy follows it (same stream; also inside a captured graph)
+    if (r->trace_on && !step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     // ---- dynamics conv over [latent | one-hot action] + BN + latent + ReLU, dynamics residual block (-> latent pool
     // slot), prediction residual block and the three 1x1 head convs (efficientzero_model.py:527-558, common.py:1189-1203):
     // ONE launch, activations stay in LDS
@@ -668,18 +731,22 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
         ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = 2;
         ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = 3;
         ca.nc1 = 3;
+#ifdef LZ_DEBUG_KNOBS
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
         if (getenv("LZ_DEBUG_CHAIN_TS")) {  // timing experiments only: stamps of the last launch, read with lz_debug_read_chain_ts
             if (!g_chain_ts) (void)lz_dev_malloc((void **)&g_chain_ts, 32 * 8);
             ca.tstamp = g_chain_ts;
         }
+#endif
         ProfScope ps(r->eng, s);
         if (step && !lz_chain_fusable(ca, *step)) {  // decided by the caller with chain_takes_step(); kept as a guard
             lz_tree_launch_backprop_traverse(step->t, step->new_node, step->discount, step->vps, step->values, step->logits,
                                              step->horizon, step->a, step->delta, step->vtp, s);
             step = nullptr;
         }
+        const bool fused_step = step != nullptr;
         if (!dbg_skip('c')) lz_launch_chain(ca, s, step);
+        if (r->trace_on && fused_step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     }
     // ---- value prefix LSTM (+ BN1d + ReLU), then the three head MLPs with h^-1 fused
     lz_lstm_args l{};
@@ -730,7 +797,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     // The expand + backup of simulation s and the selection of simulation s + 1 are one tree step per root; for the conv
     // models it runs in the prologue of simulation s + 1's chain launch (same workgroup-per-root mapping) while the tree
     // of a root still fits the LDS budget, else as its own launch.  LZ_NO_TREE_FUSE=1 keeps it separate (parity tests).
-    const bool fuse = r->eng->model->cfg.model_type < 2 && !r->trace_on && !getenv("LZ_NO_TREE_FUSE");
+    const bool fuse = r->eng->model->cfg.model_type < 2 && !getenv("LZ_NO_TREE_FUSE");
     lz_tree_step step{};
     bool pending = false;  // a step that the next chain launch has to run
     for (int sim = 0; sim < num_simulations; ++sim) {
@@ -758,7 +825,10 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
 static uint64_t graph_knobs()
 {
     uint64_t knobs = 0;
-    const char *names[] = {"LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256", "LZ_DEBUG_SKIP",
+    const char *names[] = {"LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256",
+#ifdef LZ_DEBUG_KNOBS
+                           "LZ_DEBUG_SKIP",
+#endif
                            "LZ_LSTM_ROWS32"};
     for (const char *n : names) {
         const char *v = getenv(n);
@@ -796,6 +866,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->inferred && r->prepared, "lz_search needs lz_initial_inference and a prepare call first");
+    LZ_REQUIRE(r->pool_model_uid == r->eng->model_uid, "the engine's model was replaced after these roots were inferred");
     LZ_REQUIRE(lstm_horizon_len > 0 || r->eng->model->cfg.model_type == 1 || r->eng->model->cfg.model_type == 2, "lstm_horizon_len must be positive (mcts_ctree.py:858)");
     if (num_simulations < 1 || num_simulations >= r->t.NN) {
         lz_set_error("num_simulations %d exceeds the node pool (max_simulations %d)", num_simulations, r->t.NN - 1);
@@ -807,7 +878,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     lz_traverse_args ta;
     ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
     ta.tiebreak = r->tiebreak; ta.seed = r->seed; ta.counter = 0;
-    const bool use_graph = !r->trace_on && !r->eng->prof_on && !getenv("LZ_NO_GRAPH");
+    const bool use_graph = !r->eng->prof_on && !getenv("LZ_NO_GRAPH");
     if (!use_graph) {
         enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
         LZ_HIP_CHECK(hipGetLastError());
@@ -817,6 +888,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     key.sims = num_simulations; key.pb_c_base = pb_c_base; key.pb_c_init = pb_c_init; key.discount = discount_factor;
     key.horizon = lstm_horizon_len; key.delta = value_delta_max; key.players = r->players; key.tiebreak = r->tiebreak;
     key.seed = r->seed; key.knobs = graph_knobs();
+    key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = r->trace_on ? 1 : 0;
     return launch_captured(r, key, [&]() { enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s); });
 }
 
@@ -827,6 +899,7 @@ extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_consider
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->t.variant == LZ_TREE_GUMBEL_MUZERO, "not a Gumbel MuZero roots handle");
     LZ_REQUIRE(r->inferred && r->prepared, "lz_gsearch needs lz_initial_inference and a prepare call first");
+    LZ_REQUIRE(r->pool_model_uid == r->eng->model_uid, "the engine's model was replaced after these roots were inferred");
     LZ_REQUIRE(r->players == 1, "the Gumbel MuZero tree is single-player (cnode.cpp:618)");
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
@@ -845,7 +918,7 @@ extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_consider
             else lz_gtree_launch_backprop(t, slot, discount_factor, rew, val, lg, s);
         }
     };
-    if (r->trace_on || r->eng->prof_on || getenv("LZ_NO_GRAPH")) {
+    if (r->eng->prof_on || getenv("LZ_NO_GRAPH")) {
         enqueue();
         LZ_HIP_CHECK(hipGetLastError());
         return LZ_OK;
@@ -854,6 +927,7 @@ extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_consider
     key.sims = num_simulations; key.pb_c_base = max_num_considered_actions; key.discount = discount_factor;
     key.horizon = -7;  // marks a Gumbel search (a roots handle is either Gumbel or not, so the slot is never shared)
     key.players = r->players; key.tiebreak = r->tiebreak; key.seed = r->seed; key.knobs = graph_knobs();
+    key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = r->trace_on ? 1 : 0;
     return launch_captured(r, key, enqueue);
 }
 
@@ -866,6 +940,7 @@ extern "C" int lz_search_with_reuse(lz_roots *r, int num_simulations, int pb_c_b
 {
     LZ_REQUIRE(r != nullptr && h_true_action != nullptr && h_reuse_value != nullptr, "NULL argument");
     LZ_REQUIRE(r->inferred && r->prepared, "lz_search_with_reuse needs lz_initial_inference and a prepare call first");
+    LZ_REQUIRE(r->pool_model_uid == r->eng->model_uid, "the engine's model was replaced after these roots were inferred");
     LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "the sampled tree has no reuse variant");
     const int mt = r->eng->model->cfg.model_type;
     LZ_REQUIRE(lstm_horizon_len > 0 || mt == 1 || mt == 2, "lstm_horizon_len must be positive (mcts_ctree.py:967)");
@@ -977,9 +1052,82 @@ extern "C" int lz_roots_read_hidden(lz_roots *r, int slot, float *h_h, float *h_
     return LZ_OK;
 }
 
+// ---- teacher-forced / foreign-driver access to the pools
+extern "C" int lz_roots_write_latent(lz_roots *r, int slot, const float *h_in_nchw)
+{
+    LZ_REQUIRE(r != nullptr && h_in_nchw != nullptr, "NULL argument");
+    lz_model *m = r->eng->model;
+    LZ_REQUIRE(m != nullptr && m->finalized, "no finalized model on this engine");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = m->cfg.model_type >= 2 ? lz_mlp_ensure_pools(r) : ensure_pools(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
+    const size_t B = r->t.B, C = m->cfg.num_channels, HW = m->HWl;
+    std::vector<float> tmp(B * HW * C);
+    for (size_t b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p)
+            for (size_t ch = 0; ch < C; ++ch) tmp[(b * HW + p) * C + ch] = h_in_nchw[(b * C + ch) * HW + p];
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(r->latent_pool + slot * B * HW * C, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    r->inferred = true;  // the pools now hold a caller-provided state
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_write_hidden(lz_roots *r, int slot, const float *h_h, const float *h_c)
+{
+    LZ_REQUIRE(r != nullptr && h_h != nullptr && h_c != nullptr, "NULL argument");
+    lz_model *m = r->eng->model;
+    LZ_REQUIRE(m != nullptr && m->finalized, "no finalized model on this engine");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    int rc = m->cfg.model_type >= 2 ? lz_mlp_ensure_pools(r) : ensure_pools(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
+    const size_t B = r->t.B, H = m->cfg.model_type >= 2 ? (size_t)lz_mlp_hidden_size(m) : (size_t)(m->cfg.model_type == 0 ? m->cfg.lstm_hidden_size : 0);
+    LZ_REQUIRE(H > 0, "this model has no LSTM state");
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(r->h_pool + slot * B * H, h_h, B * H * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(r->c_pool + slot * B * H, h_c, B * H * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// Model.recurrent_inference(latent_state, reward_hidden_state, action) (efficientzero_model.py:240-273, muzero_model.py:240-272)
+// on pool slots: root i reads slot h_parent_slot[i], the results land in out_slot (read them with lz_roots_read_*).
+extern "C" int lz_recurrent_inference(lz_roots *r, const int32_t *h_parent_slot, const int32_t *h_actions, const float *h_actions_f,
+                                      const int32_t *h_search_len, int lstm_horizon_len, int out_slot)
+{
+    LZ_REQUIRE(r != nullptr && h_parent_slot != nullptr, "NULL argument");
+    lz_model *m = r->eng->model;
+    LZ_REQUIRE(m != nullptr && m->finalized, "no finalized model on this engine");
+    LZ_REQUIRE(r->pool_slab != nullptr && r->pool_model_uid == r->eng->model_uid && r->inferred,
+               "the pools hold no state: run lz_initial_inference (or lz_roots_write_latent) first");
+    LZ_REQUIRE(out_slot >= 1 && out_slot < r->t.NN, "out_slot out of range");
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B;
+    const bool sampled = t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO;
+    LZ_REQUIRE(sampled ? h_actions_f != nullptr : h_actions != nullptr, "actions: int32 [B] (float [B][D] for sampled roots)");
+    for (size_t i = 0; i < B; ++i) {
+        LZ_REQUIRE(h_parent_slot[i] >= 0 && h_parent_slot[i] < t.NN && h_parent_slot[i] != out_slot, "parent slot out of range");
+        if (!sampled) LZ_REQUIRE(h_actions[i] >= 0 && h_actions[i] < m->cfg.action_space_size, "action out of range");
+    }
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    std::vector<int32_t> ones(B, 1);
+    LZ_HIP_CHECK(hipMemcpyAsync(t.res_ix, h_parent_slot, B * 4, hipMemcpyHostToDevice, s));
+    if (!sampled) LZ_HIP_CHECK(hipMemcpyAsync(t.res_last_action, h_actions, B * 4, hipMemcpyHostToDevice, s));
+    else LZ_HIP_CHECK(hipMemcpyAsync(t.res_last_action_f, h_actions_f, B * (size_t)t.D * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(t.res_search_len, h_search_len ? h_search_len : ones.data(), B * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));  // the sources are caller / stack memory
+    recurrent(r, out_slot - 1, h_search_len ? lstm_horizon_len : 0, s);
+    LZ_HIP_CHECK(hipGetLastError());
+    return LZ_OK;
+}
+
 extern "C" int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out)
 {
     LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr && h_out != nullptr && (which == 0 || which == 1), "bad argument");
+    LZ_REQUIRE(r->trace_on, "the debug logits are written only while tracing is on (lz_roots_enable_trace before the inference)");
     const size_t B = r->t.B, SUP = r->eng->model->cfg.support_size;
     hipStream_t s = r->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(h_out, r->dbg_logits[which], B * SUP * 4, hipMemcpyDeviceToHost, s));

@@ -21,7 +21,6 @@ import numpy as np
 from ... import _lib as L
 
 DEFAULT_MAX_SIMULATIONS = 512
-_seed_counter = [0x5EED]
 
 
 def make_module(variant, has_deterministic_flag):
@@ -54,12 +53,26 @@ def make_module(variant, has_deterministic_flag):
             self._engine = engine
             self._h = None
             self._tiebreak = None  # None -> module default
-            _seed_counter[0] += 1
-            self._seed = _seed_counter[0]
+            # the reference seeds its tie-break stream from the clock (srand(tv_usec) per traverse, cnode.cpp:901); here it follows
+            # np.random's state and the rank (set_tiebreak(mode, seed) / the policies' ``mcts_seed`` pin it)
+            self._seed = L.process_seed()
+            self._inferred_by = None
+            self._touched = False  # a prepare / inference has used the device handle
 
         @property
         def num(self):
             return self.root_num
+
+        def _bind_engine(self, engine):
+            """an engine model is about to run on these roots: they must live on the model's engine"""
+            mine = self._engine if self._engine is not None else L.default_engine()
+            if self._h is not None and getattr(mine, "value", mine) != getattr(engine, "value", engine):
+                if self._touched:
+                    raise L.LzError("these roots already hold a search on another engine than the model's: build them with "
+                                    "Roots(..., engine=model.engine) / MCTSCtree.roots(..., engine=model.engine)")
+                self.clear()  # an empty node pool: re-create it where the model lives
+            self._engine = engine
+            self._touched = True
 
         def _ensure(self, A):
             if self._h is not None:
@@ -109,6 +122,7 @@ def make_module(variant, has_deterministic_flag):
             if logits.ndim != 2 or logits.shape[0] != self.root_num:
                 raise ValueError("policy_logits_pool must be [root_num][action_space_size]")
             self._ensure(logits.shape[1])
+            self._touched = True
             nz = L.f32([x for row in noises for x in row] or [0.0])
             want = sum(len(l) if l else self._A for l in self._legal)
             if nz.size < want:
@@ -121,20 +135,32 @@ def make_module(variant, has_deterministic_flag):
             if logits.ndim != 2 or logits.shape[0] != self.root_num:
                 raise ValueError("policy_logits_pool must be [root_num][action_space_size]")
             self._ensure(logits.shape[1])
+            self._touched = True
             L.check(L.lib().lz_roots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), logits,
                                              L.i32(to_play_batch)))
 
         def prepare_from_inference(self, root_noise_weight, noises, to_play_batch):
             """Roots.prepare with the policy logits an engine model's initial_inference left in HBM
             (value prefix 0, efficientzero_model.py:238); noises: one list per root over its legal actions."""
+            if self._h is None:
+                raise L.LzError("prepare_from_inference before an engine model's initial_inference on these roots")
             if isinstance(noises, np.ndarray):  # [root_num][n_legal] rows of equal length
                 nz = np.ascontiguousarray(noises, np.float32).reshape(-1)
             else:
                 nz = np.concatenate([np.asarray(row, np.float32).reshape(-1) for row in noises]) if len(noises) else np.zeros(1, np.float32)
+            want = sum(len(l) if l else self._A for l in self._legal)
+            if nz.size < want:  # the library copies sum(n_legal) floats from this pointer
+                raise ValueError("noises must hold one value per legal action (%d < %d)" % (nz.size, want))
+            if len(to_play_batch) != self.root_num:
+                raise ValueError("to_play_batch must have root_num entries")
             L.check(L.lib().lz_roots_prepare_from_inference(self._h, float(root_noise_weight), nz.ctypes.data,
                                                             L.i32(to_play_batch)))
 
         def prepare_from_inference_no_noise(self, to_play_batch):
+            if self._h is None:
+                raise L.LzError("prepare_from_inference_no_noise before an engine model's initial_inference on these roots")
+            if len(to_play_batch) != self.root_num:
+                raise ValueError("to_play_batch must have root_num entries")
             L.check(L.lib().lz_roots_prepare_from_inference(self._h, 0.0, None, L.i32(to_play_batch)))
 
         def get_distributions(self):
@@ -265,6 +291,8 @@ def make_module(variant, has_deterministic_flag):
         _bind(roots, min_max_stats_lst)
         B = roots.root_num
         vtp = L.i32(virtual_to_play_batch).copy()
+        if vtp.shape != (B,) or len(true_action) != B or len(reuse_value) != B:
+            raise ValueError("virtual_to_play_batch, true_action and reuse_value must have root_num entries")
         ix = np.zeros(B, np.int32); iy = np.zeros(B, np.int32); la = np.zeros(B, np.int32); sl = np.zeros(B, np.int32)
         L.check(L.lib().lz_batch_traverse_with_reuse(roots._h, int(pb_c_base), float(pb_c_init), float(discount_factor), vtp,
                                                      L.i32(true_action), L.f32(reuse_value), ix, iy, la, sl))

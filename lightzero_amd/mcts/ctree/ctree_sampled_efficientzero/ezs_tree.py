@@ -13,7 +13,6 @@ import numpy as np
 from .... import _lib as L
 
 DEFAULT_MAX_SIMULATIONS = 512
-_seed = [0xC0FFEE]
 
 
 class MinMaxStatsList(object):
@@ -42,21 +41,31 @@ class Roots(object):
         self.root_num, self.K = int(root_num), int(num_of_sampled_actions)
         self.continuous = bool(continuous_action_space)
         self._S = int(max_simulations) if max_simulations else DEFAULT_MAX_SIMULATIONS
-        h = L.P()
-        eng = engine if engine is not None else L.default_engine()
-        if self.continuous:
-            self.D, self._pw = int(action_space_size), 2 * int(action_space_size)   # policy = (mu | sigma)
-            L.check(L.lib().lz_sroots_create(eng, self.root_num, self.D, self.K, self._S, ctypes.byref(h)))
-        else:  # discrete: an action is the float of its index (cnode.cpp:436-441), policy = action_space_size logits
-            self.D, self._pw = 1, int(action_space_size)
-            L.check(L.lib().lz_sroots_create_discrete(eng, self.root_num, self._pw, self.K, self._S, ctypes.byref(h)))
-        self._h = h
-        _seed[0] += 1
-        self._seed = _seed[0]
-        L.check(L.lib().lz_roots_set_tiebreak(self._h, 1, self._seed))
+        self._A_arg = int(action_space_size)
+        self._inferred_by = None
+        self._h = None
+        self._seed = None
+        self._touched = False
+        self._create(engine if engine is not None else L.default_engine())
         self.given = None            # draws of the NEXT expand, [B][K][D]
         self.given_provider = None   # or: callable(record_index) -> draws (record 0 = prepare, s + 1 = simulation s)
         self._record = 0
+
+    def _create(self, eng):
+        h = L.P()
+        self._engine = eng
+        if self.continuous:
+            self.D, self._pw = self._A_arg, 2 * self._A_arg   # policy = (mu | sigma)
+            L.check(L.lib().lz_sroots_create(eng, self.root_num, self.D, self.K, self._S, ctypes.byref(h)))
+        else:  # discrete: an action is the float of its index (cnode.cpp:436-441), policy = action_space_size logits
+            self.D, self._pw = 1, self._A_arg
+            L.check(L.lib().lz_sroots_create_discrete(eng, self.root_num, self._pw, self.K, self._S, ctypes.byref(h)))
+        self._h = h
+        if self._seed is None:
+            # the reference seeds its sampling / tie-break generators from the clock; here: np.random's state mixed with the
+            # rank (set_tiebreak(mode, seed) / the policy's ``mcts_seed`` pin it)
+            self._seed = L.process_seed()
+        L.check(L.lib().lz_roots_set_tiebreak(self._h, getattr(self, "_mode", 1), self._seed))
 
     @property
     def num(self):
@@ -65,7 +74,19 @@ class Roots(object):
     def set_tiebreak(self, mode, seed=None):
         if seed is not None:
             self._seed = int(seed)
-        L.check(L.lib().lz_roots_set_tiebreak(self._h, int(mode), self._seed))
+        self._mode = int(mode)
+        L.check(L.lib().lz_roots_set_tiebreak(self._h, self._mode, self._seed))
+
+    def _bind_engine(self, engine):
+        """an engine model is about to run on these roots: they must live on the model's engine"""
+        if getattr(self._engine, "value", self._engine) != getattr(engine, "value", engine):
+            if self._touched:
+                raise L.LzError("these roots already hold a search on another engine than the model's: build them with "
+                                "Roots(..., engine=model.engine)")
+            L.lib().lz_roots_destroy(self._h)  # an empty node pool: re-create it where the model lives
+            self._h = None
+            self._create(engine)
+        self._touched = True
 
     def _take_given(self):
         rec = self._record
@@ -79,6 +100,7 @@ class Roots(object):
         return self._g.ctypes.data
 
     def prepare(self, root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch):
+        self._touched = True
         pol = L.f32(policy_logits_pool)
         if pol.shape != (self.root_num, self._pw):
             raise ValueError("policy_logits_pool must be [root_num][2 * action_space_size] (mu | sigma), or [root_num][action_space_size] logits for discrete actions")
@@ -87,6 +109,7 @@ class Roots(object):
                                           L.i32(to_play_batch), self._take_given()))
 
     def prepare_no_noise(self, value_prefix_pool, policy_logits_pool, to_play_batch):
+        self._touched = True
         pol = L.f32(policy_logits_pool)
         if pol.shape != (self.root_num, self._pw):
             raise ValueError("policy_logits_pool has the wrong width")

@@ -35,20 +35,34 @@ class EfficientZeroModel(object):
         self.num_channels = int(num_channels)
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
         self.reward_support_size = self.value_support_size
-        self._engine = engine if engine is not None else L.default_engine()
+        # one model per engine: the first model of the process lives on the default engine, later ones get their own
+        self._engine = engine if engine is not None else L.engine_for_new_model()
         cfg = L.ModelCfg(self._model_type, self.observation_shape[0], self.observation_shape[1], self.observation_shape[2],
                          self.action_space_size, self.num_channels, self.lstm_hidden_size, int(value_head_channels),
                          int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5,
                          1 if downsample else 0)
+        self._create(cfg)
+
+    def _create(self, cfg):
         L.check(L.lib().lz_model_create(self._engine, ctypes.byref(cfg)))
+        self._uid = L.lib().lz_engine_model_uid(self._engine)
         self._loaded = False
+
+    def _check_owner(self):
+        """another model object may have been created on this engine since (it replaces this one's weights)"""
+        if L.lib().lz_engine_model_uid(self._engine) != self._uid:
+            raise L.LzError("%s: its engine now holds another model (one model per engine: pass engine=L.new_engine() "
+                            "or let the constructor pick one)" % type(self).__name__)
 
     @property
     def engine(self):
         return self._engine
 
     def load_state_dict(self, state_dict, strict=True):
-        """state_dict: reference key -> array-like (torch tensors or numpy), e.g. a LightZero checkpoint's ``model``."""
+        """state_dict: reference key -> array-like (torch tensors or numpy), e.g. a LightZero checkpoint's ``model``.
+        Calling it again on a loaded model is a weight refresh (collector after a learner update): tensors are overwritten in
+        place on the device, roots and their captured search graphs stay valid."""
+        self._check_owner()
         for name, value in state_dict.items():
             if name.endswith("num_batches_tracked"):
                 continue
@@ -73,7 +87,9 @@ class EfficientZeroModel(object):
         (and its synchronisation) and returns None."""
         if not self._loaded:
             raise L.LzError("EfficientZeroModel: load_state_dict has not been called")
+        self._check_owner()
         B = roots.num
+        roots._bind_engine(self._engine)
         roots._ensure(self.action_space_size)
         if hasattr(obs, "data_ptr"):
             if tuple(obs.shape) != (B,) + self.observation_shape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":

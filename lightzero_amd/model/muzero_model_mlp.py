@@ -36,14 +36,13 @@ class _EngineModelMLP(EfficientZeroModel):
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
         self.reward_support_size = self.value_support_size
         self._policy_width = 2 * self.action_space_size if self.continuous_action_space else self.action_space_size
-        self._engine = engine if engine is not None else L.default_engine()
+        self._engine = engine if engine is not None else L.engine_for_new_model()
         enc = 2 if self.continuous_action_space else (0 if discrete_action_encoding_type == 'one_hot' else 1)
         cfg = L.ModelCfg(self._model_type, self.observation_shape[0], 1, 1, self.action_space_size, self.latent_state_dim,
                          self.lstm_hidden_size, 0, 0, self.value_support_size, float(value_support_range[0]), 1e-5, 0,
                          self._activation, 1 if res_connection_in_dynamics else 0, enc, self.num_of_sampled_actions, 0,
                          1 if bound_type == 'tanh' else 0, 1e-5)
-        L.check(L.lib().lz_model_create(self._engine, ctypes.byref(cfg)))
-        self._loaded = False
+        self._create(cfg)
 
     def initial_inference(self, obs, roots, fetch=True):
         """initial_inference for the batch held by ``roots``; ``obs``: [B, observation_shape] fp32 (device tensor or host
@@ -53,7 +52,9 @@ class _EngineModelMLP(EfficientZeroModel):
         import numpy as np
         if not self._loaded:
             raise L.LzError("%s: load_state_dict has not been called" % type(self).__name__)
+        self._check_owner()
         B = roots.num
+        roots._bind_engine(self._engine)
         roots._ensure(self.action_space_size)
         if hasattr(obs, "data_ptr") and getattr(obs, "is_cuda", False):
             if tuple(obs.shape) != (B,) + self.observation_shape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":

@@ -17,6 +17,18 @@ def _g(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
+def _mcts_seed(cfg):
+    """``mcts_seed`` (optional policy config entry): pins the device-side random streams of the search (stochastic tie-breaks,
+    sampled actions) for reproducible runs; mixed with the rank so that data-parallel collectors still differ.  None: the
+    roots draw their seed from np.random (see lightzero_amd._lib.process_seed)."""
+    import os
+    seed = _g(cfg, "mcts_seed", None)
+    if seed is None:
+        return None
+    rank = int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")))
+    return (int(seed) ^ ((rank + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1)
+
+
 class _HbmTokens(object):
     """stands in for the network output of an engine model whose latent / LSTM state stayed in HBM"""
 
@@ -62,7 +74,7 @@ class EfficientZeroPolicy(object):
         if roots is None:
             roots = MCTSCtree.roots(n, legal_actions, action_space_size=self._collect_model.action_space_size,
                                     max_simulations=int(self._mcfg["num_simulations"]))
-            roots.set_tiebreak(self._tiebreak)
+            roots.set_tiebreak(self._tiebreak, seed=_mcts_seed(self._cfg))
             self._roots_cache[n] = roots
         else:
             roots.reset(legal_actions)
@@ -91,6 +103,28 @@ class EfficientZeroPolicy(object):
                 early = None
         legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_collect_env_num)]
         roots = early.reset(legal_actions, keep_inference=True) if early is not None else self._roots(active_collect_env_num, legal_actions)
+        if bool(_g(self._cfg, "collect_with_pure_policy", False)):
+            # efficientzero.py:597,644-655: no search; sample from softmax(policy logits over the legal actions)
+            if early is None:
+                network_output = self._collect_model.initial_inference(data, roots)
+                pred_values, logits = np.asarray(network_output.value, np.float32), np.asarray(network_output.policy_logits)
+            else:
+                pred_values = np.zeros(active_collect_env_num, np.float32)
+                logits = np.zeros((active_collect_env_num, self._collect_model.action_space_size), np.float32)
+                from .. import _lib as L
+                L.check(L.lib().lz_roots_get_root_outputs(roots._h, pred_values, logits.reshape(-1)))
+            pred_values = pred_values.reshape(active_collect_env_num, 1)
+            policy_logits = logits.tolist()
+            for i, env_id in enumerate(ready_env_id):
+                z = np.asarray([policy_logits[i][a] for a in legal_actions[i]], np.float32)
+                e = np.exp(z - z.max())
+                policy_values = (e / e.sum()).tolist()
+                policy_values = policy_values / np.sum(policy_values)
+                idx = np.random.choice(len(legal_actions[i]), p=policy_values)
+                action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
+                output[env_id] = {'action': action, 'searched_value': pred_values[i], 'predicted_value': pred_values[i],
+                                  'predicted_policy_logits': policy_logits[i]}
+            return output
         alpha = self._mcfg["root_dirichlet_alpha"]
         counts = [len(l) for l in legal_actions]
         if len(set(counts)) == 1:  # one vectorised draw instead of one np.random.dirichlet call per env (efficientzero.py:599-602)
@@ -119,6 +153,7 @@ class EfficientZeroPolicy(object):
             self._search(self._mcts_collect, roots, self._collect_model, network_output, to_play)
             roots_visit_count_distributions = roots.get_distributions()
             roots_values = roots.get_values()
+        pred_values = np.asarray(pred_values, np.float32).reshape(active_collect_env_num, 1)  # efficientzero.py:583: [B, 1]
         eps_cfg = _g(self._cfg, "eps", {}) or {}
         eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
         if self._device_select and not fused:
@@ -176,6 +211,7 @@ class EfficientZeroPolicy(object):
             roots_values = roots.get_values()
             if self._device_select:
                 dev_pos, dev_ent = roots.select_action(1, deterministic=True)
+        pred_values = np.asarray(pred_values, np.float32).reshape(active_eval_env_num, 1)  # efficientzero.py:711: [B, 1]
         for i, env_id in enumerate(ready_env_id):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]
             if self._device_select:

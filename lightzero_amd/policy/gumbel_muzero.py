@@ -4,7 +4,7 @@
 import numpy as np
 
 from ..mcts.tree_search.mcts_ctree import GumbelMuZeroMCTSCtree as MCTSCtree
-from .efficientzero import _g
+from .efficientzero import _g, _mcts_seed
 from .utils import select_action
 
 

@@ -1,7 +1,7 @@
 """Collect / eval halves of lzero/policy/muzero.py::MuZeroPolicy (``_forward_collect`` :705-829, ``_forward_eval``
 :842-930) on the MI355X engine; same arguments and per-env output dict as the reference."""
 from ..mcts.tree_search.mcts_ctree import MuZeroMCTSCtree
-from .efficientzero import EfficientZeroPolicy, _g
+from .efficientzero import EfficientZeroPolicy, _g, _mcts_seed
 
 
 class MuZeroPolicy(EfficientZeroPolicy):
@@ -15,7 +15,7 @@ class MuZeroPolicy(EfficientZeroPolicy):
         if roots is None:
             roots = MuZeroMCTSCtree.roots(n, legal_actions, action_space_size=self._collect_model.action_space_size,
                                           max_simulations=int(self._mcfg["num_simulations"]))
-            roots.set_tiebreak(self._tiebreak)
+            roots.set_tiebreak(self._tiebreak, seed=_mcts_seed(self._cfg))
             self._roots_cache[n] = roots
         else:
             roots.reset(legal_actions)

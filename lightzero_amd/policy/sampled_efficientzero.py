@@ -8,7 +8,7 @@ reference (incl. ``root_sampled_actions``)."""
 import numpy as np
 
 from ..mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree as MCTSCtree, _inverse_scalar_transform
-from .efficientzero import _g
+from .efficientzero import _g, _mcts_seed
 from .utils import select_action
 
 
@@ -44,7 +44,7 @@ class SampledEfficientZeroPolicy(object):
             # the reference passes the action mask's indices for discrete spaces; its CRoots ignores them (cnode.cpp:653-659)
             legal_actions = [[-1 for _ in range(self._K)] for _ in range(n)]
             roots = MCTSCtree.roots(n, legal_actions, self._A, self._K, self._continuous, max_simulations=int(self._mcfg["num_simulations"]))
-            roots.set_tiebreak(self._tiebreak)
+            roots.set_tiebreak(self._tiebreak, seed=_mcts_seed(self._cfg))
             self._roots_cache[n] = roots
         return roots
 

@@ -15,9 +15,12 @@ so the inference graphs are restated with the reference's parameter names (a Lig
   nn.Sequential(Linear, norm, act, ..., Linear).
 * ``InverseScalarTransform`` lzero/policy/scaling_transform.py:64-92
 
-NN parity is unpinned by the reference's own tests (they assert shapes only,
-lzero/model/tests/test_efficientzero_model.py:89-127); the pin used here is this restatement on
-shared random weights, plus the h^-1 known-answer of lzero/policy/tests/test_scaling_transform.py.
+The reference's own tests assert shapes only (lzero/model/tests/test_efficientzero_model.py:89-127).  PIN: every class here
+is checked BIT-EQUAL against the reference's own module of the same name, imported from /root/reference as it lies with a stub
+``ding`` (tests/test_torch_models_vs_reference.py; the residual restatement is DI-engine's ResBlock / MLP /
+ReparameterizationHead in tests/ref_stubs), ``InverseScalarTransform`` against lzero/policy/scaling_transform.py directly
+(incl. the reference's own check lzero/policy/tests/test_scaling_transform.py:7-19), and against the committed outputs of those
+reference modules (tests/golden/nn_*.npz, tests/test_nn_golden_cpu.py) on machines without /root/reference.
 """
 import math
 from collections import namedtuple
@@ -568,7 +571,7 @@ def synthetic_init(model, seed=0):
             if p.dim() >= 2:
                 fan_in = p[0].numel()
                 p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(fan_in)))
-            elif name.endswith("bias"):
+            elif name.endswith("bias") or ".bias_" in name:  # nn.LSTM names its biases bias_ih_l0 / bias_hh_l0
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
         for m in model.modules():
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):

@@ -1,0 +1,79 @@
+"""Shared definition of the network parity cases: the constructor keywords (identical for the reference class, the oracle
+restatement and the engine model), the weight seed and the seeded inputs.  Used by
+  * tests/test_torch_models_vs_reference.py  (CPU, here): oracle restatement == the reference's own modules, bit for bit
+  * tests/golden/make_golden_nn.py           (CPU, here): reference-module outputs -> tests/golden/nn_*.npz
+  * tests/test_nn_golden_gpu.py              (GPU box):   HIP kernels vs those files
+Inputs come from numpy's PCG64 (identical on every machine), never from a torch generator."""
+import numpy as np
+
+CASES = {
+    # BASELINE configs[1]: EfficientZero Atari, 96x96x4 -> 6x6 latent
+    "ez_atari96": dict(family="ez", kw=dict(observation_shape=(4, 96, 96), action_space_size=6, downsample=True), B=6, seed=11),
+    # the shipped Atari config: 64x64 -> 8x8 latent, supports (-50, 51, 1)
+    "ez_atari64": dict(family="ez", kw=dict(observation_shape=(4, 64, 64), action_space_size=6, downsample=True,
+                                            reward_support_range=(-50., 51., 1.), value_support_range=(-50., 51., 1.)), B=5, seed=12),
+    # BASELINE configs[2]: MuZero Atari
+    "mz_atari96": dict(family="mz", kw=dict(observation_shape=(4, 96, 96), action_space_size=4, downsample=True), B=6, seed=13),
+    # BASELINE configs[3]: Go 9x9 board, 82 actions, no downsample
+    "mz_go9": dict(family="mz", kw=dict(observation_shape=(17, 9, 9), action_space_size=82, downsample=False), B=5, seed=14),
+    # BASELINE configs[0]: CartPole MuZeroModelMLP
+    "mz_mlp_cartpole": dict(family="mz_mlp", kw=dict(observation_shape=4, action_space_size=2, latent_state_dim=128), B=8, seed=15),
+    "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),
+    # BASELINE configs[4]: Sampled EfficientZero, continuous actions, K = 20
+    "sez_mlp_cont": dict(family="sez_mlp", kw=dict(observation_shape=5, action_space_size=1, num_of_sampled_actions=20,
+                                                   continuous_action_space=True), B=8, seed=17),
+    "sez_mlp_disc": dict(family="sez_mlp", kw=dict(observation_shape=6, action_space_size=5, num_of_sampled_actions=3,
+                                                   continuous_action_space=False), B=8, seed=18),
+}
+STEPS = 3  # recurrent inferences chained after the initial one (teacher-forced on the reference's own states)
+
+
+def oracle_class(tm, family):
+    return {"ez": tm.EfficientZeroModel, "mz": tm.MuZeroModel, "mz_mlp": tm.MuZeroModelMLP, "ez_mlp": tm.EfficientZeroModelMLP,
+            "sez_mlp": tm.SampledEfficientZeroModelMLP}[family]
+
+
+def reference_class(ref, family):
+    return {"ez": ref.efficientzero_model.EfficientZeroModel, "mz": ref.muzero_model.MuZeroModel,
+            "mz_mlp": ref.muzero_model_mlp.MuZeroModelMLP, "ez_mlp": ref.efficientzero_model_mlp.EfficientZeroModelMLP,
+            "sez_mlp": ref.sampled_efficientzero_model_mlp.SampledEfficientZeroModelMLP}[family]
+
+
+def engine_class(family):
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.model.muzero_model import MuZeroModel
+    from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP
+    from lightzero_amd.model.efficientzero_model_mlp import EfficientZeroModelMLP
+    from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
+    return {"ez": EfficientZeroModel, "mz": MuZeroModel, "mz_mlp": MuZeroModelMLP, "ez_mlp": EfficientZeroModelMLP,
+            "sez_mlp": SampledEfficientZeroModelMLP}[family]
+
+
+def reference_kwargs(case):
+    """the reference constructors take one more switch the restatement has no use for"""
+    kw = dict(case["kw"])
+    if case["family"] in ("ez", "mz"):
+        kw["self_supervised_learning_loss"] = False
+    else:
+        kw["self_supervised_learning_loss"] = False
+    return kw
+
+
+def has_lstm(family):
+    return family in ("ez", "ez_mlp", "sez_mlp")
+
+
+def inputs(case):
+    """seeded observation batch and the action sequence of the chained recurrent steps"""
+    rng = np.random.default_rng(case["seed"])
+    kw, B = case["kw"], case["B"]
+    shape = kw["observation_shape"]
+    if isinstance(shape, int):
+        obs = rng.standard_normal((B, shape)).astype(np.float32)
+    else:
+        obs = rng.random((B,) + tuple(shape), dtype=np.float32)
+    if case["family"] == "sez_mlp" and kw.get("continuous_action_space", True):
+        actions = np.tanh(rng.standard_normal((STEPS, B, kw["action_space_size"]))).astype(np.float32)
+    else:
+        actions = rng.integers(0, kw["action_space_size"], size=(STEPS, B)).astype(np.int64)
+    return obs, actions

@@ -46,3 +46,13 @@ def test_synthetic_state_dict_matches_reference_layout():
     sd = efficientzero_state_dict(seed=0, action_space_size=6)
     ref = {k: tuple(v.shape) for k, v in tm.EfficientZeroModel(action_space_size=6).state_dict().items() if "num_batches" not in k}
     assert {k: tuple(v.shape) for k, v in sd.items()} == ref
+
+
+def test_release_library_has_no_skip_work_knobs():
+    """the switches that drop kernels / layers from a search (timing experiments) are compiled only into
+    liblz_mi355_dbg.so (-DLZ_DEBUG_KNOBS); the release library must not even contain their names."""
+    from lightzero_amd import build
+    blob = open(build.build(), "rb").read()
+    for knob in (b"LZ_DEBUG_SKIP", b"LZ_DEBUG_CHAIN_LAYERS", b"LZ_DEBUG_CHAIN_TS", b"LZ_DEBUG_LSTM_ROWS"):
+        assert knob not in blob, knob
+    assert not hasattr(ctypes.CDLL(build.LIB), "lz_debug_read_chain_ts")

@@ -24,7 +24,7 @@ def _setup(B, A=6, S=12, seed=0):
     dev = EfficientZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
     g = torch.Generator().manual_seed(seed + 1)
     obs = torch.rand(B, 4, 96, 96, generator=g)
-    roots = ez_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S)
+    roots = ez_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S, engine=dev.engine)
     roots.set_tiebreak(0)
     roots._ensure(A)
     return ref, dev, obs, roots
@@ -41,6 +41,7 @@ def test_initial_inference_matches_torch(B):
     ref, dev, obs, roots = _setup(B)
     d_obs = obs.cuda().contiguous()
     torch.cuda.synchronize()
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))  # the heads write their support-wide logits only while tracing
     L.check(L.lib().lz_initial_inference(roots._h, d_obs.data_ptr()))
     lat = np.zeros((B, 64, 6, 6), np.float32)
     L.check(L.lib().lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
@@ -58,8 +59,9 @@ def test_initial_inference_matches_torch(B):
 
 
 def test_recurrent_inference_matches_torch_teacher_forced():
-    """Every simulation of a device search: feed the torch model the SAME (latent, h, c, action) the
-    device gathered and compare everything the step produced."""
+    """Every simulation of a device search -- run as the benchmark runs it: captured HIP graph, tree step fused into the chain
+    launch (k_chain<6,6,false,1>), the trace being one D2D copy per simulation inside the graph: feed the torch model the SAME
+    (latent, h, c, action) the device gathered and compare everything the step produced."""
     from lightzero_amd import _lib as L
     from oracle import torch_models as tm
     B, A, S = 16, 6, 12
@@ -73,7 +75,7 @@ def test_recurrent_inference_matches_torch_teacher_forced():
     L.check(lib.lz_roots_prepare_from_inference(roots._h, 0.25, noises.ctypes.data, L.i32([-1] * B)))
     L.check(lib.lz_roots_enable_trace(roots._h, 1))
     L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
-    L.check(lib.lz_engine_synchronize(L.default_engine()))
+    L.check(lib.lz_engine_synchronize(dev.engine))
     trace = np.zeros((S, B, 4), np.int32)
     L.check(lib.lz_roots_read_trace(roots._h, S, trace.reshape(-1)))
     lat = np.zeros((S + 1, B, 64, 6, 6), np.float32); hh = np.zeros((S + 1, B, 512), np.float32); cc = np.zeros_like(hh)

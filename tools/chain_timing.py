@@ -5,6 +5,10 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("LZ_DEBUG_CHAIN_TS", "1"); os.environ.setdefault("LZ_NO_GRAPH", "1")
+# the stamps exist only in the -DLZ_DEBUG_KNOBS build of the library (python -m lightzero_amd.build --debug-knobs)
+from lightzero_amd import build as _b
+os.environ.setdefault("LZ_MI355_LIB", _b.DBG_LIB)
+assert os.path.exists(os.environ["LZ_MI355_LIB"]), "build the debug library first: python -m lightzero_amd.build --debug-knobs"
 import torch
 from lightzero_amd import _lib as L
 from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
@@ -13,13 +17,13 @@ lib = L.lib()
 from lightzero_amd.model.synthetic import efficientzero_state_dict
 model = EfficientZeroModel(action_space_size=6).load_state_dict(efficientzero_state_dict(seed=0, action_space_size=6))
 B, S = 256, 50
-roots = ez_tree.Roots(B, [list(range(6))] * B, action_space_size=6, max_simulations=S); roots._ensure(6)
+roots = ez_tree.Roots(B, [list(range(6))] * B, action_space_size=6, max_simulations=S, engine=model.engine); roots._ensure(6)
 obs = torch.rand(B, 4, 96, 96).cuda()
 for it in range(3):
     L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
     L.check(lib.lz_roots_prepare_from_inference(roots._h, 0.25, None, L.i32([-1] * B)))
     L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
-    L.check(lib.lz_engine_synchronize(L.default_engine()))
+    L.check(lib.lz_engine_synchronize(model.engine))
 lib.lz_debug_read_chain_ts.argtypes = [ctypes.c_void_p]
 out = np.zeros(32, np.uint64)
 L.check(lib.lz_debug_read_chain_ts(out.ctypes.data))
