@@ -266,6 +266,22 @@ int lz_roots_get_search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out
 int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count, float *h_out_values,
                                        float *h_pred_values, float *h_policy_logits, double temperature, int deterministic,
                                        uint64_t seed, int32_t *h_action_pos, double *h_entropy);
+/* Env-step rows -- the collector-side glue: everything MuZeroCollector keeps per env and step
+ * (muzero_collector.py:557-620) in the field set of GameSegment.append / store_search_stats (game_segment.py:158-182, 241-263),
+ * written by one kernel from device buffers after a fused search, select_action (lzero/policy/utils.py:637-661) included.
+ * Row = row_words float32 (>= lz_rows_width(A, frame_floats)):
+ *   [0] action  [1] reward (0: filled by the environment side)  [2] searched root value  [3] predicted value  [4] to_play
+ *   [5] timestep (h_timestep[i], -1 when NULL)  [6] visit-count entropy (bits)  [7] number of legal actions
+ *   [8, 8+A) child visits / sum in legal-list order (game_segment.py:247-252)   [8+A, 8+2A) action mask
+ *   [8+2A, 8+2A+frame_floats) the newest observation frame = the LAST frame_floats floats of each env's observation
+ *   (d_obs; NULL = the batch of the latest lz_initial_inference).
+ * d_rows: DEVICE [root_num][row_words] -- the payload of the trajectory all-gather (lightzero_amd/shard.py), it never
+ * crosses PCIe here.  h_header [root_num][8+2A]: host copy of the row headers (what stepping the environments needs);
+ * h_policy_logits [root_num][A] may be NULL.  One readout, one select_action, one pack launch, one synchronisation. */
+int lz_rows_width(int action_space_size, int frame_floats);
+int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
+                          int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, float *h_header,
+                          float *h_policy_logits);
 /* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
  * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
 int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,

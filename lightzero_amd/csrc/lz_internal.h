@@ -149,6 +149,8 @@ struct lz_roots {
     float *d_noise = nullptr;       // [B][A]
     int32_t *d_noise_off = nullptr; // [B]
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
+    const float *last_obs = nullptr; // the observation batch of the latest lz_initial_inference (caller's or d_obs): the newest
+                                    // frame of every env-step row comes from here (lz_roots_collect_rows)
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
     std::vector<int32_t> h_n_legal;  // host copy of n_legal (noise offsets without a device round trip)
     void *h_prep = nullptr;          // pinned staging of prepare_from_inference (noise | offsets | to_play), own buffer so that the

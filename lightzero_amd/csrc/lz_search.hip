@@ -270,16 +270,18 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // gets fresh pools, result blocks and observation staging for the new one
 int lz_roots_release_pools_if_stale(lz_roots *r)
 {
-    if (r->pool_slab && r->pool_model_uid == r->eng->model_uid) return LZ_OK;
-    if (!r->pool_slab && !r->d_obs && !r->d_results) { r->pool_model_uid = r->eng->model_uid; return LZ_OK; }
-    LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
-    if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
-    if (r->pool_slab) { (void)hipFree(r->pool_slab); r->pool_slab = nullptr; }
-    if (r->d_obs) { (void)hipFree(r->d_obs); r->d_obs = nullptr; r->d_obs_bytes = 0; }
-    if (r->d_results) { (void)hipFree(r->d_results); r->d_results = nullptr; }
-    if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
-    r->results_bytes = 0;
-    r->inferred = false; r->inference_fresh = false;
+    if (r->pool_model_uid == r->eng->model_uid) return LZ_OK;
+    if (r->pool_slab || r->d_obs || r->d_results) {
+        LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
+        if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
+        if (r->pool_slab) { (void)hipFree(r->pool_slab); r->pool_slab = nullptr; }
+        if (r->d_obs) { (void)hipFree(r->d_obs); r->d_obs = nullptr; }
+        if (r->d_results) { (void)hipFree(r->d_results); r->d_results = nullptr; }
+        if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
+        r->d_obs_bytes = 0;
+        r->results_bytes = 0;
+        r->inferred = false; r->inference_fresh = false;
+    }
     r->pool_model_uid = r->eng->model_uid;
     return LZ_OK;
 }
@@ -484,6 +486,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     LZ_HIP_CHECK(hipGetLastError());
     r->inferred = true;
     r->inference_fresh = true;  // no prepare has consumed it yet (lz_roots_reset_keep_inference)
+    r->last_obs = d_obs;
     return LZ_OK;
 }
 
@@ -576,6 +579,107 @@ extern "C" int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_di
 {
     return search_results(r, h_out_dist, h_out_count, h_out_values, h_pred_values, h_policy_logits, true, temperature, deterministic,
                           seed, h_action_pos, h_entropy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Env-step rows: what MuZeroCollector keeps per env and step (muzero_collector.py:557-620) in the field set of
+// GameSegment.append / store_search_stats (game_segment.py:158-182, 241-263), written by ONE kernel from device buffers --
+// the packed trajectory row of SURVEY.md 8(e)/(f4), the unit of the RCCL all-gather.  float32 words:
+//   0 action (in the full action space)   1 reward (0 here: the environment fills it after stepping)   2 root value (searched)
+//   3 predicted value   4 to_play   5 timestep   6 visit-count-distribution entropy (bits)   7 number of legal actions
+//   8 .. 8+A      child visits / sum of visits in LEGAL-LIST order, zero padded (store_search_stats, game_segment.py:247-252)
+//   8+A .. 8+2A   action mask (1 legal / 0 not)
+//   8+2A ..       the newest observation frame: the last `frame_floats` floats of the env's observation (image_channel x H x W of
+//                 the stacked [C, H, W] input; the whole vector for vector observations) -- what obs_segment holds for the step
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_pack_rows(lz_tree_dev t, const int32_t *__restrict__ dist, const int32_t *__restrict__ cnt,
+                                                   const float *__restrict__ values, const float *__restrict__ pred,
+                                                   const int32_t *__restrict__ pos, const double *__restrict__ ent,
+                                                   const int32_t *__restrict__ to_play, const int32_t *__restrict__ timestep,
+                                                   const float *__restrict__ obs, int obs_floats, int frame_floats,
+                                                   float *__restrict__ rows, int row_words)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, A = t.A;
+    float *row = rows + (size_t)b * row_words;
+    const int n = cnt[b];
+    if (tid == 0) {
+        int total = 0;
+        for (int j = 0; j < n; ++j) total += dist[(size_t)b * A + j];
+        const float sum_visits = total == 0 ? 1e-6f : (float)total;  // game_segment.py:244-246
+        row[0] = (float)t.legal[(size_t)b * A + pos[b]];
+        row[1] = 0.0f;
+        row[2] = values[b];
+        row[3] = pred[b];
+        row[4] = (float)to_play[b];
+        row[5] = timestep ? (float)timestep[b] : -1.0f;
+        row[6] = (float)ent[b];
+        row[7] = (float)n;
+        for (int j = 0; j < A; ++j) row[8 + j] = j < n ? (float)dist[(size_t)b * A + j] / sum_visits : 0.0f;
+        for (int j = 0; j < A; ++j) row[8 + A + j] = 0.0f;
+        for (int j = 0; j < n; ++j) row[8 + A + t.legal[(size_t)b * A + j]] = 1.0f;
+    }
+    if (frame_floats > 0) {
+        const float *src = obs + (size_t)b * obs_floats + (obs_floats - frame_floats);
+        float *dst = row + 8 + 2 * A;
+        for (int i = tid; i < frame_floats; i += 256) dst[i] = src[i];
+    }
+}
+}  // namespace
+
+extern "C" int lz_rows_width(int action_space_size, int frame_floats) { return 8 + 2 * action_space_size + frame_floats; }
+
+extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
+                                     int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
+                                     float *h_header, float *h_policy_logits)
+{
+    LZ_REQUIRE(r != nullptr && d_rows != nullptr && h_header != nullptr, "NULL argument");
+    LZ_REQUIRE(r->prepared && r->inferred && r->pool_slab != nullptr, "roots not searched through the fused path");
+    LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "sampled roots: use lz_roots_get_search_results + the lz_sroots_* getters");
+    LZ_REQUIRE(temperature > 0.0, "select_action needs a positive temperature");
+    const lz_tree_dev &t = r->t;
+    lz_model *m = r->eng->model;
+    const size_t B = t.B, A = t.A;
+    const size_t PA = m->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(m) : A;
+    const int obs_floats = m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
+    if (!d_obs) d_obs = r->last_obs;
+    LZ_REQUIRE(frame_floats >= 0 && frame_floats <= obs_floats && (frame_floats == 0 || d_obs != nullptr), "frame_floats exceeds the observation / no observation known");
+    LZ_REQUIRE(row_words >= (int)(8 + 2 * A) + frame_floats, "row_words too small (lz_rows_width)");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    const size_t n_i = B * A + 2 * B + B, n_f = B + B * PA, bytes = B * 8 + (n_i + n_f) * 4;  // + timestep [B]
+    if (r->results_bytes < bytes + 4096) {
+        if (r->d_results) { LZ_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(r->d_results); r->d_results = nullptr; }
+        if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
+        LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes + 4096));
+        LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes + 4096, hipHostMallocDefault));
+        r->results_bytes = bytes + 4096;
+    }
+    double *d_ent = (double *)r->d_results;
+    int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B, *d_ts = d_pos + B;
+    float *d_val = (float *)(d_ts + B), *d_lg = d_val + B;
+    lz_tree_launch_readout(t, d_dist, d_cnt, d_val, s);
+    lz_launch_select_action(t, 1.0 / temperature, deterministic, seed, d_pos, d_ent, s);
+    if (h_timestep) {
+        memcpy(r->h_results, h_timestep, B * 4);
+        LZ_HIP_CHECK(hipMemcpyAsync(d_ts, r->h_results, B * 4, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)B), dim3(256), 0, s, t, d_dist, d_cnt, d_val, r->sim_value, d_pos, d_ent,
+                       r->d_to_play, h_timestep ? d_ts : nullptr, d_obs, obs_floats, frame_floats, d_rows, row_words);
+    LZ_HIP_CHECK(hipGetLastError());
+    // the header words of every row (what the collector needs to step the environments) and the root policy logits come back
+    // in one synchronisation; the frames stay in HBM for the all-gather
+    const size_t hw = 8 + 2 * A;
+    float *hh = (float *)((char *)r->h_results + 4096);
+    LZ_HIP_CHECK(hipMemcpy2DAsync(hh, hw * 4, d_rows, (size_t)row_words * 4, hw * 4, B, hipMemcpyDeviceToHost, s));
+    if (h_policy_logits) {
+        LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
+        LZ_HIP_CHECK(hipMemcpyAsync(hh + B * hw, d_lg, B * PA * 4, hipMemcpyDeviceToHost, s));
+    }
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_header, hh, B * hw * 4);
+    if (h_policy_logits) memcpy(h_policy_logits, hh + B * hw, B * PA * 4);
+    return LZ_OK;
 }
 
 extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records)
@@ -711,9 +815,6 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     const size_t B = t.B, A = t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size;
     const int slot = sim + 1;
     const size_t lat_slot = B * HW * C;
-    // trace: the selection this simulation's network launches consume.  With the tree step fused into the chain launch the
-    // res_* arrays are written by that launch's prologue, so the copy follows it (same stream; also inside a captured graph)
-    if (r->trace_on && !step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     // ---- dynamics conv over [latent | one-hot action] + BN + latent + ReLU, dynamics residual block (-> latent pool
     // slot), prediction residual block and the three 1x1 head convs (efficientzero_model.py:527-558, common.py:1189-1203):
     // ONE launch, activations stay in LDS
@@ -738,15 +839,19 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
             ca.tstamp = g_chain_ts;
         }
 #endif
-        ProfScope ps(r->eng, s);
-        if (step && !lz_chain_fusable(ca, *step)) {  // decided by the caller with chain_takes_step(); kept as a guard
+        if (step && !lz_chain_fusable(ca, *step)) {  // the tree outgrew the LDS budget (or the shape has no fused instance)
             lz_tree_launch_backprop_traverse(step->t, step->new_node, step->discount, step->vps, step->values, step->logits,
                                              step->horizon, step->a, step->delta, step->vtp, s);
             step = nullptr;
         }
-        const bool fused_step = step != nullptr;
-        if (!dbg_skip('c')) lz_launch_chain(ca, s, step);
-        if (r->trace_on && fused_step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
+        // trace: the selection this simulation's network launches consume.  With the tree step fused into the chain launch the
+        // res_* arrays are written by that launch's prologue, so the copy follows it (same stream; also inside a captured graph)
+        if (r->trace_on && !step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
+        {
+            ProfScope ps(r->eng, s);
+            if (!dbg_skip('c')) lz_launch_chain(ca, s, step);
+        }
+        if (r->trace_on && step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     }
     // ---- value prefix LSTM (+ BN1d + ReLU), then the three head MLPs with h^-1 fused
     lz_lstm_args l{};
@@ -1117,6 +1222,15 @@ extern "C" int lz_recurrent_inference(lz_roots *r, const int32_t *h_parent_slot,
     LZ_HIP_CHECK(hipMemcpyAsync(t.res_ix, h_parent_slot, B * 4, hipMemcpyHostToDevice, s));
     if (!sampled) LZ_HIP_CHECK(hipMemcpyAsync(t.res_last_action, h_actions, B * 4, hipMemcpyHostToDevice, s));
     else LZ_HIP_CHECK(hipMemcpyAsync(t.res_last_action_f, h_actions_f, B * (size_t)t.D * 4, hipMemcpyHostToDevice, s));
+    std::vector<int32_t> disc_idx;
+    if (sampled && t.disc_A > 0) {  // discrete sampled roots: an action is the float of its index; the network encodes the index
+        disc_idx.resize(B);
+        for (size_t i = 0; i < B; ++i) {
+            disc_idx[i] = (int32_t)h_actions_f[i];
+            LZ_REQUIRE(disc_idx[i] >= 0 && disc_idx[i] < t.disc_A, "action out of range");
+        }
+        LZ_HIP_CHECK(hipMemcpyAsync(t.res_last_action, disc_idx.data(), B * 4, hipMemcpyHostToDevice, s));
+    }
     LZ_HIP_CHECK(hipMemcpyAsync(t.res_search_len, h_search_len ? h_search_len : ones.data(), B * 4, hipMemcpyHostToDevice, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));  // the sources are caller / stack memory
     recurrent(r, out_slot - 1, h_search_len ? lstm_horizon_len : 0, s);

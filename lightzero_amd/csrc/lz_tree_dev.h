@@ -257,7 +257,13 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
                 }
             }
         }
-        if (nxt == -3) nxt = uni(v.child[(size_t)node * A + action]);  // degenerate fallback (action 0 by default)
+        if (nxt == -3) {
+            // no child entered the reference's tie list (every score NaN: a node whose logits all lie below FLOAT_MIN = -1e6 has
+            // priors 0 / 0, cnode.cpp:123-137): `action` stays 0 (cnode.cpp:687-693).  The walk continues below that child
+            // with ITS visit count like any other step.
+            nxt = uni(v.child[(size_t)node * A + action]);
+            sel_visit = uni(__float_as_int(v.edge[(size_t)node * A + action].y));
+        }
         if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
         if (lane == (depth & 63)) { my_node = node; my_act = action; }
         last_action = action;

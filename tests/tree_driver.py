@@ -40,6 +40,12 @@ CASES = {
     # action spaces beyond 128: four 64-lane chunks per node in the device kernels
     "ez_wide_a150": dict(variant="ez", B=6, A=150, S=60, seed=13, legal="random"),
     "mz_wide_a200_2p": dict(variant="mz", B=5, A=200, S=80, seed=14, legal="random", to_play="random12", discount=1.0),
+    # a diverged network (random weights unrolled 40+ steps deep produce logits of 1e14 and h^-1 values of 1e4): nodes whose
+    # logits all lie below FLOAT_MIN = -1e6 get priors 0 / 0 = NaN (cnode.cpp:123-137), every score at such a node is NaN, no child
+    # enters the tie list and cselect_child returns its default action 0 (cnode.cpp:687-693); found by the exact replay gate at
+    # BASELINE configs[2] size (round 2)
+    "mz_runaway_logits": dict(variant="mz", B=24, A=4, S=120, seed=15, runaway=True),
+    "ez_runaway_logits": dict(variant="ez", B=24, A=6, S=120, seed=16, runaway=True),
     "ez_deep_chain": dict(variant="ez", B=4, A=2, S=150, seed=11, deep=True),
     "mz_deep_chain": dict(variant="mz", B=3, A=3, S=200, seed=12, deep=True),
 }
@@ -48,7 +54,7 @@ CASES = {
 def make_inputs(case):
     """Seeded synthetic 'network outputs' for every simulation of a case (all float32)."""
     c = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.997, delta=0.01, noise_w=0.25, horizon=5, legal=None,
-             to_play=None, zero=False, scale=1.0, deep=False)
+             to_play=None, zero=False, scale=1.0, deep=False, runaway=False)
     c.update(case)
     rng = np.random.default_rng(c["seed"])
     B, A, S = c["B"], c["A"], c["S"]
@@ -85,6 +91,15 @@ def make_inputs(case):
             v=(z * rng.standard_normal(B)).astype(np.float32),
             logits=(z * c["scale"] * rng.standard_normal((B, A))).astype(np.float32),
         ))
+        if c["runaway"]:
+            bad = rng.random(B) < 0.35                     # these leaves: every logit far below -1e6
+            mag = (10.0 ** rng.uniform(7, 15, size=(B, 1))).astype(np.float32)
+            lg = sims[-1]["logits"]
+            lg[bad] = (-mag * (1.0 + rng.random((B, A)).astype(np.float32)))[bad]
+            hot = rng.random(B) < 0.2                      # and some with one overwhelming action
+            lg[hot & ~bad, 0] = 1e13
+            sims[-1]["vp"] = (sims[-1]["vp"] * 2e4).astype(np.float32)
+            sims[-1]["v"] = (sims[-1]["v"] * 2e4).astype(np.float32)
         if c["deep"]:
             sims[-1]["vp"] = (0.01 * rng.random(B)).astype(np.float32)
             sims[-1]["v"] = (1.0 + 0.5 * si + 0.01 * rng.random(B)).astype(np.float32)
