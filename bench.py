@@ -4,11 +4,15 @@ observations, 50 simulations, 256 parallel envs per MI355X (BASELINE.json config
 
 A "step" is one pass of the hot path over one batch of 256 synthetic observations that are already
 resident in HBM: initial_inference -> root prepare with Dirichlet noise -> 50 x [select -> recurrent
-inference -> expand/backup] on the device -> visit-count distributions and root values on the host
-(the `_forward_collect` contract).  Weak scaling: every GPU owns its own 256 envs; the only collective
-is the all-gather of the packed trajectory rows (lightzero_amd/shard.py).
+inference -> expand/backup] on the device -> select_action + the packed env-step rows (action, search
+statistics, action mask, to_play, newest observation frame: the GameSegment field set, 36.9 KB per
+env-step) written by one kernel -> row headers on the host (the `_forward_collect` contract: what the
+collector needs to step its environments).  Weak scaling: every GPU owns its own 256 envs; the only
+collective is the all-gather of the rows (lightzero_amd/shard.py), issued asynchronously so that it
+overlaps the next step's search.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                       # re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -16,6 +20,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,12 +31,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS, SIMS, ACTIONS = 256, 50, 6
+FRAME = 96 * 96                  # image_channel = 1: the newest frame of the 4-frame stack
 FLOP_RECURRENT = 18381312        # per env per simulation
 FLOP_INITIAL = 292222912         # per env-step
 FLOP_CHAIN = 2 * 36 * 64 * (70 + 4 * 64) * 9 + 2 * 36 * 64 * 48  # dyn conv 70->64 + 4 convs 64->64 + three 1x1 64->16 = 13,741,056 per env
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
+TRAFFIC_FILE = "r02_traffic.json"
 
 
 def _reference_model(weights):
@@ -43,41 +51,90 @@ def _reference_model(weights):
     return m.eval()
 
 
-def cpu_baseline(weights, obs_cpu, noises, budget_s=25.0, device="cpu"):
-    """The reference pipeline on the host cores: reference ctree (compiled from its own sources when
-    oracle/_ref is present, else the C restatement) + restated Python driver + torch fp32 model.
-    device="cuda" is SURVEY.md 8d's second arm, the reference as deployed with cuda=True: same driver and
-    host ctree, torch model on the MI355X through stock PyTorch-ROCm (MIOpen / rocBLAS)."""
-    import torch
+def _baseline_pipeline(weights, device):
+    from oracle import build_ref, ctree as octree, search as osearch
     ref_model = _reference_model(weights)
     if device != "cpu":
         ref_model = ref_model.to(device)
-        obs_cpu = obs_cpu.to(device)
-    from oracle import build_ref, ctree as octree, search as osearch
     mods = build_ref.load("stock")
     kind_tree = "reference ctree (oracle/_ref/stock)" if mods else "C restatement of the ctree (oracle/ctree_oracle.c)"
     tree = mods[0] if mods else octree.ez_tree
     kw = {} if mods else dict(roots_kwargs=dict(action_space_size=ACTIONS, max_simulations=SIMS))
-    cores = torch.get_num_threads()
-    legal = [list(range(ACTIONS))] * ENVS
-    n, t_used = 0, 0.0
     kw["device"] = device
-    osearch.ez_forward_collect(tree, ref_model, obs_cpu[:32], legal[:32], [z for z in noises[:32]], [-1] * 32, CFG, **kw)  # warm-up
-    if device != "cpu":
-        osearch.ez_forward_collect(tree, ref_model, obs_cpu, legal, noises, [-1] * ENVS, CFG, **kw)  # MIOpen solver search at B=256
-    while t_used < budget_s * 0.5 and n < 3:
+
+    def run(obs, noises):
+        n = obs.shape[0]
         t0 = time.perf_counter()
-        osearch.ez_forward_collect(tree, ref_model, obs_cpu, legal, noises, [-1] * ENVS, CFG, **kw)
-        t_used += time.perf_counter() - t0
-        n += 1
-    if device != "cpu":
-        return dict(value=ENVS * n / t_used, unit="env-steps/s", cores=1, kind="port",
-                    sample="%d full env-step batches after warm-up; %s on 1 host thread + restated driver + torch fp32 model on "
-                           "the MI355X via stock PyTorch-ROCm (the reference with cuda=True); %.1f s" % (n, kind_tree, t_used))
-    return dict(value=ENVS * n / t_used, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d full env-step batches (256 envs x 50 sims) after a 32-env warm-up; %s + restated "
-                       "EfficientZeroMCTSCtree.search driver + torch fp32 model on %d threads; %.1f s" %
-                       (n, kind_tree, cores, t_used))
+        osearch.ez_forward_collect(tree, ref_model, obs, [list(range(ACTIONS))] * n, noises[:n], [-1] * n, CFG, **kw)
+        return time.perf_counter() - t0
+    return run, kind_tree
+
+
+def cpu_baseline(weights, obs_cpu, noises, budget_s=30.0):
+    """The reference pipeline on the host cores: reference ctree (compiled from its own sources when oracle/_ref is present,
+    else the C restatement) + restated Python driver + torch fp32 model.  METHOD: the torch thread count is swept over
+    {8, 16, 32, 64, all} on one 64-env sub-batch each (after a warm-up); the fastest setting then runs full 256-env x 50-sim
+    env-step batches until 5 are timed or the budget is spent (never fewer than 2); value = envs / median batch time."""
+    import torch
+    run, kind_tree = _baseline_pipeline(weights, "cpu")
+    allc = os.cpu_count() or torch.get_num_threads()
+    cands = sorted({c for c in (8, 16, 32, 64, allc) if c <= allc})
+    sub = obs_cpu[:64]
+    sweep = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        run(sub[:16], noises)  # warm-up at this thread count
+        sweep[c] = 64 / run(sub, noises)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times, used = [], 0.0
+    while len(times) < 5 and (used < budget_s or len(times) < 2):
+        times.append(run(obs_cpu, noises))
+        used += times[-1]
+    torch.set_num_threads(allc)
+    med = float(np.median(times))
+    return dict(value=ENVS / med, unit="env-steps/s", cores=best, kind="port",
+                thread_sweep_env_steps_per_s={str(k): round(v, 1) for k, v in sweep.items()},
+                batches=len(times), batch_s_min_median_max=[min(times), med, max(times)],
+                sample="%d full env-step batches (256 envs x 50 sims) at the best of a torch-thread sweep %s (64-env sub-batch each); "
+                       "%s + restated EfficientZeroMCTSCtree.search driver + torch fp32 model; median batch time; %.1f s" %
+                       (len(times), cands, kind_tree, used))
+
+
+def deployed_baseline(weights, obs_cpu, noises, batches=10):
+    """SURVEY.md 8d's second arm, the reference as deployed with cuda=True: same driver and host ctree, torch model on the MI355X
+    through stock PyTorch-ROCm (MIOpen / rocBLAS).  10 timed batches after two warm-ups (MIOpen solver search), min / median / max."""
+    run, kind_tree = _baseline_pipeline(weights, "cuda")
+    obs = obs_cpu.to("cuda")
+    run(obs[:32], noises)
+    run(obs, noises)
+    times = [run(obs, noises) for _ in range(batches)]
+    med = float(np.median(times))
+    return dict(value=ENVS / med, unit="env-steps/s", cores=1, kind="port", batches=batches,
+                env_steps_per_s_min_median_max=[ENVS / max(times), ENVS / med, ENVS / min(times)],
+                sample="%d full env-step batches after warm-up; %s on 1 host thread + restated driver + torch fp32 model on the "
+                       "MI355X via stock PyTorch-ROCm (the reference with cuda=True); median batch time; %.1f s" % (batches, kind_tree, sum(times)))
+
+
+def policy_surface(model, obs, steps=10):
+    """env-steps/s through EfficientZeroPolicy._forward_collect (device select_action): search + the Python glue of the policy surface"""
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    pol = EfficientZeroPolicy(dict(CFG, device_select_action=True), model)
+    mask = np.ones((ENVS, ACTIONS), np.float32)
+    for _ in range(3):
+        pol._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * ENVS)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pol._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * ENVS)
+    return ENVS * steps / (time.perf_counter() - t0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -92,17 +149,31 @@ def main():
                          "kernels of the other")
     ap.add_argument("--tiebreak", choices=["first", "random"], default="random",
                     help="random = the reference's stochastic tie rule (default, like collection); first = parity mode")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for every step's all-gather instead of overlapping it with the next search")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    # one rank per GPU over RCCL; with fewer devices than ranks (plumbing runs on a 1-GPU box) the ranks share devices and the
+    # collective goes through gloo on host copies of the rows -- reported as such, never a headline number
+    backend = "nccl" if ndev >= world else "gloo"
+    device_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
 
     from lightzero_amd import _lib as L, shard
     from lightzero_amd.model.synthetic import efficientzero_state_dict  # seeded random-init weights (no checkpoints offline)
@@ -110,16 +181,14 @@ def main():
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
     lib = L.lib()
     weights = efficientzero_state_dict(seed=0, action_space_size=ACTIONS)
+    if world > 1:  # the weight-refresh path: rank 0's state_dict reaches every rank through one broadcast, then an in-place re-ingest
+        weights = shard.broadcast_state_dict(weights, src=0)
     NS = max(1, args.streams)
     assert ENVS % NS == 0
     EPS = ENVS // NS  # envs per sub-batch
     engs, models = [], []
     for k in range(NS):
-        if k == 0:
-            e = L.default_engine(local_rank)
-        else:
-            e = L.P()
-            L.check(lib.lz_engine_create(local_rank, ctypes.byref(e)))
+        e = L.default_engine(device_index) if k == 0 else L.new_engine(device_index)
         engs.append(e)
         models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e).load_state_dict(weights))
     eng = engs[0]
@@ -138,34 +207,48 @@ def main():
         roots_l.append(r)
     to_play = L.i32([-1] * EPS)
     obs_parts = [obs[k * EPS:(k + 1) * EPS].contiguous() for k in range(NS)]
-    dist_out = np.zeros((ENVS, ACTIONS), np.int32)
-    cnt_out = np.zeros(ENVS, np.int32)
-    val_out = np.zeros(ENVS, np.float32)
-    pred_out = np.zeros(ENVS, np.float32)
-    logit_out = np.zeros((ENVS, ACTIONS), np.float32)
-    rows_dev = torch.zeros(ENVS, 4 + ACTIONS, device="cuda")
+    W = shard.row_width(ACTIONS, FRAME)
+    HW = shard.HEADER + 2 * ACTIONS
+    rows_dev = [torch.zeros(ENVS, W, device="cuda") for _ in range(2)]          # double-buffered: step i's all-gather reads one
+    gathered = [torch.zeros(world * ENVS, W, device="cuda") for _ in range(2)] if world > 1 and backend == "nccl" else None
+    header = np.zeros((ENVS, HW), np.float32)
+    logits = np.zeros((ENVS, ACTIONS), np.float32)
+    timestep = np.zeros(EPS, np.int32)
+    pending = [None, None]
 
     def step(i):
+        buf = i & 1
+        if pending[buf] is not None:  # the all-gather that still reads this row buffer (issued two steps ago)
+            pending[buf].wait()
+            pending[buf] = None
         for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
             L.check(lib.lz_initial_inference(r._h, obs_parts[k].data_ptr()))
             nz = np.ascontiguousarray(noise_steps[i][k * EPS:(k + 1) * EPS])
             L.check(lib.lz_roots_prepare_from_inference(r._h, CFG["root_noise_weight"], nz.ctypes.data, to_play))
             L.check(lib.lz_search(r._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"],
                                   CFG["lstm_horizon_len"], CFG["value_delta_max"]))
-        for k, r in enumerate(roots_l):
-            sl = slice(k * EPS, (k + 1) * EPS)
-            d = np.zeros((EPS, ACTIONS), np.int32); c = np.zeros(EPS, np.int32); v = np.zeros(EPS, np.float32)
-            p = np.zeros(EPS, np.float32); lg = np.zeros((EPS, ACTIONS), np.float32)
-            L.check(lib.lz_roots_get_search_results(r._h, d, c, v, p.ctypes.data, lg.ctypes.data))
-            dist_out[sl], cnt_out[sl], val_out[sl], pred_out[sl], logit_out[sl] = d, c, v, p, lg
-        if world > 1:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI)
-            rows = np.concatenate([np.zeros((ENVS, 1), np.float32), val_out[:, None], pred_out[:, None],
-                                   cnt_out[:, None].astype(np.float32), dist_out.astype(np.float32)], 1)
-            rows_dev.copy_(torch.from_numpy(rows))
-            shard.all_gather_rows(rows_dev)
+        for k, r in enumerate(roots_l):  # select_action + packed env-step rows: one kernel, header words back on the host
+            timestep[:] = i
+            h = np.zeros((EPS, HW), np.float32); lg = np.zeros((EPS, ACTIONS), np.float32)
+            L.check(lib.lz_roots_collect_rows(r._h, 1.0, 0, (i * 1315423911 + rank * 97 + k) & (2 ** 62 - 1), None, FRAME, timestep.ctypes.data,
+                                              rows_dev[buf][k * EPS:(k + 1) * EPS].data_ptr(), W, h, lg.ctypes.data))
+            header[k * EPS:(k + 1) * EPS], logits[k * EPS:(k + 1) * EPS] = h, lg
+        if world > 1:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI), overlapped with the next search
+            if backend == "nccl":
+                _, work = shard.all_gather_rows_equal(rows_dev[buf], out=gathered[buf], async_op=not args.sync_gather)
+                pending[buf] = work if not args.sync_gather else None
+            else:
+                shard.all_gather_rows(rows_dev[buf].cpu())
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for i in range(args.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     for e in engs:
         L.check(lib.lz_engine_synchronize(e))
@@ -174,17 +257,31 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
+    drain()
     for e in engs:
         L.check(lib.lz_engine_synchronize(e))
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [my_elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert (dist_out.sum(1) == SIMS).all(), "search did not run all simulations"
+        mine = torch.tensor([my_elapsed], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
+    # every step ran all its simulations: child visits of every row sum to 1 with 50 visits behind them
+    rows_last = rows_dev[(total - 1) & 1][:, :HW].cpu().numpy()
+    assert np.allclose(rows_last[:, shard.HEADER:shard.HEADER + ACTIONS].sum(1), 1.0, atol=1e-5), "rows carry no search statistics"
+    assert np.array_equal(rows_last, header), "host header differs from the device rows"
+    dist_chk = np.zeros((EPS, ACTIONS), np.int32); cnt_chk = np.zeros(EPS, np.int32)
+    L.check(lib.lz_roots_get_distributions(roots_l[0]._h, dist_chk, cnt_chk))
+    assert (dist_chk.sum(1) == SIMS).all(), "search did not run all simulations"
     # Roofline pass: the timed region replays the search from a captured HIP graph, which cannot carry event
     # records, so the dominant kernel is timed right after it, same process and inputs, with HIP event pairs recorded
     # on the engine stream around every k_chain launch of `prof_steps` eagerly launched steps.
@@ -192,14 +289,15 @@ def main():
     L.check(lib.lz_profile_enable(eng, SIMS * prof_steps))
     for i in range(prof_steps):
         step(args.warmup + i)
+    drain()
     n_launch = ctypes.c_int64(0)
     tot_ms = ctypes.c_double(0.0)
     L.check(lib.lz_profile_read(eng, ctypes.byref(n_launch), ctypes.byref(tot_ms)))
     L.check(lib.lz_profile_enable(eng, 0))
 
     traffic = None
-    try:  # HBM bytes per k_chain launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE), see profiles/r01_traffic.json
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+    try:  # HBM bytes per k_chain launch from the PMC passes (FETCH_SIZE / WRITE_SIZE), see profiles/
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             traffic = json.load(f)["k_chain"]["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -208,6 +306,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         avg_us = tot_ms.value / max(n_launch.value, 1) * 1e3
         achieved = (EPS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
+        knobs = sorted(k for k in os.environ if k.startswith("LZ_"))
         out = {
             "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,26 +316,36 @@ def main():
                                    "256 envs per GPU, A=6, support 601, LSTM 512; synthetic obs, seed-0 random-init weights",
                        "envs_per_gpu": ENVS, "num_simulations": SIMS, "mcts_sims_per_s": value * SIMS,
                        "tiebreak": args.tiebreak, "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
-                       "parallelism": "env-shard x%d" % world},
+                       "parallelism": "env-shard x%d" % world, "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend if world > 1 else None,
+                       "per_rank_env_steps_per_s": [ENVS * args.steps / t for t in per_rank],
+                       "row_bytes_per_env_step": W * 4, "all_gather_bytes_per_step_per_rank": (world - 1) * ENVS * W * 4 if world > 1 else 0,
+                       "all_gather_overlapped": bool(world > 1 and backend == "nccl" and not args.sync_gather),
+                       "debug_knobs": knobs},
             "roofline": {"bound": "mfma", "kernel": "k_chain (per root: [tree step of the root: expand + backup + next selection, one wave, prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation; achieved counts only the convolution FLOPs over the whole launch)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes of profiles/r01_traffic.json, not re-measured in this run)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes of profiles/%s, not re-measured in this run)" % TRAFFIC_FILE,
                          "avg_launch_us": avg_us, "launches_timed": n_launch.value,
                          "timing": "HIP event pairs on the engine stream around each launch, %d eager steps run right after the "
                                    "graph-replayed timed region" % prof_steps,
                          "algorithmic_flop_per_launch": EPS * FLOP_CHAIN},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(weights, obs_cpu, [z.tolist() for z in noise_steps[0]])
+            try:
+                out["config"]["policy_surface_env_steps_per_s"] = policy_surface(models[0], obs)
+            except Exception as e:
+                out["config"]["policy_surface_env_steps_per_s"] = repr(e)
+            noises0 = [z.tolist() for z in noise_steps[0]]
+            out["cpu_baseline"] = cpu_baseline(weights, obs_cpu, noises0)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             try:
-                out["deployed_baseline"] = cpu_baseline(weights, obs_cpu, [z.tolist() for z in noise_steps[0]], device="cuda")
-                out["config"]["speedup_vs_deployed_baseline"] = value / out["deployed_baseline"]["value"]
+                out["deployed_baseline"] = deployed_baseline(weights, obs_cpu, noises0)
+                out["config"]["speedup_vs_deployed_baseline_min_median_max"] = [value / x for x in out["deployed_baseline"]["env_steps_per_s_min_median_max"][::-1]]
             except Exception as e:  # the reported baselines never take the measured line down with them
                 out["deployed_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -647,13 +647,16 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
     LZ_REQUIRE(row_words >= (int)(8 + 2 * A) + frame_floats, "row_words too small (lz_rows_width)");
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
-    const size_t n_i = B * A + 2 * B + B, n_f = B + B * PA, bytes = B * 8 + (n_i + n_f) * 4;  // + timestep [B]
-    if (r->results_bytes < bytes + 4096) {
+    const size_t hw = 8 + 2 * A;
+    const size_t n_i = B * A + 2 * B + B, n_f = B + B * PA, dev_bytes = B * 8 + (n_i + n_f) * 4;  // + timestep [B]
+    const size_t ts_bytes = align_up(B * 4, 4096), host_bytes = ts_bytes + (B * hw + B * PA) * 4;   // pinned: timestep | headers | logits
+    const size_t bytes = dev_bytes > host_bytes ? dev_bytes : host_bytes;
+    if (r->results_bytes < bytes) {
         if (r->d_results) { LZ_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(r->d_results); r->d_results = nullptr; }
         if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
-        LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes + 4096));
-        LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes + 4096, hipHostMallocDefault));
-        r->results_bytes = bytes + 4096;
+        LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes));
+        LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
+        r->results_bytes = bytes;
     }
     double *d_ent = (double *)r->d_results;
     int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B, *d_ts = d_pos + B;
@@ -669,8 +672,7 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
     LZ_HIP_CHECK(hipGetLastError());
     // the header words of every row (what the collector needs to step the environments) and the root policy logits come back
     // in one synchronisation; the frames stay in HBM for the all-gather
-    const size_t hw = 8 + 2 * A;
-    float *hh = (float *)((char *)r->h_results + 4096);
+    float *hh = (float *)((char *)r->h_results + ts_bytes);
     LZ_HIP_CHECK(hipMemcpy2DAsync(hh, hw * 4, d_rows, (size_t)row_words * 4, hw * 4, B, hipMemcpyDeviceToHost, s));
     if (h_policy_logits) {
         LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));

@@ -109,6 +109,30 @@ def make_module(variant, has_deterministic_flag):
                 L.check(fn(self._h, flat, cnt))
             return self
 
+        def reset_mask(self, action_mask, keep_inference=False):
+            """``reset`` from the [root_num, A] action mask itself (the collector's array, muzero_collector.py:533): the legal lists
+            are never materialised as Python lists -- one np.nonzero for the whole batch instead of one per env
+            (efficientzero.py:595)."""
+            m = np.asarray(action_mask) != 0
+            if m.shape != (self.root_num, self._A) or self._h is None:
+                raise ValueError("reset_mask needs an existing device handle and a [root_num, action_space_size] mask")
+            cnt = m.sum(1).astype(np.int32)
+            if (cnt == 0).any():
+                raise ValueError("every root needs at least one legal action")
+            flat = np.ascontiguousarray(np.nonzero(m)[1].astype(np.int32))  # row-major: ascending actions per root
+            self._legal = None
+            self._n_noise = int(cnt.sum())
+            if not keep_inference:
+                self._inferred_by = None
+            fn = L.lib().lz_roots_reset_keep_inference if keep_inference else L.lib().lz_roots_reset
+            L.check(fn(self._h, flat, cnt))
+            return self
+
+        def _want_noise(self):
+            if self._legal is None:
+                return self._n_noise
+            return sum(len(l) if l else self._A for l in self._legal)
+
         def set_tiebreak(self, mode, seed=None):
             """0: first arg-max (deterministic); 1: uniform over the reference's tie list."""
             self._tiebreak = int(mode)
@@ -124,7 +148,7 @@ def make_module(variant, has_deterministic_flag):
             self._ensure(logits.shape[1])
             self._touched = True
             nz = L.f32([x for row in noises for x in row] or [0.0])
-            want = sum(len(l) if l else self._A for l in self._legal)
+            want = self._want_noise()
             if nz.size < want:
                 raise ValueError("noises must hold one value per legal action")
             L.check(L.lib().lz_roots_prepare(self._h, float(root_noise_weight), nz.ctypes.data,
@@ -148,7 +172,7 @@ def make_module(variant, has_deterministic_flag):
                 nz = np.ascontiguousarray(noises, np.float32).reshape(-1)
             else:
                 nz = np.concatenate([np.asarray(row, np.float32).reshape(-1) for row in noises]) if len(noises) else np.zeros(1, np.float32)
-            want = sum(len(l) if l else self._A for l in self._legal)
+            want = self._want_noise()
             if nz.size < want:  # the library copies sum(n_legal) floats from this pointer
                 raise ValueError("noises must hold one value per legal action (%d < %d)" % (nz.size, want))
             if len(to_play_batch) != self.root_num:
@@ -207,6 +231,22 @@ def make_module(variant, has_deterministic_flag):
             L.check(L.lib().lz_roots_get_search_results_select(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data,
                                                                float(temperature), 1 if deterministic else 0, int(seed), pos, ent.ctypes.data))
             return dist, cnt, val, pred, lg, pos, ent
+
+        def collect_rows(self, temperature, deterministic, d_rows_ptr, row_words, frame_floats, timestep=None, seed=None,
+                         policy_width=None, d_obs_ptr=None):
+            """After a fused search: select_action + the packed env-step rows (lightzero_amd/shard.py schema) written on the device
+            into ``d_rows_ptr`` ([root_num][row_words] float32 in HBM); returns (row headers [B, 8 + 2A] on the host, root policy
+            logits [B, policy_width]) -- one synchronisation (lz_roots_collect_rows)."""
+            B, A = self.root_num, self._A
+            hdr = np.zeros((B, 8 + 2 * A), np.float32)
+            lg = np.zeros((B, policy_width or A), np.float32)
+            if seed is None:
+                seed = int(np.random.randint(0, 2 ** 62))
+            ts = None if timestep is None else L.i32(timestep)
+            L.check(L.lib().lz_roots_collect_rows(self._h, float(temperature), 1 if deterministic else 0, int(seed), d_obs_ptr,
+                                                  int(frame_floats), None if ts is None else ts.ctypes.data, d_rows_ptr, int(row_words),
+                                                  hdr, lg.ctypes.data))
+            return hdr, lg
 
         def select_action(self, temperature=1, deterministic=True, seed=None):
             """select_action (lzero/policy/utils.py:637-661) for every root on the device: returns (action positions

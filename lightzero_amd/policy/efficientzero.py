@@ -183,6 +183,43 @@ class EfficientZeroPolicy(object):
             }
         return output
 
+    def forward_collect_rows(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None):
+        """The collect forward for a vectorised collector: same search as ``_forward_collect`` (engine model, device
+        tensors), but what comes back is not a dict per env: ``rows_out`` -- a float32 [B, W] tensor IN HBM (W =
+        shard.row_width(A, frame_floats)) -- receives the packed env-step rows (action, search statistics, action mask, to_play,
+        newest observation frame: the GameSegment field set) straight from the device, and the return value is the [B, 8 + 2A]
+        header block on the host: ``header[:, shard.F_ACTION]`` steps the environments, ``GameSegmentBatch.store_search_stats_rows
+        (header)`` does the per-step bookkeeping of muzero_collector.py:588-620 for all envs at once.  No per-env Python loop:
+        one np.nonzero, one Dirichlet draw, one read-back."""
+        from .. import shard
+        model = self._collect_model
+        B, A = data.shape[0], model.action_space_size
+        mask = np.asarray(action_mask)
+        roots = self._roots_cache.get(B)
+        if roots is None:
+            roots = self._roots(B, [np.nonzero(mask[j])[0].tolist() for j in range(B)])
+            model.initial_inference(data, roots, fetch=False)
+        else:
+            model.initial_inference(data, roots, fetch=False)   # launched before the host touches the mask
+            roots.reset_mask(mask, keep_inference=True)
+        counts = (mask != 0).sum(1)
+        alpha = self._mcfg["root_dirichlet_alpha"]
+        if (counts == counts[0]).all():
+            noises = np.random.dirichlet([alpha] * int(counts[0]), size=B).astype(np.float32)
+        else:  # ragged: one gamma draw for the whole batch, normalised per root (what np.random.dirichlet does per env)
+            g = np.random.gamma(alpha, size=int(counts.sum()))
+            seg = np.repeat(np.arange(B), counts)
+            noises = (g / np.bincount(seg, weights=g, minlength=B)[seg]).astype(np.float32)
+        tp = list(to_play) if len(to_play) == B else [to_play[0]] * B
+        roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, tp)
+        self._search(self._mcts_collect, roots, model, _HbmTokens(roots), tp)
+        if frame_floats is None:
+            frame_floats = rows_out.shape[1] - shard.HEADER - 2 * A
+        eps_cfg = _g(self._cfg, "eps", {}) or {}
+        header, _ = roots.collect_rows(temperature, bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False)), rows_out.data_ptr(),
+                                       rows_out.shape[1], frame_floats, timestep=timestep)
+        return header
+
     def _forward_eval(self, data, action_mask, to_play=[-1], ready_env_id=None, **kwargs):
         active_eval_env_num = data.shape[0]
         if ready_env_id is None:

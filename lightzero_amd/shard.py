@@ -1,15 +1,22 @@
-"""Multi-GPU self-play: one process per GPU, env batches sharded by contiguous blocks, no collective
-inside a search.  The only exchange step is pooling finished trajectory rows so that every rank (or
-the learner rank) can push them into its replay buffer -- one RCCL all-gather per collect interval
-(new relative to the reference, whose DDP ranks keep private buffers).
+"""Multi-GPU self-play: one process per GPU, env batches sharded by contiguous blocks, no collective inside a search.
+Two exchange steps exist, both here:
 
-Row schema (float32, one row per env-step): [action, searched_value, predicted_value, n_legal,
-visit_count[0..A-1]] -- the fields MuZeroCollector stores per step (muzero_collector.py:557-568,
-game_segment.py:241-263).
+* ``all_gather_rows``: pooling the finished env-step rows of every rank so that every rank (or the learner rank) can push them
+  into its replay buffer -- one RCCL all-gather over xGMI per collect step (new relative to the reference, whose DDP ranks keep
+  private buffers).  The row is the field set of ``GameSegment.append`` / ``store_search_stats``
+  (lzero/mcts/buffer/game_segment.py:158-182, 241-263; arrays of ``game_segment_to_array`` :265-338): action, reward, searched
+  root value, predicted value, to_play, timestep, visit entropy, child visits, action mask and the newest observation frame --
+  for BASELINE configs[1] 8 + 2*6 + 96*96 float32 = 36.9 KB per env-step.  On the device the rows are written by one kernel
+  (``lz_roots_collect_rows``, include/lz_mi355.h); ``pack_rows`` is the host twin for non-engine paths and tests.
+* ``broadcast_state_dict``: the weight refresh after a learner update (checkpoint ``model`` state_dict,
+  lzero/policy/muzero.py:1043-1047): one flat fp32 broadcast, then ``model.load_state_dict`` re-ingests in place.
 """
 import os
 
 import numpy as np
+
+HEADER = 8  # words before the per-action blocks
+F_ACTION, F_REWARD, F_ROOT_VALUE, F_PRED_VALUE, F_TO_PLAY, F_TIMESTEP, F_ENTROPY, F_N_LEGAL = range(HEADER)
 
 
 def rank_world():
@@ -23,29 +30,119 @@ def shard_range(n_envs, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_rows(output, action_space_size):
-    """policy output dict (env_id -> dict) -> float32 [n_env, 4 + A] rows, ordered by env id."""
+def row_width(action_space_size, frame_floats):
+    return HEADER + 2 * action_space_size + frame_floats
+
+
+def pack_rows(output, action_mask, to_play, action_space_size, frames=None, timestep=None):
+    """Host twin of lz_roots_collect_rows: policy output dict (env_id -> dict, efficientzero.py:636-643) + the collector's
+    per-env action mask / to_play (/ timestep) + the newest observation frame of every env -> float32 [n_env, W] rows ordered by
+    env id.  ``frames``: [n_env, ...] or None."""
     ids = sorted(output)
-    rows = np.zeros((len(ids), 4 + action_space_size), np.float32)
+    A = action_space_size
+    F = 0 if frames is None else int(np.prod(np.asarray(frames).shape[1:]))
+    rows = np.zeros((len(ids), row_width(A, F)), np.float32)
     for k, i in enumerate(ids):
         o = output[i]
-        d = o["visit_count_distributions"]
-        rows[k, 0] = o["action"]
-        rows[k, 1] = o["searched_value"]
-        rows[k, 2] = o["predicted_value"]
-        rows[k, 3] = len(d)
-        rows[k, 4:4 + len(d)] = d
+        d = np.asarray(o["visit_count_distributions"], np.float32)
+        s = np.float32(d.sum()) if d.sum() != 0 else np.float32(1e-6)  # game_segment.py:244-246
+        rows[k, F_ACTION] = o["action"]
+        rows[k, F_ROOT_VALUE] = np.asarray(o["searched_value"]).reshape(-1)[0]
+        rows[k, F_PRED_VALUE] = np.asarray(o["predicted_value"]).reshape(-1)[0]
+        rows[k, F_TO_PLAY] = to_play[k] if np.ndim(to_play) else to_play
+        rows[k, F_TIMESTEP] = -1 if timestep is None else timestep[k]
+        rows[k, F_ENTROPY] = o.get("visit_count_distribution_entropy", 0.0)
+        rows[k, F_N_LEGAL] = len(d)
+        rows[k, HEADER:HEADER + len(d)] = d / s
+        rows[k, HEADER + A:HEADER + 2 * A] = np.asarray(action_mask[k], np.float32)
+        if F:
+            rows[k, HEADER + 2 * A:] = np.asarray(frames[k], np.float32).reshape(-1)
     return rows
 
 
-def all_gather_rows(rows_t):
-    """rows_t: torch tensor [n, W] on this rank's device (cuda -> RCCL over xGMI, cpu -> gloo).
-    Returns [world * n, W].  Equal n on every rank (pad the last block if the split is uneven)."""
+def unpack_rows(rows, action_space_size, frame_shape=None):
+    """[n, W] rows (numpy) -> dict of column arrays; child visits stay in legal-list order, padded with zeros"""
+    rows = np.asarray(rows)
+    A = action_space_size
+    out = dict(action=rows[:, F_ACTION].astype(np.int64), reward=rows[:, F_REWARD].copy(), root_value=rows[:, F_ROOT_VALUE].copy(),
+               predicted_value=rows[:, F_PRED_VALUE].copy(), to_play=rows[:, F_TO_PLAY].astype(np.int64),
+               timestep=rows[:, F_TIMESTEP].astype(np.int64), entropy=rows[:, F_ENTROPY].copy(),
+               n_legal=rows[:, F_N_LEGAL].astype(np.int64), child_visits=rows[:, HEADER:HEADER + A].copy(),
+               action_mask=rows[:, HEADER + A:HEADER + 2 * A].copy())
+    if rows.shape[1] > HEADER + 2 * A:
+        fr = rows[:, HEADER + 2 * A:]
+        out["frame"] = fr.reshape((rows.shape[0],) + tuple(frame_shape)) if frame_shape is not None else fr.copy()
+    return out
+
+
+def all_gather_rows(rows_t, async_op=False):
+    """rows_t: torch tensor [n, W] on this rank's device (cuda -> RCCL over xGMI, cpu -> gloo); n may differ between ranks
+    (uneven env split: blocks are padded to the largest one for the collective and the padding is dropped again).
+    Returns [sum of n over ranks, W] in rank order.  ``async_op=True`` returns (work, finish) instead: wait on ``work``
+    (or just call ``finish()``, which waits) -- the collective of step i then overlaps the search of step i + 1 on the
+    engine's own stream."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return rows_t
-    out = torch.empty((dist.get_world_size() * rows_t.shape[0],) + tuple(rows_t.shape[1:]), dtype=rows_t.dtype,
-                      device=rows_t.device)
-    dist.all_gather_into_tensor(out, rows_t.contiguous())
+        return (None, lambda: rows_t) if async_op else rows_t
+    world = dist.get_world_size()
+    n = torch.tensor([rows_t.shape[0]], dtype=torch.int64, device=rows_t.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    send = rows_t.contiguous()
+    if send.shape[0] < nmax:
+        pad = torch.zeros((nmax - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad], 0)
+    out = torch.empty((world * nmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    work = dist.all_gather_into_tensor(out, send, async_op=async_op)
+
+    def finish():
+        if work is not None:
+            work.wait()
+        if all(c == nmax for c in counts):
+            return out
+        return torch.cat([out[r * nmax:r * nmax + counts[r]] for r in range(world)], 0)
+    return (work, finish) if async_op else finish()
+
+
+def all_gather_rows_equal(rows_t, out=None, async_op=False):
+    """The steady-state form for equal blocks (weak scaling: every GPU owns the same number of envs): no size exchange, the
+    output buffer can be pre-allocated and the work handle returned for overlap."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return rows_t, None
+    if out is None:
+        out = torch.empty((dist.get_world_size() * rows_t.shape[0],) + tuple(rows_t.shape[1:]), dtype=rows_t.dtype, device=rows_t.device)
+    work = dist.all_gather_into_tensor(out, rows_t, async_op=async_op)
+    return out, work
+
+
+def broadcast_state_dict(state_dict, src=0, device=None):
+    """Weight refresh across ranks: rank ``src`` holds the new ``state_dict`` (name -> array-like, reference names), every other
+    rank passes its current one (same names and shapes; only used as the layout).  One flat float32 broadcast (RCCL on cuda
+    tensors, gloo on cpu).  Returns name -> numpy float32 arrays, ready for ``model.load_state_dict`` (in-place re-ingest)."""
+    import torch
+    import torch.distributed as dist
+    names = sorted(k for k in state_dict if not k.endswith("num_batches_tracked"))
+
+    def arr(v):
+        return np.ascontiguousarray(v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v), dtype=np.float32)
+    shapes = [tuple(np.shape(state_dict[k])) for k in names]
+    sizes = [int(np.prod(s)) if len(s) else 1 for s in shapes]
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {k: arr(state_dict[k]) for k in names}
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        flat.copy_(torch.from_numpy(np.concatenate([arr(state_dict[k]).reshape(-1) for k in names])))
+    dist.broadcast(flat, src=src)
+    host = flat.cpu().numpy()
+    out, off = {}, 0
+    for k, s, n in zip(names, shapes, sizes):
+        out[k] = host[off:off + n].reshape(s).copy()
+        off += n
     return out

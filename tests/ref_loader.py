@@ -3,7 +3,7 @@ only) under a private package name, with tests/ref_stubs standing in for DI-engi
 
     ref = load()            # None when /root/reference is absent (the GPU box)
     ref.common, ref.efficientzero_model, ref.muzero_model, ref.muzero_model_mlp, ref.efficientzero_model_mlp,
-    ref.sampled_efficientzero_model_mlp, ref.scaling_transform
+    ref.sampled_efficientzero_model_mlp, ref.scaling_transform, ref.game_segment (lzero/mcts/buffer/game_segment.py)
 """
 import importlib
 import importlib.util
@@ -48,6 +48,10 @@ def load():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     ns.scaling_transform = mod
+    spec = importlib.util.spec_from_file_location("lzref_game_segment", os.path.join(REF, "mcts", "buffer", "game_segment.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ns.game_segment = mod
     if _cache.get("fake_transformers"):
         del sys.modules["transformers"]
     _cache["ref"] = ns

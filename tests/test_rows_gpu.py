@@ -1,0 +1,98 @@
+"""the env-step rows the device writes after a search (lz_roots_collect_rows: select_action + packing in one
+kernel) against the host packer on the policy's own output dict (lightzero_amd.shard.pack_rows, itself checked against the
+reference's GameSegment in tests/test_segment_rows_cpu.py), and the vectorised collect forward against the dict-returning one."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(num_simulations=16, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
+           lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
+
+
+def _model(A=6, seed=0):
+    from oracle import torch_models as tm
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    sd = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=seed).state_dict()
+    return EfficientZeroModel(action_space_size=A).load_state_dict(sd)
+
+
+def test_device_rows_equal_host_packer():
+    from lightzero_amd import _lib as L, shard
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    B, A, S, F = 37, 6, CFG["num_simulations"], 96 * 96
+    model = _model(A)
+    rng = np.random.default_rng(2)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(4)).cuda().contiguous()
+    mask = (rng.random((B, A)) < 0.6).astype(np.float32)
+    mask[np.arange(B), rng.integers(0, A, size=B)] = 1
+    legal = [np.nonzero(mask[i])[0].tolist() for i in range(B)]
+    to_play = rng.integers(1, 3, size=B).tolist()
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    model.initial_inference(obs, roots, fetch=False)
+    roots.prepare_from_inference_no_noise(to_play)
+    L.check(L.lib().lz_search(roots._h, S, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], CFG["lstm_horizon_len"], CFG["value_delta_max"]))
+    for deterministic, T in ((True, 1.0), (False, 0.5)):
+        seed = 12345
+        dist, cnt, val, pred, logits, pos, ent = roots.get_search_results(select=(T, deterministic, seed))
+        out = {i: dict(action=legal[i][pos[i]], visit_count_distributions=dist[i, :cnt[i]].tolist(), visit_count_distribution_entropy=ent[i],
+                       searched_value=val[i], predicted_value=pred[i]) for i in range(B)}
+        frames = obs[:, -1].reshape(B, -1).cpu().numpy()
+        want = shard.pack_rows(out, mask, to_play, A, frames=frames, timestep=list(range(B)))
+        W = shard.row_width(A, F)
+        rows = torch.full((B, W + 3), -7.0, device="cuda")  # a wider stride than needed: the tail must stay untouched
+        hdr, lg = roots.collect_rows(T, deterministic, rows.data_ptr(), W + 3, F, timestep=list(range(B)), seed=seed)
+        got = rows.cpu().numpy()
+        assert (got[:, W:] == -7.0).all()
+        assert np.array_equal(got[:, :shard.HEADER + 2 * A], hdr)
+        assert np.array_equal(lg, logits)
+        # integers, masks, frames, values: identical; entropy float64 -> float32; child visits: float32 division on both sides
+        for col in (shard.F_ACTION, shard.F_REWARD, shard.F_ROOT_VALUE, shard.F_PRED_VALUE, shard.F_TO_PLAY, shard.F_TIMESTEP, shard.F_N_LEGAL):
+            assert np.array_equal(got[:, col], want[:, col]), col
+        assert np.array_equal(got[:, shard.HEADER + A:], want[:, shard.HEADER + A:])           # mask + frame
+        assert np.array_equal(got[:, shard.HEADER:shard.HEADER + A], want[:, shard.HEADER:shard.HEADER + A])  # child visits
+        assert np.allclose(got[:, shard.F_ENTROPY], want[:, shard.F_ENTROPY], rtol=1e-6, atol=1e-7)
+        assert all(mask[i, int(got[i, shard.F_ACTION])] == 1 for i in range(B))
+
+
+def test_forward_collect_rows_matches_dict_forward_and_feeds_the_segment_batch():
+    """same search through both collect forwards (deterministic tie-break, eps-greedy arg-max selection, pinned seeds); the rows
+    path then drives GameSegmentBatch for a few steps without any per-env loop"""
+    from lightzero_amd import shard
+    from lightzero_amd.mcts.buffer.game_segment import GameSegmentBatch
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    B, A, F = 32, 6, 96 * 96
+    model = _model(A, seed=1)
+    cfg = dict(CFG, mcts_tiebreak="first", device_select_action=True, eps=dict(eps_greedy_exploration_in_collect=True))
+    pol_a, pol_b = EfficientZeroPolicy(cfg, model), EfficientZeroPolicy(cfg, model)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(6)).cuda().contiguous()
+    rng = np.random.default_rng(3)
+    mask = np.ones((B, A), np.float32)  # equal legal counts: both forwards draw the Dirichlet noise with the same np.random call
+    rows = torch.zeros(B, shard.row_width(A, F), device="cuda")
+    batch = GameSegmentBatch(B, A, 4, (1, 96, 96), frame_stack_num=4)
+    batch.reset(obs.cpu().numpy().reshape(B, 4, 1, 96, 96))
+    for t in range(3):
+        np.random.seed(100 + t)
+        out = pol_a._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B, epsilon=0.0)
+        np.random.seed(100 + t)
+        hdr = pol_b.forward_collect_rows(obs, mask, rows, temperature=1.0, to_play=[-1] * B, timestep=[t] * B)
+        assert [int(a) for a in hdr[:, shard.F_ACTION]] == [int(out[i]["action"]) for i in range(B)]
+        assert np.array_equal(hdr[:, shard.F_ROOT_VALUE], np.array([out[i]["searched_value"] for i in range(B)], np.float32))
+        for i in range(B):
+            d = np.asarray(out[i]["visit_count_distributions"], np.float32)
+            assert np.array_equal(hdr[i, shard.HEADER:shard.HEADER + len(d)], d / d.sum())
+        batch.store_search_stats_rows(hdr)
+        batch.append(rows[:, shard.HEADER + 2 * A:].cpu().numpy(), np.zeros(B, np.float32))
+    seg = batch.to_arrays(5)
+    assert seg["action_segment"].shape == (3,) and seg["obs_segment"].shape == (4 + 3, 1, 96, 96)
+    assert np.array_equal(seg["action_mask_segment"][0], mask[5])
+    # ragged masks: one gamma draw for the whole batch; every action legal, every row normalised
+    ragged = (rng.random((B, A)) < 0.5).astype(np.float32)
+    ragged[np.arange(B), rng.integers(0, A, size=B)] = 1
+    hdr = pol_b.forward_collect_rows(obs, ragged, rows, temperature=1.0, to_play=[-1] * B)
+    assert all(ragged[i, int(hdr[i, shard.F_ACTION])] == 1 for i in range(B))
+    assert np.array_equal(hdr[:, shard.HEADER + A:shard.HEADER + 2 * A], ragged)
+    assert np.allclose(hdr[:, shard.HEADER:shard.HEADER + A].sum(1), 1.0, atol=1e-6)
+    assert np.array_equal(hdr[:, shard.F_N_LEGAL], ragged.sum(1))

@@ -1,4 +1,5 @@
-"""CPU: the N>1 path -- contiguous env sharding and the trajectory-row all-gather -- with gloo, world size 2."""
+"""CPU: the N>1 path -- contiguous env sharding, the env-step-row all-gather (uneven blocks, asynchronous form) and the weight
+refresh broadcast -- with gloo, world size 2."""
 import os
 import socket
 import subprocess
@@ -15,17 +16,46 @@ sys.path.insert(0, %r)
 from lightzero_amd import shard
 dist.init_process_group("gloo")
 rank, world = shard.rank_world()
-lo, hi = shard.shard_range(10, rank, world)
-A = 6
-out = {i: dict(action=i %% A, searched_value=0.5 * i, predicted_value=-0.25 * i,
-               visit_count_distributions=[i, 1, 2][: 2 + (i %% 2)]) for i in range(lo, hi)}
-rows = torch.from_numpy(shard.pack_rows(out, A))
+# ---- uneven env split (11 envs over 2 ranks: 6 + 5): the blocks are padded for the collective and stripped again
+N, A, F = 11, 6, 12
+lo, hi = shard.shard_range(N, rank, world)
+def outputs(i):
+    return dict(action=i %% A, searched_value=0.5 * i, predicted_value=np.array([-0.25 * i], np.float32),
+                visit_count_distribution_entropy=0.125 * i, visit_count_distributions=[i, 1, 2][: 2 + (i %% 2)])
+def mask(i):
+    m = np.zeros(A, np.float32); m[: 2 + (i %% 2)] = 1
+    return m
+out = {i: outputs(i) for i in range(lo, hi)}
+frames = np.stack([np.full(F, i, np.float32) for i in range(lo, hi)])
+rows = torch.from_numpy(shard.pack_rows(out, [mask(i) for i in range(lo, hi)], [1 + i %% 2 for i in range(lo, hi)], A, frames=frames,
+                                        timestep=list(range(lo, hi))))
+assert rows.shape == (hi - lo, shard.row_width(A, F))
 allrows = shard.all_gather_rows(rows)
-assert allrows.shape == (10, 4 + A), allrows.shape
-exp_ids = list(range(10))
-assert allrows[:, 1].tolist() == [0.5 * i for i in exp_ids]
-assert allrows[:, 0].tolist() == [float(i %% A) for i in exp_ids]
-assert allrows[:, 3].tolist() == [float(2 + (i %% 2)) for i in exp_ids]
+assert allrows.shape == (N, shard.row_width(A, F)), allrows.shape
+cols = shard.unpack_rows(allrows.numpy(), A, frame_shape=(F,))
+ids = np.arange(N)
+assert cols["action"].tolist() == (ids %% A).tolist()
+assert cols["root_value"].tolist() == (0.5 * ids).tolist() and cols["predicted_value"].tolist() == (-0.25 * ids).tolist()
+assert cols["n_legal"].tolist() == (2 + ids %% 2).tolist() and cols["to_play"].tolist() == (1 + ids %% 2).tolist()
+assert cols["timestep"].tolist() == ids.tolist()
+assert (cols["frame"] == ids[:, None]).all()
+assert np.allclose(cols["child_visits"].sum(1), 1.0) and (cols["action_mask"].sum(1) == cols["n_legal"]).all()
+# the asynchronous form (collective of step i overlapped with the work of step i + 1)
+work, finish = shard.all_gather_rows(rows, async_op=True)
+assert torch.equal(finish(), allrows)
+# equal blocks, pre-allocated output
+eq = rows[:5].contiguous()
+buf, w = shard.all_gather_rows_equal(eq, async_op=True)
+w.wait()
+assert buf.shape[0] == 10 and torch.equal(buf[:5] if rank == 0 else buf[5:], eq)
+# ---- weight refresh: rank 0 holds the new state_dict, rank 1 a stale one of the same layout
+rng = np.random.default_rng(5)
+new = {"a.weight": rng.standard_normal((3, 4)).astype(np.float32), "a.bias": rng.standard_normal(3).astype(np.float32),
+       "bn.running_var": rng.random(3).astype(np.float32), "bn.num_batches_tracked": np.array(7)}
+mine = new if rank == 0 else {k: np.zeros_like(v) for k, v in new.items()}
+got = shard.broadcast_state_dict(mine, src=0)
+assert sorted(got) == ["a.bias", "a.weight", "bn.running_var"]
+assert all(np.array_equal(got[k], new[k]) and got[k].dtype == np.float32 for k in got)
 if rank == 0:
     print("OK")
 dist.destroy_process_group()
