@@ -51,7 +51,7 @@ def test_device_rows_equal_host_packer():
         # integers, masks, frames, values: identical; entropy float64 -> float32; child visits: float32 division on both sides
         for col in (shard.F_ACTION, shard.F_REWARD, shard.F_ROOT_VALUE, shard.F_PRED_VALUE, shard.F_TO_PLAY, shard.F_TIMESTEP, shard.F_N_LEGAL):
             assert np.array_equal(got[:, col], want[:, col]), col
-        assert np.array_equal(got[:, shard.HEADER + A:], want[:, shard.HEADER + A:])           # mask + frame
+        assert np.array_equal(got[:, shard.HEADER + A:W], want[:, shard.HEADER + A:])          # mask + frame
         assert np.array_equal(got[:, shard.HEADER:shard.HEADER + A], want[:, shard.HEADER:shard.HEADER + A])  # child visits
         assert np.allclose(got[:, shard.F_ENTROPY], want[:, shard.F_ENTROPY], rtol=1e-6, atol=1e-7)
         assert all(mask[i, int(got[i, shard.F_ACTION])] == 1 for i in range(B))
