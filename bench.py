@@ -73,22 +73,23 @@ def _baseline_pipeline(weights, device):
 def cpu_baseline(weights, obs_cpu, noises, budget_s=30.0):
     """The reference pipeline on the host cores: reference ctree (compiled from its own sources when oracle/_ref is present,
     else the C restatement) + restated Python driver + torch fp32 model.  METHOD: the torch thread count is swept over
-    {8, 16, 32, 64, all hardware threads} on one 64-env sub-batch each after a 16-env warm-up (a setting whose warm-up is already
+    {8, 16, 32, 64, all hardware threads up to 128} on one 64-env sub-batch each after a 4-env warm-up (a setting whose warm-up is already
     3x slower than the best one so far is recorded as such and skipped: with one thread per hardware thread the tiny 6x6
     convolutions of this model run ~1000x slower than at 16 threads); the fastest setting then runs full 256-env x 50-sim
     env-step batches until 5 are timed or the budget is spent (never fewer than 2); value = envs / median batch time."""
     import torch
     run, kind_tree = _baseline_pipeline(weights, "cpu")
     allc = os.cpu_count() or torch.get_num_threads()
-    cands = sorted({c for c in (8, 16, 32, 64, allc) if c <= allc})
+    # capped at 128: one torch thread per hardware thread of the 256-thread GPU box was measured once at 0.1 env-steps/s
+    # (gpurun_out/r2d/bench.json, round 2) -- ten minutes for a single 64-env batch
+    cands = sorted({c for c in (8, 16, 32, 64, min(allc, 128)) if c <= allc})
     sub = obs_cpu[:64]
     sweep, best_warm = {}, None
     for c in cands:
         torch.set_num_threads(c)
-        run(sub[:4], noises)
-        warm = run(sub[:16], noises)  # warm-up at this thread count
+        warm = run(sub[:4], noises)   # also the warm-up at this thread count
         if best_warm is not None and warm > 3.0 * best_warm:
-            sweep[c] = 16 / warm  # hopeless: not worth a 64-env batch
+            sweep[c] = 4 / warm  # hopeless: not worth a 64-env batch
             continue
         best_warm = warm if best_warm is None else min(best_warm, warm)
         sweep[c] = 64 / run(sub, noises)
