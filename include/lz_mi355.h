@@ -215,10 +215,11 @@ typedef struct lz_model_cfg {
                                actions (sampled_efficientzero_model_mlp.py) */
     int obs_c, obs_h, obs_w;/* observation_shape, e.g. 4, 96, 96; MLP models: obs_c = vector length, obs_h = obs_w = 1 */
     int action_space_size;
-    int num_channels;       /* 64; MLP models: latent_state_dim */
+    int num_channels;       /* 64 (Atari, Go, Connect4), 32 (gomoku) or 16 (tictactoe) -- the narrow ones without downsample only;
+                               MLP models: latent_state_dim */
     int lstm_hidden_size;   /* 512 (EfficientZero) */
     int head_channels;      /* reward/value/policy head channels (16) */
-    int head_hidden;        /* hidden width of the head MLPs (32) */
+    int head_hidden;        /* hidden width of the head MLPs: 32, or less (tictactoe: 8) */
     int support_size;       /* 601 */
     float support_min;      /* -300 */
     float bn_eps;           /* 1e-5 */
@@ -232,6 +233,8 @@ typedef struct lz_model_cfg {
     int sigma_type;         /* 0 conditioned */
     int bound_type;         /* 0 None, 1 tanh on mu */
     float ln_eps;           /* 1e-5 */
+    /* ---- convolutional models */
+    int num_res_blocks;     /* residual blocks of the representation / dynamics / prediction networks: 1 (0 means 1), 2 or 3 */
 } lz_model_cfg;
 
 /* One model per engine (creating another replaces it: roots of the old one re-size their pools on the next inference).

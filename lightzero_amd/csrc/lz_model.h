@@ -42,15 +42,16 @@ struct lz_model {
     ConvW rin;    // no-downsample input conv (weights [9][C][64] in rin.w)
     // representation
     float *first_w = nullptr, *first_s = nullptr, *first_t = nullptr;
-    ConvW r1a, r1b, dn1, dn2, dn3, r2a, r2b, r3a, r3b, rpa, rpb;
+    ConvW r1a, r1b, dn1, dn2, dn3, r2a, r2b, r3a, r3b;
+    // num_res_blocks residual blocks each (two convolutions per block: [2 i] = conv1, [2 i + 1] = conv2)
+    std::vector<ConvW> rep_res, dyn_res, pred_res;
     // dynamics
-    ConvW dyn, dra, drb;
+    ConvW dyn;
     float *act_table = nullptr;
     C1W rew_c;
     float *lstm_w = nullptr, *lstm_wf = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
     MlpW fc_reward;
     // prediction
-    ConvW pa, pb;
     C1W val_c, pol_c;
     MlpW fc_value, fc_policy;
     // workspaces for initial inference
@@ -165,8 +166,12 @@ struct Builder {
     }
     // Linear - BN1d - ReLU - Linear; conv_flat: K1 = HC*HW in the reference's (channel, pixel) order ->
     // permute the columns to this engine's (pixel, channel) order
+    // The head kernel is compiled for 32 hidden units; a narrower head (tictactoe: [8]) is padded with units whose weights,
+    // bias and BatchNorm shift are zero: they output relu(0) = 0 and add exact zeros in the second layer, so the real units'
+    // sums keep their order and their bits.
     MlpW mlp(const std::string &prefix, int K1, int HID, int NOUT, bool conv_flat, int HC, int HW)
     {
+        constexpr int HP = 32;
         MlpW o;
         o.K1 = K1;
         o.NOUT = NOUT;
@@ -175,17 +180,22 @@ struct Builder {
         std::vector<float> sc, sh;
         bn(prefix + ".1", HID, sc, sh);
         if (!w1 || !b1 || !w2 || !b2) return o;
-        std::vector<float> w1p(w1->data);
+        if (HID > HP) { if (err.empty()) err = "head hidden width above 32"; return o; }
+        std::vector<float> w1p((size_t)HP * K1, 0.0f), b1p(HP, 0.0f), scp(HP, 1.0f), shp(HP, 0.0f);
+        for (int u = 0; u < HID; ++u) {
+            b1p[u] = b1->data[u]; scp[u] = sc[u]; shp[u] = sh[u];
+            for (int k = 0; k < K1; ++k) w1p[(size_t)u * K1 + k] = w1->data[(size_t)u * K1 + k];
+        }
         if (conv_flat) {
             for (int u = 0; u < HID; ++u)
                 for (int p = 0; p < HW; ++p)
                     for (int c = 0; c < HC; ++c) w1p[(size_t)u * K1 + p * HC + c] = w1->data[(size_t)u * K1 + c * HW + p];
         }
         o.w1 = upload(w1p);
-        o.b1 = upload(b1->data);
-        o.s1 = upload(sc);
-        o.t1 = upload(sh);
-        std::vector<float> w2t((size_t)HID * NOUT);
+        o.b1 = upload(b1p);
+        o.s1 = upload(scp);
+        o.t1 = upload(shp);
+        std::vector<float> w2t((size_t)HP * NOUT, 0.0f);
         for (int n = 0; n < NOUT; ++n)
             for (int k = 0; k < HID; ++k) w2t[(size_t)k * NOUT + n] = w2->data[(size_t)n * HID + k];
         o.w2 = upload(w2t);

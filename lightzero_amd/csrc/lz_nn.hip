@@ -383,15 +383,18 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ ob
 
 // first layer of a no-downsample RepresentationNetwork (board games, common.py:735-741,768-771): conv3x3 stride 1 from
 // NCHW observations [B][C][H][W] to NHWC [B][H*W][64], + BN + ReLU.  thread = (pixel, 8 output channels).
+// COUT = 64 | 32 | 16 output channels: COUT / 8 threads per pixel
+template <int COUT>
 __global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ obs, const float *__restrict__ w,
                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                  float *__restrict__ out, int B, int C, int H, int W)
 {
-    extern __shared__ float sw[];  // [9][C][64]
-    for (int i = threadIdx.x; i < 9 * C * 64; i += 256) sw[i] = w[i];
+    constexpr int TPP = COUT / 8, PPB = 256 / TPP;  // threads per pixel, pixels per block
+    extern __shared__ float sw[];  // [9][C][COUT]
+    for (int i = threadIdx.x; i < 9 * C * COUT; i += 256) sw[i] = w[i];
     __syncthreads();
-    const int g = threadIdx.x & 7;
-    const int64_t m = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int g = threadIdx.x % TPP;
+    const int64_t m = (int64_t)blockIdx.x * PPB + (threadIdx.x / TPP);
     if (m >= (int64_t)B * H * W) return;
     const int b = (int)(m / (H * W)), p = (int)(m - (int64_t)b * H * W), y = p / W, x = p - y * W;
     float acc[8];
@@ -402,12 +405,12 @@ __global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ obs, 
         if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
         for (int ci = 0; ci < C; ++ci) {
             const float xv = obs[(((size_t)b * C + ci) * H + iy) * W + ix];
-            const float *wr = sw + (t * C + ci) * 64 + g * 8;
+            const float *wr = sw + (t * C + ci) * COUT + g * 8;
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] += xv * wr[c];
         }
     }
-    float *o = out + (size_t)m * 64 + g * 8;
+    float *o = out + (size_t)m * COUT + g * 8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) o[c] = fmaxf(acc[c] * scale[g * 8 + c] + shift[g * 8 + c], 0.0f);
 }
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_ar
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS;  // HW pixels + one all-zero pixel
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats, then the
     float *sTab = smem + 4 * BUF;          // [HW][PS] one-hot-action table slice of this root's action
-    float *sSS = sTab + HW * PS;           // [6 layers][2][64] folded-BN scale / shift: the epilogues read LDS only,
+    float *sSS = sTab + HW * PS;           // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift: the epilogues read LDS only,
                                            // a global load there would make the compiler drain the weight ring (vmcnt(0))
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_ar
     }
     int g_slot = 0, g_action = 0;
     if constexpr (TREE != 0) {
-        int32_t *s_sel = reinterpret_cast<int32_t *>(sSS + 6 * 128 + (TS ? 64 : 0));
+        int32_t *s_sel = reinterpret_cast<int32_t *>(sSS + LZ_CHAIN_MAX_LAYERS * 128 + (TS ? 64 : 0));
         if (wv == 0)
             dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
                                       step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel);
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_ar
     }
     const int kq4 = (lane >> 4) * 4;
     // TS instantiation only (debugging): s_memtime stamps of workgroup 0 / thread 0 into LDS, copied out at the end
-    unsigned long long *sTS = reinterpret_cast<unsigned long long *>(sSS + 6 * 128);
+    unsigned long long *sTS = reinterpret_cast<unsigned long long *>(sSS + LZ_CHAIN_MAX_LAYERS * 128);
     int nts = 0;
 #define LZ_TS() do { if constexpr (TS) { if (b == 0 && tid == 0) sTS[nts++] = __builtin_readcyclecounter(); } } while (0)
     LZ_TS();
@@ -759,6 +762,143 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_ar
         }
     }
 #undef LZ_TS
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same chain for narrow networks (num_channels = 32 | 16: the reference's gomoku / tictactoe configs,
+// zoo/board_games/gomoku/config/gomoku_muzero_bot_mode_config.py:41-42, tictactoe/...:33-34).  One workgroup per root, activations in
+// LDS across layers; C / 16 output-channel tiles, so the four waves split as (N-tile, M-group): with 32 channels two waves share
+// the pixel tiles of each channel half, with 16 channels all four split the pixels.  K = 9 taps x C / 16 steps (18 | 9): the
+// whole layer's weight fragments sit in registers and the next layer's are requested before this layer's first MFMA.  Small
+// boards, small batches: written for correctness and a short launch, not tuned like k_chain; the tree step keeps its own launch.
+// ------------------------------------------------------------------------------------------------
+template <int GW, int GH, int C>
+__global__ __launch_bounds__(256) void k_chain_small(lz_chain_args a)
+{
+    constexpr int PS = C + 4, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS;
+    constexpr int NT = C / 16, MG = 4 / NT, G = C / 16, STEPS = 9 * G, MTW = (MT + MG - 1) / MG, C4 = C / 4;
+    static_assert(C == 16 || C == 32, "narrow chain: 16 or 32 channels");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers, the action-table slice, scale / shift
+    float *sTab = smem + 4 * BUF;
+    float *sSS = sTab + HW * PS;   // [LZ_CHAIN_MAX_LAYERS][2][C]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    const int nt = wv % NT, mg = wv / NT;
+    f32x4 wcur[STEPS], wnxt[STEPS];
+    {
+        const f32x4 *w0 = reinterpret_cast<const f32x4 *>(a.layer[0].wf) + (size_t)nt * STEPS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) wcur[s] = w0[s * 64];
+    }
+    const int g_slot = a.gather_ix ? a.gather_ix[b] : 0, g_action = a.act_table ? a.action[b] : 0;
+    {
+        const float *src = a.in + (size_t)b * HW * C + (size_t)g_slot * a.slot_stride;
+        for (int idx = tid; idx < HW * C4; idx += 256)
+            *reinterpret_cast<float4 *>(smem + (idx / C4) * PS + (idx % C4) * 4) = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
+        if (tid < 4 * C4) *reinterpret_cast<float4 *>(smem + (tid / C4) * BUF + HW * PS + (tid % C4) * 4) = vzero4();  // the all-zero pixel of every buffer
+        if (a.act_table) {
+            const float *tsrc = a.act_table + (size_t)g_action * HW * C;
+            for (int idx = tid; idx < HW * C4; idx += 256)
+                *reinterpret_cast<float4 *>(sTab + (idx / C4) * PS + (idx % C4) * 4) = *reinterpret_cast<const float4 *>(tsrc + (size_t)idx * 4);
+        }
+        for (int i = tid; i < a.nlayers * 2 * C; i += 256) {
+            const int L = i / (2 * C), r = i % (2 * C);
+            sSS[i] = (r < C) ? a.layer[L].scale[r] : a.layer[L].shift[r - C];
+        }
+    }
+    // this wave's M-tiles: mg, mg + MG, ...; geometry of this lane's row in each
+    const int zoff = HW * PS;
+    int base[MTW], mask[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int row = (mg + j * MG) * 16 + (lane & 15);
+        const int p = min(row, HW - 1), y = p / GW, x = p - y * GW;
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            mk |= ((iy >= 0) & (iy < GH) & (ix >= 0) & (ix < GW) & (row < HW)) << t;
+        }
+        int bs = p * PS;
+        asm volatile("" : "+v"(mk), "+v"(bs));
+        base[j] = bs;
+        mask[j] = mk;
+    }
+    const int kq4 = (lane >> 4) * 4;
+    __syncthreads();
+    for (int L = 0; L < a.nlayers; ++L) {
+        const lz_chain_layer &ly = a.layer[L];
+        const float *sIn = smem + ly.in * BUF + kq4;
+        float *sOut = smem + ly.out * BUF;
+        {   // the next layer's fragments travel while this layer computes
+            const f32x4 *wn = reinterpret_cast<const f32x4 *>(a.layer[min(L + 1, a.nlayers - 1)].wf) + (size_t)nt * STEPS * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) wnxt[s] = wn[s * 64];
+        }
+        f32x4 acc[MTW];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int t = s / G, g = s % G;
+            const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PS;
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) {
+                const int bit = (mask[j] >> t) & 1;
+                const int off = zoff + bit * (base[j] + toff - zoff);
+                const float4 af = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af, q), wcur[s][q], acc[j], 0, 0, 0);
+            }
+        }
+        const int col = nt * 16 + (lane & 15);
+        const float sc = sSS[L * 2 * C + col], sh = sSS[L * 2 * C + C + col];
+        const float *sRes = smem + max(ly.res, 0) * BUF;
+#pragma unroll
+        for (int j = 0; j < MTW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (mg + j * MG) * 16 + 4 * (lane >> 4) + q;
+                if (row < HW) {
+                    float v = acc[j][q];
+                    if (ly.act) v += sTab[row * PS + col];
+                    v = v * sc + sh;
+                    if (ly.res >= 0) v += sRes[row * PS + col];
+                    if (ly.relu) v = fmaxf(v, 0.0f);
+                    sOut[row * PS + col] = v;
+                    if (ly.gout) ly.gout[((size_t)b * HW + row) * C + col] = v;
+                }
+            }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) wcur[s] = wnxt[s];
+        __syncthreads();
+    }
+    // 1x1 head convolutions (C -> 16) + bias + BN + ReLU: wave j runs job j over every pixel tile
+    if (wv < a.nc1) {
+        const lz_c1_job &jb = a.c1[wv];
+        const float *sIn = smem + a.c1_in[wv] * BUF + kq4;
+        const int col = lane & 15;
+        const float bi = jb.bias[col], sc = jb.scale[col], sh = jb.shift[col];
+        float4 cw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) cw[g] = *reinterpret_cast<const float4 *>(jb.w + (size_t)col * C + g * 16 + kq4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int r16 = i * 16 + (lane & 15);
+            const int off = (r16 < HW) ? r16 * PS : zoff;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float4 af = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af, q), vget(cw[g], q), acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = i * 16 + 4 * (lane >> 4) + q;
+                if (row < HW) jb.out[((size_t)b * HW + row) * jb.out_stride + jb.out_off + col] = fmaxf((acc[q] + bi) * sc + sh, 0.0f);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1304,10 +1444,15 @@ void lz_launch_conv_first(const float *obs, const float *w, const float *scale, 
 }
 
 void lz_launch_conv_in(const float *obs, const float *w, const float *scale, const float *shift, float *out, int B, int C,
-                       int H, int W, hipStream_t s)
+                       int H, int W, int Cout, hipStream_t s)
 {
     const int64_t M = (int64_t)B * H * W;
-    hipLaunchKernelGGL(k_conv_in, dim3((unsigned)((M + 31) / 32)), dim3(256), (size_t)9 * C * 64 * 4, s, obs, w, scale, shift, out, B, C, H, W);
+    const int ppb = 256 / (Cout / 8);
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb));
+    const size_t lds = (size_t)9 * C * Cout * 4;
+    if (Cout == 64) hipLaunchKernelGGL(k_conv_in<64>, grid, dim3(256), lds, s, obs, w, scale, shift, out, B, C, H, W);
+    else if (Cout == 32) hipLaunchKernelGGL(k_conv_in<32>, grid, dim3(256), lds, s, obs, w, scale, shift, out, B, C, H, W);
+    else if (Cout == 16) hipLaunchKernelGGL(k_conv_in<16>, grid, dim3(256), lds, s, obs, w, scale, shift, out, B, C, H, W);
 }
 
 void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s)
@@ -1326,6 +1471,7 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 // per action covers the node, and a gather / action table is what the chain would have read anyway
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
 {
+    if (a.C != 0 && a.C != 64) return false;  // the narrow chain has no fused instance
     if (!((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) || a.tstamp || !a.gather_ix || !a.act_table) return false;
     if (step.t.A > 64 || step.t.B != a.B) return false;
     if (step.t.variant != LZ_TREE_EFFICIENTZERO && step.t.variant != LZ_TREE_MUZERO) return false;
@@ -1335,9 +1481,30 @@ bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
     return lz_tree_lds_bytes(step.t, step.new_node) <= (lim < room ? lim : room);
 }
 
+template <int GW, int GH, int C>
+static void launch_chain_small(const lz_chain_args &a, hipStream_t s)
+{
+    constexpr int HW = GW * GH, PS = C + 4;
+    const size_t lds = (size_t)(4 * (HW + 1) * PS + HW * PS + LZ_CHAIN_MAX_LAYERS * 2 * C) * 4;
+    hipLaunchKernelGGL((k_chain_small<GW, GH, C>), dim3(a.B), dim3(256), lds, s, a);
+}
+
+// grids / widths with a narrow-chain instance (board games: tictactoe 3x3, gomoku 6x6, connect4 6x7, Go 9x9)
+bool lz_chain_small_supported(int gw, int gh, int C)
+{
+    if (C != 16 && C != 32) return false;
+    return (gw == 3 && gh == 3) || (gw == 6 && gh == 6) || (gw == 7 && gh == 6) || (gw == 9 && gh == 9);
+}
+
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step)
 {
-    auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + 6 * 128 + extra) * 4; };
+    if (a.C == 16 || a.C == 32) {  // narrow networks: k_chain_small, never tree-fused
+#define LZ_SMALL(GWv, GHv) if (a.gw == GWv && a.gh == GHv) { if (a.C == 32) launch_chain_small<GWv, GHv, 32>(a, s); else launch_chain_small<GWv, GHv, 16>(a, s); return; }
+        LZ_SMALL(3, 3) LZ_SMALL(6, 6) LZ_SMALL(7, 6) LZ_SMALL(9, 9)
+#undef LZ_SMALL
+        return;
+    }
+    auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + extra) * 4; };
     if (step) {
         const bool ez = step->t.variant == LZ_TREE_EFFICIENTZERO;
         if (a.gw == 8) {
@@ -1351,9 +1518,9 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
     }
     if (a.gw == 8 && a.gh == 8) { hipLaunchKernelGGL((k_chain<8, 8>), dim3(a.B), dim3(256), lds_of(64, 0), s, a, no_step{}); return; }
     if (a.gw == 7 && a.gh == 6) { hipLaunchKernelGGL((k_chain<7, 6>), dim3(a.B), dim3(256), lds_of(42, 0), s, a, no_step{}); return; }
-    if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128 + 64) * 4, s, a, no_step{});
-    else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), (size_t)(4 * 37 * 68 + 36 * 68 + 6 * 128) * 4, s, a, no_step{});
-    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), (size_t)(4 * 82 * 68 + 81 * 68 + 6 * 128) * 4, s, a, no_step{});
+    if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), lds_of(36, 64), s, a, no_step{});
+    else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), lds_of(36, 0), s, a, no_step{});
+    else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), lds_of(81, 0), s, a, no_step{});
 }
 
 template <int MROWS>

@@ -32,8 +32,8 @@ void lz_launch_conv_first(const float *obs_nchw, const float *w /*[9][C][Cout]*/
                           const float *shift, float *out, int B, int C, int H, int W, int Cout, hipStream_t s);
 
 // first layer of a no-downsample representation network: conv3x3 stride 1 from NCHW obs to NHWC [B][H*W][64] + BN + ReLU
-void lz_launch_conv_in(const float *obs_nchw, const float *w /*[9][C][64]*/, const float *scale, const float *shift,
-                       float *out, int B, int C, int H, int W, hipStream_t s);
+void lz_launch_conv_in(const float *obs_nchw, const float *w /*[9][C][Cout]*/, const float *scale, const float *shift,
+                       float *out, int B, int C, int H, int W, int Cout, hipStream_t s);
 
 // AvgPool2d(kernel 3, stride 2, pad 1, count_include_pad) on NHWC
 void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s);
@@ -64,14 +64,16 @@ struct lz_chain_layer {
     int relu, act;         // act: add the one-hot-action table before BN (dynamics conv)
     float *gout;           // optional global NHWC [B][36][64] copy of the output (latent pool slot)
 };
+#define LZ_CHAIN_MAX_LAYERS 14   // dynamics conv + 2 k convs of the dynamics blocks + 2 k of the prediction blocks, num_res_blocks k <= 3
 struct lz_chain_args {
     const float *in;             // NHWC [B][36][64], or a pool base when gather_ix != null
     const int32_t *gather_ix;    // optional [B] pool slot per root
     int64_t slot_stride;
     const float *act_table;      // [A][36][64]
     const int32_t *action;       // [B]
-    lz_chain_layer layer[6];
+    lz_chain_layer layer[LZ_CHAIN_MAX_LAYERS];
     int nlayers;
+    int C;                       // channels of every layer: 64 (k_chain, the tuned kernel), 32 or 16 (k_chain_small: board-game configs)
     lz_c1_job c1[3];             // 1x1 head convolutions on LDS buffers c1_in[j]; .in is ignored
     int c1_in[3];
     int nc1;
@@ -84,6 +86,7 @@ struct lz_chain_args {
 // (which the step still writes for the kernels that follow).  Requires lz_chain_fusable(step).
 struct lz_tree_step;
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step);
+bool lz_chain_small_supported(int gw, int gh, int C);
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step = nullptr);
 
 // one LSTM step (nn.LSTM, 1 layer) fused with BatchNorm1d + ReLU of the output:

@@ -70,7 +70,13 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
         e->model->GW = e->model->GH = e->model->HWl = 1;
         return LZ_OK;
     }
-    LZ_REQUIRE(cfg->num_channels == 64, "num_channels must be 64");
+    LZ_REQUIRE(cfg->num_channels == 64 || cfg->num_channels == 32 || cfg->num_channels == 16, "num_channels must be 64, 32 or 16");
+    LZ_REQUIRE(cfg->num_res_blocks >= 0 && cfg->num_res_blocks <= 3, "num_res_blocks must be 1, 2 or 3");
+    if (cfg->num_channels != 64) {
+        // the narrow chain (k_chain_small): the reference's small board-game models (gomoku 32 channels, tictactoe 16)
+        LZ_REQUIRE(!cfg->downsample && cfg->model_type == 1, "num_channels 32 / 16: MuZeroModel without downsample (board games)");
+        LZ_REQUIRE(lz_chain_small_supported(cfg->obs_w, cfg->obs_h, cfg->num_channels), "no narrow-chain instance for this board: 3x3, 6x6, 6x7, 9x9");
+    }
     if (cfg->downsample) {
         // the two sizes the reference models define a latent size for (efficientzero_model.py:121-124): 96x96 ends on a 6x6
         // latent; 64x64 (the shipped Atari configs, zoo/atari/config/atari_efficientzero_config.py:29) skips DownSample's
@@ -79,11 +85,12 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
                    "observation must be 96x96 or 64x64 on the downsample path (efficientzero_model.py:121-124)");
         LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
     } else {
-        LZ_REQUIRE((cfg->obs_h == 9 && cfg->obs_w == 9) || (cfg->obs_h == 6 && cfg->obs_w == 7),
-                   "without downsample the compiled latent grids are 9x9 (Go) and 6x7 (Connect4, zoo/board_games/connect4/config)");
+        LZ_REQUIRE((cfg->obs_h == 9 && cfg->obs_w == 9) || (cfg->obs_h == 6 && cfg->obs_w == 7) || (cfg->obs_h == 6 && cfg->obs_w == 6) ||
+                       (cfg->obs_h == 3 && cfg->obs_w == 3 && cfg->num_channels != 64),
+                   "without downsample the compiled latent grids are 9x9 (Go), 6x7 (Connect4), 6x6 (gomoku) and, for the narrow models, 3x3 (tictactoe)");
         LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_c <= 64, "obs_c must be in [1, 64]");
     }
-    LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden == 32, "head_channels must be 16 and head_hidden 32");
+    LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden >= 1 && cfg->head_hidden <= 32, "head_channels must be 16 and head_hidden at most 32");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
     if (cfg->model_type == 0) {  // the value-prefix LSTM reads [16 channels x latent pixels | hidden]: compiled K shapes
@@ -139,7 +146,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
     if (m->cfg.model_type >= 2) return lz_mlp_finalize(e);
     const lz_model_cfg &c = m->cfg;
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
-              H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size;
+              H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size, NRB = c.num_res_blocks > 0 ? c.num_res_blocks : 1;
     Builder b{m, ""};
     // ---- representation (common.py:266-365, :706-787)
     {
@@ -181,8 +188,12 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->r3a = b.resconv(d + "resblocks3.0", 1, C, C);
         m->r3b = b.resconv(d + "resblocks3.0", 2, C, C);
         }
-        m->rpa = b.resconv("representation_network.resblocks.0", 1, C, C);
-        m->rpb = b.resconv("representation_network.resblocks.0", 2, C, C);
+        m->rep_res.clear();
+        for (int i = 0; i < NRB; ++i) {
+            const std::string p = "representation_network.resblocks." + std::to_string(i);
+            m->rep_res.push_back(b.resconv(p, 1, C, C));
+            m->rep_res.push_back(b.resconv(p, 2, C, C));
+        }
     }
     // ---- dynamics (efficientzero_model.py:427-569)
     {
@@ -207,8 +218,11 @@ extern "C" int lz_model_finalize(lz_engine *e)
                         }
             m->act_table = b.upload(tab);
         }
-        m->dra = b.resconv(d + "resblocks.0", 1, C, C);
-        m->drb = b.resconv(d + "resblocks.0", 2, C, C);
+        m->dyn_res.clear();
+        for (int i = 0; i < NRB; ++i) {
+            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C));
+            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C));
+        }
         m->rew_c = b.conv1x1(d + "conv1x1_reward", d + "norm_reward", HC, C);
         if (c.model_type == 1) {
             // MuZero DynamicsNetwork (muzero_model.py:505-538): reward = MLP(flatten(relu(bn(conv1x1(next latent)))))
@@ -247,8 +261,11 @@ extern "C" int lz_model_finalize(lz_engine *e)
     // ---- prediction (common.py:1081-1216)
     {
         const std::string d = "prediction_network.";
-        m->pa = b.resconv(d + "resblocks.0", 1, C, C);
-        m->pb = b.resconv(d + "resblocks.0", 2, C, C);
+        m->pred_res.clear();
+        for (int i = 0; i < NRB; ++i) {
+            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C));
+            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C));
+        }
         m->val_c = b.conv1x1(d + "conv1x1_value", d + "norm_value", HC, C);
         m->pol_c = b.conv1x1(d + "conv1x1_policy", d + "norm_policy", HC, C);
         m->fc_value = b.mlp(d + "fc_value", HC * HW, HID, SUP, true, HC, HW);
@@ -346,6 +363,22 @@ static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu
     return l;
 }
 
+// appends the 2 k convolutions of k residual blocks (ding ResBlock 'basic': conv-bn-relu, conv-bn, + input, relu) to a chain.  x = LDS
+// buffer of the input, keep = a buffer that must survive the blocks (-1: none), gout_last = optional HBM copy of the last block's
+// output.  Returns the buffer that holds the output.
+static int chain_blocks(lz_chain_args &ca, const std::vector<ConvW> &blocks, int x, int keep, float *gout_last)
+{
+    const int k = (int)blocks.size() / 2;
+    for (int i = 0; i < k; ++i) {
+        int f[2], n = 0;
+        for (int b = 0; b < 4 && n < 2; ++b) if (b != x && b != keep) f[n++] = b;
+        ca.layer[ca.nlayers++] = chlayer(blocks[2 * i], x, f[0], -1, 1, 0, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(blocks[2 * i + 1], f[0], f[1], x, 1, 0, i == k - 1 ? gout_last : nullptr);
+        x = f[1];
+    }
+    return x;
+}
+
 static lz_c1_job c1job(const C1W &w, const float *in, float *out, int stride, int off)
 {
     lz_c1_job j{};
@@ -380,7 +413,7 @@ static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_v
         if (c.model_type == 1) h[n++] = headdesc(m->fc_reward, r->t_rx, HW * HC, HC, 1, c.support_min, dbg_vp_logits, out_vp);
         else h[n++] = headdesc(m->fc_reward, r->t_hbn, c.lstm_hidden_size, 16, 1, c.support_min, dbg_vp_logits, out_vp);
     }
-    lz_launch_heads(h, n, B, c.head_hidden, s);
+    lz_launch_heads(h, n, B, 32, s);  // Builder::mlp pads narrower heads to the compiled 32 hidden units
 }
 
 // records a HIP-event pair around one launch when in-stream profiling is on (bench.py roofline)
@@ -427,7 +460,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     const int B = r->t.B, C = c.num_channels, H = c.model_type == 0 ? c.lstm_hidden_size : 0;
     float *w0 = m->ws[0], *w1 = m->ws[1], *w2 = m->ws[2];
     if (!c.downsample) {
-        lz_launch_conv_in(d_obs, m->rin.w, m->rin.scale, m->rin.shift, w0, B, c.obs_c, c.obs_h, c.obs_w, s);
+        lz_launch_conv_in(d_obs, m->rin.w, m->rin.scale, m->rin.shift, w0, B, c.obs_c, c.obs_h, c.obs_w, C, s);
     } else {
     // DownSample (common.py:266-365)
     int stage = 0;
@@ -468,13 +501,11 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     // and the value / policy 1x1 convs, all in one LDS-resident chain launch
     {
         lz_chain_args ca{};
-        ca.in = w0; ca.B = B; ca.gw = m->GW; ca.gh = m->GH;
-        ca.layer[ca.nlayers++] = chlayer(m->rpa, 0, 1, -1, 1, 0, nullptr);
-        ca.layer[ca.nlayers++] = chlayer(m->rpb, 1, 2, 0, 1, 0, r->latent_pool);
-        ca.layer[ca.nlayers++] = chlayer(m->pa, 2, 3, -1, 1, 0, nullptr);
-        ca.layer[ca.nlayers++] = chlayer(m->pb, 3, 0, 2, 1, 0, nullptr);
-        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = 0;
-        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = 0;
+        ca.in = w0; ca.B = B; ca.gw = m->GW; ca.gh = m->GH; ca.C = C;
+        const int x_lat = chain_blocks(ca, m->rep_res, 0, -1, r->latent_pool);
+        const int x_p = chain_blocks(ca, m->pred_res, x_lat, -1, nullptr);
+        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = x_p;
+        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = x_p;
         ca.nc1 = 2;
         lz_launch_chain(ca, s);
     }
@@ -824,15 +855,13 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     {
         lz_chain_args ca{};
         ca.in = r->latent_pool; ca.gather_ix = t.res_ix; ca.slot_stride = (int64_t)lat_slot;
-        ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B; ca.gw = m->GW; ca.gh = m->GH;
+        ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B; ca.gw = m->GW; ca.gh = m->GH; ca.C = (int)C;
         ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, 1, 1, nullptr);
-        ca.layer[ca.nlayers++] = chlayer(m->dra, 1, 2, -1, 1, 0, nullptr);
-        ca.layer[ca.nlayers++] = chlayer(m->drb, 2, 3, 1, 1, 0, next_latent);
-        ca.layer[ca.nlayers++] = chlayer(m->pa, 3, 0, -1, 1, 0, nullptr);
-        ca.layer[ca.nlayers++] = chlayer(m->pb, 0, 2, 3, 1, 0, nullptr);
-        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = 2;
-        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = 2;
-        ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = 3;
+        const int x_lat = chain_blocks(ca, m->dyn_res, 1, -1, next_latent);   // the next latent state: kept for the reward 1x1 conv
+        const int x_p = chain_blocks(ca, m->pred_res, x_lat, x_lat, nullptr);
+        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = x_p;
+        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = x_p;
+        ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = x_lat;
         ca.nc1 = 3;
 #ifdef LZ_DEBUG_KNOBS
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only

@@ -21,10 +21,13 @@ class EfficientZeroModel(object):
                  reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
                  categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
                  engine=None, **kwargs):
-        if num_res_blocks != 1 or norm_type != 'BN' or not categorical_distribution \
+        if not 1 <= int(num_res_blocks) <= 3 or norm_type != 'BN' or not categorical_distribution \
                 or discrete_action_encoding_type != 'one_hot':
-            raise NotImplementedError("engine model: num_res_blocks=1, norm_type='BN', "
+            raise NotImplementedError("engine model: num_res_blocks in 1..3, norm_type='BN', "
                                       "categorical_distribution=True, one_hot action encoding")
+        if not (reward_head_hidden_channels[0] == value_head_hidden_channels[0] == policy_head_hidden_channels[0]) \
+                or len(value_head_hidden_channels) != 1:
+            raise NotImplementedError("the three heads must have one hidden layer of the same width")
         if tuple(reward_support_range) != tuple(value_support_range) or value_support_range[2] != 1.:
             raise NotImplementedError("reward and value supports must be equal with step 1")
         if not (reward_head_channels == value_head_channels == policy_head_channels):
@@ -33,6 +36,7 @@ class EfficientZeroModel(object):
         self.action_space_size = int(action_space_size)
         self.lstm_hidden_size = int(lstm_hidden_size)
         self.num_channels = int(num_channels)
+        self.num_res_blocks = int(num_res_blocks)
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
         self.reward_support_size = self.value_support_size
         # one model per engine: the first model of the process lives on the default engine, later ones get their own
@@ -41,6 +45,7 @@ class EfficientZeroModel(object):
                          self.action_space_size, self.num_channels, self.lstm_hidden_size, int(value_head_channels),
                          int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5,
                          1 if downsample else 0)
+        cfg.num_res_blocks = self.num_res_blocks
         self._create(cfg)
 
     def _create(self, cfg):

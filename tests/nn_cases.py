@@ -16,6 +16,16 @@ CASES = {
     "mz_atari96": dict(family="mz", kw=dict(observation_shape=(4, 96, 96), action_space_size=4, downsample=True), B=6, seed=13),
     # BASELINE configs[3]: Go 9x9 board, 82 actions, no downsample
     "mz_go9": dict(family="mz", kw=dict(observation_shape=(17, 9, 9), action_space_size=82, downsample=False), B=5, seed=14),
+    # the reference's narrow board-game models: gomoku (zoo/board_games/gomoku/config/gomoku_muzero_bot_mode_config.py:36-45: 32 channels,
+    # 6x6 board, supports (-10, 11, 1)) and tictactoe (tictactoe_muzero_bot_mode_config.py:26-39: 16 channels, 3x3, head hidden [8])
+    "mz_gomoku_c32": dict(family="mz", kw=dict(observation_shape=(3, 6, 6), action_space_size=36, downsample=False, num_channels=32,
+                                               reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.)), B=7, seed=19),
+    "mz_tictactoe_c16": dict(family="mz", kw=dict(observation_shape=(3, 3, 3), action_space_size=9, downsample=False, num_channels=16,
+                                                  reward_head_hidden_channels=[8], value_head_hidden_channels=[8], policy_head_hidden_channels=[8],
+                                                  reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.)), B=7, seed=20),
+    # num_res_blocks > 1 (RepresentationNetwork / DynamicsNetwork / PredictionNetwork are generic in it, common.py:706-787)
+    "ez_atari96_rb2": dict(family="ez", kw=dict(observation_shape=(4, 96, 96), action_space_size=6, downsample=True, num_res_blocks=2), B=4, seed=21),
+    "mz_connect4_rb3": dict(family="mz", kw=dict(observation_shape=(3, 6, 7), action_space_size=7, downsample=False, num_res_blocks=3), B=5, seed=22),
     # BASELINE configs[0]: CartPole MuZeroModelMLP
     "mz_mlp_cartpole": dict(family="mz_mlp", kw=dict(observation_shape=4, action_space_size=2, latent_state_dim=128), B=8, seed=15),
     "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),

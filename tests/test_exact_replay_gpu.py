@@ -227,3 +227,38 @@ def test_two_models_in_one_process_do_not_share_an_engine():
     MuZeroModel(action_space_size=4, engine=a.engine)
     with pytest.raises(L.LzError):
         a._check_owner()
+
+
+def test_gomoku_narrow_model_two_player_replays_exactly():
+    """the reference's gomoku configuration (32 channels, 6x6 board, A = 36, supports (-10, 11, 1), two players): the narrow chain
+    kernel (k_chain_small) in the search loop"""
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    B, A, S = 32, 36, 50
+    kw = dict(observation_shape=(3, 6, 6), downsample=False, num_channels=32, reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.))
+    model = _mz_model(A, seed=11, **kw)
+    rng = np.random.default_rng(12)
+    obs = (torch.rand(B, 3, 6, 6, generator=torch.Generator().manual_seed(28)) < 0.3).float().cuda().contiguous()
+    legal = []
+    for _ in range(B):
+        m = rng.random(A) < 0.7
+        m[rng.integers(0, A)] = True
+        legal.append(np.nonzero(m)[0].tolist())
+    to_play = rng.integers(1, 3, size=B).tolist()
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("mz", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
+
+
+def test_two_residual_blocks_replays_exactly():
+    """num_res_blocks = 2: nine convolutions in the recurrent chain launch, tree step fused"""
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    B, A, S = 64, 6, 30
+    model = _ez_model(A, seed=13, num_res_blocks=2)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(29)).cuda().contiguous()
+    rng = np.random.default_rng(14)
+    noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    legal = [list(range(A))] * B
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)

@@ -21,14 +21,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     run, tag = sys.argv[1], sys.argv[2]
     prof = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(run, "stats", "*", "*kernel_stats.csv"))[0]
+    stats = glob.glob(os.path.join(run, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, os.path.join(prof, "%s_final_kernel_stats.csv" % tag))
     line = open(os.path.join(run, "bench_n1.json")).read().strip().splitlines()[-1]
     bench = json.loads(line)
     open(os.path.join(prof, "%s_bench_n1.json" % tag), "w").write(line + "\n")
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
-        for f in glob.glob(os.path.join(run, d, "*", "*counter_collection.csv")):
+        for f in glob.glob(os.path.join(run, d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(stats))}
