@@ -18,7 +18,10 @@ class GameSegmentBatch(object):
         self.n_env, self.A, self.L = int(n_env), int(action_space_size), int(game_segment_length)
         self.frame_shape, self.stack = tuple(frame_shape), int(frame_stack_num)
         cap = self.L + int(extra)
-        self.obs = np.zeros((self.n_env, self.stack + cap) + self.frame_shape, np.float32)
+        # observation frames are kept the way the reference keeps them -- by reference (its obs_segment is a list of the arrays
+        # the environment returned): one entry per append call = (env ids or None, [n, *frame_shape] array, per-env positions)
+        self._init_obs = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)
+        self._frames = []
         self.action = np.zeros((self.n_env, cap), np.int64)
         self.reward = np.zeros((self.n_env, cap), np.float32)
         self.child_visits = np.zeros((self.n_env, cap, self.A), np.float32)
@@ -40,7 +43,12 @@ class GameSegmentBatch(object):
         ``init_observations`` [n, frame_stack_num, *frame_shape]"""
         ids = self._ids(env_ids)
         init = np.asarray(init_observations, np.float32).reshape((len(ids), self.stack) + self.frame_shape)
-        self.obs[ids, :self.stack] = init
+        self._init_obs[ids] = init
+        if env_ids is None:
+            self._frames = []
+        else:  # the appended frames of these envs belong to their previous segment
+            drop = set(int(i) for i in ids)
+            self._frames = [(fi, fr, pos) for fi, fr, pos in self._frames if fi is not None and not drop.intersection(fi.tolist())]
         self.len[ids] = 0
         self._stats[ids] = 0
 
@@ -67,7 +75,8 @@ class GameSegmentBatch(object):
         fields came with ``store_search_stats_rows``"""
         ids = self._ids(env_ids)
         t = self.len[ids]
-        self.obs[ids, self.stack + t] = np.asarray(next_observations, np.float32).reshape((len(ids),) + self.frame_shape)
+        frames = np.asarray(next_observations, np.float32).reshape((len(ids),) + self.frame_shape)  # a view when already float32
+        self._frames.append((None if env_ids is None else ids.copy(), frames, t.copy()))
         self.reward[ids, t] = np.asarray(rewards, np.float32)
         self.len[ids] = t + 1
 
@@ -86,7 +95,16 @@ class GameSegmentBatch(object):
             child = np.empty(ns, dtype=object)
             for k in range(ns):
                 child[k] = self.child_visits[env, k, :int(nl[k])].tolist()
-        return dict(obs_segment=self.obs[env, :self.stack + n].copy(), action_segment=self.action[env, :n].copy(),
+        obs = np.zeros((self.stack + n,) + self.frame_shape, np.float32)
+        obs[:self.stack] = self._init_obs[env]
+        for fi, fr, pos in self._frames:
+            if fi is None:
+                obs[self.stack + int(pos[env])] = fr[env]
+            else:
+                k = np.nonzero(fi == env)[0]
+                if k.size:
+                    obs[self.stack + int(pos[k[0]])] = fr[k[0]]
+        return dict(obs_segment=obs, action_segment=self.action[env, :n].copy(),
                     reward_segment=self.reward[env, :n].copy(), child_visit_segment=child,
                     root_value_segment=self.root_value[env, :ns].copy(), action_mask_segment=self.action_mask[env, :n].copy(),
                     to_play_segment=self.to_play[env, :n].copy(), timestep_segment=self.timestep[env, :n].copy())

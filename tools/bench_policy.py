@@ -27,3 +27,25 @@ for dev_sel in (False, True):
         out = pol._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B)
     dt = (time.perf_counter() - t0) / n
     print("device_select_action=%s: %.2f ms per _forward_collect (%d envs) -> %.0f env-steps/s" % (dev_sel, dt * 1e3, B, B / dt))
+
+# the vectorised collector path: forward_collect_rows + GameSegmentBatch bookkeeping, no per-env Python loop
+from lightzero_amd import shard  # noqa: E402
+from lightzero_amd.mcts.buffer.game_segment import GameSegmentBatch  # noqa: E402
+F = 96 * 96
+pol = EfficientZeroPolicy(dict(num_simulations=50, discount_factor=0.997, lstm_horizon_len=5), model)
+rows = torch.zeros(B, shard.row_width(A, F), device="cuda")
+batch = GameSegmentBatch(B, A, 400, (1, 96, 96), frame_stack_num=4)
+batch.reset(np.zeros((B, 4, 1, 96, 96), np.float32))
+next_frame = np.zeros((B, 1, 96, 96), np.float32)
+reward = np.zeros(B, np.float32)
+for _ in range(3):
+    pol.forward_collect_rows(obs, mask, rows, temperature=1.0, to_play=[-1] * B)
+t0 = time.perf_counter()
+n = 20
+for t in range(n):
+    hdr = pol.forward_collect_rows(obs, mask, rows, temperature=1.0, to_play=[-1] * B, timestep=np.full(B, t, np.int32))
+    actions = hdr[:, shard.F_ACTION]            # -> env.step(actions); next_frame / reward come back from the environments
+    batch.store_search_stats_rows(hdr)
+    batch.append(next_frame, reward)
+dt = (time.perf_counter() - t0) / n
+print("forward_collect_rows + GameSegmentBatch (store_search_stats + append for %d envs): %.2f ms per env-step -> %.0f env-steps/s" % (B, dt * 1e3, B / dt))
