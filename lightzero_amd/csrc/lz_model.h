@@ -19,6 +19,7 @@ struct HostTensor {
 struct ConvW {
     float *w = nullptr, *scale = nullptr, *shift = nullptr;
     float *wf = nullptr;  // MFMA-fragment order [cout/16][9][cin/16][64 lanes][4] for the LDS-resident conv chain
+    float *uf = nullptr;  // Winograd F(2x2, 3x3) transform U = G g G^T of the same weights, [cout/16][16][cin/16][64 lanes][4] (tower convs)
     int cin = 0, cout = 0;
 };
 struct MlpW {
@@ -146,10 +147,35 @@ struct Builder {
         }
         return c;
     }
-    ConvW resconv(const std::string &prefix, int idx, int cout, int cin)  // ding ResBlock convN = Sequential(conv, bn[, act])
+    ConvW resconv(const std::string &prefix, int idx, int cout, int cin, bool winograd = false)  // ding ResBlock convN = Sequential(conv, bn[, act])
     {
         const std::string p = prefix + ".conv" + std::to_string(idx);
-        return conv(p + ".0.weight", p + ".1", cout, cin, cin);
+        ConvW c = conv(p + ".0.weight", p + ".1", cout, cin, cin);
+        if (winograd) c.uf = wino(p + ".0.weight", cout, cin);
+        return c;
+    }
+    // U = G g G^T per (cout, cin) filter, G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]] (Lavin & Gray 2016), computed in
+    // binary64 and rounded once; fragment order of k_conv_wino: lane (n = l & 15, kq = l >> 4) holds U_p[ci = 16 g + 4 kq + j][co = 16 nt + n]
+    float *wino(const std::string &wname, int cout, int cin)
+    {
+        const HostTensor *w = get(wname, {cout, cin, 3, 3});
+        if (!w) return nullptr;
+        static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        const int G = cin / 16;
+        std::vector<float> f((size_t)cout * cin * 16);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) {
+                const float *g = &w->data[((size_t)co * cin + ci) * 9];
+                double t[4][3], U[4][4];
+                for (int i = 0; i < 4; ++i)
+                    for (int k = 0; k < 3; ++k) t[i][k] = Gm[i][0] * g[0 * 3 + k] + Gm[i][1] * g[1 * 3 + k] + Gm[i][2] * g[2 * 3 + k];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) U[i][j] = t[i][0] * Gm[j][0] + t[i][1] * Gm[j][1] + t[i][2] * Gm[j][2];
+                const int nt = co / 16, n = co % 16, gq = ci / 16, kq = (ci % 16) / 4, jj = ci % 4, lane = kq * 16 + n;
+                for (int p = 0; p < 16; ++p)
+                    f[((((size_t)nt * 16 + p) * G + gq) * 64 + lane) * 4 + jj] = (float)U[p / 4][p % 4];
+            }
+        return upload(f);
     }
     C1W conv1x1(const std::string &cprefix, const std::string &bnprefix, int cout, int cin)
     {

@@ -178,15 +178,15 @@ extern "C" int lz_model_finalize(lz_engine *e)
             m->first_s = b.upload(sc);
             m->first_t = b.upload(sh);
         }
-        m->r1a = b.resconv(d + "resblocks1.0", 1, C2, C2);
-        m->r1b = b.resconv(d + "resblocks1.0", 2, C2, C2);
+        m->r1a = b.resconv(d + "resblocks1.0", 1, C2, C2, true);
+        m->r1b = b.resconv(d + "resblocks1.0", 2, C2, C2, true);
         m->dn1 = b.resconv(d + "downsample_block", 1, C, C2);
-        m->dn2 = b.resconv(d + "downsample_block", 2, C, C);
+        m->dn2 = b.resconv(d + "downsample_block", 2, C, C, true);
         m->dn3 = b.conv(d + "downsample_block.conv3.0.weight", "", C, C2, C2);
-        m->r2a = b.resconv(d + "resblocks2.0", 1, C, C);
-        m->r2b = b.resconv(d + "resblocks2.0", 2, C, C);
-        m->r3a = b.resconv(d + "resblocks3.0", 1, C, C);
-        m->r3b = b.resconv(d + "resblocks3.0", 2, C, C);
+        m->r2a = b.resconv(d + "resblocks2.0", 1, C, C, true);
+        m->r2b = b.resconv(d + "resblocks2.0", 2, C, C, true);
+        m->r3a = b.resconv(d + "resblocks3.0", 1, C, C, true);
+        m->r3b = b.resconv(d + "resblocks3.0", 2, C, C, true);
         }
         m->rep_res.clear();
         for (int i = 0; i < NRB; ++i) {
@@ -351,7 +351,7 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
                  int relu, hipStream_t s)
 {
     lz_conv_args a{};
-    a.in = in; a.w = w.w; a.wf = w.wf; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
+    a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
 }
