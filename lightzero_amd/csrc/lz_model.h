@@ -23,7 +23,7 @@ struct ConvW {
     int cin = 0, cout = 0;
 };
 struct MlpW {
-    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* transposed [HID][NOUT] */, *b2 = nullptr;
+    float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* [32 / 4][NOUT][4], hidden width padded to the compiled 32 */, *b2 = nullptr;
     int K1 = 0, NOUT = 0;
 };
 struct C1W {
@@ -221,10 +221,13 @@ struct Builder {
         o.b1 = upload(b1p);
         o.s1 = upload(scp);
         o.t1 = upload(shp);
-        std::vector<float> w2t((size_t)HP * NOUT, 0.0f);
+        // second layer as [32 / 4][NOUT][4]: thread n takes its column's weights with eight coalesced 16-byte loads (a wave reads
+        // 1 KB per instruction) instead of thirty-two 4-byte ones from a plain transpose (measured: no change of the 8.2 us
+        // launch, which is a chain of dependent stages, not load-issue bound; kept for the fewer instructions)
+        std::vector<float> w2n((size_t)NOUT * HP, 0.0f);
         for (int n = 0; n < NOUT; ++n)
-            for (int k = 0; k < HID; ++k) w2t[(size_t)k * NOUT + n] = w2->data[(size_t)n * HID + k];
-        o.w2 = upload(w2t);
+            for (int k = 0; k < HID; ++k) w2n[((size_t)(k / 4) * NOUT + n) * 4 + k % 4] = w2->data[(size_t)n * HID + k];
+        o.w2 = upload(w2n);
         o.b2 = upload(b2->data);
         return o;
     }

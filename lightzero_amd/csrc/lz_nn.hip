@@ -1424,7 +1424,10 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
         const int n = min(tid + i * NTHR, h.NOUT - 1);
         b2r[i] = h.b2[n];
 #pragma unroll
-        for (int k = 0; k < HID; ++k) w2r[i][k] = h.w2t[(size_t)k * h.NOUT + n];
+        for (int k4 = 0; k4 < HID / 4; ++k4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(h.w2t + ((size_t)k4 * h.NOUT + n) * 4);
+            w2r[i][4 * k4] = w4[0]; w2r[i][4 * k4 + 1] = w4[1]; w2r[i][4 * k4 + 2] = w4[2]; w2r[i][4 * k4 + 3] = w4[3];
+        }
     }
     const float b1v = h.b1[min(u, HID - 1)], s1v = h.s1[min(u, HID - 1)], t1v = h.t1[min(u, HID - 1)];
     for (int i = tid; i < EPB * (K1 / 4); i += NTHR) {  // 16-channel runs are contiguous: float4 loads

@@ -120,7 +120,7 @@ struct lz_head_desc {
     const float *in;
     int env_stride, pix_stride;
     const float *w1, *b1, *s1, *t1;  // Linear [HID][K1], bias, folded BN1d
-    const float *w2t, *b2;           // Linear transposed [HID][NOUT], bias [NOUT]
+    const float *w2t, *b2;           // second Linear as [HID / 4][NOUT][4] (coalesced float4 per output column), bias [NOUT]
     int K1, NOUT;
     int categorical;       // 1: softmax . support -> inverse scalar transform -> out_scalar[B]
     float support_min;     // support = support_min + k (step 1)

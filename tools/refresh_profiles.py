@@ -55,8 +55,8 @@ def main():
                                "2.36 MB + 0.74 MB of weights once per XCD L2 (8 x) + the staged trees / leaf outputs of the tree step; "
                                "writes: next latent 2.36 MB + head-conv outputs 1.77 MB + tree write-through. Algorithmic bytes of "
                                "the chain 7.2 MB."}}
-    for key in ("k_chain<6, 6, false, 0>", "k_heads<32, 512>", "k_lstm2<68", "k_conv3x3_big<64, 64, 1, 144>",
-                "k_conv3x3_big<32, 32, 1, 128>", "k_conv3x3_big<32, 64, 2, 48>", "k_conv_first", "k_avgpool"):
+    for key in ("k_chain<6, 6, false, 0>", "k_heads<32, 512>", "k_lstm2<68", "k_conv_wino<64, 64, 16>", "k_conv_wino<32, 32, 32>",
+                "k_conv3x3_big<32, 64, 2, 48>", "k_conv_first", "k_avgpool", "k_pack_rows"):
         out[key] = {"fetch_size_kb": mean(key, "FETCH_SIZE"), "write_size_kb": mean(key, "WRITE_SIZE")}
     json.dump(out, open(os.path.join(prof, "%s_traffic.json" % tag), "w"), indent=1)
     # MFMA utilisation of the roofline kernel: busy cycles per SIMD over the launch duration at the sustained clock
