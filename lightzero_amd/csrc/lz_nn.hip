@@ -1209,14 +1209,22 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // ------------------------------------------------------------------------------------------------
 // XV = float4 per lane of the optional input transform (8 lanes per row): KX = 32 * XV; 0 = no transform compiled in
 // MR = rows per workgroup: 32, or 16 when 32 staged rows would not fit the 160 KB of LDS (K = 1536: 64x64 observations)
-template <int NKB, int XV = 0, int MR = 32>
+// KXB > 0 (= KX / 16, compile-time): the x columns are staged first and the MFMAs over them start while the h columns -- requested
+// in the same burst, parked in registers -- are still in flight; they go to LDS behind a second barrier.  One exposed round trip
+// instead of two, and the second one under 36 K-steps of matrix work.
+// (Measured and dropped: one 8-wave 32-row workgroup per CU -- (gate, row tile) waves sharing every weight fragment through L1,
+// 411 KB instead of 684 KB through the CU -- 13.9 us against 13.6 us for two 4-wave 16-row workgroups: the kernel is bound by
+// the matrix pipe (17.4 k MFMA cycles per SIMD) plus its serial staging / epilogue, not by the L1 fill rate.)
+template <int NKB, int XV = 0, int MR = 32, int KXB = 0>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
     constexpr int K = NKB * 16, PS = K + 4, R = 12;
-    constexpr int NQ = MR / 16, TPR = 256 / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
+    constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
+    constexpr bool TWO = MR == 32;                         // a wave computes both 16-row tiles of a 32-row workgroup
     static_assert(MR == 32 || (MR == 16 && XV == 0), "the input transform is written for 8 staging lanes per row");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [MR][PS]; reused for the gate exchange
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int mt = 0;
     const int tile = blockIdx.x, r0 = blockIdx.y * MR;
     const int H = a.H, KX = a.KX;
     const size_t slot = (size_t)a.B * H;
@@ -1233,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     const int32_t *slp = a.search_len ? a.search_len : a.gather_ix;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int p = tid + 256 * q, row = p >> 4, u = p & 15;
+        const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
         const int b = min(r0 + row, a.B - 1), unit = tile * 16 + u;
         c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
         const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + 4 * unit);
@@ -1243,7 +1251,23 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     }
     // stage the rows: [x (KX) | h (H)] per row; TPR (8) threads per row, batches of 12 float4 loads in flight per thread
     constexpr int K4 = K / 4, NI = (K4 + TPR - 1) / TPR, NBATCH = 12;
-    {
+    constexpr int NXS = KXB > 0 ? KXB * 4 / TPR : 0, NHS = KXB > 0 ? (K4 - KXB * 4) / TPR : 1;
+    static_assert(KXB == 0 || (XV == 0 && (KXB * 4) % TPR == 0 && (K4 - KXB * 4) % TPR == 0), "split staging needs whole thread strides");
+    f32x4 hv[NHS];  // native vectors: an array of HIP's float4 struct that lives across the K loop ends up in scratch
+    if constexpr (KXB > 0) {
+        const int row = tid / TPR, part = tid % TPR;
+        const int b = min(r0 + row, a.B - 1);
+        const float *xrow = a.x + (size_t)b * KX;
+        const float *hrow = a.h_pool + (size_t)a.gather_ix[b] * slot + (size_t)b * H;
+        float *dst = smem + row * PS;
+        f32x4 xv[NXS];
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(xrow + (part + TPR * i) * 4);
+#pragma unroll
+        for (int i = 0; i < NHS; ++i) hv[i] = *reinterpret_cast<const f32x4 *>(hrow + (part + TPR * i) * 4);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) *reinterpret_cast<f32x4 *>(dst + (part + TPR * i) * 4) = xv[i];
+    } else {
         const int row = tid / TPR, part = tid % TPR;
         const int b = min(r0 + row, a.B - 1);
         const int kx4 = KX >> 2;
@@ -1305,16 +1329,27 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         }
     }
     __syncthreads();
-    const float *sA0 = smem + (lane & 15) * PS + (lane >> 4) * 4;
-    const float *sA1 = sA0 + (MR == 32 ? 16 : 0) * PS;  // MR == 16: the second tile is not computed
+    const float *sA0 = smem + (mt * 16 + (lane & 15)) * PS + (lane >> 4) * 4;
+    const float *sA1 = sA0 + (TWO ? 16 : 0) * PS;  // only a four-wave 32-row workgroup computes a second tile per wave
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     float4 a0 = *reinterpret_cast<const float4 *>(sA0), a1 = *reinterpret_cast<const float4 *>(sA1);
 #pragma unroll
     for (int s = 0; s < NKB; ++s) {
+        if constexpr (KXB > 0) {
+            if (s == KXB) {  // the h columns have arrived behind the x part's MFMAs: into LDS, then on
+                const int row = tid / TPR, part = tid % TPR;
+                float *dst = smem + row * PS + KXB * 16;
+#pragma unroll
+                for (int i = 0; i < NHS; ++i) *reinterpret_cast<f32x4 *>(dst + (part + TPR * i) * 4) = hv[i];
+                __syncthreads();
+                a0 = *reinterpret_cast<const float4 *>(sA0 + s * 16);
+                a1 = *reinterpret_cast<const float4 *>(sA1 + s * 16);
+            }
+        }
         const float4 bfr = wq[s % R];
         if (s + R < NKB) wq[s % R] = wp[(size_t)(s + R) * 64];
         float4 n0 = a0, n1 = a1;
-        if (s + 1 < NKB) {
+        if (s + 1 < NKB && (KXB == 0 || s + 1 != KXB)) {
             n0 = *reinterpret_cast<const float4 *>(sA0 + (s + 1) * 16);
             n1 = *reinterpret_cast<const float4 *>(sA1 + (s + 1) * 16);
         }
@@ -1322,7 +1357,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a0, j), vget(bfr, j), acc0, 0, 0, 0);
-            if constexpr (MR == 32) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a1, j), vget(bfr, j), acc1, 0, 0, 0);
+            if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a1, j), vget(bfr, j), acc1, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         a0 = n0;
@@ -1334,14 +1369,14 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         const int col = lane & 15, rq = 4 * (lane >> 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            sG[(wv * MR + rq + q) * 17 + col] = acc0[q];
-            if constexpr (MR == 32) sG[(wv * MR + 16 + rq + q) * 17 + col] = acc1[q];
+            sG[(wv * MR + mt * 16 + rq + q) * 17 + col] = acc0[q];
+            if constexpr (TWO) sG[(wv * MR + 16 + rq + q) * 17 + col] = acc1[q];
         }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int p = tid + 256 * q, row = p >> 4, u = p & 15;
+        const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
         const int b = r0 + row;
         if (b >= a.B) continue;
         const int unit = tile * 16 + u;
@@ -1732,7 +1767,9 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     // are streamed twice as often
     static const char *big_rows = getenv("LZ_LSTM_ROWS32");
     if (nkb == 68 && !xf && !big_rows) {
-        hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        static const char *nosplit = getenv("LZ_LSTM_NOSPLIT");  // the one-burst staging (A/B timing, parity: both forms are bit-identical)
+        if (a.KX == 576 && !nosplit) hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        else hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
         return true;
     }
     if (nkb == 68 && !xf) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)

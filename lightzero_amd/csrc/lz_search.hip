@@ -965,7 +965,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

@@ -10,7 +10,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int DEPTH>
-__global__ __launch_bounds__(256) void k_stream(const f32x4 *__restrict__ w, int kb_per_wave, int total_kb, int mode, int reps, float *out,
+__global__ __launch_bounds__(512) void k_stream(const f32x4 *__restrict__ w, int kb_per_wave, int total_kb, int mode, int reps, float *out,
                                                 unsigned long long *cycles)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x;
