@@ -20,6 +20,7 @@ struct ConvW {
     float *w = nullptr, *scale = nullptr, *shift = nullptr;
     float *wf = nullptr;  // MFMA-fragment order [cout/16][9][cin/16][64 lanes][4] for the LDS-resident conv chain
     float *uf = nullptr;  // Winograd F(2x2, 3x3) transform U = G g G^T of the same weights, [cout/16][16][cin/16][64 lanes][4] (tower convs)
+    float *uc = nullptr;  // the same transform in the order of the LDS-resident Winograd chain (k_chain_w): [16 points][cin/4][64 = cout][4]
     int cin = 0, cout = 0;
 };
 struct MlpW {
@@ -147,12 +148,38 @@ struct Builder {
         }
         return c;
     }
-    ConvW resconv(const std::string &prefix, int idx, int cout, int cin, bool winograd = false)  // ding ResBlock convN = Sequential(conv, bn[, act])
+    ConvW resconv(const std::string &prefix, int idx, int cout, int cin, bool winograd = false, bool wchain = false)  // ding ResBlock convN = Sequential(conv, bn[, act])
     {
         const std::string p = prefix + ".conv" + std::to_string(idx);
         ConvW c = conv(p + ".0.weight", p + ".1", cout, cin, cin);
         if (winograd) c.uf = wino(p + ".0.weight", cout, cin);
+        if (wchain) c.uc = wino_chain(p + ".0.weight", cout, cin, cin);
         return c;
+    }
+    static void wino_u(const float *g, double (&U)[4][4])  // U = G g G^T, binary64
+    {
+        static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        double t[4][3];
+        for (int i = 0; i < 4; ++i)
+            for (int k = 0; k < 3; ++k) t[i][k] = Gm[i][0] * g[0 * 3 + k] + Gm[i][1] * g[1 * 3 + k] + Gm[i][2] * g[2 * 3 + k];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) U[i][j] = t[i][0] * Gm[j][0] + t[i][1] * Gm[j][1] + t[i][2] * Gm[j][2];
+    }
+    // order of k_chain_w: wave w streams the points 4w .. 4w+3; lane = output channel; one float4 = four consecutive input channels
+    // (the first `cin` of cin_total: the dynamics conv's one-hot action planes go through the action table)
+    float *wino_chain(const std::string &wname, int cout, int cin_total, int cin)
+    {
+        const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
+        if (!w || cout != 64 || (cin & 3)) return nullptr;
+        std::vector<float> f((size_t)16 * cin * cout);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) {
+                double U[4][4];
+                wino_u(&w->data[((size_t)co * cin_total + ci) * 9], U);
+                for (int p = 0; p < 16; ++p)
+                    f[((((size_t)p * (cin / 4) + ci / 4) * cout) + co) * 4 + (ci & 3)] = (float)U[p / 4][p % 4];
+            }
+        return upload(f);
     }
     // U = G g G^T per (cout, cin) filter, G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]] (Lavin & Gray 2016), computed in
     // binary64 and rounded once; fragment order of k_conv_wino: lane (n = l & 15, kq = l >> 4) holds U_p[ci = 16 g + 4 kq + j][co = 16 nt + n]
@@ -160,17 +187,12 @@ struct Builder {
     {
         const HostTensor *w = get(wname, {cout, cin, 3, 3});
         if (!w) return nullptr;
-        static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         const int G = cin / 16;
         std::vector<float> f((size_t)cout * cin * 16);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci) {
-                const float *g = &w->data[((size_t)co * cin + ci) * 9];
-                double t[4][3], U[4][4];
-                for (int i = 0; i < 4; ++i)
-                    for (int k = 0; k < 3; ++k) t[i][k] = Gm[i][0] * g[0 * 3 + k] + Gm[i][1] * g[1 * 3 + k] + Gm[i][2] * g[2 * 3 + k];
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 4; ++j) U[i][j] = t[i][0] * Gm[j][0] + t[i][1] * Gm[j][1] + t[i][2] * Gm[j][2];
+                double U[4][4];
+                wino_u(&w->data[((size_t)co * cin + ci) * 9], U);
                 const int nt = co / 16, n = co % 16, gq = ci / 16, kq = (ci % 16) / 4, jj = ci % 4, lane = kq * 16 + n;
                 for (int p = 0; p < 16; ++p)
                     f[((((size_t)nt * 16 + p) * G + gq) * 64 + lane) * 4 + jj] = (float)U[p / 4][p % 4];

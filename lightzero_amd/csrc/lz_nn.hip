@@ -906,6 +906,345 @@ __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_ar
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same chain by Winograd F(2x2, 3x3) (Lavin & Gray 2016) for even grids (6x6: 9 output tiles of 2x2 pixels per root).
+// A layer = 16 independent [tiles x 64] x [64 x 64] products, one per transform point.  With 9 rows the 16-row MFMA would be
+// 44 % padding, so the products run on v_mfma_f32_4x4x1_f32: 16 blocks of (4 tiles) x (4 channels) = 4 tiles x 64 output channels
+// per instruction, one k per instruction, 3 row blocks (12 rows, 9 used): 16 x 64 x 3 x 8 = 6,144 matrix cycles per SIMD and layer
+// instead of 10,368 for the direct form.  Wave (i, h) owns transform points 4i .. 4i+3 (row i of the 4x4 point grid) for ALL output
+// channels and the h-th part of the input channels (NW = 4 waves: all of them; NW = 8: halves), so no partial sums meet inside a
+// wave; the output transform Y = A^T M A is split the same way: a wave reduces its row (M[i][.] A, inside a lane), the row
+// results meet in LDS and every thread finishes its (pixel, channel) outputs (BN, action table, residual, ReLU) -- written to LDS as
+// the next layer's input and, for the latent, coalesced to the pool.
+// Input transform V = B^T d B: one (tile, channel quad[, row pair]) item per thread, float4 LDS reads and writes, packed adds.
+// Weights: U = G g G^T (host, binary64, rounded once; lz_model.h wino_chain) stream from L2 through a register ring that runs
+// across layer boundaries: 262 KB per layer and workgroup (1.78x the direct form's bytes for 0.59x its matrix cycles) -- the
+// layer loop is bound by what one CU can pull from L2 (tools/ubench/l2_stream.py: 33 B/clk with 4 waves, 43 with 8).
+// fp32 throughout; rounding differs from the direct form at the 1e-6 level (tests/test_nn_golden_gpu.py qualifies the chain against
+// the reference modules' outputs at 2e-5).  LZ_CHAIN_DIRECT=1 selects k_chain.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// a - b on the packed-fp32 path (the compiler packs additions but leaves subtractions scalar)
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
+{
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
+template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? 16 : 32)>
+__global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename step_arg<TREE>::type step)
+{
+    constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
+    constexpr int TW = GW / 2, TH = GH / 2, NT = TW * TH, NRB = (NT + 3) / 4;
+    constexpr int KH = NW / 4, KSW = 16 / KH, NSTEP = 4 * KSW, R = (RING < NSTEP) ? RING : NSTEP;  // k parts; channel quads per wave; steps; ring
+    constexpr int NITEM = NT * 16 * KH;      // input-transform items: (tile, channel quad) x (row pair if 8 waves)
+    constexpr int NOUT = (HW * 64 + NTHR - 1) / NTHR;  // outputs per thread in the combine step
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert((GW % 2) == 0 && (GH % 2) == 0 && NITEM <= NTHR && NT * 4 == HW && NRB <= 4, "even grid, one transform item per thread");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats, then
+    float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
+    float *sSS = sTab + HW * PS;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
+    float *sMisc = sSS + LZ_CHAIN_MAX_LAYERS * 128;     // 128 floats: time stamps (TS) | the tree step's selection
+    float *sV = sMisc + 128;                            // [16 points][NT][PS] transformed input patches
+    float *sX = sV + 16 * NT * PS;                      // [KH][4 point rows][NT][2][64] row results of the output transform
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pi = wv & 3, kh = wv >> 2;
+    const int b = blockIdx.x;
+    // step s of a wave: point 4 pi + s / KSW, channel quad kh KSW + s % KSW; weights [16 points][16 quads][64 lanes] float4
+    auto wofs = [](int s) { return ((s / KSW) * 16 + (s % KSW)) * 64; };
+    const size_t wbase = (size_t)((4 * pi) * 16 + kh * KSW) * 64 + lane;
+    f32x4 wq[R];
+    auto fill_ring = [&]() {
+        const f32x4 *w0 = reinterpret_cast<const f32x4 *>(a.layer[0].uc) + wbase;
+#pragma unroll
+        for (int s = 0; s < R; ++s) wq[s] = w0[wofs(s)];
+    };
+    // the first layer's weights are requested before anything else -- except with the tree step in the prologue: a whole layer of
+    // fragments (256 registers) cannot stay live across it, so they are requested right after it, under the latent's staging
+    if constexpr (TREE == 0) fill_ring();
+    float4 c1w[4];
+    {
+        const float *cw = a.c1[min(wv, max(a.nc1 - 1, 0))].w;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(cw + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
+    }
+    int g_slot = 0, g_action = 0;
+    if constexpr (TREE != 0) {
+        int32_t *s_sel = reinterpret_cast<int32_t *>(sMisc + 120);
+        if (wv == 0)
+            dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel);
+        __syncthreads();
+        g_slot = s_sel[0];
+        g_action = s_sel[1];
+        fill_ring();
+    } else {
+        if (a.gather_ix) g_slot = a.gather_ix[b];
+        if (a.act_table) g_action = a.action[b];
+    }
+    {
+        const float *src = a.in + (size_t)b * HW * 64 + (size_t)g_slot * a.slot_stride;
+        constexpr int NU = (HW * 16 + NTHR - 1) / NTHR;
+        float4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = u * NTHR + tid;
+            v[u] = vzero4();
+            if (idx < HW * 16) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = u * NTHR + tid;
+            if (idx < HW * 16) *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
+        }
+        if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
+        if (a.act_table) {
+            const float *tsrc = a.act_table + (size_t)g_action * HW * 64;
+            float4 tv[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = min(u * NTHR + tid, HW * 16 - 1);
+                tv[u] = *reinterpret_cast<const float4 *>(tsrc + (size_t)idx * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = u * NTHR + tid;
+                if (idx < HW * 16) *reinterpret_cast<float4 *>(sTab + (idx >> 4) * PS + (idx & 15) * 4) = tv[u];
+            }
+        }
+        for (int i = tid; i < a.nlayers * 128; i += NTHR) {
+            const int L = i >> 7, r = i & 127;
+            sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+        }
+    }
+    // ---- per-thread geometry, the same for every layer
+    // input transform item = (tile, channel quad[, row pair hr]): LDS offsets of the patch pixels it reads (outside the image:
+    // the all-zero pixel).  V rows 2 hr, 2 hr + 1 need patch rows hr .. hr + 2 (KH = 2); all four rows otherwise.
+    constexpr int PR = (KH == 2) ? 3 : 4;            // patch rows per item
+    const int it = min(tid, NITEM - 1), it_hr = (KH == 2) ? it / (NT * 16) : 0, it_tile = (it / 16) % NT, it_cq = it & 15;
+    int poff[PR * 4];
+    {
+        const int ty = it_tile / TW, tx = it_tile - ty * TW;
+#pragma unroll
+        for (int i = 0; i < PR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = 2 * ty - 1 + it_hr + i, x = 2 * tx - 1 + j;
+                const bool ok = (y >= 0) & (y < GH) & (x >= 0) & (x < GW);
+                int o = (ok ? y * GW + x : HW) * PS + it_cq * 4;
+                asm volatile("" : "+v"(o));
+                poff[4 * i + j] = o;
+            }
+    }
+    const int voff = it_tile * PS + it_cq * 4;
+    // One LDS read serves all row blocks: lanes 4 rb .. 4 rb + 3 (block rb) hold tiles 4 rb .. 4 rb + 3 and the instruction's A
+    // broadcast (CBSZ = 4: all 16 blocks take A from block ABID = rb) hands them to every block -- a third of the LDS traffic of
+    // one read per row block (768 KB per layer through the LDS pipe was as long as the matrix work itself).
+    const int aoff = ((4 * pi) * NT + min(lane & 15, NT - 1)) * PS + kh * KSW * 4;
+    // combine step: this thread finishes output channel `lane` of the pixels u = wv + NW n (u = 4 tile + 2 dy + dx)
+    int cpix[NOUT], cx[NOUT];
+    float csg[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        const int u = min(wv + NW * n, HW - 1), tile = u >> 2, dy = (u >> 1) & 1, dx = u & 1, ty = tile / TW, tx = tile - ty * TW;
+        cpix[n] = ((2 * ty + dy) * GW + 2 * tx + dx) * PS + lane;
+        cx[n] = ((dy * NT + tile) * 2 + dx) * 64 + lane;  // first of the three point rows this output sums: dy, dy + 1, dy + 2
+        csg[n] = dy ? -1.0f : 1.0f;                        // Y0 = (X0 + X1) + X2, Y1 = (X1 - X2) - X3  (A^T = [1 1 1 0; 0 1 -1 -1])
+    }
+    const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
+    unsigned long long *sTS = reinterpret_cast<unsigned long long *>(sMisc);
+    int nts = 0;
+#define LZ_TS() do { if constexpr (TS) { if (b == 0 && tid == 0 && nts < 60) sTS[nts++] = __builtin_readcyclecounter(); } } while (0)
+    LZ_TS();
+    __syncthreads();
+    LZ_TS();
+
+    for (int L = 0; L < a.nlayers; ++L) {
+        const lz_chain_layer &ly = a.layer[L];
+        const float *sIn = smem + ly.in * BUF;
+        float *sOut = smem + ly.out * BUF;
+        const bool more = L + 1 < a.nlayers;
+        const f32x4 *wc = reinterpret_cast<const f32x4 *>(ly.uc) + wbase;
+        const f32x4 *wn = reinterpret_cast<const f32x4 *>(a.layer[more ? L + 1 : L].uc) + wbase;
+        // ---- input transform V = B^T d B
+        if (tid < NITEM) {
+            f32x4 d[PR * 4];
+#pragma unroll
+            for (int k = 0; k < PR * 4; ++k) d[k] = *reinterpret_cast<const f32x4 *>(sIn + poff[k]);
+            if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
+            if constexpr (KH == 1) {
+                f32x4 e[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[0 + j] = pk_sub(d[0 + j], d[8 + j]);
+                    e[4 + j] = d[4 + j] + d[8 + j];
+                    e[8 + j] = pk_sub(d[8 + j], d[4 + j]);
+                    e[12 + j] = pk_sub(d[4 + j], d[12 + j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<f32x4 *>(sV + (4 * i + 0) * NT * PS + voff) = pk_sub(e[4 * i + 0], e[4 * i + 2]);
+                    *reinterpret_cast<f32x4 *>(sV + (4 * i + 1) * NT * PS + voff) = e[4 * i + 1] + e[4 * i + 2];
+                    *reinterpret_cast<f32x4 *>(sV + (4 * i + 2) * NT * PS + voff) = pk_sub(e[4 * i + 2], e[4 * i + 1]);
+                    *reinterpret_cast<f32x4 *>(sV + (4 * i + 3) * NT * PS + voff) = pk_sub(e[4 * i + 1], e[4 * i + 3]);
+                }
+            } else {
+                // row pair hr: patch rows r0 r1 r2 = hr, hr + 1, hr + 2.  hr = 0: e0 = r0 - r2, e1 = r1 + r2;  hr = 1: e2 = r1 - r0, e3 = r0 - r2
+                f32x4 e[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 s02 = pk_sub(d[0 + j], d[8 + j]), a12 = d[4 + j] + d[8 + j], s10 = pk_sub(d[4 + j], d[0 + j]);
+                    e[0 + j] = it_hr ? s10 : s02;
+                    e[4 + j] = it_hr ? s02 : a12;
+                }
+                float *vb = sV + (it_hr * 8) * NT * PS + voff;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    *reinterpret_cast<f32x4 *>(vb + (4 * i + 0) * NT * PS) = pk_sub(e[4 * i + 0], e[4 * i + 2]);
+                    *reinterpret_cast<f32x4 *>(vb + (4 * i + 1) * NT * PS) = e[4 * i + 1] + e[4 * i + 2];
+                    *reinterpret_cast<f32x4 *>(vb + (4 * i + 2) * NT * PS) = pk_sub(e[4 * i + 2], e[4 * i + 1]);
+                    *reinterpret_cast<f32x4 *>(vb + (4 * i + 3) * NT * PS) = pk_sub(e[4 * i + 1], e[4 * i + 3]);
+                }
+            }
+        }
+        if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
+        // the epilogue's operands do not depend on the products: read them now
+        const float sc = sSS[L * 128 + lane], sh = sSS[L * 128 + 64 + lane];
+        const bool tab = ly.act != 0, hasres = ly.res >= 0, relu = ly.relu != 0;
+        const float *sRes = smem + max(ly.res, 0) * BUF;
+        float tv[NOUT], rv[NOUT];
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) tv[n] = rv[n] = 0.0f;
+        if (tab) {   // wave-uniform: only the dynamics convolution reads the action table, only a block's second layer a residual
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) tv[n] = sTab[cpix[n]];
+        }
+        if (hasres) {
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) rv[n] = sRes[cpix[n]];
+        }
+        if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
+        __syncthreads();
+        LZ_TS();
+        // ---- this wave's four points x its channel quads: NRB row blocks x 4 k per step
+        f32x4 acc[4][NRB];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[p][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // A fragments are read AD steps (of 12 short MFMAs = 96 cycles) ahead: one step does not cover the LDS latency
+        constexpr int AD = 3;
+        f32x4 af[AD + 1];
+        auto fetch_a = [&](int s, f32x4 &f) { f = *reinterpret_cast<const f32x4 *>(sV + aoff + (s / KSW) * NT * PS + (s % KSW) * 4); };
+#pragma unroll
+        for (int s = 0; s < AD; ++s) fetch_a(s, af[s]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const f32x4 bfr = wq[s % R];
+            wq[s % R] = (s + R < NSTEP) ? wc[wofs(s + R)] : wn[wofs(s + R - NSTEP)];
+            if (s + AD < NSTEP) fetch_a(s + AD, af[(s + AD) % (AD + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                {   // the broadcast block id is an immediate
+                    f32x4 (&ac)[NRB] = acc[s / KSW];
+                    const float av = af[s % (AD + 1)][j], bv = bfr[j];
+                    ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, ac[0], 4, 0, 0);
+                    if constexpr (NRB > 1) ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, ac[1], 4, 1, 0);
+                    if constexpr (NRB > 2) ac[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, ac[2], 4, 2, 0);
+                    if constexpr (NRB > 3) ac[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, ac[3], 4, 3, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        LZ_TS();
+        // ---- output transform, first half: point row pi times A (inside the lane), to LDS
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tile = rb * 4 + q;
+                if (tile < NT) {
+                    const float m0 = acc[0][rb][q], m1 = acc[1][rb][q], m2 = acc[2][rb][q], m3 = acc[3][rb][q];
+                    sX[((wv * NT + tile) * 2 + 0) * 64 + lane] = (m0 + m1) + m2;
+                    sX[((wv * NT + tile) * 2 + 1) * 64 + lane] = (m1 - m2) - m3;
+                }
+            }
+        if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
+        __syncthreads();
+        LZ_TS();
+        // ---- second half + epilogue: BN (+ action table) (+ residual) (+ ReLU) -> LDS (and the latent pool)
+        float outv[NOUT], xs[NOUT][3 * KH];
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n)  // all reads first: the stores below may alias them as far as the compiler knows
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int h = 0; h < KH; ++h) xs[n][r * KH + h] = sX[cx[n] + (h * 4 + r) * NT * 128];
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            float x0 = xs[n][0], x1 = xs[n][KH], x2 = xs[n][2 * KH];
+            if constexpr (KH == 2) { x0 += xs[n][1]; x1 += xs[n][3]; x2 += xs[n][5]; }
+            float v = (x0 + csg[n] * x1) + csg[n] * x2;
+            v += tv[n];
+            v = v * sc + sh;
+            v += rv[n];
+            v = relu ? fmaxf(v, 0.0f) : v;
+            outv[n] = v;
+            if (wv + NW * n < HW) sOut[cpix[n]] = v;
+        }
+        if (ly.gout) {
+            float *go = ly.gout + (size_t)b * HW * 64;
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n)
+                if (wv + NW * n < HW) go[(cpix[n] / PS) * 64 + lane] = outv[n];
+        }
+        if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
+        __syncthreads();
+        LZ_TS();
+    }
+    // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU: wave j runs job j
+    if (wv < a.nc1) {
+        const lz_c1_job &jb = a.c1[wv];
+        const float *sIn = smem + a.c1_in[wv] * BUF + kq4;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bfr = c1w[g];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = i * 16 + (lane & 15);
+                const int off = (row < HW) ? row * PS : zoff;
+                const float4 af = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af, j), vget(bfr, j), acc[i], 0, 0, 0);
+            }
+        }
+        const int col = lane & 15;
+        const float bi = jb.bias[col], sc = jb.scale[col], sh = jb.shift[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = i * 16 + 4 * (lane >> 4) + q;
+                if (row < HW) {
+                    const float v = (acc[i][q] + bi) * sc + sh;
+                    jb.out[((size_t)b * HW + row) * jb.out_stride + jb.out_off + col] = fmaxf(v, 0.0f);
+                }
+            }
+    }
+    LZ_TS();
+    if constexpr (TS) {
+        if (b == 0 && tid == 0 && a.tstamp) {
+            a.tstamp[0] = (unsigned long long)nts;
+            for (int i = 0; i < nts && i < 60; ++i) a.tstamp[1 + i] = sTS[i];
+        }
+    }
+#undef LZ_TS
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same chain for narrow networks (num_channels = 32 | 16: the reference's gomoku / tictactoe configs,
 // zoo/board_games/gomoku/config/gomoku_muzero_bot_mode_config.py:41-42, tictactoe/...:33-34).  One workgroup per root, activations in
 // LDS across layers; C / 16 output-channel tiles, so the four waves split as (N-tile, M-group): with 32 channels two waves share
@@ -1701,6 +2040,28 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         return;
     }
     auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + extra) * 4; };
+    // 6x6 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
+    static const char *direct = getenv("LZ_CHAIN_DIRECT");
+    bool wino = !direct && a.gw == 6 && a.gh == 6 && a.nlayers > 0;
+    for (int i = 0; i < a.nlayers; ++i) wino = wino && a.layer[i].uc != nullptr;
+    if (wino) {
+        static const char *w4 = getenv("LZ_CHAIN_W4");  // 4 waves (one per SIMD) instead of 8
+        const int nw = w4 ? 4 : 8;
+        const size_t lds = (size_t)(4 * 37 * 68 + 36 * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 16 * 9 * 68 + nw * 9 * 2 * 64) * 4;
+        const dim3 g(a.B), blk(nw * 64);
+#define LZ_W(NWv) \
+        if (step) { \
+            if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_w<6, 6, NWv, false, 1>), g, blk, lds, s, a, *step); \
+            else hipLaunchKernelGGL((k_chain_w<6, 6, NWv, false, 2>), g, blk, lds, s, a, *step); \
+        } else if (a.tstamp) { \
+            hipLaunchKernelGGL((k_chain_w<6, 6, NWv, true>), g, blk, lds, s, a, no_step{}); \
+        } else { \
+            hipLaunchKernelGGL((k_chain_w<6, 6, NWv>), g, blk, lds, s, a, no_step{}); \
+        }
+        if (nw == 4) { LZ_W(4) } else { LZ_W(8) }
+#undef LZ_W
+        return;
+    }
     if (step) {
         const bool ez = step->t.variant == LZ_TREE_EFFICIENTZERO;
         if (a.gw == 8) {

@@ -60,6 +60,7 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s);
 // and for the tail of the representation network.
 struct lz_chain_layer {
     const float *wf;       // fragment-packed weights [4][9][4][64][4]  (N-tile, tap, 16-channel group, lane, 4 floats)
+    const float *uc;       // optional: Winograd F(2x2,3x3) weights [16 points][16 channel quads][64 = cout][4] (k_chain_w, 6x6 grids)
     const float *scale, *shift;  // [64] folded BatchNorm
     int in, out, res;      // LDS buffer indices (0..3); res < 0: no residual
     int relu, act;         // act: add the one-hot-action table before BN (dynamics conv)

@@ -148,6 +148,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
               H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size, NRB = c.num_res_blocks > 0 ? c.num_res_blocks : 1;
     Builder b{m, ""};
+    const bool wchain = C == 64 && m->GW == 6 && m->GH == 6;  // the 6x6 chain runs on Winograd-transformed weights (k_chain_w)
     // ---- representation (common.py:266-365, :706-787)
     {
         if (!c.downsample) {
@@ -191,14 +192,15 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->rep_res.clear();
         for (int i = 0; i < NRB; ++i) {
             const std::string p = "representation_network.resblocks." + std::to_string(i);
-            m->rep_res.push_back(b.resconv(p, 1, C, C));
-            m->rep_res.push_back(b.resconv(p, 2, C, C));
+            m->rep_res.push_back(b.resconv(p, 1, C, C, false, wchain));
+            m->rep_res.push_back(b.resconv(p, 2, C, C, false, wchain));
         }
     }
     // ---- dynamics (efficientzero_model.py:427-569)
     {
         const std::string d = "dynamics_network.";
         m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + A, C);
+        if (wchain) m->dyn.uc = b.wino_chain(d + "conv.weight", C, C + A, C);
         // one-hot action planes: plane a is all ones inside the 6x6 latent, so its contribution to output
         // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image
         const HostTensor *w = b.get(d + "conv.weight", {C, C + A, 3, 3});
@@ -220,8 +222,8 @@ extern "C" int lz_model_finalize(lz_engine *e)
         }
         m->dyn_res.clear();
         for (int i = 0; i < NRB; ++i) {
-            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C));
-            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C));
+            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C, false, wchain));
+            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C, false, wchain));
         }
         m->rew_c = b.conv1x1(d + "conv1x1_reward", d + "norm_reward", HC, C);
         if (c.model_type == 1) {
@@ -263,8 +265,8 @@ extern "C" int lz_model_finalize(lz_engine *e)
         const std::string d = "prediction_network.";
         m->pred_res.clear();
         for (int i = 0; i < NRB; ++i) {
-            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C));
-            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C));
+            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C, false, wchain));
+            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C, false, wchain));
         }
         m->val_c = b.conv1x1(d + "conv1x1_value", d + "norm_value", HC, C);
         m->pol_c = b.conv1x1(d + "conv1x1_policy", d + "norm_policy", HC, C);
@@ -359,7 +361,7 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
 static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu, int act, float *gout)
 {
     lz_chain_layer l{};
-    l.wf = w.wf; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
+    l.wf = w.wf; l.uc = w.uc; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
     return l;
 }
 
@@ -824,7 +826,7 @@ extern "C" int lz_debug_read_chain_ts(unsigned long long *h_out)
 {
     LZ_REQUIRE(g_chain_ts != nullptr && h_out != nullptr, "LZ_DEBUG_CHAIN_TS was not set");
     LZ_HIP_CHECK(hipDeviceSynchronize());
-    LZ_HIP_CHECK(hipMemcpy(h_out, g_chain_ts, 32 * 8, hipMemcpyDeviceToHost));
+    LZ_HIP_CHECK(hipMemcpy(h_out, g_chain_ts, 64 * 8, hipMemcpyDeviceToHost));
     return LZ_OK;
 }
 static bool dbg_skip(char k)
@@ -866,7 +868,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
 #ifdef LZ_DEBUG_KNOBS
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
         if (getenv("LZ_DEBUG_CHAIN_TS")) {  // timing experiments only: stamps of the last launch, read with lz_debug_read_chain_ts
-            if (!g_chain_ts) (void)lz_dev_malloc((void **)&g_chain_ts, 32 * 8);
+            if (!g_chain_ts) (void)lz_dev_malloc((void **)&g_chain_ts, 64 * 8);
             ca.tstamp = g_chain_ts;
         }
 #endif
@@ -965,7 +967,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

@@ -25,10 +25,13 @@ for it in range(3):
     L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
     L.check(lib.lz_engine_synchronize(model.engine))
 lib.lz_debug_read_chain_ts.argtypes = [ctypes.c_void_p]
-out = np.zeros(32, np.uint64)
+out = np.zeros(64, np.uint64)
 L.check(lib.lz_debug_read_chain_ts(out.ctypes.data))
 n = int(out[0]); ts = out[1:1 + n].astype(np.int64)
-names = ["staged", "sync"] + [x for l in range(5) for x in ("L%d loop start" % l, "L%d loop end" % l, "L%d epilogue" % l, "L%d barrier" % l)] + ["end"]
+if n > 30:   # Winograd chain (k_chain_w), timing instance
+    names = ["staged", "sync"] + [x for l in range(5) for x in ("L%d patch read" % l, "L%d V written" % l, "L%d epi operands" % l, "L%d barrier" % l, "L%d products" % l, "L%d row sums" % l, "L%d barrier " % l, "L%d combine" % l, "L%d barrier  " % l)] + ["end"]
+else:
+    names = ["staged", "sync"] + [x for l in range(5) for x in ("L%d loop start" % l, "L%d loop end" % l, "L%d epilogue" % l, "L%d barrier" % l)] + ["end"]
 print("stamps:", n)
 for i in range(1, n):
     print("%-16s +%7d cycles   (t=%7d, ~%5.1f us at 2.0 GHz)" % (names[i] if i < len(names) else i, ts[i] - ts[i - 1], ts[i] - ts[0], (ts[i] - ts[0]) / 2000.0))
