@@ -962,11 +962,21 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     // the first layer's weights are requested before anything else -- except with the tree step in the prologue: a whole layer of
     // fragments (256 registers) cannot stay live across it, so they are requested right after it, under the latent's staging
     if constexpr (TREE == 0) fill_ring();
+    // 1x1 head convolutions at the end of the kernel: unit = (job, 16-pixel tile).  8 waves: wave j < nc1 runs tile 0 and the remainder
+    // pixels (4 of 36, on the 4x4x1 instruction) of job j, wave nc1 + j its tile 1; 4 waves: wave j runs all tiles of job j.  Each wave
+    // requests its job's weights and epilogue operands now (after the products they would be an exposed L2 round trip in the tail).
+    constexpr bool C1SPLIT = NW == 8 && (HW % 16) != 0 && (HW % 16) <= 4 && HW / 16 == 2;
+    const int nj = max(a.nc1, 1);
+    const int c1j = C1SPLIT ? wv % nj : min(wv, nj - 1);   // this wave's job
     float4 c1w[4];
+    float4 c1b, c1s, c1t;   // of output channels 4 (lane >> 4) .. + 3
     {
-        const float *cw = a.c1[min(wv, max(a.nc1 - 1, 0))].w;
+        const lz_c1_job &jb = a.c1[c1j];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(cw + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
+        for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(jb.w + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
+        c1b = *reinterpret_cast<const float4 *>(jb.bias + (lane >> 4) * 4);
+        c1s = *reinterpret_cast<const float4 *>(jb.scale + (lane >> 4) * 4);
+        c1t = *reinterpret_cast<const float4 *>(jb.shift + (lane >> 4) * 4);
     }
     int g_slot = 0, g_action = 0;
     if constexpr (TREE != 0) {
@@ -1202,37 +1212,54 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
         __syncthreads();
         LZ_TS();
     }
-    // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU: wave j runs job j
-    if (wv < a.nc1) {
-        const lz_c1_job &jb = a.c1[wv];
-        const float *sIn = smem + a.c1_in[wv] * BUF + kq4;
-        f32x4 acc[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU.  The weights are the A operand: D[channel][pixel] leaves a lane with
+    // four consecutive channels of one pixel, so a tile goes out as one coalesced 1 KB store (the transposed product took 12
+    // scattered 4-byte stores per lane: 2 k cycles of the kernel's tail)
+    auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {   // c1b / c1s / c1t are those of channel quad cq
+        float4 v;
+        v.x = fmaxf((acc[0] + c1b.x) * c1s.x + c1t.x, 0.0f);
+        v.y = fmaxf((acc[1] + c1b.y) * c1s.y + c1t.y, 0.0f);
+        v.z = fmaxf((acc[2] + c1b.z) * c1s.z + c1t.z, 0.0f);
+        v.w = fmaxf((acc[3] + c1b.w) * c1s.w + c1t.w, 0.0f);
+        *reinterpret_cast<float4 *>(jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + cq * 4) = v;
+    };
+    auto c1_tile = [&](int job, int i) {   // 16 pixels from 16 i
+        const float *sIn = smem + a.c1_in[job] * BUF + kq4;
+        const int row = i * 16 + (lane & 15);
+        const int off = (row < HW) ? row * PS : zoff;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bfr = c1w[g];
+            const float4 xf = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = i * 16 + (lane & 15);
-                const int off = (row < HW) ? row * PS : zoff;
-                const float4 af = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(af, j), vget(bfr, j), acc[i], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(c1w[g], j), vget(xf, j), acc, 0, 0, 0);
         }
-        const int col = lane & 15;
-        const float bi = jb.bias[col], sc = jb.scale[col], sh = jb.shift[col];
+        if (row < HW) c1_store(a.c1[job], row, lane >> 4, acc);
+    };
+    // remainder pixels 32 .. 35: 16 blocks of (4 channels) x (4 pixels), block = (k quarter, channel quad) -- the lane layout the weight
+    // fragment already has; the four k-quarter partial sums are added across lanes (every quarter then holds the total), and of the
+    // four lanes that hold (quad cg, pixel j) the one whose k quarter equals cg stores: its epilogue operands are the right quad's
+    auto c1_rem = [&](int job) {
+        const float *sIn = smem + a.c1_in[job] * BUF + kq4;
+        const int row = (HW / 16) * 16 + (lane & 3);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int g = 0; g < 4; ++g) {
+            const float4 xf = *reinterpret_cast<const float4 *>(sIn + row * PS + g * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = i * 16 + 4 * (lane >> 4) + q;
-                if (row < HW) {
-                    const float v = (acc[i][q] + bi) * sc + sh;
-                    jb.out[((size_t)b * HW + row) * jb.out_stride + jb.out_off + col] = fmaxf(v, 0.0f);
-                }
-            }
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vget(c1w[g], j), vget(xf, j), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = xor32_sum(xor16_sum(acc[q]));
+        const int cg = (lane >> 2) & 3;
+        if ((lane >> 4) == cg) c1_store(a.c1[job], row, cg, acc);
+    };
+    if constexpr (C1SPLIT) {
+        if (wv < a.nc1) { c1_tile(c1j, 0); c1_rem(c1j); }
+        else if (wv < 2 * a.nc1) c1_tile(c1j, 1);
+    } else if (wv < a.nc1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) c1_tile(wv, i);
     }
     LZ_TS();
     if constexpr (TS) {
