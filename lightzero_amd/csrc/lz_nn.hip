@@ -1764,7 +1764,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 // ------------------------------------------------------------------------------------------------
 constexpr int EPB = 4;
 constexpr int MAXH = 4;
-struct head_pack { lz_head_desc h[MAXH]; };
+struct head_pack { lz_head_desc h[MAXH]; unsigned long long *ts; };   // ts: debugging (s_memtime stamps of workgroup 0), null in production
 
 // block-wide reduction of N values per thread (max or sum); result broadcast to every thread
 template <int N, bool IS_MAX, int NWAVES>
@@ -1831,12 +1831,16 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
         }
     }
     const float b1v = h.b1[min(u, HID - 1)], s1v = h.s1[min(u, HID - 1)], t1v = h.t1[min(u, HID - 1)];
+    const bool stamp = hp.ts && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#define LZ_HTS(i) do { if (stamp) hp.ts[i] = __builtin_readcyclecounter(); } while (0)
+    LZ_HTS(0);
     for (int i = tid; i < EPB * (K1 / 4); i += NTHR) {  // 16-channel runs are contiguous: float4 loads
         const int e = i / (K1 / 4), k = (i - e * (K1 / 4)) * 4, b = min(b0 + e, B - 1);
         *reinterpret_cast<float4 *>(xs + e * K1 + k) =
             *reinterpret_cast<const float4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
     }
     __syncthreads();
+    LZ_HTS(1);
     // ---- layer 1: HID units x 8 K-parts; a unit's row is read 128 B at a time by its 8 lanes
     {
         float acc[EPB];
@@ -1870,6 +1874,7 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
         }
     }
     __syncthreads();
+    LZ_HTS(2);
     // ---- layer 2 on the transposed weights (already in registers)
     float lg[NPT][EPB];
 #pragma unroll
@@ -1890,6 +1895,7 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
             if (ok && h.out_logits && b0 + e < B) h.out_logits[(size_t)(b0 + e) * h.NOUT + n] = acc[e];
         }
     }
+    LZ_HTS(3);
     if (!h.categorical) return;
     float m[EPB];
 #pragma unroll
@@ -1899,6 +1905,7 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
         for (int i = 1; i < NPT; ++i) m[e] = fmaxf(m[e], lg[i][e]);
     }
     block_reduce_n<EPB, true, NWAVES>(m, scr);
+    LZ_HTS(4);
     float ss[2 * EPB];
 #pragma unroll
     for (int e = 0; e < EPB; ++e) {
@@ -1916,6 +1923,7 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
         ss[2 * e + 1] = s1;
     }
     block_reduce_n<2 * EPB, false, NWAVES>(ss, scr);
+    LZ_HTS(5);
     if (tid < EPB && b0 + tid < B) {
         // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
         float s0 = ss[0], s1 = ss[1];
@@ -1933,6 +1941,185 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
         const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
         h.out_scalar[b0 + tid] = sgn * (t * t - 1.0f);
     }
+    LZ_HTS(6);
+#undef LZ_HTS
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same heads on the matrix pipe (K1 a multiple of 64 up to 576, NOUT <= 640): four roots per workgroup are exactly the four rows
+// of v_mfma_f32_4x4x1_f32, whose 16 blocks = (k quarter) x (quad of output units).  Phase stamps of the VALU kernel above showed
+// where its 15 k cycles go: 3.8 k until the rows arrive (queued behind 151 KB of weights), 3.1 k in layer 1 (every thread re-reads
+// its k slice of the four rows from LDS: 295 KB of LDS traffic for 9 KB of data), 3.4 k in layer 2, 4.2 k in the softmax's block
+// reductions.  Here: rows are requested first; layer 1 = 36 MFMAs per wave (waves = 4 k quarters x 2 halves of the hidden units),
+// 9 LDS reads per wave; layer 2 = 8 MFMAs per group of 16 outputs (waves take groups w, w + 8, ...), weights straight from L2 in the
+// [HID/4][NOUT][4] layout the VALU kernel uses; after the k-quarter partial sums are added across lanes every quarter holds all four
+// roots, so quarter q keeps root q: max / exp / sums then run on 16-lane DPP rows and 8 x 4 values cross the waves.
+// grid = (ceil(B / 4), nheads), block = 512.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_max(float v)   // max over the 16 lanes of a DPP row, in every lane of the row
+{
+    int x = __float_as_int(v);
+#define LZ_DPPR(ctrl) __int_as_float(__builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false))
+    v = fmaxf(v, LZ_DPPR(0xB1)); x = __float_as_int(v);
+    v = fmaxf(v, LZ_DPPR(0x4E)); x = __float_as_int(v);
+    v = fmaxf(v, LZ_DPPR(0x141)); x = __float_as_int(v);
+    v = fmaxf(v, LZ_DPPR(0x140));
+#undef LZ_DPPR
+    return v;
+}
+
+__global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
+{
+    constexpr int HID = 32, MAXG = 9, MAXT = 5;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const lz_head_desc &h = hp.h[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n16 = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.x * EPB, K1 = h.K1, NOUT = h.NOUT, NG1 = K1 >> 6;   // 16-wide k groups per k-quarter wave
+    float *xs = smem;                    // [4][K1]
+    float *part = xs + EPB * K1;         // [8 waves][4 roots][16 units]
+    float *hid = part + 8 * 64;          // [4][32]
+    float *scrm = hid + EPB * HID;       // [8 waves][4 roots]
+    float *scrs = scrm + 32;             // [8 waves][4 roots][2]
+    const bool stamp = hp.ts && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#define LZ_HTS(i) do { if (stamp) hp.ts[i] = __builtin_readcyclecounter(); } while (0)
+    // ---- requests, in the order of use (a wave's loads return in order): the four rows, layer-1 fragments, layer-2 fragments
+    constexpr int NXV = (EPB * 576 / 4 + 511) / 512;
+    f32x4 xv[NXV];   // (native vectors: an array of HIP's float4 struct lands in scratch memory here)
+#pragma unroll
+    for (int u = 0; u < NXV; ++u) {
+        const int i = min(tid + 512 * u, EPB * (K1 / 4) - 1);
+        const int e = i / (K1 / 4), k = (i - e * (K1 / 4)) * 4, b = min(b0 + e, B - 1);
+        xv[u] = *reinterpret_cast<const f32x4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
+    }
+    const int kw = wv & 3, uh = wv >> 2;   // layer 1: this wave's k quarter and half of the hidden units
+    f32x4 w1f[MAXG];
+    {
+        const float *wr = h.w1 + (size_t)(16 * uh + n16) * K1 + (size_t)kw * NG1 * 16 + kq * 4;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) w1f[g] = *reinterpret_cast<const f32x4 *>(wr + min(g, NG1 - 1) * 16);
+    }
+    f32x4 w2f[MAXT][2];
+    float b2v[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int n = min(16 * (wv + 8 * t) + n16, NOUT - 1);
+        b2v[t] = h.b2[n];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) w2f[t][sp] = *reinterpret_cast<const f32x4 *>(h.w2t + ((size_t)(4 * sp + kq) * NOUT + n) * 4);
+    }
+    const int hu = tid & 31;
+    const float b1v = h.b1[hu], s1v = h.s1[hu], t1v = h.t1[hu];
+    LZ_HTS(0);
+#pragma unroll
+    for (int u = 0; u < NXV; ++u) {
+        const int i = tid + 512 * u;
+        if (i < EPB * (K1 / 4)) *reinterpret_cast<f32x4 *>(xs + (size_t)i * 4) = xv[u];
+    }
+    __syncthreads();
+    LZ_HTS(1);
+    // ---- layer 1: D[root][unit] partial over this wave's k quarter (and, inside the instruction, over the four k of a step)
+    {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *xa = xs + (lane & 3) * K1 + kw * NG1 * 16 + kq * 4;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (g < NG1) {   // wave-uniform
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + g * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], w1f[g][j], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = xor32_sum(xor16_sum(acc[i]));
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[(wv * 4 + i) * 16 + n16] = acc[i];
+        }
+    }
+    __syncthreads();
+    if (tid < EPB * HID) {   // (root, unit): the four k quarters in order, then bias, BatchNorm, ReLU
+        const int r = tid >> 5, u = tid & 31, w0 = (u >> 4) * 4, n = u & 15;
+        float sum = part[((w0 + 0) * 4 + r) * 16 + n];
+        sum += part[((w0 + 1) * 4 + r) * 16 + n];
+        sum += part[((w0 + 2) * 4 + r) * 16 + n];
+        sum += part[((w0 + 3) * 4 + r) * 16 + n];
+        hid[r * HID + u] = fmaxf((sum + b1v) * s1v + t1v, 0.0f);
+    }
+    __syncthreads();
+    LZ_HTS(2);
+    // ---- layer 2: output groups wv, wv + 8, ...; after the reduction lane (quarter q, n) keeps root q
+    float lg[MAXT];
+    {
+        f32x4 a2[2];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) a2[sp] = *reinterpret_cast<const f32x4 *>(hid + (lane & 3) * HID + 16 * sp + kq * 4);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            lg[t] = -__builtin_inff();
+            if (16 * (wv + 8 * t) < NOUT) {   // wave-uniform
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2[sp][j], w2f[t][sp][j], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = xor32_sum(xor16_sum(acc[i]));
+                const float mine = kq == 0 ? acc[0] : kq == 1 ? acc[1] : kq == 2 ? acc[2] : acc[3];
+                const int n = 16 * (wv + 8 * t) + n16;
+                if (n < NOUT) {
+                    lg[t] = mine + b2v[t];
+                    if (h.out_logits && b0 + kq < B) h.out_logits[(size_t)(b0 + kq) * NOUT + n] = lg[t];
+                }
+            }
+        }
+    }
+    LZ_HTS(3);
+    if (!h.categorical) return;
+    // ---- softmax . support of root kq on the 16-lane row, then across the 8 waves
+    float m = lg[0];
+#pragma unroll
+    for (int t = 1; t < MAXT; ++t) m = fmaxf(m, lg[t]);
+    m = row16_max(m);
+    if (n16 == 0) scrm[wv * 4 + kq] = m;
+    __syncthreads();
+    m = scrm[kq];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, scrm[w * 4 + kq]);
+    LZ_HTS(4);
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int n = 16 * (wv + 8 * t) + n16;
+        if (n < NOUT) {
+            const float ex = expf(lg[t] - m);
+            s0 += ex;
+            s1 += ex * (h.support_min + (float)n);
+        }
+    }
+    s0 = group_sum<16>(s0);
+    s1 = group_sum<16>(s1);
+    if (n16 == 0) { scrs[(wv * 4 + kq) * 2] = s0; scrs[(wv * 4 + kq) * 2 + 1] = s1; }
+    __syncthreads();
+    LZ_HTS(5);
+    if (tid < EPB && b0 + tid < B) {
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { t0 += scrs[(w * 4 + tid) * 2]; t1 += scrs[(w * 4 + tid) * 2 + 1]; }
+        // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
+        const float value = t1 / t0;
+        const float eps = 0.001f;
+        float t = fabsf(value) + 1.0f;
+        t = t + eps;
+        t = 0.004f * t;
+        t = 1.0f + t;
+        t = sqrtf(t);
+        t = t - 1.0f;
+        t = t / 0.002f;
+        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
+        h.out_scalar[b0 + tid] = sgn * (t * t - 1.0f);
+    }
+    LZ_HTS(6);
+#undef LZ_HTS
 }
 
 }  // namespace
@@ -2186,9 +2373,12 @@ void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s)
     else launch_lstm_m<64>(a, s);
 }
 
+unsigned long long *lz_debug_heads_ts = nullptr;   // timing experiments (debug build): device buffer of 8 stamps, see tools/heads_timing.py
+
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s)
 {
     head_pack hp;
+    hp.ts = lz_debug_heads_ts;
     int k1max = 0;
     for (int i = 0; i < nheads && i < MAXH; ++i) {
         hp.h[i] = heads[i];
@@ -2196,7 +2386,15 @@ void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipS
     }
     const size_t lds = ((size_t)EPB * k1max + (size_t)EPB * HID + 8 * 8) * 4;
     static const char *narrow = getenv("LZ_HEADS_256");
+    static const char *valu = getenv("LZ_HEADS_VALU");   // the VALU kernel instead of the MFMA one
     if (HID != 32) return;
+    bool mm = !valu && !narrow;
+    for (int i = 0; i < nheads && i < MAXH; ++i) mm = mm && (heads[i].K1 & 63) == 0 && heads[i].K1 <= 576 && heads[i].NOUT <= 640;
+    if (mm) {
+        const size_t lds2 = ((size_t)EPB * k1max + 8 * 64 + EPB * 32 + 32 + 64) * 4;
+        hipLaunchKernelGGL(k_heads_mm, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
+        return;
+    }
     if (narrow) hipLaunchKernelGGL((k_heads<32, 256>), dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B);
     else hipLaunchKernelGGL((k_heads<32, 512>), dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds, s, hp, B);
 }

@@ -129,6 +129,7 @@ struct lz_head_desc {
     float *out_scalar;     // [B] (categorical)
 };
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s);
+extern unsigned long long *lz_debug_heads_ts;   // null in production
 
 // Dense layer for the vector-observation (MLP) model family, split over the chip in both dimensions:
 //   out = epilogue( T(x) . W^T + bias ),   T = the PRODUCER's deferred LayerNorm / activation / residual, applied on load

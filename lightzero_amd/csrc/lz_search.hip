@@ -829,6 +829,13 @@ extern "C" int lz_debug_read_chain_ts(unsigned long long *h_out)
     LZ_HIP_CHECK(hipMemcpy(h_out, g_chain_ts, 64 * 8, hipMemcpyDeviceToHost));
     return LZ_OK;
 }
+extern "C" int lz_debug_read_heads_ts(unsigned long long *h_out)   // LZ_DEBUG_HEADS_TS=1: stamps of the last k_heads launch (workgroup 0)
+{
+    LZ_REQUIRE(lz_debug_heads_ts != nullptr && h_out != nullptr, "LZ_DEBUG_HEADS_TS was not set");
+    LZ_HIP_CHECK(hipDeviceSynchronize());
+    LZ_HIP_CHECK(hipMemcpy(h_out, lz_debug_heads_ts, 8 * 8, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}
 static bool dbg_skip(char k)
 {
     const char *v = getenv("LZ_DEBUG_SKIP");
@@ -867,6 +874,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
         ca.nc1 = 3;
 #ifdef LZ_DEBUG_KNOBS
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
+        if (getenv("LZ_DEBUG_HEADS_TS") && !lz_debug_heads_ts) (void)lz_dev_malloc((void **)&lz_debug_heads_ts, 8 * 8);
         if (getenv("LZ_DEBUG_CHAIN_TS")) {  // timing experiments only: stamps of the last launch, read with lz_debug_read_chain_ts
             if (!g_chain_ts) (void)lz_dev_malloc((void **)&g_chain_ts, 64 * 8);
             ca.tstamp = g_chain_ts;
@@ -967,7 +975,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;
