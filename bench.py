@@ -329,7 +329,7 @@ def main():
                        "row_bytes_per_env_step": W * 4, "all_gather_bytes_per_step_per_rank": (world - 1) * ENVS * W * 4 if world > 1 else 0,
                        "all_gather_overlapped": bool(world > 1 and backend == "nccl" and not args.sync_gather),
                        "debug_knobs": knobs},
-            "roofline": {"bound": "mfma", "kernel": "k_chain (per root: [tree step of the root: expand + backup + next selection, one wave, prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 1 launch/simulation; achieved counts only the convolution FLOPs over the whole launch)",
+            "roofline": {"bound": "mfma", "kernel": "k_chain_w (per root: [tree step of the root: expand + backup + next selection, one wave, prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident, 3x3 convolutions by Winograd F(2x2,3x3) on v_mfma_f32_4x4x1; 1 launch/simulation; achieved = the ALGORITHMIC (direct-form) convolution FLOPs of SURVEY 8d over the whole launch -- the kernel executes 0.59x as many matrix cycles for them)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes of profiles/%s, not re-measured in this run)" % TRAFFIC_FILE,
