@@ -932,7 +932,7 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? 16 : 32)>
+template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? (GW * GH > 36 ? 8 : 16) : 32)>
 __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename step_arg<TREE>::type step)
 {
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
@@ -943,11 +943,15 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert((GW % 2) == 0 && (GH % 2) == 0 && NITEM <= NTHR && NT * 4 == HW && NRB <= 4, "even grid, one transform item per thread");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 activation buffers of BUF floats, then
-    float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
-    float *sSS = sTab + HW * PS;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
+    // BIG (8x8: 16 tiles): 160 KB hold four activation buffers and V only if the row results alias V (one more barrier per layer)
+    // and the action-table slice is read from L2 by the one layer that needs it
+    constexpr bool BIG = HW > 36;
+    float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action (not BIG)
+    float *sSS = sTab + (BIG ? 0 : HW * PS);            // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
     float *sMisc = sSS + LZ_CHAIN_MAX_LAYERS * 128;     // 128 floats: time stamps (TS) | the tree step's selection
     float *sV = sMisc + 128;                            // [16 points][NT][PS] transformed input patches
-    float *sX = sV + 16 * NT * PS;                      // [KH][4 point rows][NT][2][64] row results of the output transform
+    float *sX = BIG ? sV : sV + 16 * NT * PS;           // [KH][4 point rows][NT][2][64] row results of the output transform
+    static_assert(!BIG || NW * NT * 128 <= 16 * NT * PS, "the row results fit into V");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pi = wv & 3, kh = wv >> 2;
     const int b = blockIdx.x;
     // step s of a wave: point 4 pi + s / KSW, channel quad kh KSW + s % KSW; weights [16 points][16 quads][64 lanes] float4
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
             if (idx < HW * 16) *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
         }
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
-        if (a.act_table) {
+        if (a.act_table && !BIG) {
             const float *tsrc = a.act_table + (size_t)g_action * HW * 64;
             float4 tv[NU];
 #pragma unroll
@@ -1127,7 +1131,8 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
         for (int n = 0; n < NOUT; ++n) tv[n] = rv[n] = 0.0f;
         if (tab) {   // wave-uniform: only the dynamics convolution reads the action table, only a block's second layer a residual
 #pragma unroll
-            for (int n = 0; n < NOUT; ++n) tv[n] = sTab[cpix[n]];
+            for (int n = 0; n < NOUT; ++n)
+                tv[n] = BIG ? a.act_table[(size_t)g_action * HW * 64 + (cpix[n] / PS) * 64 + lane] : sTab[cpix[n]];
         }
         if (hasres) {
 #pragma unroll
@@ -1167,6 +1172,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
             __builtin_amdgcn_sched_barrier(0);
         }
         LZ_TS();
+        if constexpr (BIG) __syncthreads();   // the row results overwrite V: every wave is done reading it
         // ---- output transform, first half: point row pi times A (inside the lane), to LDS
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
@@ -1946,7 +1952,7 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same heads on the matrix pipe (K1 a multiple of 64 up to 576, NOUT <= 640): four roots per workgroup are exactly the four rows
+// The same heads on the matrix pipe (K1 a multiple of 64 up to 1024, NOUT <= 640): four roots per workgroup are exactly the four rows
 // of v_mfma_f32_4x4x1_f32, whose 16 blocks = (k quarter) x (quad of output units).  Phase stamps of the VALU kernel above showed
 // where its 15 k cycles go: 3.8 k until the rows arrive (queued behind 151 KB of weights), 3.1 k in layer 1 (every thread re-reads
 // its k slice of the four rows from LDS: 295 KB of LDS traffic for 9 KB of data), 3.4 k in layer 2, 4.2 k in the softmax's block
@@ -1968,9 +1974,10 @@ __device__ __forceinline__ float row16_max(float v)   // max over the 16 lanes o
     return v;
 }
 
+template <int MAXG>   // K1 <= 64 MAXG: 9 (6x6 latent: 16 x 36 head inputs, LSTM 512) | 16 (8x8 latent: 16 x 64)
 __global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
 {
-    constexpr int HID = 32, MAXG = 9, MAXT = 5;
+    constexpr int HID = 32, MAXT = 5;   // NOUT <= 128 MAXT
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const lz_head_desc &h = hp.h[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n16 = lane & 15, kq = lane >> 4;
@@ -1983,7 +1990,7 @@ __global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
     const bool stamp = hp.ts && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
 #define LZ_HTS(i) do { if (stamp) hp.ts[i] = __builtin_readcyclecounter(); } while (0)
     // ---- requests, in the order of use (a wave's loads return in order): the four rows, layer-1 fragments, layer-2 fragments
-    constexpr int NXV = (EPB * 576 / 4 + 511) / 512;
+    constexpr int NXV = (EPB * 64 * MAXG / 4 + 511) / 512;
     f32x4 xv[NXV];   // (native vectors: an array of HIP's float4 struct lands in scratch memory here)
 #pragma unroll
     for (int u = 0; u < NXV; ++u) {
@@ -2254,25 +2261,28 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         return;
     }
     auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + extra) * 4; };
-    // 6x6 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
+    // 6x6 / 8x8 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
     static const char *direct = getenv("LZ_CHAIN_DIRECT");
-    bool wino = !direct && a.gw == 6 && a.gh == 6 && a.nlayers > 0;
+    bool wino = !direct && ((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) && a.nlayers > 0;
     for (int i = 0; i < a.nlayers; ++i) wino = wino && a.layer[i].uc != nullptr;
     if (wino) {
         static const char *w4 = getenv("LZ_CHAIN_W4");  // 4 waves (one per SIMD) instead of 8
-        const int nw = w4 ? 4 : 8;
-        const size_t lds = (size_t)(4 * 37 * 68 + 36 * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 16 * 9 * 68 + nw * 9 * 2 * 64) * 4;
+        const int nw = w4 ? 4 : 8, hw = a.gw * a.gh, nt = hw / 4;
+        const bool big = hw > 36;
+        const size_t lds = (size_t)(4 * (hw + 1) * 68 + (big ? 0 : hw * 68) + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 16 * nt * 68 +
+                                    (big ? 0 : nw * nt * 2 * 64)) * 4;
         const dim3 g(a.B), blk(nw * 64);
-#define LZ_W(NWv) \
+#define LZ_W(GWv, NWv) \
         if (step) { \
-            if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_w<6, 6, NWv, false, 1>), g, blk, lds, s, a, *step); \
-            else hipLaunchKernelGGL((k_chain_w<6, 6, NWv, false, 2>), g, blk, lds, s, a, *step); \
+            if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, false, 1>), g, blk, lds, s, a, *step); \
+            else hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, false, 2>), g, blk, lds, s, a, *step); \
         } else if (a.tstamp) { \
-            hipLaunchKernelGGL((k_chain_w<6, 6, NWv, true>), g, blk, lds, s, a, no_step{}); \
+            hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, true>), g, blk, lds, s, a, no_step{}); \
         } else { \
-            hipLaunchKernelGGL((k_chain_w<6, 6, NWv>), g, blk, lds, s, a, no_step{}); \
+            hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv>), g, blk, lds, s, a, no_step{}); \
         }
-        if (nw == 4) { LZ_W(4) } else { LZ_W(8) }
+        if (a.gw == 6) { if (nw == 4) { LZ_W(6, 4) } else { LZ_W(6, 8) } }
+        else { LZ_W(8, 8) }   // (8x8 has no 4-wave instance: its 512 transform items are one per thread of 8 waves)
 #undef LZ_W
         return;
     }
@@ -2389,10 +2399,11 @@ void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipS
     static const char *valu = getenv("LZ_HEADS_VALU");   // the VALU kernel instead of the MFMA one
     if (HID != 32) return;
     bool mm = !valu && !narrow;
-    for (int i = 0; i < nheads && i < MAXH; ++i) mm = mm && (heads[i].K1 & 63) == 0 && heads[i].K1 <= 576 && heads[i].NOUT <= 640;
+    for (int i = 0; i < nheads && i < MAXH; ++i) mm = mm && (heads[i].K1 & 63) == 0 && heads[i].K1 <= 1024 && heads[i].NOUT <= 640;
     if (mm) {
         const size_t lds2 = ((size_t)EPB * k1max + 8 * 64 + EPB * 32 + 32 + 64) * 4;
-        hipLaunchKernelGGL(k_heads_mm, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
+        if (k1max <= 576) hipLaunchKernelGGL(k_heads_mm<9>, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
+        else hipLaunchKernelGGL(k_heads_mm<16>, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
         return;
     }
     if (narrow) hipLaunchKernelGGL((k_heads<32, 256>), dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B);

@@ -148,7 +148,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
               H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size, NRB = c.num_res_blocks > 0 ? c.num_res_blocks : 1;
     Builder b{m, ""};
-    const bool wchain = C == 64 && m->GW == 6 && m->GH == 6;  // the 6x6 chain runs on Winograd-transformed weights (k_chain_w)
+    const bool wchain = C == 64 && ((m->GW == 6 && m->GH == 6) || (m->GW == 8 && m->GH == 8));  // these chains run on Winograd-transformed weights (k_chain_w)
     // ---- representation (common.py:266-365, :706-787)
     {
         if (!c.downsample) {
