@@ -236,8 +236,8 @@ int lz_mlp_ensure_pools(lz_roots *r)
     auto take = [&](size_t bytes) { size_t o = off; off = align_up_(off + bytes, 256); return o; };
     const size_t o_lat = take(NN * B * L * 4), o_h = take(NN * B * H * 4), o_c = take(NN * B * H * 4), o_vp = take(NN * B * 4),
                  o_val = take(NN * B * 4), o_lg = take(NN * B * PA * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
-                 o_tr = take(NN * 5 * B * 4), o_tp = take(B * 4), o_z = take(B * 4), o_nz = take(B * std::max<size_t>(PA, r->t.A) * 4),
-                 o_no = take(B * 4);
+                 o_tr = take(NN * 5 * B * 4), o_z = take(B * 4),
+                 o_tp = take((2 * B + B * std::max<size_t>(PA, r->t.A)) * 4);   // [to_play | noise offsets | noise]: one upload per prepare
     size_t o_mt[14];
     for (int i = 0; i < 14; ++i) o_mt[i] = take(B * W * 4);
     hipError_t err = lz_dev_malloc((void **)&r->pool_slab, off);
@@ -250,7 +250,7 @@ int lz_mlp_ensure_pools(lz_roots *r)
     r->sim_vp = (float *)(base + o_vp); r->sim_value = (float *)(base + o_val); r->sim_logits = (float *)(base + o_lg);
     r->dbg_logits[0] = (float *)(base + o_d0); r->dbg_logits[1] = (float *)(base + o_d1);
     r->trace = (int32_t *)(base + o_tr); r->d_to_play = (int32_t *)(base + o_tp); r->d_zero_vp = (float *)(base + o_z);
-    r->d_noise = (float *)(base + o_nz); r->d_noise_off = (int32_t *)(base + o_no);
+    r->d_noise_off = r->d_to_play + B; r->d_noise = (float *)(r->d_noise_off + B);
     for (int i = 0; i < 14; ++i) r->mt[i] = (float *)(base + o_mt[i]);
     r->t_hbn = r->mt[13];
     LZ_HIP_CHECK(hipMemsetAsync(r->d_zero_vp, 0, B * 4, r->eng->stream));

@@ -319,7 +319,8 @@ static int ensure_pools(lz_roots *r)
                  o_vp = take(NN * B * 4), o_val = take(NN * B * 4), o_lg = take(NN * B * A * 4),
                  o_x1 = take(B * HW * C * 4), o_x2 = take(B * HW * C * 4), o_x3 = take(B * HW * C * 4),
                  o_rx = take(B * HW * HC * 4), o_pv = take(B * HW * 2 * HC * 4), o_hbn = take(B * H * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
-                 o_tr = take(NN * 5 * B * 4), o_tp = take(B * 4), o_z = take(B * 4), o_nz = take(B * A * 4), o_no = take(B * 4);
+                 o_tr = take(NN * 5 * B * 4), o_z = take(B * 4),
+                 o_tp = take((2 * B + B * A) * 4);   // [to_play B | noise offsets B | noise <= B A]: one upload per prepare
     hipError_t err = lz_dev_malloc((void **)&r->pool_slab, off);
     if (err != hipSuccess) {
         lz_set_error("hipMalloc(%zu bytes) for the latent/LSTM pools failed: %s", off, hipGetErrorString(err));
@@ -332,7 +333,7 @@ static int ensure_pools(lz_roots *r)
     r->t_rx = (float *)(base + o_rx); r->t_pv = (float *)(base + o_pv); r->t_hbn = (float *)(base + o_hbn);
     r->dbg_logits[0] = (float *)(base + o_d0); r->dbg_logits[1] = (float *)(base + o_d1);
     r->trace = (int32_t *)(base + o_tr); r->d_to_play = (int32_t *)(base + o_tp); r->d_zero_vp = (float *)(base + o_z);
-    r->d_noise = (float *)(base + o_nz); r->d_noise_off = (int32_t *)(base + o_no);
+    r->d_noise_off = r->d_to_play + B; r->d_noise = (float *)(r->d_noise_off + B);
     LZ_HIP_CHECK(hipMemsetAsync(r->d_zero_vp, 0, B * 4, r->eng->stream));
     return LZ_OK;
 }
@@ -626,6 +627,13 @@ extern "C" int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_di
 //                 the stacked [C, H, W] input; the whole vector for vector observations) -- what obs_segment holds for the step
 // ------------------------------------------------------------------------------------------------
 namespace {
+__device__ __forceinline__ uint64_t sel_mix64c(uint64_t z)   // the generator of k_select_action (lz_capi.hip): same seed, same draw
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
 __global__ __launch_bounds__(256) void k_pack_rows(lz_tree_dev t, const int32_t *__restrict__ dist, const int32_t *__restrict__ cnt,
                                                    const float *__restrict__ values, const float *__restrict__ pred,
                                                    const int32_t *__restrict__ pos, const double *__restrict__ ent,
@@ -651,6 +659,86 @@ __global__ __launch_bounds__(256) void k_pack_rows(lz_tree_dev t, const int32_t 
         for (int j = 0; j < A; ++j) row[8 + j] = j < n ? (float)dist[(size_t)b * A + j] / sum_visits : 0.0f;
         for (int j = 0; j < A; ++j) row[8 + A + j] = 0.0f;
         for (int j = 0; j < n; ++j) row[8 + A + t.legal[(size_t)b * A + j]] = 1.0f;
+    }
+    if (frame_floats > 0) {
+        const float *src = obs + (size_t)b * obs_floats + (obs_floats - frame_floats);
+        float *dst = row + 8 + 2 * A;
+        for (int i = tid; i < frame_floats; i += 256) dst[i] = src[i];
+    }
+}
+// The same row, with everything before it, in ONE launch (A <= 64): readout of the root (get_distributions / get_values,
+// cnode.cpp:389-419), select_action (lzero/policy/utils.py:637-661, float64 like k_select_action and with the same draw) on the lanes of
+// wave 0 -- lane j owns legal action j, the order-sensitive sums (normaliser, cumulative distribution, entropy) run in list order over
+// v_readlane -- and the row.  The header words and the root's policy logits are ALSO written straight into pinned host memory
+// (h_header / h_logits are device-visible pointers), the time steps are read from it: the read-back is this kernel plus one
+// synchronisation instead of three kernels, four copies and the gaps between them (~35 us per collect step).
+__device__ __forceinline__ double rl_d(double v, int lane)
+{
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__global__ __launch_bounds__(256) void k_collect_rows(lz_tree_dev t, double inv_temperature, int deterministic, uint64_t seed,
+                                                      const float *__restrict__ pred, const float *__restrict__ root_logits, int PA,
+                                                      const int32_t *__restrict__ to_play, const int32_t *__restrict__ timestep,
+                                                      const float *__restrict__ obs, int obs_floats, int frame_floats,
+                                                      float *__restrict__ rows, int row_words, float *__restrict__ h_header,
+                                                      float *__restrict__ h_logits)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, A = t.A, NN = t.NN;
+    float *row = rows + (size_t)b * row_words;
+    if (tid < 64) {
+        const int lane = tid, n = t.n_legal[b];
+        const bool live = lane < n;
+        const int act = live ? t.legal[(size_t)b * A + lane] : 0;
+        const int c = live ? __float_as_int(t.edge[((size_t)b * NN) * A + act].y) : -1;
+        const double pw = live ? pow((double)c, inv_temperature) : 0.0;
+        double sum = 0.0;
+        int total = 0, best = -1, arg = 0;
+        for (int j = 0; j < n; ++j) {
+            sum += rl_d(pw, j);
+            const int cj = __builtin_amdgcn_readlane(c, j);
+            total += cj;
+            if (cj > best) { best = cj; arg = j; }  // np.argmax: first maximum
+        }
+        const double p = live ? pw / sum : 0.0;
+        const double plog = (live && p > 0.0) ? p * log2(p) : 0.0;
+        const double u = (double)(sel_mix64c(sel_mix64c(seed) ^ (uint64_t)b) >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+        double acc = 0.0, H = 0.0;
+        int pick = -1, last = 0;
+        for (int j = 0; j < n; ++j) {
+            const double pj = rl_d(p, j);
+            if (pj > 0.0) { H -= rl_d(plog, j); last = j; }
+            acc += pj;
+            if (pick < 0 && u < acc) pick = j;  // searchsorted(cumsum(p), u, side='right') like np.random.choice
+        }
+        if (pick < 0) pick = last;
+        const int pos = deterministic ? arg : pick;
+        const int rv = t.root_visit[b];
+        const float value = (rv == 0) ? 0.0f : t.root_vsum[b] / (float)rv;
+        const float sum_visits = total == 0 ? 1e-6f : (float)total;  // game_segment.py:244-246
+        const int hw = 8 + 2 * A;
+        float *hh = h_header + (size_t)b * hw;
+        // header words: lane 0 the eight scalars, lanes < A the visit share of list position `lane` and the mask bit of action `lane`
+        if (lane == 0) {
+            const float w0 = (float)__builtin_amdgcn_readlane(act, pos), w4 = (float)to_play[b], w5 = timestep ? (float)timestep[b] : -1.0f;
+            const float w3 = pred[b], w6 = (float)H, w7 = (float)n;
+            row[0] = w0; row[1] = 0.0f; row[2] = value; row[3] = w3; row[4] = w4; row[5] = w5; row[6] = w6; row[7] = w7;
+            hh[0] = w0; hh[1] = 0.0f; hh[2] = value; hh[3] = w3; hh[4] = w4; hh[5] = w5; hh[6] = w6; hh[7] = w7;
+        }
+        if (lane < A) {
+            const float share = live ? (float)c / sum_visits : 0.0f;
+            row[8 + lane] = share;
+            hh[8 + lane] = share;
+            // mask[a] = 1 iff a is in the legal list: lane a scans the list (n <= A <= 64)
+            float mk = 0.0f;
+            for (int j = 0; j < n; ++j) if (__builtin_amdgcn_readlane(act, j) == lane) mk = 1.0f;
+            row[8 + A + lane] = mk;
+            hh[8 + A + lane] = mk;
+        }
+        if (h_logits && lane < PA) h_logits[(size_t)b * PA + lane] = root_logits[(size_t)b * PA + lane];
+    } else if (h_logits && PA > 64) {
+        for (int i = tid; i < PA; i += 256) if (i >= 64) h_logits[(size_t)b * PA + i] = root_logits[(size_t)b * PA + i];
     }
     if (frame_floats > 0) {
         const float *src = obs + (size_t)b * obs_floats + (obs_floats - frame_floats);
@@ -691,6 +779,18 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
         LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
         r->results_bytes = bytes;
     }
+    float *hh = (float *)((char *)r->h_results + ts_bytes);
+    if (A <= 64) {   // one launch; headers / logits land in the pinned block, the time steps are read from it
+        if (h_timestep) memcpy(r->h_results, h_timestep, B * 4);
+        hipLaunchKernelGGL(k_collect_rows, dim3((unsigned)B), dim3(256), 0, s, t, 1.0 / temperature, deterministic, seed, r->sim_value,
+                           r->sim_logits, (int)PA, r->d_to_play, h_timestep ? (const int32_t *)r->h_results : nullptr, d_obs, obs_floats,
+                           frame_floats, d_rows, row_words, hh, h_policy_logits ? hh + B * hw : nullptr);
+        LZ_HIP_CHECK(hipGetLastError());
+        LZ_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(h_header, hh, B * hw * 4);
+        if (h_policy_logits) memcpy(h_policy_logits, hh + B * hw, B * PA * 4);
+        return LZ_OK;
+    }
     double *d_ent = (double *)r->d_results;
     int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B, *d_ts = d_pos + B;
     float *d_val = (float *)(d_ts + B), *d_lg = d_val + B;
@@ -705,7 +805,6 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
     LZ_HIP_CHECK(hipGetLastError());
     // the header words of every row (what the collector needs to step the environments) and the root policy logits come back
     // in one synchronisation; the frames stay in HBM for the all-gather
-    float *hh = (float *)((char *)r->h_results + ts_bytes);
     LZ_HIP_CHECK(hipMemcpy2DAsync(hh, hw * 4, d_rows, (size_t)row_words * 4, hw * 4, B, hipMemcpyDeviceToHost, s));
     if (h_policy_logits) {
         LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
@@ -791,18 +890,18 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
         }
         if (!r->prep_done) LZ_HIP_CHECK(hipEventCreateWithFlags(&r->prep_done, hipEventDisableTiming));
         else LZ_HIP_CHECK(hipEventSynchronize(r->prep_done));  // the previous upload has left the buffer
-        int32_t *hp = (int32_t *)r->h_prep;
+        int32_t *hp = (int32_t *)r->h_prep;   // same layout as the device block at d_to_play: to_play | noise offsets | noise
         memcpy(hp, h_to_play, B * 4);
-        LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, hp, B * 4, hipMemcpyHostToDevice, s));
+        size_t up = B * 4;
         if (h_noises_flat) {
             int32_t *ho = hp + B;
             size_t acc = 0;
             for (size_t i = 0; i < B; ++i) { ho[i] = (int32_t)acc; acc += (size_t)r->h_n_legal[i]; }
             memcpy(hp + 2 * B, h_noises_flat, n_noise * 4);
-            LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise_off, ho, B * 4, hipMemcpyHostToDevice, s));
-            LZ_HIP_CHECK(hipMemcpyAsync(r->d_noise, hp + 2 * B, n_noise * 4, hipMemcpyHostToDevice, s));
+            up = (2 * B + n_noise) * 4;
             d_noise = r->d_noise;
         }
+        LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, hp, up, hipMemcpyHostToDevice, s));
         LZ_HIP_CHECK(hipEventRecord(r->prep_done, s));
     }
     if (t.variant == LZ_TREE_GUMBEL_MUZERO)  // roots.prepare(noise_w, noises, reward_roots = 0, pred_values, policy_logits, to_play), gumbel_muzero.py:562
