@@ -774,18 +774,20 @@ __global__ void k_select_action(lz_tree_dev t, double inv_temperature, int deter
         const int slot = sampled ? t.rep[(size_t)b * t.NN * A + j] : t.legal[(size_t)b * A + j];
         return __float_as_int(edge0[slot].y);
     };
+    // N^(1/T); T = 1 needs no pow (x^1 is x) -- k_collect_rows (lz_search.hip) computes the same expression
+    auto powt = [&](int c) -> double { return inv_temperature == 1.0 ? (double)c : pow((double)c, inv_temperature); };
     double sum = 0.0;
     int best = -1, arg = 0;
     for (int j = 0; j < n; ++j) {
         const int c = count(j);
-        sum += pow((double)c, inv_temperature);
+        sum += powt(c);
         if (c > best) { best = c; arg = j; }  // np.argmax: first maximum
     }
     const double u = (double)(sel_mix64(sel_mix64(seed) ^ (uint64_t)b) >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
     double acc = 0.0, H = 0.0;
     int pick = -1, last = 0;
     for (int j = 0; j < n; ++j) {
-        const double p = pow((double)count(j), inv_temperature) / sum;
+        const double p = powt(count(j)) / sum;
         if (p > 0.0) { H -= p * log2(p); last = j; }
         acc += p;
         if (pick < 0 && u < acc) pick = j;  // searchsorted(cumsum(p), u, side='right') like np.random.choice

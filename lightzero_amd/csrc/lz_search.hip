@@ -692,7 +692,8 @@ __global__ __launch_bounds__(256) void k_collect_rows(lz_tree_dev t, double inv_
         const bool live = lane < n;
         const int act = live ? t.legal[(size_t)b * A + lane] : 0;
         const int c = live ? __float_as_int(t.edge[((size_t)b * NN) * A + act].y) : -1;
-        const double pw = live ? pow((double)c, inv_temperature) : 0.0;
+        // N^(1/T); T = 1 (the collector's setting for most of training) needs no pow: x^1 is x
+        const double pw = live ? (inv_temperature == 1.0 ? (double)c : pow((double)c, inv_temperature)) : 0.0;
         double sum = 0.0;
         int total = 0, best = -1, arg = 0;
         for (int j = 0; j < n; ++j) {
