@@ -280,7 +280,9 @@ int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_dist, int32_t
  *   (d_obs; NULL = the batch of the latest lz_initial_inference).
  * d_rows: DEVICE [root_num][row_words] -- the payload of the trajectory all-gather (lightzero_amd/shard.py), it never
  * crosses PCIe here.  h_header [root_num][8+2A]: host copy of the row headers (what stepping the environments needs);
- * h_policy_logits [root_num][A] may be NULL.  One readout, one select_action, one pack launch, one synchronisation. */
+ * h_policy_logits [root_num][A] may be NULL.  A <= 64: ONE launch (readout + select_action + packing; the header words and the
+ * logits are written by the kernel into the library's pinned host block) and one synchronisation; A > 64: readout, select_action and
+ * pack launches, two copies, one synchronisation. */
 int lz_rows_width(int action_space_size, int frame_floats);
 int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
                           int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, float *h_header,
