@@ -284,6 +284,10 @@ int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_dist, int32_t
  * logits are written by the kernel into the library's pinned host block) and one synchronisation; A > 64: readout, select_action and
  * pack launches, two copies, one synchronisation. */
 int lz_rows_width(int action_space_size, int frame_floats);
+/* Host only: the Winograd F(2x2, 3x3) weight transform U = G g G^T the convolution kernels ingest (computed in binary64, rounded once),
+ * in a plain layout: w [cout][cin][3][3] (the reference's Conv2d weight, e.g. common.py:309-327 ResBlock convolutions) ->
+ * u [16 points][cin][cout].  Exists so that a CPU test can pin the transform against an independent statement of the algorithm. */
+int lz_wino_weights(const float *w, int cout, int cin, float *u);
 int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
                           int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, float *h_header,
                           float *h_policy_logits);

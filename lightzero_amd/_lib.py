@@ -108,6 +108,7 @@ def lib():
         "lz_recurrent_inference": [P, c_i32p, P, P, P, ctypes.c_int, ctypes.c_int],
         "lz_engine_model_uid": [P],
         "lz_rows_width": [ctypes.c_int, ctypes.c_int],
+        "lz_wino_weights": [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p],
         "lz_roots_collect_rows": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, P, ctypes.c_int, P, P, ctypes.c_int, c_f32p, P],
     }
     for name, argtypes in sig.items():

@@ -751,6 +751,21 @@ __global__ __launch_bounds__(256) void k_collect_rows(lz_tree_dev t, double inv_
 
 extern "C" int lz_rows_width(int action_space_size, int frame_floats) { return 8 + 2 * action_space_size + frame_floats; }
 
+// The weight transform of the Winograd kernels in a plain layout (host only, no device needed): u[p][ci][co] = (G g G^T)[p / 4][p % 4]
+// of filter w[co][ci][3][3] -- what Builder::wino / wino_chain permute into fragment order.  tests/test_wino_cpu.py checks it (and
+// the transform matrices the kernels hard-code) against an independent NumPy statement of F(2x2, 3x3).
+extern "C" int lz_wino_weights(const float *w, int cout, int cin, float *u)
+{
+    LZ_REQUIRE(w != nullptr && u != nullptr && cout > 0 && cin > 0, "invalid argument");
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double U[4][4];
+            Builder::wino_u(w + ((size_t)co * cin + ci) * 9, U);
+            for (int p = 0; p < 16; ++p) u[((size_t)p * cin + ci) * cout + co] = (float)U[p / 4][p % 4];
+        }
+    return LZ_OK;
+}
+
 extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
                                      int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
                                      float *h_header, float *h_policy_logits)
