@@ -1601,6 +1601,13 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     const int H = a.H, KX = a.KX;
     const size_t slot = (size_t)a.B * H;
     // weight ring first: its L2 round trip overlaps the staging
+#ifdef LZ_DEBUG_KNOBS
+    // timing experiment (debug build, LZ_DEBUG_LSTM_HOTW=1; results are then wrong): every step re-reads the first 12 fragments, i.e.
+    // the weight stream comes from L1 instead of L2 -- how much of the launch is the L2 stream?
+    const int wmul = a.debug_hot_weights ? 0 : 1;
+#else
+    constexpr int wmul = 1;
+#endif
     const float4 *wp = reinterpret_cast<const float4 *>(a.wf) + ((size_t)(tile * 4 + wv) * NKB) * 64 + lane;
     float4 wq[R];
 #pragma unroll
@@ -1719,7 +1726,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
             }
         }
         const float4 bfr = wq[s % R];
-        if (s + R < NKB) wq[s % R] = wp[(size_t)(s + R) * 64];
+        if (s + R < NKB) wq[s % R] = wp[(size_t)((s + R) * wmul + (s % R) * (1 - wmul)) * 64];
         float4 n0 = a0, n1 = a1;
         if (s + 1 < NKB && (KXB == 0 || s + 1 != KXB)) {
             n0 = *reinterpret_cast<const float4 *>(sA0 + (s + 1) * 16);

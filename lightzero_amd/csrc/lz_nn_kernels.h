@@ -110,6 +110,7 @@ struct lz_lstm_args {
     float *h_out, *c_out;    // [B][H] destination slot of the pools
     float *hbn_out;          // [B][H] relu(bn(h'))
     int B, KX, H;
+    int debug_hot_weights;   // timing experiment of the debug build only (see k_lstm2); 0 in production
 };
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s);
 // host: wcat [4H][K] (row 4*unit + gate) -> fragment order for lz_lstm_args::wf (4*H*K floats)

@@ -1015,6 +1015,9 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
+#ifdef LZ_DEBUG_KNOBS
+    l.debug_hot_weights = getenv("LZ_DEBUG_LSTM_HOTW") ? 1 : 0;
+#endif
     // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
     // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
     if (c.model_type == 0 && !dbg_skip('l')) lz_launch_lstm(l, s);
