@@ -228,6 +228,9 @@ def main():
         buf = i & 1
         if pending[buf] is not None:  # the all-gather that still reads this row buffer (issued two steps ago)
             pending[buf].wait()
+            # wait() orders torch's stream behind the collective; the rows are rewritten on the ENGINE's stream, so the host confirms
+            # the completion (free: the collective was issued two 3.5 ms steps ago)
+            torch.cuda.current_stream().synchronize()
             pending[buf] = None
         for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
             L.check(lib.lz_initial_inference(r._h, obs_parts[k].data_ptr()))
