@@ -187,6 +187,7 @@ struct lz_tree_step {
     lz_traverse_args a;
     float delta;
     const int32_t *vtp;
+    unsigned long long *ts;    // timing experiments (debug build, LZ_DEBUG_TREE_TS): s_memtime stamps of root 0's step; null in production
 };
 // select_action for every root (lz_capi.hip): d_pos [B] int32, d_ent [B] float64
 void lz_launch_select_action(const lz_tree_dev &t, double inv_temperature, int deterministic, uint64_t seed, int32_t *d_pos,

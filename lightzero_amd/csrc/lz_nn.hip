@@ -987,8 +987,9 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
         int32_t *s_sel = reinterpret_cast<int32_t *>(sMisc + 120);
         if (wv == 0)
             dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
-                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel);
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts);
         __syncthreads();
+        if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
         g_slot = s_sel[0];
         g_action = s_sel[1];
         fill_ring();
@@ -1072,6 +1073,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     LZ_TS();
     __syncthreads();
     LZ_TS();
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[6] = __builtin_readcyclecounter(); }
 
     for (int L = 0; L < a.nlayers; ++L) {
         const lz_chain_layer &ly = a.layer[L];

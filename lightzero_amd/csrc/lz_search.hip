@@ -951,6 +951,14 @@ extern "C" int lz_debug_read_heads_ts(unsigned long long *h_out)   // LZ_DEBUG_H
     LZ_HIP_CHECK(hipMemcpy(h_out, lz_debug_heads_ts, 8 * 8, hipMemcpyDeviceToHost));
     return LZ_OK;
 }
+static unsigned long long *g_tree_ts = nullptr;
+extern "C" int lz_debug_read_tree_ts(unsigned long long *h_out)   // LZ_DEBUG_TREE_TS=1: stamps of the tree step in the last fused chain launch
+{
+    LZ_REQUIRE(g_tree_ts != nullptr && h_out != nullptr, "LZ_DEBUG_TREE_TS was not set");
+    LZ_HIP_CHECK(hipDeviceSynchronize());
+    LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_ts, 8 * 8, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}
 static bool dbg_skip(char k)
 {
     const char *v = getenv("LZ_DEBUG_SKIP");
@@ -1075,6 +1083,12 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
             if (fuse) {
                 step.t = t; step.new_node = slot; step.discount = ta.discount; step.vps = vp; step.values = val; step.logits = lg;
                 step.horizon = horizon; step.a = ta; step.delta = delta; step.vtp = r->d_to_play;
+#ifdef LZ_DEBUG_KNOBS
+                if (getenv("LZ_DEBUG_TREE_TS")) {   // timing experiments only: stamps of root 0's step in the last fused launch
+                    if (!g_tree_ts) (void)lz_dev_malloc((void **)&g_tree_ts, 8 * 8);
+                    step.ts = g_tree_ts;
+                }
+#endif
                 pending = true;
             } else if (!dbg_skip('t')) {
                 lz_tree_launch_backprop_traverse(t, slot, ta.discount, vp, val, lg, horizon, ta, delta, r->d_to_play, s);

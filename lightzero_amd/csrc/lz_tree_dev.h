@@ -470,9 +470,12 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
                                              const float *__restrict__ vps, const float *__restrict__ values,
                                              const float *__restrict__ logits, int horizon, const lz_traverse_args &a,
                                              float delta_max, const int32_t *__restrict__ vtp_in, float4 *s_tree,
-                                             int32_t *s_out = nullptr)
+                                             int32_t *s_out = nullptr, unsigned long long *ts = nullptr)
 {
     const int lane = threadIdx.x;
+    const bool stamp = ts && b == 0 && lane == 0;   // timing experiments only (ts is null in production)
+#define LZ_TTS(i) do { if (stamp) ts[i] = __builtin_readcyclecounter(); } while (0)
+    LZ_TTS(0);
     const int A = t.A;
     const int nn = new_node + 1;        // nodes 0 .. new_node exist after this step
     float4 *s_edge = s_tree;                                              // [nn][A]
@@ -525,6 +528,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     const bool use_tab = new_node < 64;
     const float nf = (float)lane, tab_pbc = lz_logf((nf + (float)a.pb_c_base + 1) / (float)a.pb_c_base) + a.pb_c_init, tab_sq = sqrtf(nf);
     __builtin_amdgcn_sched_barrier(0);
+    LZ_TTS(1);
 #pragma unroll
     for (int u = 0; u < UE; ++u) {
         const int i = u * 64 + lane;
@@ -582,6 +586,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_TTS(2);
     tview v = g;
     v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
     v.path_node = s_pn; v.path_act = s_pa;
@@ -589,7 +594,10 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_TTS(3);
     dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
+    LZ_TTS(4);
+#undef LZ_TTS
 }
 
 }  // namespace

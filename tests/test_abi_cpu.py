@@ -53,6 +53,6 @@ def test_release_library_has_no_skip_work_knobs():
     liblz_mi355_dbg.so (-DLZ_DEBUG_KNOBS); the release library must not even contain their names."""
     from lightzero_amd import build
     blob = open(build.build(), "rb").read()
-    for knob in (b"LZ_DEBUG_SKIP", b"LZ_DEBUG_CHAIN_LAYERS", b"LZ_DEBUG_CHAIN_TS", b"LZ_DEBUG_LSTM_ROWS", b"LZ_DEBUG_LSTM_HOTW", b"LZ_DEBUG_HEADS_TS"):
+    for knob in (b"LZ_DEBUG_SKIP", b"LZ_DEBUG_CHAIN_LAYERS", b"LZ_DEBUG_CHAIN_TS", b"LZ_DEBUG_LSTM_ROWS", b"LZ_DEBUG_LSTM_HOTW", b"LZ_DEBUG_HEADS_TS", b"LZ_DEBUG_TREE_TS"):
         assert knob not in blob, knob
     assert not hasattr(ctypes.CDLL(build.LIB), "lz_debug_read_chain_ts")

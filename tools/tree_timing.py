@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Debugging aid: s_memtime stamps of root 0's tree step inside the last tree-fused chain launch of a search (debug build of the library).
+    python tools/tree_timing.py"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LZ_DEBUG_TREE_TS", "1"); os.environ.setdefault("LZ_NO_GRAPH", "1")   # (the stamp buffer is allocated at the first launch: not inside a capture)
+from lightzero_amd import build as _b
+os.environ.setdefault("LZ_MI355_LIB", _b.DBG_LIB)
+assert os.path.exists(os.environ["LZ_MI355_LIB"]), "build the debug library first: python -m lightzero_amd.build --debug-knobs"
+import torch
+from lightzero_amd import _lib as L
+from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+from lightzero_amd.model.synthetic import efficientzero_state_dict
+lib = L.lib()
+model = EfficientZeroModel(action_space_size=6).load_state_dict(efficientzero_state_dict(seed=0, action_space_size=6))
+B, S = 256, 50
+roots = ez_tree.Roots(B, [list(range(6))] * B, action_space_size=6, max_simulations=S, engine=model.engine); roots._ensure(6)
+obs = torch.rand(B, 4, 96, 96).cuda()
+for it in range(3):
+    L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
+    L.check(lib.lz_roots_prepare_from_inference(roots._h, 0.25, None, L.i32([-1] * B)))
+    L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+    L.check(lib.lz_engine_synchronize(model.engine))
+lib.lz_debug_read_tree_ts.argtypes = [ctypes.c_void_p]
+out = np.zeros(8, np.uint64)
+L.check(lib.lz_debug_read_tree_ts(out.ctypes.data))
+ts = out[:7].astype(np.int64)
+names = ["step entered", "all loads requested", "tree staged in LDS", "expand + backup", "selection", "barrier (other waves released)", "latent / tables staged"]
+for i in range(1, 7):
+    print("%-32s +%6d cycles   (t=%6d)" % (names[i], ts[i] - ts[i - 1], ts[i] - ts[0]))
