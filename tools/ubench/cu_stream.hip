@@ -3,7 +3,7 @@
 //   mode 0: global_load_dwordx4 from the L2-resident buffer            mode 1: the same with the non-temporal hint
 //   mode 2: every wave re-reads one 4 KB window (L1-resident: the TA -> VGPR return path alone)
 //   mode 3: global_load_lds_dwordx4 (DMA into LDS, no VGPR return), L2-resident buffer
-//   mode 4: ds_read_b128 only (LDS -> VGPR), for scale
+//   mode 4: ds_read_b128 only (LDS -> VGPR), for scale        modes 5 / 6 / 7: ds_write_b128 / b64 / b32 only (VGPR -> LDS)
 // Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o libcustream.so cu_stream.hip.  Driver: tools/ubench/cu_stream.py
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,6 +32,15 @@ __global__ __launch_bounds__(512) void k_cu_stream(const f32x4 *__restrict__ w, 
 #endif
         } else if (MODE == 4) {
             for (int i = 0; i < kb_per_wave; ++i) acc += lds[(i % DEPTH) * blockDim.x];
+        } else if (MODE == 5) {   // 1 KB per wave and store
+            for (int i = 0; i < kb_per_wave; ++i) { lds[(i % DEPTH) * blockDim.x] = acc; acc[0] += 1.0f; }
+        } else if (MODE == 6) {   // 512 B per wave and store: twice the stores for the same bytes
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 *l2 = reinterpret_cast<f32x2 *>(smem) + threadIdx.x;
+            for (int i = 0; i < 2 * kb_per_wave; ++i) { l2[(i % DEPTH) * blockDim.x] = (f32x2){acc[0], acc[1]}; acc[0] += 1.0f; }
+        } else if (MODE == 7) {
+            float *l1 = smem + threadIdx.x;
+            for (int i = 0; i < 4 * kb_per_wave; ++i) { l1[(i % DEPTH) * blockDim.x] = acc[0]; acc[0] += 1.0f; }
         } else {
             f32x4 q[DEPTH];
 #pragma unroll
@@ -65,7 +74,8 @@ extern "C" int custream_run(const void *d_w, int kb_per_wave, int mode, int reps
     const size_t lds = (size_t)16 * threads * 16;
     hipEventRecord(e0, 0);
 #define RUN(M) hipLaunchKernelGGL((k_cu_stream<M, 16>), dim3(blocks), dim3(threads), lds, 0, (const f32x4 *)d_w, kb_per_wave, reps, (float *)d_out, (unsigned long long *)d_cycles)
-    if (mode == 0) RUN(0); else if (mode == 1) RUN(1); else if (mode == 2) RUN(2); else if (mode == 3) RUN(3); else RUN(4);
+    if (mode == 0) RUN(0); else if (mode == 1) RUN(1); else if (mode == 2) RUN(2); else if (mode == 3) RUN(3); else if (mode == 4) RUN(4);
+    else if (mode == 5) RUN(5); else if (mode == 6) RUN(6); else RUN(7);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     hipEventElapsedTime(ms, e0, e1);
