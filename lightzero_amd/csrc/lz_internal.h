@@ -175,6 +175,7 @@ struct lz_traverse_args {
     int tiebreak;
     uint64_t seed;
     uint32_t counter;
+    int fresh_minmax = 0;      // k_traverse only: the first selection of a search starts a fresh CMinMaxStats (cminimax.cpp:6-10) itself
 };
 // one expand + backup + next-selection step for every root (dev_step_lds in lz_tree_dev.h), as run by k_backprop_traverse_lds
 // or by the convolution chain's prologue (lz_launch_chain with a step)

@@ -359,6 +359,12 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
     lz_launch_conv3x3(a, w.cin, stride, s);
 }
 
+__global__ void k_zero2(float4 *__restrict__ a, float4 *__restrict__ b, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) { a[i] = make_float4(0.f, 0.f, 0.f, 0.f); b[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+}
+
 static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu, int act, float *gout)
 {
     lz_chain_layer l{};
@@ -512,9 +518,15 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
         ca.nc1 = 2;
         lz_launch_chain(ca, s);
     }
-    if (H > 0) {
-        LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * H * 4, s));
-        LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
+    if (H > 0) {   // reward_hidden_state_roots = zeros (efficientzero_model.py:229-236): slot 0 of both pools, one launch
+        const size_t n4 = B * H / 4;
+        if ((B * H) % 4 == 0) {
+            hipLaunchKernelGGL(k_zero2, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4 *>(r->h_pool),
+                               reinterpret_cast<float4 *>(r->c_pool), n4);
+        } else {
+            LZ_HIP_CHECK(hipMemsetAsync(r->h_pool, 0, (size_t)B * H * 4, s));
+            LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
+        }
     }
     heads(r, r->sim_value, r->sim_logits, r->dbg_logits[0], false, nullptr, nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
@@ -744,7 +756,13 @@ __global__ __launch_bounds__(256) void k_collect_rows(lz_tree_dev t, double inv_
     if (frame_floats > 0) {
         const float *src = obs + (size_t)b * obs_floats + (obs_floats - frame_floats);
         float *dst = row + 8 + 2 * A;
-        for (int i = tid; i < frame_floats; i += 256) dst[i] = src[i];
+        if (((frame_floats | obs_floats | row_words | (2 * A)) & 3) == 0 && (((uintptr_t)obs | (uintptr_t)rows) & 15) == 0) {   // 16-byte aligned throughout
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            for (int i = tid; i < frame_floats / 4; i += 256) d4[i] = s4[i];
+        } else {
+            for (int i = tid; i < frame_floats; i += 256) dst[i] = src[i];
+        }
     }
 }
 }  // namespace
@@ -1039,9 +1057,9 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     const lz_tree_dev &t = r->t;
     const size_t B = t.B;
     const size_t A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
-    lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
     ta.counter = 0;
     if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
+        lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
         // SampledEfficientZeroMCTSCtree.search (mcts_ctree_sampled.py:480-600): the leaf's K actions are drawn on the
         // device from the (mu | sigma) the network just produced (or copied from the injected draws of a parity run)
         const size_t KD = (size_t)t.A * t.D;
@@ -1065,7 +1083,9 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
         }
         return;
     }
+    ta.fresh_minmax = 1;   // ... which the first selection starts itself
     lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
+    ta.fresh_minmax = 0;
     // The expand + backup of simulation s and the selection of simulation s + 1 are one tree step per root; for the conv
     // models it runs in the prologue of simulation s + 1's chain launch (same workgroup-per-root mapping) while the tree
     // of a root still fits the LDS budget, else as its own launch.  LZ_NO_TREE_FUSE=1 keeps it separate (parity tests).

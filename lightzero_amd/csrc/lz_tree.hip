@@ -98,6 +98,11 @@ __global__ __launch_bounds__(64) void k_traverse(lz_tree_dev t, lz_traverse_args
     const tview v = global_view(t, b);
     tscal<NC> sc;
     load_scalars<NC>(t, b, sc);
+    if (a.fresh_minmax) {   // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779) without a launch of its own
+        sc.mn = LZ_FLOAT_MAX;
+        sc.mx = LZ_FLOAT_MIN;
+        if (threadIdx.x == 0) { t.minmax[2 * b] = LZ_FLOAT_MAX; t.minmax[2 * b + 1] = LZ_FLOAT_MIN; }
+    }
     dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp_in[b]);
 }
 
