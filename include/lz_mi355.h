@@ -154,6 +154,9 @@ int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records);
 /* Roots.get_distributions ([root_num][K] visit counts) / get_sampled_actions ([root_num][K][D]) */
 int lz_sroots_get_distributions(lz_roots *r, int32_t *h_out);
 int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out);
+/* the K actions of expanded node `node` of every root, [root_num][K][D] (node 0 = the roots, node s + 1 = the node expanded by
+ * simulation s): CNode::legal_actions after expand (cnode.cpp:238-327) -- observability for the exact replay gate */
+int lz_sroots_get_node_actions(lz_roots *r, int node, float *h_out);
 
 
 /* Gumbel MuZero -- replaces lzero/mcts/ctree/ctree_gumbel_muzero/gmz_tree.pyx (lib/cnode.cpp): roots created with
@@ -258,6 +261,12 @@ int lz_initial_inference(lz_roots *r, const float *d_obs);
 /* same from a HOST observation batch (staged through HBM; the PCIe copy is on the engine stream) */
 int lz_initial_inference_host(lz_roots *r, const float *h_obs);
 int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits);
+/* The reference's call order infers before the roots exist: network_output = model.initial_inference(obs); roots = MCTSCtree.roots(n,
+ * legal); roots.prepare(noise_w, noises, value_prefix_roots, policy_logits, to_play); search(roots, model, latent_state_roots,
+ * reward_hidden_state_roots, to_play) (lzero/policy/efficientzero.py:582-610).  The engine model infers into a handle of its own
+ * (src); this call moves that inference (slot 0 of the latent / LSTM pools, root predictions) device-to-device into the roots the
+ * caller prepared from host lists (dst, same engine / root_num / action space), after which lz_search(dst, ...) runs the fused loop. */
+int lz_roots_adopt_inference(lz_roots *dst, lz_roots *src);
 /* everything _forward_collect reads back after a fused search (efficientzero.py:616-643) in one readout launch, one
  * device-to-host copy and one synchronisation: get_distributions (+ counts), get_values, and the root predictions of
  * lz_initial_inference (h_pred_values / h_policy_logits may be NULL) */
@@ -277,7 +286,8 @@ int lz_roots_get_search_results_select(lz_roots *r, int32_t *h_out_dist, int32_t
  *   [5] timestep (h_timestep[i], -1 when NULL)  [6] visit-count entropy (bits)  [7] number of legal actions
  *   [8, 8+A) child visits / sum in legal-list order (game_segment.py:247-252)   [8+A, 8+2A) action mask
  *   [8+2A, 8+2A+frame_floats) the newest observation frame = the LAST frame_floats floats of each env's observation
- *   (d_obs; NULL = the batch of the latest lz_initial_inference).
+ *   (d_obs; NULL = the batch of the latest lz_initial_inference, whose buffer the caller must then keep alive and unchanged until
+ *   this call returns -- pass the pointer explicitly when an allocator may have recycled it).
  * d_rows: DEVICE [root_num][row_words] -- the payload of the trajectory all-gather (lightzero_amd/shard.py), it never
  * crosses PCIe here.  h_header [root_num][8+2A]: host copy of the row headers (what stepping the environments needs);
  * h_policy_logits [root_num][A] may be NULL.  A <= 64: ONE launch (readout + select_action + packing; the header words and the

@@ -75,6 +75,7 @@ def lib():
         "lz_sbatch_backpropagate": [P, ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, P],
         "lz_sroots_get_distributions": [P, c_i32p],
         "lz_sroots_get_sampled_actions": [P, c_f32p],
+        "lz_sroots_get_node_actions": [P, ctypes.c_int, c_f32p],
         "lz_sroots_set_given": [P, P, ctypes.c_int],
         "lz_roots_get_search_results": [P, c_i32p, c_i32p, c_f32p, P, P],
         "lz_roots_get_search_results_select": [P, c_i32p, c_i32p, c_f32p, P, P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, c_i32p, P],
@@ -93,6 +94,7 @@ def lib():
         "lz_initial_inference": [P, P],
         "lz_initial_inference_host": [P, c_f32p],
         "lz_roots_get_root_outputs": [P, c_f32p, c_f32p],
+        "lz_roots_adopt_inference": [P, P],
         "lz_roots_prepare_from_inference": [P, ctypes.c_float, P, c_i32p],
         "lz_search": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float],
         "lz_profile_enable": [P, ctypes.c_int],
@@ -154,12 +156,23 @@ def engine_for_new_model(device_index=None):
     return new_engine(device_index)
 
 
+_seed_counter = [0]
+
+
 def process_seed():
-    """Default seed of the device-side random streams (stochastic tie-breaks, sampled actions, select_action): drawn from
-    np.random -- so ``np.random.seed`` / the config seed govern it like they govern the reference's Dirichlet noise -- and mixed
-    with the rank, so that data-parallel collectors do not explore in lock-step."""
+    """Default seed of the device-side random streams (stochastic tie-breaks, sampled actions, select_action): derived from
+    np.random's state WITHOUT consuming it -- so ``np.random.seed`` / the config seed govern it like they govern the reference's
+    Dirichlet noise, and the noise stream itself does not shift with the number of Roots objects a run happens to build -- mixed
+    with a per-process counter (every Roots object gets its own stream) and the rank (data-parallel collectors do not explore in
+    lock-step)."""
+    import hashlib
     rank = int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")))
-    return (int(np.random.randint(0, 2 ** 62)) ^ ((rank + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1)
+    st = np.random.get_state()
+    h = hashlib.blake2b(digest_size=8)
+    h.update(np.asarray(st[1]).tobytes())
+    h.update(np.asarray([st[2], _seed_counter[0]], np.int64).tobytes())
+    _seed_counter[0] += 1
+    return (int.from_bytes(h.digest(), "little") ^ ((rank + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1)
 
 
 def f32(x):

@@ -322,6 +322,7 @@ extern "C" int lz_roots_prepare(lz_roots *r, float root_noise_weight, const floa
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     r->players = players_of(h_to_play, B);
+    r->h_to_play.assign(h_to_play, h_to_play + B);   // lz_roots_adopt_inference uploads it for the fused search
     r->prepared = true;
     r->traverse_count = 0;
     return LZ_OK;
@@ -495,6 +496,7 @@ extern "C" int lz_groots_prepare(lz_roots *r, float root_noise_weight, const flo
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     r->players = 1;
+    r->h_to_play.assign(h_to_play, h_to_play + r->t.B);
     r->prepared = true;
     r->traverse_count = 0;
     return LZ_OK;
@@ -897,6 +899,7 @@ extern "C" int lz_sroots_prepare(lz_roots *r, float root_noise_weight, const flo
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     r->players = players_of(h_to_play, (int)B);
+    r->h_to_play.assign(h_to_play, h_to_play + B);
     r->prepared = true;
     r->traverse_count = 0;
     return LZ_OK;
@@ -1008,6 +1011,24 @@ extern "C" int lz_sroots_get_sampled_actions(lz_roots *r, float *h_out)
     hipStream_t s = r->eng->stream;
     // actions of node 0 of every root: [B] strided blocks of K*D floats
     LZ_HIP_CHECK(hipMemcpy2DAsync(h_out, K * D * 4, t.actions, NN * K * D * 4, K * D * 4, B, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// the K actions of expanded node `node` (0 = root, s + 1 = the node expanded by simulation s) of every root: what the
+// reference keeps in CNode::legal_actions after expand (cnode.cpp:238-327).  Observability for the exact replay gate of the
+// fused sampled search: the device's own draws are injected into the CPU oracle.
+extern "C" int lz_sroots_get_node_actions(lz_roots *r, int node, float *h_out)
+{
+    int rc = sampled_check(r);
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(h_out != nullptr && r->prepared, "NULL output / roots not prepared");
+    const lz_tree_dev &t = r->t;
+    LZ_REQUIRE(node >= 0 && node < t.NN, "node out of range");
+    const size_t B = t.B, K = t.A, D = t.D, NN = t.NN;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpy2DAsync(h_out, K * D * 4, t.actions + (size_t)node * K * D, NN * K * D * 4, K * D * 4, B, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     return LZ_OK;
 }

@@ -153,6 +153,7 @@ struct lz_roots {
                                     // frame of every env-step row comes from here (lz_roots_collect_rows)
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
     std::vector<int32_t> h_n_legal;  // host copy of n_legal (noise offsets without a device round trip)
+    std::vector<int32_t> h_to_play;  // to_play of the last HOST-side prepare (lz_roots_prepare & co.): lz_roots_adopt_inference
     void *h_prep = nullptr;          // pinned staging of prepare_from_inference (noise | offsets | to_play), own buffer so that the
     size_t prep_bytes = 0;           // upload can stay asynchronous
     hipEvent_t prep_done = nullptr;  // recorded after that upload: the buffer is rewritten only once it has fired

@@ -294,7 +294,7 @@ int lz_roots_release_pools_if_stale(lz_roots *r)
         LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
         if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
         if (r->pool_slab) { (void)hipFree(r->pool_slab); r->pool_slab = nullptr; }
-        if (r->d_obs) { (void)hipFree(r->d_obs); r->d_obs = nullptr; }
+        if (r->d_obs) { if (r->last_obs == r->d_obs) r->last_obs = nullptr; (void)hipFree(r->d_obs); r->d_obs = nullptr; }
         if (r->d_results) { (void)hipFree(r->d_results); r->d_results = nullptr; }
         if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
         r->d_obs_bytes = 0;
@@ -545,12 +545,52 @@ extern "C" int lz_initial_inference_host(lz_roots *r, const float *h_obs)
     if (int rc = lz_roots_release_pools_if_stale(r)) return rc;
     const size_t n = (size_t)r->t.B * m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
     if (r->d_obs_bytes < n * 4) {
-        if (r->d_obs) { LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream)); (void)hipFree(r->d_obs); r->d_obs = nullptr; }
+        if (r->d_obs) {
+            LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
+            if (r->last_obs == r->d_obs) r->last_obs = nullptr;   // lz_roots_collect_rows must not read the freed staging buffer
+            (void)hipFree(r->d_obs); r->d_obs = nullptr;
+        }
         LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_obs, n * 4));
         r->d_obs_bytes = n * 4;
     }
     LZ_HIP_CHECK(hipMemcpyAsync(r->d_obs, h_obs, n * 4, hipMemcpyHostToDevice, r->eng->stream));
     return lz_initial_inference(r, r->d_obs);
+}
+
+// The reference's call order -- network_output = model.initial_inference(obs); roots = MCTSCtree.roots(...); roots.prepare(host
+// lists); search(roots, model, latent_state_roots, ...) (efficientzero.py:582-610) -- infers BEFORE the roots exist.  The engine
+// model then infers into a handle of its own (src) and the search adopts that inference into the prepared roots (dst): slot 0
+// of the latent / LSTM pools and the root predictions move device to device, to_play of the host-side prepare is uploaded.
+extern "C" int lz_roots_adopt_inference(lz_roots *dst, lz_roots *src)
+{
+    LZ_REQUIRE(dst != nullptr && src != nullptr && dst != src, "NULL / identical handles");
+    LZ_REQUIRE(dst->eng == src->eng, "the two roots live on different engines");
+    lz_model *m = dst->eng->model;
+    LZ_REQUIRE(m != nullptr && m->finalized, "no finalized model on this engine");
+    LZ_REQUIRE(src->inferred && src->pool_slab != nullptr && src->pool_model_uid == src->eng->model_uid, "the source roots hold no inference of the engine's current model");
+    LZ_REQUIRE(dst->t.B == src->t.B && dst->t.variant == src->t.variant && dst->t.A == src->t.A && dst->t.D == src->t.D, "the two roots differ in shape");
+    LZ_REQUIRE(dst->prepared && (int)dst->h_to_play.size() == dst->t.B, "adopt after a host-side Roots.prepare on the destination");
+    LZ_HIP_CHECK(hipSetDevice(dst->eng->device));
+    int rc = m->cfg.model_type >= 2 ? lz_mlp_ensure_pools(dst) : ensure_pools(dst);
+    if (rc != LZ_OK) return rc;
+    const size_t B = dst->t.B, C = m->cfg.num_channels, HW = m->HWl;
+    const size_t H = m->cfg.model_type >= 2 ? (size_t)lz_mlp_hidden_size(m) : (size_t)(m->cfg.model_type == 0 ? m->cfg.lstm_hidden_size : 0);
+    const size_t PA = m->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(m) : (size_t)dst->t.A;
+    hipStream_t s = dst->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(dst->latent_pool, src->latent_pool, B * HW * C * 4, hipMemcpyDeviceToDevice, s));
+    if (H) {
+        LZ_HIP_CHECK(hipMemcpyAsync(dst->h_pool, src->h_pool, B * H * 4, hipMemcpyDeviceToDevice, s));
+        LZ_HIP_CHECK(hipMemcpyAsync(dst->c_pool, src->c_pool, B * H * 4, hipMemcpyDeviceToDevice, s));
+    }
+    LZ_HIP_CHECK(hipMemcpyAsync(dst->sim_value, src->sim_value, B * 4, hipMemcpyDeviceToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(dst->sim_vp, src->sim_vp, B * 4, hipMemcpyDeviceToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(dst->sim_logits, src->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
+    LZ_HIP_CHECK(hipMemcpyAsync(dst->d_to_play, dst->h_to_play.data(), B * 4, hipMemcpyHostToDevice, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));   // h_to_play is pageable host memory
+    dst->inferred = true;
+    dst->inference_fresh = false;
+    dst->last_obs = src->last_obs;
+    return LZ_OK;
 }
 
 extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits)

@@ -22,6 +22,17 @@ from ... import _lib as L
 
 DEFAULT_MAX_SIMULATIONS = 512
 
+# The reference builds a fresh ``Roots`` for every forward (efficientzero.py:605).  A device handle owns HBM pools (trees, and
+# after an inference the latent / LSTM pools), so handles released by a dead ``Roots`` object are parked here -- keyed by
+# (engine, variant, root_num, action space, max_simulations) -- and re-armed (lz_roots_reset) by the next ``Roots`` of that shape
+# instead of being freed and re-allocated every env-step.
+_HANDLE_CACHE = {}
+_HANDLE_CACHE_DEPTH = 2
+
+
+def _engine_key(engine):
+    return getattr(engine, "value", engine)
+
 
 def make_module(variant, has_deterministic_flag):
     class MinMaxStatsList(object):
@@ -55,8 +66,9 @@ def make_module(variant, has_deterministic_flag):
             self._tiebreak = None  # None -> module default
             # the reference seeds its tie-break stream from the clock (srand(tv_usec) per traverse, cnode.cpp:901); here it follows
             # np.random's state and the rank (set_tiebreak(mode, seed) / the policies' ``mcts_seed`` pin it)
-            self._seed = L.process_seed()
+            self._seed = None      # drawn (L.process_seed) when the device handle is created, or inherited from a re-armed handle
             self._inferred_by = None
+            self._prep_args = None  # the last host-side prepare (replayed when the handle has to be re-created, _adopt)
             self._touched = False  # a prepare / inference has used the device handle
 
         @property
@@ -82,10 +94,25 @@ def make_module(variant, has_deterministic_flag):
             if self._A != int(A):
                 raise ValueError("policy_logits width %d != action_space_size %d" % (A, self._A))
             eng = self._engine if self._engine is not None else L.default_engine()
-            cnt = L.i32([len(l) for l in self._legal])
-            flat = L.i32([a for l in self._legal for a in l] or [0])
-            h = L.P()
-            L.check(L.lib().lz_roots_create(eng, variant, self.root_num, self._A, self._S, flat, cnt, ctypes.byref(h)))
+            if self._legal is None:  # the lists were last given as a mask (reset_mask): its flattened form is kept
+                cnt, flat = self._legal_cnt, self._legal_flat
+            else:
+                cnt = L.i32([len(l) for l in self._legal])
+                flat = L.i32([a for l in self._legal for a in l] or [0])
+            self._key = (_engine_key(eng), variant, self.root_num, self._A, self._S)
+            parked = _HANDLE_CACHE.get(self._key)
+            if parked:
+                # an unpinned seed stays the handle's: the captured search graph (keyed by it) is replayed instead of re-captured,
+                # and the random streams still advance through the device-resident epoch that every prepare bumps
+                h, seed0 = parked.pop()
+                if self._seed is None:
+                    self._seed = seed0
+                L.check(L.lib().lz_roots_reset(h, flat, cnt))
+            else:
+                h = L.P()
+                L.check(L.lib().lz_roots_create(eng, variant, self.root_num, self._A, self._S, flat, cnt, ctypes.byref(h)))
+                if self._seed is None:
+                    self._seed = L.process_seed()
             self._h = h
             mode = self._tiebreak if self._tiebreak is not None else (0 if has_deterministic_flag else 1)
             L.check(L.lib().lz_roots_set_tiebreak(self._h, mode, self._seed))
@@ -121,6 +148,7 @@ def make_module(variant, has_deterministic_flag):
                 raise ValueError("every root needs at least one legal action")
             flat = np.ascontiguousarray(np.nonzero(m)[1].astype(np.int32))  # row-major: ascending actions per root
             self._legal = None
+            self._legal_cnt, self._legal_flat = cnt, flat   # what _ensure needs to re-create the device handle
             self._n_noise = int(cnt.sum())
             if not keep_inference:
                 self._inferred_by = None
@@ -147,6 +175,7 @@ def make_module(variant, has_deterministic_flag):
                 raise ValueError("policy_logits_pool must be [root_num][action_space_size]")
             self._ensure(logits.shape[1])
             self._touched = True
+            self._prep_args = ("noise", (root_noise_weight, noises, value_prefix_pool, policy_logits_pool, to_play_batch))
             nz = L.f32([x for row in noises for x in row] or [0.0])
             want = self._want_noise()
             if nz.size < want:
@@ -160,6 +189,7 @@ def make_module(variant, has_deterministic_flag):
                 raise ValueError("policy_logits_pool must be [root_num][action_space_size]")
             self._ensure(logits.shape[1])
             self._touched = True
+            self._prep_args = ("no_noise", (value_prefix_pool, policy_logits_pool, to_play_batch))
             L.check(L.lib().lz_roots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), logits,
                                              L.i32(to_play_batch)))
 
@@ -264,16 +294,48 @@ def make_module(variant, has_deterministic_flag):
             L.check(L.lib().lz_roots_get_minmax(self._h, out))
             return out
 
-        def clear(self):
+        def clear(self, park=False):
             if self._h is not None:
-                L.lib().lz_roots_destroy(self._h)
+                parked = _HANDLE_CACHE.setdefault(getattr(self, "_key", None), []) if park and getattr(self, "_key", None) else None
+                if parked is not None and len(parked) < _HANDLE_CACHE_DEPTH:
+                    try:
+                        L.check(L.lib().lz_roots_enable_trace(self._h, 0))
+                        parked.append((self._h, self._seed))
+                    except Exception:
+                        L.lib().lz_roots_destroy(self._h)
+                else:
+                    L.lib().lz_roots_destroy(self._h)
                 self._h = None
 
         def __del__(self):
             try:
-                self.clear()
+                self.clear(park=True)   # the next Roots of this shape re-arms the handle (see _HANDLE_CACHE)
             except Exception:
                 pass
+
+        # ---- the reference's call order: model.initial_inference(obs) BEFORE the roots exist (efficientzero.py:582-610)
+        def _replay_prepare(self):
+            kind, args = self._prep_args
+            (self.prepare if kind == "noise" else self.prepare_no_noise)(*args)
+
+        def _adopt(self, src_roots, model, num_simulations=None):
+            """take over the inference an engine model left in ``src_roots`` (its own handle): these roots were built and prepared
+            from host lists afterwards, reference-style.  Moves them to the model's engine / a right-sized node pool first when
+            that is needed and possible (the prepare arguments are replayed)."""
+            if self._h is None or getattr(self, "_prep_args", None) is None:
+                raise L.LzError("search with HBM tokens needs roots.prepare(...) / prepare_no_noise(...) on these roots first")
+            mine = self._engine if self._engine is not None else L.default_engine()
+            move = _engine_key(mine) != _engine_key(model.engine)
+            shrink = num_simulations is not None and self._S >= 2 * int(num_simulations) and self._S == DEFAULT_MAX_SIMULATIONS
+            if move or shrink:
+                self.clear(park=True)
+                self._engine = model.engine
+                if shrink:
+                    self._S = int(num_simulations)
+                self._replay_prepare()
+            L.check(L.lib().lz_roots_adopt_inference(self._h, src_roots._h))
+            self._inferred_by = model
+            self._touched = True
 
     def _bind(roots, mm):
         if mm._bound is not roots:

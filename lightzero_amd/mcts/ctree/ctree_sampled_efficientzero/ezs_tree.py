@@ -88,6 +88,15 @@ class Roots(object):
             self._create(engine)
         self._touched = True
 
+    def _adopt(self, src_roots, model, num_simulations=None):
+        """take over the inference an engine model left in a handle of its own (model.initial_inference(obs) without roots,
+        the reference's call order): these roots were prepared from host lists afterwards"""
+        if getattr(self._engine, "value", self._engine) != getattr(model.engine, "value", model.engine):
+            raise L.LzError("these roots live on another engine than the model's: build them with Roots(..., engine=model.engine)")
+        L.check(L.lib().lz_roots_adopt_inference(self._h, src_roots._h))
+        self._inferred_by = model
+        self._touched = True
+
     def _take_given(self):
         rec = self._record
         self._record += 1
@@ -146,6 +155,13 @@ class Roots(object):
         out = np.zeros((self.root_num, self.K, self.D), np.float32)
         L.check(L.lib().lz_sroots_get_sampled_actions(self._h, out.reshape(-1)))
         return out.tolist()
+
+    def get_node_actions(self, node):
+        """the K actions of expanded node ``node`` of every root ([B][K][D]; node 0 = the roots, node s + 1 = the node
+        expanded by simulation s) -- observability: the exact replay gate injects the device's own draws into the oracle"""
+        out = np.zeros((self.root_num, self.K, self.D), np.float32)
+        L.check(L.lib().lz_sroots_get_node_actions(self._h, int(node), out.reshape(-1)))
+        return out
 
     def get_values(self):
         out = np.zeros(self.root_num, np.float32)

@@ -31,15 +31,77 @@ def _get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
-def _inverse_scalar_transform(logits, support_min, epsilon=0.001):
+def _inverse_scalar_transform(logits, support_min, epsilon=0.001, categorical=True, step=1.0):
     """InverseScalarTransform.__call__ (lzero/policy/scaling_transform.py:82-92) with the same torch ops, for the
-    foreign-model path (``logits``: torch tensor [B, support]); returns numpy [B, 1]."""
+    foreign-model path (``logits``: torch tensor [B, support], or [B, 1] scalars when not categorical); returns numpy [B, 1]."""
     import torch
-    support = (support_min + torch.arange(logits.shape[1], dtype=torch.float32, device=logits.device)).unsqueeze(0)
-    value_probs = torch.softmax(logits, dim=1)
-    value = value_probs.mul_(support).sum(1, keepdim=True)
+    if categorical:
+        support = (support_min + step * torch.arange(logits.shape[1], dtype=torch.float32, device=logits.device)).unsqueeze(0)
+        value_probs = torch.softmax(logits, dim=1)
+        value = value_probs.mul_(support).sum(1, keepdim=True)
+    else:
+        value = logits
     tmp = ((torch.sqrt(1 + 4 * epsilon * (torch.abs(value) + 1 + epsilon)) - 1) / (2 * epsilon))
     return (torch.sign(value) * (tmp * tmp - 1)).detach().cpu().numpy()
+
+
+def _np(x):
+    """a handle may return a torch tensor (the reference's InverseScalarTransform does) or an array"""
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+class _InverseScalarTransformHandle(object):
+    """what the reference drivers keep as ``value_inverse_scalar_transform_handle`` / ``reward_inverse_scalar_transform_handle``
+    (mcts_ctree.py:726-729: one per support, built from cfg.model.{value,reward}_support_range and categorical_distribution)"""
+
+    def __init__(self, support_range, categorical_distribution=True):
+        self.support_min, self.step = float(support_range[0]), float(support_range[2]) if len(support_range) > 2 else 1.0
+        self.categorical_distribution = bool(categorical_distribution)
+
+    def __call__(self, logits):
+        if getattr(logits, "_lz_inverse_transformed", False):
+            # the root value of an engine model's initial_inference(obs): h^-1 was applied on the device.  The reference's call
+            # sites continue with ``.detach().cpu().numpy()`` (efficientzero.py:587), so a tensor goes back
+            return logits
+        return _inverse_scalar_transform(logits, self.support_min, categorical=self.categorical_distribution, step=self.step)
+
+
+def _make_handles(self):
+    model_cfg = _get(self._cfg, "model", {}) or {}
+    cat = bool(_get(model_cfg, "categorical_distribution", True))
+    vrange = _get(model_cfg, "value_support_range", (-300., 301., 1.))
+    rrange = _get(model_cfg, "reward_support_range", vrange)
+    self._support_min = float(vrange[0])
+    self._categorical = cat
+    self.value_inverse_scalar_transform_handle = _InverseScalarTransformHandle(vrange, cat)
+    self.reward_inverse_scalar_transform_handle = _InverseScalarTransformHandle(rrange, cat)
+
+
+def _fused(roots, model, latent_state_roots, num_simulations, what):
+    """True: ``model`` is an engine model and the root state is in HBM -> the fused device loop.  Either ``roots`` were filled by
+    the model's ``initial_inference(obs, roots)``, or ``latent_state_roots`` is the token of ``model.initial_inference(obs)`` (the
+    reference's call order) and the inference is adopted into the prepared roots here.
+    False: a foreign model -- anything with ``recurrent_inference`` taking arrays, an engine model's Python method included -> the
+    reference loop around the device tree.  An engine model paired with roots / tokens that are not its own is a caller error."""
+    token = latent_state_roots if getattr(latent_state_roots, "_is_lz_hbm_token", False) else None
+    if not getattr(model, "_is_lz_engine_model", False):
+        if token is not None:
+            raise L.LzError("%s: latent_state_roots is an HBM token of an engine model, but `model` is %s" % (what, type(model).__name__))
+        return False
+    if token is not None:
+        if token.model is not model:
+            raise L.LzError("%s: the latent-state token belongs to another model object than the one searching" % what)
+        roots._adopt(token.roots, model, num_simulations)
+        return True
+    if getattr(roots, "_inferred_by", None) is model:
+        return True
+    if getattr(roots, "_inferred_by", None) is not None:
+        raise L.LzError("%s: these roots were inferred by another model object; an engine model searches the roots its own "
+                        "initial_inference filled" % what)
+    if isinstance(latent_state_roots, tuple) and len(latent_state_roots) == 2 and latent_state_roots[0] == "hbm-pool":
+        raise L.LzError("%s: the latent-state token refers to other roots than the ones given (model.initial_inference(obs, roots) "
+                        "fills exactly the roots it is handed)" % what)
+    return False   # arrays: the engine model is driven through its Python recurrent_inference like any other model
 
 
 class EfficientZeroMCTSCtree(object):
@@ -58,9 +120,7 @@ class EfficientZeroMCTSCtree(object):
             default_config.update(dict(cfg) if isinstance(cfg, dict) else {k: getattr(cfg, k) for k in dir(cfg)
                                                                             if not k.startswith("_")})
         self._cfg = default_config
-        model_cfg = _get(self._cfg, "model", {}) or {}
-        rng = _get(model_cfg, "value_support_range", (-300., 301., 1.))
-        self._support_min = float(rng[0])
+        _make_handles(self)
 
     @classmethod
     def roots(cls, active_collect_env_num, legal_actions, action_space_size=None, max_simulations=None):
@@ -70,7 +130,7 @@ class EfficientZeroMCTSCtree(object):
     def search(self, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch):
         cfg = self._cfg
         num_simulations = int(cfg["num_simulations"])
-        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+        if _fused(roots, model, latent_state_roots, num_simulations, "EfficientZeroMCTSCtree.search"):
             L.check(L.lib().lz_search(roots._h, num_simulations, int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
                                       float(cfg["discount_factor"]), int(cfg["lstm_horizon_len"]),
                                       float(cfg["value_delta_max"])))
@@ -105,8 +165,8 @@ class EfficientZeroMCTSCtree(object):
                 hh = torch.from_numpy(h_all[ix, 0, iy]).to(device).unsqueeze(0)
                 out = model.recurrent_inference(latent_states, (hc, hh), torch.from_numpy(np.asarray(last_actions)).to(device).long())
                 latent_pool.append(out.latent_state.detach().cpu().numpy())
-                value = _inverse_scalar_transform(out.value, self._support_min)
-                value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min)
+                value = _np(self.value_inverse_scalar_transform_handle(out.value))
+                value_prefix = _np(self.value_inverse_scalar_transform_handle(out.value_prefix))
                 rhs = [out.reward_hidden_state[0].detach().cpu().numpy().copy(), out.reward_hidden_state[1].detach().cpu().numpy().copy()]
                 reset_idx = (np.array(search_lens) % int(cfg["lstm_horizon_len"]) == 0)
                 rhs[0][:, reset_idx, :] = 0
@@ -126,7 +186,7 @@ class EfficientZeroMCTSCtree(object):
         reference indexes a packed list by root there, which reads out of bounds whenever a root skips inference)."""
         cfg = self._cfg
         S = int(cfg["num_simulations"])
-        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+        if _fused(roots, model, latent_state_roots, S, "EfficientZeroMCTSCtree.search_with_reuse"):
             import ctypes
             length, avg = ctypes.c_int(0), ctypes.c_double(0.0)
             L.check(L.lib().lz_search_with_reuse(roots._h, S, int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
@@ -165,8 +225,8 @@ class EfficientZeroMCTSCtree(object):
                                                     (torch.from_numpy(hc).to(device).unsqueeze(0), torch.from_numpy(hh).to(device).unsqueeze(0)),
                                                     torch.from_numpy(np.asarray([last_actions[k] for k in need])).to(device).long())
                     latent_pool.append(out.latent_state.detach().cpu().numpy())
-                    value = _inverse_scalar_transform(out.value, self._support_min).reshape(-1)
-                    value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min).reshape(-1)
+                    value = _np(self.value_inverse_scalar_transform_handle(out.value)).reshape(-1)
+                    value_prefix = _np(self.value_inverse_scalar_transform_handle(out.value_prefix)).reshape(-1)
                     policy = out.policy_logits.detach().cpu().numpy()
                     rhs = [out.reward_hidden_state[0].detach().cpu().numpy().copy(), out.reward_hidden_state[1].detach().cpu().numpy().copy()]
                     reset_packed = (np.array([search_lens[k] for k in need]) % int(cfg["lstm_horizon_len"]) == 0)
@@ -199,9 +259,7 @@ class MuZeroMCTSCtree(object):
         if cfg is not None:
             default_config.update(dict(cfg))
         self._cfg = default_config
-        model_cfg = _get(self._cfg, "model", {}) or {}
-        self._support_min = float(_get(model_cfg, "value_support_range", (-300., 301., 1.))[0])
-        self._categorical = bool(_get(model_cfg, "categorical_distribution", True))
+        _make_handles(self)
 
     @classmethod
     def roots(cls, active_collect_env_num, legal_actions, action_space_size=None, max_simulations=None):
@@ -210,7 +268,7 @@ class MuZeroMCTSCtree(object):
 
     def search(self, roots, model, latent_state_roots, to_play_batch, task_id=None):
         cfg = self._cfg
-        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+        if _fused(roots, model, latent_state_roots, int(cfg["num_simulations"]), "MuZeroMCTSCtree.search"):
             # fused path: every simulation on the device (the reference runs recurrent_inference twice per
             # simulation, mcts_ctree.py:338-345; once is enough)
             L.check(L.lib().lz_search(roots._h, int(cfg["num_simulations"]), int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
@@ -234,11 +292,9 @@ class MuZeroMCTSCtree(object):
                 latent_states = torch.from_numpy(lat_all[np.asarray(ix), np.asarray(iy)]).to(device)
                 out = model.recurrent_inference(latent_states, torch.from_numpy(np.asarray(last_actions)).to(device).long())
                 latent_pool.append(out.latent_state.detach().cpu().numpy())
-                if self._categorical:
-                    value = _inverse_scalar_transform(out.value, self._support_min)
-                    reward = _inverse_scalar_transform(out.reward, self._support_min)
-                else:
-                    value = out.value.detach().cpu().numpy(); reward = out.reward.detach().cpu().numpy()
+                # the handles apply h^-1 in both modes (categorical_distribution=False: to the scalar itself, scaling_transform.py:85-91)
+                value = _np(self.value_inverse_scalar_transform_handle(out.value))
+                reward = _np(self.reward_inverse_scalar_transform_handle(out.reward))
                 tree_muzero.batch_backpropagate(simulation_index + 1, discount_factor, reward.reshape(-1), value.reshape(-1),
                                                 out.policy_logits.detach().cpu().numpy(), min_max_stats_lst, results,
                                                 virtual_to_play_batch)
@@ -247,7 +303,7 @@ class MuZeroMCTSCtree(object):
         """MuZeroMCTSCtree.search_with_reuse (mcts_ctree.py:370-470, ReZero): returns ``(length, average_infer)``."""
         cfg = self._cfg
         S = int(cfg["num_simulations"])
-        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+        if _fused(roots, model, latent_state_roots, S, "MuZeroMCTSCtree.search_with_reuse"):
             import ctypes
             length, avg = ctypes.c_int(0), ctypes.c_double(0.0)
             L.check(L.lib().lz_search_with_reuse(roots._h, S, int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
@@ -279,11 +335,8 @@ class MuZeroMCTSCtree(object):
                     out = model.recurrent_inference(torch.from_numpy(lat).to(device),
                                                     torch.from_numpy(np.asarray([last_actions[k] for k in need])).to(device).long())
                     latent_pool.append(out.latent_state.detach().cpu().numpy())
-                    if self._categorical:
-                        value = _inverse_scalar_transform(out.value, self._support_min).reshape(-1)
-                        reward = _inverse_scalar_transform(out.reward, self._support_min).reshape(-1)
-                    else:
-                        value = out.value.detach().cpu().numpy().reshape(-1); reward = out.reward.detach().cpu().numpy().reshape(-1)
+                    value = _np(self.value_inverse_scalar_transform_handle(out.value)).reshape(-1)
+                    reward = _np(self.reward_inverse_scalar_transform_handle(out.reward)).reshape(-1)
                     policy = out.policy_logits.detach().cpu().numpy()
                 else:
                     latent_pool.append([])
@@ -313,8 +366,7 @@ class SampledEfficientZeroMCTSCtree(object):
         if cfg is not None:
             default_config.update(dict(cfg))
         self._cfg = default_config
-        model_cfg = _get(self._cfg, "model", {}) or {}
-        self._support_min = float(_get(model_cfg, "value_support_range", (-300., 301., 1.))[0])
+        _make_handles(self)
 
     @classmethod
     def roots(cls, active_collect_env_num, legal_actions, action_space_size, num_of_sampled_actions,
@@ -327,7 +379,7 @@ class SampledEfficientZeroMCTSCtree(object):
         import torch
         from ..ctree.ctree_sampled_efficientzero import ezs_tree
         cfg = self._cfg
-        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+        if _fused(roots, model, latent_state_roots, int(cfg["num_simulations"]), "SampledEfficientZeroMCTSCtree.search"):
             # engine model: the whole loop (select, MLP + LSTM inference, sampling of the leaf's K actions, backup) on the device
             L.check(L.lib().lz_search(roots._h, int(cfg["num_simulations"]), int(cfg["pb_c_base"]), float(cfg["pb_c_init"]),
                                       float(cfg["discount_factor"]), int(cfg["lstm_horizon_len"]), float(cfg["value_delta_max"])))
@@ -357,8 +409,8 @@ class SampledEfficientZeroMCTSCtree(object):
                     la = la.long()  # mcts_ctree_sampled.py: discrete actions are fed as indices
                 out = model.recurrent_inference(latent_states, (hc, hh), la)
                 latent_pool.append(out.latent_state.detach().cpu().numpy())
-                value = _inverse_scalar_transform(out.value, self._support_min)
-                value_prefix = _inverse_scalar_transform(out.value_prefix, self._support_min)
+                value = _np(self.value_inverse_scalar_transform_handle(out.value))
+                value_prefix = _np(self.value_inverse_scalar_transform_handle(out.value_prefix))
                 rhs = [out.reward_hidden_state[0].detach().cpu().numpy().copy(), out.reward_hidden_state[1].detach().cpu().numpy().copy()]
                 reset_idx = (np.array(search_lens) % int(cfg["lstm_horizon_len"]) == 0)
                 rhs[0][:, reset_idx, :] = 0
@@ -386,8 +438,7 @@ class GumbelMuZeroMCTSCtree(object):
         if cfg is not None:
             default_config.update(dict(cfg))
         self._cfg = default_config
-        model_cfg = _get(self._cfg, "model", {}) or {}
-        self._support_min = float(_get(model_cfg, "value_support_range", (-300., 301., 1.))[0])
+        _make_handles(self)
 
     @classmethod
     def roots(cls, active_collect_env_num, legal_actions, action_space_size=None, max_simulations=None):
@@ -398,7 +449,7 @@ class GumbelMuZeroMCTSCtree(object):
         from ..ctree.ctree_gumbel_muzero import gmz_tree
         cfg = self._cfg
         S, m, discount_factor = int(cfg["num_simulations"]), int(cfg["max_num_considered_actions"]), cfg["discount_factor"]
-        if getattr(model, "_is_lz_engine_model", False) and getattr(roots, "_inferred_by", None) is model:
+        if _fused(roots, model, latent_state_roots, S, "GumbelMuZeroMCTSCtree.search"):
             L.check(L.lib().lz_gsearch(roots._h, S, m, float(discount_factor)))
             return
         import torch
@@ -416,7 +467,7 @@ class GumbelMuZeroMCTSCtree(object):
                 lat = np.stack(latent_pool)[np.asarray(ix), np.asarray(iy)]
                 out = model.recurrent_inference(torch.from_numpy(lat).to(device), torch.from_numpy(np.asarray(last_actions)).to(device).long())
                 latent_pool.append(out.latent_state.detach().cpu().numpy())
-                value = _inverse_scalar_transform(out.value, self._support_min).reshape(-1)
-                reward = _inverse_scalar_transform(out.reward, self._support_min).reshape(-1)
+                value = _np(self.value_inverse_scalar_transform_handle(out.value)).reshape(-1)
+                reward = _np(self.reward_inverse_scalar_transform_handle(out.reward)).reshape(-1)
                 gmz_tree.batch_back_propagate(simulation_index + 1, discount_factor, reward, value,
                                               out.policy_logits.detach().cpu().numpy(), mm, results, vtp)

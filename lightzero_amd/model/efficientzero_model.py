@@ -12,6 +12,29 @@ import numpy as np
 from .. import _lib as L
 
 
+class HbmToken(object):
+    """Stands for a tensor of an engine model's network output that stayed in HBM (the root latent state / LSTM state, slot 0 of
+    the pools of ``roots``).  It survives the conversions the reference applies to network outputs
+    (``x.detach().cpu().numpy()``, efficientzero.py:588-593) and is what ``search(roots, model, latent_state_roots, ...)`` receives
+    in their place; a fused search adopts the inference it refers to."""
+    _is_lz_hbm_token = True
+
+    def __init__(self, model, roots, what):
+        self.model, self.roots, self.what = model, roots, what
+
+    def detach(self):
+        return self
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self
+
+    def __repr__(self):
+        return "<HBM-resident %s of %d roots>" % (self.what, self.roots.num)
+
+
 class EfficientZeroModel(object):
     _model_type = 0  # lz_model_cfg.model_type
 
@@ -37,6 +60,7 @@ class EfficientZeroModel(object):
         self.lstm_hidden_size = int(lstm_hidden_size)
         self.num_channels = int(num_channels)
         self.num_res_blocks = int(num_res_blocks)
+        self._downsample = bool(downsample)
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
         self.reward_support_size = self.value_support_size
         # one model per engine: the first model of the process lives on the default engine, later ones get their own
@@ -80,25 +104,49 @@ class EfficientZeroModel(object):
         return self
 
     _is_lz_engine_model = True
+    training = False    # torch.nn.Module.training of a model in eval() mode (the reference's _forward_eval reads it)
+    _uses_lstm = True   # the value-prefix LSTM (EfficientZero); MuZeroModel clears it
 
-    def initial_inference(self, obs, roots, fetch=True):
-        """EfficientZeroModel.initial_inference (efficientzero_model.py:203-238) for the batch held by ``roots``
-        (a lightzero_amd ez_tree.Roots): the latent state and the zero LSTM state are written into the roots'
-        HBM pools (slot 0) instead of being returned.  ``obs``: [B,C,H,W] fp32 -- a device tensor exposing
-        ``data_ptr()`` (used in place) or a host numpy array (staged over PCIe).
-        Returns an ``EZNetworkOutput``-like namespace: ``value`` is already passed through
-        InverseScalarTransform (shape [B]), ``value_prefix`` is ``[0.]*B``, ``policy_logits`` is [B,A] numpy;
-        ``latent_state`` / ``reward_hidden_state`` are opaque tokens bound to ``roots``.  ``fetch=False`` skips the read-back
-        (and its synchronisation) and returns None."""
-        if not self._loaded:
-            raise L.LzError("EfficientZeroModel: load_state_dict has not been called")
-        self._check_owner()
+    # ---- shapes the shared inference code needs (the MLP family overrides _policy_width / _latent_shape)
+    @property
+    def _pw(self):
+        return getattr(self, "_policy_width", self.action_space_size)
+
+    def _latent_shape(self):
+        c, h, w = self.observation_shape
+        if not getattr(self, "_downsample", True):
+            return (self.num_channels, h, w)
+        g = h // 16 if h == 96 else h // 8   # 96 -> 6 (two poolings), 64 -> 8 (common.py:358-359)
+        return (self.num_channels, g, g)
+
+    def _tree(self):
+        if self._uses_lstm:
+            from ..mcts.ctree.ctree_efficientzero import ez_tree as tree
+        else:
+            from ..mcts.ctree.ctree_muzero import mz_tree as tree
+        return tree
+
+    def _own_roots(self, B, slot, max_simulations, trace=False):
+        """a roots handle the MODEL owns (per batch size): where initial_inference(obs) without roots leaves the root state, and
+        the scratch pool of the Python recurrent_inference"""
+        cache = self.__dict__.setdefault("_own", {})
+        r = cache.get((slot, B))
+        if r is None:
+            A = self.action_space_size
+            r = self._tree().Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=max_simulations, engine=self._engine)
+            r._bind_engine(self._engine)
+            r._ensure(A)
+            if trace:
+                L.check(L.lib().lz_roots_enable_trace(r._h, 1))   # the heads also write their support-wide logits
+            cache[(slot, B)] = r
+        return r
+
+    def _run_initial(self, obs, roots):
         B = roots.num
-        roots._bind_engine(self._engine)
-        roots._ensure(self.action_space_size)
+        oshape = tuple(self.observation_shape)
         if hasattr(obs, "data_ptr"):
-            if tuple(obs.shape) != (B,) + self.observation_shape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":
-                raise ValueError("obs must be a contiguous float32 [B,C,H,W] tensor")
+            if tuple(obs.shape) != (B,) + oshape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":
+                raise ValueError("obs must be a contiguous float32 [B, *observation_shape] tensor")
             if getattr(obs, "is_cuda", False):
                 import torch
                 torch.cuda.current_stream().synchronize()  # torch produced obs on its own stream
@@ -107,20 +155,134 @@ class EfficientZeroModel(object):
                 L.check(L.lib().lz_initial_inference_host(roots._h, np.ascontiguousarray(obs.numpy(), np.float32).reshape(-1)))
         else:
             arr = np.ascontiguousarray(obs, dtype=np.float32)
-            if arr.shape != (B,) + self.observation_shape:
-                raise ValueError("obs must be [B,C,H,W]")
+            if arr.shape != (B,) + oshape:
+                raise ValueError("obs must be [B, *observation_shape]")
             L.check(L.lib().lz_initial_inference_host(roots._h, arr.reshape(-1)))
+
+    def initial_inference(self, obs, roots=None, fetch=True):
+        """EfficientZeroModel.initial_inference (efficientzero_model.py:203-238).  The latent state and the zero LSTM state stay in
+        HBM (slot 0 of a roots handle's pools); what comes back are the root predictions plus TOKENS for those tensors.
+
+        ``model.initial_inference(obs)`` -- the reference's signature and call order (efficientzero.py:582-610: infer, THEN build
+        and prepare the roots, then search(roots, model, latent_state_roots, reward_hidden_state_roots, to_play)): the state is
+        left in a handle the model owns; the returned object has the reference's fields with torch types -- ``policy_logits``
+        [B, A], ``value`` [B, 1] ALREADY passed through InverseScalarTransform on the device (the engine's
+        ``value_inverse_scalar_transform_handle`` recognises it and passes it on), ``value_prefix`` / ``reward`` = [0.] * B,
+        ``latent_state`` / ``reward_hidden_state`` = tokens that survive ``.detach().cpu().numpy()``; the search adopts the
+        inference into the roots it is given (lz_roots_adopt_inference).
+
+        ``model.initial_inference(obs, roots[, fetch])`` -- the engine-native form: inference straight into ``roots`` (no
+        adoption copy; ``fetch=False``: no read-back and no synchronisation, returns None); numpy-typed fields, ``value`` [B].
+
+        ``obs``: [B, *observation_shape] fp32 -- a device tensor exposing ``data_ptr()`` (used in place) or a host array."""
+        if not self._loaded:
+            raise L.LzError("%s: load_state_dict has not been called" % type(self).__name__)
+        self._check_owner()
+        import types
+        if roots is None:
+            import torch
+            B = int(obs.shape[0])
+            own = self._own_roots(B, "infer", 2)
+            self._run_initial(obs, own)
+            own._inferred_by = self
+            values = np.zeros(B, np.float32)
+            logits = np.zeros((B, self._pw), np.float32)
+            L.check(L.lib().lz_roots_get_root_outputs(own._h, values, logits.reshape(-1)))
+            value = torch.from_numpy(values.reshape(B, 1))
+            value._lz_inverse_transformed = True
+            out = types.SimpleNamespace(value=value, policy_logits=torch.from_numpy(logits), latent_state=HbmToken(self, own, "latent_state"))
+            if self._uses_lstm:
+                out.value_prefix = [0. for _ in range(B)]
+                out.reward_hidden_state = (HbmToken(self, own, "reward_hidden_state[0]"), HbmToken(self, own, "reward_hidden_state[1]"))
+            else:
+                out.reward = [0. for _ in range(B)]
+            return out
+        B = roots.num
+        roots._bind_engine(self._engine)
+        roots._ensure(self.action_space_size)
+        self._run_initial(obs, roots)
         roots._inferred_by = self
         if not fetch:
             # the caller reads the root predictions after the search (Roots.get_search_results): no host-device
             # synchronisation between the representation network and the search
             return None
         values = np.zeros(B, np.float32)
-        logits = np.zeros((B, self.action_space_size), np.float32)
+        logits = np.zeros((B, self._pw), np.float32)
         L.check(L.lib().lz_roots_get_root_outputs(roots._h, values, logits.reshape(-1)))
+        out = types.SimpleNamespace(value=values, policy_logits=logits, latent_state=("hbm-pool", roots))
+        if self._uses_lstm:
+            out.value_prefix = [0. for _ in range(B)]
+            out.reward_hidden_state = ("hbm-pool", roots)
+        else:
+            out.reward = [0. for _ in range(B)]
+        return out
+
+    def recurrent_inference(self, latent_state, *rest):
+        """EfficientZeroModel.recurrent_inference(latent_state, reward_hidden_state, action) (efficientzero_model.py:240-273) /
+        MuZeroModel.recurrent_inference(latent_state, action) (muzero_model.py:240-272) with ARRAYS in and out, over
+        lz_recurrent_inference on a scratch pool: what a foreign driver loop (the reference's search with host-side pools,
+        mcts_ctree.py:815-847) or a reanalyze caller needs.  Returns the reference's fields as torch CPU tensors: ``value`` /
+        ``value_prefix`` | ``reward`` are the SUPPORT-WIDE logits [B, support] (not yet inverse-transformed, like the reference's),
+        ``policy_logits`` [B, A], ``latent_state`` [B, C, H, W] | [B, L], ``reward_hidden_state`` = (h [1, B, H], c [1, B, H]).
+        Every call crosses PCIe both ways -- the fused search (model.initial_inference + search) never does."""
         import types
-        return types.SimpleNamespace(value=values, value_prefix=[0. for _ in range(B)], policy_logits=logits,
-                                     latent_state=("hbm-pool", roots), reward_hidden_state=("hbm-pool", roots))
+        import torch
+        if not self._loaded:
+            raise L.LzError("%s: load_state_dict has not been called" % type(self).__name__)
+        self._check_owner()
+        if self._uses_lstm:
+            if len(rest) != 2:
+                raise TypeError("recurrent_inference(latent_state, reward_hidden_state, action)")
+            hidden, action = rest
+        else:
+            if len(rest) != 1:
+                raise TypeError("recurrent_inference(latent_state, action)")
+            hidden, action = None, rest[0]
+
+        def host(x, dt=np.float32):
+            if hasattr(x, "detach"):
+                x = x.detach().cpu().numpy()
+            return np.ascontiguousarray(x, dtype=dt)
+        if isinstance(latent_state, HbmToken):
+            raise L.LzError("recurrent_inference takes arrays; HBM tokens belong to the fused search (search(roots, model, tokens, ...))")
+        lat = host(latent_state)
+        B = lat.shape[0]
+        lshape = tuple(self._latent_shape())
+        if tuple(lat.shape[1:]) != lshape:
+            raise ValueError("latent_state must be [B, %s]" % ", ".join(str(d) for d in lshape))
+        lib = L.lib()
+        r = self._own_roots(B, "scratch", 2, trace=True)
+        L.check(lib.lz_roots_write_latent(r._h, 0, lat.reshape(-1)))
+        H = int(self.lstm_hidden_size) if self._uses_lstm else 0
+        if self._uses_lstm:
+            h0, c0 = host(hidden[0]).reshape(B, H), host(hidden[1]).reshape(B, H)
+            L.check(lib.lz_roots_write_hidden(r._h, 0, h0.reshape(-1), c0.reshape(-1)))
+        zeros = np.zeros(B, np.int32)
+        cont = bool(getattr(self, "continuous_action_space", False))
+        if cont:
+            af = host(action).reshape(B, -1)
+            L.check(lib.lz_recurrent_inference(r._h, zeros, None, af.ctypes.data, None, 0, 1))
+        else:
+            a = host(action, np.int64).reshape(B).astype(np.int32)
+            L.check(lib.lz_recurrent_inference(r._h, zeros, a.ctypes.data, None, None, 0, 1))
+        nxt = np.zeros((B,) + lshape, np.float32)
+        L.check(lib.lz_roots_read_latent(r._h, 1, nxt.reshape(-1)))
+        SUP = int(self.value_support_size)
+        vlog = np.zeros((B, SUP), np.float32); rlog = np.zeros((B, SUP), np.float32)
+        L.check(lib.lz_roots_read_debug_logits(r._h, 0, vlog.reshape(-1)))
+        L.check(lib.lz_roots_read_debug_logits(r._h, 1, rlog.reshape(-1)))
+        pol = np.zeros((B, self._pw), np.float32)
+        scalar = np.zeros(B, np.float32)   # (the post-h^-1 scalars; the reference's contract returns the logits)
+        L.check(lib.lz_roots_read_sim_outputs(r._h, 1, scalar, scalar.copy(), pol.reshape(-1)))
+        out = types.SimpleNamespace(value=torch.from_numpy(vlog), policy_logits=torch.from_numpy(pol), latent_state=torch.from_numpy(nxt))
+        if self._uses_lstm:
+            hh = np.zeros((B, H), np.float32); cc = np.zeros((B, H), np.float32)
+            L.check(lib.lz_roots_read_hidden(r._h, 1, hh.reshape(-1), cc.reshape(-1)))
+            out.value_prefix = torch.from_numpy(rlog)
+            out.reward_hidden_state = (torch.from_numpy(hh).unsqueeze(0), torch.from_numpy(cc).unsqueeze(0))
+        else:
+            out.reward = torch.from_numpy(rlog)
+        return out
 
     def eval(self):
         return self

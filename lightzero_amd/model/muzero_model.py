@@ -6,6 +6,7 @@ from .efficientzero_model import EfficientZeroModel
 
 class MuZeroModel(EfficientZeroModel):
     _model_type = 1
+    _uses_lstm = False
 
     def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, **kwargs):
         kwargs.setdefault("lstm_hidden_size", 0)

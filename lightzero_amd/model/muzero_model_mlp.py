@@ -44,42 +44,23 @@ class _EngineModelMLP(EfficientZeroModel):
                          1 if bound_type == 'tanh' else 0, 1e-5)
         self._create(cfg)
 
-    def initial_inference(self, obs, roots, fetch=True):
-        """initial_inference for the batch held by ``roots``; ``obs``: [B, observation_shape] fp32 (device tensor or host
-        array).  Same return contract as the convolutional engine models; ``policy_logits`` is [B, A] (or [B, 2 D] =
-        (mu | sigma) for continuous actions)."""
-        import types
-        import numpy as np
-        if not self._loaded:
-            raise L.LzError("%s: load_state_dict has not been called" % type(self).__name__)
-        self._check_owner()
-        B = roots.num
-        roots._bind_engine(self._engine)
-        roots._ensure(self.action_space_size)
-        if hasattr(obs, "data_ptr") and getattr(obs, "is_cuda", False):
-            if tuple(obs.shape) != (B,) + self.observation_shape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":
-                raise ValueError("obs must be a contiguous float32 [B, observation_shape] tensor")
-            import torch
-            torch.cuda.current_stream().synchronize()
-            L.check(L.lib().lz_initial_inference(roots._h, obs.data_ptr()))
-        else:
-            arr = np.ascontiguousarray(obs.numpy() if hasattr(obs, "numpy") else obs, dtype=np.float32)
-            if arr.shape != (B,) + self.observation_shape:
-                raise ValueError("obs must be [B, observation_shape]")
-            L.check(L.lib().lz_initial_inference_host(roots._h, arr.reshape(-1)))
-        roots._inferred_by = self
-        if not fetch:
-            return None
-        values = np.zeros(B, np.float32)
-        logits = np.zeros((B, self._policy_width), np.float32)
-        L.check(L.lib().lz_roots_get_root_outputs(roots._h, values, logits.reshape(-1)))
-        out = types.SimpleNamespace(value=values, policy_logits=logits, latent_state=("hbm-pool", roots))
-        if self._uses_lstm:
-            out.value_prefix = [0. for _ in range(B)]
-            out.reward_hidden_state = ("hbm-pool", roots)
-        else:
-            out.reward = [0. for _ in range(B)]
-        return out
+    def _latent_shape(self):
+        return (self.latent_state_dim,)
+
+    def _own_roots(self, B, slot, max_simulations, trace=False):
+        if self._model_type != 4:
+            return super()._own_roots(B, slot, max_simulations, trace)
+        cache = self.__dict__.setdefault("_own", {})
+        r = cache.get((slot, B))
+        if r is None:  # Sampled EfficientZero: the sampled tree's handle (K actions per node)
+            from ..mcts.ctree.ctree_sampled_efficientzero import ezs_tree
+            K = self.num_of_sampled_actions
+            r = ezs_tree.Roots(B, [[-1] * K] * B, self.action_space_size, K, self.continuous_action_space, max_simulations=max_simulations,
+                               engine=self._engine)
+            if trace:
+                L.check(L.lib().lz_roots_enable_trace(r._h, 1))
+            cache[(slot, B)] = r
+        return r
 
 
 class MuZeroModelMLP(_EngineModelMLP):

@@ -183,7 +183,8 @@ class EfficientZeroPolicy(object):
             }
         return output
 
-    def forward_collect_rows(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None):
+    def forward_collect_rows(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None,
+                             epsilon=0.25):
         """The collect forward for a vectorised collector: same search as ``_forward_collect`` (engine model, device
         tensors), but what comes back is not a dict per env: ``rows_out`` -- a float32 [B, W] tensor IN HBM (W =
         shard.row_width(A, frame_floats)) -- receives the packed env-step rows (action, search statistics, action mask, to_play,
@@ -192,6 +193,9 @@ class EfficientZeroPolicy(object):
         (header)`` does the per-step bookkeeping of muzero_collector.py:588-620 for all envs at once.  No per-env Python loop:
         one np.nonzero, one Dirichlet draw, one read-back."""
         from .. import shard
+        if bool(_g(self._cfg, "collect_with_pure_policy", False)):
+            raise NotImplementedError("forward_collect_rows runs the search; collect_with_pure_policy is served by _forward_collect")
+        self.collect_epsilon = epsilon
         model = self._collect_model
         B, A = data.shape[0], model.action_space_size
         mask = np.asarray(action_mask)
@@ -216,8 +220,22 @@ class EfficientZeroPolicy(object):
         if frame_floats is None:
             frame_floats = rows_out.shape[1] - shard.HEADER - 2 * A
         eps_cfg = _g(self._cfg, "eps", {}) or {}
-        header, _ = roots.collect_rows(temperature, bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False)), rows_out.data_ptr(),
-                                       rows_out.shape[1], frame_floats, timestep=timestep)
+        eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
+        # the observation pointer is passed explicitly: the library's cached pointer of the last initial inference would outlive a
+        # tensor the caller's allocator has recycled in between
+        header, _ = roots.collect_rows(temperature, eps_greedy, rows_out.data_ptr(), rows_out.shape[1], frame_floats, timestep=timestep,
+                                       d_obs_ptr=data.data_ptr() if hasattr(data, "data_ptr") and getattr(data, "is_cuda", False) else None)
+        if eps_greedy:
+            # efficientzero.py:622-632: arg-max of the visit counts, replaced by a uniformly random LEGAL action with probability
+            # collect_epsilon -- for all envs at once; the action word of the device rows is patched too
+            explore = np.nonzero(np.random.rand(B) < float(epsilon))[0]
+            if explore.size:
+                legal = mask[explore] != 0
+                pick = (np.random.rand(explore.size) * legal.sum(1)).astype(np.int64)             # position in the legal list
+                acts = np.argmax(np.cumsum(legal, 1) > pick[:, None], 1).astype(np.float32)       # -> action index
+                header[explore, shard.F_ACTION] = acts
+                import torch
+                rows_out[torch.as_tensor(explore, device=rows_out.device), shard.F_ACTION] = torch.as_tensor(acts, device=rows_out.device)
         return header
 
     def _forward_eval(self, data, action_mask, to_play=[-1], ready_env_id=None, **kwargs):

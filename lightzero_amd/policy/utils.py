@@ -14,3 +14,14 @@ def select_action(visit_counts, temperature=1, deterministic=True):
     nz = action_probs[action_probs > 0]
     entropy = float(-(nz * np.log2(nz)).sum())
     return action_pos, entropy
+
+
+def ez_network_output_unpack(network_output):
+    """lzero/policy/utils.py:782-794: (latent_state, value_prefix, reward_hidden_state, value, policy_logits)"""
+    return (network_output.latent_state, network_output.value_prefix, network_output.reward_hidden_state, network_output.value,
+            network_output.policy_logits)
+
+
+def mz_network_output_unpack(network_output):
+    """lzero/policy/utils.py:796-807: (latent_state, reward, value, policy_logits)"""
+    return network_output.latent_state, network_output.reward, network_output.value, network_output.policy_logits

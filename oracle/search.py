@@ -18,9 +18,10 @@ from .torch_models import InverseScalarTransform
 
 
 def ez_search(tree, roots, model, latent_state_roots, reward_hidden_state_roots, to_play_batch, cfg, device="cpu",
-              record=None):
-    """cfg: dict(num_simulations, pb_c_base, pb_c_init, discount_factor, value_delta_max, lstm_horizon_len)."""
-    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
+              record=None, ist=None):
+    """cfg: dict(num_simulations, pb_c_base, pb_c_init, discount_factor, value_delta_max, lstm_horizon_len).
+    ``ist``: replaces the value_inverse_scalar_transform_handle (tests replay recorded post-transform scalars through it)."""
+    ist = ist or InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         batch_size = roots.num
@@ -90,11 +91,11 @@ def ez_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
         return roots.get_distributions(), roots.get_values(), pred_values.reshape(-1), policy_logits
 
 
-def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device="cpu", deterministic=None):
+def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device="cpu", deterministic=None, ist=None):
     """MuZeroMCTSCtree.search  lzero/mcts/tree_search/mcts_ctree.py:267-368 (the reference calls
     recurrent_inference twice per simulation, :338 and :340-345, and discards the first result; it is called once
     here, which leaves the outputs unchanged)."""
-    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
+    ist = ist or InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         batch_size = roots.num

@@ -78,7 +78,9 @@ def test_go_fused_search_vs_oracle(game):
         worst["rew"] = max(worst["rew"], rel(rew[s + 1], ist(q.reward).reshape(-1).numpy()))
         worst["val"] = max(worst["val"], rel(val[s + 1], ist(q.value).reshape(-1).numpy()))
     print("go worst |d| / (1 + |ref|):", worst)
-    assert worst["lat"] < 2e-5 and worst["pol"] < 2e-5 and worst["rew"] < 3e-4 and worst["val"] < 3e-4, worst
+    import parity_record
+    parity_record.check("recurrent_teacher_forced/mz_%s/B%d_S%d" % (game, B, S),
+                        dict(latent=worst["lat"], policy=worst["pol"], reward=worst["rew"], value=worst["val"]), extra=dict(batch=B, simulations=S))
     o_dist, o_val, _, _ = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, to_play, CFG,
                                                      roots_kwargs=dict(action_space_size=A, max_simulations=S),
                                                      deterministic=True)

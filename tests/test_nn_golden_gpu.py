@@ -3,8 +3,9 @@
 step TEACHER-FORCED -- the reference's own (latent, h, c) of the previous step is written into a pool slot
 (lz_roots_write_latent / _hidden) and lz_recurrent_inference runs on it, so each step is compared on identical inputs.
 
-Tolerances (fp32 everywhere, only summation order differs):
-  latent / LSTM state / policy logits / support-wide logits: |d| <= 2e-5 (1 + |x|)
+Tolerances (fp32 everywhere, only summation order differs; tests/parity_record.py holds the table and keeps
+the MEASURED worst case of every run as data -> profiles/rNN_parity.json):
+  latent / LSTM state / policy logits / support-wide logits: |d| <= 1e-5 (1 + |x|)   (north_star's bound)
   value / value-prefix / reward scalars after h^-1:           |d| <= 3e-4 (1 + |x|)   (the reference's own fp32 formula quantises
                                                               its output in steps of ~1.3e-4 (1 + |x|))"""
 import os
@@ -14,6 +15,7 @@ import numpy as np
 import pytest
 
 import nn_cases
+import parity_record
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -60,11 +62,11 @@ def test_hip_network_matches_reference_module_outputs(name):
     model = nn_cases.engine_class(fam)(**ekw).load_state_dict(sd)
     roots = _roots_for(case, model, B)
     obs, actions = nn_cases.inputs(case)
-    conv = fam in ("ez", "mz")
-    if conv:
+    if fam != "sez_mlp":   # (the sampled roots create their device handle in the constructor)
         roots._bind_engine(model.engine)
         roots._ensure(kw["action_space_size"])
-        L.check(lib.lz_roots_enable_trace(roots._h, 1))   # the heads also write their support-wide logits
+    L.check(lib.lz_roots_enable_trace(roots._h, 1))   # the heads also write their support-wide logits
+    conv = True   # the vector-observation models expose their support-wide logits the same way
     out = model.initial_inference(obs, roots)
     lat = np.zeros(g["init_latent"].shape, np.float32)
     L.check(lib.lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
@@ -111,5 +113,4 @@ def test_hip_network_matches_reference_module_outputs(name):
             L.check(lib.lz_roots_read_debug_logits(roots._h, 1, rl.reshape(-1)))
             worst["logits"] = max(worst["logits"], _rel(vl, g["s%d_value_logits" % s]), _rel(rl, g["s%d_reward_logits" % s]))
     print(name, "worst relative differences:", worst)
-    assert worst["latent"] < 2e-5 and worst["policy"] < 2e-5 and worst["hc"] < 2e-5 and worst["logits"] < 2e-5, worst
-    assert worst["scalar"] < 3e-4, worst
+    parity_record.check("golden/" + name, worst, extra=dict(batch=int(B), steps=int(nn_cases.STEPS)))

@@ -77,7 +77,7 @@ def test_forward_collect_rows_matches_dict_forward_and_feeds_the_segment_batch()
         np.random.seed(100 + t)
         out = pol_a._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B, epsilon=0.0)
         np.random.seed(100 + t)
-        hdr = pol_b.forward_collect_rows(obs, mask, rows, temperature=1.0, to_play=[-1] * B, timestep=[t] * B)
+        hdr = pol_b.forward_collect_rows(obs, mask, rows, temperature=1.0, to_play=[-1] * B, timestep=[t] * B, epsilon=0.0)
         assert [int(a) for a in hdr[:, shard.F_ACTION]] == [int(out[i]["action"]) for i in range(B)]
         assert np.array_equal(hdr[:, shard.F_ROOT_VALUE], np.array([out[i]["searched_value"] for i in range(B)], np.float32))
         for i in range(B):
