@@ -38,7 +38,18 @@ FLOP_CHAIN = 2 * 36 * 64 * (70 + 4 * 64) * 9 + 2 * 36 * 64 * 48  # dyn conv 70->
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
-TRAFFIC_FILE = "r02_traffic.json"
+MANIFEST = "r03_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
+
+
+def _profile_manifest():
+    """the committed rocprofv3 summary, if it was measured on the kernel sources this run is built from"""
+    try:
+        from lightzero_amd.build import csrc_digest
+        with open(os.path.join(ROOT, "profiles", MANIFEST)) as f:
+            m = json.load(f)
+        return m if m.get("csrc_sha256") == csrc_digest() else None
+    except Exception:
+        return None
 
 
 def _reference_model(weights):
@@ -156,8 +167,20 @@ def main():
                          "(HIP stream): the MFMA-bound conv chain of one overlaps the latency-bound tree / LSTM / head "
                          "kernels of the other")
     ap.add_argument("--tiebreak", choices=["first", "random"], default="random",
-                    help="random = the reference's stochastic tie rule (default, like collection); first = parity mode")
+                    help="random = the reference's stochastic tie rule (default, like collection); first = parity mode (the other "
+                         "arm is timed too and reported in config)")
+    ap.add_argument("--noise", choices=["device", "host"], default="device",
+                    help="device = Dirichlet root noise drawn by a kernel inside the step (north_star); host = np.random.dirichlet "
+                         "inside the step + upload, like efficientzero.py:599-602")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra steps after the timed region for config.sustained_env_steps_per_s")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for every step's all-gather instead of overlapping it with the next search")
+    ap.add_argument("--total-envs", type=int, default=0,
+                    help="STRONG scaling (BASELINE configs[3] / [4]: 512 envs over 8 GPUs, 256 over 4): this many envs in total, split into "
+                         "contiguous blocks by shard.shard_range (sizes may differ by one); default 0 = weak scaling, 256 envs per GPU")
+    ap.add_argument("--refresh-every", type=int, default=0,
+                    help="every K steps, INSIDE the timed loop: broadcast the checkpoint's model state_dict from rank 0 (shard.broadcast_state_dict) "
+                         "and re-ingest it in place (a collector's weight refresh after a learner update)")
+    ap.add_argument("--check-gather", action="store_true", help="after the timed region: every rank verifies the pooled rows block by block")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
@@ -192,7 +215,14 @@ def main():
     if world > 1:  # the weight-refresh path: rank 0's state_dict reaches every rank through one broadcast, then an in-place re-ingest
         weights = shard.broadcast_state_dict(weights, src=0)
     NS = max(1, args.streams)
-    assert ENVS % NS == 0
+    if args.total_envs:   # strong scaling: this rank's contiguous block of the global env batch
+        blocks = [shard.shard_range(args.total_envs, q, world) for q in range(world)]
+        counts = [hi - lo for lo, hi in blocks]
+    else:
+        counts = [256] * world
+    ENVS = counts[rank]   # (shadows the module constant: everything below is per rank)
+    NMAX = max(counts)
+    assert ENVS > 0 and ENVS % NS == 0
     EPS = ENVS // NS  # envs per sub-batch
     engs, models = [], []
     for k in range(NS):
@@ -205,7 +235,6 @@ def main():
     obs = obs_cpu.cuda().contiguous()
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
-    noise_steps = [rng.dirichlet([0.3] * ACTIONS, size=ENVS).astype(np.float32) for _ in range(total)]
     legal = [list(range(ACTIONS))] * EPS
     roots_l = []
     for k in range(NS):
@@ -217,8 +246,11 @@ def main():
     obs_parts = [obs[k * EPS:(k + 1) * EPS].contiguous() for k in range(NS)]
     W = shard.row_width(ACTIONS, FRAME)
     HW = shard.HEADER + 2 * ACTIONS
-    rows_dev = [torch.zeros(ENVS, W, device="cuda") for _ in range(2)]          # double-buffered: step i's all-gather reads one
-    gathered = [torch.zeros(world * ENVS, W, device="cuda") for _ in range(2)] if world > 1 and backend == "nccl" else None
+    # double-buffered: step i's all-gather reads one.  Uneven blocks (strong scaling): every buffer has the largest block's rows, the
+    # collective moves equal blocks with no size exchange (all ranks know shard_range) and the consumer strips the padding
+    rows_dev = [torch.zeros(NMAX, W, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(world * NMAX, W, device="cuda") for _ in range(2)] if world > 1 and backend == "nccl" else None
+    gathered_host = [None, None]
     header = np.zeros((ENVS, HW), np.float32)
     logits = np.zeros((ENVS, ACTIONS), np.float32)
     timestep = np.zeros(EPS, np.int32)
@@ -234,8 +266,11 @@ def main():
             pending[buf] = None
         for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
             L.check(lib.lz_initial_inference(r._h, obs_parts[k].data_ptr()))
-            nz = np.ascontiguousarray(noise_steps[i][k * EPS:(k + 1) * EPS])
-            L.check(lib.lz_roots_prepare_from_inference(r._h, CFG["root_noise_weight"], nz.ctypes.data, to_play))
+            if args.noise == "device":   # Dirichlet(0.3) over the legal actions of every root, drawn by a kernel of this step
+                L.check(lib.lz_roots_prepare_from_inference_dirichlet(r._h, CFG["root_noise_weight"], CFG["root_dirichlet_alpha"], to_play))
+            else:                        # drawn on the host INSIDE the step (one vectorised numpy call) and uploaded
+                nz = rng.dirichlet([CFG["root_dirichlet_alpha"]] * ACTIONS, size=EPS).astype(np.float32)
+                L.check(lib.lz_roots_prepare_from_inference(r._h, CFG["root_noise_weight"], nz.ctypes.data, to_play))
             L.check(lib.lz_search(r._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"],
                                   CFG["lstm_horizon_len"], CFG["value_delta_max"]))
         for k, r in enumerate(roots_l):  # select_action + packed env-step rows: one kernel, header words back on the host
@@ -249,7 +284,13 @@ def main():
                 _, work = shard.all_gather_rows_equal(rows_dev[buf], out=gathered[buf], async_op=not args.sync_gather)
                 pending[buf] = work if not args.sync_gather else None
             else:
-                shard.all_gather_rows(rows_dev[buf].cpu())
+                gathered_host[buf], _ = shard.all_gather_rows_equal(rows_dev[buf].cpu())
+        if args.refresh_every and (i + 1) % args.refresh_every == 0:
+            # weight refresh inside the loop: one flat broadcast from rank 0, then the device tensors are overwritten in place
+            # (same buffers: the captured search graphs stay valid)
+            fresh = shard.broadcast_state_dict(weights, src=0)
+            for mdl in models:
+                mdl.load_state_dict(fresh)
 
     def drain():
         for b in (0, 1):
@@ -257,21 +298,21 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
+    def sync_all():
+        drain()
+        for e in engs:
+            L.check(lib.lz_engine_synchronize(e))
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
         step(i)
-    drain()
-    torch.cuda.synchronize()
-    for e in engs:
-        L.check(lib.lz_engine_synchronize(e))
+    sync_all()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-    drain()
-    for e in engs:
-        L.check(lib.lz_engine_synchronize(e))
-    torch.cuda.synchronize()
+    sync_all()
     my_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
@@ -287,12 +328,58 @@ def main():
         dist.all_gather(allr, mine)
         per_rank = [float(x.item()) for x in allr]
     # every step ran all its simulations: child visits of every row sum to 1 with 50 visits behind them
-    rows_last = rows_dev[(total - 1) & 1][:, :HW].cpu().numpy()
+    rows_last = rows_dev[(total - 1) & 1][:ENVS, :HW].cpu().numpy()
     assert np.allclose(rows_last[:, shard.HEADER:shard.HEADER + ACTIONS].sum(1), 1.0, atol=1e-5), "rows carry no search statistics"
     assert np.array_equal(rows_last, header), "host header differs from the device rows"
     dist_chk = np.zeros((EPS, ACTIONS), np.int32); cnt_chk = np.zeros(EPS, np.int32)
     L.check(lib.lz_roots_get_distributions(roots_l[0]._h, dist_chk, cnt_chk))
     assert (dist_chk.sum(1) == SIMS).all(), "search did not run all simulations"
+    gather_check = None
+    if args.check_gather and world > 1:
+        # every rank: the pooled rows of the last step, block q, must be rank q's own rows (exchanged once more, as float64 checksums
+        # per row, through a plain all_gather) -- with the padding of uneven blocks stripped
+        buf = (total - 1) & 1
+        sync_all()
+        pooled = (gathered[buf] if backend == "nccl" else gathered_host[buf]).cpu().double()
+        mine = rows_dev[buf][:ENVS].cpu().double()
+        wts = torch.arange(1, W + 1, dtype=torch.float64)
+        sums = torch.zeros(NMAX, dtype=torch.float64)
+        sums[:ENVS] = (mine * wts).sum(1)
+        cdev = "cuda" if backend == "nccl" else "cpu"
+        alls = [torch.zeros(NMAX, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(alls, sums.to(cdev))
+        alls = [a.cpu() for a in alls]
+        ok = all(torch.equal((pooled[q * NMAX:q * NMAX + counts[q]] * wts).sum(1), alls[q][:counts[q]]) for q in range(world))
+        ok = ok and torch.equal(pooled[rank * NMAX:rank * NMAX + ENVS], mine)
+        gather_check = "ok" if ok else "MISMATCH"
+        assert ok, "the pooled rows differ from the ranks' own rows"
+    # ---- secondary arms, rank-local, after the contract's timed region (same process, same roots)
+    # (a) sustained: the contract's K = 20 steps are 0.07 s of GPU work, a burst before the clock settles -- keep stepping for
+    #     >= --sustain-s seconds and report that rate too
+    sustained = None
+    if args.sustain_s > 0:
+        # the step count comes from the (all-reduced) time of the timed region: identical on every rank, so the row all-gathers match
+        n_s = 20 * max(1, int(np.ceil(args.sustain_s / (elapsed / args.steps) / 20)))
+        t_s = time.perf_counter()
+        for j in range(n_s):
+            step(total + j)
+        sync_all()
+        sustained = dict(env_steps_per_s=sum(counts) * n_s / (time.perf_counter() - t_s), steps=n_s, seconds=time.perf_counter() - t_s)
+    # (b) the other tie-break arm (the parity tests pin "first": deterministic first arg-max; collection uses the reference's
+    #     stochastic rule): same K steps after W warm-ups, the search graph re-captured for the other rule
+    other = "first" if args.tiebreak == "random" else "random"
+    for k, r in enumerate(roots_l):
+        r.set_tiebreak(0 if other == "first" else 1, seed=rank * 16 + k + 1)
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t_o = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    other_rate = sum(counts) * args.steps / (time.perf_counter() - t_o)   # (rank 0's clock; the ranks run in lock-step through the all-gathers)
+    for k, r in enumerate(roots_l):
+        r.set_tiebreak(0 if args.tiebreak == "first" else 1, seed=rank * 16 + k + 1)
     # Roofline pass: the timed region replays the search from a captured HIP graph, which cannot carry event
     # records, so the dominant kernel is timed right after it, same process and inputs, with HIP event pairs recorded
     # on the engine stream around every k_chain launch of `prof_steps` eagerly launched steps.
@@ -306,39 +393,50 @@ def main():
     L.check(lib.lz_profile_read(eng, ctypes.byref(n_launch), ctypes.byref(tot_ms)))
     L.check(lib.lz_profile_enable(eng, 0))
 
-    traffic = None
-    try:  # HBM bytes per k_chain launch from the PMC passes (FETCH_SIZE / WRITE_SIZE), see profiles/
-        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
-            traffic = json.load(f)["k_chain"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    # The committed rocprofv3 summary (profiles/r03_manifest.json) is used only when it was measured on the kernel sources this run is
+    # built from (digest of csrc/): then the roofline divides by the profiler's average launch duration and carries the PMC traffic;
+    # otherwise by this run's own HIP-event pairs (which include the gaps of eager launches) with traffic null.
+    man = _profile_manifest()
+    traffic = man["k_chain"]["hbm_bytes_per_launch"] if man else None
     if rank == 0:
-        value = world * ENVS * args.steps / elapsed
+        value = sum(counts) * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
-        avg_us = tot_ms.value / max(n_launch.value, 1) * 1e3
+        ev_us = tot_ms.value / max(n_launch.value, 1) * 1e3
+        use_man = bool(man) and EPS == 256
+        avg_us = man["k_chain"]["rocprof_avg_us"] if use_man else ev_us
+        clock = ("rocprofv3 --kernel-trace average of profiles/%s (measured on these kernel sources: csrc digest matches)" % MANIFEST) if use_man \
+            else "HIP event pairs of this run (no committed profile of these kernel sources)"
         achieved = (EPS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
         knobs = sorted(k for k in os.environ if k.startswith("LZ_"))
         out = {
             "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Atari Pong EfficientZero, obs 4x96x96, 50 sims, "
                                    "256 envs per GPU, A=6, support 601, LSTM 512; synthetic obs, seed-0 random-init weights",
-                       "envs_per_gpu": ENVS, "num_simulations": SIMS, "mcts_sims_per_s": value * SIMS,
-                       "tiebreak": args.tiebreak, "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
+                       "envs_per_gpu": ENVS, "envs_per_rank": counts, "total_envs": sum(counts), "num_simulations": SIMS,
+                       "weight_refresh_every": args.refresh_every, "gather_check": gather_check, "mcts_sims_per_s": value * SIMS,
+                       "tiebreak": args.tiebreak, "tiebreak_%s_env_steps_per_s" % other: other_rate,
+                       "root_noise": "drawn on the device inside every step (lz_roots_prepare_from_inference_dirichlet)" if args.noise == "device"
+                                     else "np.random dirichlet drawn inside every step, uploaded",
+                       "sustained_env_steps_per_s": sustained["env_steps_per_s"] if sustained else None,
+                       "sustained_steps": sustained["steps"] if sustained else 0, "sustained_seconds": sustained["seconds"] if sustained else 0.0,
+                       "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
                        "parallelism": "env-shard x%d" % world, "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend if world > 1 else None,
-                       "per_rank_env_steps_per_s": [ENVS * args.steps / t for t in per_rank],
-                       "row_bytes_per_env_step": W * 4, "all_gather_bytes_per_step_per_rank": (world - 1) * ENVS * W * 4 if world > 1 else 0,
+                       "per_rank_env_steps_per_s": [counts[q] * args.steps / t for q, t in enumerate(per_rank)],
+                       "row_bytes_per_env_step": W * 4, "all_gather_bytes_per_step_per_rank": (world - 1) * NMAX * W * 4 if world > 1 else 0,
                        "all_gather_overlapped": bool(world > 1 and backend == "nccl" and not args.sync_gather),
                        "debug_knobs": knobs},
             "roofline": {"bound": "mfma", "kernel": "k_chain_w (per root: [tree step of the root: expand + backup + next selection, one wave, prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident, 3x3 convolutions by Winograd F(2x2,3x3) on v_mfma_f32_4x4x1; 1 launch/simulation; achieved = the ALGORITHMIC (direct-form) convolution FLOPs of SURVEY 8d over the whole launch -- the kernel executes 0.59x as many matrix cycles for them)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MATRIX_TFLOPS) if achieved else None, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes of profiles/%s, not re-measured in this run)" % TRAFFIC_FILE,
-                         "avg_launch_us": avg_us, "launches_timed": n_launch.value,
+                         "traffic_unit": ("HBM bytes per launch: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE) of profiles/%s" % MANIFEST) if man
+                                         else "null: no committed PMC pass of these kernel sources",
+                         "avg_launch_us": avg_us, "clock": clock,
+                         "avg_launch_us_hip_events": ev_us, "launches_timed": n_launch.value,
                          "timing": "HIP event pairs on the engine stream around each launch, %d eager steps run right after the "
-                                   "graph-replayed timed region" % prof_steps,
+                                   "graph-replayed timed region (this run); the profiler's average when the committed profile is current" % prof_steps,
                          "algorithmic_flop_per_launch": EPS * FLOP_CHAIN},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -346,7 +444,7 @@ def main():
                 out["config"]["policy_surface_env_steps_per_s"] = policy_surface(models[0], obs)
             except Exception as e:
                 out["config"]["policy_surface_env_steps_per_s"] = repr(e)
-            noises0 = [z.tolist() for z in noise_steps[0]]
+            noises0 = [z.tolist() for z in rng.dirichlet([CFG["root_dirichlet_alpha"]] * ACTIONS, size=ENVS).astype(np.float32)]
             out["cpu_baseline"] = cpu_baseline(weights, obs_cpu, noises0)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             try:

@@ -86,6 +86,9 @@ int lz_roots_num(const lz_roots *r);
  * Also resets min/max to (+FLOAT_MAX, -FLOAT_MAX) like a freshly constructed MinMaxStatsList. */
 int lz_roots_minmax_reset(lz_roots *r, float value_delta_max);
 int lz_roots_set_tiebreak(lz_roots *r, int mode, uint64_t seed);
+/* restart the handle's random streams (stochastic tie-breaks, sampled actions, device-side Dirichlet noise, select_action) from `seed`:
+ * also rewinds the device-resident epoch that every prepare advances.  For a handle that is re-armed for a new Roots object. */
+int lz_roots_reseed(lz_roots *r, uint64_t seed);
 
 /* Roots.prepare / prepare_no_noise               ez_tree.pyx:34-42 -> CRoots::prepare cnode.cpp:325-360
  * h_noises_flat: per root, one noise per LEGAL action in list order (cnode.cpp:163-170); NULL => no noise.
@@ -121,6 +124,9 @@ int lz_roots_get_values(lz_roots *r, float *h_out_values);
 int lz_roots_get_trajectories(lz_roots *r, int32_t *h_out, int stride);
 /* (minimum, maximum) per root [root_num][2] -- observability for tests */
 int lz_roots_get_minmax(lz_roots *r, float *h_out);
+/* priors of the root's edges after prepare, [root_num][A] by action, 0 where illegal (CNode::prior, cnode.cpp:139-150, 163-170) --
+ * observability for tests */
+int lz_roots_get_root_priors(lz_roots *r, float *h_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampled EfficientZero trees, continuous action space -- replaces ezs_tree.pyx (ctree_sampled_efficientzero).
@@ -301,10 +307,29 @@ int lz_wino_weights(const float *w, int cout, int cin, float *u);
 int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
                           int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, float *h_header,
                           float *h_policy_logits);
+/* The rows of the two further families (game_segment.py:254-258, muzero_collector.py:606-612): an EXTRA block of lz_rows_extra_words(r)
+ * floats between the action mask and the frame --
+ *   Sampled EfficientZero roots: root_sampled_actions [K][D]; visit block / mask / n_legal are over the K sampled actions, word 0 is
+ *     the selected POSITION (its action = extra[pos * D, pos * D + D));
+ *   Gumbel MuZero roots: improved_policy_probs [A] (CRoots::get_policies, cnode.cpp:506-541, with discount_factor); word 0 = arg-max of
+ *     the improved policy over the legal actions (lzero/policy/gumbel_muzero.py:591-592);
+ *   EfficientZero / MuZero roots: no extra block (the call is lz_roots_collect_rows).
+ * row_words >= 8 + 2 A + extra + frame_floats; h_header is [root_num][8 + 2 A + extra]. */
+int lz_rows_extra_words(lz_roots *r);
+int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor, const float *d_obs,
+                             int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, float *h_header,
+                             float *h_policy_logits);
 /* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
  * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
 int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
                                     const int32_t *h_to_play);
+/* The same prepare with the exploration noise DRAWN ON THE DEVICE: Dirichlet(root_dirichlet_alpha) over every root's legal actions
+ * (lzero/policy/efficientzero.py:599-602 draws np.random.dirichlet([alpha] * n_legal) per env on the host), gamma variates by
+ * Marsaglia-Tsang from a counter-based generator keyed by (roots seed, device-resident epoch that every prepare advances, root,
+ * legal position); only to_play crosses PCIe.  Distribution-equivalent to the reference, not stream-equivalent (parity runs inject
+ * their noise through lz_roots_prepare_from_inference). */
+int lz_roots_prepare_from_inference_dirichlet(lz_roots *r, float root_noise_weight, float root_dirichlet_alpha,
+                                              const int32_t *h_to_play);
 /* EfficientZeroMCTSCtree.search (lzero/mcts/tree_search/mcts_ctree.py:745-876): num_simulations x
  * [select -> gather latent/LSTM state by (ix, iy) -> recurrent_inference -> h^-1 -> LSTM reset every
  * lstm_horizon_len -> expand + backup], entirely on the device, no host synchronisation inside.

@@ -60,6 +60,7 @@ def lib():
         "lz_roots_reset_keep_inference": [P, c_i32p, c_i32p],
         "lz_roots_minmax_reset": [P, ctypes.c_float],
         "lz_roots_set_tiebreak": [P, ctypes.c_int, ctypes.c_uint64],
+        "lz_roots_reseed": [P, ctypes.c_uint64],
         "lz_roots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_i32p],
         "lz_roots_prepare_device": [P, ctypes.c_float, P, P, P, P, ctypes.c_int],
         "lz_batch_traverse": [P, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p],
@@ -68,6 +69,7 @@ def lib():
         "lz_roots_get_values": [P, c_f32p],
         "lz_roots_get_trajectories": [P, c_i32p, ctypes.c_int],
         "lz_roots_get_minmax": [P, c_f32p],
+        "lz_roots_get_root_priors": [P, c_f32p],
         "lz_sroots_create": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)],
         "lz_sroots_create_discrete": [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)],
         "lz_sroots_prepare": [P, ctypes.c_float, P, c_f32p, c_f32p, c_i32p, P],
@@ -96,6 +98,7 @@ def lib():
         "lz_roots_get_root_outputs": [P, c_f32p, c_f32p],
         "lz_roots_adopt_inference": [P, P],
         "lz_roots_prepare_from_inference": [P, ctypes.c_float, P, c_i32p],
+        "lz_roots_prepare_from_inference_dirichlet": [P, ctypes.c_float, ctypes.c_float, c_i32p],
         "lz_search": [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float],
         "lz_profile_enable": [P, ctypes.c_int],
         "lz_profile_read": [P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)],
@@ -111,6 +114,8 @@ def lib():
         "lz_engine_model_uid": [P],
         "lz_rows_width": [ctypes.c_int, ctypes.c_int],
         "lz_wino_weights": [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p],
+        "lz_rows_extra_words": [P],
+        "lz_roots_collect_rows_ex": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_float, P, ctypes.c_int, P, P, ctypes.c_int, c_f32p, P],
         "lz_roots_collect_rows": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, P, ctypes.c_int, P, P, ctypes.c_int, c_f32p, P],
     }
     for name, argtypes in sig.items():

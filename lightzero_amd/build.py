@@ -27,6 +27,20 @@ UNITS = [
 ]
 
 
+def csrc_digest():
+    """sha256 over the sources the library is built from (csrc/*.hip, csrc/*.h, include/lz_mi355.h): what a committed profile or
+    parity record was measured on.  profiles/rNN_manifest.json carries it; bench.py trusts the committed rocprofv3 numbers only when
+    it matches the tree it runs from, and tests/test_profiles_cpu.py fails when a kernel source changed after the last profile."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(PKG), "include", "lz_mi355.h"), "rb").read())
+    return h.hexdigest()
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 

@@ -286,6 +286,17 @@ static int players_of(const int32_t *to_play, int n)
     return largest == -1 ? 1 : 2;
 }
 
+// (re)seed the random streams of a handle that is being re-armed for a new Roots object with a pinned seed: the device-resident
+// epoch (advanced by every prepare) restarts, so that "same seed" means "same streams" whatever the handle did before
+extern "C" int lz_roots_reseed(lz_roots *r, uint64_t seed)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    r->seed = seed;
+    if (r->t.rng_epoch) LZ_HIP_CHECK(hipMemsetAsync(r->t.rng_epoch, 0, 4, r->eng->stream));
+    return LZ_OK;
+}
+
 extern "C" int lz_roots_prepare(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
                                 const float *h_value_prefix, const float *h_policy_logits, const int32_t *h_to_play)
 {
@@ -317,8 +328,7 @@ extern "C" int lz_roots_prepare(lz_roots *r, float root_noise_weight, const floa
     LZ_HIP_CHECK(hipMemcpyAsync(d, h, o_nl, hipMemcpyHostToDevice, s));
     lz_tree_launch_prepare(t, root_noise_weight, h_noises_flat ? (const float *)(d + o_nz) : nullptr, 1,
                            (const int32_t *)(d + o_off), (const float *)(d + o_vp), (const float *)(d + o_lg),
-                           (const int32_t *)(d + o_tp), s);
-    lz_tree_launch_bump_epoch(t, s);
+                           (const int32_t *)(d + o_tp), s);   // (k_prepare bumps the random-stream epoch)
     LZ_HIP_CHECK(hipGetLastError());
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     r->players = players_of(h_to_play, B);
@@ -338,7 +348,6 @@ extern "C" int lz_roots_prepare_device(lz_roots *r, float root_noise_weight, con
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     lz_tree_launch_prepare(r->t, root_noise_weight, d_noises, 0, nullptr, d_value_prefix, d_policy_logits, d_to_play,
                            r->eng->stream);
-    lz_tree_launch_bump_epoch(r->t, r->eng->stream);
     LZ_HIP_CHECK(hipGetLastError());
     r->players = players;
     r->prepared = true;
@@ -736,6 +745,23 @@ extern "C" int lz_roots_get_trajectories(lz_roots *r, int32_t *h_out, int stride
     LZ_HIP_CHECK(hipMemcpyAsync(r->h_stage, r->d_stage, (size_t)B * stride * 4, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));
     memcpy(h_out, r->h_stage, (size_t)B * stride * 4);
+    return LZ_OK;
+}
+
+// observability: the priors of the root's edges after prepare (CNode::prior of the root's children, cnode.cpp:139-150 and, with
+// noise, :163-170), [root_num][A] by ACTION (0 for illegal actions)
+extern "C" int lz_roots_get_root_priors(lz_roots *r, float *h_out)
+{
+    LZ_REQUIRE(r != nullptr && h_out != nullptr && r->prepared, "NULL output / roots not prepared");
+    const lz_tree_dev &t = r->t;
+    LZ_REQUIRE(t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "not for sampled roots");
+    const size_t B = t.B, A = t.A, NN = t.NN;
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    std::vector<float4> tmp(B * A);
+    LZ_HIP_CHECK(hipMemcpy2DAsync(tmp.data(), A * sizeof(float4), t.edge, NN * A * sizeof(float4), A * sizeof(float4), B, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < B * A; ++i) h_out[i] = tmp[i].x;
     return LZ_OK;
 }
 

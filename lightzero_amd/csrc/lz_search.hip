@@ -459,7 +459,11 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
         else LZ_REQUIRE(r->t.A == m->cfg.action_space_size, "roots action space differs from the model's");
     }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
-    if (m->cfg.model_type >= 2) return lz_mlp_initial_inference(r, d_obs);
+    if (m->cfg.model_type >= 2) {
+        const int rc = lz_mlp_initial_inference(r, d_obs);
+        if (rc == LZ_OK) r->last_obs = d_obs;   // the env-step rows take their newest observation from here
+        return rc;
+    }
     int rc = ensure_pools(r);
     if (rc != LZ_OK) return rc;
     rc = ensure_ws(m, r->t.B);
@@ -890,6 +894,133 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
     return LZ_OK;
 }
 
+// ---- env-step rows of the two further families that ship: an EXTRA block between the action mask and the frame carries what
+// their store_search_stats keeps besides visits and value (game_segment.py:254-258, muzero_collector.py:606-612):
+//   Sampled EfficientZero   root_sampled_actions [K][D]; the visit block / mask / n_legal are over the K sampled actions (mask = 1),
+//                           word 0 is the selected POSITION (the action is extra[pos D .. pos D + D))
+//   Gumbel MuZero           improved_policy_probs [A] (softmax(logits + sigma(completed Q)), CRoots::get_policies cnode.cpp:506-541);
+//                           word 0 is arg-max of the improved policy over the legal actions (gumbel_muzero.py:591-592)
+namespace {
+__global__ __launch_bounds__(256) void k_pack_rows_ex(lz_tree_dev t, int variant, const int32_t *__restrict__ dist, const int32_t *__restrict__ cnt,
+                                                      const float *__restrict__ values, const float *__restrict__ pred,
+                                                      const int32_t *__restrict__ pos, const double *__restrict__ ent,
+                                                      const int32_t *__restrict__ to_play, const int32_t *__restrict__ timestep,
+                                                      const float *__restrict__ extra, int extra_words,
+                                                      const float *__restrict__ obs, int obs_floats, int frame_floats,
+                                                      float *__restrict__ rows, int row_words)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, A = t.A;
+    float *row = rows + (size_t)b * row_words;
+    const bool sampled = variant == LZ_TREE_SAMPLED_EFFICIENTZERO;
+    const int n = sampled ? A : cnt[b];
+    const float *ex = extra + (size_t)b * extra_words;
+    if (tid == 0) {
+        int total = 0;
+        for (int j = 0; j < n; ++j) total += dist[(size_t)b * A + j];
+        const float sum_visits = total == 0 ? 1e-6f : (float)total;  // game_segment.py:244-246
+        float action = sampled ? (float)pos[b] : (float)t.legal[(size_t)b * A + pos[b]];
+        if (variant == LZ_TREE_GUMBEL_MUZERO) {   // np.argmax over where(mask, improved, 0): first maximum, all-zero -> action 0
+            float best = 0.0f;
+            int arg = 0;
+            for (int j = 0; j < n; ++j) {
+                const int a = t.legal[(size_t)b * A + j];
+                const float v = ex[a];
+                if (v > best || (v == best && a < arg && v > 0.0f)) { best = v; arg = a; }
+            }
+            action = (float)arg;
+        }
+        row[0] = action;
+        row[1] = 0.0f;
+        row[2] = values[b];
+        row[3] = pred[b];
+        row[4] = (float)to_play[b];
+        row[5] = timestep ? (float)timestep[b] : -1.0f;
+        row[6] = (float)ent[b];
+        row[7] = (float)n;
+        for (int j = 0; j < A; ++j) row[8 + j] = j < n ? (float)dist[(size_t)b * A + j] / sum_visits : 0.0f;
+        for (int j = 0; j < A; ++j) row[8 + A + j] = sampled ? 1.0f : 0.0f;
+        if (!sampled) for (int j = 0; j < n; ++j) row[8 + A + t.legal[(size_t)b * A + j]] = 1.0f;
+    }
+    for (int i = tid; i < extra_words; i += 256) row[8 + 2 * A + i] = ex[i];
+    if (frame_floats > 0) {
+        const float *src = obs + (size_t)b * obs_floats + (obs_floats - frame_floats);
+        float *dst = row + 8 + 2 * A + extra_words;
+        for (int i = tid; i < frame_floats; i += 256) dst[i] = src[i];
+    }
+}
+}  // namespace
+
+extern "C" int lz_rows_extra_words(lz_roots *r)
+{
+    if (!r) return LZ_ERR_INVALID;
+    if (r->t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) return r->t.A * r->t.D;
+    if (r->t.variant == LZ_TREE_GUMBEL_MUZERO) return r->t.A;
+    return 0;
+}
+
+extern "C" int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor,
+                                        const float *d_obs, int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
+                                        float *h_header, float *h_policy_logits)
+{
+    LZ_REQUIRE(r != nullptr && d_rows != nullptr && h_header != nullptr, "NULL argument");
+    const int E = lz_rows_extra_words(r);
+    if (E == 0) return lz_roots_collect_rows(r, temperature, deterministic, seed, d_obs, frame_floats, h_timestep, d_rows, row_words, h_header, h_policy_logits);
+    LZ_REQUIRE(r->prepared && r->inferred && r->pool_slab != nullptr, "roots not searched through the fused path");
+    LZ_REQUIRE(temperature > 0.0, "select_action needs a positive temperature");
+    const lz_tree_dev &t = r->t;
+    lz_model *m = r->eng->model;
+    const bool sampled = t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO;
+    const size_t B = t.B, A = t.A;
+    const size_t PA = m->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(m) : A;
+    const int obs_floats = m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
+    if (!d_obs) d_obs = r->last_obs;
+    LZ_REQUIRE(frame_floats >= 0 && frame_floats <= obs_floats && (frame_floats == 0 || d_obs != nullptr), "frame_floats exceeds the observation / no observation known");
+    LZ_REQUIRE(row_words >= (int)(8 + 2 * A) + E + frame_floats, "row_words too small (lz_rows_width + lz_rows_extra_words)");
+    LZ_HIP_CHECK(hipSetDevice(r->eng->device));
+    hipStream_t s = r->eng->stream;
+    const size_t hw = 8 + 2 * A + (size_t)E;    // the header that returns to the host includes the extra block
+    const size_t n_i = B * A + 3 * B, n_f = B + B * PA + B * (size_t)E, dev_bytes = B * 8 + (n_i + n_f) * 4;
+    const size_t host_bytes = (B + B * hw + B * PA) * 4;
+    const size_t bytes = dev_bytes > host_bytes ? dev_bytes : host_bytes;
+    if (r->results_bytes < bytes) {
+        if (r->d_results) { LZ_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(r->d_results); r->d_results = nullptr; }
+        if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
+        LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_results, bytes));
+        LZ_HIP_CHECK(hipHostMalloc(&r->h_results, bytes, hipHostMallocDefault));
+        r->results_bytes = bytes;
+    }
+    double *d_ent = (double *)r->d_results;
+    int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B, *d_ts = d_pos + B;
+    float *d_val = (float *)(d_ts + B), *d_lg = d_val + B, *d_extra = d_lg + B * PA;
+    if (sampled) {
+        lz_stree_launch_readout(t, d_dist, d_val, s);
+        // the roots' K sampled actions: node 0 of every root, [B] strided blocks of K * D floats
+        LZ_HIP_CHECK(hipMemcpy2DAsync(d_extra, (size_t)E * 4, t.actions, (size_t)t.NN * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s));
+    } else {
+        lz_tree_launch_readout(t, d_dist, d_cnt, d_val, s);
+        lz_gtree_launch_policies(t, discount_factor, d_extra, nullptr, s);
+    }
+    lz_launch_select_action(t, 1.0 / temperature, deterministic, seed, d_pos, d_ent, s);
+    int32_t *hts = (int32_t *)r->h_results;
+    if (h_timestep) {
+        memcpy(hts, h_timestep, B * 4);
+        LZ_HIP_CHECK(hipMemcpyAsync(d_ts, hts, B * 4, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_pack_rows_ex, dim3((unsigned)B), dim3(256), 0, s, t, (int)t.variant, d_dist, d_cnt, d_val, r->sim_value, d_pos, d_ent,
+                       r->d_to_play, h_timestep ? d_ts : nullptr, d_extra, E, d_obs, obs_floats, frame_floats, d_rows, row_words);
+    LZ_HIP_CHECK(hipGetLastError());
+    float *hh = (float *)(hts + B);
+    LZ_HIP_CHECK(hipMemcpy2DAsync(hh, hw * 4, d_rows, (size_t)row_words * 4, hw * 4, B, hipMemcpyDeviceToHost, s));
+    if (h_policy_logits) {
+        LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
+        LZ_HIP_CHECK(hipMemcpyAsync(hh + B * hw, d_lg, B * PA * 4, hipMemcpyDeviceToHost, s));
+    }
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(h_header, hh, B * hw * 4);
+    if (h_policy_logits) memcpy(h_policy_logits, hh + B * hw, B * PA * 4);
+    return LZ_OK;
+}
+
 extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records)
 {
     LZ_REQUIRE(r != nullptr && r->t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO, "not a Sampled-EfficientZero roots handle");
@@ -906,8 +1037,10 @@ extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int record
     return LZ_OK;
 }
 
-extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
-                                               const int32_t *h_to_play)
+static void launch_dirichlet(lz_roots *r, float alpha, hipStream_t s);
+
+static int prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat, const int32_t *h_to_play,
+                                  float device_alpha)
 {
     LZ_REQUIRE(r != nullptr && r->inferred && h_to_play != nullptr, "lz_initial_inference must run first; to_play required");
     r->inference_fresh = false;
@@ -978,15 +1111,100 @@ extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_wei
         LZ_HIP_CHECK(hipMemcpyAsync(r->d_to_play, hp, up, hipMemcpyHostToDevice, s));
         LZ_HIP_CHECK(hipEventRecord(r->prep_done, s));
     }
+    int ragged = 1;
+    if (device_alpha > 0.0f) {   // Dirichlet(alpha) over every root's legal actions, drawn on the device: [B][A] by legal position
+        launch_dirichlet(r, device_alpha, s);
+        d_noise = r->d_noise;
+        ragged = 0;
+    }
     if (t.variant == LZ_TREE_GUMBEL_MUZERO)  // roots.prepare(noise_w, noises, reward_roots = 0, pred_values, policy_logits, to_play), gumbel_muzero.py:562
-        lz_gtree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_value, r->sim_logits, r->d_to_play, s);
+        lz_gtree_launch_prepare(t, root_noise_weight, d_noise, ragged, r->d_noise_off, r->d_zero_vp, r->sim_value, r->sim_logits, r->d_to_play, s);
     else
-        lz_tree_launch_prepare(t, root_noise_weight, d_noise, 1, r->d_noise_off, r->d_zero_vp, r->sim_logits, r->d_to_play, s);
+        lz_tree_launch_prepare(t, root_noise_weight, d_noise, ragged, r->d_noise_off, r->d_zero_vp, r->sim_logits, r->d_to_play, s);
     LZ_HIP_CHECK(hipGetLastError());
     r->players = players;
     r->prepared = true;
     r->traverse_count = 0;
     return LZ_OK;
+}
+
+extern "C" int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,
+                                               const int32_t *h_to_play)
+{
+    return prepare_from_inference(r, root_noise_weight, h_noises_flat, h_to_play, 0.0f);
+}
+
+// ---- Dirichlet exploration noise drawn on the device (efficientzero.py:599-602: np.random.dirichlet([alpha] * n_legal) per env).
+// One workgroup per root, thread i = position i of the root's legal list: gamma(alpha) by Marsaglia & Tsang (2000) -- for
+// alpha < 1 a gamma(alpha + 1) variate times u^(1 / alpha) --, normalised over the root's legal actions.  Counter-based generator
+// keyed by (seed, device-resident epoch bumped by every prepare, root, position): a captured or replayed step draws fresh noise
+// without any host involvement.  The draws are compared with nothing bit for bit (the reference's come from numpy's
+// MT19937); tests/test_dirichlet_gpu.py checks the distribution (Beta marginals, unit sums, independence across roots / steps).
+namespace {
+// splitmix64 finaliser (same generator as the tree kernels' tie-break / sampling streams, lz_tree_dev.h)
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t st, int shift) { return ((float)((st >> shift) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void k_dirichlet(lz_tree_dev t, float alpha, uint64_t seed, float *__restrict__ out /* [B][A] by legal position */)
+{
+    __shared__ float s_part[4];
+    const int b = blockIdx.x, i = threadIdx.x, n = t.n_legal[b];
+    const uint32_t epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;
+    float g = 0.0f;
+    if (i < n) {
+        uint64_t st = mix64(mix64(seed ^ 0xd1b54a32d192ed03ull ^ ((uint64_t)epoch << 20)) ^ ((uint64_t)b << 24) ^ (uint64_t)i);
+        const float a = alpha < 1.0f ? alpha + 1.0f : alpha;
+        const float d = a - (1.0f / 3.0f), c = __builtin_amdgcn_rsqf(9.0f * d);
+        float v = 1.0f;
+        for (int it = 0; it < 24; ++it) {   // acceptance > 95 % per round
+            st = mix64(st);
+            const float u1 = u01(st, 40), u2 = u01(st, 16);
+            const float x = __fsqrt_rn(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
+            st = mix64(st);
+            const float u = u01(st, 40);
+            const float w = 1.0f + c * x;
+            v = w * w * w;
+            if (w > 0.0f && __logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) break;
+            v = 1.0f;
+        }
+        g = d * v;
+        if (alpha < 1.0f) {
+            st = mix64(st);
+            g *= __expf(__logf(u01(st, 40)) / alpha);
+        }
+        g = fmaxf(g, 1e-37f);   // (u^(1/alpha) underflows for tiny alpha: keep the sum positive)
+    }
+    float sum = g;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((i & 63) == 0) s_part[i >> 6] = sum;
+    __syncthreads();
+    const float tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (i < t.A) out[(size_t)b * t.A + i] = i < n ? g / tot : 0.0f;
+}
+}  // namespace
+
+static void launch_dirichlet(lz_roots *r, float alpha, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dirichlet, dim3(r->t.B), dim3(256), 0, s, r->t, alpha, r->seed, r->d_noise);
+}
+
+// Roots.prepare with the policy logits of lz_initial_inference AND Dirichlet(alpha) noise drawn on the device for every root's legal
+// actions (efficientzero.py:599-605): nothing but to_play crosses PCIe.
+extern "C" int lz_roots_prepare_from_inference_dirichlet(lz_roots *r, float root_noise_weight, float root_dirichlet_alpha,
+                                                         const int32_t *h_to_play)
+{
+    LZ_REQUIRE(r != nullptr && r->inferred && h_to_play != nullptr, "lz_initial_inference must run first; to_play required");
+    LZ_REQUIRE(root_dirichlet_alpha > 0.0f, "root_dirichlet_alpha must be positive");
+    LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "the sampled tree's shipped score never reads the noisy priors: use lz_roots_prepare_from_inference");
+    LZ_REQUIRE(r->t.A <= 256, "action space beyond 256");
+    return prepare_from_inference(r, root_noise_weight, nullptr, h_to_play, root_dirichlet_alpha);
 }
 
 // Timing experiments that SKIP WORK (results are then meaningless) exist only in the -DLZ_DEBUG_KNOBS build

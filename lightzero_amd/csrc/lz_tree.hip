@@ -87,6 +87,9 @@ __global__ __launch_bounds__(64) void k_prepare(lz_tree_dev t, float noise_w, co
         t.node_bidx[o] = b;   // CNode::batch_index of the root (cnode.cpp:334)
         t.root_visit[b] = 1;  // visit_count += 1 (cnode.cpp:341)
         t.root_vsum[b] = 0.0f;
+        // every prepare starts a new env-step: the random streams keyed by the epoch (stochastic tie-breaks, device-side Dirichlet
+        // noise) move on.  Nothing in this kernel reads it; the kernels that do are launched after it.
+        if (b == 0 && t.rng_epoch) t.rng_epoch[0] += 1u;
     }
 }
 

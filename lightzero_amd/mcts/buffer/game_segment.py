@@ -1,27 +1,42 @@
-"""Vectorised counterpart of lzero/mcts/buffer/game_segment.py::GameSegment for a whole batch of environments: what
-``MuZeroCollector.collect`` does per env and step with Python lists (muzero_collector.py:588-620:
+"""Vectorised counterpart of lzero/mcts/buffer/game_segment.py::GameSegment for a whole batch of environments, plus the segment
+hand-over of the collector: what ``MuZeroCollector.collect`` does per env and step with Python lists (muzero_collector.py:588-620:
 ``store_search_stats`` game_segment.py:241-263 + ``append`` :158-182) is two array writes for all envs here, fed by the packed
-env-step rows the engine writes on the device (``lz_roots_collect_rows`` / lightzero_amd.shard.pack_rows).
+env-step rows the engine writes on the device (``lz_roots_collect_rows`` / lightzero_amd.shard.pack_rows); ``rollover`` is the
+collector's segment logic (muzero_collector.py:308-410, 649-692): a full segment waits for the first ``num_unroll_steps + td_steps``
+entries of its successor (``pad_over``, game_segment.py:183-234), then goes to the pool with its priorities and done flag.
 
 Per env it holds exactly the lists of the reference class as pre-allocated arrays (``obs_segment`` incl. the ``frame_stack_num``
 initial frames of ``reset``, ``action_segment``, ``reward_segment``, ``child_visit_segment``, ``root_value_segment``,
-``action_mask_segment``, ``to_play_segment``, ``timestep_segment``); ``to_arrays(env)`` returns what
-``game_segment_to_array`` (:265-338) leaves in those attributes.  Replay buffers, targets and ``pad_over`` stay out of scope."""
+``action_mask_segment``, ``to_play_segment``, ``timestep_segment``, and for the sampled / Gumbel families ``root_sampled_actions`` /
+``improved_policy_probs``); ``to_arrays(env)`` returns what ``game_segment_to_array`` (:265-338) leaves in those attributes.
+Replay buffers and target computation stay out of scope."""
 import numpy as np
 
 from ... import shard
 
 
 class GameSegmentBatch(object):
-    def __init__(self, n_env, action_space_size, game_segment_length, frame_shape, frame_stack_num=1, extra=0):
-        """``extra``: room for the ``num_unroll_steps + td_steps`` entries ``pad_over`` may add in the reference (unused here)."""
+    def __init__(self, n_env, action_space_size, game_segment_length, frame_shape, frame_stack_num=1, num_unroll_steps=5, td_steps=5,
+                 sampled_actions_shape=None, improved_policy=False, use_priority=False, use_max_priority_for_new_data=False,
+                 ignore_done=False, extra=0):
+        """``sampled_actions_shape`` (K, D): Sampled EfficientZero -- the row's child visits are over the K sampled actions and every
+        step also stores the root's sampled actions (game_segment.py:254-255).  ``improved_policy``: Gumbel MuZero -- every step stores
+        the improved policy over the A actions (:257-258).  ``use_priority`` / ``use_max_priority_for_new_data``: muzero_collector.py:
+        308-334."""
         self.n_env, self.A, self.L = int(n_env), int(action_space_size), int(game_segment_length)
         self.frame_shape, self.stack = tuple(frame_shape), int(frame_stack_num)
+        self.pad = int(num_unroll_steps) + int(td_steps)
+        self.use_priority = bool(use_priority) and not bool(use_max_priority_for_new_data)
+        self.ignore_done = bool(ignore_done)
         cap = self.L + int(extra)
-        # observation frames are kept the way the reference keeps them -- by reference (its obs_segment is a list of the arrays
-        # the environment returned): one entry per append call = (env ids or None, [n, *frame_shape] array, per-env positions)
+        # observation frames are kept the way the reference keeps them -- by reference (its obs_segment is a list of the arrays the
+        # environment returned): one entry per append call = (env ids or None, [n, *frame_shape] array, per-env positions, per-env
+        # segment generation).  An entry belongs to an env's CURRENT segment while its generation tag equals gen[env]; ``reset`` of
+        # some envs bumps their generation and leaves every other env's frames alone.
         self._init_obs = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)
+        self._window = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)   # observation_window_stack of the collector
         self._frames = []
+        self._gen = np.zeros(self.n_env, np.int64)
         self.action = np.zeros((self.n_env, cap), np.int64)
         self.reward = np.zeros((self.n_env, cap), np.float32)
         self.child_visits = np.zeros((self.n_env, cap, self.A), np.float32)
@@ -32,8 +47,14 @@ class GameSegmentBatch(object):
         self.timestep = np.zeros((self.n_env, cap), np.int64)
         self.predicted_value = np.zeros((self.n_env, cap), np.float32)
         self.entropy = np.zeros((self.n_env, cap), np.float32)
+        self.sampled_shape = tuple(sampled_actions_shape) if sampled_actions_shape else None
+        self.sampled_actions = np.zeros((self.n_env, cap) + self.sampled_shape, np.float32) if self.sampled_shape else None
+        self.improved = np.zeros((self.n_env, cap, self.A), np.float32) if improved_policy else None
         self.len = np.zeros(self.n_env, np.int64)       # transitions appended so far (= len(action_segment))
         self._stats = np.zeros(self.n_env, np.int64)    # search statistics stored so far (= len(root_value_segment))
+        self._last = [None] * self.n_env                # the previous, full segment of an env: waits for its padding
+        self._last_pri = [None] * self.n_env
+        self.pool = []                                  # (segment dict, priorities | None, done): muzero_collector.py game_segment_pool
 
     def _ids(self, env_ids):
         return np.arange(self.n_env) if env_ids is None else np.asarray(env_ids, np.int64)
@@ -44,17 +65,18 @@ class GameSegmentBatch(object):
         ids = self._ids(env_ids)
         init = np.asarray(init_observations, np.float32).reshape((len(ids), self.stack) + self.frame_shape)
         self._init_obs[ids] = init
-        if env_ids is None:
-            self._frames = []
-        else:  # the appended frames of these envs belong to their previous segment
-            drop = set(int(i) for i in ids)
-            self._frames = [(fi, fr, pos) for fi, fr, pos in self._frames if fi is not None and not drop.intersection(fi.tolist())]
+        self._window[ids] = init
+        self._gen[ids] += 1   # the frames appended so far belong to the previous segments of these envs -- and only of these
+        if len(self._frames) > 4 * (self.L + self.pad + 8):   # entries none of whose envs is current any more
+            self._frames = [e for e in self._frames if (e[3] == self._gen[self._ids(e[0])]).any()]
         self.len[ids] = 0
         self._stats[ids] = 0
 
-    def store_search_stats_rows(self, rows, env_ids=None):
+    def store_search_stats_rows(self, rows, env_ids=None, sampled_actions=None, improved_policy=None):
         """store_search_stats (:241-263) for every env of ``rows`` ([n, >= 8 + 2A] env-step rows, frames not needed): child
-        visits / sum and root value; also keeps the decision-time fields ``append`` will take (action, mask, to_play, timestep)."""
+        visits / sum and root value; also keeps the decision-time fields ``append`` will take (action, mask, to_play, timestep).
+        ``sampled_actions`` [n, K, D] / ``improved_policy`` [n, A]: the extra argument the sampled / Gumbel families store
+        (taken from the row's extra block by default, shard.unpack_rows)."""
         ids = self._ids(env_ids)
         rows = np.asarray(rows)
         t = self._stats[ids]
@@ -68,21 +90,106 @@ class GameSegmentBatch(object):
         self.action_mask[ids, t] = rows[:, H + A:H + 2 * A]
         self.to_play[ids, t] = rows[:, shard.F_TO_PLAY].astype(np.int64)
         self.timestep[ids, t] = rows[:, shard.F_TIMESTEP].astype(np.int64)
+        if self.sampled_actions is not None:
+            n_extra = int(np.prod(self.sampled_shape))
+            sa = sampled_actions if sampled_actions is not None else rows[:, H + 2 * A:H + 2 * A + n_extra]
+            self.sampled_actions[ids, t] = np.asarray(sa, np.float32).reshape((len(ids),) + self.sampled_shape)
+        if self.improved is not None:
+            ip = improved_policy if improved_policy is not None else rows[:, H + 2 * A:H + 3 * A]
+            self.improved[ids, t] = np.asarray(ip, np.float32).reshape(len(ids), A)
         self._stats[ids] = t + 1
 
     def append(self, next_observations, rewards, env_ids=None):
         """the environment-side half of GameSegment.append (:158-182): o_{t+1} and r_t of the transition whose decision-time
-        fields came with ``store_search_stats_rows``"""
+        fields came with ``store_search_stats_rows``; also the collector's observation window (muzero_collector.py:641)"""
         ids = self._ids(env_ids)
         t = self.len[ids]
         frames = np.asarray(next_observations, np.float32).reshape((len(ids),) + self.frame_shape)  # a view when already float32
-        self._frames.append((None if env_ids is None else ids.copy(), frames, t.copy()))
+        self._frames.append((None if env_ids is None else ids.copy(), frames, t.copy(), self._gen[ids].copy()))
         self.reward[ids, t] = np.asarray(rewards, np.float32)
         self.len[ids] = t + 1
+        if self.stack > 1:
+            self._window[ids, :-1] = self._window[ids, 1:]
+        self._window[ids, -1] = frames
 
     def is_full(self):
         """GameSegment.is_full (:370-377), per env"""
         return self.len >= self.L
+
+    # ---- segment hand-over (muzero_collector.py:308-410, 649-692)
+    def _priorities(self, env):
+        """_compute_priorities (:308-334): L1 distance of predicted and searched root values + 1e-6, or None (= the buffer's maximum)"""
+        if not self.use_priority:
+            return None
+        n = int(self._stats[env])
+        return np.abs(self.predicted_value[env, :n] - self.root_value[env, :n]) + np.float32(1e-6)
+
+    def _pad_and_save(self, env, done):
+        """pad_and_save_last_trajectory (:336-410): the waiting segment of ``env`` takes the first entries of the current one
+        (pad_over, game_segment.py:183-234: ``pad`` observations / actions / child visits / root values, ``pad - 1`` rewards), is
+        converted to arrays and pooled"""
+        last, cur = self._last[env], self.to_arrays(env)
+        p, s = self.pad, self.stack
+        last["valid_transition_count"] = min(len(last["action_segment"]), self.L)
+        last["obs_segment"] = np.concatenate([last["obs_segment"], cur["obs_segment"][s:s + p]], 0)
+        last["reward_segment"] = np.concatenate([last["reward_segment"], cur["reward_segment"][:p - 1]], 0)
+        last["action_segment"] = np.concatenate([last["action_segment"], cur["action_segment"][:p]], 0)
+        last["root_value_segment"] = np.concatenate([last["root_value_segment"], cur["root_value_segment"][:p]], 0)
+        a, b = last["child_visit_segment"], cur["child_visit_segment"][:p]
+        if a.dtype == object or b.dtype == object or (a.ndim == 2 and b.ndim == 2 and a.shape[1] != b.shape[1]):
+            merged = np.empty(len(a) + len(b), dtype=object)   # variable action spaces: dtype=object like the reference (:316-321)
+            for k, row in enumerate(list(a) + list(b)):
+                merged[k] = list(row)
+            if len(merged) and all(len(x) == len(merged[0]) for x in merged):
+                merged = np.array([list(x) for x in merged])
+            last["child_visit_segment"] = merged
+        else:
+            last["child_visit_segment"] = np.concatenate([a, b.reshape((len(b),) + a.shape[1:])], 0) if len(b) else a
+        if self.improved is not None:
+            last["improved_policy_probs"] = np.concatenate([last["improved_policy_probs"], cur["improved_policy_probs"][:p]], 0)
+        self.pool.append((last, self._last_pri[env], bool(done)))
+        self._last[env], self._last_pri[env] = None, None
+
+    def rollover(self, done=None, reset_observations=None):
+        """The collector's segment logic for every env, after this step's ``append`` (muzero_collector.py:649-692 inside the per-env
+        loop): a FULL segment pads and pools its predecessor, takes its place as the waiting segment (with its priorities) and a new
+        segment starts from the observation window; a DONE env pads and pools the waiting segment, pools the current one (if it holds
+        a transition) and -- when ``reset_observations`` ([n_env | n_done, *frame_shape], the first observation of the next episode)
+        is given -- starts a fresh episode.  Returns the number of segments pooled."""
+        before = len(self.pool)
+        done = np.zeros(self.n_env, bool) if done is None or self.ignore_done else np.asarray(done, bool)
+        full = self.is_full()
+        n_done = 0
+        for env in np.nonzero(full | done)[0]:   # env by env, like the collector's loop: the pool keeps its order
+            if full[env]:
+                if self._last[env] is not None:
+                    self._pad_and_save(env, done[env])
+                pri = self._priorities(env)
+                self._last[env] = self.to_arrays(env)
+                self._last_pri[env] = pri
+                self.reset(self._window[env][None], env_ids=[env])
+            if done[env]:
+                if self._last[env] is not None:
+                    self._pad_and_save(env, done[env])
+                pri = self._priorities(env)
+                seg = self.to_arrays(env)
+                seg["valid_transition_count"] = min(len(seg["action_segment"]), self.L)
+                if len(seg["reward_segment"]) > 0:
+                    self.pool.append((seg, pri, bool(done[env])))
+                if reset_observations is not None:
+                    ro = np.asarray(reset_observations, np.float32)
+                    frame = ro[env] if ro.shape[0] == self.n_env else ro[n_done]
+                    self.reset(np.repeat(frame.reshape((1, 1) + self.frame_shape), self.stack, 1), env_ids=[env])
+                self._last[env], self._last_pri[env] = None, None
+                n_done += 1
+        return len(self.pool) - before
+
+    def drain_pool(self):
+        """(segments, [{'priorities', 'done', 'unroll_plus_td_steps'}]) like the collector's return_data (:700-710); empties the pool"""
+        segs = [p[0] for p in self.pool]
+        meta = [dict(priorities=p[1], done=p[2], unroll_plus_td_steps=self.pad) for p in self.pool]
+        self.pool = []
+        return segs, meta
 
     def to_arrays(self, env):
         """game_segment_to_array (:265-338) for one env: the arrays its attributes hold afterwards"""
@@ -97,14 +204,21 @@ class GameSegmentBatch(object):
                 child[k] = self.child_visits[env, k, :int(nl[k])].tolist()
         obs = np.zeros((self.stack + n,) + self.frame_shape, np.float32)
         obs[:self.stack] = self._init_obs[env]
-        for fi, fr, pos in self._frames:
+        g = self._gen[env]
+        for fi, fr, pos, gen in self._frames:
             if fi is None:
-                obs[self.stack + int(pos[env])] = fr[env]
+                if gen[env] == g:
+                    obs[self.stack + int(pos[env])] = fr[env]
             else:
                 k = np.nonzero(fi == env)[0]
-                if k.size:
+                if k.size and gen[k[0]] == g:
                     obs[self.stack + int(pos[k[0]])] = fr[k[0]]
-        return dict(obs_segment=obs, action_segment=self.action[env, :n].copy(),
-                    reward_segment=self.reward[env, :n].copy(), child_visit_segment=child,
-                    root_value_segment=self.root_value[env, :ns].copy(), action_mask_segment=self.action_mask[env, :n].copy(),
-                    to_play_segment=self.to_play[env, :n].copy(), timestep_segment=self.timestep[env, :n].copy())
+        out = dict(obs_segment=obs, action_segment=self.action[env, :n].copy(),
+                   reward_segment=self.reward[env, :n].copy(), child_visit_segment=child,
+                   root_value_segment=self.root_value[env, :ns].copy(), action_mask_segment=self.action_mask[env, :n].copy(),
+                   to_play_segment=self.to_play[env, :n].copy(), timestep_segment=self.timestep[env, :n].copy())
+        if self.sampled_actions is not None:
+            out["root_sampled_actions"] = self.sampled_actions[env, :ns].copy()
+        if self.improved is not None:
+            out["improved_policy_probs"] = self.improved[env, :ns].copy()
+        return out

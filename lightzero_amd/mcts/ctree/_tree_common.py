@@ -34,6 +34,23 @@ def _engine_key(engine):
     return getattr(engine, "value", engine)
 
 
+def collect_rows_ex(roots, A_row, temperature, deterministic, d_rows_ptr, row_words, frame_floats, discount=0.997, timestep=None, seed=None,
+                    policy_width=None, d_obs_ptr=None):
+    """lz_roots_collect_rows_ex for any roots handle: (header [B, 8 + 2 A_row + extra] on the host, root policy logits); the extra
+    block holds root_sampled_actions (sampled roots) / improved_policy_probs (Gumbel roots), see include/lz_mi355.h"""
+    B = roots.root_num
+    E = int(L.lib().lz_rows_extra_words(roots._h))
+    hdr = np.zeros((B, 8 + 2 * A_row + E), np.float32)
+    lg = np.zeros((B, policy_width or A_row), np.float32)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 62))
+    ts = None if timestep is None else L.i32(timestep)
+    L.check(L.lib().lz_roots_collect_rows_ex(roots._h, float(temperature), 1 if deterministic else 0, int(seed), float(discount), d_obs_ptr,
+                                             int(frame_floats), None if ts is None else ts.ctypes.data, d_rows_ptr, int(row_words), hdr,
+                                             lg.ctypes.data))
+    return hdr, lg
+
+
 def make_module(variant, has_deterministic_flag):
     class MinMaxStatsList(object):
         def __init__(self, num):
@@ -107,6 +124,8 @@ def make_module(variant, has_deterministic_flag):
                 h, seed0 = parked.pop()
                 if self._seed is None:
                     self._seed = seed0
+                else:   # a pinned seed means the same streams whatever the handle did before
+                    L.check(L.lib().lz_roots_reseed(h, self._seed))
                 L.check(L.lib().lz_roots_reset(h, flat, cnt))
             else:
                 h = L.P()
@@ -210,6 +229,17 @@ def make_module(variant, has_deterministic_flag):
             L.check(L.lib().lz_roots_prepare_from_inference(self._h, float(root_noise_weight), nz.ctypes.data,
                                                             L.i32(to_play_batch)))
 
+        def prepare_from_inference_dirichlet(self, root_noise_weight, root_dirichlet_alpha, to_play_batch):
+            """Roots.prepare with the logits of the engine model's initial_inference and Dirichlet(alpha) exploration noise drawn
+            ON THE DEVICE for every root's legal actions (efficientzero.py:599-605 draws it per env with numpy): no noise array
+            is built or uploaded.  Same distribution as the reference's, its own random stream (seed: set_tiebreak / mcts_seed)."""
+            if self._h is None:
+                raise L.LzError("prepare_from_inference_dirichlet before an engine model's initial_inference on these roots")
+            if len(to_play_batch) != self.root_num:
+                raise ValueError("to_play_batch must have root_num entries")
+            L.check(L.lib().lz_roots_prepare_from_inference_dirichlet(self._h, float(root_noise_weight), float(root_dirichlet_alpha),
+                                                                      L.i32(to_play_batch)))
+
         def prepare_from_inference_no_noise(self, to_play_batch):
             if self._h is None:
                 raise L.LzError("prepare_from_inference_no_noise before an engine model's initial_inference on these roots")
@@ -288,6 +318,12 @@ def make_module(variant, has_deterministic_flag):
                 seed = int(np.random.randint(0, 2 ** 62))
             L.check(L.lib().lz_roots_select_action(self._h, float(temperature), 1 if deterministic else 0, int(seed), pos, ent))
             return pos, ent
+
+        def get_root_priors(self):
+            """priors of the roots' edges after prepare ([root_num, A] by action, 0 where illegal) -- observability"""
+            out = np.zeros((self.root_num, self._A), np.float32)
+            L.check(L.lib().lz_roots_get_root_priors(self._h, out.reshape(-1)))
+            return out
 
         def get_minmax(self):
             out = np.zeros((self.root_num, 2), np.float32)

@@ -30,6 +30,14 @@ class Roots(_base["Roots"]):
         L.check(L.lib().lz_groots_prepare(self._h, 0.0, None, L.f32(value_prefix_pool), L.f32(value_pool), logits,
                                           L.i32(to_play_batch)))
 
+    def collect_rows(self, temperature, deterministic, d_rows_ptr, row_words, frame_floats, timestep=None, seed=None, policy_width=None,
+                     d_obs_ptr=None, discount=0.997):
+        """after a fused search: the env-step rows with the improved policy in the extra block and arg-max(improved policy over the
+        legal actions) as the action (gumbel_muzero.py:591-592); returns (header [B, 8 + 3 A], root policy logits)"""
+        from .._tree_common import collect_rows_ex
+        return collect_rows_ex(self, self._A, temperature, deterministic, d_rows_ptr, row_words, frame_floats, discount=discount,
+                               timestep=timestep, seed=seed, policy_width=policy_width, d_obs_ptr=d_obs_ptr)
+
     def get_policies(self, discount, action_space_size):
         out = np.zeros((self.root_num, self._A), np.float32)
         L.check(L.lib().lz_groots_get_policies(self._h, float(discount), out.ctypes.data, None))

@@ -163,6 +163,15 @@ class Roots(object):
         L.check(L.lib().lz_sroots_get_node_actions(self._h, int(node), out.reshape(-1)))
         return out
 
+    def collect_rows(self, temperature, deterministic, d_rows_ptr, row_words, frame_floats, timestep=None, seed=None, policy_width=None,
+                     d_obs_ptr=None):
+        """after a fused search: select_action + the env-step rows on the device; the visit block / mask are over the K sampled
+        actions, word 0 is the selected position, the extra block holds root_sampled_actions [K, D] (game_segment.py:254-255);
+        returns (header [B, 8 + 2 K + K D], root policy)"""
+        from .._tree_common import collect_rows_ex
+        return collect_rows_ex(self, self.K, temperature, deterministic, d_rows_ptr, row_words, frame_floats, timestep=timestep, seed=seed,
+                               policy_width=policy_width or self._pw, d_obs_ptr=d_obs_ptr)
+
     def get_values(self):
         out = np.zeros(self.root_num, np.float32)
         L.check(L.lib().lz_roots_get_values(self._h, out))

@@ -63,6 +63,9 @@ class EfficientZeroPolicy(object):
         # True: select_action (temperature sampling / arg-max + entropy) runs as one device kernel over all roots
         # (lz_roots_select_action) instead of the reference's per-env Python loop with np.random.choice
         self._device_select = bool(_g(cfg, "device_select_action", False))
+        # True: the Dirichlet exploration noise of a collect forward is drawn on the device (lz_roots_prepare_from_inference_dirichlet)
+        # instead of with np.random.dirichlet per env (efficientzero.py:599-602): same distribution, the engine's own random stream
+        self._device_noise = bool(_g(cfg, "device_root_noise", False))
 
     def forward(self, *args, **kwargs):
         return self._forward_collect(*args, **kwargs)
@@ -126,17 +129,22 @@ class EfficientZeroPolicy(object):
                                   'predicted_policy_logits': policy_logits[i]}
             return output
         alpha = self._mcfg["root_dirichlet_alpha"]
+        fused = getattr(self._collect_model, "_is_lz_engine_model", False) and hasattr(roots, "get_search_results")
         counts = [len(l) for l in legal_actions]
-        if len(set(counts)) == 1:  # one vectorised draw instead of one np.random.dirichlet call per env (efficientzero.py:599-602)
+        if fused and self._device_noise:
+            noises = None
+        elif len(set(counts)) == 1:  # one vectorised draw instead of one np.random.dirichlet call per env (efficientzero.py:599-602)
             noises = np.random.dirichlet([alpha] * counts[0], size=active_collect_env_num).astype(np.float32)
         else:
             noises = [np.random.dirichlet([alpha] * c).astype(np.float32) for c in counts]
-        fused = getattr(self._collect_model, "_is_lz_engine_model", False) and hasattr(roots, "get_search_results")
         if fused:
             # no read-back (and no synchronisation) before the search: predictions come back with the search results
             if early is None:
                 self._collect_model.initial_inference(data, roots, fetch=False)
-            roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
+            if noises is None:
+                roots.prepare_from_inference_dirichlet(self._mcfg["root_noise_weight"], alpha, to_play)
+            else:
+                roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
             self._search(self._mcts_collect, roots, self._collect_model, _HbmTokens(roots), to_play)
             eps_cfg0 = _g(self._cfg, "eps", {}) or {}
             if self._device_select:  # select_action on the device, inside the same read-back
@@ -208,14 +216,17 @@ class EfficientZeroPolicy(object):
             roots.reset_mask(mask, keep_inference=True)
         counts = (mask != 0).sum(1)
         alpha = self._mcfg["root_dirichlet_alpha"]
-        if (counts == counts[0]).all():
-            noises = np.random.dirichlet([alpha] * int(counts[0]), size=B).astype(np.float32)
-        else:  # ragged: one gamma draw for the whole batch, normalised per root (what np.random.dirichlet does per env)
-            g = np.random.gamma(alpha, size=int(counts.sum()))
-            seg = np.repeat(np.arange(B), counts)
-            noises = (g / np.bincount(seg, weights=g, minlength=B)[seg]).astype(np.float32)
         tp = list(to_play) if len(to_play) == B else [to_play[0]] * B
-        roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, tp)
+        if self._device_noise:
+            roots.prepare_from_inference_dirichlet(self._mcfg["root_noise_weight"], alpha, tp)
+        else:
+            if (counts == counts[0]).all():
+                noises = np.random.dirichlet([alpha] * int(counts[0]), size=B).astype(np.float32)
+            else:  # ragged: one gamma draw for the whole batch, normalised per root (what np.random.dirichlet does per env)
+                g = np.random.gamma(alpha, size=int(counts.sum()))
+                seg = np.repeat(np.arange(B), counts)
+                noises = (g / np.bincount(seg, weights=g, minlength=B)[seg]).astype(np.float32)
+            roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, tp)
         self._search(self._mcts_collect, roots, model, _HbmTokens(roots), tp)
         if frame_floats is None:
             frame_floats = rows_out.shape[1] - shard.HEADER - 2 * A

@@ -30,23 +30,32 @@ def shard_range(n_envs, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def row_width(action_space_size, frame_floats):
-    return HEADER + 2 * action_space_size + frame_floats
+def row_width(action_space_size, frame_floats, extra_words=0):
+    """``extra_words``: the block the sampled / Gumbel families add between the action mask and the frame (root_sampled_actions
+    [K * D] / improved_policy_probs [A], game_segment.py:254-258); ``action_space_size`` = K for Sampled-EfficientZero rows"""
+    return HEADER + 2 * action_space_size + extra_words + frame_floats
 
 
-def pack_rows(output, action_mask, to_play, action_space_size, frames=None, timestep=None):
-    """Host twin of lz_roots_collect_rows: policy output dict (env_id -> dict, efficientzero.py:636-643) + the collector's
+def pack_rows(output, action_mask, to_play, action_space_size, frames=None, timestep=None, extra_key=None):
+    """Host twin of lz_roots_collect_rows(_ex): policy output dict (env_id -> dict, efficientzero.py:636-643) + the collector's
     per-env action mask / to_play (/ timestep) + the newest observation frame of every env -> float32 [n_env, W] rows ordered by
-    env id.  ``frames``: [n_env, ...] or None."""
+    env id.  ``frames``: [n_env, ...] or None.  ``extra_key``: 'root_sampled_actions' (Sampled EfficientZero: the row's visit block
+    and mask are over the K sampled actions -- pass a [n, K] mask of ones --, word 0 is the selected POSITION) or
+    'improved_policy_probs' (Gumbel MuZero): that entry of the output dict fills the extra block (game_segment.py:254-258)."""
     ids = sorted(output)
     A = action_space_size
     F = 0 if frames is None else int(np.prod(np.asarray(frames).shape[1:]))
-    rows = np.zeros((len(ids), row_width(A, F)), np.float32)
+    E = 0 if extra_key is None else int(np.asarray(output[ids[0]][extra_key]).size)
+    rows = np.zeros((len(ids), row_width(A, F, E)), np.float32)
     for k, i in enumerate(ids):
         o = output[i]
         d = np.asarray(o["visit_count_distributions"], np.float32)
         s = np.float32(d.sum()) if d.sum() != 0 else np.float32(1e-6)  # game_segment.py:244-246
-        rows[k, F_ACTION] = o["action"]
+        if extra_key == "root_sampled_actions":   # the position of the chosen action among the root's sampled actions
+            acts = np.asarray(o[extra_key], np.float32).reshape(len(d), -1)
+            rows[k, F_ACTION] = int(np.nonzero((acts == np.asarray(o["action"], np.float32).reshape(1, -1)).all(1))[0][0])
+        else:
+            rows[k, F_ACTION] = o["action"]
         rows[k, F_ROOT_VALUE] = np.asarray(o["searched_value"]).reshape(-1)[0]
         rows[k, F_PRED_VALUE] = np.asarray(o["predicted_value"]).reshape(-1)[0]
         rows[k, F_TO_PLAY] = to_play[k] if np.ndim(to_play) else to_play
@@ -55,22 +64,26 @@ def pack_rows(output, action_mask, to_play, action_space_size, frames=None, time
         rows[k, F_N_LEGAL] = len(d)
         rows[k, HEADER:HEADER + len(d)] = d / s
         rows[k, HEADER + A:HEADER + 2 * A] = np.asarray(action_mask[k], np.float32)
+        if E:
+            rows[k, HEADER + 2 * A:HEADER + 2 * A + E] = np.asarray(o[extra_key], np.float32).reshape(-1)
         if F:
-            rows[k, HEADER + 2 * A:] = np.asarray(frames[k], np.float32).reshape(-1)
+            rows[k, HEADER + 2 * A + E:] = np.asarray(frames[k], np.float32).reshape(-1)
     return rows
 
 
-def unpack_rows(rows, action_space_size, frame_shape=None):
+def unpack_rows(rows, action_space_size, frame_shape=None, extra_words=0):
     """[n, W] rows (numpy) -> dict of column arrays; child visits stay in legal-list order, padded with zeros"""
     rows = np.asarray(rows)
-    A = action_space_size
+    A, E = action_space_size, int(extra_words)
     out = dict(action=rows[:, F_ACTION].astype(np.int64), reward=rows[:, F_REWARD].copy(), root_value=rows[:, F_ROOT_VALUE].copy(),
                predicted_value=rows[:, F_PRED_VALUE].copy(), to_play=rows[:, F_TO_PLAY].astype(np.int64),
                timestep=rows[:, F_TIMESTEP].astype(np.int64), entropy=rows[:, F_ENTROPY].copy(),
                n_legal=rows[:, F_N_LEGAL].astype(np.int64), child_visits=rows[:, HEADER:HEADER + A].copy(),
                action_mask=rows[:, HEADER + A:HEADER + 2 * A].copy())
-    if rows.shape[1] > HEADER + 2 * A:
-        fr = rows[:, HEADER + 2 * A:]
+    if E:
+        out["extra"] = rows[:, HEADER + 2 * A:HEADER + 2 * A + E].copy()
+    if rows.shape[1] > HEADER + 2 * A + E:
+        fr = rows[:, HEADER + 2 * A + E:]
         out["frame"] = fr.reshape((rows.shape[0],) + tuple(frame_shape)) if frame_shape is not None else fr.copy()
     return out
 

@@ -96,3 +96,84 @@ def test_forward_collect_rows_matches_dict_forward_and_feeds_the_segment_batch()
     assert np.array_equal(hdr[:, shard.HEADER + A:shard.HEADER + 2 * A], ragged)
     assert np.allclose(hdr[:, shard.HEADER:shard.HEADER + A].sum(1), 1.0, atol=1e-6)
     assert np.array_equal(hdr[:, shard.F_N_LEGAL], ragged.sum(1))
+
+
+def test_device_rows_of_the_sampled_and_gumbel_families_equal_host_packer():
+    """lz_roots_collect_rows_ex -- the extra block (root_sampled_actions / improved_policy_probs, game_segment.py:254-258)
+    written on the device == shard.pack_rows on the policy-style output dict (itself == the reference GameSegment,
+    tests/test_segment_rollover_cpu.py), and the rows feed GameSegmentBatch"""
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L, shard
+    from lightzero_amd.mcts.buffer.game_segment import GameSegmentBatch
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree, GumbelMuZeroMCTSCtree
+    from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
+    from lightzero_amd.model.muzero_model import MuZeroModel
+    from lightzero_amd.policy.utils import select_action
+    # ---- Sampled EfficientZero, continuous actions (BASELINE configs[4] shape)
+    B, D, K, S = 48, 2, 20, 24
+    ref = tm.synthetic_init(tm.SampledEfficientZeroModelMLP(observation_shape=5, action_space_size=D, continuous_action_space=True, num_of_sampled_actions=K), seed=3)
+    model = SampledEfficientZeroModelMLP(observation_shape=5, action_space_size=D, continuous_action_space=True, num_of_sampled_actions=K).load_state_dict(ref.state_dict())
+    cfg = dict(CFG, num_simulations=S, model=dict(action_space_size=D, num_of_sampled_actions=K, continuous_action_space=True))
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [[-1] * K] * B, D, K, True, max_simulations=S)
+    roots.set_tiebreak(0, seed=5)
+    obs = torch.randn(B, 5, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
+    out = model.initial_inference(obs, roots)
+    roots.prepare_from_inference(0.25, None, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    dist, val, acts = roots.get_distributions(), roots.get_values(), np.asarray(roots.get_sampled_actions(), np.float32)
+    F, E = 5, K * D
+    W = shard.row_width(K, F, E)
+    rows = torch.zeros(B, W, device="cuda")
+    hdr, pol = roots.collect_rows(1.0, True, rows.data_ptr(), W, F, timestep=list(range(B)), seed=9)
+    got = rows.cpu().numpy()
+    assert np.array_equal(got[:, :shard.HEADER + 2 * K + E], hdr) and np.array_equal(pol, out.policy_logits)
+    o = {}
+    for i in range(B):
+        idx, ent = select_action(dist[i], temperature=1.0, deterministic=True)
+        o[i] = dict(action=acts[i][idx], visit_count_distributions=dist[i], visit_count_distribution_entropy=ent, searched_value=val[i],
+                    predicted_value=out.value[i], root_sampled_actions=acts[i])
+    want = shard.pack_rows(o, np.ones((B, K), np.float32), [-1] * B, K, frames=obs.cpu().numpy(), timestep=list(range(B)), extra_key="root_sampled_actions")
+    # (duplicated sampled actions share a child: the arg-max position is the first of the class on both sides)
+    for col in (shard.F_ACTION, shard.F_ROOT_VALUE, shard.F_PRED_VALUE, shard.F_TO_PLAY, shard.F_TIMESTEP, shard.F_N_LEGAL):
+        assert np.array_equal(got[:, col], want[:, col]), col
+    assert np.array_equal(got[:, shard.HEADER:], want[:, shard.HEADER:])   # visits, mask, sampled actions, frame
+    assert np.allclose(got[:, shard.F_ENTROPY], want[:, shard.F_ENTROPY], rtol=1e-6, atol=1e-7)
+    cols = shard.unpack_rows(got, K, extra_words=E)
+    assert np.array_equal(cols["extra"].reshape(B, K, D), acts)
+    seg = GameSegmentBatch(B, K, 4, (5,), sampled_actions_shape=(K, D))
+    seg.reset(obs.cpu().numpy().reshape(B, 1, 5))
+    seg.store_search_stats_rows(hdr)
+    seg.append(obs.cpu().numpy(), np.zeros(B))
+    assert np.array_equal(seg.to_arrays(3)["root_sampled_actions"][0], acts[3])
+    # ---- Gumbel MuZero
+    B, A, S, m = 40, 6, 20, 4
+    refm = tm.synthetic_init(tm.MuZeroModel(action_space_size=A), seed=4)
+    gmodel = MuZeroModel(action_space_size=A).load_state_dict(refm.state_dict())
+    gcfg = dict(num_simulations=S, discount_factor=0.997, max_num_considered_actions=m, value_delta_max=0.01, root_noise_weight=0.25)
+    g = GumbelMuZeroMCTSCtree(gcfg)
+    rng = np.random.default_rng(6)
+    mask = (rng.random((B, A)) < 0.7).astype(np.float32); mask[:, 3] = 1
+    legal = [np.nonzero(x)[0].tolist() for x in mask]
+    groots = g.roots(B, legal, action_space_size=A, max_simulations=S)
+    gobs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(2)).cuda().contiguous()
+    gout = gmodel.initial_inference(gobs, groots)
+    groots.prepare_from_inference_no_noise([-1] * B)
+    g.search(groots, gmodel, gout.latent_state, [-1] * B)
+    gd, gv = groots.get_distributions(), groots.get_values()
+    improved = np.asarray(groots.get_policies(0.997, A), np.float32)
+    F = 96 * 96
+    W = shard.row_width(A, F, A)
+    grows = torch.zeros(B, W, device="cuda")
+    ghdr, _ = groots.collect_rows(1.0, True, grows.data_ptr(), W, F, discount=0.997)
+    ggot = grows.cpu().numpy()
+    o = {}
+    for i in range(B):
+        _, ent = select_action(gd[i], temperature=1.0, deterministic=True)
+        o[i] = dict(action=int(np.argmax(np.where(mask[i] == 1.0, improved[i], 0.0))), visit_count_distributions=gd[i],
+                    visit_count_distribution_entropy=ent, searched_value=gv[i], predicted_value=gout.value[i], improved_policy_probs=improved[i])
+    gwant = shard.pack_rows(o, mask, [-1] * B, A, frames=gobs[:, -1].reshape(B, -1).cpu().numpy(), extra_key="improved_policy_probs")
+    for col in (shard.F_ACTION, shard.F_ROOT_VALUE, shard.F_PRED_VALUE, shard.F_TO_PLAY, shard.F_TIMESTEP, shard.F_N_LEGAL):
+        assert np.array_equal(ggot[:, col], gwant[:, col]), col
+    assert np.array_equal(ggot[:, shard.HEADER:], gwant[:, shard.HEADER:])
+    assert np.array_equal(ggot[:, :shard.HEADER + 3 * A], ghdr)

@@ -4,7 +4,10 @@
                plus python bench.py > gpurun_out/<run>/bench_n1.json>'
     python tools/refresh_profiles.py gpurun_out/<run> r01
 
-writes profiles/<tag>_final_kernel_stats.csv, <tag>_bench_n1.json, <tag>_traffic.json, <tag>_pmc_summary.txt.
+writes profiles/<tag>_final_kernel_stats.csv, <tag>_bench_n1.json, <tag>_traffic.json, <tag>_pmc_summary.txt, <tag>_parity.json (the
+measured worst-case floating-point differences of the run's GPU tests, per kernel variant) and <tag>_manifest.json: the digest of the
+kernel sources everything above was measured on (lightzero_amd.build.csrc_digest, written ON THE GPU BOX by tools/profile_run.sh),
+the git commit this tool ran at, and the roofline kernel's rocprofv3 numbers -- what bench.py reads when the digest matches.
 """
 import collections
 import csv
@@ -43,7 +46,10 @@ def main():
         v = t.get(counter) if t else None
         return round(sum(v) / len(v), 2) if v else None
 
-    fused = "k_chain_w<6, 6, 8, false, 1"
+    # the roofline kernel: the k_chain_w instantiation with the largest total time (the fused tree-step + chain launch)
+    tot = {r["Name"]: float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats))}
+    fused = max((n for n in tot if "k_chain_w" in n), key=lambda n: tot[n])
+    fused = fused.split("(")[0]
     f, w = mean(fused, "FETCH_SIZE"), mean(fused, "WRITE_SIZE")
     out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and rocprofv3 --kernel-trace --pmc WRITE_SIZE (two separate passes) -- "
                    "python bench.py --steps 1 --warmup 1 --no-cpu-baseline, MI355X; per-dispatch means in KB as reported "
@@ -60,13 +66,21 @@ def main():
     json.dump(out, open(os.path.join(prof, "%s_traffic.json" % tag), "w"), indent=1)
     # the bench line of the same run read the PREVIOUS traffic file (bench.py takes roofline.traffic from profiles/): carry this run's
     # counters instead, so that the committed line and the committed counters belong together
-    bench["roofline"]["traffic"] = out["k_chain"]["hbm_bytes_per_launch"]
-    bench["roofline"]["traffic_unit"] = ("HBM bytes per launch (rocprofv3 PMC passes of the same profiling run, profiles/%s_traffic.json; "
-                                         "patched in by tools/refresh_profiles.py)" % tag)
+    d_chain = find(fused, dur)
+    rl = bench["roofline"]
+    rl["traffic"] = out["k_chain"]["hbm_bytes_per_launch"]
+    rl["traffic_unit"] = ("HBM bytes per launch (rocprofv3 PMC passes of the same profiling run, profiles/%s_traffic.json; "
+                          "patched in by tools/refresh_profiles.py)" % tag)
+    # the line was printed before this run's profile existed: it divided by its own HIP-event pairs.  Carry the profiler's average
+    # duration of the same run instead (what bench.py does by itself once the manifest below is committed)
+    rl["avg_launch_us"] = d_chain
+    rl["achieved"] = rl["algorithmic_flop_per_launch"] / (d_chain * 1e-6) / 1e12
+    rl["frac"] = rl["achieved"] / rl["peak"]
+    rl["clock"] = "rocprofv3 --kernel-trace average of the same profiling run (profiles/%s_final_kernel_stats.csv; patched in by tools/refresh_profiles.py)" % tag
     open(os.path.join(prof, "%s_bench_n1.json" % tag), "w").write(json.dumps(bench) + "\n")
     # MFMA utilisation of the roofline kernel: busy cycles per SIMD over the launch duration at the sustained clock
     busy = mean(fused, "SQ_VALU_MFMA_BUSY_CYCLES")
-    d_us = find(fused, dur)
+    d_us = d_chain
     hdr = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY",
            "#   + separate passes --pmc FETCH_SIZE / --pmc WRITE_SIZE   -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline   (MI355X)",
            "# per-dispatch means.  Counters are summed over the 8 XCDs / 1024 SIMDs; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY count quad-cycles;",
@@ -83,6 +97,42 @@ def main():
                           [os.path.join(run, d) for d in ("pmc_sq", "pmc_fetch", "pmc_write")],
                           stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
     open(os.path.join(prof, "%s_pmc_summary.txt" % tag), "w").write("\n".join(hdr) + "\n" + body)
+    # ---- measured parity of the run's GPU tests, all kernel variants in one file
+    par = {}
+    for f in sorted(glob.glob(os.path.join(run, "parity", "*.json"))):
+        d = json.load(open(f))
+        par[d["variant"]] = d["tests"]
+        bounds, unit = d["bounds"], d["unit"]
+    if par:
+        worst = {}
+        for v, tests in par.items():
+            for t, classes in tests.items():
+                for k, x in classes.items():
+                    if k in bounds and isinstance(x, float):
+                        worst[k] = max(worst.get(k, 0.0), x)
+        json.dump({"_how": "worst |device - reference| / (1 + |reference|) per tensor class, recorded by the GPU tests of the profiling run "
+                           "(tests/parity_record.py) for the default kernels and for every alternative path behind an LZ_* switch; "
+                           "bounds = what the tests assert (north_star's 1e-5 before the inverse scalar transform; 3e-4 after it, DESIGN.md section 6)",
+                   "unit": unit, "bounds": bounds, "worst_over_everything": worst, "variants": par},
+                  open(os.path.join(prof, "%s_parity.json" % tag), "w"), indent=1, sort_keys=True)
+    # ---- manifest
+    man = json.load(open(os.path.join(run, "manifest.json")))
+    try:
+        man["git_head_at_refresh"] = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, universal_newlines=True).stdout.strip()
+        man["csrc_dirty_at_refresh"] = bool(subprocess.run(["git", "status", "--porcelain", "lightzero_amd/csrc", "include"], cwd=ROOT, stdout=subprocess.PIPE,
+                                                             universal_newlines=True).stdout.strip())
+    except Exception:
+        pass
+    sys.path.insert(0, ROOT)
+    from lightzero_amd.build import csrc_digest
+    man["csrc_sha256_here"] = csrc_digest()
+    man["k_chain"] = {"kernel": fused, "rocprof_avg_us": d_chain, "hbm_bytes_per_launch": out["k_chain"]["hbm_bytes_per_launch"],
+                      "mfma_busy_cycles_per_simd": (busy / 1024.0) if busy else None}
+    man["kernel_avg_us"] = {k.split("(")[0]: round(v, 2) for k, v in dur.items() if v > 3.0}
+    man["files"] = sorted(f for f in os.listdir(prof) if f.startswith(tag + "_"))
+    json.dump(man, open(os.path.join(prof, "%s_manifest.json" % tag), "w"), indent=1, sort_keys=True)
+    if man["csrc_sha256"] != man["csrc_sha256_here"]:
+        print("WARNING: the kernel sources here differ from the ones profiled on the GPU box")
     r = bench["roofline"]
     print("value %.0f env-steps/s, %.3f ms/step; roofline %.1f TFLOP/s frac %.3f (%.1f us/launch); cpu_baseline %.1f; chain %.2f us, traffic %d B"
           % (bench["value"], bench["ms_per_step"], r["achieved"], r["frac"], r["avg_launch_us"], bench["cpu_baseline"]["value"], d_us or 0,
