@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/lz_mi355.h"
+#include "lz_nn_kernels.h"
 
 void lz_set_error(const char *fmt, ...);
 
@@ -151,6 +152,7 @@ struct lz_roots {
     float *d_obs = nullptr;         // staging for lz_initial_inference_host
     const float *last_obs = nullptr; // the observation batch of the latest lz_initial_inference (caller's or d_obs): the newest
                                     // frame of every env-step row comes from here (lz_roots_collect_rows)
+    float *sh_part = nullptr;       // split heads: [B][3 heads][H/16 unit tiles][32] first-layer partial sums of the head MLPs (LSTM launch)
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
     std::vector<int32_t> h_n_legal;  // host copy of n_legal (noise offsets without a device round trip)
     std::vector<int32_t> h_to_play;  // to_play of the last HOST-side prepare (lz_roots_prepare & co.): lz_roots_adopt_inference
@@ -190,6 +192,8 @@ struct lz_tree_step {
     float delta;
     const int32_t *vtp;
     unsigned long long *ts;    // timing experiments (debug build, LZ_DEBUG_TREE_TS): s_memtime stamps of root 0's step; null in production
+    lz_split_heads sh;         // sh.on: the leaf's network outputs are not in vps / values / logits yet -- the other waves of the chain
+                               // launch compute them from the LSTM launch's partials and hand them over in LDS (k_chain_w)
 };
 // select_action for every root (lz_capi.hip): d_pos [B] int32, d_ent [B] float64
 void lz_launch_select_action(const lz_tree_dev &t, double inv_temperature, int deterministic, uint64_t seed, int32_t *d_pos,

@@ -24,6 +24,8 @@ struct ConvW {
     int cin = 0, cout = 0;
 };
 struct MlpW {
+    std::vector<float> h_w1;   // host copy of w1 as uploaded ([32][K1], conv heads in (pixel, channel) order): lz_model_finalize builds the
+                               // split-head fragments from it
     float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* [32 / 4][NOUT][4], hidden width padded to the compiled 32 */, *b2 = nullptr;
     int K1 = 0, NOUT = 0;
 };
@@ -56,6 +58,11 @@ struct lz_model {
     // prediction
     C1W val_c, pol_c;
     MlpW fc_value, fc_policy;
+    // split heads (EfficientZero, 6x6 latent; lz_search.hip): the first layers of the three head MLPs as MFMA B fragments for the
+    // LSTM launch, sliced by LSTM unit tile u -- sh_w1c [H/16][9][4][64]: rows 36 u .. 36 u + 35 of the combined [value | policy]
+    // head input (the 1x1-conv outputs t_pv, 1152 floats per root) x 64 hidden units (value 0..31 | policy 32..63, zero where the
+    // input channel belongs to the other head); sh_w1r [H/16][4][2][64]: LSTM units 16 u .. 16 u + 15 x the value-prefix head's 32
+    float *sh_w1c = nullptr, *sh_w1r = nullptr;
     // workspaces for initial inference
     int ws_B = 0;
     float *ws[3] = {nullptr, nullptr, nullptr};
@@ -240,6 +247,7 @@ struct Builder {
                     for (int c = 0; c < HC; ++c) w1p[(size_t)u * K1 + p * HC + c] = w1->data[(size_t)u * K1 + c * HW + p];
         }
         o.w1 = upload(w1p);
+        o.h_w1 = w1p;
         o.b1 = upload(b1p);
         o.s1 = upload(scp);
         o.t1 = upload(shp);

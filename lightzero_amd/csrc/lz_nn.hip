@@ -932,7 +932,139 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? (GW * GH > 36 ? 8 : 16) : 32)>
+// ---- split heads: the head MLPs of the PREVIOUS simulation's leaf, finished by waves 1..7 of the root's workgroup while wave 0 stages
+// the root's tree (lz_split_heads).  hw = wave - 1: 0..2 value head, 3..5 value-prefix head (601 outputs over 3 waves x 64 lanes x <= 4),
+// 6 policy head.  Every wave first sums the first-layer partial blocks of the LSTM launch for its head (32 unit tiles, fixed order: two
+// halves of 16 sequentially, then half 0 + half 1), applies bias / BatchNorm / ReLU -> hidden unit j in lanes j and j + 32 -- and
+// has requested its second-layer weights right behind them.  The three waves of a categorical head meet ONCE in LDS (each sums
+// exp(logit - its own maximum); the first of them waits on a counter for the other two and rescales to the common maximum; wave 0 of
+// the workgroup is not part of this); the scalars go to the pool slot and to s_leaf, then s_ctr[2] counts the finished heads (3 = the
+// leaf is ready).  s_ctr[0..3] must be zero when this starts.  Measured (tools/tree_timing.py, root 0, simulation 49): the 155 KB of
+// second-layer weights of a root pass the CU's vector-memory path (64 B/clk) in ~4.4 k cycles, the scalars are out at ~8-10 k -- the
+// tree wave has staged its tree by ~7 k, so ~2-3 k cycles of this remain exposed in the launch.
+__device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int b, int A, int hw, int lane, float *s_leaf, int32_t *s_ctr,
+                                                  float *s_red, unsigned long long *ts = nullptr)
+{
+    const bool stamp = ts && b == 0 && hw == 0 && lane == 0;   // timing experiments (debug build): stamps of head wave 1 of root 0
+#define LZ_HPS(i) do { if (stamp) ts[8 + i] = __builtin_readcyclecounter(); } while (0)
+    LZ_HPS(0);
+    const int head = hw < 3 ? 0 : (hw < 6 ? 2 : 1);   // 0 value, 1 policy, 2 value prefix (the order of lz_split_heads' arrays)
+    const int gw = hw < 6 ? hw % 3 : 0, grp = hw < 3 ? 0 : 1;
+    const int NOUT = head == 1 ? A : sh.nout;
+    // ---- requests in the order of use (a wave's loads return in order): the first-layer partials of this root and head -- [32 unit
+    // tiles][32 hidden] contiguous; lane (ug = lane >> 3, jq = lane & 7) takes the hidden quad 4 jq .. + 3 of unit tiles ug, ug + 8,
+    // ug + 16, ug + 24 --, the first layer's bias / BatchNorm, then the second-layer weights of this lane's outputs
+    const int NU = sh.n_unit_tiles, ug = lane >> 3, jq = lane & 7;
+    const float *pp = sh.part + ((size_t)b * 3 + head) * (NU * 32) + ug * 32 + jq * 4;
+    f32x4 pv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pv[q] = *reinterpret_cast<const f32x4 *>(pp + (size_t)q * 8 * 32);
+    const f32x4 b1v = *reinterpret_cast<const f32x4 *>(sh.b1[head] + jq * 4), s1v = *reinterpret_cast<const f32x4 *>(sh.s1[head] + jq * 4),
+                t1v = *reinterpret_cast<const f32x4 *>(sh.t1[head] + jq * 4);
+    constexpr int NT = 4;
+    f32x4 w2[NT][8];
+    float lg[NT];
+    const int nstep = head == 1 ? 64 : 192, n0 = gw * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = min(n0 + nstep * t, NOUT - 1);
+        lg[t] = sh.b2[head][n];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) w2[t][k4] = *reinterpret_cast<const f32x4 *>(sh.w2t[head] + ((size_t)k4 * NOUT + n) * 4);
+    }
+    LZ_HPS(1);
+    // ---- hidden units: the four partials of a lane in order, then the eight ug groups over lanes ^ 8, ^ 16, ^ 32 (a fixed order,
+    // the same in every lane of a column); bias, BatchNorm, ReLU; one copy per wave in LDS for the broadcast reads below
+    f32x4 hid4;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        float v = ((pv[0][c4] + pv[1][c4]) + pv[2][c4]) + pv[3][c4];
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8 = lane ^ 8
+        v = xor32_sum(xor16_sum(v));
+        hid4[c4] = fmaxf((v + b1v[c4]) * s1v[c4] + t1v[c4], 0.0f);
+    }
+    float *s_hid = s_red + 64 + hw * 32;
+    if (lane < 8) *reinterpret_cast<f32x4 *>(s_hid + lane * 4) = hid4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_HPS(2);
+    // ---- second layer: the hidden units come back as broadcast reads (same address in every lane)
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        const f32x4 h4 = *reinterpret_cast<const f32x4 *>(s_hid + k4 * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            lg[t] += (w2[t][k4][0] * h4[0] + w2[t][k4][1] * h4[1]) + (w2[t][k4][2] * h4[2] + w2[t][k4][3] * h4[3]);
+    }
+    LZ_HPS(3);
+    if (head == 1) {   // policy logits
+        if (lane < A) {
+            sh.out_logits[(size_t)b * A + lane] = lg[0];
+            s_leaf[2 + lane] = lg[0];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(s_ctr + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    // ---- softmax . support -> inverse scalar transform.  Each of the head's three waves sums exp(logit - ITS OWN maximum); the three
+    // (maximum, sum, weighted sum) triples meet once in LDS and are rescaled to the common maximum: one rendezvous instead of two
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) m = (n0 + nstep * t < NOUT) ? fmaxf(m, lg[t]) : m;
+    m = wave_max(m);
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + nstep * t;
+        if (n < NOUT) {
+            const float ex = expf(lg[t] - m);
+            s0 += ex;
+            s1 += ex * (sh.support_min + (float)n);
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    float *red = s_red + grp * 16;
+    if (lane == 0) { red[4 * gw] = m; red[4 * gw + 1] = s0; red[4 * gw + 2] = s1; }
+    LZ_HPS(4);
+    if (gw != 0) {   // waves 1 and 2 of the head only contribute
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(s_ctr + grp, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    while (__hip_atomic_load(s_ctr + grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_HPS(5);
+    {
+        const float m1 = red[4], m2 = red[8];
+        const float M = fmaxf(fmaxf(m, m1), m2);
+        const float e0 = expf(m - M), e1 = expf(m1 - M), e2 = expf(m2 - M);
+        const float t0 = (s0 * e0 + red[5] * e1) + red[9] * e2, t1 = (s1 * e0 + red[6] * e1) + red[10] * e2;
+        // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
+        const float value = t1 / t0;
+        const float eps = 0.001f;
+        float t = fabsf(value) + 1.0f;
+        t = t + eps;
+        t = 0.004f * t;
+        t = 1.0f + t;
+        t = sqrtf(t);
+        t = t - 1.0f;
+        t = t / 0.002f;
+        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
+        const float out = sgn * (t * t - 1.0f);
+        if (lane == 0) {
+            (head == 0 ? sh.out_value : sh.out_vp)[b] = out;
+            s_leaf[head == 0 ? 1 : 0] = out;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(s_ctr + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    LZ_HPS(6);
+#undef LZ_HPS
+}
+
+template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? (GW * GH > 36 ? 8 : 16) : 32), bool HEADS = false>
 __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename step_arg<TREE>::type step)
 {
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
@@ -985,9 +1117,27 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     int g_slot = 0, g_action = 0;
     if constexpr (TREE != 0) {
         int32_t *s_sel = reinterpret_cast<int32_t *>(sMisc + 120);
+        // split heads: V is free until the first layer's input transform -- the leaf hand-over, the counters and the reduction
+        // scratch of the head waves live there
+        float *s_leaf = sV;
+        int32_t *s_ctr = reinterpret_cast<int32_t *>(sV + 80);
+        float *s_red = sV + 96;
+        bool heads_on = false;
+        if constexpr (HEADS) {
+            static_assert(NW == 8, "seven head waves");
+            heads_on = step.sh.on != 0;
+            if (heads_on) {
+                if (tid < 8) s_ctr[tid] = 0;
+                __syncthreads();
+            }
+        }
         if (wv == 0)
             dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
-                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts);
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
+                                      heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
+        else if constexpr (HEADS) {
+            if (heads_on) heads_in_prologue(step.sh, b, step.t.A, wv - 1, lane, s_leaf, s_ctr, s_red, step.ts);
+        }
         __syncthreads();
         if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
         g_slot = s_sel[0];
@@ -1589,9 +1739,10 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // (Measured and dropped: one 8-wave 32-row workgroup per CU -- (gate, row tile) waves sharing every weight fragment through L1,
 // 411 KB instead of 684 KB through the CU -- 13.9 us against 13.6 us for two 4-wave 16-row workgroups: the kernel is bound by
 // the matrix pipe (17.4 k MFMA cycles per SIMD) plus its serial staging / epilogue, not by the L1 fill rate.)
-template <int NKB, int XV = 0, int MR = 32, int KXB = 0>
+template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
+    static_assert(!SH || MR == 16, "the split-head partials are written for 16-row workgroups");
     constexpr int K = NKB * 16, PS = K + 4, R = 12;
     constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
     constexpr bool TWO = MR == 32;                         // a wave computes both 16-row tiles of a 32-row workgroup
@@ -1606,7 +1757,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #ifdef LZ_DEBUG_KNOBS
     // timing experiment (debug build, LZ_DEBUG_LSTM_HOTW=1; results are then wrong): every step re-reads the first 12 fragments, i.e.
     // the weight stream comes from L1 instead of L2 -- how much of the launch is the L2 stream?
-    const int wmul = a.debug_hot_weights ? 0 : 1;
+    const int wmul = (a.debug_hot_weights & 1) ? 0 : 1;
 #else
     constexpr int wmul = 1;
 #endif
@@ -1614,6 +1765,24 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     float4 wq[R];
 #pragma unroll
     for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)min(s, NKB - 1) * 64];
+    // split heads: operands of the first-layer partial products (consumed after the K loop).  value | policy heads: A = rows r0 .. r0 + 15
+    // of the combined 1x1-conv outputs, columns 36 tile .. + 35 (9 k-steps of 4), B = this wave's 16 of the 64 hidden columns;
+    // value-prefix head (waves 0, 1): B = units 16 tile .. + 15 x 16 hidden columns.  Requested AFTER the row staging loads below
+    // (a wave's loads return in order: in front of them they would delay the first MFMA by their own -- scattered -- round trip).
+    f32x4 sh_av = {0.f, 0.f, 0.f, 0.f}, sh_bv[3], sh_brv;
+    auto sh_request = [&]() {
+        // A: 16 rows x 36 floats (144 B per row, contiguous) = 144 float4, one per thread 0..143; B: this lane's 9 (+ 3 pad) | 4 weights
+        const int row = min(tid / 9, 15), c4 = tid % 9;
+        const int bb = min(r0 + row, a.B - 1);
+#ifdef LZ_DEBUG_KNOBS
+        if (a.debug_hot_weights & 2) { sh_bv[0] = sh_bv[1] = sh_bv[2] = sh_brv = sh_av; return; }
+#endif
+        sh_av = *reinterpret_cast<const f32x4 *>(a.sh_pv + (size_t)bb * a.sh_kc + 36 * tile + 4 * c4);
+        const float *bp = a.sh_w1c + (((size_t)tile * 4 + wv) * 64 + lane) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sh_bv[i] = *reinterpret_cast<const f32x4 *>(bp + 4 * i);
+        sh_brv = *reinterpret_cast<const f32x4 *>(a.sh_w1r + (((size_t)tile * 2 + (wv & 1)) * 64 + lane) * 4);
+    };
     // everything the cell epilogue needs for this thread's two (row, unit) pairs is requested now: previous cell state, gate
     // biases, BatchNorm scale / shift, reset flag (unconditional loads; dummies where a pointer is null)
     float c_prev[NQ], gb[NQ][4], bns[NQ], bnt[NQ];
@@ -1646,6 +1815,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         for (int i = 0; i < NXS; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(xrow + (part + TPR * i) * 4);
 #pragma unroll
         for (int i = 0; i < NHS; ++i) hv[i] = *reinterpret_cast<const f32x4 *>(hrow + (part + TPR * i) * 4);
+        if constexpr (SH) sh_request();
 #pragma unroll
         for (int i = 0; i < NXS; ++i) *reinterpret_cast<f32x4 *>(dst + (part + TPR * i) * 4) = xv[i];
     } else {
@@ -1746,6 +1916,12 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     }
     __syncthreads();  // every wave is done reading the staged rows: the buffer becomes the gate exchange [4][32][17]
     float *sG = smem;
+    float *sHb = smem + 4 * MR * 17;   // split heads: relu(bn(h')) of this workgroup's 16 rows x 16 units [16][17]
+    float *sA2 = sHb + 16 * 17;        //              the value | policy heads' input slice [16 rows][40] (36 used)
+    float *sP = sA2 + 16 * 40;         //              the partial block of this workgroup [16 rows][3 heads][32 hidden]
+    if constexpr (SH) {
+        if (tid < 144) *reinterpret_cast<f32x4 *>(sA2 + (tid / 9) * 40 + (tid % 9) * 4) = sh_av;
+    }
     {
         const int col = lane & 15, rq = 4 * (lane >> 4);
 #pragma unroll
@@ -1759,7 +1935,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     for (int q = 0; q < NQ; ++q) {
         const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
         const int b = r0 + row;
-        if (b >= a.B) continue;
+        if (b >= a.B) { if constexpr (SH) sHb[row * 17 + u] = 0.0f; continue; }
         const int unit = tile * 16 + u;
         const float gi = sG[(0 * MR + row) * 17 + u] + gb[q][0];
         const float gf = sG[(1 * MR + row) * 17 + u] + gb[q][1];
@@ -1770,7 +1946,45 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         const bool reset = a.search_len && a.horizon > 0 && (slen[q] % a.horizon) == 0;  // mcts_ctree.py:859-863
         a.h_out[(size_t)b * H + unit] = reset ? 0.0f : hn;
         a.c_out[(size_t)b * H + unit] = reset ? 0.0f : cn;
-        a.hbn_out[(size_t)b * H + unit] = a.bn_scale ? fmaxf(hn * bns[q] + bnt[q], 0.0f) : hn;
+        const float hb = a.bn_scale ? fmaxf(hn * bns[q] + bnt[q], 0.0f) : hn;
+        a.hbn_out[(size_t)b * H + unit] = hb;
+        if constexpr (SH) sHb[row * 17 + u] = hb;
+    }
+    if constexpr (SH) {
+        // value | policy heads, first layer: [16 rows x 36] x [36 x this wave's 16 of the 64 hidden columns] (sA2 was written before the
+        // gate barrier); D[row = 4 (lane >> 4) + q][col = lane & 15] -> sP[row][head = wave / 2][16 (wave & 1) + col]
+        {
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks)
+                pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sA2[(lane & 15) * 40 + 4 * ks + (lane >> 4)], sh_bv[ks >> 2][ks & 3], pacc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sP[(4 * (lane >> 4) + q) * 96 + (wv >> 1) * 32 + 16 * (wv & 1) + (lane & 15)] = pacc[q];
+        }
+        __syncthreads();   // relu(bn(h')) of all 16 x 16 (row, unit) pairs is in sHb
+        if (wv < 2) {      // value-prefix head, first layer: [16 rows x 16 units of this tile] x [16 x 16 hidden columns of wave 0 | 1]
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sHb[(lane & 15) * 17 + 4 * ks + (lane >> 4)], sh_brv[ks], pacc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sP[(4 * (lane >> 4) + q) * 96 + 64 + 16 * wv + (lane & 15)] = pacc[q];
+        }
+        __syncthreads();
+        // the block goes out as whole 128-byte lines: (row, head) = 32 floats at [root][head][unit tile][32]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHR * i;
+            if (idx < 16 * 24) {
+                const int row = idx / 24, c4 = idx % 24;
+#ifdef LZ_DEBUG_KNOBS
+                if (a.debug_hot_weights & 4) continue;
+#endif
+                if (r0 + row < a.B)
+                    *reinterpret_cast<f32x4 *>(a.sh_part + ((size_t)(r0 + row) * 3 + (c4 >> 3)) * (gridDim.x * 32) + (size_t)tile * 32 + (c4 & 7) * 4) =
+                        *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4);
+            }
+        }
     }
 }
 
@@ -2283,7 +2497,8 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         const dim3 g(a.B), blk(nw * 64);
 #define LZ_W(GWv, NWv) \
         if (step) { \
-            if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, false, 1>), g, blk, lds, s, a, *step); \
+            if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on && GWv == 6 && NWv == 8) hipLaunchKernelGGL((k_chain_w<6, 6, 8, false, 1, 16, true>), g, blk, lds, s, a, *step); \
+            else if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, false, 1>), g, blk, lds, s, a, *step); \
             else hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, false, 2>), g, blk, lds, s, a, *step); \
         } else if (a.tstamp) { \
             hipLaunchKernelGGL((k_chain_w<GWv, GWv, NWv, true>), g, blk, lds, s, a, no_step{}); \
@@ -2362,7 +2577,9 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     static const char *big_rows = getenv("LZ_LSTM_ROWS32");
     if (nkb == 68 && !xf && !big_rows) {
         static const char *nosplit = getenv("LZ_LSTM_NOSPLIT");  // the one-burst staging (A/B timing, parity: both forms are bit-identical)
-        if (a.KX == 576 && !nosplit) hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        if (a.KX == 576 && !nosplit && a.sh_part && a.H == 512 && a.sh_kc == 1152)
+            hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        else if (a.KX == 576 && !nosplit) hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
         else hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
         return true;
     }

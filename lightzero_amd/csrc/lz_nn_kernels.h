@@ -87,6 +87,20 @@ struct lz_chain_args {
 // prologue of the root's workgroup, and the chain reads the selected (slot, action) from LDS instead of gather_ix / action
 // (which the step still writes for the kernels that follow).  Requires lz_chain_fusable(step).
 struct lz_tree_step;
+// The heads of the PREVIOUS simulation, finished inside the chain launch whose prologue runs that simulation's tree step: waves 1..7
+// of a root's workgroup sum the first-layer partials the LSTM launch left (fixed order), apply bias / BatchNorm / ReLU, run the second
+// layers (value and value prefix: softmax . support -> inverse scalar transform; policy: logits), write the leaf's network outputs
+// to the pool slot AND hand them to wave 0 through LDS, which has been staging the root's tree meanwhile.
+struct lz_split_heads {
+    int on;
+    const float *part;                    // [B][3 heads][H / 16 unit tiles][32 hidden]: first-layer partial sums left by the LSTM launch
+    const float *b1[3], *s1[3], *t1[3];   // 0 value, 1 policy, 2 value prefix
+    const float *w2t[3], *b2[3];          // [32 / 4][NOUT][4], [NOUT]
+    int nout;                             // support size of the value / value-prefix heads (<= 768)
+    int n_unit_tiles;                     // H / 16
+    float support_min;
+    float *out_value, *out_vp, *out_logits;   // pool slot of the leaf: [B], [B], [B][A]
+};
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step);
 bool lz_chain_small_supported(int gw, int gh, int C);
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step = nullptr);
@@ -111,6 +125,14 @@ struct lz_lstm_args {
     float *hbn_out;          // [B][H] relu(bn(h'))
     int B, KX, H;
     int debug_hot_weights;   // timing experiment of the debug build only (see k_lstm2); 0 in production
+    // split heads (optional, sh_part != null; EfficientZero 6x6 instance only): the FIRST layers of the three head MLPs are
+    // computed here as partial sums, one block per (16-row tile, unit tile u) -- the value-prefix head's over this workgroup's own 16
+    // hidden units, the value / policy heads' over columns 36 u .. 36 u + 35 of the combined 1x1-conv output rows (sh_pv) -- and the
+    // next chain launch finishes the heads for its root while its tree step stages (lz_split_heads)
+    const float *sh_pv;              // [B][sh_kc] (t_pv)
+    int sh_kc;
+    const float *sh_w1c, *sh_w1r;    // lz_model::sh_w1c / sh_w1r
+    float *sh_part;                  // [B][3 heads: value, policy, value prefix][H/16 unit tiles][32 hidden]
 };
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s);
 // host: wcat [4H][K] (row 4*unit + gate) -> fragment order for lz_lstm_args::wf (4*H*K floats)

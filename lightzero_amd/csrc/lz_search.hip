@@ -273,6 +273,34 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->fc_value = b.mlp(d + "fc_value", HC * HW, HID, SUP, true, HC, HW);
         m->fc_policy = b.mlp(d + "fc_policy", HC * HW, HID, A, true, HC, HW);
     }
+    // ---- split heads (see enqueue_search): first layers of the three head MLPs as per-unit-tile MFMA fragments for the LSTM launch
+    m->sh_w1c = m->sh_w1r = nullptr;
+    if (c.model_type == 0 && wchain && m->GW == 6 && HC == 16 && H == 512 && m->fc_value.h_w1.size() == (size_t)32 * HC * HW &&
+        m->fc_policy.h_w1.size() == (size_t)32 * HC * HW && m->fc_reward.h_w1.size() == (size_t)32 * H) {
+        const int NU = H / 16, K1 = HC * HW, KS = 2 * K1 / NU;   // 32 unit tiles; 576; 36 combined input columns per tile
+        if (KS == 36) {
+            // per unit tile u and wave (= 16-column tile nt of the 64 | 32 hidden columns): lane (n = lane & 15, kq = lane >> 4) holds the
+            // B operands of its 9 | 4 k-steps contiguously (12 | 4 floats: three | one float4 load)
+            std::vector<float> wc((size_t)NU * 4 * 64 * 12, 0.0f), wr((size_t)NU * 2 * 64 * 4);
+            for (int u = 0; u < NU; ++u) {
+                for (int nt = 0; nt < 4; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int ks = 0; ks < KS / 4; ++ks) {
+                            const int kk = KS * u + 4 * ks + (lane >> 4), pix = kk / (2 * HC), c32 = kk % (2 * HC), col = 16 * nt + (lane & 15);
+                            float w = 0.0f;
+                            if (col < 32 && c32 < HC) w = m->fc_value.h_w1[(size_t)col * K1 + pix * HC + c32];
+                            if (col >= 32 && c32 >= HC) w = m->fc_policy.h_w1[(size_t)(col - 32) * K1 + pix * HC + (c32 - HC)];
+                            wc[(((size_t)u * 4 + nt) * 64 + lane) * 12 + ks] = w;
+                        }
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int ks = 0; ks < 4; ++ks)
+                            wr[(((size_t)u * 2 + nt) * 64 + lane) * 4 + ks] = m->fc_reward.h_w1[(size_t)(16 * nt + (lane & 15)) * H + 16 * u + 4 * ks + (lane >> 4)];
+            }
+            m->sh_w1c = b.upload(wc);
+            m->sh_w1r = b.upload(wr);
+        }
+    }
     if (!b.err.empty()) {
         lz_set_error("lz_model_finalize: %s", b.err.c_str());
         return LZ_ERR_STATE;
@@ -321,6 +349,9 @@ static int ensure_pools(lz_roots *r)
                  o_rx = take(B * HW * HC * 4), o_pv = take(B * HW * 2 * HC * 4), o_hbn = take(B * H * 4), o_d0 = take(B * SUP * 4), o_d1 = take(B * SUP * 4),
                  o_tr = take(NN * 5 * B * 4), o_z = take(B * 4),
                  o_tp = take((2 * B + B * A) * 4);   // [to_play B | noise offsets B | noise <= B A]: one upload per prepare
+    // split heads: first-layer partial sums of the three head MLPs, one block per (16-row tile, LSTM unit tile)
+    const size_t NU = H / 16;
+    const size_t o_pc = take(m->sh_w1c ? B * 3 * NU * 32 * 4 : 0);
     hipError_t err = lz_dev_malloc((void **)&r->pool_slab, off);
     if (err != hipSuccess) {
         lz_set_error("hipMalloc(%zu bytes) for the latent/LSTM pools failed: %s", off, hipGetErrorString(err));
@@ -334,6 +365,7 @@ static int ensure_pools(lz_roots *r)
     r->dbg_logits[0] = (float *)(base + o_d0); r->dbg_logits[1] = (float *)(base + o_d1);
     r->trace = (int32_t *)(base + o_tr); r->d_to_play = (int32_t *)(base + o_tp); r->d_zero_vp = (float *)(base + o_z);
     r->d_noise_off = r->d_to_play + B; r->d_noise = (float *)(r->d_noise_off + B);
+    r->sh_part = m->sh_w1c ? (float *)(base + o_pc) : nullptr;
     LZ_HIP_CHECK(hipMemsetAsync(r->d_zero_vp, 0, B * 4, r->eng->stream));
     return LZ_OK;
 }
@@ -1232,7 +1264,7 @@ extern "C" int lz_debug_read_tree_ts(unsigned long long *h_out)   // LZ_DEBUG_TR
 {
     LZ_REQUIRE(g_tree_ts != nullptr && h_out != nullptr, "LZ_DEBUG_TREE_TS was not set");
     LZ_HIP_CHECK(hipDeviceSynchronize());
-    LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_ts, 8 * 8, hipMemcpyDeviceToHost));
+    LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_ts, 16 * 8, hipMemcpyDeviceToHost));   // [0..6] the tree wave, [8..14] head wave 1 (split heads)
     return LZ_OK;
 }
 static bool dbg_skip(char k)
@@ -1247,30 +1279,56 @@ static constexpr bool dbg_skip(char) { return false; }
 // the network part of one simulation (mcts_ctree.py:834-847): recurrent_inference for the leaves selected by the
 // last traverse, outputs into slot sim + 1 of the pools
 // `step` (conv models only): the tree step that selects this simulation's leaves, run inside the chain launch
-static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz_tree_step *step = nullptr)
+// the arguments of the chain launch of simulation `sim` (outputs into pool slot sim + 1)
+static void chain_args_for(lz_roots *r, int sim, lz_chain_args &ca)
+{
+    lz_model *m = r->eng->model;
+    const lz_model_cfg &c = m->cfg;
+    const lz_tree_dev &t = r->t;
+    const size_t B = t.B, C = c.num_channels, HW = m->HWl;
+    const size_t lat_slot = B * HW * C;
+    float *next_latent = r->latent_pool + (size_t)(sim + 1) * lat_slot;
+    ca = lz_chain_args{};
+    ca.in = r->latent_pool; ca.gather_ix = t.res_ix; ca.slot_stride = (int64_t)lat_slot;
+    ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B; ca.gw = m->GW; ca.gh = m->GH; ca.C = (int)C;
+    ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, 1, 1, nullptr);
+    const int x_lat = chain_blocks(ca, m->dyn_res, 1, -1, next_latent);   // the next latent state: kept for the reward 1x1 conv
+    const int x_p = chain_blocks(ca, m->pred_res, x_lat, x_lat, nullptr);
+    ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = x_p;
+    ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = x_p;
+    ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = x_lat;
+    ca.nc1 = 3;
+}
+
+// split heads: what the chain launch that follows simulation `leaf_slot - 1` needs to finish that simulation's heads (lz_split_heads)
+static void split_heads_for(lz_roots *r, int leaf_slot, lz_split_heads &sh)
+{
+    lz_model *m = r->eng->model;
+    const size_t B = r->t.B, A = r->t.A;
+    sh = lz_split_heads{};
+    sh.on = 1;
+    sh.part = r->sh_part;
+    const MlpW *w[3] = {&m->fc_value, &m->fc_policy, &m->fc_reward};
+    for (int i = 0; i < 3; ++i) { sh.b1[i] = w[i]->b1; sh.s1[i] = w[i]->s1; sh.t1[i] = w[i]->t1; sh.w2t[i] = w[i]->w2; sh.b2[i] = w[i]->b2; }
+    sh.nout = m->cfg.support_size; sh.n_unit_tiles = m->cfg.lstm_hidden_size / 16; sh.support_min = m->cfg.support_min;
+    sh.out_value = r->sim_value + (size_t)leaf_slot * B; sh.out_vp = r->sim_vp + (size_t)leaf_slot * B;
+    sh.out_logits = r->sim_logits + (size_t)leaf_slot * B * A;
+}
+
+static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz_tree_step *step = nullptr, bool defer_heads = false)
 {
     lz_model *m = r->eng->model;
     if (m->cfg.model_type >= 2) { lz_mlp_recurrent(r, sim, horizon, s); return; }
     const lz_model_cfg &c = m->cfg;
     const lz_tree_dev &t = r->t;
-    const size_t B = t.B, A = t.A, C = c.num_channels, HW = m->HWl, H = c.lstm_hidden_size;
+    const size_t B = t.B, A = t.A, HW = m->HWl, H = c.lstm_hidden_size;
     const int slot = sim + 1;
-    const size_t lat_slot = B * HW * C;
     // ---- dynamics conv over [latent | one-hot action] + BN + latent + ReLU, dynamics residual block (-> latent pool
     // slot), prediction residual block and the three 1x1 head convs (efficientzero_model.py:527-558, common.py:1189-1203):
     // ONE launch, activations stay in LDS
-    float *next_latent = r->latent_pool + (size_t)slot * lat_slot;
     {
-        lz_chain_args ca{};
-        ca.in = r->latent_pool; ca.gather_ix = t.res_ix; ca.slot_stride = (int64_t)lat_slot;
-        ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B; ca.gw = m->GW; ca.gh = m->GH; ca.C = (int)C;
-        ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, 1, 1, nullptr);
-        const int x_lat = chain_blocks(ca, m->dyn_res, 1, -1, next_latent);   // the next latent state: kept for the reward 1x1 conv
-        const int x_p = chain_blocks(ca, m->pred_res, x_lat, x_lat, nullptr);
-        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = x_p;
-        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = x_p;
-        ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = x_lat;
-        ca.nc1 = 3;
+        lz_chain_args ca;
+        chain_args_for(r, sim, ca);
 #ifdef LZ_DEBUG_KNOBS
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
         if (getenv("LZ_DEBUG_HEADS_TS") && !lz_debug_heads_ts) (void)lz_dev_malloc((void **)&lz_debug_heads_ts, 8 * 8);
@@ -1280,6 +1338,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
         }
 #endif
         if (step && !lz_chain_fusable(ca, *step)) {  // the tree outgrew the LDS budget (or the shape has no fused instance)
+            // (never with split heads: the simulation before this one deferred its heads only after the same test succeeded)
             lz_tree_launch_backprop_traverse(step->t, step->new_node, step->discount, step->vps, step->values, step->logits,
                                              step->horizon, step->a, step->delta, step->vtp, s);
             step = nullptr;
@@ -1299,14 +1358,19 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
+    if (defer_heads) {   // split heads: the first layers of the head MLPs ride on this launch, the next chain launch finishes them
+        l.sh_pv = r->t_pv; l.sh_kc = 2 * c.head_channels * (int)HW; l.sh_w1c = m->sh_w1c; l.sh_w1r = m->sh_w1r;
+        l.sh_part = r->sh_part;
+    }
 #ifdef LZ_DEBUG_KNOBS
-    l.debug_hot_weights = getenv("LZ_DEBUG_LSTM_HOTW") ? 1 : 0;
+    l.debug_hot_weights = getenv("LZ_DEBUG_LSTM_HOTW") ? atoi(getenv("LZ_DEBUG_LSTM_HOTW")) : 0;   // bit 0: hot weights; split heads: bit 1 no operand loads, bit 2 no partial stores
 #endif
     // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
     // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
     if (c.model_type == 0 && !dbg_skip('l')) lz_launch_lstm(l, s);
-    if (!dbg_skip('h')) heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
-          r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
+    if (!defer_heads && !dbg_skip('h'))
+        heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
+              r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
 }
 
 // the whole search: traverse, then per simulation [network, expand + backup fused with the next selection]
@@ -1348,10 +1412,35 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     // models it runs in the prologue of simulation s + 1's chain launch (same workgroup-per-root mapping) while the tree
     // of a root still fits the LDS budget, else as its own launch.  LZ_NO_TREE_FUSE=1 keeps it separate (parity tests).
     const bool fuse = r->eng->model->cfg.model_type < 2 && !getenv("LZ_NO_TREE_FUSE");
+    // Split heads (EfficientZero, 6x6 latent; LZ_HEADS_LAUNCH=1 keeps the separate head launch): a simulation whose successor's chain
+    // launch will run the tree step in its prologue leaves its heads to that launch -- the LSTM launch computes their first layers as
+    // partial sums, waves 1..7 of the next chain launch finish them for their root while wave 0 stages the tree.  2 launches per
+    // simulation instead of 3; the last simulation (and every one followed by a separate tree launch) keeps the head launch.
+    lz_model *mdl = r->eng->model;
+    const bool split = fuse && mdl->cfg.model_type == 0 && mdl->sh_w1c && r->sh_part && t.A <= 64 && mdl->cfg.support_size <= 768 &&
+                       mdl->cfg.lstm_hidden_size == 512 && t.variant == LZ_TREE_EFFICIENTZERO && !getenv("LZ_HEADS_LAUNCH") && !getenv("LZ_CHAIN_DIRECT") &&
+                       !getenv("LZ_CHAIN_W4") && !getenv("LZ_LSTM_NOSPLIT") && !getenv("LZ_LSTM_ROWS32") && !getenv("LZ_LSTM_CHUNKED");
+    auto make_step = [&](int slot) {
+        lz_tree_step st{};
+        st.t = t; st.new_node = slot; st.discount = ta.discount;
+        st.vps = r->sim_vp + (size_t)slot * B; st.values = r->sim_value + (size_t)slot * B; st.logits = r->sim_logits + (size_t)slot * B * A;
+        st.horizon = horizon; st.a = ta; st.delta = delta; st.vtp = r->d_to_play;
+        return st;
+    };
     lz_tree_step step{};
     bool pending = false;  // a step that the next chain launch has to run
     for (int sim = 0; sim < num_simulations; ++sim) {
-        recurrent(r, sim, horizon, s, pending ? &step : nullptr);
+        bool defer = false;   // will simulation sim + 1's chain launch run the tree step -- and with it this simulation's heads?
+        if (split && sim + 1 < num_simulations) {
+            lz_traverse_args ta2 = ta;
+            ta2.counter = (uint32_t)(sim + 1);
+            lz_tree_step nxt = make_step(sim + 1);
+            nxt.a = ta2;
+            lz_chain_args ca;
+            chain_args_for(r, sim + 1, ca);
+            defer = lz_chain_fusable(ca, nxt);
+        }
+        recurrent(r, sim, horizon, s, pending ? &step : nullptr, defer);
         pending = false;
         const int slot = sim + 1;
         const float *vp = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
@@ -1359,11 +1448,11 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
         if (sim + 1 < num_simulations) {
             ta.counter = (uint32_t)(sim + 1);
             if (fuse) {
-                step.t = t; step.new_node = slot; step.discount = ta.discount; step.vps = vp; step.values = val; step.logits = lg;
-                step.horizon = horizon; step.a = ta; step.delta = delta; step.vtp = r->d_to_play;
+                step = make_step(slot);
+                if (defer) split_heads_for(r, slot, step.sh);
 #ifdef LZ_DEBUG_KNOBS
                 if (getenv("LZ_DEBUG_TREE_TS")) {   // timing experiments only: stamps of root 0's step in the last fused launch
-                    if (!g_tree_ts) (void)lz_dev_malloc((void **)&g_tree_ts, 8 * 8);
+                    if (!g_tree_ts) (void)lz_dev_malloc((void **)&g_tree_ts, 16 * 8);
                     step.ts = g_tree_ts;
                 }
 #endif
@@ -1385,7 +1474,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

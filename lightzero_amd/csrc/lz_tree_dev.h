@@ -465,12 +465,16 @@ __device__ __forceinline__ void load_leaf(const lz_tree_dev &t, int b, const flo
 // ids, node records, the previous path, the leaf's network outputs and the root scalars), the backup and the selection
 // then chase pointers inside LDS, and every store is written through to HBM.  One wavefront; s_tree needs
 // lz_tree_lds_bytes(t, new_node) bytes.  s_out (optional, LDS): [0] = selected parent slot (res_ix), [1] = last action.
+// s_leaf (optional, LDS): the leaf's network outputs arrive HERE instead of in vps / values / logits -- [0] value prefix, [1] value,
+// [2 .. 2 + A) policy logits, written by other waves of the workgroup, which then raise s_leaf_flag[0] to leaf_ready (split heads,
+// k_chain_w): the tree is staged first, then this wave waits for the flag.
 template <int NC, int VARIANT>
 __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int new_node, float discount,
                                              const float *__restrict__ vps, const float *__restrict__ values,
                                              const float *__restrict__ logits, int horizon, const lz_traverse_args &a,
                                              float delta_max, const int32_t *__restrict__ vtp_in, float4 *s_tree,
-                                             int32_t *s_out = nullptr, unsigned long long *ts = nullptr)
+                                             int32_t *s_out = nullptr, unsigned long long *ts = nullptr,
+                                             const float *s_leaf = nullptr, const int32_t *s_leaf_flag = nullptr, int leaf_ready = 0)
 {
     const int lane = threadIdx.x;
     const bool stamp = ts && b == 0 && lane == 0;   // timing experiments only (ts is null in production)
@@ -491,7 +495,8 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     // the first use: a predicated load, or a wave-uniform read of a loaded value in between, would split this into
     // several dependent HBM/L2 round trips (~0.6 us each).
     const int r_nroot = t.n_legal[b], r_visit = t.root_visit[b], r_d = t.res_search_len[b], r_tp = t.res_vtp[b];
-    const float r_vsum = t.root_vsum[b], r_mn = t.minmax[2 * b], r_mx = t.minmax[2 * b + 1], r_vp = vps[b], r_val = values[b];
+    const float r_vsum = t.root_vsum[b], r_mn = t.minmax[2 * b], r_mx = t.minmax[2 * b + 1];
+    float r_vp = s_leaf ? 0.0f : vps[b], r_val = s_leaf ? 0.0f : values[b];
     const uint32_t r_epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;
     const int vtp = vtp_in[b];
     int r_act[NC];
@@ -500,7 +505,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     for (int c = 0; c < NC; ++c) {
         const int j = min(c * 64 + lane, A - 1);
         r_act[c] = t.legal[(size_t)b * A + j];
-        r_lg[c] = logits[(size_t)b * A + j];
+        r_lg[c] = s_leaf ? 0.0f : logits[(size_t)b * A + j];
     }
     const int ne = new_node * A;        // edges / child ids of the existing nodes 0 .. new_node - 1 (ne >= 1)
     // first batch of every array: all requests, then the table arithmetic (it runs while they are in flight), then the LDS stores;
@@ -567,6 +572,13 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
             const int i = i0 + u * 64 + lane;
             if (i < new_node) { s_vp[i] = nv[u]; s_reset[i] = nr[u]; s_tp[i] = nt[u]; s_pn[i] = pn[u]; s_pa[i] = pa[u]; }
         }
+    }
+    if (s_leaf) {   // the tree is staged; now the leaf's network outputs, once the waves that compute them say so
+        while (__hip_atomic_load(s_leaf_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != leaf_ready) __builtin_amdgcn_s_sleep(1);
+        r_vp = s_leaf[0];
+        r_val = s_leaf[1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) r_lg[c] = s_leaf[2 + min(c * 64 + lane, A - 1)];
     }
     // the same values load_scalars / load_leaf produce
     tscal<NC> sc;

@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_HEADS_VALU", "LZ_LSTM_NOSPLIT", "LZ_NO_TREE_FUSE", "LZ_NO_GRAPH"]
+VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_LSTM_NOSPLIT", "LZ_NO_TREE_FUSE", "LZ_NO_GRAPH"]
 
 
 @pytest.mark.gpu
@@ -16,7 +16,9 @@ VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_HEADS_VALU",
 def test_nn_goldens_hold_on_the_alternative_path(knob):
     env = dict(os.environ)
     env[knob] = "1"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_nn_golden_gpu.py"), "-x", "-q", "-p", "no:cacheprovider"],
+    # the goldens (teacher-forced single steps) and the teacher-forced check of every simulation of a captured search at B = 67 / 256
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_nn_golden_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_nn_gpu.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "%s=1:\n%s\n%s" % (knob, r.stdout[-3000:], r.stderr[-2000:])
     assert " passed" in r.stdout

@@ -24,9 +24,15 @@ for it in range(3):
     L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
     L.check(lib.lz_engine_synchronize(model.engine))
 lib.lz_debug_read_tree_ts.argtypes = [ctypes.c_void_p]
-out = np.zeros(8, np.uint64)
+out = np.zeros(16, np.uint64)
 L.check(lib.lz_debug_read_tree_ts(out.ctypes.data))
 ts = out[:7].astype(np.int64)
 names = ["step entered", "all loads requested", "tree staged in LDS", "expand + backup", "selection", "barrier (other waves released)", "latent / tables staged"]
 for i in range(1, 7):
     print("%-32s +%6d cycles   (t=%6d)" % (names[i], ts[i] - ts[i - 1], ts[i] - ts[0]))
+hs = out[8:15].astype(np.int64)
+if hs[0]:   # split heads: head wave 1 (value head, output group 0) of the same workgroup
+    hn = ["entered", "loads requested", "partials arrived", "hidden units", "second layer", "max barrier", "sum barrier", "scalar out"]
+    print("head wave 1 (value head): entered at t=%6d of the tree wave's clock" % (hs[0] - ts[0]))
+    for i in range(1, 7):
+        print("  %-30s +%6d cycles   (t=%6d)" % (hn[i + 1] if i < 6 else hn[7], hs[i] - hs[i - 1], hs[i] - ts[0]))
