@@ -966,8 +966,8 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
     float lg[NT];
     const int nstep = head == 1 ? 64 : 192, n0 = gw * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = min(n0 + nstep * t, NOUT - 1);
+    for (int t = 0; t < NT; ++t) {   // unconditional, clamped: predicating the unused columns away (25 % of the requests) split the burst
+        const int n = min(n0 + nstep * t, NOUT - 1);   // into dependent pieces and was measured slower (heads out at 11.5 k instead of 8.2 k cycles)
         lg[t] = sh.b2[head][n];
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) w2[t][k4] = *reinterpret_cast<const f32x4 *>(sh.w2t[head] + ((size_t)k4 * NOUT + n) * 4);
@@ -1131,18 +1131,33 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
                 __syncthreads();
             }
         }
-        if (wv == 0)
+        if (wv == 0) {
+            // the tree step is one wave of strictly dependent instructions: it goes first wherever it competes with the head waves
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(3);
             dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
                                       step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
                                       heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
-        else if constexpr (HEADS) {
-            if (heads_on) heads_in_prologue(step.sh, b, step.t.A, wv - 1, lane, s_leaf, s_ctr, s_red, step.ts);
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(0);
+        } else {
+            if constexpr (HEADS) {
+                // head roles: waves 1-3 value, 5-7 value prefix, wave 4 -- which shares its SIMD with the tree wave -- the light policy head
+                const int hw = wv < 4 ? wv - 1 : (wv == 4 ? 6 : wv - 2);
+                if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
+            }
+            // the first layer's first weight fragments do not depend on the selection: the waves that are not the tree wave request
+            // theirs now (7 / 8 of the 131 KB that used to be requested after the step -- ~3 k cycles of this launch), and stage the
+            // folded-BatchNorm tables of all layers
+            fill_ring();
+            for (int i = tid - 64; i < a.nlayers * 128; i += NTHR - 64) {
+                const int L = i >> 7, r = i & 127;
+                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+            }
         }
         __syncthreads();
         if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
         g_slot = s_sel[0];
         g_action = s_sel[1];
-        fill_ring();
+        if (wv == 0) fill_ring();
     } else {
         if (a.gather_ix) g_slot = a.gather_ix[b];
         if (a.act_table) g_action = a.action[b];
@@ -1155,6 +1170,9 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
         for (int u = 0; u < NU; ++u) {
             const int idx = u * NTHR + tid;
             v[u] = vzero4();
+#ifdef LZ_DEBUG_KNOBS
+            if (a.debug_flags & 1) continue;
+#endif
             if (idx < HW * 16) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
         }
 #pragma unroll
@@ -1163,7 +1181,11 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
             if (idx < HW * 16) *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
         }
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
+#ifdef LZ_DEBUG_KNOBS
+        if (a.act_table && !BIG && !(a.debug_flags & 2)) {
+#else
         if (a.act_table && !BIG) {
+#endif
             const float *tsrc = a.act_table + (size_t)g_action * HW * 64;
             float4 tv[NU];
 #pragma unroll
@@ -1177,9 +1199,11 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
                 if (idx < HW * 16) *reinterpret_cast<float4 *>(sTab + (idx >> 4) * PS + (idx & 15) * 4) = tv[u];
             }
         }
-        for (int i = tid; i < a.nlayers * 128; i += NTHR) {
-            const int L = i >> 7, r = i & 127;
-            sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+        if (TREE == 0) {   // (with the tree step in the prologue the other waves staged these during the step)
+            for (int i = tid; i < a.nlayers * 128; i += NTHR) {
+                const int L = i >> 7, r = i & 127;
+                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+            }
         }
     }
     // ---- per-thread geometry, the same for every layer

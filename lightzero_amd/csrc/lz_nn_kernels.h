@@ -82,6 +82,7 @@ struct lz_chain_args {
     int B;
     int gw, gh;                  // latent grid (6x6 Atari with downsample, 9x9 Go); compiled instances: 6x6, 9x9
     unsigned long long *tstamp;  // debugging: s_memtime stamps of workgroup 0 / wave 0 (null in production)
+    int debug_flags;             // timing experiments of the debug build (results are then wrong): 1 = no latent gather, 2 = no action-table slice
 };
 // step != null: the tree step of every root (expand + backup of the previous simulation, selection of this one) runs as the
 // prologue of the root's workgroup, and the chain reads the selected (slot, action) from LDS instead of gather_ix / action

@@ -1331,6 +1331,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
         chain_args_for(r, sim, ca);
 #ifdef LZ_DEBUG_KNOBS
         if (const char *dbg = getenv("LZ_DEBUG_CHAIN_LAYERS")) ca.nlayers = atoi(dbg);  // timing experiments only
+        if (const char *dbg = getenv("LZ_DEBUG_CHAIN_FLAGS")) ca.debug_flags = atoi(dbg);
         if (getenv("LZ_DEBUG_HEADS_TS") && !lz_debug_heads_ts) (void)lz_dev_malloc((void **)&lz_debug_heads_ts, 8 * 8);
         if (getenv("LZ_DEBUG_CHAIN_TS")) {  // timing experiments only: stamps of the last launch, read with lz_debug_read_chain_ts
             if (!g_chain_ts) (void)lz_dev_malloc((void **)&g_chain_ts, 64 * 8);
