@@ -21,6 +21,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def short(name):
+    """'void (anonymous namespace)::k_x<1, 2>(args...)' -> 'k_x<1, 2>'"""
+    name = name.replace("void (anonymous namespace)::", "")
+    if ">(" in name:
+        return name[:name.index(">(") + 1]
+    return name.split("(")[0]
+
+
 def main():
     run, tag = sys.argv[1], sys.argv[2]
     prof = os.path.join(ROOT, "profiles")
@@ -49,18 +57,20 @@ def main():
     # the roofline kernel: the k_chain_w instantiation with the largest total time (the fused tree-step + chain launch)
     tot = {r["Name"]: float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats))}
     fused = max((n for n in tot if "k_chain_w" in n), key=lambda n: tot[n])
-    fused = fused.split("(")[0]
+    fused = short(fused)
     f, w = mean(fused, "FETCH_SIZE"), mean(fused, "WRITE_SIZE")
     out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and rocprofv3 --kernel-trace --pmc WRITE_SIZE (two separate passes) -- "
                    "python bench.py --steps 1 --warmup 1 --no-cpu-baseline, MI355X; per-dispatch means in KB as reported "
                    "(tools/refresh_profiles.py). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B "
                    "request of a wide coalesced read, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE taken as reported (uncalibrated).",
            "k_chain": {"fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": int(round((2 * f + w) * 1024)),
-                       "note": "k_chain_w<6,6,8,false,1> = the root's tree step (prologue) + the Winograd convolution chain. reads: latent "
-                               "gather 2.36 MB + 1.31 MB of transformed weights once per XCD L2 (8 x: L2 does not survive a kernel boundary) "
-                               "+ the staged trees / leaf outputs of the tree step; writes: next latent 2.36 MB + head-conv outputs 1.77 MB "
-                               "+ tree write-through. Algorithmic bytes of the chain 7.8 MB (activations in and out + the weights once)."}}
-    for key in ("k_chain_w<6, 6, 8, false, 0", "k_heads_mm", "k_lstm2<68", "k_conv_wino<64, 64, 16>", "k_conv_wino<32, 32, 32>",
+                       "kernel": fused,
+                       "note": "the root's prologue (tree step on wave 0; split heads: the previous simulation's head MLPs finished on waves 1-7 "
+                               "from the LSTM launch's 3.1 MB of first-layer partial sums + 0.16 MB of second-layer weights per XCD) + the "
+                               "Winograd convolution chain. reads: latent gather 2.36 MB + 1.31 MB of transformed weights once per XCD L2 (8 x: "
+                               "L2 does not survive a kernel boundary) + the staged trees; writes: next latent 2.36 MB + head-conv outputs "
+                               "1.77 MB + tree write-through. Algorithmic bytes of the chain 7.8 MB (activations in and out + the weights once)."}}
+    for key in ("k_chain_w<6, 6, 8, false, 0", "k_heads_mm", "k_lstm2<68, 0, 16, 36, true>", "k_conv_wino<64, 64, 16>", "k_conv_wino<32, 32, 32>",
                 "k_conv3x3_big<32, 64, 2, 48>", "k_conv_first", "k_avgpool", "k_pack_rows"):
         out[key] = {"fetch_size_kb": mean(key, "FETCH_SIZE"), "write_size_kb": mean(key, "WRITE_SIZE")}
     json.dump(out, open(os.path.join(prof, "%s_traffic.json" % tag), "w"), indent=1)
@@ -128,7 +138,10 @@ def main():
     man["csrc_sha256_here"] = csrc_digest()
     man["k_chain"] = {"kernel": fused, "rocprof_avg_us": d_chain, "hbm_bytes_per_launch": out["k_chain"]["hbm_bytes_per_launch"],
                       "mfma_busy_cycles_per_simd": (busy / 1024.0) if busy else None}
-    man["kernel_avg_us"] = {k.split("(")[0]: round(v, 2) for k, v in dur.items() if v > 3.0}
+    man["kernel_avg_us"] = {short(k): round(v, 2) for k, v in dur.items() if v > 3.0 and "k_" in k}
+    # the other BASELINE configurations, measured by tools/config_lines.py into <run>/cfg/
+    for f in sorted(glob.glob(os.path.join(run, "cfg", "cfg*.json"))):
+        shutil.copy(f, os.path.join(prof, "%s_%s" % (tag, os.path.basename(f))))
     man["files"] = sorted(f for f in os.listdir(prof) if f.startswith(tag + "_"))
     json.dump(man, open(os.path.join(prof, "%s_manifest.json" % tag), "w"), indent=1, sort_keys=True)
     if man["csrc_sha256"] != man["csrc_sha256_here"]:
