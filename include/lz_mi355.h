@@ -237,13 +237,19 @@ typedef struct lz_model_cfg {
     /* ---- MLP model family only (model_type >= 2); the layer widths are taken from the tensors themselves */
     int activation;         /* 0 ReLU, 1 GELU(approximate='tanh') */
     int res_connection_in_dynamics;
-    int action_encoding;    /* 0 one_hot, 1 not_one_hot (action / action_space_size), 2 continuous (the action vector) */
+    int action_encoding;    /* 0 one_hot, 1 not_one_hot (action / action_space_size; also on the conv models: ONE action plane,
+                               efficientzero_model.py:355-369), 2 continuous (the action vector) */
     int num_of_sampled_actions;  /* K (model_type 4) */
     int sigma_type;         /* 0 conditioned */
     int bound_type;         /* 0 None, 1 tanh on mu */
     float ln_eps;           /* 1e-5 */
     /* ---- convolutional models */
     int num_res_blocks;     /* residual blocks of the representation / dynamics / prediction networks: 1 (0 means 1), 2 or 3 */
+    /* MuZeroModel (conv) only: a reward support that differs from the value support (reward_support_range, muzero_model.py; the drivers
+     * build one inverse-transform handle per support, mcts_ctree.py:726-729); 0 = the value support.  The reference's EfficientZero
+     * driver sends the value prefix through the VALUE handle (mcts_ctree.py:839-841), so there the two must be equal. */
+    int reward_support_size;
+    float reward_support_min;
 } lz_model_cfg;
 
 /* One model per engine (creating another replaces it: roots of the old one re-size their pools on the next inference).

@@ -22,7 +22,8 @@ class ModelCfg(ctypes.Structure):
                 ("support_min", ctypes.c_float), ("bn_eps", ctypes.c_float), ("downsample", ctypes.c_int),
                 ("activation", ctypes.c_int), ("res_connection_in_dynamics", ctypes.c_int), ("action_encoding", ctypes.c_int),
                 ("num_of_sampled_actions", ctypes.c_int), ("sigma_type", ctypes.c_int), ("bound_type", ctypes.c_int),
-                ("ln_eps", ctypes.c_float), ("num_res_blocks", ctypes.c_int)]
+                ("ln_eps", ctypes.c_float), ("num_res_blocks", ctypes.c_int), ("reward_support_size", ctypes.c_int),
+                ("reward_support_min", ctypes.c_float)]
 
 
 _lib = None

@@ -51,6 +51,9 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(e != nullptr && cfg != nullptr, "NULL argument");
     LZ_REQUIRE(cfg->model_type >= 0 && cfg->model_type <= 4, "model_type must be 0 (EfficientZeroModel), 1 (MuZeroModel), 2 (MuZeroModelMLP), 3 (EfficientZeroModelMLP) or 4 (SampledEfficientZeroModelMLP)");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
+    LZ_REQUIRE(cfg->reward_support_size >= 0 && cfg->reward_support_size <= 768, "reward_support_size must be in [0, 768] (0 = the value support)");
+    LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
+               "a reward support of its own: MuZeroModel (conv) only (the EfficientZero driver transforms the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {
         // vector observations: obs_c = observation_shape, num_channels = latent_state_dim; the layer widths come from the tensors
         LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_h == 1 && cfg->obs_w == 1, "MLP models take obs_c = observation_shape, obs_h = obs_w = 1");
@@ -93,6 +96,7 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden >= 1 && cfg->head_hidden <= 32, "head_channels must be 16 and head_hidden at most 32");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
+    LZ_REQUIRE(cfg->action_encoding == 0 || cfg->action_encoding == 1, "conv models: action_encoding 0 (one_hot) or 1 (not_one_hot)");
     if (cfg->model_type == 0) {  // the value-prefix LSTM reads [16 channels x latent pixels | hidden]: compiled K shapes
         const int gpix = cfg->downsample ? (cfg->obs_h == 64 ? 64 : 36) : cfg->obs_h * cfg->obs_w;
         const int K = cfg->head_channels * gpix + cfg->lstm_hidden_size;
@@ -147,6 +151,8 @@ extern "C" int lz_model_finalize(lz_engine *e)
     const lz_model_cfg &c = m->cfg;
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
               H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size, NRB = c.num_res_blocks > 0 ? c.num_res_blocks : 1;
+    const int RSUP = c.reward_support_size > 0 ? c.reward_support_size : SUP;
+    const int AE = c.action_encoding == 1 ? 1 : A;   // action planes of the dynamics convolution's input (efficientzero_model.py:105-108)
     Builder b{m, ""};
     const bool wchain = C == 64 && ((m->GW == 6 && m->GH == 6) || (m->GW == 8 && m->GH == 8));  // these chains run on Winograd-transformed weights (k_chain_w)
     // ---- representation (common.py:266-365, :706-787)
@@ -199,11 +205,12 @@ extern "C" int lz_model_finalize(lz_engine *e)
     // ---- dynamics (efficientzero_model.py:427-569)
     {
         const std::string d = "dynamics_network.";
-        m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + A, C);
-        if (wchain) m->dyn.uc = b.wino_chain(d + "conv.weight", C, C + A, C);
+        m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + AE, C);
+        if (wchain) m->dyn.uc = b.wino_chain(d + "conv.weight", C, C + AE, C);
         // one-hot action planes: plane a is all ones inside the 6x6 latent, so its contribution to output
-        // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image
-        const HostTensor *w = b.get(d + "conv.weight", {C, C + A, 3, 3});
+        // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image.  not_one_hot: ONE plane holding
+        // action / action_space_size (fp32, like the reference's expand(...) / A): entry a = the in-bounds taps of W[co][C] times that
+        const HostTensor *w = b.get(d + "conv.weight", {C, C + AE, 3, 3});
         if (w) {
             const int SW = m->GW, SH = m->GH;
             std::vector<float> tab((size_t)A * HW * C);
@@ -212,9 +219,10 @@ extern "C" int lz_model_finalize(lz_engine *e)
                     for (int x = 0; x < SW; ++x)
                         for (int co = 0; co < C; ++co) {
                             float acc = 0.0f;
+                            const float plane = AE == 1 ? (float)a / (float)A : 1.0f;
                             for (int t = 0; t < 9; ++t) {
                                 const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-                                if (iy >= 0 && iy < SH && ix >= 0 && ix < SW) acc += w->data[((size_t)co * (C + A) + C + a) * 9 + t];
+                                if (iy >= 0 && iy < SH && ix >= 0 && ix < SW) acc += w->data[((size_t)co * (C + AE) + C + (AE == 1 ? 0 : a)) * 9 + t] * plane;
                             }
                             tab[((size_t)a * HW + y * SW + x) * C + co] = acc;
                         }
@@ -228,7 +236,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->rew_c = b.conv1x1(d + "conv1x1_reward", d + "norm_reward", HC, C);
         if (c.model_type == 1) {
             // MuZero DynamicsNetwork (muzero_model.py:505-538): reward = MLP(flatten(relu(bn(conv1x1(next latent)))))
-            m->fc_reward = b.mlp(d + "fc_reward_head", HC * HW, HID, SUP, true, HC, HW);
+            m->fc_reward = b.mlp(d + "fc_reward_head", HC * HW, HID, RSUP, true, HC, HW);
         } else {
         // LSTM: rows re-ordered to 4*unit + gate; the x columns permuted from the reference's
         // (channel, pixel) flatten order to (pixel, channel)
@@ -340,7 +348,7 @@ static int ensure_pools(lz_roots *r)
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
     const size_t B = r->t.B, NN = r->t.NN, A = r->t.A, C = c.num_channels, HW = m->HWl, H = c.model_type == 0 ? c.lstm_hidden_size : 0,
-                 HC = c.head_channels, SUP = c.support_size;
+                 HC = c.head_channels, SUP = std::max(c.support_size, c.reward_support_size);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_lat = take(NN * B * HW * C * 4), o_h = take(NN * B * H * 4), o_c = take(NN * B * H * 4),
@@ -451,7 +459,7 @@ static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_v
     h[n++] = headdesc(m->fc_value, r->t_pv, HW * 2 * HC, 2 * HC, 1, c.support_min, dbg_value_logits, out_value);
     h[n++] = headdesc(m->fc_policy, r->t_pv + HC, HW * 2 * HC, 2 * HC, 0, 0.f, out_logits, nullptr);
     if (with_vp) {
-        if (c.model_type == 1) h[n++] = headdesc(m->fc_reward, r->t_rx, HW * HC, HC, 1, c.support_min, dbg_vp_logits, out_vp);
+        if (c.model_type == 1) h[n++] = headdesc(m->fc_reward, r->t_rx, HW * HC, HC, 1, c.reward_support_size > 0 ? c.reward_support_min : c.support_min, dbg_vp_logits, out_vp);
         else h[n++] = headdesc(m->fc_reward, r->t_hbn, c.lstm_hidden_size, 16, 1, c.support_min, dbg_vp_logits, out_vp);
     }
     lz_launch_heads(h, n, B, 32, s);  // Builder::mlp pads narrower heads to the compiled 32 hidden units
@@ -1783,7 +1791,8 @@ extern "C" int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out)
 {
     LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr && h_out != nullptr && (which == 0 || which == 1), "bad argument");
     LZ_REQUIRE(r->trace_on, "the debug logits are written only while tracing is on (lz_roots_enable_trace before the inference)");
-    const size_t B = r->t.B, SUP = r->eng->model->cfg.support_size;
+    const lz_model_cfg &mc = r->eng->model->cfg;
+    const size_t B = r->t.B, SUP = (which == 1 && mc.reward_support_size > 0) ? mc.reward_support_size : mc.support_size;
     hipStream_t s = r->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(h_out, r->dbg_logits[which], B * SUP * 4, hipMemcpyDeviceToHost, s));
     LZ_HIP_CHECK(hipStreamSynchronize(s));

@@ -45,14 +45,17 @@ class EfficientZeroModel(object):
                  categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
                  engine=None, **kwargs):
         if not 1 <= int(num_res_blocks) <= 3 or norm_type != 'BN' or not categorical_distribution \
-                or discrete_action_encoding_type != 'one_hot':
-            raise NotImplementedError("engine model: num_res_blocks in 1..3, norm_type='BN', "
-                                      "categorical_distribution=True, one_hot action encoding")
+                or discrete_action_encoding_type not in ('one_hot', 'not_one_hot'):
+            raise NotImplementedError("engine model: num_res_blocks in 1..3, norm_type='BN', categorical_distribution=True, "
+                                      "discrete_action_encoding_type 'one_hot' | 'not_one_hot'")
         if not (reward_head_hidden_channels[0] == value_head_hidden_channels[0] == policy_head_hidden_channels[0]) \
                 or len(value_head_hidden_channels) != 1:
             raise NotImplementedError("the three heads must have one hidden layer of the same width")
-        if tuple(reward_support_range) != tuple(value_support_range) or value_support_range[2] != 1.:
-            raise NotImplementedError("reward and value supports must be equal with step 1")
+        if value_support_range[2] != 1. or reward_support_range[2] != 1.:
+            raise NotImplementedError("supports with step 1")
+        if tuple(reward_support_range) != tuple(value_support_range) and self._model_type != 1:
+            # the reference's EfficientZero driver transforms the value prefix with the VALUE handle (mcts_ctree.py:839-841)
+            raise NotImplementedError("EfficientZero: reward and value supports must be equal (MuZeroModel takes a reward support of its own)")
         if not (reward_head_channels == value_head_channels == policy_head_channels):
             raise NotImplementedError("head channel counts must be equal")
         self.observation_shape = tuple(observation_shape)
@@ -62,7 +65,8 @@ class EfficientZeroModel(object):
         self.num_res_blocks = int(num_res_blocks)
         self._downsample = bool(downsample)
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
-        self.reward_support_size = self.value_support_size
+        self.reward_support_size = int(round((reward_support_range[1] - reward_support_range[0]) / reward_support_range[2]))
+        self.discrete_action_encoding_type = discrete_action_encoding_type
         # one model per engine: the first model of the process lives on the default engine, later ones get their own
         self._engine = engine if engine is not None else L.engine_for_new_model()
         cfg = L.ModelCfg(self._model_type, self.observation_shape[0], self.observation_shape[1], self.observation_shape[2],
@@ -70,6 +74,9 @@ class EfficientZeroModel(object):
                          int(value_head_hidden_channels[0]), self.value_support_size, float(value_support_range[0]), 1e-5,
                          1 if downsample else 0)
         cfg.num_res_blocks = self.num_res_blocks
+        cfg.action_encoding = 0 if discrete_action_encoding_type == 'one_hot' else 1
+        if tuple(reward_support_range) != tuple(value_support_range):
+            cfg.reward_support_size, cfg.reward_support_min = self.reward_support_size, float(reward_support_range[0])
         self._create(cfg)
 
     def _create(self, cfg):
@@ -268,7 +275,7 @@ class EfficientZeroModel(object):
         nxt = np.zeros((B,) + lshape, np.float32)
         L.check(lib.lz_roots_read_latent(r._h, 1, nxt.reshape(-1)))
         SUP = int(self.value_support_size)
-        vlog = np.zeros((B, SUP), np.float32); rlog = np.zeros((B, SUP), np.float32)
+        vlog = np.zeros((B, SUP), np.float32); rlog = np.zeros((B, int(self.reward_support_size)), np.float32)
         L.check(lib.lz_roots_read_debug_logits(r._h, 0, vlog.reshape(-1)))
         L.check(lib.lz_roots_read_debug_logits(r._h, 1, rlog.reshape(-1)))
         pol = np.zeros((B, self._pw), np.float32)

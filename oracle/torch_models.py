@@ -145,6 +145,22 @@ class PredictionNetwork(nn.Module):  # common.py:1081-1216
         return policy, value
 
 
+def _action_encoding(model, latent_state, action):
+    """efficientzero_model.py:335-369 / muzero_model.py (same code): one-hot planes, or ONE plane holding action / action_space_size"""
+    if model.discrete_action_encoding_type == 'one_hot':
+        if len(action.shape) == 1:
+            action = action.unsqueeze(-1)
+        action_one_hot = torch.zeros(action.shape[0], model.action_space_size, device=action.device)
+        action_one_hot.scatter_(1, action.long(), 1)
+        return action_one_hot.unsqueeze(-1).unsqueeze(-1).expand(
+            latent_state.shape[0], model.action_space_size, latent_state.shape[2], latent_state.shape[3])
+    if len(action.shape) == 2:
+        action = action.unsqueeze(-1).unsqueeze(-1)
+    elif len(action.shape) == 1:
+        action = action.unsqueeze(-1).unsqueeze(-1).unsqueeze(-1)
+    return action.expand(latent_state.shape[0], 1, latent_state.shape[2], latent_state.shape[3]) / model.action_space_size
+
+
 class EZDynamicsNetwork(nn.Module):  # efficientzero_model.py:427-569
     def __init__(self, action_encoding_dim, num_res_blocks, num_channels, reward_head_channels, reward_hidden,
                  support_size, flat_reward, lstm_hidden_size):
@@ -181,9 +197,13 @@ class EfficientZeroModel(nn.Module):  # efficientzero_model.py:20-382 (inference
     def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, lstm_hidden_size=512, num_res_blocks=1,
                  num_channels=64, reward_head_channels=16, value_head_channels=16, policy_head_channels=16,
                  reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
-                 reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True):
+                 reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
+                 discrete_action_encoding_type='one_hot'):
         super().__init__()
         self.action_space_size = action_space_size
+        assert discrete_action_encoding_type in ('one_hot', 'not_one_hot')
+        self.discrete_action_encoding_type = discrete_action_encoding_type
+        self.action_encoding_dim = action_space_size if discrete_action_encoding_type == 'one_hot' else 1   # efficientzero_model.py:103-108
         self.lstm_hidden_size = lstm_hidden_size
         self.reward_support_size = len(torch.arange(*reward_support_range))
         self.value_support_size = len(torch.arange(*value_support_range))
@@ -195,7 +215,7 @@ class EfficientZeroModel(nn.Module):  # efficientzero_model.py:20-382 (inference
             latent_size = observation_shape[1] * observation_shape[2]
         hw = latent_size if downsample else observation_shape[1] * observation_shape[2]
         self.representation_network = RepresentationNetwork(observation_shape, num_res_blocks, num_channels, downsample)
-        self.dynamics_network = EZDynamicsNetwork(action_space_size, num_res_blocks, num_channels + action_space_size,
+        self.dynamics_network = EZDynamicsNetwork(self.action_encoding_dim, num_res_blocks, num_channels + self.action_encoding_dim,
                                                   reward_head_channels, reward_head_hidden_channels[0],
                                                   self.reward_support_size, reward_head_channels * hw, lstm_hidden_size)
         self.prediction_network = PredictionNetwork(action_space_size, num_res_blocks, num_channels, value_head_channels,
@@ -212,12 +232,7 @@ class EfficientZeroModel(nn.Module):  # efficientzero_model.py:20-382 (inference
         return EZNetworkOutput(value, [0. for _ in range(batch_size)], policy_logits, latent_state, reward_hidden_state)
 
     def recurrent_inference(self, latent_state, reward_hidden_state, action):
-        if len(action.shape) == 1:
-            action = action.unsqueeze(-1)
-        action_one_hot = torch.zeros(action.shape[0], self.action_space_size, device=action.device)
-        action_one_hot.scatter_(1, action.long(), 1)
-        action_encoding = action_one_hot.unsqueeze(-1).unsqueeze(-1).expand(
-            latent_state.shape[0], self.action_space_size, latent_state.shape[2], latent_state.shape[3])
+        action_encoding = _action_encoding(self, latent_state, action)
         state_action_encoding = torch.cat((latent_state, action_encoding), dim=1)
         next_latent_state, reward_hidden_state, value_prefix = self.dynamics_network(state_action_encoding,
                                                                                     reward_hidden_state)
@@ -256,9 +271,13 @@ class MuZeroModel(nn.Module):  # lzero/model/muzero_model.py:20-374 (inference g
     def __init__(self, observation_shape=(4, 96, 96), action_space_size=6, num_res_blocks=1, num_channels=64,
                  reward_head_channels=16, value_head_channels=16, policy_head_channels=16,
                  reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
-                 reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True):
+                 reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
+                 discrete_action_encoding_type='one_hot'):
         super().__init__()
         self.action_space_size = action_space_size
+        assert discrete_action_encoding_type in ('one_hot', 'not_one_hot')
+        self.discrete_action_encoding_type = discrete_action_encoding_type
+        self.action_encoding_dim = action_space_size if discrete_action_encoding_type == 'one_hot' else 1   # muzero_model.py:105-110
         self.reward_support_size = len(torch.arange(*reward_support_range))
         self.value_support_size = len(torch.arange(*value_support_range))
         if observation_shape[1] == 96:
@@ -269,7 +288,7 @@ class MuZeroModel(nn.Module):  # lzero/model/muzero_model.py:20-374 (inference g
             latent_size = observation_shape[1] * observation_shape[2]
         hw = latent_size if downsample else observation_shape[1] * observation_shape[2]
         self.representation_network = RepresentationNetwork(observation_shape, num_res_blocks, num_channels, downsample)
-        self.dynamics_network = MZDynamicsNetwork(action_space_size, num_res_blocks, num_channels + action_space_size,
+        self.dynamics_network = MZDynamicsNetwork(self.action_encoding_dim, num_res_blocks, num_channels + self.action_encoding_dim,
                                                   reward_head_channels, reward_head_hidden_channels[0],
                                                   self.reward_support_size, reward_head_channels * hw)
         self.prediction_network = PredictionNetwork(action_space_size, num_res_blocks, num_channels, value_head_channels,
@@ -284,12 +303,7 @@ class MuZeroModel(nn.Module):  # lzero/model/muzero_model.py:20-374 (inference g
         return MZNetworkOutput(value, [0. for _ in range(batch_size)], policy_logits, latent_state)
 
     def recurrent_inference(self, latent_state, action):
-        if len(action.shape) == 1:
-            action = action.unsqueeze(-1)
-        action_one_hot = torch.zeros(action.shape[0], self.action_space_size, device=action.device)
-        action_one_hot.scatter_(1, action.long(), 1)
-        action_encoding = action_one_hot.unsqueeze(-1).unsqueeze(-1).expand(
-            latent_state.shape[0], self.action_space_size, latent_state.shape[2], latent_state.shape[3])
+        action_encoding = _action_encoding(self, latent_state, action)
         next_latent_state, reward = self.dynamics_network(torch.cat((latent_state, action_encoding), dim=1))
         policy_logits, value = self.prediction_network(next_latent_state)
         return MZNetworkOutput(value, reward, policy_logits, next_latent_state)

@@ -33,7 +33,10 @@ def main():
     ref = ref_loader.load()
     assert ref is not None, "/root/reference is needed to (re)generate the goldens"
     st = ref.scaling_transform
+    only = set(sys.argv[1:])   # optional: regenerate only these cases
     for name, case in sorted(nn_cases.CASES.items()):
+        if only and name not in only:
+            continue
         fam, kw = case["family"], case["kw"]
         ora = tm.synthetic_init(nn_cases.oracle_class(tm, fam)(**kw), seed=case["seed"])   # only as the seeded weight recipe
         rmod = nn_cases.reference_class(ref, fam)(**nn_cases.reference_kwargs(case))
@@ -42,6 +45,7 @@ def main():
         rmod.eval()
         support = kw.get("value_support_range", kw.get("support_range", (-300., 301., 1.)))
         ist = st.InverseScalarTransform(st.DiscreteSupport(*support), True)
+        rist = st.InverseScalarTransform(st.DiscreteSupport(*kw.get("reward_support_range", support)), True)   # mcts_ctree.py:726-729
         obs, actions = nn_cases.inputs(case)
         out = {"weights_sha256": np.frombuffer(weights_digest(ora.state_dict()).encode(), np.uint8)}
         lstm = nn_cases.has_lstm(fam)
@@ -67,7 +71,7 @@ def main():
                     rew_logits = r.reward
                 out["s%d_latent" % s] = r.latent_state.numpy()
                 out["s%d_reward_logits" % s] = rew_logits.numpy()
-                out["s%d_reward" % s] = ist(rew_logits.clone()).reshape(-1).numpy()
+                out["s%d_reward" % s] = rist(rew_logits.clone()).reshape(-1).numpy()
                 out["s%d_value_logits" % s] = r.value.numpy()
                 out["s%d_value" % s] = ist(r.value.clone()).reshape(-1).numpy()
                 out["s%d_policy" % s] = r.policy_logits.numpy()

@@ -26,6 +26,14 @@ CASES = {
     # num_res_blocks > 1 (RepresentationNetwork / DynamicsNetwork / PredictionNetwork are generic in it, common.py:706-787)
     "ez_atari96_rb2": dict(family="ez", kw=dict(observation_shape=(4, 96, 96), action_space_size=6, downsample=True, num_res_blocks=2), B=4, seed=21),
     "mz_connect4_rb3": dict(family="mz", kw=dict(observation_shape=(3, 6, 7), action_space_size=7, downsample=False, num_res_blocks=3), B=5, seed=22),
+    # discrete_action_encoding_type='not_one_hot' (one plane holding action / action_space_size; the reference ships it for chinese chess,
+    # zoo/board_games/chinese_chess/config/chinese_chess_muzero_bot_mode_config.py) and unequal reward / value supports (MuZero only: the
+    # reference's EfficientZero driver sends the value prefix through the VALUE handle, mcts_ctree.py:839-841)
+    "ez_atari96_noh": dict(family="ez", kw=dict(observation_shape=(4, 96, 96), action_space_size=6, downsample=True,
+                                                discrete_action_encoding_type='not_one_hot'), B=5, seed=23),
+    "mz_board_noh_supports": dict(family="mz", kw=dict(observation_shape=(5, 6, 6), action_space_size=36, downsample=False,
+                                                       discrete_action_encoding_type='not_one_hot',
+                                                       reward_support_range=(-2., 3., 1.), value_support_range=(-10., 11., 1.)), B=6, seed=24),
     # BASELINE configs[0]: CartPole MuZeroModelMLP
     "mz_mlp_cartpole": dict(family="mz_mlp", kw=dict(observation_shape=4, action_space_size=2, latent_state_dim=128), B=8, seed=15),
     "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),

@@ -24,6 +24,7 @@ def test_oracle_reproduces_reference_goldens(name):
     ora = tm.synthetic_init(nn_cases.oracle_class(tm, fam)(**kw), seed=case["seed"])
     assert weights_digest(ora.state_dict()) == bytes(g["weights_sha256"]).decode(), "seeded weights differ from the golden's"
     ist = tm.InverseScalarTransform(kw.get("value_support_range", (-300., 301., 1.)))
+    rist = tm.InverseScalarTransform(kw.get("reward_support_range", kw.get("value_support_range", (-300., 301., 1.))))
     obs, actions = nn_cases.inputs(case)
 
     def eq(a, key):
@@ -47,4 +48,4 @@ def test_oracle_reproduces_reference_goldens(name):
                 rew = o.reward
             eq(o.latent_state, "s%d_latent" % s); eq(rew, "s%d_reward_logits" % s); eq(o.value, "s%d_value_logits" % s)
             eq(o.policy_logits, "s%d_policy" % s)
-            eq(ist(rew.clone()).reshape(-1), "s%d_reward" % s); eq(ist(o.value.clone()).reshape(-1), "s%d_value" % s)
+            eq(rist(rew.clone()).reshape(-1), "s%d_reward" % s); eq(ist(o.value.clone()).reshape(-1), "s%d_value" % s)

@@ -72,7 +72,7 @@ def test_hip_network_matches_reference_module_outputs(name):
     L.check(lib.lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
     worst = dict(latent=_rel(lat, g["init_latent"]), policy=_rel(out.policy_logits, g["init_policy"]),
                  scalar=_rel(out.value, g["init_value"]), logits=0.0, hc=0.0)
-    SUP = g["init_value_logits"].shape[1]
+    SUP, RSUP = g["init_value_logits"].shape[1], g["s0_reward_logits"].shape[1]
     if conv:
         vl = np.zeros((B, SUP), np.float32)
         L.check(lib.lz_roots_read_debug_logits(roots._h, 0, vl.reshape(-1)))
@@ -108,7 +108,7 @@ def test_hip_network_matches_reference_module_outputs(name):
             L.check(lib.lz_roots_read_hidden(roots._h, 1, hh.reshape(-1), cc.reshape(-1)))
             worst["hc"] = max(worst["hc"], _rel(hh, g["s%d_h" % s]), _rel(cc, g["s%d_c" % s]))
         if conv:
-            vl = np.zeros((B, SUP), np.float32); rl = np.zeros((B, SUP), np.float32)
+            vl = np.zeros((B, SUP), np.float32); rl = np.zeros((B, RSUP), np.float32)
             L.check(lib.lz_roots_read_debug_logits(roots._h, 0, vl.reshape(-1)))
             L.check(lib.lz_roots_read_debug_logits(roots._h, 1, rl.reshape(-1)))
             worst["logits"] = max(worst["logits"], _rel(vl, g["s%d_value_logits" % s]), _rel(rl, g["s%d_reward_logits" % s]))
