@@ -34,7 +34,6 @@ class GameSegmentBatch(object):
         # segment generation).  An entry belongs to an env's CURRENT segment while its generation tag equals gen[env]; ``reset`` of
         # some envs bumps their generation and leaves every other env's frames alone.
         self._init_obs = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)
-        self._window = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)   # observation_window_stack of the collector
         self._frames = []
         self._gen = np.zeros(self.n_env, np.int64)
         self.action = np.zeros((self.n_env, cap), np.int64)
@@ -65,7 +64,6 @@ class GameSegmentBatch(object):
         ids = self._ids(env_ids)
         init = np.asarray(init_observations, np.float32).reshape((len(ids), self.stack) + self.frame_shape)
         self._init_obs[ids] = init
-        self._window[ids] = init
         self._gen[ids] += 1   # the frames appended so far belong to the previous segments of these envs -- and only of these
         if len(self._frames) > 4 * (self.L + self.pad + 8):   # entries none of whose envs is current any more
             self._frames = [e for e in self._frames if (e[3] == self._gen[self._ids(e[0])]).any()]
@@ -108,9 +106,25 @@ class GameSegmentBatch(object):
         self._frames.append((None if env_ids is None else ids.copy(), frames, t.copy(), self._gen[ids].copy()))
         self.reward[ids, t] = np.asarray(rewards, np.float32)
         self.len[ids] = t + 1
-        if self.stack > 1:
-            self._window[ids, :-1] = self._window[ids, 1:]
-        self._window[ids, -1] = frames
+
+    def window(self, env):
+        """the collector's observation_window_stack of one env (muzero_collector.py:641): the ``frame_stack_num`` newest observations
+        of its current segment, [frame_stack_num, *frame_shape].  Built on demand from the frames kept by reference -- the per-step
+        path never shifts or copies a window"""
+        n, g, s = int(self.len[env]), self._gen[env], self.stack
+        out = np.zeros((s,) + self.frame_shape, np.float32)
+        need = min(s, n)
+        if n < s:
+            out[:s - n] = self._init_obs[env, n:]
+        for fi, fr, pos, gen in reversed(self._frames):
+            if need == 0:
+                break
+            k = env if fi is None else (np.nonzero(fi == env)[0][0] if (fi == env).any() else -1)
+            if k < 0 or gen[k] != g or int(pos[k]) < n - s:
+                continue
+            out[s - (n - int(pos[k]))] = fr[k]
+            need -= 1
+        return out
 
     def is_full(self):
         """GameSegment.is_full (:370-377), per env"""
@@ -167,7 +181,7 @@ class GameSegmentBatch(object):
                 pri = self._priorities(env)
                 self._last[env] = self.to_arrays(env)
                 self._last_pri[env] = pri
-                self.reset(self._window[env][None], env_ids=[env])
+                self.reset(self._last[env]["obs_segment"][-self.stack:][None], env_ids=[env])   # = the observation window
             if done[env]:
                 if self._last[env] is not None:
                     self._pad_and_save(env, done[env])

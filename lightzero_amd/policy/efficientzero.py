@@ -104,8 +104,21 @@ class EfficientZeroPolicy(object):
                 self._collect_model.initial_inference(data, early, fetch=False)
             else:
                 early = None
-        legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_collect_env_num)]
-        roots = early.reset(legal_actions, keep_inference=True) if early is not None else self._roots(active_collect_env_num, legal_actions)
+        # efficientzero.py:595's legal lists from ONE np.nonzero over the [B, A] mask
+        mask2d = np.asarray(action_mask) != 0
+        if mask2d.ndim == 2 and mask2d.shape[0] == active_collect_env_num:
+            flat = np.nonzero(mask2d)[1].tolist()
+            ends = np.cumsum(mask2d.sum(1)).tolist()
+            legal_actions = [flat[a:b] for a, b in zip([0] + ends[:-1], ends)]
+        else:
+            mask2d = None
+            legal_actions = [np.nonzero(action_mask[j])[0].tolist() for j in range(active_collect_env_num)]
+        if early is None:
+            roots = self._roots(active_collect_env_num, legal_actions)
+        elif mask2d is not None and all(legal_actions) and mask2d.shape == (early.root_num, early._A):
+            roots = early.reset_mask(mask2d, keep_inference=True)
+        else:
+            roots = early.reset(legal_actions, keep_inference=True)
         if bool(_g(self._cfg, "collect_with_pure_policy", False)):
             # efficientzero.py:597,644-655: no search; sample from softmax(policy logits over the legal actions)
             if early is None:
@@ -152,7 +165,7 @@ class EfficientZeroPolicy(object):
                     select=(self._collect_mcts_temperature, bool(_g(eps_cfg0, "eps_greedy_exploration_in_collect", False))))
             else:
                 dist, cnt, roots_values, pred_values, logits = roots.get_search_results()
-            roots_visit_count_distributions = [dist[i, :cnt[i]].tolist() for i in range(active_collect_env_num)]
+            roots_visit_count_distributions = [r[:c] for r, c in zip(dist.tolist(), cnt.tolist())]
             policy_logits = logits.tolist()
         else:
             network_output = self._collect_model.initial_inference(data, roots)
@@ -161,15 +174,18 @@ class EfficientZeroPolicy(object):
             self._search(self._mcts_collect, roots, self._collect_model, network_output, to_play)
             roots_visit_count_distributions = roots.get_distributions()
             roots_values = roots.get_values()
-        pred_values = np.asarray(pred_values, np.float32).reshape(active_collect_env_num, 1)  # efficientzero.py:583: [B, 1]
+        pred_values = list(np.asarray(pred_values, np.float32).reshape(active_collect_env_num, 1))  # efficientzero.py:583: [B, 1]
         eps_cfg = _g(self._cfg, "eps", {}) or {}
         eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
         if self._device_select and not fused:
             dev_pos, dev_ent = roots.select_action(self._collect_mcts_temperature, deterministic=eps_greedy)
+        if self._device_select:
+            dev_pos, dev_ent = np.asarray(dev_pos).tolist(), np.asarray(dev_ent, np.float64).tolist()
+        roots_values = list(roots_values)
         for i, env_id in enumerate(ready_env_id):
             distributions, value = roots_visit_count_distributions[i], roots_values[i]
             if self._device_select:
-                idx, entropy = int(dev_pos[i]), float(dev_ent[i])
+                idx, entropy = dev_pos[i], dev_ent[i]
                 action = legal_actions[i][idx]
                 if eps_greedy and np.random.rand() < self.collect_epsilon:
                     action = np.random.choice(legal_actions[i])

@@ -88,9 +88,11 @@ def unpack_rows(rows, action_space_size, frame_shape=None, extra_words=0):
     return out
 
 
-def all_gather_rows(rows_t, async_op=False):
+def all_gather_rows(rows_t, async_op=False, counts=None):
     """rows_t: torch tensor [n, W] on this rank's device (cuda -> RCCL over xGMI, cpu -> gloo); n may differ between ranks
     (uneven env split: blocks are padded to the largest one for the collective and the padding is dropped again).
+    ``counts``: the block sizes of all ranks when the caller knows them (``[hi - lo for lo, hi in (shard_range(n_envs, r, world) ...)]``,
+    the steady state of a collector): no size exchange and no host synchronisation then; without it the sizes are all-gathered first.
     Returns [sum of n over ranks, W] in rank order.  ``async_op=True`` returns (work, finish) instead: wait on ``work``
     (or just call ``finish()``, which waits) -- the collective of step i then overlaps the search of step i + 1 on the
     engine's own stream."""
@@ -99,10 +101,14 @@ def all_gather_rows(rows_t, async_op=False):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return (None, lambda: rows_t) if async_op else rows_t
     world = dist.get_world_size()
-    n = torch.tensor([rows_t.shape[0]], dtype=torch.int64, device=rows_t.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        n = torch.tensor([rows_t.shape[0]], dtype=torch.int64, device=rows_t.device)
+        cts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(cts, n)
+        counts = [int(c.item()) for c in cts]
+    else:
+        counts = [int(c) for c in counts]
+        assert len(counts) == world and counts[dist.get_rank()] == rows_t.shape[0]
     nmax = max(counts)
     send = rows_t.contiguous()
     if send.shape[0] < nmax:

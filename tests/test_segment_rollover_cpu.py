@@ -117,6 +117,8 @@ def test_rollover_equals_the_collectors_logic_on_reference_segments(mode):
         batch.store_search_stats_rows(rows, sampled_actions=np.stack(extra) if sampled else None, improved_policy=np.stack(extra) if gumbel else None)
         batch.append(nxt, rew)
         batch.rollover(done, reset_observations=fresh)
+        for e in range(N):   # the collector's observation window, built on demand
+            assert np.array_equal(batch.window(e), np.stack(window[e]).reshape(batch.window(e).shape)), (t, e)
     assert len(pool) > 12 and len(batch.pool) == len(pool)
     segs_b, meta = batch.drain_pool()
     assert batch.pool == [] and all(m["unroll_plus_td_steps"] == UNROLL + TD for m in meta)
@@ -163,3 +165,4 @@ def test_partial_reset_keeps_the_other_envs_frames():
     b.store_search_stats_rows(rows[:1], env_ids=[2])
     b.append(f3, [0.0], env_ids=[2])
     assert np.array_equal(b.to_arrays(2)["obs_segment"][1], f3[0]) and np.array_equal(b.to_arrays(0)["obs_segment"][2], f2[0])
+    assert np.array_equal(b.window(2)[0], f3[0]) and np.array_equal(b.window(1)[0], f2[1])

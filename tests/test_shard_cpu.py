@@ -43,6 +43,9 @@ assert np.allclose(cols["child_visits"].sum(1), 1.0) and (cols["action_mask"].su
 # the asynchronous form (collective of step i overlapped with the work of step i + 1)
 work, finish = shard.all_gather_rows(rows, async_op=True)
 assert torch.equal(finish(), allrows)
+# block sizes known to the caller: no size exchange
+known = [b - a for a, b in (shard.shard_range(N, r, world) for r in range(world))]
+assert torch.equal(shard.all_gather_rows(rows, counts=known), allrows)
 # equal blocks, pre-allocated output
 eq = rows[:5].contiguous()
 buf, w = shard.all_gather_rows_equal(eq, async_op=True)
