@@ -6,7 +6,7 @@ step: algorithmic FLOP per launch / its average duration against the fp32-matrix
 kernels, whose HBM traffic is a per-cent of the peak).  Writes <out>/cfg{0,2,3,4}.json; tools/refresh_profiles.py copies them to
 profiles/rNN_cfgK.json.
 
-    python tools/config_lines.py gpurun_out/<run>          (on the GPU box)
+    python tools/config_lines.py gpurun_out/<run> [name ...]         (on the GPU box; names = a subset of the configurations)
 """
 import csv
 import glob
@@ -28,6 +28,10 @@ CONFIGS = {
                  chain_flop=CHAIN_ATARI_MZ, workload="BASELINE.json configs[2]: Atari Breakout MuZero, obs 4x96x96, 400 sims, 1024 envs, A = 4"),
     "cfg3": dict(index=3, cmd=["tools/bench_conv_configs.py", "--go", "--envs", "64", "--sims", "200", "--steps", "10", "--warmup", "2"], prof_steps="3",
                  chain_flop=CHAIN_GO, workload="BASELINE.json configs[3], one GPU's share: Go 9x9 MuZero, obs 17x9x9, A = 82, 200 sims, 64 of the 512 envs (8 GPUs)"),
+    "cfg3_256": dict(index=3, cmd=["tools/bench_conv_configs.py", "--go", "--envs", "256", "--sims", "200", "--steps", "6", "--warmup", "1"], prof_steps="2",
+                     chain_flop=CHAIN_GO, workload="BASELINE.json configs[3] on 2 GPUs instead of 8: Go 9x9 MuZero, 256 of the 512 envs on this GPU (one chain workgroup per CU)"),
+    "cfg3_all": dict(index=3, cmd=["tools/bench_conv_configs.py", "--go", "--envs", "512", "--sims", "200", "--steps", "4", "--warmup", "1"], prof_steps="1",
+                     chain_flop=CHAIN_GO, workload="BASELINE.json configs[3], all 512 envs on one GPU: Go 9x9 MuZero, obs 17x9x9, A = 82, 200 sims"),
     "cfg4": dict(index=4, cmd=["tools/bench_mlp_configs.py", "--config", "4", "--envs", "64", "--steps", "50"], prof_steps="20",
                  workload="BASELINE.json configs[4], one GPU's share: DMC cartpole-swingup Sampled EfficientZero (obs 5, action dim 1, K = 20), 50 sims, 64 of the 256 envs (4 GPUs)"),
     "cfg4_all": dict(index=4, cmd=["tools/bench_mlp_configs.py", "--config", "4", "--envs", "256", "--steps", "50"], prof_steps="20",
@@ -65,7 +69,10 @@ def main():
     out = os.path.abspath(sys.argv[1])
     os.makedirs(out, exist_ok=True)
     from lightzero_amd.build import csrc_digest
+    only = sys.argv[2:]
     for name, c in CONFIGS.items():
+        if only and name not in only:
+            continue
         try:
             line = run_tool(c["cmd"])
             table = kernel_table(c["cmd"], os.path.join(out, "prof_" + name), c["prof_steps"])
