@@ -262,3 +262,22 @@ def test_two_residual_blocks_replays_exactly():
     roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
     roots.set_tiebreak(0)
     _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
+
+
+@pytest.mark.parametrize("B,A,S,ragged", [(1, 18, 12, False), (33, 3, 20, True), (300, 18, 30, True), (17, 64, 9, True)])
+def test_odd_batches_and_action_counts_replay_exactly(B, A, S, ragged):
+    """Edge shapes of the fused EfficientZero loop (split heads, tree step in the chain launch): one root; a batch that is neither a
+    multiple of the 16-row LSTM / head tiles nor of the CU count; the full 18-action Atari set; 64 actions = one lane per action."""
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    model = _ez_model(A, seed=5)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(30 + B)).cuda().contiguous()
+    rng = np.random.default_rng(B * 131 + A)
+    legal = []
+    for _ in range(B):
+        m = rng.random(A) < 0.7 if ragged else np.ones(A, bool)
+        m[rng.integers(0, A)] = True
+        legal.append(np.nonzero(m)[0].tolist())
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
