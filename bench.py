@@ -8,8 +8,8 @@ inference -> expand/backup] on the device -> select_action + the packed env-step
 statistics, action mask, to_play, newest observation frame: the GameSegment field set, 36.9 KB per
 env-step) written by one kernel -> row headers on the host (the `_forward_collect` contract: what the
 collector needs to step its environments).  Weak scaling: every GPU owns its own 256 envs; the only
-collective is the all-gather of the rows (lightzero_amd/shard.py), issued asynchronously so that it
-overlaps the next step's search.
+collective is the all-gather of the rows (lightzero_amd/shard.py), issued asynchronously: it runs
+under the next step's representation tower and that step's search is ordered behind it (--gather-fence).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8                       # re-executes itself under torch.distributed.run
@@ -180,6 +180,10 @@ def main():
     ap.add_argument("--refresh-every", type=int, default=0,
                     help="every K steps, INSIDE the timed loop: broadcast the checkpoint's model state_dict from rank 0 (shard.broadcast_state_dict) "
                          "and re-ingest it in place (a collector's weight refresh after a learner update)")
+    ap.add_argument("--gather-fence", choices=["tower", "none"], default="tower",
+                    help="N > 1, overlapped all-gather: 'tower' (default) lets the collective of step i run under the representation tower of "
+                         "step i + 1 and makes the search wait for it -- the search's chain launch is one workgroup per CU on all 256 CUs, so a "
+                         "collective kernel holding even one CU during it costs that launch a second round; 'none' = no ordering")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region: every rank verifies the pooled rows block by block")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -200,7 +204,13 @@ def main():
     backend = "nccl" if ndev >= world else "gloo"
     device_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # LZ_FORCE_COLLECTIVE=1: run the collective code path with a single rank too (a 1-GPU box then exercises the RCCL branch --
+    # process group, asynchronous all-gather, the fence below -- that otherwise only an N > 1 node reaches); never a headline run
+    dist_on = world > 1 or bool(os.environ.get("LZ_FORCE_COLLECTIVE"))
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -212,7 +222,7 @@ def main():
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
     lib = L.lib()
     weights = efficientzero_state_dict(seed=0, action_space_size=ACTIONS)
-    if world > 1:  # the weight-refresh path: rank 0's state_dict reaches every rank through one broadcast, then an in-place re-ingest
+    if dist_on:  # the weight-refresh path: rank 0's state_dict reaches every rank through one broadcast, then an in-place re-ingest
         weights = shard.broadcast_state_dict(weights, src=0)
     NS = max(1, args.streams)
     if args.total_envs:   # strong scaling: this rank's contiguous block of the global env batch
@@ -249,12 +259,14 @@ def main():
     # double-buffered: step i's all-gather reads one.  Uneven blocks (strong scaling): every buffer has the largest block's rows, the
     # collective moves equal blocks with no size exchange (all ranks know shard_range) and the consumer strips the padding
     rows_dev = [torch.zeros(NMAX, W, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(world * NMAX, W, device="cuda") for _ in range(2)] if world > 1 and backend == "nccl" else None
+    gathered = [torch.zeros(world * NMAX, W, device="cuda") for _ in range(2)] if dist_on and backend == "nccl" else None
     gathered_host = [None, None]
     header = np.zeros((ENVS, HW), np.float32)
     logits = np.zeros((ENVS, ACTIONS), np.float32)
     timestep = np.zeros(EPS, np.int32)
     pending = [None, None]
+    fence_mode = args.gather_fence
+    eng_streams = [torch.cuda.ExternalStream(lib.lz_engine_stream(e)) for e in engs]   # the engines' HIP streams, for stream-ordering only
 
     def step(i):
         buf = i & 1
@@ -266,6 +278,11 @@ def main():
             pending[buf] = None
         for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
             L.check(lib.lz_initial_inference(r._h, obs_parts[k].data_ptr()))
+            if fence_mode == "tower" and pending[buf ^ 1] is not None:
+                # the previous step's all-gather has had the tower to itself (thousands of workgroups: a few CUs less cost it a per
+                # cent); the search -- 256 workgroups that each need a whole CU -- starts behind it
+                with torch.cuda.stream(eng_streams[k]):
+                    pending[buf ^ 1].wait()
             if args.noise == "device":   # Dirichlet(0.3) over the legal actions of every root, drawn by a kernel of this step
                 L.check(lib.lz_roots_prepare_from_inference_dirichlet(r._h, CFG["root_noise_weight"], CFG["root_dirichlet_alpha"], to_play))
             else:                        # drawn on the host INSIDE the step (one vectorised numpy call) and uploaded
@@ -279,7 +296,7 @@ def main():
             L.check(lib.lz_roots_collect_rows(r._h, 1.0, 0, (i * 1315423911 + rank * 97 + k) & (2 ** 62 - 1), None, FRAME, timestep.ctypes.data,
                                               rows_dev[buf][k * EPS:(k + 1) * EPS].data_ptr(), W, h, lg.ctypes.data))
             header[k * EPS:(k + 1) * EPS], logits[k * EPS:(k + 1) * EPS] = h, lg
-        if world > 1:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI), overlapped with the next search
+        if dist_on:  # pool the finished env-step rows of all ranks (RCCL all-gather over xGMI), overlapped with the next search
             if backend == "nccl":
                 _, work = shard.all_gather_rows_equal(rows_dev[buf], out=gathered[buf], async_op=not args.sync_gather)
                 pending[buf] = work if not args.sync_gather else None
@@ -307,18 +324,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync_all()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
     sync_all()
     my_elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     per_rank = [my_elapsed]
-    if world > 1:
+    if dist_on:
         dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -335,7 +352,7 @@ def main():
     L.check(lib.lz_roots_get_distributions(roots_l[0]._h, dist_chk, cnt_chk))
     assert (dist_chk.sum(1) == SIMS).all(), "search did not run all simulations"
     gather_check = None
-    if args.check_gather and world > 1:
+    if args.check_gather and dist_on:
         # every rank: the pooled rows of the last step, block q, must be rank q's own rows (exchanged once more, as float64 checksums
         # per row, through a plain all_gather) -- with the padding of uneven blocks stripped
         buf = (total - 1) & 1
@@ -423,10 +440,11 @@ def main():
                        "sustained_env_steps_per_s": sustained["env_steps_per_s"] if sustained else None,
                        "sustained_steps": sustained["steps"] if sustained else 0, "sustained_seconds": sustained["seconds"] if sustained else 0.0,
                        "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
-                       "parallelism": "env-shard x%d" % world, "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend if world > 1 else None,
+                       "parallelism": "env-shard x%d" % world, "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend if dist_on else None,
                        "per_rank_env_steps_per_s": [counts[q] * args.steps / t for q, t in enumerate(per_rank)],
                        "row_bytes_per_env_step": W * 4, "all_gather_bytes_per_step_per_rank": (world - 1) * NMAX * W * 4 if world > 1 else 0,
-                       "all_gather_overlapped": bool(world > 1 and backend == "nccl" and not args.sync_gather),
+                       "all_gather_overlapped": bool(dist_on and backend == "nccl" and not args.sync_gather),
+                       "all_gather_fence": fence_mode if (dist_on and backend == "nccl" and not args.sync_gather) else None,
                        "debug_knobs": knobs},
             "roofline": {"bound": "mfma", "kernel": "k_chain_w (per root: [tree step of the root: expand + backup + next selection, one wave, prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident, 3x3 convolutions by Winograd F(2x2,3x3) on v_mfma_f32_4x4x1; 1 launch/simulation; achieved = the ALGORITHMIC (direct-form) convolution FLOPs of SURVEY 8d over the whole launch -- the kernel executes 0.59x as many matrix cycles for them)",
                          "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
@@ -453,7 +471,7 @@ def main():
             except Exception as e:  # the reported baselines never take the measured line down with them
                 out["deployed_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

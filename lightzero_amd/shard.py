@@ -98,7 +98,7 @@ def all_gather_rows(rows_t, async_op=False, counts=None):
     engine's own stream."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or _single_rank(dist):
         return (None, lambda: rows_t) if async_op else rows_t
     world = dist.get_world_size()
     if counts is None:
@@ -126,12 +126,18 @@ def all_gather_rows(rows_t, async_op=False, counts=None):
     return (work, finish) if async_op else finish()
 
 
+def _single_rank(dist):
+    """a one-rank group needs no collective -- unless LZ_FORCE_COLLECTIVE=1 asks for it (tests on a 1-GPU box: the RCCL call sequence
+    of the N > 1 path with N = 1)"""
+    return dist.get_world_size() == 1 and not os.environ.get("LZ_FORCE_COLLECTIVE")
+
+
 def all_gather_rows_equal(rows_t, out=None, async_op=False):
     """The steady-state form for equal blocks (weak scaling: every GPU owns the same number of envs): no size exchange, the
     output buffer can be pre-allocated and the work handle returned for overlap."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or _single_rank(dist):
         return rows_t, None
     if out is None:
         out = torch.empty((dist.get_world_size() * rows_t.shape[0],) + tuple(rows_t.shape[1:]), dtype=rows_t.dtype, device=rows_t.device)
@@ -151,7 +157,7 @@ def broadcast_state_dict(state_dict, src=0, device=None):
         return np.ascontiguousarray(v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v), dtype=np.float32)
     shapes = [tuple(np.shape(state_dict[k])) for k in names]
     sizes = [int(np.prod(s)) if len(s) else 1 for s in shapes]
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or _single_rank(dist):
         return {k: arr(state_dict[k]) for k in names}
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"

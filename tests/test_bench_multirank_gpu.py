@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(*extra):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustain-s", "0",
+def _run(*extra, gpus="2", env_extra=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustain-s", "0",
                         "--check-gather"] + list(extra), cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -41,3 +41,15 @@ def test_two_ranks_strong_scaling_uneven_blocks():
     d = _run("--total-envs", "129")
     c = d["config"]
     assert c["envs_per_rank"] == [65, 64] and c["gather_check"] == "ok" and d["value"] > 0
+
+
+@pytest.mark.parametrize("fence", ["tower", "none"])
+def test_rccl_branch_with_one_rank(fence):
+    """The RCCL branch of the collective path on the 1-GPU box (LZ_FORCE_COLLECTIVE=1: a one-rank process group): device-side
+    asynchronous all-gather into the double-buffered pool, the search ordered behind the previous step's collective on the engine's
+    stream (--gather-fence tower), weight broadcast, the pooled rows verified."""
+    d = _run("--refresh-every", "2", "--gather-fence", fence, gpus="1", env_extra={"LZ_FORCE_COLLECTIVE": "1"})
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["collective_backend"] == "nccl" and c["rccl_ranks"] == 1
+    assert c["all_gather_overlapped"] is True and c["all_gather_fence"] == fence and c["gather_check"] == "ok"
+    assert d["value"] > 0
