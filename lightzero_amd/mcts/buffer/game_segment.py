@@ -171,25 +171,26 @@ class GameSegmentBatch(object):
         a transition) and -- when ``reset_observations`` ([n_env | n_done, *frame_shape], the first observation of the next episode)
         is given -- starts a fresh episode.  Returns the number of segments pooled."""
         before = len(self.pool)
-        done = np.zeros(self.n_env, bool) if done is None or self.ignore_done else np.asarray(done, bool)
+        done = np.zeros(self.n_env, bool) if done is None else np.asarray(done, bool)
+        flag = np.zeros(self.n_env, bool) if self.ignore_done else done   # what the pool records (muzero_collector.py:621); the episode still ends
         full = self.is_full()
         n_done = 0
         for env in np.nonzero(full | done)[0]:   # env by env, like the collector's loop: the pool keeps its order
             if full[env]:
                 if self._last[env] is not None:
-                    self._pad_and_save(env, done[env])
+                    self._pad_and_save(env, flag[env])
                 pri = self._priorities(env)
                 self._last[env] = self.to_arrays(env)
                 self._last_pri[env] = pri
                 self.reset(self._last[env]["obs_segment"][-self.stack:][None], env_ids=[env])   # = the observation window
             if done[env]:
                 if self._last[env] is not None:
-                    self._pad_and_save(env, done[env])
+                    self._pad_and_save(env, flag[env])
                 pri = self._priorities(env)
                 seg = self.to_arrays(env)
                 seg["valid_transition_count"] = min(len(seg["action_segment"]), self.L)
                 if len(seg["reward_segment"]) > 0:
-                    self.pool.append((seg, pri, bool(done[env])))
+                    self.pool.append((seg, pri, bool(flag[env])))
                 if reset_observations is not None:
                     ro = np.asarray(reset_observations, np.float32)
                     frame = ro[env] if ro.shape[0] == self.n_env else ro[n_done]

@@ -1,0 +1,171 @@
+"""The collect loop of lzero/worker/muzero_collector.py::MuZeroCollector.collect (:416-760) for a VECTORISED environment: the caller
+side of the hot path.  Per env-step the reference walks its ready envs in Python -- unpack the policy's dict, two
+``GameSegment`` calls, the observation window, is_full / done hand-over -- here a step is one ``forward_collect_rows`` (search +
+``select_action`` + packed env-step rows written by the device), one ``env.step`` over all envs, two array writes
+(``GameSegmentBatch.store_search_stats_rows`` / ``append``) and ``rollover`` for the envs whose segment filled up or whose episode
+ended.  What it returns is what the reference returns: ``[segments, [{'priorities', 'done', 'unroll_plus_td_steps'}]]``, segments in
+the order the reference's per-env loop pools them (``game_segment_to_array`` field set, as dicts).
+
+Environment protocol (``env``; no DI-engine env manager here -- the reference's ``ready_obs`` / ``step`` dictionaries keyed by env id
+become arrays over all ``env.env_num`` envs):
+    reset() -> obs                       obs = {'observation': [n, *frame_shape] newest frame, 'action_mask': [n, A], 'to_play': [n],
+                                                 'timestep': [n] (optional)}
+    step(actions [n], active [n] bool) -> (obs, reward [n], done [n], info)
+        rows of inactive envs are ignored; for a finished env ``obs`` holds the TERMINAL observation (it is appended to the segment
+        like any other, muzero_collector.py:616-620) and ``info['reset_obs']`` -- same keys as ``obs``, rows valid where ``done`` --
+        the first observation of its next episode (DI-engine's env manager resets a finished env by itself; :707-727 reads it from
+        ``ready_obs``); ``info['eval_episode_return']`` [n] is read where ``done``.
+
+Policy protocol: ``policy.forward_collect_rows(data, action_mask, rows_out, temperature=, to_play=, timestep=, frame_floats=,
+epsilon=) -> header [n, 8 + 2 A (+ extra)]`` (lightzero_amd.policy.efficientzero.EfficientZeroPolicy; rows_out may be None for a
+host-only policy).  ``data`` is the stacked observation ``[n, frame_stack_num * C, H, W]`` (``prepare_observation`` for conv models,
+or ``[n, frame_stack_num * D]`` for vector observations), kept on ``device`` across steps: only the newest frame of every env is
+uploaded per step, the stack is shifted where it lives.
+Not here: the PPO / pure-policy branches, chance labels, task ids, logging, DDP statistics."""
+import numpy as np
+
+from .. import shard
+from ..mcts.buffer.game_segment import GameSegmentBatch
+
+
+def _g(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class MuZeroVectorCollector(object):
+    def __init__(self, env, policy, policy_config, device=None, rows_on_device=True):
+        self._env, self._policy, self._cfg = env, policy, policy_config
+        self._n = int(env.env_num)
+        m = _g(policy_config, "model", {})
+        self._A = int(_g(m, "action_space_size"))
+        self._stack = int(_g(m, "frame_stack_num", 1))
+        self._L = int(_g(policy_config, "game_segment_length"))
+        self.unroll_plus_td_steps = int(_g(policy_config, "num_unroll_steps")) + int(_g(policy_config, "td_steps"))
+        self._default_n_episode = _g(policy_config, "n_episode", None)
+        self._device = device
+        self._rows_on_device = rows_on_device and device is not None
+        self.episode_info = []          # {'reward', 'step', 'visit_entropy'} per finished episode (muzero_collector.py:659-666)
+        self.total_envstep_count = 0
+        self.total_episode_count = 0
+        self.total_loop_steps = 0       # policy forwards issued (every one over all env_num envs, also while some wait for the last episodes)
+        self._batch = None
+
+    # ---- stacked observation on the device (or on the host for a host-only policy)
+    def _stack_init(self, frames):
+        st = np.repeat(frames[:, None], self._stack, 1)   # [n, stack, *frame_shape]: the first frame repeated (:479-482)
+        if self._device is None:
+            return st
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(st)).to(self._device)
+
+    def _stack_push(self, st, frames, reset_rows=None, reset_frames=None):
+        if self._device is None:
+            st = np.concatenate([st[:, 1:], frames[:, None]], 1)
+            if reset_rows is not None and len(reset_rows):
+                st[reset_rows] = np.repeat(reset_frames[:, None], self._stack, 1)
+            return st
+        import torch
+        new = torch.from_numpy(np.ascontiguousarray(frames)).to(self._device, non_blocking=True)
+        st = torch.cat([st[:, 1:], new[:, None]], 1)
+        if reset_rows is not None and len(reset_rows):
+            rf = torch.from_numpy(np.ascontiguousarray(reset_frames)).to(self._device)
+            st[torch.as_tensor(reset_rows, device=self._device)] = rf[:, None].expand(-1, self._stack, *rf.shape[1:])
+        return st
+
+    def _data(self, st):
+        n = self._n
+        if len(self._frame_shape) == 3:   # image frames [C, H, W]: stacked along the channel axis (prepare_observation, 'conv')
+            c, h, w = self._frame_shape
+            return st.reshape(n, self._stack * c, h, w)
+        return st.reshape(n, -1)
+
+    def collect(self, n_episode=None, train_iter=0, policy_kwargs=None):
+        if n_episode is None:
+            if self._default_n_episode is None:
+                raise RuntimeError("Please specify `n_episode` for collection.")
+            n_episode = self._default_n_episode
+        n = self._n
+        assert n_episode >= n, "Please ensure n_episode (%d) >= env_num (%d)." % (n_episode, n)
+        policy_kwargs = policy_kwargs or {}
+        temperature, epsilon = policy_kwargs.get("temperature", 1.0), policy_kwargs.get("epsilon", 0.0)
+        cfg, A = self._cfg, self._A
+        obs = self._env.reset()
+        frames = np.asarray(obs["observation"], np.float32)
+        self._frame_shape = tuple(frames.shape[1:])
+        F = int(np.prod(self._frame_shape))
+        sampled = bool(_g(cfg, "sampled_algo", False))
+        K = int(_g(_g(cfg, "model", {}), "num_of_sampled_actions", 0) or 0)
+        D = int(_g(_g(cfg, "model", {}), "action_space_size", 0) or 0) if sampled else 0
+        AW = K if sampled else A            # width of the row's visit-count block
+        batch = GameSegmentBatch(n, AW, self._L, self._frame_shape, frame_stack_num=self._stack,
+                                 num_unroll_steps=int(_g(cfg, "num_unroll_steps")), td_steps=int(_g(cfg, "td_steps")),
+                                 sampled_actions_shape=(K, D) if sampled else None, improved_policy=bool(_g(cfg, "gumbel_algo", False)),
+                                 use_priority=bool(_g(cfg, "use_priority", False)),
+                                 use_max_priority_for_new_data=bool(_g(cfg, "use_max_priority_for_new_data", False)),
+                                 ignore_done=bool(_g(cfg, "ignore_done", False)))
+        batch.reset(np.repeat(frames[:, None], self._stack, 1))
+        self._batch = batch
+        st = self._stack_init(frames)
+        mask = np.asarray(obs["action_mask"], np.float32).copy()
+        to_play = np.asarray(obs["to_play"]).astype(np.int64).copy()
+        timestep = np.asarray(obs.get("timestep", np.full(n, -1))).astype(np.int64).copy()
+        extra = K * D if sampled else (A if _g(cfg, "gumbel_algo", False) else 0)   # root_sampled_actions / improved_policy_probs block
+        W = shard.row_width(AW, F, extra)
+        rows_out = None
+        if self._rows_on_device:
+            import torch
+            rows_out = torch.zeros(n, W, device=self._device)
+        active = np.ones(n, bool)                       # ready_env_id (:513-516): every env starts one episode ...
+        remain_episode = n_episode - n                  # ... and a finished env starts another one while episodes remain
+        eps_steps, entropies = np.zeros(n, np.int64), np.zeros(n, np.float64)
+        collected_episode = collected_step = 0
+        while True:
+            header = self._policy.forward_collect_rows(self._data(st), mask, rows_out, temperature=temperature, to_play=to_play.tolist(),
+                                                       timestep=timestep.astype(np.int32), frame_floats=F, epsilon=epsilon)
+            header = np.asarray(header)
+            actions = header[:, shard.F_ACTION].astype(np.int64)
+            obs, reward, done, info = self._env.step(actions, active.copy())
+            done = np.asarray(done, bool) & active
+            ids = None if active.all() else np.nonzero(active)[0]
+            sel = slice(None) if ids is None else ids
+            # the decision-time fields of the rows are the mask / to_play / timestep the policy saw (muzero_collector.py:616-620)
+            batch.store_search_stats_rows(header[sel], env_ids=ids)
+            nxt = np.asarray(obs["observation"], np.float32)
+            batch.append(nxt[sel], np.asarray(reward, np.float32)[sel], env_ids=ids)
+            mask[sel] = np.asarray(obs["action_mask"], np.float32)[sel]
+            to_play[sel] = np.asarray(obs["to_play"]).astype(np.int64)[sel]
+            if "timestep" in obs:
+                timestep[sel] = np.asarray(obs["timestep"]).astype(np.int64)[sel]
+            eps_steps[sel] += 1
+            entropies[sel] += header[sel, shard.F_ENTROPY]
+            collected_step += int(active.sum())
+            self.total_loop_steps += 1
+            # ---- segment hand-over and episode ends, env by env in the reference's order (:649-735)
+            fin = np.nonzero(done)[0]
+            reset_frames = None
+            if fin.size:
+                ro = info["reset_obs"]
+                reset_frames = np.asarray(ro["observation"], np.float32)
+            batch.rollover(done, reset_observations=reset_frames)
+            st = self._stack_push(st, nxt, fin, reset_frames[fin] if fin.size else None)
+            for e in fin:
+                collected_episode += 1
+                self.episode_info.append(dict(reward=float(np.asarray(info["eval_episode_return"])[e]), step=int(eps_steps[e]),
+                                              visit_entropy=float(entropies[e] / eps_steps[e]) if eps_steps[e] else 0.0))
+                mask[e] = np.asarray(ro["action_mask"], np.float32)[e]
+                to_play[e] = int(np.asarray(ro["to_play"])[e])
+                timestep[e] = int(np.asarray(ro["timestep"])[e]) if "timestep" in ro else -1
+                eps_steps[e], entropies[e] = 0, 0.0
+                active[e] = False
+            for e in fin:   # (:513-516 of the next iteration) a finished env takes one of the remaining episodes, lowest id first
+                if remain_episode > 0:
+                    active[e] = True
+                    remain_episode -= 1
+            if collected_episode >= n_episode:
+                break
+        self.total_envstep_count += collected_step
+        self.total_episode_count += collected_episode
+        segs, meta = batch.drain_pool()
+        return [segs, meta]

@@ -49,3 +49,40 @@ for t in range(n):
     batch.append(next_frame, reward)
 dt = (time.perf_counter() - t0) / n
 print("forward_collect_rows + GameSegmentBatch (store_search_stats + append for %d envs): %.2f ms per env-step -> %.0f env-steps/s" % (B, dt * 1e3, B / dt))
+
+# the whole collect loop (lightzero_amd.worker.MuZeroVectorCollector): policy rows -> env.step -> segment bookkeeping -> rollover / pool,
+# device-resident frame stack (one 9.4 MB frame upload per step); synthetic env: frames from a pre-generated pool, episodes of ~150 steps
+from lightzero_amd.worker import MuZeroVectorCollector  # noqa: E402
+
+
+class _Env:
+    def __init__(self):
+        self.env_num, self.rng, self.k = B, np.random.default_rng(0), 0
+        self.pool = [np.random.default_rng(i).random((B, 1, 96, 96), dtype=np.float32) for i in range(4)]
+        self.mask, self.tp = np.ones((B, A), np.float32), np.full(B, -1)
+
+    def _obs(self):
+        self.k += 1
+        return dict(observation=self.pool[self.k % 4], action_mask=self.mask, to_play=self.tp)
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, actions, active):
+        done = (self.rng.random(B) < 1.0 / 150) & active
+        return self._obs(), np.zeros(B, np.float32), done, dict(reset_obs=self._obs(), eval_episode_return=np.zeros(B))
+
+
+ccfg = dict(num_simulations=50, discount_factor=0.997, lstm_horizon_len=5, game_segment_length=400, num_unroll_steps=5, td_steps=5,
+            model=dict(frame_stack_num=4, action_space_size=A))
+col = MuZeroVectorCollector(_Env(), EfficientZeroPolicy(ccfg, model), ccfg, device="cuda")
+col.collect(n_episode=B)          # warm-up: handles, graphs
+t0 = time.perf_counter()
+n0, l0 = col.total_envstep_count, col.total_loop_steps
+segs, meta = col.collect(n_episode=B + B // 2)
+dt = time.perf_counter() - t0
+steps = col.total_loop_steps - l0
+print("MuZeroVectorCollector.collect: %.2f ms per collector step of %d envs (search + frame upload + bookkeeping + rollover) -> %.0f env-steps/s while "
+      "every env is active; this call: %d loop steps, %d env-steps of active envs (like the reference's collect(n_episode) the loop runs until the "
+      "last episodes end, with the finished envs idle), %d segments pooled, %.2f s"
+      % (dt / steps * 1e3, B, B * steps / dt, steps, col.total_envstep_count - n0, len(segs), dt))
