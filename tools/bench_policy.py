@@ -86,3 +86,21 @@ print("MuZeroVectorCollector.collect: %.2f ms per collector step of %d envs (sea
       "every env is active; this call: %d loop steps, %d env-steps of active envs (like the reference's collect(n_episode) the loop runs until the "
       "last episodes end, with the finished envs idle), %d segments pooled, %.2f s"
       % (dt / steps * 1e3, B, B * steps / dt, steps, col.total_envstep_count - n0, len(segs), dt))
+
+# the reanalyze caller: batch_size 256 x (num_unroll_steps 5 + 1) = 1536 stored positions searched again, targets built
+from lightzero_amd.mcts.buffer import reanalyze as rz  # noqa: E402
+U = 5
+rng = np.random.default_rng(0)
+lens = np.full(B, 40)
+ctx = [torch.rand(B * (U + 1), 4, 1, 96, 96).numpy(), [1] * (B * (U + 1)), rng.integers(0, 30, B).tolist(), list(range(B)),
+       [[[0.0] * A for _ in range(60)] for _ in range(B)], [[0.0] * 60 for _ in range(B)], lens.tolist(),
+       [[np.ones(A, np.int8)] * 40 for _ in range(B)], [np.full(40, -1) for _ in range(B)]]
+rcfg = dict(num_unroll_steps=U, num_simulations=50, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, lstm_horizon_len=5, value_delta_max=0.01,
+            root_dirichlet_alpha=0.3, root_noise_weight=0.25, reanalyze_noise=False, action_type="fixed_action_space", model=dict(model_type="conv", action_space_size=A))
+rz.compute_target_policy_reanalyzed(ctx, model, rcfg)
+t0 = time.perf_counter()
+for _ in range(5):
+    rz.compute_target_policy_reanalyzed(ctx, model, rcfg)
+dt = (time.perf_counter() - t0) / 5
+print("compute_target_policy_reanalyzed: %d positions x 50 simulations in %.1f ms (incl. the 226 MB observation upload) -> %.0f positions/s"
+      % (B * (U + 1), dt * 1e3, B * (U + 1) / dt))
