@@ -18,11 +18,13 @@ from ... import shard
 class GameSegmentBatch(object):
     def __init__(self, n_env, action_space_size, game_segment_length, frame_shape, frame_stack_num=1, num_unroll_steps=5, td_steps=5,
                  sampled_actions_shape=None, improved_policy=False, use_priority=False, use_max_priority_for_new_data=False,
-                 ignore_done=False, extra=0):
+                 ignore_done=False, extra=0, continuous_action_space=False):
         """``sampled_actions_shape`` (K, D): Sampled EfficientZero -- the row's child visits are over the K sampled actions and every
         step also stores the root's sampled actions (game_segment.py:254-255).  ``improved_policy``: Gumbel MuZero -- every step stores
         the improved policy over the A actions (:257-258).  ``use_priority`` / ``use_max_priority_for_new_data``: muzero_collector.py:
-        308-334."""
+        308-334.  ``continuous_action_space`` (with ``sampled_actions_shape``): the row's action word is the POSITION of the chosen action
+        among the K sampled ones; what the segment stores is the action itself, a [D] vector (sampled_efficientzero.py:905-913) -- or, for a
+        discrete sampled space, its first component as an int."""
         self.n_env, self.A, self.L = int(n_env), int(action_space_size), int(game_segment_length)
         self.frame_shape, self.stack = tuple(frame_shape), int(frame_stack_num)
         self.pad = int(num_unroll_steps) + int(td_steps)
@@ -36,7 +38,9 @@ class GameSegmentBatch(object):
         self._init_obs = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)
         self._frames = []
         self._gen = np.zeros(self.n_env, np.int64)
-        self.action = np.zeros((self.n_env, cap), np.int64)
+        self.continuous = bool(continuous_action_space) and sampled_actions_shape is not None
+        self.action = (np.zeros((self.n_env, cap, int(sampled_actions_shape[1])), np.float32) if self.continuous
+                       else np.zeros((self.n_env, cap), np.int64))
         self.reward = np.zeros((self.n_env, cap), np.float32)
         self.child_visits = np.zeros((self.n_env, cap, self.A), np.float32)
         self.n_legal = np.zeros((self.n_env, cap), np.int64)
@@ -84,14 +88,19 @@ class GameSegmentBatch(object):
         self.root_value[ids, t] = rows[:, shard.F_ROOT_VALUE]
         self.predicted_value[ids, t] = rows[:, shard.F_PRED_VALUE]
         self.entropy[ids, t] = rows[:, shard.F_ENTROPY]
-        self.action[ids, t] = rows[:, shard.F_ACTION].astype(np.int64)
+        pos = rows[:, shard.F_ACTION].astype(np.int64)
+        if self.sampled_actions is None:
+            self.action[ids, t] = pos
         self.action_mask[ids, t] = rows[:, H + A:H + 2 * A]
         self.to_play[ids, t] = rows[:, shard.F_TO_PLAY].astype(np.int64)
         self.timestep[ids, t] = rows[:, shard.F_TIMESTEP].astype(np.int64)
         if self.sampled_actions is not None:
             n_extra = int(np.prod(self.sampled_shape))
             sa = sampled_actions if sampled_actions is not None else rows[:, H + 2 * A:H + 2 * A + n_extra]
-            self.sampled_actions[ids, t] = np.asarray(sa, np.float32).reshape((len(ids),) + self.sampled_shape)
+            sa = np.asarray(sa, np.float32).reshape((len(ids),) + self.sampled_shape)
+            self.sampled_actions[ids, t] = sa
+            chosen = sa[np.arange(len(sa)), pos]               # the action itself: [n, D]
+            self.action[ids, t] = chosen if self.continuous else chosen[:, 0].astype(np.int64)
         if self.improved is not None:
             ip = improved_policy if improved_policy is not None else rows[:, H + 2 * A:H + 3 * A]
             self.improved[ids, t] = np.asarray(ip, np.float32).reshape(len(ids), A)

@@ -78,5 +78,28 @@ class GumbelMuZeroPolicy(object):
         self._collect_mcts_temperature = temperature
         return self._run(self._mcts_collect, self._collect_model, data, action_mask, to_play, True, temperature, False, ready_env_id)
 
+    def forward_collect_rows(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None, epsilon=0.0):
+        """The collect forward for a vectorised collector: ``rows_out`` [n, shard.row_width(A, frame_floats, A)] in HBM receives the
+        env-step rows (extra block = improved_policy_probs [A]; the action is the arg-max of the improved policy over the legal
+        actions, gumbel_muzero.py:591-592), the header block [n, 8 + 3 A] comes back on the host."""
+        from .. import shard
+        model = self._collect_model
+        n, A = data.shape[0], model.action_space_size
+        to_play = list(to_play) if len(to_play) == n else [to_play[0]] * n
+        mask = np.asarray(action_mask)
+        legal_actions = [np.nonzero(mask[j])[0].tolist() for j in range(n)]
+        roots = self._roots(n, legal_actions)
+        model.initial_inference(data, roots, fetch=False)
+        alpha = self._mcfg["root_dirichlet_alpha"]
+        noises = [np.random.dirichlet([alpha] * len(l)).astype(np.float32).tolist() for l in legal_actions]
+        roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
+        self._mcts_collect.search(roots, model, ("hbm-pool", roots), to_play)
+        if frame_floats is None:
+            frame_floats = rows_out.shape[1] - shard.HEADER - 3 * A
+        hdr, _ = roots.collect_rows(temperature, False, rows_out.data_ptr(), rows_out.shape[1], frame_floats,
+                                    discount=self._mcfg["discount_factor"], timestep=timestep,
+                                    d_obs_ptr=data.data_ptr() if hasattr(data, "data_ptr") and getattr(data, "is_cuda", False) else None)
+        return hdr
+
     def _forward_eval(self, data, action_mask, to_play=[-1], ready_env_id=None, **kwargs):
         return self._run(self._mcts_eval, self._eval_model, data, action_mask, to_play, False, 1, True, ready_env_id)

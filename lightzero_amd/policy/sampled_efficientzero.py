@@ -111,6 +111,24 @@ class SampledEfficientZeroPolicy(object):
         roots, pred_values, policy_logits = self._run(self._mcts_collect, self._collect_model, data, to_play, True)
         return self._output(roots, pred_values, policy_logits, ready_env_id, self._collect_mcts_temperature, False)
 
+    def forward_collect_rows(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None, epsilon=0.0):
+        """The collect forward for a vectorised collector (EfficientZeroPolicy.forward_collect_rows for this family): ``rows_out``
+        [n, shard.row_width(K, frame_floats, K * D)] in HBM receives the env-step rows -- visit block and mask over the K sampled
+        actions, the extra block = root_sampled_actions [K][D], word 0 = the POSITION of the chosen action among them -- and the
+        header block [n, 8 + 2 K + K D] comes back on the host (engine model only)."""
+        from .. import shard
+        n = data.shape[0]
+        to_play = list(to_play) if len(to_play) == n else [to_play[0]] * n
+        self._collect_mcts_temperature = temperature
+        if not getattr(self._collect_model, "_is_lz_engine_model", False):
+            raise NotImplementedError("forward_collect_rows needs the engine model; any other model is served by _forward_collect")
+        roots, _, _ = self._run(self._mcts_collect, self._collect_model, data, to_play, True)
+        E = self._K * (self._A if self._continuous else 1)
+        if frame_floats is None:
+            frame_floats = rows_out.shape[1] - shard.HEADER - 2 * self._K - E
+        hdr, _ = roots.collect_rows(temperature, False, rows_out.data_ptr(), rows_out.shape[1], frame_floats, timestep=timestep)
+        return hdr
+
     def _forward_eval(self, data, action_mask=None, to_play=[-1], ready_env_id=None, **kwargs):
         n = data.shape[0]
         if ready_env_id is None:

@@ -96,15 +96,16 @@ class MuZeroVectorCollector(object):
         self._frame_shape = tuple(frames.shape[1:])
         F = int(np.prod(self._frame_shape))
         sampled = bool(_g(cfg, "sampled_algo", False))
+        continuous = sampled and bool(_g(_g(cfg, "model", {}), "continuous_action_space", False))
         K = int(_g(_g(cfg, "model", {}), "num_of_sampled_actions", 0) or 0)
-        D = int(_g(_g(cfg, "model", {}), "action_space_size", 0) or 0) if sampled else 0
+        D = (int(_g(_g(cfg, "model", {}), "action_space_size", 0) or 0) if continuous else 1) if sampled else 0
         AW = K if sampled else A            # width of the row's visit-count block
         batch = GameSegmentBatch(n, AW, self._L, self._frame_shape, frame_stack_num=self._stack,
                                  num_unroll_steps=int(_g(cfg, "num_unroll_steps")), td_steps=int(_g(cfg, "td_steps")),
                                  sampled_actions_shape=(K, D) if sampled else None, improved_policy=bool(_g(cfg, "gumbel_algo", False)),
                                  use_priority=bool(_g(cfg, "use_priority", False)),
                                  use_max_priority_for_new_data=bool(_g(cfg, "use_max_priority_for_new_data", False)),
-                                 ignore_done=bool(_g(cfg, "ignore_done", False)))
+                                 ignore_done=bool(_g(cfg, "ignore_done", False)), continuous_action_space=continuous)
         batch.reset(np.repeat(frames[:, None], self._stack, 1))
         self._batch = batch
         st = self._stack_init(frames)
@@ -126,6 +127,9 @@ class MuZeroVectorCollector(object):
                                                        timestep=timestep.astype(np.int32), frame_floats=F, epsilon=epsilon)
             header = np.asarray(header)
             actions = header[:, shard.F_ACTION].astype(np.int64)
+            if sampled:   # word 0 is the position among the K sampled actions; the action is that entry of the extra block
+                sa = header[:, shard.HEADER + 2 * AW:shard.HEADER + 2 * AW + K * D].reshape(n, K, D)[np.arange(n), actions]
+                actions = sa if continuous else sa[:, 0].astype(np.int64)
             obs, reward, done, info = self._env.step(actions, active.copy())
             done = np.asarray(done, bool) & active
             ids = None if active.all() else np.nonzero(active)[0]

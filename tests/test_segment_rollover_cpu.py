@@ -58,7 +58,7 @@ def test_rollover_equals_the_collectors_logic_on_reference_segments(mode):
         last[e], last_pri[e] = None, None
     # ---- engine side
     batch = GameSegmentBatch(N, AW, L, FRAME, frame_stack_num=STACK, num_unroll_steps=UNROLL, td_steps=TD, use_priority=use_pri,
-                             sampled_actions_shape=(K, D) if sampled else None, improved_policy=gumbel)
+                             sampled_actions_shape=(K, D) if sampled else None, improved_policy=gumbel, continuous_action_space=sampled)
     batch.reset(np.repeat(first[:, None], STACK, 1))
     for t in range(60):
         out, masks, tps, extra = {}, [], [], []
@@ -69,11 +69,16 @@ def test_rollover_equals_the_collectors_logic_on_reference_segments(mode):
                 m[rng.integers(0, AW)] = 1
             legal = np.nonzero(m)[0]
             visits = rng.integers(0, 20, size=len(legal)).tolist()
-            out[e] = dict(action=int(legal[rng.integers(0, len(legal))]), visit_count_distributions=visits,
+            ex = rng.random((K, D)).astype(np.float32) if sampled else (rng.random(A).astype(np.float32) if gumbel else None)
+            pick = int(legal[rng.integers(0, len(legal))])
+            # Sampled EfficientZero, continuous: the action IS the chosen sampled action, a [D] vector (sampled_efficientzero.py:905-907)
+            out[e] = dict(action=ex[pick].copy() if sampled else pick, visit_count_distributions=visits,
                           visit_count_distribution_entropy=float(rng.random()), searched_value=float(np.float32(rng.standard_normal())),
                           predicted_value=np.array([rng.standard_normal()], np.float32))
             masks.append(m); tps.append(int(rng.integers(1, 3)) if ragged else -1)
-            extra.append(rng.random((K, D)).astype(np.float32) if sampled else (rng.random(A).astype(np.float32) if gumbel else None))
+            extra.append(ex)
+            if sampled:
+                out[e]["root_sampled_actions"] = ex
         nxt = rng.random((N,) + FRAME).astype(np.float32)
         rew = rng.standard_normal(N).astype(np.float32)
         done = rng.random(N) < 0.07
@@ -113,8 +118,8 @@ def test_rollover_equals_the_collectors_logic_on_reference_segments(mode):
                 last[e], last_pri[e] = None, None
                 pred_l[e], search_l[e] = [], []
         # (b) rows -> vectorised batch -> rollover
-        rows = shard.pack_rows(out, masks, tps, AW, timestep=[t] * N)
-        batch.store_search_stats_rows(rows, sampled_actions=np.stack(extra) if sampled else None, improved_policy=np.stack(extra) if gumbel else None)
+        rows = shard.pack_rows(out, masks, tps, AW, timestep=[t] * N, extra_key="root_sampled_actions" if sampled else None)
+        batch.store_search_stats_rows(rows, improved_policy=np.stack(extra) if gumbel else None)   # sampled actions: from the row's extra block
         batch.append(nxt, rew)
         batch.rollover(done, reset_observations=fresh)
         for e in range(N):   # the collector's observation window, built on demand
@@ -129,7 +134,8 @@ def test_rollover_equals_the_collectors_logic_on_reference_segments(mode):
             np.testing.assert_allclose(m["priorities"], rp, rtol=1e-6, atol=0)
         assert mine["valid_transition_count"] == rs.valid_transition_count
         assert np.array_equal(mine["obs_segment"], rs.obs_segment), k
-        assert np.array_equal(mine["action_segment"], rs.action_segment), k
+        assert np.array_equal(mine["action_segment"], np.asarray(rs.action_segment)), k
+        assert mine["action_segment"].shape == np.asarray(rs.action_segment).shape
         assert np.array_equal(mine["reward_segment"], np.asarray(rs.reward_segment, np.float32)), k
         assert np.array_equal(mine["action_mask_segment"], rs.action_mask_segment) and np.array_equal(mine["to_play_segment"], rs.to_play_segment)
         assert np.array_equal(mine["timestep_segment"], rs.timestep_segment)
