@@ -34,10 +34,124 @@ def _g(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+class _Group(object):
+    """the state of one collect() call over one vectorised env: everything muzero_collector.py:470-512 initialises, as arrays"""
+
+    def __init__(self, col, env, policy, n_episode, policy_kwargs):
+        cfg = col._cfg
+        self.col, self.env, self.policy, self.n_episode = col, env, policy, int(n_episode)
+        n = self.n = int(env.env_num)
+        assert n_episode >= n, "Please ensure n_episode (%d) >= env_num (%d)." % (n_episode, n)
+        self.temperature, self.epsilon = policy_kwargs.get("temperature", 1.0), policy_kwargs.get("epsilon", 0.0)
+        A = col._A
+        obs = env.reset()
+        frames = np.asarray(obs["observation"], np.float32)
+        self.frame_shape = tuple(frames.shape[1:])
+        self.F = int(np.prod(self.frame_shape))
+        self.sampled = bool(_g(cfg, "sampled_algo", False))
+        self.continuous = self.sampled and bool(_g(_g(cfg, "model", {}), "continuous_action_space", False))
+        K = self.K = int(_g(_g(cfg, "model", {}), "num_of_sampled_actions", 0) or 0)
+        D = self.D = (int(_g(_g(cfg, "model", {}), "action_space_size", 0) or 0) if self.continuous else 1) if self.sampled else 0
+        AW = self.AW = K if self.sampled else A            # width of the row's visit-count block
+        self.batch = GameSegmentBatch(n, AW, col._L, self.frame_shape, frame_stack_num=col._stack,
+                                      num_unroll_steps=int(_g(cfg, "num_unroll_steps")), td_steps=int(_g(cfg, "td_steps")),
+                                      sampled_actions_shape=(K, D) if self.sampled else None, improved_policy=bool(_g(cfg, "gumbel_algo", False)),
+                                      use_priority=bool(_g(cfg, "use_priority", False)),
+                                      use_max_priority_for_new_data=bool(_g(cfg, "use_max_priority_for_new_data", False)),
+                                      ignore_done=bool(_g(cfg, "ignore_done", False)), continuous_action_space=self.continuous)
+        self.batch.reset(np.repeat(frames[:, None], col._stack, 1))
+        self.st = col._stack_init(frames)
+        self.mask = np.asarray(obs["action_mask"], np.float32).copy()
+        self.to_play = np.asarray(obs["to_play"]).astype(np.int64).copy()
+        self.timestep = np.asarray(obs.get("timestep", np.full(n, -1))).astype(np.int64).copy()
+        extra = K * D if self.sampled else (A if _g(cfg, "gumbel_algo", False) else 0)   # root_sampled_actions / improved_policy_probs block
+        self.rows_out = None
+        if col._rows_on_device:
+            import torch
+            self.rows_out = torch.zeros(n, shard.row_width(AW, self.F, extra), device=col._device)
+        self.active = np.ones(n, bool)                  # ready_env_id (:513-516): every env starts one episode ...
+        self.remain_episode = self.n_episode - n        # ... and a finished env starts another one while episodes remain
+        self.eps_steps, self.entropies = np.zeros(n, np.int64), np.zeros(n, np.float64)
+        self.collected_episode = self.collected_step = self.loop_steps = 0
+        self.episode_info = []
+        self.done = False
+
+    def run_policy(self):
+        """the policy forward of this step (search + select_action + rows on the device); no env or segment state is touched"""
+        c = self.col
+        if c._device is not None and self.rows_out is not None:
+            import torch
+            torch.cuda.set_device(self.rows_out.device)   # a worker thread starts on device 0: this rank's device is the rows' device
+        st = self.st
+        if len(self.frame_shape) == 3:   # image frames [C, H, W]: stacked along the channel axis (prepare_observation, 'conv')
+            ch, h, w = self.frame_shape
+            data = st.reshape(self.n, c._stack * ch, h, w)
+        else:
+            data = st.reshape(self.n, -1)
+        return np.asarray(self.policy.forward_collect_rows(data, self.mask, self.rows_out, temperature=self.temperature, to_play=self.to_play.tolist(),
+                                                           timestep=self.timestep.astype(np.int32), frame_floats=self.F, epsilon=self.epsilon))
+
+    def finish(self, header):
+        """env.step + the bookkeeping of muzero_collector.py:588-735 for this step; returns True when n_episode episodes are in"""
+        n, AW, K, D, batch, active = self.n, self.AW, self.K, self.D, self.batch, self.active
+        mask, to_play, timestep = self.mask, self.to_play, self.timestep
+        actions = header[:, shard.F_ACTION].astype(np.int64)
+        if self.sampled:   # word 0 is the position among the K sampled actions; the action is that entry of the extra block
+            sa = header[:, shard.HEADER + 2 * AW:shard.HEADER + 2 * AW + K * D].reshape(n, K, D)[np.arange(n), actions]
+            actions = sa if self.continuous else sa[:, 0].astype(np.int64)
+        obs, reward, done, info = self.env.step(actions, active.copy())
+        done = np.asarray(done, bool) & active
+        ids = None if active.all() else np.nonzero(active)[0]
+        sel = slice(None) if ids is None else ids
+        # the decision-time fields of the rows are the mask / to_play / timestep the policy saw (muzero_collector.py:616-620)
+        batch.store_search_stats_rows(header[sel], env_ids=ids)
+        nxt = np.asarray(obs["observation"], np.float32)
+        batch.append(nxt[sel], np.asarray(reward, np.float32)[sel], env_ids=ids)
+        mask[sel] = np.asarray(obs["action_mask"], np.float32)[sel]
+        to_play[sel] = np.asarray(obs["to_play"]).astype(np.int64)[sel]
+        if "timestep" in obs:
+            timestep[sel] = np.asarray(obs["timestep"]).astype(np.int64)[sel]
+        self.eps_steps[sel] += 1
+        self.entropies[sel] += header[sel, shard.F_ENTROPY]
+        self.collected_step += int(active.sum())
+        self.loop_steps += 1
+        # ---- segment hand-over and episode ends, env by env in the reference's order (:649-735)
+        fin = np.nonzero(done)[0]
+        reset_frames = None
+        if fin.size:
+            ro = info["reset_obs"]
+            reset_frames = np.asarray(ro["observation"], np.float32)
+        batch.rollover(done, reset_observations=reset_frames)
+        self.st = self.col._stack_push(self.st, nxt, fin, reset_frames[fin] if fin.size else None)
+        for e in fin:
+            self.collected_episode += 1
+            self.episode_info.append(dict(reward=float(np.asarray(info["eval_episode_return"])[e]), step=int(self.eps_steps[e]),
+                                          visit_entropy=float(self.entropies[e] / self.eps_steps[e]) if self.eps_steps[e] else 0.0))
+            mask[e] = np.asarray(ro["action_mask"], np.float32)[e]
+            to_play[e] = int(np.asarray(ro["to_play"])[e])
+            timestep[e] = int(np.asarray(ro["timestep"])[e]) if "timestep" in ro else -1
+            self.eps_steps[e], self.entropies[e] = 0, 0.0
+            active[e] = False
+        for e in fin:   # (:513-516 of the next iteration) a finished env takes one of the remaining episodes, lowest id first
+            if self.remain_episode > 0:
+                active[e] = True
+                self.remain_episode -= 1
+        self.done = self.collected_episode >= self.n_episode
+        return self.done
+
+
 class MuZeroVectorCollector(object):
     def __init__(self, env, policy, policy_config, device=None, rows_on_device=True):
-        self._env, self._policy, self._cfg = env, policy, policy_config
-        self._n = int(env.env_num)
+        """``env`` / ``policy``: one vectorised env and one policy -- or two lists of the same length (env GROUPS, one policy object per
+        group, all on the same engine model): ``collect`` then pipelines the groups -- while the device searches for one group (the
+        policy forward runs on a worker thread; the library calls release the GIL) the host steps the environments of the other and
+        does its segment bookkeeping, so the GPU goes from one group's search straight into the next one's.  Every group by itself runs
+        the loop of the single-group form (same transcript -> same pooled segments); only one forward is in flight at any time, so
+        the engine sees the same serialised call sequence."""
+        self._groups_env = list(env) if isinstance(env, (list, tuple)) else [env]
+        self._groups_policy = list(policy) if isinstance(policy, (list, tuple)) else [policy]
+        assert len(self._groups_env) == len(self._groups_policy), "one policy object per env group"
+        self._cfg = policy_config
         m = _g(policy_config, "model", {})
         self._A = int(_g(m, "action_space_size"))
         self._stack = int(_g(m, "frame_stack_num", 1))
@@ -49,8 +163,8 @@ class MuZeroVectorCollector(object):
         self.episode_info = []          # {'reward', 'step', 'visit_entropy'} per finished episode (muzero_collector.py:659-666)
         self.total_envstep_count = 0
         self.total_episode_count = 0
-        self.total_loop_steps = 0       # policy forwards issued (every one over all env_num envs, also while some wait for the last episodes)
-        self._batch = None
+        self.total_loop_steps = 0       # policy forwards issued (every one over all envs of its group, also while some wait for the last episodes)
+        self.group_results = []        # per group of the last collect(): (segments, meta, episode_info)
 
     # ---- stacked observation on the device (or on the host for a host-only policy)
     def _stack_init(self, frames):
@@ -74,102 +188,49 @@ class MuZeroVectorCollector(object):
             st[torch.as_tensor(reset_rows, device=self._device)] = rf[:, None].expand(-1, self._stack, *rf.shape[1:])
         return st
 
-    def _data(self, st):
-        n = self._n
-        if len(self._frame_shape) == 3:   # image frames [C, H, W]: stacked along the channel axis (prepare_observation, 'conv')
-            c, h, w = self._frame_shape
-            return st.reshape(n, self._stack * c, h, w)
-        return st.reshape(n, -1)
-
     def collect(self, n_episode=None, train_iter=0, policy_kwargs=None):
+        """``n_episode``: episodes to collect in total; with env groups it is split evenly (the remainder to the first groups) and every
+        group needs at least ``env_num`` of them, like the reference's single env manager (:449)."""
         if n_episode is None:
             if self._default_n_episode is None:
                 raise RuntimeError("Please specify `n_episode` for collection.")
             n_episode = self._default_n_episode
-        n = self._n
-        assert n_episode >= n, "Please ensure n_episode (%d) >= env_num (%d)." % (n_episode, n)
-        policy_kwargs = policy_kwargs or {}
-        temperature, epsilon = policy_kwargs.get("temperature", 1.0), policy_kwargs.get("epsilon", 0.0)
-        cfg, A = self._cfg, self._A
-        obs = self._env.reset()
-        frames = np.asarray(obs["observation"], np.float32)
-        self._frame_shape = tuple(frames.shape[1:])
-        F = int(np.prod(self._frame_shape))
-        sampled = bool(_g(cfg, "sampled_algo", False))
-        continuous = sampled and bool(_g(_g(cfg, "model", {}), "continuous_action_space", False))
-        K = int(_g(_g(cfg, "model", {}), "num_of_sampled_actions", 0) or 0)
-        D = (int(_g(_g(cfg, "model", {}), "action_space_size", 0) or 0) if continuous else 1) if sampled else 0
-        AW = K if sampled else A            # width of the row's visit-count block
-        batch = GameSegmentBatch(n, AW, self._L, self._frame_shape, frame_stack_num=self._stack,
-                                 num_unroll_steps=int(_g(cfg, "num_unroll_steps")), td_steps=int(_g(cfg, "td_steps")),
-                                 sampled_actions_shape=(K, D) if sampled else None, improved_policy=bool(_g(cfg, "gumbel_algo", False)),
-                                 use_priority=bool(_g(cfg, "use_priority", False)),
-                                 use_max_priority_for_new_data=bool(_g(cfg, "use_max_priority_for_new_data", False)),
-                                 ignore_done=bool(_g(cfg, "ignore_done", False)), continuous_action_space=continuous)
-        batch.reset(np.repeat(frames[:, None], self._stack, 1))
-        self._batch = batch
-        st = self._stack_init(frames)
-        mask = np.asarray(obs["action_mask"], np.float32).copy()
-        to_play = np.asarray(obs["to_play"]).astype(np.int64).copy()
-        timestep = np.asarray(obs.get("timestep", np.full(n, -1))).astype(np.int64).copy()
-        extra = K * D if sampled else (A if _g(cfg, "gumbel_algo", False) else 0)   # root_sampled_actions / improved_policy_probs block
-        W = shard.row_width(AW, F, extra)
-        rows_out = None
-        if self._rows_on_device:
-            import torch
-            rows_out = torch.zeros(n, W, device=self._device)
-        active = np.ones(n, bool)                       # ready_env_id (:513-516): every env starts one episode ...
-        remain_episode = n_episode - n                  # ... and a finished env starts another one while episodes remain
-        eps_steps, entropies = np.zeros(n, np.int64), np.zeros(n, np.float64)
-        collected_episode = collected_step = 0
-        while True:
-            header = self._policy.forward_collect_rows(self._data(st), mask, rows_out, temperature=temperature, to_play=to_play.tolist(),
-                                                       timestep=timestep.astype(np.int32), frame_floats=F, epsilon=epsilon)
-            header = np.asarray(header)
-            actions = header[:, shard.F_ACTION].astype(np.int64)
-            if sampled:   # word 0 is the position among the K sampled actions; the action is that entry of the extra block
-                sa = header[:, shard.HEADER + 2 * AW:shard.HEADER + 2 * AW + K * D].reshape(n, K, D)[np.arange(n), actions]
-                actions = sa if continuous else sa[:, 0].astype(np.int64)
-            obs, reward, done, info = self._env.step(actions, active.copy())
-            done = np.asarray(done, bool) & active
-            ids = None if active.all() else np.nonzero(active)[0]
-            sel = slice(None) if ids is None else ids
-            # the decision-time fields of the rows are the mask / to_play / timestep the policy saw (muzero_collector.py:616-620)
-            batch.store_search_stats_rows(header[sel], env_ids=ids)
-            nxt = np.asarray(obs["observation"], np.float32)
-            batch.append(nxt[sel], np.asarray(reward, np.float32)[sel], env_ids=ids)
-            mask[sel] = np.asarray(obs["action_mask"], np.float32)[sel]
-            to_play[sel] = np.asarray(obs["to_play"]).astype(np.int64)[sel]
-            if "timestep" in obs:
-                timestep[sel] = np.asarray(obs["timestep"]).astype(np.int64)[sel]
-            eps_steps[sel] += 1
-            entropies[sel] += header[sel, shard.F_ENTROPY]
-            collected_step += int(active.sum())
-            self.total_loop_steps += 1
-            # ---- segment hand-over and episode ends, env by env in the reference's order (:649-735)
-            fin = np.nonzero(done)[0]
-            reset_frames = None
-            if fin.size:
-                ro = info["reset_obs"]
-                reset_frames = np.asarray(ro["observation"], np.float32)
-            batch.rollover(done, reset_observations=reset_frames)
-            st = self._stack_push(st, nxt, fin, reset_frames[fin] if fin.size else None)
-            for e in fin:
-                collected_episode += 1
-                self.episode_info.append(dict(reward=float(np.asarray(info["eval_episode_return"])[e]), step=int(eps_steps[e]),
-                                              visit_entropy=float(entropies[e] / eps_steps[e]) if eps_steps[e] else 0.0))
-                mask[e] = np.asarray(ro["action_mask"], np.float32)[e]
-                to_play[e] = int(np.asarray(ro["to_play"])[e])
-                timestep[e] = int(np.asarray(ro["timestep"])[e]) if "timestep" in ro else -1
-                eps_steps[e], entropies[e] = 0, 0.0
-                active[e] = False
-            for e in fin:   # (:513-516 of the next iteration) a finished env takes one of the remaining episodes, lowest id first
-                if remain_episode > 0:
-                    active[e] = True
-                    remain_episode -= 1
-            if collected_episode >= n_episode:
-                break
-        self.total_envstep_count += collected_step
-        self.total_episode_count += collected_episode
-        segs, meta = batch.drain_pool()
-        return [segs, meta]
+        G = len(self._groups_env)
+        share = [n_episode // G + (1 if g < n_episode % G else 0) for g in range(G)]
+        groups = [_Group(self, e, p, k, policy_kwargs or {}) for e, p, k in zip(self._groups_env, self._groups_policy, share)]
+        if G == 1:
+            g = groups[0]
+            while not g.finish(g.run_policy()):
+                pass
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                live = list(groups)
+                cur = live[0]
+                fut = pool.submit(cur.run_policy)
+                while True:
+                    header = fut.result()
+                    others = [g for g in live if g is not cur]
+                    nxt = others[(live.index(cur)) % len(others)] if others else None   # round robin over the other live groups
+                    if nxt is not None:
+                        fut = pool.submit(nxt.run_policy)     # the device starts on the next group ...
+                    if cur.finish(header):                    # ... while this group's envs are stepped and its segments updated
+                        live.remove(cur)
+                    if nxt is None:
+                        if not live:
+                            break
+                        fut = pool.submit(cur.run_policy)     # a single group left: the plain loop
+                        nxt = cur
+                    cur = nxt
+        self.group_results = []
+        segs_all, meta_all = [], []
+        for g in groups:
+            segs, meta = g.batch.drain_pool()
+            self.group_results.append((segs, meta, g.episode_info))
+            segs_all += segs
+            meta_all += meta
+            self.episode_info += g.episode_info
+            self.total_envstep_count += g.collected_step
+            self.total_episode_count += g.collected_episode
+            self.total_loop_steps += g.loop_steps
+        return [segs_all, meta_all]

@@ -73,13 +73,58 @@ def test_collect_equals_the_reference_loop_on_reference_segments(mode, n_episode
     ref = ref_loader.load()
     if ref is None:
         pytest.skip("/root/reference not present")
-    GS = ref.game_segment.GameSegment
     ragged = use_pri = mode == "ragged_priority"
     cfg = _cfg(use_pri, mode == "ignore_done")
     seed = {"plain": 11, "ragged_priority": 12, "ignore_done": 13}[mode]
     env, pol = StubEnv(np.random.default_rng(seed), ragged), StubPolicy(np.random.default_rng(seed + 100))
     col = MuZeroVectorCollector(env, pol, cfg, device=None)
     segs_v, meta_v = col.collect(n_episode=n_episode)
+    _check_against_reference_loop(ref, mode, cfg, env, pol, n_episode, segs_v, meta_v, col.episode_info)
+    assert col.total_episode_count == len(col.episode_info) and col.total_envstep_count == sum(int(s["active"].sum()) for s in env.steps)
+
+
+@pytest.mark.parametrize("groups", [2, 3])
+def test_pipelined_env_groups_each_equal_the_reference_loop(groups):
+    """env groups: the policy forward of one group runs on a worker thread while the host steps the other group's envs; every group's
+    transcript still replays exactly through the reference loop, and the engine-facing calls never overlap"""
+    ref = ref_loader.load()
+    if ref is None:
+        pytest.skip("/root/reference not present")
+    import threading
+    cfg = _cfg(True, False)
+    envs = [StubEnv(np.random.default_rng(40 + g), True) for g in range(groups)]
+    pols = [StubPolicy(np.random.default_rng(140 + g)) for g in range(groups)]
+    in_flight, overlaps, threads = [0], [0], set()
+    lock = threading.Lock()
+    for p in pols:   # the forwards run off the main thread and one at a time
+        inner = p.forward_collect_rows
+
+        def spy(*a, _inner=inner, **kw):
+            with lock:
+                in_flight[0] += 1
+                overlaps[0] += in_flight[0] > 1
+                threads.add(threading.current_thread().name)
+            try:
+                return _inner(*a, **kw)
+            finally:
+                with lock:
+                    in_flight[0] -= 1
+        p.forward_collect_rows = spy
+    col = MuZeroVectorCollector(envs, pols, cfg, device=None)
+    n_episode = 9 * groups + 1
+    segs_v, meta_v = col.collect(n_episode=n_episode)
+    assert overlaps[0] == 0 and threading.current_thread().name not in threads
+    share = [n_episode // groups + (1 if g < n_episode % groups else 0) for g in range(groups)]
+    assert len(col.group_results) == groups and sum(len(r[0]) for r in col.group_results) == len(segs_v)
+    for g in range(groups):
+        sv, mv, info = col.group_results[g]
+        _check_against_reference_loop(ref, "ragged_priority", cfg, envs[g], pols[g], share[g], sv, mv, info)
+    assert col.total_episode_count == sum(len(r[2]) for r in col.group_results) >= n_episode
+
+
+def _check_against_reference_loop(ref, mode, cfg, env, pol, n_episode, segs_v, meta_v, episode_info_v):
+    GS = ref.game_segment.GameSegment
+    ragged = use_pri = mode == "ragged_priority"
     assert len(env.steps) == len(pol.calls) > 10
     # ---- the reference loop (muzero_collector.py:470-735) over the same transcript
     init = env.first
@@ -162,10 +207,9 @@ def test_collect_equals_the_reference_loop_on_reference_segments(mode, n_episode
         if collected >= n_episode:
             assert k == len(env.steps) - 1   # the collector stopped exactly here
             break
-    assert collected == col.total_episode_count >= n_episode
-    assert col.total_envstep_count == sum(int(s["active"].sum()) for s in env.steps)
-    assert len(col.episode_info) == len(episode_info)
-    for a, b in zip(col.episode_info, episode_info):
+    assert collected >= n_episode
+    assert len(episode_info_v) == len(episode_info) == collected
+    for a, b in zip(episode_info_v, episode_info):
         assert a["reward"] == b["reward"] and a["step"] == b["step"] and abs(a["visit_entropy"] - b["visit_entropy"]) < 1e-6
     assert len(pool) == len(segs_v) > n_episode - 1
     for k, ((rs, rp, rd), mine, m) in enumerate(zip(pool, segs_v, meta_v)):

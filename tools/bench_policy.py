@@ -87,6 +87,17 @@ print("MuZeroVectorCollector.collect: %.2f ms per collector step of %d envs (sea
       "last episodes end, with the finished envs idle), %d segments pooled, %.2f s"
       % (dt / steps * 1e3, B, B * steps / dt, steps, col.total_envstep_count - n0, len(segs), dt))
 
+# the same loop over TWO env groups of 256 envs, pipelined: the device searches for one group while the host steps the other's envs
+col2 = MuZeroVectorCollector([_Env(), _Env()], [EfficientZeroPolicy(ccfg, model), EfficientZeroPolicy(ccfg, model)], ccfg, device="cuda")
+col2.collect(n_episode=2 * B)
+t0 = time.perf_counter()
+l0 = col2.total_loop_steps
+col2.collect(n_episode=3 * B)
+dt = time.perf_counter() - t0
+steps = col2.total_loop_steps - l0
+print("MuZeroVectorCollector.collect, 2 pipelined env groups of %d envs: %.2f ms per group step -> %.0f env-steps/s while every env is active"
+      % (B, dt / steps * 1e3, B * steps / dt))
+
 # the reanalyze caller: batch_size 256 x (num_unroll_steps 5 + 1) = 1536 stored positions searched again, targets built
 from lightzero_amd.mcts.buffer import reanalyze as rz  # noqa: E402
 U = 5
