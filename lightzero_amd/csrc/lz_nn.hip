@@ -1298,7 +1298,24 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
             }
         }
         if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
-        // the epilogue's operands do not depend on the products: read them now
+        if constexpr (TS) { LZ_TS(); }
+        __syncthreads();
+        LZ_TS();
+        // ---- this wave's four points x its channel quads: NRB row blocks x 4 k per step
+        f32x4 acc[4][NRB];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[p][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // A fragments are read AD steps (of 12 short MFMAs = 96 cycles) ahead: one step does not cover the LDS latency
+        constexpr int AD = 3;
+        f32x4 af[AD + 1];
+        auto fetch_a = [&](int s, f32x4 &f) { f = *reinterpret_cast<const f32x4 *>(sV + aoff + (s / KSW) * NT * PS + (s % KSW) * 4); };
+#pragma unroll
+        for (int s = 0; s < AD; ++s) fetch_a(s, af[s]);
+        // the epilogue's operands do not depend on the products and nobody writes them before the combine step: they are requested
+        // behind the barrier and arrive under the products (in front of the barrier they were on the critical path of the waves that
+        // carry a transform item)
         const float sc = sSS[L * 128 + lane], sh = sSS[L * 128 + 64 + lane];
         const bool tab = ly.act != 0, hasres = ly.res >= 0, relu = ly.relu != 0;
         const float *sRes = smem + max(ly.res, 0) * BUF;
@@ -1314,21 +1331,6 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
 #pragma unroll
             for (int n = 0; n < NOUT; ++n) rv[n] = sRes[cpix[n]];
         }
-        if constexpr (TS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LZ_TS(); }
-        __syncthreads();
-        LZ_TS();
-        // ---- this wave's four points x its channel quads: NRB row blocks x 4 k per step
-        f32x4 acc[4][NRB];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) acc[p][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // A fragments are read AD steps (of 12 short MFMAs = 96 cycles) ahead: one step does not cover the LDS latency
-        constexpr int AD = 3;
-        f32x4 af[AD + 1];
-        auto fetch_a = [&](int s, f32x4 &f) { f = *reinterpret_cast<const f32x4 *>(sV + aoff + (s / KSW) * NT * PS + (s % KSW) * 4); };
-#pragma unroll
-        for (int s = 0; s < AD; ++s) fetch_a(s, af[s]);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const f32x4 bfr = wq[s % R];
