@@ -37,6 +37,8 @@ class GameSegmentBatch(object):
         # some envs bumps their generation and leaves every other env's frames alone.
         self._init_obs = np.zeros((self.n_env, self.stack) + self.frame_shape, np.float32)
         self._frames = []
+        self._base = 0                                   # entries dropped from the front of _frames so far
+        self._first = np.zeros(self.n_env, np.int64)     # per env: absolute index of the first entry that can belong to its current segment
         self._gen = np.zeros(self.n_env, np.int64)
         self.continuous = bool(continuous_action_space) and sampled_actions_shape is not None
         self.action = (np.zeros((self.n_env, cap, int(sampled_actions_shape[1])), np.float32) if self.continuous
@@ -69,8 +71,11 @@ class GameSegmentBatch(object):
         init = np.asarray(init_observations, np.float32).reshape((len(ids), self.stack) + self.frame_shape)
         self._init_obs[ids] = init
         self._gen[ids] += 1   # the frames appended so far belong to the previous segments of these envs -- and only of these
-        if len(self._frames) > 4 * (self.L + self.pad + 8):   # entries none of whose envs is current any more
-            self._frames = [e for e in self._frames if (e[3] == self._gen[self._ids(e[0])]).any()]
+        self._first[ids] = self._base + len(self._frames)    # the new segments' frames are appended from here on
+        drop = int(self._first.min()) - self._base            # entries in front of every env's current segment
+        if drop > 64:
+            del self._frames[:drop]
+            self._base += drop
         self.len[ids] = 0
         self._stats[ids] = 0
 
@@ -229,7 +234,7 @@ class GameSegmentBatch(object):
         obs = np.zeros((self.stack + n,) + self.frame_shape, np.float32)
         obs[:self.stack] = self._init_obs[env]
         g = self._gen[env]
-        for fi, fr, pos, gen in self._frames:
+        for fi, fr, pos, gen in self._frames[int(self._first[env]) - self._base:]:   # (older entries: previous segments of this env)
             if fi is None:
                 if gen[env] == g:
                     obs[self.stack + int(pos[env])] = fr[env]
