@@ -398,15 +398,13 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &
         }
         int new_root_visit = 0;
         float new_root_vsum = 0.0f;
+        float q = 0.0f;
         if (valid) {
             vsum = same ? vsum + my_boot : vsum + (-my_boot);
             vis += 1;
             const float value = vsum / (float)vis;
-            float q;
             if (VARIANT == LZ_TREE_EFFICIENTZERO) q = true_reward + discount * value;  // cnode.cpp:516/:558
             else q = (to_play == -1) ? true_reward + discount * value : true_reward + discount * -value;
-            mx = fmaxf(mx, q);
-            mn = fminf(mn, q);
             if (k >= 1) {
                 const float4 ne = make_float4(prior, __int_as_float(vis), vsum, own_vp);
                 v.edge[(size_t)pn * A + pa] = ne;
@@ -418,14 +416,13 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &
                 new_root_vsum = vsum;
             }
         }
+        minmax_update_ordered(q, valid, mn, mx);
         // the root is lane k0 of the chunk that contains k == 0
         if (k0 < 64) {
             sc.root_visit = rl_i(new_root_visit, k0);
             sc.root_vsum = rl_f(new_root_vsum, k0);
         }
     }
-    mx = wave_max(mx);
-    mn = wave_min(mn);
     if (lane == 0) { t.minmax[2 * b] = mn; t.minmax[2 * b + 1] = mx; }
     sc.mn = mn;
     sc.mx = mx;

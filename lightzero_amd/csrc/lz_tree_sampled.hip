@@ -349,19 +349,17 @@ __device__ __forceinline__ void dev_sbackprop(const lz_tree_dev &t, int new_node
             else if (rl_i(same, i)) bootstrap = -tre + discount * bootstrap;
             else bootstrap = tre + discount * bootstrap;
         }
+        float q = 0.0f;
         if (valid) {
             vsum = same ? vsum + my_boot : vsum + (-my_boot);
             vis += 1;
             const float value = vsum / (float)vis;
-            const float q = true_reward + discount * value;
-            mx = fmaxf(mx, q);
-            mn = fminf(mn, q);
+            q = true_reward + discount * value;
             if (k >= 1) edge_b[(size_t)pn * K + pa] = make_float4(prior, __int_as_float(vis), vsum, own_vp);
             else { t.root_visit[b] = vis; t.root_vsum[b] = vsum; }
         }
+        minmax_update_ordered(q, valid, mn, mx);
     }
-    mx = wave_max(mx);
-    mn = wave_min(mn);
     if (lane == 0) { t.minmax[2 * b] = mn; t.minmax[2 * b + 1] = mx; }
 }
 

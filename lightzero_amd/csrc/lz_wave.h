@@ -77,4 +77,22 @@ __device__ __forceinline__ float xor32_sum(float v)
 __device__ __forceinline__ float wave_max(float v) { return wave_red<true>(v); }
 __device__ __forceinline__ float wave_min(float v) { return wave_red<false>(v); }
 
+// CMinMaxStats::update (cminimax.cpp:19-26) for a whole chunk of a backup path at once, with the reference's outcome down to the SIGN OF
+// ZERO: the reference walks the path and replaces an extremum only on a strict comparison (value > maximum / value < minimum), so
+// of several equal extrema the first one in walk order stays -- visible when the equal values are +0 and -0 (all-zero networks in
+// two-player mode).  q: this lane's value (walk order = lane order), valid: the lane carries one.  mn / mx: the running statistics
+// (wave-uniform), updated in place.
+__device__ __forceinline__ void minmax_update_ordered(float q, bool valid, float &mn, float &mx)
+{
+    const float cmn = wave_min(valid ? q : __builtin_inff()), cmx = wave_max(valid ? q : -__builtin_inff());
+    if (cmn < mn) {
+        mn = cmn;
+        if (cmn == 0.0f) mn = __shfl(q, __builtin_ctzll(__ballot(valid && q == 0.0f)));   // the first zero of the walk, with its sign
+    }
+    if (cmx > mx) {
+        mx = cmx;
+        if (cmx == 0.0f) mx = __shfl(q, __builtin_ctzll(__ballot(valid && q == 0.0f)));
+    }
+}
+
 }  // namespace
