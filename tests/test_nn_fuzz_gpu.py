@@ -1,0 +1,114 @@
+"""GPU: randomised sweep of the network kernels -- model configurations the committed goldens do not hold (action counts, residual
+blocks, supports, observation sizes / board grids, channel widths, batch sizes that are not tile multiples) against the torch
+restatement evaluated here (oracle/torch_models.py, bit-equal to the reference's own modules: tests/test_torch_models_vs_reference.py),
+through the same teacher-forced checker as tests/test_nn_golden_gpu.py.
+
+Bounds: north_star's 1e-5 (3e-4 after h^-1) per tensor class -- or, on a network whose own fp32 evaluation loses more than a third of that,
+three times what torch's fp32 loses against a binary64 evaluation of the same inputs (three residual blocks unrolled three steps: the
+latent's magnitude grows with every step and so does every fp32 implementation's error; the engine may differ from torch fp32 by the sum
+of the two rounding errors).  A configuration the engine does not compile must be refused with a message, never computed wrongly."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import nn_cases
+import parity_record
+from test_nn_golden_gpu import check_case
+
+pytestmark = pytest.mark.gpu
+SUPPORTS = [(-300., 301., 1.), (-50., 51., 1.), (-10., 11., 1.), (-2., 3., 1.)]
+
+
+def _case(seed):
+    r = np.random.default_rng(4000 + seed)
+    kind = ["ez_atari", "mz_atari", "mz_board", "ez_board"][int(r.integers(0, 4))]
+    sup = SUPPORTS[int(r.integers(0, len(SUPPORTS)))]
+    kw = dict(num_res_blocks=int(r.integers(1, 4)), reward_support_range=sup, value_support_range=sup)
+    if kind.endswith("atari"):
+        hw = int(r.choice([96, 64]))
+        kw.update(observation_shape=(int(r.choice([4, 1, 3])), hw, hw), action_space_size=int(r.integers(2, 19)), downsample=True)
+    else:
+        gh, gw = [(3, 3), (6, 6), (6, 7), (9, 9), (8, 8)][int(r.integers(0, 5))]
+        kw.update(observation_shape=(int(r.integers(1, 18)), gh, gw), action_space_size=int(r.integers(2, gh * gw + 2)), downsample=False)
+        if r.random() < 0.4 and (gh, gw) != (8, 8):
+            kw["num_channels"] = int(r.choice([32, 16]))
+    if r.random() < 0.25:
+        kw["discrete_action_encoding_type"] = "not_one_hot"
+    return dict(family="ez" if kind.startswith("ez") else "mz", kw=kw, B=int(r.integers(1, 41)), seed=600 + seed)
+
+
+def _oracle_outputs(case, model, forced=None):
+    """the golden file's arrays, computed by the torch restatement (tests/golden/make_golden_nn.py does the same on the reference modules).
+    ``forced``: the arrays of an earlier (fp32) run -- every step then consumes THAT run's states, cast to this model's dtype: the binary64
+    evaluation of exactly the inputs the checker feeds the engine"""
+    from oracle import torch_models as tm
+    kw = case["kw"]
+    dt = next(model.parameters()).dtype
+    ist = tm.InverseScalarTransform(kw["value_support_range"])
+    rist = tm.InverseScalarTransform(kw["reward_support_range"])
+    ist.value_support, rist.value_support = ist.value_support.to(dt), rist.value_support.to(dt)
+    obs, actions = nn_cases.inputs(case)
+    lstm = nn_cases.has_lstm(case["family"])
+    out = {}
+    with torch.no_grad():
+        r = model.initial_inference(torch.from_numpy(obs).to(dt))
+        out["init_latent"], out["init_value_logits"] = r.latent_state.numpy(), r.value.numpy()
+        out["init_value"], out["init_policy"] = ist(r.value.clone()).reshape(-1).numpy(), r.policy_logits.numpy()
+        lat, hc = r.latent_state, (r.reward_hidden_state if lstm else None)
+        for s in range(nn_cases.STEPS):
+            a = torch.from_numpy(actions[s])
+            if forced is not None:
+                lat = torch.from_numpy(forced["s%d_in_latent" % s]).to(dt)
+                if lstm:
+                    hc = (torch.from_numpy(forced["s%d_in_h" % s]).to(dt)[None], torch.from_numpy(forced["s%d_in_c" % s]).to(dt)[None])
+            out["s%d_in_latent" % s] = lat.numpy()
+            if lstm:
+                out["s%d_in_h" % s], out["s%d_in_c" % s] = hc[0][0].numpy(), hc[1][0].numpy()
+                r = model.recurrent_inference(lat, hc, a)
+                out["s%d_h" % s], out["s%d_c" % s] = r.reward_hidden_state[0][0].numpy(), r.reward_hidden_state[1][0].numpy()
+                rew_logits, hc = r.value_prefix, r.reward_hidden_state
+            else:
+                r = model.recurrent_inference(lat, a)
+                rew_logits = r.reward
+            out["s%d_latent" % s], out["s%d_reward_logits" % s] = r.latent_state.numpy(), rew_logits.numpy()
+            out["s%d_reward" % s] = rist(rew_logits.clone()).reshape(-1).numpy()
+            out["s%d_value_logits" % s], out["s%d_value" % s] = r.value.numpy(), ist(r.value.clone()).reshape(-1).numpy()
+            out["s%d_policy" % s] = r.policy_logits.numpy()
+            lat = r.latent_state
+    return out
+
+
+def _fp32_cost(g32, g64):
+    """per tensor class: what fp32 arithmetic itself loses on this network -- torch fp32 against binary64 on the same inputs"""
+    def rel(k):
+        a, b = np.asarray(g32[k], np.float64), np.asarray(g64[k], np.float64)
+        return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+    cls = dict(latent=[0.0], policy=[0.0], scalar=[0.0], logits=[0.0], hc=[0.0])
+    for k in g32:
+        if "_in_" in k:
+            continue
+        for suffix, c in (("_latent", "latent"), ("_policy", "policy"), ("_logits", "logits"), ("_value", "scalar"), ("_reward", "scalar"),
+                          ("_h", "hc"), ("_c", "hc")):
+            if k.endswith(suffix):
+                cls[c].append(rel(k))
+                break
+    return {k: max(v) for k, v in cls.items()}
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_model_configuration_matches_the_torch_restatement(seed):
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    case = _case(seed)
+    model = tm.synthetic_init(nn_cases.oracle_class(tm, case["family"])(**case["kw"]), seed=case["seed"]).eval()
+    g32 = _oracle_outputs(case, model)
+    cost = _fp32_cost(g32, _oracle_outputs(case, copy.deepcopy(model).double(), forced=g32))
+    bounds = {k: max(parity_record.BOUNDS[k], 3.0 * cost[k]) for k in cost}
+    print("fp32 cost of this network (torch fp32 vs binary64):", cost)
+    try:
+        check_case("fuzz%02d" % seed, case, g32, model.state_dict(), record="fuzz/", bounds=bounds)
+    except (L.LzError, ValueError, NotImplementedError) as e:
+        assert len(str(e)) > 20, repr(e)
+        pytest.skip("refused by the engine: %s" % e)

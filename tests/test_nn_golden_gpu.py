@@ -45,17 +45,21 @@ def _roots_for(case, model, B):
 
 @pytest.mark.parametrize("name", sorted(nn_cases.CASES))
 def test_hip_network_matches_reference_module_outputs(name):
-    import ctypes
-    import torch
     from make_golden_nn import weights_digest
     from oracle import torch_models as tm
-    from lightzero_amd import _lib as L
-    lib = L.lib()
     case = nn_cases.CASES[name]
-    fam, kw, B = case["family"], case["kw"], case["B"]
+    fam, kw = case["family"], case["kw"]
     g = np.load(os.path.join(GOLD, "nn_%s.npz" % name))
     sd = tm.synthetic_init(nn_cases.oracle_class(tm, fam)(**kw), seed=case["seed"]).state_dict()  # the seeded weight recipe only
     assert weights_digest(sd) == bytes(g["weights_sha256"]).decode(), "seeded weights differ from the golden's"
+    check_case(name, case, g, sd)
+
+
+def check_case(name, case, g, sd, record="golden/", bounds=None):
+    """engine model with the weights ``sd`` on the seeded inputs of ``case`` against the arrays ``g`` (the golden file's layout)"""
+    from lightzero_amd import _lib as L
+    lib = L.lib()
+    fam, kw, B = case["family"], case["kw"], case["B"]
     ekw = dict(kw)
     if fam in ("mz_mlp", "ez_mlp"):
         ekw["norm_type"] = "BN"
@@ -113,4 +117,5 @@ def test_hip_network_matches_reference_module_outputs(name):
             L.check(lib.lz_roots_read_debug_logits(roots._h, 1, rl.reshape(-1)))
             worst["logits"] = max(worst["logits"], _rel(vl, g["s%d_value_logits" % s]), _rel(rl, g["s%d_reward_logits" % s]))
     print(name, "worst relative differences:", worst)
-    parity_record.check("golden/" + name, worst, extra=dict(batch=int(B), steps=int(nn_cases.STEPS)))
+    parity_record.check(record + name, worst, extra=dict(batch=int(B), steps=int(nn_cases.STEPS)), bounds=bounds)
+    return worst
