@@ -209,8 +209,8 @@ int lz_mlp_finalize(lz_engine *e)
         // the LSTM input may carry a deferred LayerNorm / activation, which only the k_lstm2 instantiations below apply
         const std::vector<DenseW> &src = M.res ? M.dyn2 : M.dyn1;
         const bool deferred = !src.empty() && src.back().ln_g;
-        const bool compiled = (M.L == 256 && M.H == 512) || (M.L == 128 && M.H == 128);
-        if (deferred && !compiled) b.err = "LayerNorm MLP models are compiled for (latent_state_dim, lstm_hidden_size) = (256, 512) and (128, 128)";
+        const bool compiled = (M.L == 256 && M.H == 512) || (M.L == 256 && M.H == 256) || (M.L == 128 && M.H == 128);
+        if (deferred && !compiled) b.err = "LayerNorm MLP models are compiled for (latent_state_dim, lstm_hidden_size) = (256, 512), (256, 256) and (128, 128)";
     }
     if (!b.err.empty()) { lz_set_error("lz_model_finalize: %s", b.err.c_str()); return LZ_ERR_STATE; }
     int w = std::max(M.L, M.H);

@@ -2568,6 +2568,8 @@ static void launch_lstm_m(const lz_lstm_args &a, hipStream_t s)
     else if (nchunk == 9) hipLaunchKernelGGL((k_lstm<9, MROWS>), grid, block, lds, s, a);
     else if (nchunk == 12) hipLaunchKernelGGL((k_lstm<12, MROWS>), grid, block, lds, s, a);  // MLP models: latent 256 + hidden 512
     else if (nchunk == 4) hipLaunchKernelGGL((k_lstm<4, MROWS>), grid, block, lds, s, a);    // latent 128 + hidden 128
+    else if (nchunk == 8) hipLaunchKernelGGL((k_lstm<8, MROWS>), grid, block, lds, s, a);    // latent 256 + hidden 256
+    else if (nchunk == 6) hipLaunchKernelGGL((k_lstm<6, MROWS>), grid, block, lds, s, a);    // 128 + 256 | 256 + 128
 }
 
 void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out)
@@ -2613,6 +2615,9 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     else if (nkb == 48 && a.KX == 256) {                                                    // 256 + 512 (MLP models)
         if (xf) hipLaunchKernelGGL((k_lstm2<48, 8>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_lstm2<48>), grid, block, lds, s, a);
+    } else if (nkb == 32 && a.KX == 256) {                                                  // 256 + 256 (the reference's LunarLander / BipedalWalker /
+        if (xf) hipLaunchKernelGGL((k_lstm2<32, 8>), grid, block, lds, s, a);               //  MuJoCo / MiniGrid EfficientZero configs)
+        else hipLaunchKernelGGL((k_lstm2<32>), grid, block, lds, s, a);
     } else if (nkb == 16 && a.KX == 128) {                                                  // 128 + 128
         if (xf) hipLaunchKernelGGL((k_lstm2<16, 4>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_lstm2<16>), grid, block, lds, s, a);

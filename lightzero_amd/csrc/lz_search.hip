@@ -63,8 +63,8 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
         LZ_REQUIRE(cfg->action_encoding != 2 || cfg->model_type == 4, "continuous actions need the SampledEfficientZeroModelMLP");
         if (cfg->model_type != 2) {
             const int nchunk = (cfg->num_channels + cfg->lstm_hidden_size) / 64;
-            LZ_REQUIRE(cfg->num_channels % 64 == 0 && cfg->lstm_hidden_size % 64 == 0 && (nchunk == 4 || nchunk == 12 || nchunk == 9 || nchunk == 13 || nchunk == 17),
-                       "compiled LSTM shapes: (latent_state_dim + lstm_hidden_size) / 64 in {4, 9, 12, 13, 17}, both multiples of 64");
+            LZ_REQUIRE(cfg->num_channels % 64 == 0 && cfg->lstm_hidden_size % 64 == 0 && (nchunk == 4 || nchunk == 6 || nchunk == 8 || nchunk == 12 || nchunk == 9 || nchunk == 13 || nchunk == 17),
+                       "compiled LSTM shapes: (latent_state_dim + lstm_hidden_size) / 64 in {4, 6, 8, 9, 12, 13, 17}, both multiples of 64");
         }
         if (int rc = replace_model(e)) return rc;
         e->model->cfg = *cfg;

@@ -37,6 +37,12 @@ CASES = {
     # BASELINE configs[0]: CartPole MuZeroModelMLP
     "mz_mlp_cartpole": dict(family="mz_mlp", kw=dict(observation_shape=4, action_space_size=2, latent_state_dim=128), B=8, seed=15),
     "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),
+    # the sizes of the reference's LunarLander / BipedalWalker / MuJoCo / MiniGrid configs: latent 256 + LSTM 256
+    # (zoo/box2d/lunarlander/config/lunarlander_disc_efficientzero_config.py, zoo/mujoco/config/mujoco_sampled_efficientzero_config.py)
+    "ez_mlp_lunarlander": dict(family="ez_mlp", kw=dict(observation_shape=8, action_space_size=4, lstm_hidden_size=256, latent_state_dim=256), B=9, seed=25),
+    "sez_mlp_mujoco": dict(family="sez_mlp", kw=dict(observation_shape=11, action_space_size=3, num_of_sampled_actions=20, continuous_action_space=True,
+                                                     lstm_hidden_size=256, latent_state_dim=256), B=7, seed=26),
+    "ez_mlp_128_256": dict(family="ez_mlp", kw=dict(observation_shape=5, action_space_size=3, lstm_hidden_size=256, latent_state_dim=128), B=6, seed=27),
     # BASELINE configs[4]: Sampled EfficientZero, continuous actions, K = 20
     "sez_mlp_cont": dict(family="sez_mlp", kw=dict(observation_shape=5, action_space_size=1, num_of_sampled_actions=20,
                                                    continuous_action_space=True), B=8, seed=17),

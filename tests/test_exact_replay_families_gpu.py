@@ -72,6 +72,24 @@ def test_efficientzero_mlp_replays_exactly(res):
     _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
 
 
+def test_lunarlander_sized_efficientzero_mlp_replays_exactly():
+    """the sizes of the reference's LunarLander / BipedalWalker / MiniGrid EfficientZero configs (latent_state_dim 256, lstm_hidden_size
+    256, zoo/box2d/lunarlander/config/lunarlander_disc_efficientzero_config.py): 256 roots x 50 simulations"""
+    from oracle import torch_models as tm
+    from lightzero_amd.model.efficientzero_model_mlp import EfficientZeroModelMLP
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    B, A, S = 256, 4, 50
+    kw = dict(observation_shape=8, action_space_size=A, lstm_hidden_size=256, latent_state_dim=256)
+    model = EfficientZeroModelMLP(**kw).load_state_dict(tm.synthetic_init(tm.EfficientZeroModelMLP(**kw), seed=9).state_dict())
+    obs = torch.randn(B, 8, generator=torch.Generator().manual_seed(4)).cuda().contiguous()
+    rng = np.random.default_rng(8)
+    legal = [list(range(A))] * B
+    noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
+
+
 # ------------------------------------------------------------------------------------------------------ Sampled EfficientZero
 def _sampled_replay(model, roots, S, draws_of, noises, to_play, continuous, A_disc=None):
     """device results + per-simulation outputs -> the C oracle with `draws_of(record)` injected at every expand"""

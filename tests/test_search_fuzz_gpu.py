@@ -1,0 +1,96 @@
+"""GPU: randomised sweep of the FUSED search loops through the exact replay gate (tests/test_exact_replay_gpu.py: the device's own
+network outputs of every simulation replayed through the oracle trees -> identical visit counts, bit-equal root values and min-max
+statistics, identical per-simulation selection records): EfficientZero Atari models (split heads, tree step in the chain launch) and
+two-player MuZero board models at random batch sizes, action counts, simulation counts, ragged legal lists, noise on / off."""
+import numpy as np
+import pytest
+import torch
+
+from test_exact_replay_gpu import _ez_model, _mz_model, _search_and_replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_efficientzero_search_replays_exactly(seed):
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    r = np.random.default_rng(1200 + seed)
+    B, A, S = int(r.integers(1, 300)), int(r.integers(2, 19)), int(r.integers(1, 70))
+    hw = int(r.choice([96, 64]))
+    kw = dict(observation_shape=(4, hw, hw))
+    if hw == 64:
+        kw.update(reward_support_range=(-50., 51., 1.), value_support_range=(-50., 51., 1.))
+    model = _ez_model(A, seed=seed, **kw)
+    obs = torch.rand(B, 4, hw, hw, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+    legal = []
+    for _ in range(B):
+        m = r.random(A) < (0.6 if seed % 2 else 1.1)
+        m[r.integers(0, A)] = True
+        legal.append(np.nonzero(m)[0].tolist())
+    noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal] if seed % 3 else None
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, float(r.choice([0.997, 0.99])), trace=bool(seed % 2))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_two_player_board_search_replays_exactly(seed):
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    r = np.random.default_rng(1300 + seed)
+    gh, gw = [(6, 6), (6, 7), (9, 9), (3, 3)][seed % 4]
+    C = int(r.integers(1, 18))
+    A = gh * gw + int(r.integers(0, 2))
+    B, S = int(r.integers(1, 90)), int(r.integers(1, 80))
+    kw = dict(observation_shape=(C, gh, gw), downsample=False, num_res_blocks=int(r.integers(1, 3)))
+    if (gh, gw) == (3, 3):
+        kw.update(num_channels=16, reward_head_hidden_channels=[8], value_head_hidden_channels=[8], policy_head_hidden_channels=[8],
+                  reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.))
+    model = _mz_model(A, seed=seed, **kw)
+    obs = (torch.rand(B, C, gh, gw, generator=torch.Generator().manual_seed(seed)) < 0.4).float().cuda().contiguous()
+    legal = []
+    for _ in range(B):
+        m = r.random(A) < 0.6
+        m[A - 1] = True
+        legal.append(np.nonzero(m)[0].tolist())
+    to_play = r.integers(1, 3, size=B).tolist()
+    noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal] if seed % 2 else None
+    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("mz", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_mlp_model_search_replays_exactly(seed):
+    """vector-observation models (MuZeroModelMLP / EfficientZeroModelMLP): random observation widths, latent widths, action counts"""
+    from oracle import torch_models as tm
+    r = np.random.default_rng(1400 + seed)
+    A, obs_dim = int(r.integers(2, 12)), int(r.integers(2, 30))
+    B, S = int(r.integers(1, 200)), int(r.integers(1, 60))
+    latent = int(r.choice([128, 256]))
+    if seed % 2:
+        from lightzero_amd.model.efficientzero_model_mlp import EfficientZeroModelMLP as M
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+        kw = dict(observation_shape=obs_dim, action_space_size=A, lstm_hidden_size=int(r.choice([128, 256])), latent_state_dim=latent,
+                  res_connection_in_dynamics=bool(r.integers(0, 2)))
+        ref, variant = tm.EfficientZeroModelMLP(**kw), "ez"
+    else:
+        from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP as M
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as tree
+        kw = dict(observation_shape=obs_dim, action_space_size=A, latent_state_dim=latent)
+        ref, variant = tm.MuZeroModelMLP(**kw), "mz"
+    from lightzero_amd import _lib as L
+    try:
+        model = M(**kw).load_state_dict(tm.synthetic_init(ref, seed=seed).state_dict())
+    except (L.LzError, ValueError, NotImplementedError) as e:
+        assert len(str(e)) > 20
+        pytest.skip("refused by the engine: %s" % e)
+    obs = torch.randn(B, obs_dim, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+    legal = []
+    for _ in range(B):
+        m = r.random(A) < 0.7
+        m[r.integers(0, A)] = True
+        legal.append(np.nonzero(m)[0].tolist())
+    noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay(variant, model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
