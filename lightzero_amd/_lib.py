@@ -144,11 +144,30 @@ def default_engine(device_index=None):
     return _engines[device_index]
 
 
+_engine_death_hooks = []   # callables(engine address): whoever parks device handles of an engine (the roots-handle cache) frees them first
+
+
+class OwnedEngine(ctypes.c_void_p):
+    """An engine created by ``new_engine``: destroyed (weights, stream, workspace back to the device) when the last Python object
+    that holds it -- the model, every Roots built on it -- is gone.  The per-device default engine is a plain pointer and lives as
+    long as the process."""
+
+    def __del__(self):
+        try:
+            if self.value:
+                for hook in _engine_death_hooks:
+                    hook(self.value)
+                lib().lz_engine_destroy(self)
+                self.value = None
+        except Exception:   # interpreter shutdown: the library may be gone already
+            pass
+
+
 def new_engine(device_index=None):
-    """a fresh engine (its own HIP stream, room for one model) on the device"""
+    """a fresh engine (its own HIP stream, room for one model) on the device; freed with its last user (OwnedEngine)"""
     if device_index is None:
         device_index = int(os.environ.get("LOCAL_RANK", "0"))
-    h = P()
+    h = OwnedEngine()
     check(lib().lz_engine_create(device_index, ctypes.byref(h)))
     return h
 

@@ -34,6 +34,16 @@ def _engine_key(engine):
     return getattr(engine, "value", engine)
 
 
+def _purge_engine(engine_value):
+    """an engine is about to be destroyed (lightzero_amd._lib.OwnedEngine): its parked roots handles go first"""
+    for key in [k for k in _HANDLE_CACHE if k and k[0] == engine_value]:
+        for h, _ in _HANDLE_CACHE.pop(key):
+            L.lib().lz_roots_destroy(h)
+
+
+L._engine_death_hooks.append(_purge_engine)
+
+
 def collect_rows_ex(roots, A_row, temperature, deterministic, d_rows_ptr, row_words, frame_floats, discount=0.997, timestep=None, seed=None,
                     policy_width=None, d_obs_ptr=None):
     """lz_roots_collect_rows_ex for any roots handle: (header [B, 8 + 2 A_row + extra] on the host, root policy logits); the extra

@@ -1,0 +1,67 @@
+"""GPU: handle lifecycle -- device memory must come back.  Roots handles of changing sizes are created, searched and dropped; models are
+re-created on fresh engines; a policy object serves changing batch sizes.  After a warm-up round the free device memory
+(hipMemGetInfo through torch) may not shrink from round to round."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_roots_and_models_release_their_device_memory():
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    A = 6
+    sd = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=1).state_dict()
+    rng = np.random.default_rng(0)
+
+    def round_(k):
+        model = EfficientZeroModel(action_space_size=A).load_state_dict(sd)
+        for B in (int(rng.integers(1, 200)), 64, int(rng.integers(1, 200))):
+            S = int(rng.integers(2, 30))
+            roots = ez_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S, engine=model.engine)
+            obs = torch.rand(B, 4, 96, 96, device="cuda")
+            model.initial_inference(obs, roots, fetch=False)
+            roots.prepare_from_inference_no_noise([-1] * B)
+            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
+            assert all(sum(d) == S for d in roots.get_distributions())
+            roots.clear()
+            del roots, obs
+        del model
+        gc.collect()
+        torch.cuda.empty_cache()
+    round_(0); round_(1)
+    base = _free()
+    lows = []
+    for k in range(2, 8):
+        round_(k)
+        lows.append(_free())
+    # no downward trend: the last rounds hold what the first measured rounds held (allocator granularity: 64 MB of slack)
+    assert min(lows[-2:]) >= base - (64 << 20), (base, lows)
+
+
+def test_policy_with_changing_batch_sizes_keeps_a_bounded_footprint():
+    from oracle import torch_models as tm
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    A = 6
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=2).state_dict())
+    pol = EfficientZeroPolicy(dict(num_simulations=8, discount_factor=0.997, lstm_horizon_len=5), model)
+    sizes = [32, 7, 32, 19, 7, 32, 19]
+    marks = []
+    for rep in range(5):
+        for B in sizes:
+            obs = torch.rand(B, 4, 96, 96, device="cuda")
+            out = pol._forward_collect(obs, action_mask=np.ones((B, A), np.float32), temperature=1.0, to_play=[-1] * B)
+            assert len(out) == B
+        marks.append(_free())
+    assert min(marks[-2:]) >= marks[1] - (64 << 20), marks   # the cached roots of the three sizes are re-armed, not re-allocated
