@@ -2549,6 +2549,7 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
     }
     if (a.gw == 8 && a.gh == 8) { hipLaunchKernelGGL((k_chain<8, 8>), dim3(a.B), dim3(256), lds_of(64, 0), s, a, no_step{}); return; }
     if (a.gw == 7 && a.gh == 6) { hipLaunchKernelGGL((k_chain<7, 6>), dim3(a.B), dim3(256), lds_of(42, 0), s, a, no_step{}); return; }
+    if (a.gw == 4 && a.gh == 4) { hipLaunchKernelGGL((k_chain<4, 4>), dim3(a.B), dim3(256), lds_of(16, 0), s, a, no_step{}); return; }   // 2048
     if (a.gw == 6 && a.gh == 6 && a.tstamp) hipLaunchKernelGGL((k_chain<6, 6, true>), dim3(a.B), dim3(256), lds_of(36, 64), s, a, no_step{});
     else if (a.gw == 6 && a.gh == 6) hipLaunchKernelGGL((k_chain<6, 6>), dim3(a.B), dim3(256), lds_of(36, 0), s, a, no_step{});
     else if (a.gw == 9 && a.gh == 9) hipLaunchKernelGGL((k_chain<9, 9>), dim3(a.B), dim3(256), lds_of(81, 0), s, a, no_step{});

@@ -89,8 +89,8 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
         LZ_REQUIRE(cfg->obs_c == 1 || cfg->obs_c == 3 || cfg->obs_c == 4 || cfg->obs_c == 12, "obs_c must be 1, 3, 4 or 12");
     } else {
         LZ_REQUIRE((cfg->obs_h == 9 && cfg->obs_w == 9) || (cfg->obs_h == 6 && cfg->obs_w == 7) || (cfg->obs_h == 6 && cfg->obs_w == 6) ||
-                       (cfg->obs_h == 3 && cfg->obs_w == 3 && cfg->num_channels != 64),
-                   "without downsample the compiled latent grids are 9x9 (Go), 6x7 (Connect4), 6x6 (gomoku) and, for the narrow models, 3x3 (tictactoe)");
+                       (cfg->obs_h == 8 && cfg->obs_w == 8 && cfg->num_channels == 64) || (cfg->obs_h == 4 && cfg->obs_w == 4 && cfg->num_channels == 64) || (cfg->obs_h == 3 && cfg->obs_w == 3 && cfg->num_channels != 64),
+                   "without downsample the compiled latent grids are 9x9 (Go), 8x8 and 4x4 (2048) with 64 channels, 6x7 (Connect4), 6x6 (gomoku) and, for the narrow models, 3x3 (tictactoe)");
         LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_c <= 64, "obs_c must be in [1, 64]");
     }
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden >= 1 && cfg->head_hidden <= 32, "head_channels must be 16 and head_hidden at most 32");
@@ -100,8 +100,8 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     if (cfg->model_type == 0) {  // the value-prefix LSTM reads [16 channels x latent pixels | hidden]: compiled K shapes
         const int gpix = cfg->downsample ? (cfg->obs_h == 64 ? 64 : 36) : cfg->obs_h * cfg->obs_w;
         const int K = cfg->head_channels * gpix + cfg->lstm_hidden_size;
-        const bool frag = K / 16 == 68 || K / 16 == 96, chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 9);
-        LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): 6x6 latent with hidden 512 | 256, 8x8 latent (64x64 observations) with hidden 512");
+        const bool frag = K / 16 == 68 || K / 16 == 96, chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 12 || K / 64 == 9);
+        LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): 6x6 latent with hidden 512 | 256, 8x8 latent with hidden 512, 4x4 latent with hidden 512");
     }
     if (int rc = replace_model(e)) return rc;
     e->model->cfg = *cfg;

@@ -37,6 +37,11 @@ CASES = {
     # BASELINE configs[0]: CartPole MuZeroModelMLP
     "mz_mlp_cartpole": dict(family="mz_mlp", kw=dict(observation_shape=4, action_space_size=2, latent_state_dim=128), B=8, seed=15),
     "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),
+    # 8x8 boards without downsample (64 channels): the 8x8 Winograd chain of the 64x64 Atari latents serves them
+    "mz_board8": dict(family="mz", kw=dict(observation_shape=(3, 8, 8), action_space_size=65, downsample=False, num_res_blocks=2), B=6, seed=28),
+    "ez_board8": dict(family="ez", kw=dict(observation_shape=(5, 8, 8), action_space_size=64, downsample=False), B=5, seed=29),
+    # 2048 (zoo/game_2048/config/muzero_2048_config.py: observation (16, 4, 4), 4 actions)
+    "mz_2048": dict(family="mz", kw=dict(observation_shape=(16, 4, 4), action_space_size=4, downsample=False), B=7, seed=30),
     # the sizes of the reference's LunarLander / BipedalWalker / MuJoCo / MiniGrid configs: latent 256 + LSTM 256
     # (zoo/box2d/lunarlander/config/lunarlander_disc_efficientzero_config.py, zoo/mujoco/config/mujoco_sampled_efficientzero_config.py)
     "ez_mlp_lunarlander": dict(family="ez_mlp", kw=dict(observation_shape=8, action_space_size=4, lstm_hidden_size=256, latent_state_dim=256), B=9, seed=25),

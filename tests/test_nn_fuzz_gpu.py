@@ -30,7 +30,7 @@ def _case(seed):
         hw = int(r.choice([96, 64]))
         kw.update(observation_shape=(int(r.choice([4, 1, 3])), hw, hw), action_space_size=int(r.integers(2, 19)), downsample=True)
     else:
-        gh, gw = [(3, 3), (6, 6), (6, 7), (9, 9), (8, 8)][int(r.integers(0, 5))]
+        gh, gw = [(3, 3), (6, 6), (6, 7), (9, 9), (8, 8), (4, 4)][int(r.integers(0, 6))]
         kw.update(observation_shape=(int(r.integers(1, 18)), gh, gw), action_space_size=int(r.integers(2, gh * gw + 2)), downsample=False)
         if r.random() < 0.4 and (gh, gw) != (8, 8):
             kw["num_channels"] = int(r.choice([32, 16]))

@@ -33,11 +33,11 @@ def test_random_efficientzero_search_replays_exactly(seed):
     _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, float(r.choice([0.997, 0.99])), trace=bool(seed % 2))
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(12))
 def test_random_two_player_board_search_replays_exactly(seed):
     from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
     r = np.random.default_rng(1300 + seed)
-    gh, gw = [(6, 6), (6, 7), (9, 9), (3, 3)][seed % 4]
+    gh, gw = [(6, 6), (6, 7), (9, 9), (3, 3), (8, 8), (4, 4)][seed % 6]
     C = int(r.integers(1, 18))
     A = gh * gw + int(r.integers(0, 2))
     B, S = int(r.integers(1, 90)), int(r.integers(1, 80))
