@@ -2612,6 +2612,14 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
         else hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
         return true;
     }
+    if (nkb == 41 && !xf) { hipLaunchKernelGGL((k_lstm2<41>), grid, block, lds, s, a); return true; }   // 16 x 9 + 512 (TicTacToe EfficientZero)
+    if ((nkb == 74 || nkb == 113) && !xf) {   // 16 x 42 + 512 (6x7 boards), 16 x 81 + 512 (9x9 boards): 16-row tiles (116 KB of LDS at 9x9)
+        const dim3 g16(a.H / 16, (a.B + 15) / 16);
+        const size_t l16 = (size_t)16 * ((size_t)nkb * 16 + 4) * 4;
+        if (nkb == 74) hipLaunchKernelGGL((k_lstm2<74, 0, 16>), g16, block, l16, s, a);
+        else hipLaunchKernelGGL((k_lstm2<113, 0, 16>), g16, block, l16, s, a);
+        return true;
+    }
     if (nkb == 68 && !xf) hipLaunchKernelGGL((k_lstm2<68>), grid, block, lds, s, a);       // 576 + 512 (EfficientZero conv)
     else if (nkb == 48 && a.KX == 256) {                                                    // 256 + 512 (MLP models)
         if (xf) hipLaunchKernelGGL((k_lstm2<48, 8>), grid, block, lds, s, a);

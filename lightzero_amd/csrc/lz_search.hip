@@ -77,7 +77,7 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->num_res_blocks >= 0 && cfg->num_res_blocks <= 3, "num_res_blocks must be 1, 2 or 3");
     if (cfg->num_channels != 64) {
         // the narrow chain (k_chain_small): the reference's small board-game models (gomoku 32 channels, tictactoe 16)
-        LZ_REQUIRE(!cfg->downsample && cfg->model_type == 1, "num_channels 32 / 16: MuZeroModel without downsample (board games)");
+        LZ_REQUIRE(!cfg->downsample && (cfg->model_type == 1 || cfg->model_type == 0), "num_channels 32 / 16: models without downsample (board games)");
         LZ_REQUIRE(lz_chain_small_supported(cfg->obs_w, cfg->obs_h, cfg->num_channels), "no narrow-chain instance for this board: 3x3, 6x6, 6x7, 9x9");
     }
     if (cfg->downsample) {
@@ -100,8 +100,8 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     if (cfg->model_type == 0) {  // the value-prefix LSTM reads [16 channels x latent pixels | hidden]: compiled K shapes
         const int gpix = cfg->downsample ? (cfg->obs_h == 64 ? 64 : 36) : cfg->obs_h * cfg->obs_w;
         const int K = cfg->head_channels * gpix + cfg->lstm_hidden_size;
-        const bool frag = K / 16 == 68 || K / 16 == 96, chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 12 || K / 64 == 9);
-        LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): 6x6 latent with hidden 512 | 256, 8x8 latent with hidden 512, 4x4 latent with hidden 512");
+        const bool frag = K % 16 == 0 && (K / 16 == 68 || K / 16 == 96 || K / 16 == 41 || K / 16 == 74 || K / 16 == 113), chunked = K % 64 == 0 && (K / 64 == 17 || K / 64 == 13 || K / 64 == 12 || K / 64 == 9);
+        LZ_REQUIRE(frag || chunked, "no LSTM kernel instance for this (latent grid, lstm_hidden_size): hidden 512 on 3x3, 4x4, 6x6, 6x7, 8x8, 9x9 latents; hidden 256 on 6x6");
     }
     if (int rc = replace_model(e)) return rc;
     e->model->cfg = *cfg;

@@ -40,6 +40,10 @@ CASES = {
     # 8x8 boards without downsample (64 channels): the 8x8 Winograd chain of the 64x64 Atari latents serves them
     "mz_board8": dict(family="mz", kw=dict(observation_shape=(3, 8, 8), action_space_size=65, downsample=False, num_res_blocks=2), B=6, seed=28),
     "ez_board8": dict(family="ez", kw=dict(observation_shape=(5, 8, 8), action_space_size=64, downsample=False), B=5, seed=29),
+    # TicTacToe EfficientZero (zoo/board_games/tictactoe/config/tictactoe_efficientzero_bot_mode_config.py): the 16-channel model with the LSTM
+    "ez_tictactoe_c16": dict(family="ez", kw=dict(observation_shape=(3, 3, 3), action_space_size=9, downsample=False, num_channels=16,
+                                                  reward_head_hidden_channels=[8], value_head_hidden_channels=[8], policy_head_hidden_channels=[8],
+                                                  reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.)), B=7, seed=31),
     # 2048 (zoo/game_2048/config/muzero_2048_config.py: observation (16, 4, 4), 4 actions)
     "mz_2048": dict(family="mz", kw=dict(observation_shape=(16, 4, 4), action_space_size=4, downsample=False), B=7, seed=30),
     # the sizes of the reference's LunarLander / BipedalWalker / MuJoCo / MiniGrid configs: latent 256 + LSTM 256

@@ -45,7 +45,8 @@ def test_random_two_player_board_search_replays_exactly(seed):
     if (gh, gw) == (3, 3):
         kw.update(num_channels=16, reward_head_hidden_channels=[8], value_head_hidden_channels=[8], policy_head_hidden_channels=[8],
                   reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.))
-    model = _mz_model(A, seed=seed, **kw)
+    ez = seed >= 6 and (gh, gw) != (3, 3)      # the second half of the seeds: EfficientZero models on the same boards
+    model = (_ez_model if ez else _mz_model)(A, seed=seed, **kw)
     obs = (torch.rand(B, C, gh, gw, generator=torch.Generator().manual_seed(seed)) < 0.4).float().cuda().contiguous()
     legal = []
     for _ in range(B):
@@ -54,9 +55,13 @@ def test_random_two_player_board_search_replays_exactly(seed):
         legal.append(np.nonzero(m)[0].tolist())
     to_play = r.integers(1, 3, size=B).tolist()
     noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal] if seed % 2 else None
-    roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    if ez:
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+    else:
+        tree = mz_tree
+    roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
     roots.set_tiebreak(0)
-    _search_and_replay("mz", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
+    _search_and_replay("ez" if ez else "mz", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -94,3 +99,25 @@ def test_random_mlp_model_search_replays_exactly(seed):
     roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
     roots.set_tiebreak(0)
     _search_and_replay(variant, model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_tictactoe_efficientzero_two_player_replays_exactly(seed):
+    """the reference's TicTacToe EfficientZero configuration (16-channel model, value-prefix LSTM on 16 x 9 + 512 inputs), two players"""
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    r = np.random.default_rng(1500 + seed)
+    A, B, S = 9, int(r.integers(1, 70)), int(r.integers(5, 60))
+    kw = dict(observation_shape=(3, 3, 3), downsample=False, num_channels=16, reward_head_hidden_channels=[8], value_head_hidden_channels=[8],
+              policy_head_hidden_channels=[8], reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.))
+    model = _ez_model(A, seed=seed, **kw)
+    obs = (torch.rand(B, 3, 3, 3, generator=torch.Generator().manual_seed(seed)) < 0.4).float().cuda().contiguous()
+    legal = []
+    for _ in range(B):
+        m = r.random(A) < 0.6
+        m[r.integers(0, A)] = True
+        legal.append(np.nonzero(m)[0].tolist())
+    to_play = r.integers(1, 3, size=B).tolist()
+    noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("ez", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
