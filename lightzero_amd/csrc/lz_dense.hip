@@ -193,6 +193,61 @@ __global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
     }
 }
 
+// The same layer for WIDE raw inputs (a representation network's first Linear on a long observation vector: MiniGrid's 2835 features,
+// zoo/minigrid/config/minigrid_*_config.py): the 16 input rows pass through LDS in chunks of 512 columns, the accumulator tile stays in
+// registers across the chunks.  No deferred input transform, no second input block (raw observations have neither).
+// grid = (ceil(B/16), ceil(N/64)), block = 256: wave w owns the 16-column tile 4 * blockIdx.y + w.
+constexpr int WCH = 512;   // input columns per chunk
+__global__ __launch_bounds__(256) void k_dense_wide(lz_dense_args a)
+{
+    __shared__ __attribute__((aligned(16))) float sX[16 * (WCH + 4)];
+    const lz_dense_job &j = a.job[0];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = blockIdx.x * 16, B = a.B, K = j.K1, Kp = (K + 15) & ~15, KB = Kp >> 4, PS = WCH + 4;
+    const int N = j.N, NT = (N + 15) >> 4, ct = blockIdx.y * 4 + wv;
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(j.wf) + (size_t)min(ct, NT - 1) * KB * 64 + lane;
+    const int n_ep = min(min(ct, NT - 1) * 16 + (lane & 15), N - 1);
+    const float bias_ep = j.bias[n_ep];
+    const float *scp = j.scale ? j.scale : j.bias, *shp = j.scale ? j.shift : j.bias;
+    const float sc_ep = scp[n_ep], sh_ep = shp[n_ep];
+    const float *sAf = sX + (lane & 15) * PS + (lane >> 4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < Kp; c0 += WCH) {
+        const int cw = min(WCH, Kp - c0);            // columns of this chunk (a multiple of 16)
+        if (c0 > 0) __syncthreads();                 // every wave is done with the previous chunk
+        {
+            const int row = tid >> 4, part = tid & 15;
+            const float *src = j.x + (size_t)min(r0 + row, B - 1) * K;
+            for (int k = part; k < cw; k += 16) sX[row * PS + k] = (c0 + k < K) ? src[c0 + k] : 0.0f;
+        }
+        __syncthreads();
+        if (ct < NT) {
+            const int kb0 = c0 >> 4, nkb = cw >> 4;
+            for (int q0 = 0; q0 < nkb; q0 += 8) {
+                f32x4 bf[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bf[q] = wp[(size_t)min(kb0 + q0 + q, KB - 1) * 64];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q0 + q < nkb) {
+                        const f32x4 af = *reinterpret_cast<const f32x4 *>(sAf + (q0 + q) * 16);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[q][i], acc, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const int n = ct * 16 + (lane & 15);
+    if (ct >= NT || n >= N) return;
+    const float sc = j.scale ? sc_ep : 1.0f, sh = j.scale ? sh_ep : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = r0 + 4 * (lane >> 4) + q;
+        if (b < B) j.out[(size_t)b * N + n] = act_fn((acc[q] + bias_ep) * sc + sh, j.act);
+    }
+}
+
 // grid = (ceil(B/4), njobs), block = 256: one wave per row
 __global__ __launch_bounds__(256) void k_rowfinal(lz_rowfinal_args a)
 {
@@ -232,6 +287,10 @@ __global__ __launch_bounds__(256) void k_rowfinal(lz_rowfinal_args a)
 
 void lz_launch_dense(const lz_dense_args &a, hipStream_t s)
 {
+    if (a.njobs == 1 && a.job[0].K1 > 640) {   // a wide raw input (lz_model_finalize admits it for the first representation layer only)
+        hipLaunchKernelGGL(k_dense_wide, dim3((a.B + 15) / 16, (a.job[0].N + 63) / 64), dim3(256), 0, s, a);
+        return;
+    }
     size_t lds = 0;
     int ncg = 1;
     for (int i = 0; i < a.njobs; ++i) {

@@ -203,8 +203,11 @@ int lz_mlp_finalize(lz_engine *e)
         else if (M.common.empty() || M.common.back().N != M.L) b.err = "fc_prediction_common shape mismatch";
     }
     for (const auto *v : {&M.rep, &M.dyn1, &M.dyn2, &M.rew, &M.common, &M.val, &M.pol})
-        for (const DenseW &dw : *v)
-            if (b.err.empty() && (dw.K > 512 || dw.N > 640)) b.err = "dense layer beyond the compiled limits (in_features <= 512, out_features <= 640)";
+        for (const DenseW &dw : *v) {
+            const bool first = v == &M.rep && &dw == &M.rep.front();   // raw observations may be wide (k_dense_wide: MiniGrid's 2835 features)
+            if (b.err.empty() && ((dw.K > 640 && !(first && dw.K <= 16384)) || dw.N > 640))
+                b.err = "dense layer beyond the compiled limits (in_features <= 640 -- the observation: <= 16384 --, out_features <= 640)";
+        }
     if (b.err.empty() && M.lstm) {
         // the LSTM input may carry a deferred LayerNorm / activation, which only the k_lstm2 instantiations below apply
         const std::vector<DenseW> &src = M.res ? M.dyn2 : M.dyn1;

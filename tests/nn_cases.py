@@ -52,6 +52,9 @@ CASES = {
     "sez_mlp_mujoco": dict(family="sez_mlp", kw=dict(observation_shape=11, action_space_size=3, num_of_sampled_actions=20, continuous_action_space=True,
                                                      lstm_hidden_size=256, latent_state_dim=256), B=7, seed=26),
     "ez_mlp_128_256": dict(family="ez_mlp", kw=dict(observation_shape=5, action_space_size=3, lstm_hidden_size=256, latent_state_dim=128), B=6, seed=27),
+    # MiniGrid (zoo/minigrid/config/minigrid_muzero_config.py / minigrid_efficientzero_config.py): 2835 observation features
+    "mz_mlp_minigrid": dict(family="mz_mlp", kw=dict(observation_shape=2835, action_space_size=7, latent_state_dim=512), B=6, seed=32),
+    "ez_mlp_minigrid": dict(family="ez_mlp", kw=dict(observation_shape=2835, action_space_size=7, lstm_hidden_size=256, latent_state_dim=256), B=5, seed=33),
     # BASELINE configs[4]: Sampled EfficientZero, continuous actions, K = 20
     "sez_mlp_cont": dict(family="sez_mlp", kw=dict(observation_shape=5, action_space_size=1, num_of_sampled_actions=20,
                                                    continuous_action_space=True), B=8, seed=17),

@@ -121,3 +121,29 @@ def test_tictactoe_efficientzero_two_player_replays_exactly(seed):
     roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
     roots.set_tiebreak(0)
     _search_and_replay("ez", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
+
+
+@pytest.mark.parametrize("family", ["mz", "ez"])
+def test_minigrid_sized_models_replay_exactly(family):
+    """the reference's MiniGrid configurations: 2835 observation features (the wide first layer, k_dense_wide), 7 actions; MuZero with
+    latent 512, EfficientZero with latent 256 + LSTM 256"""
+    from oracle import torch_models as tm
+    B, A, S, OBS = 64, 7, 30, 2835
+    if family == "mz":
+        from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP as M
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as tree
+        kw = dict(observation_shape=OBS, action_space_size=A, latent_state_dim=512)
+        ref = tm.MuZeroModelMLP(**kw)
+    else:
+        from lightzero_amd.model.efficientzero_model_mlp import EfficientZeroModelMLP as M
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+        kw = dict(observation_shape=OBS, action_space_size=A, lstm_hidden_size=256, latent_state_dim=256)
+        ref = tm.EfficientZeroModelMLP(**kw)
+    model = M(**kw).load_state_dict(tm.synthetic_init(ref, seed=3).state_dict())
+    obs = torch.randn(B, OBS, generator=torch.Generator().manual_seed(9)).cuda().contiguous()
+    r = np.random.default_rng(2)
+    legal = [list(range(A))] * B
+    noises = [r.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay(family, model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
