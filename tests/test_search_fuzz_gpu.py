@@ -147,3 +147,88 @@ def test_minigrid_sized_models_replay_exactly(family):
     roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
     roots.set_tiebreak(0)
     _search_and_replay(family, model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sampled_efficientzero_search_replays_exactly(seed):
+    """Sampled EfficientZero fused loop, device-side draws (the production path) read back per node and injected into the oracle:
+    continuous (D = 1..3) and discrete (K of A without replacement) action spaces, random K, batch, simulations, observation width"""
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    from test_exact_replay_families_gpu import _sampled_replay, _sez_model
+    r = np.random.default_rng(1600 + seed)
+    continuous = bool(seed % 2)
+    B, S, obs_dim = int(r.integers(1, 150)), int(r.integers(2, 60)), int(r.integers(2, 24))
+    if continuous:
+        D, K = int(r.integers(1, 4)), int(r.integers(2, 24))
+        A = D
+    else:
+        A = int(r.integers(3, 14))
+        D, K = 1, int(r.integers(2, A + 1))
+    model = _sez_model(continuous, A, K, obs_dim, seed=50 + seed)
+    cfg = dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5,
+               root_noise_weight=0.25, model=dict(action_space_size=A, num_of_sampled_actions=K, continuous_action_space=continuous))
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    legal = [[-1] * K] * B if continuous else [list(range(A))] * B
+    roots = mcts.roots(B, legal, A, K, continuous, max_simulations=S)
+    roots.set_tiebreak(0, seed=77 + seed)
+    obs = torch.randn(B, obs_dim, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+    noises = r.dirichlet([0.3] * K, size=B).astype(np.float32)
+    out = model.initial_inference(obs, roots)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    node_actions = [roots.get_node_actions(e) for e in range(S + 1)]
+    _sampled_replay(model, roots, S, lambda e: node_actions[e], noises, [-1] * B, continuous, A_disc=A)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_gumbel_search_replays_exactly(seed):
+    """lz_gsearch (Gumbel MuZero) on conv and vector-observation MuZero models: random action counts, considered-action counts m,
+    simulation budgets, ragged legal masks, noise on / off -- records, visit counts, root values, improved policies, completed Q-values"""
+    import gumbel_driver as gd
+    from oracle import ctree as octree, torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.tree_search.mcts_ctree import GumbelMuZeroMCTSCtree
+    from test_exact_replay_families_gpu import _sims
+    r = np.random.default_rng(1700 + seed)
+    B, S = int(r.integers(1, 100)), int(r.integers(1, 64))
+    if seed % 2:
+        from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP
+        A, obs_dim = int(r.integers(2, 20)), int(r.integers(2, 30))
+        kw = dict(observation_shape=obs_dim, action_space_size=A, latent_state_dim=int(r.choice([128, 256])))
+        model = MuZeroModelMLP(**kw).load_state_dict(tm.synthetic_init(tm.MuZeroModelMLP(**kw), seed=seed).state_dict())
+        obs = torch.randn(B, obs_dim, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+    else:
+        from lightzero_amd.model.muzero_model import MuZeroModel
+        A = int(r.integers(2, 19))
+        model = MuZeroModel(action_space_size=A).load_state_dict(tm.synthetic_init(tm.MuZeroModel(action_space_size=A), seed=seed).state_dict())
+        obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+    m = int(r.integers(1, min(A, 16) + 1))
+    mcts = GumbelMuZeroMCTSCtree(dict(num_simulations=S, discount_factor=0.997, max_num_considered_actions=m, value_delta_max=0.01, root_noise_weight=0.25))
+    legal = []
+    for _ in range(B):
+        k = r.random(A) < 0.7
+        k[r.integers(0, A)] = True
+        legal.append(np.nonzero(k)[0].tolist())
+    noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal] if seed % 3 else None
+    roots = mcts.roots(B, legal, action_space_size=A, max_simulations=S)
+    out = model.initial_inference(obs, roots)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    if noises is not None:
+        roots.prepare_from_inference(0.25, noises, [-1] * B)
+    else:
+        roots.prepare_from_inference_no_noise([-1] * B)
+    mcts.search(roots, model, out.latent_state, [-1] * B)
+    pred = np.zeros(B, np.float32); pol0 = np.zeros((B, A), np.float32)
+    L.check(L.lib().lz_roots_get_root_outputs(roots._h, pred, pol0.reshape(-1)))
+    sims = _sims(roots, S, B, A)
+    c = dict(B=B, A=A, S=S, m=m, discount=0.997, delta=0.01, noise_w=0.25, legal_list=legal, root_logits=pol0, root_reward=np.zeros(B, np.float32),
+             root_value=pred, noises=noises, sims=[dict(r=x["vp"], v=x["v"], logits=x["logits"]) for x in sims])
+    o = gd.run_tree(octree.gmz_tree, c, roots_kwargs=dict(action_space_size=A, max_simulations=S))
+    dist = np.full((B, A), -1, np.int32)
+    for i, d in enumerate(roots.get_distributions()):
+        dist[i, :len(d)] = d
+    assert (o["distributions"] == dist).all(), "visit counts differ"
+    for k, got in (("values", roots.get_values()), ("policies", roots.get_policies(0.997, A)), ("children_values", roots.get_children_values(0.997, A))):
+        assert np.array_equal(o[k].view(np.uint32), np.asarray(got, np.float32).view(np.uint32)), "%s not bit-equal" % k
