@@ -232,3 +232,37 @@ def test_random_gumbel_search_replays_exactly(seed):
     assert (o["distributions"] == dist).all(), "visit counts differ"
     for k, got in (("values", roots.get_values()), ("policies", roots.get_policies(0.997, A)), ("children_values", roots.get_children_values(0.997, A))):
         assert np.array_equal(o[k].view(np.uint32), np.asarray(got, np.float32).view(np.uint32)), "%s not bit-equal" % k
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_rezero_search_with_reuse_replays_exactly(seed):
+    """lz_search_with_reuse (ReZero): EfficientZero Atari models and two-player MuZero board models, random shapes, ragged legal lists,
+    random true actions / reuse values (roots that select their true action skip the network for that simulation)"""
+    from lightzero_amd.mcts.tree_search.mcts_ctree import EfficientZeroMCTSCtree, MuZeroMCTSCtree
+    from test_exact_replay_families_gpu import _reuse_replay
+    r = np.random.default_rng(1800 + seed)
+    B, S = int(r.integers(1, 120)), int(r.integers(2, 60))
+    if seed % 2:
+        gh, gw = [(6, 6), (6, 7), (9, 9), (8, 8)][(seed // 2) % 4]
+        C, A = int(r.integers(1, 18)), gh * gw + 1
+        model = _mz_model(A, seed=seed, observation_shape=(C, gh, gw), downsample=False)
+        mcts = MuZeroMCTSCtree(dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=1.0, value_delta_max=0.01, env_type="board_games"))
+        obs = (torch.rand(B, C, gh, gw, generator=torch.Generator().manual_seed(seed)) < 0.3).float().cuda().contiguous()
+        to_play, variant, disc = r.integers(1, 3, size=B).tolist(), "mz", 1.0
+    else:
+        A = int(r.integers(2, 19))
+        model = _ez_model(A, seed=seed)
+        mcts = EfficientZeroMCTSCtree(dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5))
+        obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+        to_play, variant, disc = [-1] * B, "ez", 0.997
+    legal = []
+    for _ in range(B):
+        k = r.random(A) < 0.7
+        k[A - 1] = True
+        legal.append(np.nonzero(k)[0].tolist())
+    noises = [r.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    roots = mcts.roots(B, legal, action_space_size=A, max_simulations=S)
+    roots.set_tiebreak(0)
+    true_action = [int(l[r.integers(0, len(l))]) for l in legal]
+    reuse_value = r.standard_normal(B).astype(np.float32).tolist()
+    _reuse_replay(variant, model, roots, mcts, obs, legal, to_play, noises, S, disc, true_action, reuse_value)
