@@ -38,7 +38,7 @@ FLOP_CHAIN = 2 * 36 * 64 * (70 + 4 * 64) * 9 + 2 * 36 * 64 * 48  # dyn conv 70->
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
-MANIFEST = "r03_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
+MANIFEST = "r04_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
 
 
 def _profile_manifest():
@@ -81,6 +81,27 @@ def _baseline_pipeline(weights, device):
     return run, kind_tree
 
 
+def host_cores():
+    """(physical cores, hardware threads) of the host: distinct (physical id, core id) pairs of /proc/cpuinfo"""
+    threads = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        return (len(pairs) or threads), threads
+    except Exception:
+        return threads, threads
+
+
 def cpu_baseline(weights, obs_cpu, noises, budget_s=30.0):
     """The reference pipeline on the host cores: reference ctree (compiled from its own sources when oracle/_ref is present,
     else the C restatement) + restated Python driver + torch fp32 model.  METHOD: the torch thread count is swept over
@@ -112,9 +133,12 @@ def cpu_baseline(weights, obs_cpu, noises, budget_s=30.0):
         used += times[-1]
     torch.set_num_threads(allc)
     med = float(np.median(times))
-    return dict(value=ENVS / med, unit="env-steps/s", cores=best, kind="port",
+    phys, thr = host_cores()
+    return dict(value=ENVS / med, unit="env-steps/s", cores=best, host_cores=phys, host_threads=thr, kind="port",
                 thread_sweep_env_steps_per_s={str(k): round(v, 1) for k, v in sweep.items()},
                 batches=len(times), batch_s_min_median_max=[min(times), med, max(times)],
+                cores_note="cores = the torch intra-op thread count that won the sweep (the tree and the Python driver are one thread); "
+                           "host_cores / host_threads = physical cores / hardware threads of this host",
                 sample="%d full env-step batches (256 envs x 50 sims) at the best of a torch-thread sweep %s (64-env sub-batch each); "
                        "%s + restated EfficientZeroMCTSCtree.search driver + torch fp32 model; median batch time; %.1f s" %
                        (len(times), cands, kind_tree, used))
@@ -410,7 +434,38 @@ def main():
     L.check(lib.lz_profile_read(eng, ctypes.byref(n_launch), ctypes.byref(tot_ms)))
     L.check(lib.lz_profile_enable(eng, 0))
 
-    # The committed rocprofv3 summary (profiles/r03_manifest.json) is used only when it was measured on the kernel sources this run is
+    # THIS run's clock for the roofline kernel, on the benchmarked (graph-replayed) launch sequence: the first workgroup of every
+    # chain and LSTM launch stores its s_memrealtime start, the last one its end (100 MHz constant-rate counter; lz_roots_enable_stamps;
+    # the search graph is re-captured with the stamp pointers, nothing else changes).  A launch's cost in the stream is the time from
+    # its first workgroup's start to the NEXT launch's first start (execution + drain + dispatch of the successor): that period is
+    # what `frac` divides by; first workgroup's start -> last workgroup's end of the launch itself is reported beside it.
+    stamp = None
+    try:
+        r0 = roots_l[0]
+        L.check(lib.lz_roots_enable_stamps(r0._h, 1))
+        for i in range(2):
+            step(args.warmup + i)
+        per, exe, lper, lexe, sims = [], [], [], [], []
+        st = np.zeros((SIMS, 4), np.uint64)
+        for i in range(max(prof_steps, 5)):
+            step(args.warmup + i)
+            drain()
+            L.check(lib.lz_engine_synchronize(eng))
+            L.check(lib.lz_roots_read_stamps(r0._h, SIMS, st))
+            t = st.astype(np.int64) * 10e-3   # microseconds
+            # simulations 1 .. S-2: the fused launch (tree step + split-head finish + chain) followed by an LSTM launch and another chain
+            per.append(t[1:SIMS - 1, 2] - t[1:SIMS - 1, 0]); exe.append(t[1:SIMS - 1, 1] - t[1:SIMS - 1, 0])
+            lper.append(t[2:SIMS, 0] - t[1:SIMS - 1, 2]); lexe.append(t[1:SIMS - 1, 3] - t[1:SIMS - 1, 2])
+            sims.append(t[SIMS - 1, 3] - t[0, 0])
+        L.check(lib.lz_roots_enable_stamps(r0._h, 0))
+        per, exe, lper, lexe = (np.concatenate(x) for x in (per, exe, lper, lexe))
+        stamp = dict(chain_period_us=float(per.mean()), chain_exec_us=float(exe.mean()), lstm_period_us=float(lper.mean()), lstm_exec_us=float(lexe.mean()),
+                     chain_period_us_min_max=[float(per.min()), float(per.max())], launches=int(per.size),
+                     search_us=float(np.mean(sims)), per_simulation_us=float((per.mean() + lper.mean())))
+    except Exception as e:   # (an older library without the stamp entry points: the HIP-event pass below still gives a clock)
+        stamp = dict(error=repr(e))
+
+    # The committed rocprofv3 summary (profiles/r04_manifest.json) is used only when it was measured on the kernel sources this run is
     # built from (digest of csrc/): then the roofline divides by the profiler's average launch duration and carries the PMC traffic;
     # otherwise by this run's own HIP-event pairs (which include the gaps of eager launches) with traffic null.
     man = _profile_manifest()
@@ -419,11 +474,15 @@ def main():
         value = sum(counts) * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         ev_us = tot_ms.value / max(n_launch.value, 1) * 1e3
-        use_man = bool(man) and EPS == 256
-        avg_us = man["k_chain"]["rocprof_avg_us"] if use_man else ev_us
-        clock = ("rocprofv3 --kernel-trace average of profiles/%s (measured on these kernel sources: csrc digest matches)" % MANIFEST) if use_man \
-            else "HIP event pairs of this run (no committed profile of these kernel sources)"
-        achieved = (EPS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if n_launch.value else None
+        have_stamp = bool(stamp) and "chain_period_us" in stamp and EPS == ENVS
+        # frac comes from THIS run's clock (in-graph stamps); the committed profile's figure rides along as frac_profile
+        avg_us = stamp["chain_period_us"] if have_stamp else ev_us
+        clock = ("this run: s_memrealtime stamps inside the graph-replayed search (first workgroup start of the launch -> first workgroup "
+                 "start of the next launch; %d launches)" % stamp["launches"]) if have_stamp \
+            else "this run: HIP event pairs around eagerly launched steps (gaps included)"
+        achieved = (EPS * FLOP_CHAIN) / (avg_us * 1e-6) / 1e12 if avg_us else None
+        prof_us = man["k_chain"]["rocprof_avg_us"] if (man and EPS == 256) else None
+        achieved_prof = (EPS * FLOP_CHAIN) / (prof_us * 1e-6) / 1e12 if prof_us else None
         knobs = sorted(k for k in os.environ if k.startswith("LZ_"))
         out = {
             "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
@@ -452,9 +511,18 @@ def main():
                          "traffic_unit": ("HBM bytes per launch: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE) of profiles/%s" % MANIFEST) if man
                                          else "null: no committed PMC pass of these kernel sources",
                          "avg_launch_us": avg_us, "clock": clock,
+                         "avg_exec_us": stamp.get("chain_exec_us") if stamp else None,
+                         "exec_note": "avg_exec_us = first workgroup start -> last workgroup end of the launch (no dispatch gap); frac uses avg_launch_us",
+                         "achieved_exec": ((EPS * FLOP_CHAIN) / (stamp["chain_exec_us"] * 1e-6) / 1e12) if have_stamp else None,
+                         "lstm_launch_us": stamp.get("lstm_period_us") if stamp else None, "lstm_exec_us": stamp.get("lstm_exec_us") if stamp else None,
+                         "per_simulation_us": stamp.get("per_simulation_us") if stamp else None, "stamps": stamp,
+                         "achieved_profiled": achieved_prof, "frac_profile": (achieved_prof / PEAK_FP32_MATRIX_TFLOPS) if achieved_prof else None,
+                         "avg_launch_us_profile": prof_us,
+                         "profile": ("rocprofv3 --kernel-trace average of profiles/%s (measured on these kernel sources: csrc digest matches)" % MANIFEST) if prof_us
+                                    else "no committed profile of these kernel sources",
                          "avg_launch_us_hip_events": ev_us, "launches_timed": n_launch.value,
-                         "timing": "HIP event pairs on the engine stream around each launch, %d eager steps run right after the "
-                                   "graph-replayed timed region (this run); the profiler's average when the committed profile is current" % prof_steps,
+                         "timing": "in-graph s_memrealtime stamps over %d graph-replayed steps right after the timed region (this run); HIP event "
+                                   "pairs around each launch of %d eagerly launched steps as a cross-check" % (max(prof_steps, 5), prof_steps),
                          "algorithmic_flop_per_launch": EPS * FLOP_CHAIN},
         }
         if world == 1 and not args.no_cpu_baseline:

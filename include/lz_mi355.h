@@ -345,7 +345,7 @@ int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, 
 
 /* observability for parity tests: per-simulation records and pools (host copies)                  */
 /* tracing is off by default; when on, the captured search graph carries one extra D2D copy per simulation and the head
- * kernels also write their support-wide logits (lz_roots_read_debug_logits) */
+ * kernels also write their support-wide logits (lz_roots_read_debug_logits); on & 2: head debug buffers too (lz_roots_read_head_debug) */
 int lz_roots_enable_trace(lz_roots *r, int on);
 int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out /* [S][B][4] ix, action, search_len, to_play */);
 int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_prefix, float *h_value, float *h_policy_logits);
@@ -368,6 +368,22 @@ int lz_roots_read_debug_logits(lz_roots *r, int which, float *h_out);
  * the dominant kernel of the recurrent loop -- for bench.py's roofline object */
 int lz_profile_enable(lz_engine *e, int max_launches);
 int lz_profile_read(lz_engine *e, int64_t *out_launches, double *out_total_ms);
+/* In-graph timing of the two launches of a simulation (bench.py's roofline clock of THIS run; HIP events cannot be recorded inside a
+ * captured graph): while on, the first workgroup of every chain and LSTM launch stores its s_memrealtime start and the last one (by
+ * block id) its end (100 MHz constant-rate counter, 10 ns ticks) into per-simulation words; the search graph is re-captured with the stamp pointers.
+ * lz_roots_read_stamps: h_out [num_simulations][4] = {chain: first workgroup's start, last workgroup's end, LSTM: the same}. */
+int lz_roots_enable_stamps(lz_roots *r, int on);
+int lz_roots_read_stamps(lz_roots *r, int num_simulations, uint64_t *h_out);
+/* lz_roots_enable_trace(r, 3): tracing + head debug buffers -- the support-wide logits [B][support] and the pre-transform expectation
+ * softmax . support [B] of the value (which = 0) / value-prefix | reward (which = 1) head at pool slot `slot`, for EVERY simulation and
+ * whichever kernel finished the head (the head launch, or the split heads inside the next chain launch).  Replaces nothing in the
+ * reference: InverseScalarTransform.__call__ (scaling_transform.py:82-92) computes both inside one expression; the parity tests
+ * compare them with torch at north_star's 1e-5. */
+int lz_roots_read_head_debug(lz_roots *r, int slot, int which, float *h_logits, float *h_expect);
+/* h_out[i] = the device's inverse scalar transform of h_in[i] (scaling_transform.py:88-91 in fp32, torch's operation order), evaluated
+ * by the copy compiled into the conv-model head kernels (which = 0) or the MLP family's row finisher (which = 1): the parity test holds
+ * both BIT-EQUAL to torch on >= 10^6 inputs over the support range. */
+int lz_debug_inverse_scalar_transform(lz_engine *e, int which, const float *h_in, int64_t n, float *h_out);
 /* debugging aids: stop lz_initial_inference after stage k ("stop_stage"), read a workspace buffer */
 int lz_debug_set(lz_engine *e, const char *key, int value);
 int lz_debug_read_ws(lz_engine *e, int which, float *h_out, int64_t n);

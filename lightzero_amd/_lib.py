@@ -109,6 +109,10 @@ def lib():
         "lz_roots_read_latent": [P, ctypes.c_int, c_f32p],
         "lz_roots_read_hidden": [P, ctypes.c_int, c_f32p, c_f32p],
         "lz_roots_read_debug_logits": [P, ctypes.c_int, c_f32p],
+        "lz_roots_read_head_debug": [P, ctypes.c_int, ctypes.c_int, P, P],
+        "lz_roots_enable_stamps": [P, ctypes.c_int],
+        "lz_roots_read_stamps": [P, ctypes.c_int, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")],
+        "lz_debug_inverse_scalar_transform": [P, ctypes.c_int, c_f32p, ctypes.c_int64, c_f32p],
         "lz_roots_write_latent": [P, ctypes.c_int, c_f32p],
         "lz_roots_write_hidden": [P, ctypes.c_int, c_f32p, c_f32p],
         "lz_recurrent_inference": [P, c_i32p, P, P, P, ctypes.c_int, ctypes.c_int],

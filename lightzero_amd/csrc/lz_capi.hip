@@ -246,6 +246,8 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     if (r->slab) (void)hipFree(r->slab);
     if (r->graph_exec) (void)hipGraphExecDestroy(r->graph_exec);
     if (r->pool_slab) (void)hipFree(r->pool_slab);
+    if (r->hd_logits) (void)hipFree(r->hd_logits);
+    if (r->stamps) (void)hipFree(r->stamps);
     if (r->d_obs) (void)hipFree(r->d_obs);
     if (r->d_given) (void)hipFree(r->d_given);
     if (r->h_prep) (void)hipHostFree(r->h_prep);

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "lz_nn_kernels.h"
+#include "lz_hinv.h"
 #include "lz_wave.h"
 
 namespace {
@@ -268,22 +269,24 @@ __global__ __launch_bounds__(256) void k_rowfinal(lz_rowfinal_args a)
     s0 = red_sum(s0);
     s1 = red_sum(s1);
     if (lane == 0) {
-        // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
+        // softmax . support, then InverseScalarTransform.__call__ (scaling_transform.py:82-92) in torch's fp32 op order (lz_hinv.h)
         const float value = s1 / s0;
-        const float eps = 0.001f;
-        float tt = fabsf(value) + 1.0f;
-        tt = tt + eps;
-        tt = 0.004f * tt;
-        tt = 1.0f + tt;
-        tt = sqrtf(tt);
-        tt = tt - 1.0f;
-        tt = tt / 0.002f;
-        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
-        j.out_scalar[b] = sgn * (tt * tt - 1.0f);
+        j.out_scalar[b] = lz_inverse_scalar_transform(value);
     }
 }
 
+__global__ __launch_bounds__(256) void k_hinv_dense(const float *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = lz_inverse_scalar_transform(in[i]);
+}
+
 }  // namespace
+
+void lz_launch_hinv_dense(const float *d_in, float *d_out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hinv_dense, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
+}
 
 void lz_launch_dense(const lz_dense_args &a, hipStream_t s)
 {

@@ -109,8 +109,8 @@ struct lz_graph_key {
     uint64_t seed;
     uint64_t knobs;   // the debugging switches that change the captured launch sequence (so that toggling one re-captures)
     uint64_t model_uid, weights_gen;  // the kernel arguments hold weight pointers: a re-created model or re-allocated weights re-capture
-    int trace;        // tracing adds one device-to-device copy per simulation to the captured sequence
-    int pad_;
+    int trace;        // tracing adds one device-to-device copy per simulation to the captured sequence (bit 1: head debug buffers)
+    int stamps;       // in-graph timing stamps change kernel arguments
 };
 
 struct lz_roots {
@@ -142,6 +142,15 @@ struct lz_roots {
     float *t_rx = nullptr;          // [B][HW*HC] reward conv output
     float *t_pv = nullptr;          // [B][HW][2*HC] value | policy conv outputs
     bool trace_on = false;          // record res_* of every simulation (parity tests)
+    bool head_debug = false;        // lz_roots_enable_trace(on & 2): every simulation's support-wide head logits and pre-transform
+                                    // expectations go to hd_logits / hd_expect (split heads included)
+    float *hd_logits = nullptr;     // [NN][2: value, value prefix | reward][B][SUP]   (own allocation, only while head_debug)
+    float *hd_expect = nullptr;     // [NN][2][B]                                       (same allocation)
+    size_t hd_sup = 0;
+    // in-graph timing (bench.py roofline; lz_roots_enable_stamps): constant-rate (100 MHz) s_memrealtime stamps written by the
+    // first / last workgroup of the two launches of a simulation -- [NN][4] = {start, end} of the chain launch, then of the LSTM launch
+    unsigned long long *stamps = nullptr;
+    bool stamps_on = false;
     float *t_hbn = nullptr;         // [B][H]
     float *dbg_logits[2] = {nullptr, nullptr};  // [B][support]
     int32_t *trace = nullptr;       // [NN][5][B]  copies of res_* per simulation

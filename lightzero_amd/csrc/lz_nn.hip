@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "lz_nn_kernels.h"
+#include "lz_hinv.h"
 #define LZ_TREE_DEV_RESTORE_FAST_CONTRACT
 #include "lz_tree_dev.h"
 
@@ -932,6 +933,18 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// in-graph timing (bench.py): the FIRST workgroup of a launch stores the time it starts, the LAST one (by block id) the time it ends
+// (s_memrealtime: 100 MHz, independent of the shader clock); st == null in production (one wave-uniform branch).  Plain stores from two
+// workgroups: a first version that folded every workgroup's times in by atomics cost the 512-workgroup LSTM launch 3 us.
+__device__ __forceinline__ void lz_stamp_begin(unsigned long long *st)
+{
+    if (st && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) st[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void lz_stamp_end(unsigned long long *st)
+{
+    if (st && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) st[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+}
+
 // ---- split heads: the head MLPs of the PREVIOUS simulation's leaf, finished by waves 1..7 of the root's workgroup while wave 0 stages
 // the root's tree (lz_split_heads).  hw = wave - 1: 0..2 value head, 3..5 value-prefix head (601 outputs over 3 waves x 64 lanes x <= 4),
 // 6 policy head.  Every wave first sums the first-layer partial blocks of the LSTM launch for its head (32 unit tiles, fixed order: two
@@ -998,6 +1011,13 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
             lg[t] += (w2[t][k4][0] * h4[0] + w2[t][k4][1] * h4[1]) + (w2[t][k4][2] * h4[2] + w2[t][k4][3] * h4[3]);
     }
     LZ_HPS(3);
+    if (sh.dbg_logits && head != 1) {   // parity tests (tracing): the support-wide logits of this simulation's value / value-prefix head
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + nstep * t;
+            if (n < NOUT) sh.dbg_logits[((size_t)grp * sh.dbg_B + b) * NOUT + n] = lg[t];
+        }
+    }
     if (head == 1) {   // policy logits
         if (lane < A) {
             sh.out_logits[(size_t)b * A + lane] = lg[0];
@@ -1041,18 +1061,10 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
         const float M = fmaxf(fmaxf(m, m1), m2);
         const float e0 = expf(m - M), e1 = expf(m1 - M), e2 = expf(m2 - M);
         const float t0 = (s0 * e0 + red[5] * e1) + red[9] * e2, t1 = (s1 * e0 + red[6] * e1) + red[10] * e2;
-        // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
+        // softmax . support, then InverseScalarTransform.__call__ (scaling_transform.py:82-92) in torch's fp32 op order (lz_hinv.h)
         const float value = t1 / t0;
-        const float eps = 0.001f;
-        float t = fabsf(value) + 1.0f;
-        t = t + eps;
-        t = 0.004f * t;
-        t = 1.0f + t;
-        t = sqrtf(t);
-        t = t - 1.0f;
-        t = t / 0.002f;
-        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
-        const float out = sgn * (t * t - 1.0f);
+        const float out = lz_inverse_scalar_transform(value);
+        if (sh.dbg_expect && lane == 0) sh.dbg_expect[(size_t)grp * sh.dbg_B + b] = value;   // parity tests (tracing): the pre-transform expectation
         if (lane == 0) {
             (head == 0 ? sh.out_value : sh.out_vp)[b] = out;
             s_leaf[head == 0 ? 1 : 0] = out;
@@ -1086,6 +1098,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     static_assert(!BIG || NW * NT * 128 <= 16 * NT * PS, "the row results fit into V");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pi = wv & 3, kh = wv >> 2;
     const int b = blockIdx.x;
+    lz_stamp_begin(a.stamp);
     // step s of a wave: point 4 pi + s / KSW, channel quad kh KSW + s % KSW; weights [16 points][16 quads][64 lanes] float4
     auto wofs = [](int s) { return ((s / KSW) * 16 + (s % KSW)) * 64; };
     const size_t wbase = (size_t)((4 * pi) * 16 + kh * KSW) * 64 + lane;
@@ -1453,6 +1466,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
         }
     }
 #undef LZ_TS
+    lz_stamp_end(a.stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1779,6 +1793,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     const int tile = blockIdx.x, r0 = blockIdx.y * MR;
     const int H = a.H, KX = a.KX;
     const size_t slot = (size_t)a.B * H;
+    lz_stamp_begin(a.stamp);
     // weight ring first: its L2 round trip overlaps the staging
 #ifdef LZ_DEBUG_KNOBS
     // timing experiment (debug build, LZ_DEBUG_LSTM_HOTW=1; results are then wrong): every step re-reads the first 12 fragments, i.e.
@@ -2012,6 +2027,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
             }
         }
     }
+    lz_stamp_end(a.stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2185,16 +2201,8 @@ __global__ __launch_bounds__(NTHR) void k_heads(head_pack hp, int B)
 #pragma unroll
         for (int e = 1; e < EPB; ++e) if (tid == e) { s0 = ss[2 * e]; s1 = ss[2 * e + 1]; }
         const float value = s1 / s0;
-        const float eps = 0.001f;
-        float t = fabsf(value) + 1.0f;
-        t = t + eps;
-        t = 0.004f * t;
-        t = 1.0f + t;
-        t = sqrtf(t);
-        t = t - 1.0f;
-        t = t / 0.002f;
-        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
-        h.out_scalar[b0 + tid] = sgn * (t * t - 1.0f);
+        h.out_scalar[b0 + tid] = lz_inverse_scalar_transform(value);
+        if (h.out_expect) h.out_expect[b0 + tid] = value;   // parity tests (tracing): the pre-transform expectation
     }
     LZ_HTS(6);
 #undef LZ_HTS
@@ -2363,19 +2371,17 @@ __global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
         for (int w = 0; w < 8; ++w) { t0 += scrs[(w * 4 + tid) * 2]; t1 += scrs[(w * 4 + tid) * 2 + 1]; }
         // InverseScalarTransform.__call__ (scaling_transform.py:82-92), torch's fp32 op order
         const float value = t1 / t0;
-        const float eps = 0.001f;
-        float t = fabsf(value) + 1.0f;
-        t = t + eps;
-        t = 0.004f * t;
-        t = 1.0f + t;
-        t = sqrtf(t);
-        t = t - 1.0f;
-        t = t / 0.002f;
-        const float sgn = (value > 0.0f) ? 1.0f : (value < 0.0f ? -1.0f : 0.0f);
-        h.out_scalar[b0 + tid] = sgn * (t * t - 1.0f);
+        h.out_scalar[b0 + tid] = lz_inverse_scalar_transform(value);
+        if (h.out_expect) h.out_expect[b0 + tid] = value;   // parity tests (tracing): the pre-transform expectation
     }
     LZ_HTS(6);
 #undef LZ_HTS
+}
+
+__global__ __launch_bounds__(256) void k_hinv_nn(const float *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = lz_inverse_scalar_transform(in[i]);
 }
 
 }  // namespace
@@ -2405,6 +2411,11 @@ static void launch_wino(const lz_conv_args &a, hipStream_t s)
     const int ntiles = a.B * (a.Hout / 2) * (a.Wout / 2);
     const size_t lds = (size_t)8 * TMT * (CIN + 4) * 4;
     hipLaunchKernelGGL((k_conv_wino<CIN, COUT, TMT>), dim3((ntiles + TMT - 1) / TMT), dim3(256), lds, s, a);
+}
+
+void lz_launch_hinv_nn(const float *d_in, float *d_out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hinv_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
 }
 
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s)

@@ -83,6 +83,8 @@ struct lz_chain_args {
     int gw, gh;                  // latent grid (6x6 Atari with downsample, 9x9 Go); compiled instances: 6x6, 9x9
     unsigned long long *tstamp;  // debugging: s_memtime stamps of workgroup 0 / wave 0 (null in production)
     int debug_flags;             // timing experiments of the debug build (results are then wrong): 1 = no latent gather, 2 = no action-table slice
+    unsigned long long *stamp;   // optional [2]: {start of the first workgroup, end of the last workgroup (by block id)} in s_memrealtime ticks (100 MHz,
+                                 // constant rate) -- bench.py's in-graph timing of the roofline kernel (k_chain_w only); null in production
 };
 // step != null: the tree step of every root (expand + backup of the previous simulation, selection of this one) runs as the
 // prologue of the root's workgroup, and the chain reads the selected (slot, action) from LDS instead of gather_ix / action
@@ -101,6 +103,10 @@ struct lz_split_heads {
     int n_unit_tiles;                     // H / 16
     float support_min;
     float *out_value, *out_vp, *out_logits;   // pool slot of the leaf: [B], [B], [B][A]
+    // observability for the parity tests (null unless the roots are tracing): the support-wide logits of the value (0) / value-prefix (1)
+    // head [2][dbg_B][nout] and the pre-transform expectation softmax . support [2][dbg_B] of THIS simulation's leaf
+    float *dbg_logits, *dbg_expect;
+    int dbg_B;
 };
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step);
 bool lz_chain_small_supported(int gw, int gh, int C);
@@ -134,6 +140,7 @@ struct lz_lstm_args {
     int sh_kc;
     const float *sh_w1c, *sh_w1r;    // lz_model::sh_w1c / sh_w1r
     float *sh_part;                  // [B][3 heads: value, policy, value prefix][H/16 unit tiles][32 hidden]
+    unsigned long long *stamp;       // optional [2] start / end stamps like lz_chain_args::stamp (k_lstm2 only)
 };
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s);
 // host: wcat [4H][K] (row 4*unit + gate) -> fragment order for lz_lstm_args::wf (4*H*K floats)
@@ -151,6 +158,7 @@ struct lz_head_desc {
     float support_min;     // support = support_min + k (step 1)
     float *out_logits;     // optional [B][NOUT]
     float *out_scalar;     // [B] (categorical)
+    float *out_expect;     // optional [B] (categorical): softmax . support before the inverse scalar transform (parity tests)
 };
 void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipStream_t s);
 extern unsigned long long *lz_debug_heads_ts;   // null in production
@@ -204,3 +212,8 @@ struct lz_rowfinal_args {
     int njobs, B;
 };
 void lz_launch_rowfinal(const lz_rowfinal_args &a, hipStream_t s);
+
+// Debugging / parity: out[i] = lz_inverse_scalar_transform(in[i]) (lz_hinv.h) evaluated by the copy of the function compiled into
+// lz_nn.hip (which = 0: the head kernels and the split heads) or lz_dense.hip (which = 1: k_rowfinal).  Device pointers.
+void lz_launch_hinv_nn(const float *d_in, float *d_out, int64_t n, hipStream_t s);
+void lz_launch_hinv_dense(const float *d_in, float *d_out, int64_t n, hipStream_t s);

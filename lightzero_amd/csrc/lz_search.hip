@@ -330,6 +330,7 @@ int lz_roots_release_pools_if_stale(lz_roots *r)
         LZ_HIP_CHECK(hipStreamSynchronize(r->eng->stream));
         if (r->graph_exec) { (void)hipGraphExecDestroy(r->graph_exec); r->graph_exec = nullptr; }
         if (r->pool_slab) { (void)hipFree(r->pool_slab); r->pool_slab = nullptr; }
+        if (r->hd_logits) { (void)hipFree(r->hd_logits); r->hd_logits = r->hd_expect = nullptr; }
         if (r->d_obs) { if (r->last_obs == r->d_obs) r->last_obs = nullptr; (void)hipFree(r->d_obs); r->d_obs = nullptr; }
         if (r->d_results) { (void)hipFree(r->d_results); r->d_results = nullptr; }
         if (r->h_results) { (void)hipHostFree(r->h_results); r->h_results = nullptr; }
@@ -445,8 +446,31 @@ static lz_head_desc headdesc(const MlpW &w, const float *in, int env_stride, int
     return h;
 }
 
-// the head MLPs (value, policy[, value prefix]) in one launch; inputs are the 1x1-conv outputs t_pv / the LSTM output
-static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_value_logits, bool with_vp, float *out_vp,
+// head debug buffers (lz_roots_enable_trace(r, 3)): every simulation's support-wide logits and pre-transform expectations, per pool slot
+static int ensure_head_debug(lz_roots *r)
+{
+    if (!r->head_debug || r->hd_logits) return LZ_OK;
+    const lz_model_cfg &c = r->eng->model->cfg;
+    LZ_REQUIRE(c.model_type < 2, "head debug buffers exist for the conv models only");
+    const size_t B = r->t.B, NN = r->t.NN, SUP = std::max(c.support_size, c.reward_support_size);
+    const size_t n = NN * 2 * B * (SUP + 1);
+    hipError_t err = lz_dev_malloc((void **)&r->hd_logits, n * 4);
+    if (err != hipSuccess) {
+        r->hd_logits = nullptr;
+        lz_set_error("hipMalloc(%zu bytes) for the head debug buffers failed: %s", n * 4, hipGetErrorString(err));
+        return err == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP;
+    }
+    r->hd_expect = r->hd_logits + NN * 2 * B * SUP;
+    r->hd_sup = SUP;
+    LZ_HIP_CHECK(hipMemsetAsync(r->hd_logits, 0, n * 4, r->eng->stream));
+    return LZ_OK;
+}
+static float *hd_logits_at(lz_roots *r, int slot, int which) { return r->hd_logits + ((size_t)slot * 2 + which) * r->t.B * r->hd_sup; }
+static float *hd_expect_at(lz_roots *r, int slot, int which) { return r->hd_expect + ((size_t)slot * 2 + which) * r->t.B; }
+
+// the head MLPs (value, policy[, value prefix]) in one launch; inputs are the 1x1-conv outputs t_pv / the LSTM output.
+// slot = the pool slot the outputs belong to (head debug buffers)
+static void heads(lz_roots *r, int slot, float *out_value, float *out_logits, float *dbg_value_logits, bool with_vp, float *out_vp,
                   float *dbg_vp_logits, hipStream_t s)
 {
     lz_model *m = r->eng->model;
@@ -456,13 +480,20 @@ static void heads(lz_roots *r, float *out_value, float *out_logits, float *dbg_v
     int n = 0;
     // the support-wide logits are observability for the parity tests (lz_roots_read_debug_logits): written only while tracing is on
     if (!r->trace_on) dbg_value_logits = dbg_vp_logits = nullptr;
+    const bool hd = r->trace_on && r->head_debug && r->hd_logits;   // per-slot copies (+ the pre-transform expectations)
     h[n++] = headdesc(m->fc_value, r->t_pv, HW * 2 * HC, 2 * HC, 1, c.support_min, dbg_value_logits, out_value);
+    if (hd) h[n - 1].out_expect = hd_expect_at(r, slot, 0);
     h[n++] = headdesc(m->fc_policy, r->t_pv + HC, HW * 2 * HC, 2 * HC, 0, 0.f, out_logits, nullptr);
     if (with_vp) {
         if (c.model_type == 1) h[n++] = headdesc(m->fc_reward, r->t_rx, HW * HC, HC, 1, c.reward_support_size > 0 ? c.reward_support_min : c.support_min, dbg_vp_logits, out_vp);
         else h[n++] = headdesc(m->fc_reward, r->t_hbn, c.lstm_hidden_size, 16, 1, c.support_min, dbg_vp_logits, out_vp);
+        if (hd) h[n - 1].out_expect = hd_expect_at(r, slot, 1);
     }
     lz_launch_heads(h, n, B, 32, s);  // Builder::mlp pads narrower heads to the compiled 32 hidden units
+    if (hd) {   // the launch wrote its logits [B][NOUT] to the "latest head launch" buffers: keep a copy with the slot
+        if (dbg_value_logits) (void)hipMemcpyAsync(hd_logits_at(r, slot, 0), dbg_value_logits, (size_t)B * m->fc_value.NOUT * 4, hipMemcpyDeviceToDevice, s);
+        if (with_vp && dbg_vp_logits) (void)hipMemcpyAsync(hd_logits_at(r, slot, 1), dbg_vp_logits, (size_t)B * m->fc_reward.NOUT * 4, hipMemcpyDeviceToDevice, s);
+    }
 }
 
 // records a HIP-event pair around one launch when in-stream profiling is on (bench.py roofline)
@@ -506,6 +537,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     }
     int rc = ensure_pools(r);
     if (rc != LZ_OK) return rc;
+    if (r->trace_on && r->head_debug && (rc = ensure_head_debug(r)) != LZ_OK) return rc;
     rc = ensure_ws(m, r->t.B);
     if (rc != LZ_OK) return rc;
     hipStream_t s = r->eng->stream;
@@ -572,7 +604,7 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
             LZ_HIP_CHECK(hipMemsetAsync(r->c_pool, 0, (size_t)B * H * 4, s));
         }
     }
-    heads(r, r->sim_value, r->sim_logits, r->dbg_logits[0], false, nullptr, nullptr, s);
+    heads(r, 0, r->sim_value, r->sim_logits, r->dbg_logits[0], false, nullptr, nullptr, s);
     LZ_HIP_CHECK(hipGetLastError());
     r->inferred = true;
     r->inference_fresh = true;  // no prepare has consumed it yet (lz_roots_reset_keep_inference)
@@ -1284,6 +1316,12 @@ static bool dbg_skip(char k)
 static constexpr bool dbg_skip(char) { return false; }
 #endif
 
+__global__ void k_stamp_init(unsigned long long *st, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) st[i] = (i & 1) ? 0ull : ~0ull;
+}
+
 // the network part of one simulation (mcts_ctree.py:834-847): recurrent_inference for the leaves selected by the
 // last traverse, outputs into slot sim + 1 of the pools
 // `step` (conv models only): the tree step that selects this simulation's leaves, run inside the chain launch
@@ -1321,6 +1359,10 @@ static void split_heads_for(lz_roots *r, int leaf_slot, lz_split_heads &sh)
     sh.nout = m->cfg.support_size; sh.n_unit_tiles = m->cfg.lstm_hidden_size / 16; sh.support_min = m->cfg.support_min;
     sh.out_value = r->sim_value + (size_t)leaf_slot * B; sh.out_vp = r->sim_vp + (size_t)leaf_slot * B;
     sh.out_logits = r->sim_logits + (size_t)leaf_slot * B * A;
+    if (r->trace_on && r->head_debug && r->hd_logits && r->hd_sup == (size_t)sh.nout) {
+        // [2][B][nout] / [2][B] of the leaf's slot; the kernel indexes (head, root) itself
+        sh.dbg_logits = hd_logits_at(r, leaf_slot, 0); sh.dbg_expect = hd_expect_at(r, leaf_slot, 0); sh.dbg_B = (int)B;
+    }
 }
 
 static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz_tree_step *step = nullptr, bool defer_heads = false)
@@ -1355,6 +1397,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
         // trace: the selection this simulation's network launches consume.  With the tree step fused into the chain launch the
         // res_* arrays are written by that launch's prologue, so the copy follows it (same stream; also inside a captured graph)
         if (r->trace_on && !step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
+        if (r->stamps_on && r->stamps) ca.stamp = r->stamps + (size_t)slot * 4;
         {
             ProfScope ps(r->eng, s);
             if (!dbg_skip('c')) lz_launch_chain(ca, s, step);
@@ -1376,9 +1419,10 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
 #endif
     // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
     // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
+    if (r->stamps_on && r->stamps) l.stamp = r->stamps + (size_t)slot * 4 + 2;
     if (c.model_type == 0 && !dbg_skip('l')) lz_launch_lstm(l, s);
     if (!defer_heads && !dbg_skip('h'))
-        heads(r, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
+        heads(r, slot, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
               r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
 }
 
@@ -1414,6 +1458,8 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
         }
         return;
     }
+    if (r->stamps_on && r->stamps)   // {start, end} x {chain, LSTM} per pool slot, cleared per search
+        hipLaunchKernelGGL(k_stamp_init, dim3((unsigned)((t.NN * 4 + 255) / 256)), dim3(256), 0, s, r->stamps, t.NN * 4);
     ta.fresh_minmax = 1;   // ... which the first selection starts itself
     lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
     ta.fresh_minmax = 0;
@@ -1528,6 +1574,9 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     }
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
+    if (r->trace_on && r->head_debug && r->eng->model->cfg.model_type < 2)   // (allocations cannot happen inside the capture)
+        if (int rc = ensure_head_debug(r)) return rc;
+    if (r->stamps_on && !r->stamps) LZ_HIP_CHECK(lz_dev_malloc((void **)&r->stamps, (size_t)r->t.NN * 4 * sizeof(unsigned long long)));
     r->delta = value_delta_max;
     lz_traverse_args ta;
     ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
@@ -1542,7 +1591,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     key.sims = num_simulations; key.pb_c_base = pb_c_base; key.pb_c_init = pb_c_init; key.discount = discount_factor;
     key.horizon = lstm_horizon_len; key.delta = value_delta_max; key.players = r->players; key.tiebreak = r->tiebreak;
     key.seed = r->seed; key.knobs = graph_knobs();
-    key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = r->trace_on ? 1 : 0;
+    key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = (r->trace_on ? 1 : 0) | (r->trace_on && r->head_debug ? 2 : 0); key.stamps = r->stamps_on ? 1 : 0;
     return launch_captured(r, key, [&]() { enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s); });
 }
 
@@ -1581,7 +1630,7 @@ extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_consider
     key.sims = num_simulations; key.pb_c_base = max_num_considered_actions; key.discount = discount_factor;
     key.horizon = -7;  // marks a Gumbel search (a roots handle is either Gumbel or not, so the slot is never shared)
     key.players = r->players; key.tiebreak = r->tiebreak; key.seed = r->seed; key.knobs = graph_knobs();
-    key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = r->trace_on ? 1 : 0;
+    key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = (r->trace_on ? 1 : 0) | (r->trace_on && r->head_debug ? 2 : 0); key.stamps = r->stamps_on ? 1 : 0;
     return launch_captured(r, key, enqueue);
 }
 
@@ -1643,6 +1692,66 @@ extern "C" int lz_roots_enable_trace(lz_roots *r, int on)
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     r->trace_on = on != 0;
+    r->head_debug = (on & 2) != 0;   // + per-slot support-wide head logits / pre-transform expectations of EVERY simulation
+    return LZ_OK;
+}
+
+// In-graph timing of the two launches of a simulation (bench.py's roofline clock): while on, the chain and LSTM
+// launches' first / last workgroup store their s_memrealtime start / end into [slot][4] words; the captured search is re-captured with the stamp pointers.
+extern "C" int lz_roots_enable_stamps(lz_roots *r, int on)
+{
+    LZ_REQUIRE(r != nullptr, "roots is NULL");
+    r->stamps_on = on != 0;
+    return LZ_OK;
+}
+
+// h_out [num_simulations][4] = {chain: first workgroup start, last workgroup end, LSTM: start, end} of simulation s (pool slot s + 1),
+// in ticks of the 100 MHz constant-rate counter (10 ns)
+extern "C" int lz_roots_read_stamps(lz_roots *r, int num_simulations, uint64_t *h_out)
+{
+    LZ_REQUIRE(r != nullptr && h_out != nullptr && r->stamps != nullptr, "no stamps: lz_roots_enable_stamps(roots, 1) before lz_search");
+    LZ_REQUIRE(num_simulations >= 1 && num_simulations < r->t.NN, "num_simulations out of range");
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(h_out, r->stamps + 4, (size_t)num_simulations * 4 * 8, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// Head debug buffers (lz_roots_enable_trace(roots, 3) before the inference / search): the support-wide logits [B][support] and the
+// pre-transform expectation softmax . support [B] of the value (which = 0) or value-prefix / reward (which = 1) head at pool slot
+// `slot` -- for EVERY simulation, whichever kernel finished the head (k_heads_mm, or the split heads in the next chain launch)
+extern "C" int lz_roots_read_head_debug(lz_roots *r, int slot, int which, float *h_logits, float *h_expect)
+{
+    LZ_REQUIRE(r != nullptr && (which == 0 || which == 1), "bad argument");
+    LZ_REQUIRE(r->trace_on && r->head_debug && r->hd_logits, "head debug is off: lz_roots_enable_trace(roots, 3) before the inference");
+    LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
+    const lz_model_cfg &mc = r->eng->model->cfg;
+    const size_t B = r->t.B, SUP = (which == 1 && mc.reward_support_size > 0) ? mc.reward_support_size : mc.support_size;
+    hipStream_t s = r->eng->stream;
+    if (h_logits) LZ_HIP_CHECK(hipMemcpyAsync(h_logits, hd_logits_at(r, slot, which), B * SUP * 4, hipMemcpyDeviceToHost, s));
+    if (h_expect) LZ_HIP_CHECK(hipMemcpyAsync(h_expect, hd_expect_at(r, slot, which), B * 4, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    return LZ_OK;
+}
+
+// out[i] = the device's inverse scalar transform of in[i] (lz_hinv.h) -- host arrays in and out.  which = 0: the copy compiled into the
+// conv-model head kernels (k_heads, k_heads_mm, split heads), 1: the copy in the MLP family's k_rowfinal.  tests/test_hinv_gpu.py holds
+// both bit-equal to torch's evaluation of scaling_transform.py:88-91.
+extern "C" int lz_debug_inverse_scalar_transform(lz_engine *e, int which, const float *h_in, int64_t n, float *h_out)
+{
+    LZ_REQUIRE(e != nullptr && h_in != nullptr && h_out != nullptr && n > 0 && (which == 0 || which == 1), "bad argument");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    float *d = nullptr;
+    LZ_HIP_CHECK(lz_dev_malloc((void **)&d, (size_t)n * 8));
+    hipStream_t s = e->stream;
+    hipError_t err = hipMemcpyAsync(d, h_in, (size_t)n * 4, hipMemcpyHostToDevice, s);
+    if (err == hipSuccess) {
+        if (which == 0) lz_launch_hinv_nn(d, d + n, n, s); else lz_launch_hinv_dense(d, d + n, n, s);
+        err = hipMemcpyAsync(h_out, d + n, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    LZ_HIP_CHECK(err);
     return LZ_OK;
 }
 

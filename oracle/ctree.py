@@ -51,6 +51,8 @@ def lib():
         L.otree_get_values.argtypes = [P, fp]
         L.otree_get_minmax.argtypes = [P, fp]
         L.otree_get_trajectories.argtypes = [P, ip, ctypes.c_int]
+        L.otree_probe.restype = ctypes.c_int
+        L.otree_probe.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ip, fp, ip]
         _lib = L
     return _lib
 
@@ -135,6 +137,14 @@ def _make(variant):
             out = np.zeros((self.root_num, 2), np.float32)
             lib().otree_get_minmax(self._h, out)
             return out
+
+        def probe(self, env, pb_c_base, pb_c_init, discount_factor, players=1):
+            """diagnostic: the next selection of root ``env`` level by level, without touching the tree ->
+            [(latent index of the node, {action: cucb_score}, action the deterministic rule picks), ...]"""
+            cap = self._S + 2
+            lat = np.zeros(cap, np.int32); act = np.zeros(cap, np.int32); sc = np.zeros((cap, self._A), np.float32)
+            n = lib().otree_probe(self._h, int(env), int(pb_c_base), pb_c_init, discount_factor, int(players), cap, lat, sc, act)
+            return [(int(lat[i]), {a: float(sc[i, a]) for a in range(self._A) if sc[i, a] > -999999.0}, int(act[i])) for i in range(n)]
 
         def get_trajectories(self):
             stride = self._S + 2

@@ -322,6 +322,42 @@ void otree_traverse(OTree *t, int pb_c_base, float pb_c_init, float discount, in
     }
 }
 
+/* Diagnostic (no counterpart in the reference): the selection the NEXT otree_traverse would make for root `env`, level by level,
+ * WITHOUT touching the tree -- per level the node's latent index, the cucb_score of every legal action (action-indexed row of A
+ * floats, illegal = O_FLOAT_MIN) and the action the deterministic rule picks.  Used by tests/test_e2e_cfg1_gpu.py to attribute a root
+ * whose visit counts differ between two pipelines to the first selection that differed and to say how close its best two scores were.
+ * Returns the number of levels written (<= max_levels). */
+int otree_probe(const OTree *t, int env, int pb_c_base, float pb_c_init, float discount, int players, int max_levels,
+                int *out_node_latent, float *out_scores, int *out_action)
+{
+    const ONode *pool = &t->nodes[(size_t)env * t->cap];
+    float parent_q = 0.0f;
+    int ni = 0, is_root = 1, lv = 0;
+    while (pool[ni].expanded && lv < max_levels) {
+        const ONode *node = &pool[ni];
+        float mean_q = compute_mean_q(t, env, node, is_root, parent_q, discount);
+        is_root = 0;
+        parent_q = mean_q;
+        float *row = out_scores + (size_t)lv * t->A;
+        for (int a = 0; a < t->A; ++a) row[a] = O_FLOAT_MIN;
+        float max_score = O_FLOAT_MIN;
+        int best = 0, have = 0;
+        for (int j = 0; j < node->n_legal; ++j) {
+            int a = legal_at(t, env, node, j);
+            const ONode *child = &pool[node->first_child + a];
+            float sc = ucb_score(t, child, &t->mm[env], mean_q, node->is_reset, (float)(node->visit_count - 1), node->value_prefix,
+                                 (float)pb_c_base, pb_c_init, discount, players);
+            row[a] = sc;
+            if (!have || max_score < sc) { max_score = sc; best = a; have = 1; }  /* front of the tie list: first maximum */
+        }
+        out_node_latent[lv] = node->latent_index;
+        out_action[lv] = best;
+        ni = node->first_child + best;
+        ++lv;
+    }
+    return lv;
+}
+
 /* cbackpropagate  cnode.cpp:482-575 (EZ) / ctree_muzero cnode.cpp:419-478 (MZ) */
 static void backpropagate(OTree *t, int env, int to_play, float value, float discount)
 {

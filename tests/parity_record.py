@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # tensor class -> asserted bound on |d| / (1 + |x|)
 BOUNDS = {
     "latent": 1e-5, "h": 1e-5, "c": 1e-5, "hc": 1e-5, "policy": 1e-5, "logits": 1e-5,
+    # split heads (the production path of 49 of 50 simulations): support-wide logits and the pre-transform expectation softmax . support
+    "logits_split": 1e-5, "expect": 1e-5, "expect_split": 1e-5,
     "scalar": 3e-4, "value": 3e-4, "value_prefix": 3e-4, "reward": 3e-4,
 }
 

@@ -81,12 +81,12 @@ def main():
     rl["traffic"] = out["k_chain"]["hbm_bytes_per_launch"]
     rl["traffic_unit"] = ("HBM bytes per launch (rocprofv3 PMC passes of the same profiling run, profiles/%s_traffic.json; "
                           "patched in by tools/refresh_profiles.py)" % tag)
-    # the line was printed before this run's profile existed: it divided by its own HIP-event pairs.  Carry the profiler's average
-    # duration of the same run instead (what bench.py does by itself once the manifest below is committed)
-    rl["avg_launch_us"] = d_chain
-    rl["achieved"] = rl["algorithmic_flop_per_launch"] / (d_chain * 1e-6) / 1e12
-    rl["frac"] = rl["achieved"] / rl["peak"]
-    rl["clock"] = "rocprofv3 --kernel-trace average of the same profiling run (profiles/%s_final_kernel_stats.csv; patched in by tools/refresh_profiles.py)" % tag
+    # the line carries its own clock (in-graph stamps of that run: roofline.avg_launch_us / frac); the profiler's average duration of the
+    # same profiling run rides along as the *_profile fields (what bench.py fills in by itself once the manifest below is committed)
+    rl["avg_launch_us_profile"] = d_chain
+    rl["achieved_profiled"] = rl["algorithmic_flop_per_launch"] / (d_chain * 1e-6) / 1e12
+    rl["frac_profile"] = rl["achieved_profiled"] / rl["peak"]
+    rl["profile"] = "rocprofv3 --kernel-trace average of the same profiling run (profiles/%s_final_kernel_stats.csv; patched in by tools/refresh_profiles.py)" % tag
     open(os.path.join(prof, "%s_bench_n1.json" % tag), "w").write(json.dumps(bench) + "\n")
     # MFMA utilisation of the roofline kernel: busy cycles per SIMD over the launch duration at the sustained clock
     busy = mean(fused, "SQ_VALU_MFMA_BUSY_CYCLES")
@@ -153,7 +153,7 @@ def main():
     if man["csrc_sha256"] != man["csrc_sha256_here"]:
         print("WARNING: the kernel sources here differ from the ones profiled on the GPU box")
     r = bench["roofline"]
-    print("value %.0f env-steps/s, %.3f ms/step; roofline %.1f TFLOP/s frac %.3f (%.1f us/launch); cpu_baseline %.1f; chain %.2f us, traffic %d B"
+    print("value %.0f env-steps/s, %.3f ms/step; roofline %.1f TFLOP/s frac %.3f (%.1f us/launch by the run's stamps); cpu_baseline %.1f; chain %.2f us by rocprofv3, traffic %d B"
           % (bench["value"], bench["ms_per_step"], r["achieved"], r["frac"], r["avg_launch_us"], bench["cpu_baseline"]["value"], d_us or 0,
              out["k_chain"]["hbm_bytes_per_launch"]))
 
