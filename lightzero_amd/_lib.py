@@ -204,6 +204,39 @@ def process_seed():
     return (int.from_bytes(h.digest(), "little") ^ ((rank + 1) * 0x9E3779B97F4A7C15)) & (2 ** 63 - 1)
 
 
+_tls = None
+
+
+def rs():
+    """The host-side random source of the policies / tree shims (Dirichlet root noise, eps-greedy draws, seeds of the device-side
+    streams): the global ``np.random`` -- what the reference uses, governed by ``np.random.seed`` -- unless the calling THREAD has
+    installed a ``np.random.RandomState`` of its own with ``random_source``.  The vectorised collector does that for its pipelined env
+    groups: a group's policy forward runs on a worker thread while the main thread steps the other group's envs, and two threads
+    interleaving on the one global stream would make seeded runs irreproducible."""
+    src = getattr(_tls, "rs", None) if _tls is not None else None
+    return src if src is not None else np.random
+
+
+class random_source(object):
+    """``with random_source(np.random.RandomState(seed)):`` -- this thread's draws come from that stream inside the block"""
+
+    def __init__(self, state):
+        self.state = state
+
+    def __enter__(self):
+        global _tls
+        if _tls is None:
+            import threading
+            _tls = threading.local()
+        self.prev = getattr(_tls, "rs", None)
+        _tls.rs = self.state
+        return self.state
+
+    def __exit__(self, *exc):
+        _tls.rs = self.prev
+        return False
+
+
 def f32(x):
     return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
 

@@ -1474,7 +1474,14 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     lz_model *mdl = r->eng->model;
     const bool split = fuse && mdl->cfg.model_type == 0 && mdl->sh_w1c && r->sh_part && t.A <= 64 && mdl->cfg.support_size <= 768 &&
                        mdl->cfg.lstm_hidden_size == 512 && t.variant == LZ_TREE_EFFICIENTZERO && !getenv("LZ_HEADS_LAUNCH") && !getenv("LZ_CHAIN_DIRECT") &&
-                       !getenv("LZ_CHAIN_W4") && !getenv("LZ_LSTM_NOSPLIT") && !getenv("LZ_LSTM_ROWS32") && !getenv("LZ_LSTM_CHUNKED");
+                       !getenv("LZ_CHAIN_W4") && !getenv("LZ_LSTM_NOSPLIT") && !getenv("LZ_LSTM_ROWS32") && !getenv("LZ_LSTM_CHUNKED")
+#ifdef LZ_DEBUG_KNOBS
+                       // recurrent() mutates the chain arguments under these switches AFTER the defer decision below was taken from the
+                       // unmodified ones (a stamped / truncated chain is not fusable): a simulation could defer its heads to a launch
+                       // that then never finishes them.  The timing experiments that use them run with the separate head launch.
+                       && !getenv("LZ_DEBUG_CHAIN_TS") && !getenv("LZ_DEBUG_CHAIN_LAYERS") && !getenv("LZ_DEBUG_CHAIN_FLAGS")
+#endif
+        ;
     auto make_step = [&](int slot) {
         lz_tree_step st{};
         st.t = t; st.new_node = slot; st.discount = ta.discount;

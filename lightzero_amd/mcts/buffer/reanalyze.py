@@ -14,6 +14,8 @@ structure).  Any other model object goes through the same MCTS class's reference
 ``policy_re_context`` is the reference's tuple (game_buffer_muzero.py:_prepare_policy_reanalyzed_context):
 (policy_obs_list, policy_mask, pos_in_game_segment_list, batch_index_list, child_visits, root_values, game_segment_lens,
 action_mask_segment, to_play_segment)."""
+import os
+
 import numpy as np
 
 
@@ -79,6 +81,10 @@ def compute_target_policy_reanalyzed(policy_re_context, model, cfg, mcts_cls=Non
     T, B = len(policy_obs_list), len(pos_in_game_segment_list)
     to_play, action_mask = preprocess_to_play_and_action_mask(B, to_play_segment, action_mask_segment, pos_in_game_segment_list, U, A,
                                                               bool(_g(mcfg, "continuous_action_space", False)))
+    if action_mask is None or bool(_g(mcfg, "continuous_action_space", False)):
+        # game_buffer_sampled_efficientzero.py builds K sampled actions per root instead of legal-action lists: not this function
+        raise NotImplementedError("compute_target_policy_reanalyzed serves discrete action spaces (game_buffer_efficientzero.py / "
+                                  "game_buffer_muzero.py); continuous (Sampled EfficientZero) reanalysis is not built")
     m2 = action_mask != 0
     counts = m2.sum(1)
     flat = np.nonzero(m2)[1].tolist()
@@ -90,6 +96,11 @@ def compute_target_policy_reanalyzed(policy_re_context, model, cfg, mcts_cls=Non
     elif obs.ndim == 3 and str(_g(mcfg, "model_type", "conv")).startswith("mlp"):
         obs = obs.reshape(T, -1)
     noises = None
+    # RNG-stream note: the reference draws these Dirichlet noises unconditionally (game_buffer_efficientzero.py:377-380) and uses them
+    # only when reanalyze_noise is set; here they are drawn only when used, so with reanalyze_noise = False a seeded np.random stream is
+    # NOT advanced by this call (it is by the reference's).  Set LZ_REANALYZE_DRAW_ALWAYS=1 for stream parity with the reference.
+    if not bool(_g(cfg, "reanalyze_noise", False)) and os.environ.get("LZ_REANALYZE_DRAW_ALWAYS"):
+        np.random.dirichlet([float(_g(cfg, "root_dirichlet_alpha"))] * A, size=T)
     if bool(_g(cfg, "reanalyze_noise", False)):
         # game_buffer_efficientzero.py:377-380: one Dirichlet over the whole action space per root; a root uses its first #legal entries
         full = np.random.dirichlet([float(_g(cfg, "root_dirichlet_alpha"))] * A, size=T).astype(np.float32)

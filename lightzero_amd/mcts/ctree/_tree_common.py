@@ -14,7 +14,9 @@ runs HIP kernels (lightzero_amd/csrc/lz_tree.hip).  Differences, all forced by t
   EfficientZero tree and follows the ``deterministic`` flag for the MuZero tree; call
   ``Roots.set_tiebreak(0)`` for the deterministic first-arg-max rule.
 """
+import collections
 import ctypes
+import os
 
 import numpy as np
 
@@ -26,19 +28,74 @@ DEFAULT_MAX_SIMULATIONS = 512
 # after an inference the latent / LSTM pools), so handles released by a dead ``Roots`` object are parked here -- keyed by
 # (engine, variant, root_num, action space, max_simulations) -- and re-armed (lz_roots_reset) by the next ``Roots`` of that shape
 # instead of being freed and re-allocated every env-step.
+# Bounded: at most _HANDLE_CACHE_DEPTH handles per shape and _HANDLE_CACHE_MAX handles in total (LZ_HANDLE_CACHE_MAX, default 6);
+# beyond that the least recently parked handle is destroyed (its trees and latent / LSTM pools go back to the device).  A driver that
+# builds a fresh Roots per forward with a varying ready-env count therefore keeps a few pool sets, not one or two per batch size
+# it has ever seen (120 MB each at 256 roots x 50 simulations).  ``flush_handle_cache()`` frees everything that is parked.
 _HANDLE_CACHE = {}
 _HANDLE_CACHE_DEPTH = 2
+_HANDLE_CACHE_MAX = max(0, int(os.environ.get("LZ_HANDLE_CACHE_MAX", "6")))
+_PARK_ORDER = collections.OrderedDict()   # handle address -> key, oldest first
 
 
 def _engine_key(engine):
     return getattr(engine, "value", engine)
 
 
+def _haddr(h):
+    return getattr(h, "value", h)
+
+
+def _unpark(key):
+    """the most recently parked handle of this shape, or None"""
+    parked = _HANDLE_CACHE.get(key)
+    if not parked:
+        return None
+    h, seed = parked.pop()
+    _PARK_ORDER.pop(_haddr(h), None)
+    if not parked:
+        _HANDLE_CACHE.pop(key, None)
+    return h, seed
+
+
+def _park(key, h, seed):
+    """park a released handle; returns False when the caller has to destroy it (cache disabled / this shape is full)"""
+    if _HANDLE_CACHE_MAX == 0 or len(_HANDLE_CACHE.get(key, ())) >= _HANDLE_CACHE_DEPTH:
+        return False
+    _HANDLE_CACHE.setdefault(key, []).append((h, seed))
+    _PARK_ORDER[_haddr(h)] = key
+    while len(_PARK_ORDER) > _HANDLE_CACHE_MAX:   # evict the least recently parked handle, whatever its shape
+        addr, k = _PARK_ORDER.popitem(last=False)
+        lst = _HANDLE_CACHE.get(k, [])
+        for i, (hh, _) in enumerate(lst):
+            if _haddr(hh) == addr:
+                lst.pop(i)
+                L.lib().lz_roots_destroy(hh)
+                break
+        if not lst:
+            _HANDLE_CACHE.pop(k, None)
+    return True
+
+
+def flush_handle_cache(engine=None):
+    """destroy every parked roots handle (of one engine, or of all): their HBM goes back to the device.  Returns the count."""
+    ev = None if engine is None else _engine_key(engine)
+    n = 0
+    for key in [k for k in _HANDLE_CACHE if ev is None or (k and k[0] == ev)]:
+        for h, _ in _HANDLE_CACHE.pop(key):
+            _PARK_ORDER.pop(_haddr(h), None)
+            L.lib().lz_roots_destroy(h)
+            n += 1
+    return n
+
+
+def handle_cache_size():
+    return len(_PARK_ORDER)
+
+
 def _purge_engine(engine_value):
     """an engine is about to be destroyed (lightzero_amd._lib.OwnedEngine): its parked roots handles go first"""
-    for key in [k for k in _HANDLE_CACHE if k and k[0] == engine_value]:
-        for h, _ in _HANDLE_CACHE.pop(key):
-            L.lib().lz_roots_destroy(h)
+    flush_handle_cache(engine_value)
 
 
 L._engine_death_hooks.append(_purge_engine)
@@ -53,7 +110,7 @@ def collect_rows_ex(roots, A_row, temperature, deterministic, d_rows_ptr, row_wo
     hdr = np.zeros((B, 8 + 2 * A_row + E), np.float32)
     lg = np.zeros((B, policy_width or A_row), np.float32)
     if seed is None:
-        seed = int(np.random.randint(0, 2 ** 62))
+        seed = int(L.rs().randint(0, 2 ** 62))
     ts = None if timestep is None else L.i32(timestep)
     L.check(L.lib().lz_roots_collect_rows_ex(roots._h, float(temperature), 1 if deterministic else 0, int(seed), float(discount), d_obs_ptr,
                                              int(frame_floats), None if ts is None else ts.ctypes.data, d_rows_ptr, int(row_words), hdr,
@@ -127,11 +184,11 @@ def make_module(variant, has_deterministic_flag):
                 cnt = L.i32([len(l) for l in self._legal])
                 flat = L.i32([a for l in self._legal for a in l] or [0])
             self._key = (_engine_key(eng), variant, self.root_num, self._A, self._S)
-            parked = _HANDLE_CACHE.get(self._key)
+            parked = _unpark(self._key)
             if parked:
                 # an unpinned seed stays the handle's: the captured search graph (keyed by it) is replayed instead of re-captured,
                 # and the random streams still advance through the device-resident epoch that every prepare bumps
-                h, seed0 = parked.pop()
+                h, seed0 = parked
                 if self._seed is None:
                     self._seed = seed0
                 else:   # a pinned seed means the same streams whatever the handle did before
@@ -296,7 +353,7 @@ def make_module(variant, has_deterministic_flag):
                 L.check(L.lib().lz_roots_get_search_results(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data))
                 return dist, cnt, val, pred, lg
             temperature, deterministic = select[0], select[1]
-            seed = select[2] if len(select) > 2 and select[2] is not None else int(np.random.randint(0, 2 ** 62))
+            seed = select[2] if len(select) > 2 and select[2] is not None else int(L.rs().randint(0, 2 ** 62))
             pos = np.zeros(B, np.int32); ent = np.zeros(B, np.float64)
             L.check(L.lib().lz_roots_get_search_results_select(self._h, dist, cnt, val, pred.ctypes.data, lg.ctypes.data,
                                                                float(temperature), 1 if deterministic else 0, int(seed), pos, ent.ctypes.data))
@@ -311,7 +368,7 @@ def make_module(variant, has_deterministic_flag):
             hdr = np.zeros((B, 8 + 2 * A), np.float32)
             lg = np.zeros((B, policy_width or A), np.float32)
             if seed is None:
-                seed = int(np.random.randint(0, 2 ** 62))
+                seed = int(L.rs().randint(0, 2 ** 62))
             ts = None if timestep is None else L.i32(timestep)
             L.check(L.lib().lz_roots_collect_rows(self._h, float(temperature), 1 if deterministic else 0, int(seed), d_obs_ptr,
                                                   int(frame_floats), None if ts is None else ts.ctypes.data, d_rows_ptr, int(row_words),
@@ -325,7 +382,7 @@ def make_module(variant, has_deterministic_flag):
             pos = np.zeros(self.root_num, np.int32)
             ent = np.zeros(self.root_num, np.float64)
             if seed is None:
-                seed = int(np.random.randint(0, 2 ** 62))
+                seed = int(L.rs().randint(0, 2 ** 62))
             L.check(L.lib().lz_roots_select_action(self._h, float(temperature), 1 if deterministic else 0, int(seed), pos, ent))
             return pos, ent
 
@@ -342,14 +399,14 @@ def make_module(variant, has_deterministic_flag):
 
         def clear(self, park=False):
             if self._h is not None:
-                parked = _HANDLE_CACHE.setdefault(getattr(self, "_key", None), []) if park and getattr(self, "_key", None) else None
-                if parked is not None and len(parked) < _HANDLE_CACHE_DEPTH:
+                kept = False
+                if park and getattr(self, "_key", None):
                     try:
                         L.check(L.lib().lz_roots_enable_trace(self._h, 0))
-                        parked.append((self._h, self._seed))
+                        kept = _park(self._key, self._h, self._seed)
                     except Exception:
-                        L.lib().lz_roots_destroy(self._h)
-                else:
+                        kept = False
+                if not kept:
                     L.lib().lz_roots_destroy(self._h)
                 self._h = None
 

@@ -184,7 +184,7 @@ class Roots(object):
         pos = np.zeros(self.root_num, np.int32)
         ent = np.zeros(self.root_num, np.float64)
         if seed is None:
-            seed = int(np.random.randint(0, 2 ** 62))
+            seed = int(L.rs().randint(0, 2 ** 62))
         L.check(L.lib().lz_roots_select_action(self._h, float(temperature), 1 if deterministic else 0, int(seed), pos, ent))
         return pos, ent
 

@@ -133,12 +133,20 @@ class EfficientZeroModel(object):
             from ..mcts.ctree.ctree_muzero import mz_tree as tree
         return tree
 
+    _OWN_ROOTS_MAX = 4   # model-owned roots handles (initial_inference without roots / the Python recurrent_inference), LRU
+
     def _own_roots(self, B, slot, max_simulations, trace=False):
         """a roots handle the MODEL owns (per batch size): where initial_inference(obs) without roots leaves the root state, and
         the scratch pool of the Python recurrent_inference"""
-        cache = self.__dict__.setdefault("_own", {})
+        import collections
+        cache = self.__dict__.setdefault("_own", collections.OrderedDict())
         r = cache.get((slot, B))
+        if r is not None:
+            cache.move_to_end((slot, B))
         if r is None:
+            while len(cache) >= self._OWN_ROOTS_MAX:   # a driver whose ready-env count varies: keep the few most recent batch sizes
+                _, old = cache.popitem(last=False)
+                old.clear()   # destroyed, not parked: its pools go back to the device
             A = self.action_space_size
             r = self._tree().Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=max_simulations, engine=self._engine)
             r._bind_engine(self._engine)

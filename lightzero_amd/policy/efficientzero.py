@@ -136,7 +136,7 @@ class EfficientZeroPolicy(object):
                 e = np.exp(z - z.max())
                 policy_values = (e / e.sum()).tolist()
                 policy_values = policy_values / np.sum(policy_values)
-                idx = np.random.choice(len(legal_actions[i]), p=policy_values)
+                idx = L.rs().choice(len(legal_actions[i]), p=policy_values)
                 action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
                 output[env_id] = {'action': action, 'searched_value': pred_values[i], 'predicted_value': pred_values[i],
                                   'predicted_policy_logits': policy_logits[i]}
@@ -147,9 +147,9 @@ class EfficientZeroPolicy(object):
         if fused and self._device_noise:
             noises = None
         elif len(set(counts)) == 1:  # one vectorised draw instead of one np.random.dirichlet call per env (efficientzero.py:599-602)
-            noises = np.random.dirichlet([alpha] * counts[0], size=active_collect_env_num).astype(np.float32)
+            noises = L.rs().dirichlet([alpha] * counts[0], size=active_collect_env_num).astype(np.float32)
         else:
-            noises = [np.random.dirichlet([alpha] * c).astype(np.float32) for c in counts]
+            noises = [L.rs().dirichlet([alpha] * c).astype(np.float32) for c in counts]
         if fused:
             # no read-back (and no synchronisation) before the search: predictions come back with the search results
             if early is None:
@@ -187,13 +187,13 @@ class EfficientZeroPolicy(object):
             if self._device_select:
                 idx, entropy = dev_pos[i], dev_ent[i]
                 action = legal_actions[i][idx]
-                if eps_greedy and np.random.rand() < self.collect_epsilon:
-                    action = np.random.choice(legal_actions[i])
+                if eps_greedy and L.rs().rand() < self.collect_epsilon:
+                    action = L.rs().choice(legal_actions[i])
             elif eps_greedy:
                 idx, entropy = select_action(distributions, temperature=self._collect_mcts_temperature, deterministic=True)
                 action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
-                if np.random.rand() < self.collect_epsilon:
-                    action = np.random.choice(legal_actions[i])
+                if L.rs().rand() < self.collect_epsilon:
+                    action = L.rs().choice(legal_actions[i])
             else:
                 idx, entropy = select_action(distributions, temperature=self._collect_mcts_temperature, deterministic=False)
                 action = np.where(np.asarray(action_mask[i]) == 1.0)[0][idx]
@@ -237,9 +237,9 @@ class EfficientZeroPolicy(object):
             roots.prepare_from_inference_dirichlet(self._mcfg["root_noise_weight"], alpha, tp)
         else:
             if (counts == counts[0]).all():
-                noises = np.random.dirichlet([alpha] * int(counts[0]), size=B).astype(np.float32)
+                noises = L.rs().dirichlet([alpha] * int(counts[0]), size=B).astype(np.float32)
             else:  # ragged: one gamma draw for the whole batch, normalised per root (what np.random.dirichlet does per env)
-                g = np.random.gamma(alpha, size=int(counts.sum()))
+                g = L.rs().gamma(alpha, size=int(counts.sum()))
                 seg = np.repeat(np.arange(B), counts)
                 noises = (g / np.bincount(seg, weights=g, minlength=B)[seg]).astype(np.float32)
             roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, tp)
@@ -255,10 +255,10 @@ class EfficientZeroPolicy(object):
         if eps_greedy:
             # efficientzero.py:622-632: arg-max of the visit counts, replaced by a uniformly random LEGAL action with probability
             # collect_epsilon -- for all envs at once; the action word of the device rows is patched too
-            explore = np.nonzero(np.random.rand(B) < float(epsilon))[0]
+            explore = np.nonzero(L.rs().rand(B) < float(epsilon))[0]
             if explore.size:
                 legal = mask[explore] != 0
-                pick = (np.random.rand(explore.size) * legal.sum(1)).astype(np.int64)             # position in the legal list
+                pick = (L.rs().rand(explore.size) * legal.sum(1)).astype(np.int64)             # position in the legal list
                 acts = np.argmax(np.cumsum(legal, 1) > pick[:, None], 1).astype(np.float32)       # -> action index
                 header[explore, shard.F_ACTION] = acts
                 import torch

@@ -3,6 +3,7 @@
 (``roots_completed_value`` and ``improved_policy_probs`` included); the action is the arg-max of the improved policy."""
 import numpy as np
 
+from .. import _lib as L
 from ..mcts.tree_search.mcts_ctree import GumbelMuZeroMCTSCtree as MCTSCtree
 from .efficientzero import _g, _mcts_seed
 from .utils import select_action
@@ -47,7 +48,7 @@ class GumbelMuZeroPolicy(object):
         pred_values, policy_logits = out.value, out.policy_logits.tolist()
         if noise:
             alpha = self._mcfg["root_dirichlet_alpha"]
-            noises = [np.random.dirichlet([alpha] * int(sum(action_mask[j]))).astype(np.float32).tolist() for j in range(n)]
+            noises = [L.rs().dirichlet([alpha] * int(sum(action_mask[j]))).astype(np.float32).tolist() for j in range(n)]
             roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
         else:
             roots.prepare_from_inference_no_noise(to_play)
@@ -91,7 +92,7 @@ class GumbelMuZeroPolicy(object):
         roots = self._roots(n, legal_actions)
         model.initial_inference(data, roots, fetch=False)
         alpha = self._mcfg["root_dirichlet_alpha"]
-        noises = [np.random.dirichlet([alpha] * len(l)).astype(np.float32).tolist() for l in legal_actions]
+        noises = [L.rs().dirichlet([alpha] * len(l)).astype(np.float32).tolist() for l in legal_actions]
         roots.prepare_from_inference(self._mcfg["root_noise_weight"], noises, to_play)
         self._mcts_collect.search(roots, model, ("hbm-pool", roots), to_play)
         if frame_floats is None:

@@ -7,6 +7,7 @@ model's inference contract (the reference loop with the device tree).  Same argu
 reference (incl. ``root_sampled_actions``)."""
 import numpy as np
 
+from .. import _lib as L
 from ..mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree as MCTSCtree, _inverse_scalar_transform
 from .efficientzero import _g, _mcts_seed
 from .utils import select_action
@@ -52,7 +53,7 @@ class SampledEfficientZeroPolicy(object):
         n = data.shape[0]
         roots = self._roots(n)
         alpha = self._mcfg["root_dirichlet_alpha"]
-        noises = [np.random.dirichlet([alpha] * self._K).astype(np.float32).tolist() for _ in range(n)] if noise else None
+        noises = [L.rs().dirichlet([alpha] * self._K).astype(np.float32).tolist() for _ in range(n)] if noise else None
         if getattr(model, "_is_lz_engine_model", False):
             out = model.initial_inference(data, roots)
             pred_values, policy_logits = out.value, out.policy_logits.tolist()

@@ -1,6 +1,8 @@
 """Host-side post-search helpers (restated from lzero/policy/utils.py)."""
 import numpy as np
 
+from .. import _lib as L
+
 
 def select_action(visit_counts, temperature=1, deterministic=True):
     """lzero/policy/utils.py:637-661: p ~ N^(1/T); argmax (eval) or sample (collect); entropy in bits."""
@@ -10,7 +12,7 @@ def select_action(visit_counts, temperature=1, deterministic=True):
     if deterministic:
         action_pos = int(np.argmax(visit_counts))
     else:
-        action_pos = int(np.random.choice(len(visit_counts), p=action_probs))
+        action_pos = int(L.rs().choice(len(visit_counts), p=action_probs))
     nz = action_probs[action_probs > 0]
     entropy = float(-(nz * np.log2(nz)).sum())
     return action_pos, entropy

@@ -75,6 +75,7 @@ class _Group(object):
         self.collected_episode = self.collected_step = self.loop_steps = 0
         self.episode_info = []
         self.done = False
+        self.rs = None   # this group's host-side random stream (pipelined groups only, MuZeroVectorCollector.collect)
 
     def run_policy(self):
         """the policy forward of this step (search + select_action + rows on the device); no env or segment state is touched"""
@@ -88,8 +89,14 @@ class _Group(object):
             data = st.reshape(self.n, c._stack * ch, h, w)
         else:
             data = st.reshape(self.n, -1)
-        return np.asarray(self.policy.forward_collect_rows(data, self.mask, self.rows_out, temperature=self.temperature, to_play=self.to_play.tolist(),
-                                                           timestep=self.timestep.astype(np.int32), frame_floats=self.F, epsilon=self.epsilon))
+        def forward():
+            return np.asarray(self.policy.forward_collect_rows(data, self.mask, self.rows_out, temperature=self.temperature, to_play=self.to_play.tolist(),
+                                                               timestep=self.timestep.astype(np.int32), frame_floats=self.F, epsilon=self.epsilon))
+        if self.rs is None:      # a single group: the global np.random stream, like the reference
+            return forward()
+        from .. import _lib as L
+        with L.random_source(self.rs):   # pipelined groups: this group's own stream (the forward runs on a worker thread)
+            return forward()
 
     def finish(self, header):
         """env.step + the bookkeeping of muzero_collector.py:588-735 for this step; returns True when n_episode episodes are in"""
@@ -146,7 +153,9 @@ class MuZeroVectorCollector(object):
         group, all on the same engine model): ``collect`` then pipelines the groups -- while the device searches for one group (the
         policy forward runs on a worker thread; the library calls release the GIL) the host steps the environments of the other and
         does its segment bookkeeping, so the GPU goes from one group's search straight into the next one's.  Every group by itself runs
-        the loop of the single-group form (same transcript -> same pooled segments); only one forward is in flight at any time, so
+        the loop of the single-group form (same transcript -> same pooled segments; with more than one group every group draws its host-side
+        random numbers from a stream of its own, seeded from np.random at the start of ``collect``, so a seeded run is reproducible as long as the
+        envs do not share the global np.random stream across groups either); only one forward is in flight at any time, so
         the engine sees the same serialised call sequence."""
         self._groups_env = list(env) if isinstance(env, (list, tuple)) else [env]
         self._groups_policy = list(policy) if isinstance(policy, (list, tuple)) else [policy]
@@ -198,6 +207,13 @@ class MuZeroVectorCollector(object):
         G = len(self._groups_env)
         share = [n_episode // G + (1 if g < n_episode % G else 0) for g in range(G)]
         groups = [_Group(self, e, p, k, policy_kwargs or {}) for e, p, k in zip(self._groups_env, self._groups_policy, share)]
+        if G > 1:
+            # Pipelined groups: a group's policy forward (Dirichlet noise, eps-greedy draws, the seeds of the device-side select_action)
+            # runs on a worker thread while the main thread steps the other group's envs -- which typically draw from np.random too.
+            # Two threads interleaving on the global stream would make a seeded run irreproducible, so every group gets its own
+            # stream, seeded HERE on the main thread from np.random (np.random.seed governs it).  A single group keeps the global stream.
+            for g in groups:
+                g.rs = np.random.RandomState(int(np.random.randint(0, 2 ** 31 - 1)))
         if G == 1:
             g = groups[0]
             while not g.finish(g.run_policy()):

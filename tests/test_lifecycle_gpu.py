@@ -65,3 +65,43 @@ def test_policy_with_changing_batch_sizes_keeps_a_bounded_footprint():
             assert len(out) == B
         marks.append(_free())
     assert min(marks[-2:]) >= marks[1] - (64 << 20), marks   # the cached roots of the three sizes are re-armed, not re-allocated
+
+
+def test_parked_roots_handles_are_bounded_and_flushable():
+    """a reference-style driver builds a fresh Roots per forward; with a ready-env count that varies over 1..N every dying
+    Roots used to park its device handle (trees + latent / LSTM pools) under its own shape, without a global bound.  Now: at most
+    LZ_HANDLE_CACHE_MAX handles stay parked (LRU), the free device memory stops shrinking once the bound is reached, and
+    flush_handle_cache() gives everything back."""
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree import _tree_common as tc
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    A, S = 6, 50
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=3).state_dict())
+    tc.flush_handle_cache()
+
+    def forward(B):
+        roots = ez_tree.Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=S, engine=model.engine)
+        obs = torch.rand(B, 4, 96, 96, device="cuda")
+        model.initial_inference(obs, roots, fetch=False)
+        roots.prepare_from_inference_no_noise([-1] * B)
+        L.check(L.lib().lz_search(roots._h, 4, 19652, 1.25, 0.997, 5, 0.01))
+        assert all(sum(d) == 4 for d in roots.get_distributions())
+        del roots   # parks the handle
+
+    sizes = list(range(100, 140))   # 40 distinct batch sizes, ~50 MB of pools each
+    for B in sizes[:tc._HANDLE_CACHE_MAX + 2]:
+        forward(B)
+    gc.collect()
+    assert tc.handle_cache_size() <= tc._HANDLE_CACHE_MAX
+    mark = _free()
+    for B in sizes[tc._HANDLE_CACHE_MAX + 2:]:
+        forward(B)
+    gc.collect()
+    assert tc.handle_cache_size() <= tc._HANDLE_CACHE_MAX
+    assert _free() >= mark - (96 << 20), (mark, _free())   # 30 more shapes did not add 30 more pool sets
+    forward(sizes[-1])   # the most recent shape is re-armed, not re-created
+    n = tc.flush_handle_cache()
+    assert n >= 1 and tc.handle_cache_size() == 0
+    assert _free() >= mark, (mark, _free())
