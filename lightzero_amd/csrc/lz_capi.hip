@@ -11,6 +11,9 @@
 #include <random>
 #include <vector>
 
+#include <mutex>
+#include <unordered_set>
+
 #include "lz_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -67,10 +70,22 @@ extern "C" int lz_engine_create(int device_index, lz_engine **out)
     return LZ_OK;
 }
 
+// Live roots handles.  A host-language binding frees handles from finalizers whose order it does not control (Python's garbage
+// collector): destroying a roots handle twice, or after its engine, must be an error status, not a crash.  lz_roots_destroy therefore
+// only accepts handles that are registered here, and lz_engine_destroy takes the engine's remaining roots down with it.
+static std::mutex g_roots_mu;
+static std::unordered_set<lz_roots *> g_live_roots;
+
 extern "C" int lz_engine_destroy(lz_engine *e)
 {
     if (!e) return LZ_OK;
     (void)hipSetDevice(e->device);
+    std::vector<lz_roots *> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_roots_mu);
+        for (lz_roots *r : g_live_roots) if (r->eng == e) mine.push_back(r);
+    }
+    for (lz_roots *r : mine) (void)lz_roots_destroy(r);   // (a later lz_roots_destroy on one of them returns LZ_ERR_INVALID)
     if (e->model) lz_model_destroy(e->model);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -159,6 +174,10 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
         LZ_HIP_CHECK(hipStreamSynchronize(e->stream));  // g is a stack vector
     }
     t.res_ix = res; t.res_iy = res + B; t.res_last_action = res + 2 * B; t.res_search_len = res + 3 * B; t.res_vtp = res + 4 * B;
+    {
+        std::lock_guard<std::mutex> lk(g_roots_mu);
+        g_live_roots.insert(r);
+    }
     *out = r;
     return LZ_OK;
 }
@@ -241,6 +260,13 @@ extern "C" int lz_roots_reset_keep_inference(lz_roots *r, const int32_t *h_legal
 extern "C" int lz_roots_destroy(lz_roots *r)
 {
     if (!r) return LZ_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_roots_mu);
+        if (!g_live_roots.erase(r)) {
+            lz_set_error("lz_roots_destroy: %p is not a live roots handle (destroyed before, or its engine was destroyed)", (void *)r);
+            return LZ_ERR_INVALID;
+        }
+    }
     (void)hipSetDevice(r->eng->device);
     (void)hipStreamSynchronize(r->eng->stream);
     if (r->slab) (void)hipFree(r->slab);

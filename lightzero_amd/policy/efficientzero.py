@@ -7,6 +7,7 @@ the per-env output dict (``action``, ``visit_count_distributions``, ``visit_coun
 """
 import numpy as np
 
+from .. import _lib as L
 from ..mcts.tree_search.mcts_ctree import EfficientZeroMCTSCtree as MCTSCtree
 from .utils import select_action
 
@@ -127,7 +128,6 @@ class EfficientZeroPolicy(object):
             else:
                 pred_values = np.zeros(active_collect_env_num, np.float32)
                 logits = np.zeros((active_collect_env_num, self._collect_model.action_space_size), np.float32)
-                from .. import _lib as L
                 L.check(L.lib().lz_roots_get_root_outputs(roots._h, pred_values, logits.reshape(-1)))
             pred_values = pred_values.reshape(active_collect_env_num, 1)
             policy_logits = logits.tolist()

@@ -55,3 +55,21 @@ def test_bad_arguments_are_refused_and_the_handle_survives():
     # ---- the handle still works
     L.check(lib.lz_search(roots._h, S, 19652, 1.25, 0.997, 5, 0.01))
     assert all(sum(d) == S for d in roots.get_distributions())
+
+
+def test_destroying_a_roots_handle_twice_or_after_its_engine_is_an_error_not_a_crash():
+    """a host-language binding frees handles from finalizers whose order it does not control: lz_roots_destroy accepts live handles
+    only, lz_engine_destroy takes the engine's remaining roots with it"""
+    from lightzero_amd import _lib as L
+    lib = L.lib()
+    A, B, S = 4, 3, 5
+    eng = L.P()
+    L.check(lib.lz_engine_create(0, ctypes.byref(eng)))
+    cnt, flat = L.i32([A] * B), L.i32(list(range(A)) * B)
+    h1, h2 = L.P(), L.P()
+    L.check(lib.lz_roots_create(eng, 0, B, A, S, flat, cnt, ctypes.byref(h1)))
+    L.check(lib.lz_roots_create(eng, 1, B, A, S, flat, cnt, ctypes.byref(h2)))
+    L.check(lib.lz_roots_destroy(h1))
+    assert "not a live roots handle" in _err(lib.lz_roots_destroy(h1))     # twice
+    L.check(lib.lz_engine_destroy(eng))                                       # ... takes h2 with it
+    assert "not a live roots handle" in _err(lib.lz_roots_destroy(h2))     # after its engine
