@@ -188,6 +188,7 @@ struct lz_traverse_args {
     uint64_t seed;
     uint32_t counter;
     int fresh_minmax = 0;      // k_traverse only: the first selection of a search starts a fresh CMinMaxStats (cminimax.cpp:6-10) itself
+    unsigned long long *dbg_ts = nullptr;  // timing experiments (debug build, LZ_DEBUG_TREE_SEP_TS): [64 roots][8] cycle stamps of k_backprop_traverse
 };
 // one expand + backup + next-selection step for every root (dev_step_lds in lz_tree_dev.h), as run by k_backprop_traverse_lds
 // or by the convolution chain's prologue (lz_launch_chain with a step)

@@ -415,8 +415,7 @@ __global__ __launch_bounds__(256) void k_conv_wino(lz_conv_args a)
         for (int pp = 0; pp < PCH; ++pp) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                constexpr int dummy = 0; (void)dummy;
-                const int s = (ch * PCH + pp) * G + g;
+                        const int s = (ch * PCH + pp) * G + g;
                 const f32x4 bfr = wq[s % R];
                 if (s + R < STEPS) wq[s % R] = wl[(s + R) * 64];
                 f32x4 af[MTW];
@@ -2031,6 +2030,207 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM step, 32-row workgroups with PIPELINED staging (round 4).  What bounds k_lstm2 at its 16-row default is the vector-memory path
+// of a CU: 2 x (278 KB of gate weights + 70 KB of rows) = 696 KB per CU and launch at the ~34 B/clk a CU receives under
+// MFMA load.  32 rows per workgroup halve the weight stream -- every fragment feeds TWO 16-row MFMA tiles from the same registers:
+// 278 + 139 = 417 KB per CU -- but the k_lstm2<..., 32> form staged all 139 KB before its first MFMA with nothing else resident on
+// the CU to hide it (14.2 us against 13.6 us).  Here the rows arrive in chunks of 16 k-steps (32 rows x 256 columns = 32 KB): chunk
+// c + 1 is requested into registers before the MFMAs of chunk c start and written to ITS OWN region of LDS after them (no buffer is
+// reused, so one barrier per chunk and no wait on the way in); the first MFMA needs 32 KB, and that chunk is x columns only (no
+// dependent pool gather).  grid = (H / 16, ceil(B / 32)) = 256 workgroups at 256 roots: one per CU, unit tiles walk the XCDs.
+// Same k order and accumulation as k_lstm2 -> bit-identical gates, cell states and split-head partials (tools/dump_search.py --compare,
+// 256 x 50 and 67 x 12).  MEASURED (same box, alternating, in-graph stamps): 15.15 us per launch against 15.05 us for the 16-row default
+// (first workgroup start -> last end 12.9 vs 12.7 us) -- halving the weight stream buys nothing: the 9 us of matrix work plus the
+// exposed prologue (first chunk + ring) and cell epilogue of ONE workgroup per CU cost what two resident 16-row workgroups lose to the
+// stream.  Kept behind LZ_LSTM3=1 (qualified, not the default).
+// SH: the split-head first layers (lz_lstm_args::sh_*) for both 16-row halves.
+// ------------------------------------------------------------------------------------------------
+template <int NKB, bool SH>
+__global__ __launch_bounds__(256) void k_lstm3(lz_lstm_args a)
+{
+    constexpr int K = NKB * 16, PS = K + 4, R = 12, MR = 32, NTHR = 256;
+    constexpr int CH = 16, NCH = (NKB + CH - 1) / CH;   // k-steps per staging chunk; chunks
+    constexpr int K4 = K / 4, F4C = CH * 4, NLD = F4C / 8;   // float4 per row; per row and chunk; per thread and chunk (8 threads per row)
+    constexpr int NQ = MR * 16 / NTHR;                  // (row, unit) pairs per thread in the cell epilogue
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [32][PS]; reused for the gate exchange
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x, r0 = blockIdx.y * MR;
+    const int H = a.H, KX = a.KX;
+    const size_t slot = (size_t)a.B * H;
+    lz_stamp_begin(a.stamp);
+    // ---- requests in the order of use: the first weight fragments, the first chunk of rows (x columns: no gather), the pool slot
+    const float4 *wp = reinterpret_cast<const float4 *>(a.wf) + ((size_t)(tile * 4 + wv) * NKB) * 64 + lane;
+    float4 wq[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)min(s, NKB - 1) * 64];
+    const int srow = tid >> 3, spart = tid & 7;
+    const int sb = min(r0 + srow, a.B - 1);
+    const int kx4 = KX >> 2;
+    const float *xrow = a.x + (size_t)sb * KX;
+    float *sdst = smem + srow * PS;
+    f32x4 cv[NLD];
+    // chunk 0 lies inside the x columns for every shape this kernel is instantiated for (KX >= 256)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) cv[i] = *reinterpret_cast<const f32x4 *>(xrow + (spart + 8 * i) * 4);
+    const float *hrow = a.h_pool + (size_t)a.gather_ix[sb] * slot + (size_t)sb * H - KX;   // (k4 >= kx4 ? hrow : xrow) + 4 k4
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int k4 = min(c * F4C + spart + 8 * i, K4 - 1);
+            cv[i] = *reinterpret_cast<const f32x4 *>((k4 < kx4 ? xrow : hrow) + k4 * 4);
+        }
+    };
+    auto store_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int k4 = c * F4C + spart + 8 * i;
+            if (k4 < K4) *reinterpret_cast<f32x4 *>(sdst + k4 * 4) = cv[i];
+        }
+    };
+    // split heads: operands of the first-layer partial products (consumed after the K loop): rows r0 .. r0 + 31 of the combined
+    // 1x1-conv outputs, columns 36 tile .. + 35 (288 float4: one per thread + 32 more), this wave's weight slices
+    f32x4 sh_av[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, sh_bv[3], sh_brv;
+    if constexpr (SH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = min(tid + NTHR * u, 32 * 9 - 1), row = idx / 9, c4 = idx - row * 9;
+            const int bb = min(r0 + row, a.B - 1);
+            sh_av[u] = *reinterpret_cast<const f32x4 *>(a.sh_pv + (size_t)bb * a.sh_kc + 36 * tile + 4 * c4);
+        }
+        const float *bp = a.sh_w1c + (((size_t)tile * 4 + wv) * 64 + lane) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sh_bv[i] = *reinterpret_cast<const f32x4 *>(bp + 4 * i);
+        sh_brv = *reinterpret_cast<const f32x4 *>(a.sh_w1r + (((size_t)tile * 2 + (wv & 1)) * 64 + lane) * 4);
+    }
+    // the cell epilogue's operands (previous cell state, gate biases, BatchNorm, reset flag) for this thread's two (row, unit) pairs
+    float c_prev[NQ], gb[NQ][4], bns[NQ], bnt[NQ];
+    int slen[NQ];
+    const float *bnsp = a.bn_scale ? a.bn_scale : a.bias, *bntp = a.bn_scale ? a.bn_shift : a.bias;
+    const int32_t *slp = a.search_len ? a.search_len : a.gather_ix;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
+        const int b = min(r0 + row, a.B - 1), unit = tile * 16 + u;
+        c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + 4 * unit);
+        gb[q][0] = b4.x; gb[q][1] = b4.y; gb[q][2] = b4.z; gb[q][3] = b4.w;
+        bns[q] = bnsp[unit]; bnt[q] = bntp[unit];
+        slen[q] = slp[b];
+    }
+    store_chunk(0);
+    __syncthreads();
+    const float *sA0 = smem + (lane & 15) * PS + (lane >> 4) * 4, *sA1 = sA0 + 16 * PS;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) load_chunk(c + 1);   // in flight under this chunk's MFMAs
+        const int s0 = c * CH, s1 = (c + 1) * CH < NKB ? (c + 1) * CH : NKB;
+        float4 a0 = *reinterpret_cast<const float4 *>(sA0 + s0 * 16), a1 = *reinterpret_cast<const float4 *>(sA1 + s0 * 16);
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            const float4 bfr = wq[s % R];
+            if (s + R < NKB) wq[s % R] = wp[(size_t)(s + R) * 64];
+            float4 n0 = a0, n1 = a1;
+            if (s + 1 < s1) {
+                n0 = *reinterpret_cast<const float4 *>(sA0 + (s + 1) * 16);
+                n1 = *reinterpret_cast<const float4 *>(sA1 + (s + 1) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a0, j), vget(bfr, j), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(a1, j), vget(bfr, j), acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
+        }
+        if (c + 1 < NCH) {
+            store_chunk(c + 1);
+            __syncthreads();
+        }
+    }
+    __syncthreads();  // every wave is done reading the staged rows: the buffer becomes the gate exchange
+    float *sG = smem;                  // [4 gates][32 rows][17]
+    float *sHb = smem + 4 * MR * 17;   // split heads: relu(bn(h')) [32][17]
+    float *sA2 = sHb + MR * 17;        //              the value | policy heads' input slice [32 rows][40] (36 used)
+    float *sP = sA2 + MR * 40;         //              the partial block of this workgroup [32 rows][3 heads][32 hidden]
+    if constexpr (SH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + NTHR * u;
+            if (idx < 32 * 9) *reinterpret_cast<f32x4 *>(sA2 + (idx / 9) * 40 + (idx % 9) * 4) = sh_av[u];
+        }
+    }
+    {
+        const int col = lane & 15, rq = 4 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sG[(wv * MR + rq + q) * 17 + col] = acc0[q];
+            sG[(wv * MR + 16 + rq + q) * 17 + col] = acc1[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
+        const int b = r0 + row;
+        if (b >= a.B) { if constexpr (SH) sHb[row * 17 + u] = 0.0f; continue; }
+        const int unit = tile * 16 + u;
+        const float gi = sG[(0 * MR + row) * 17 + u] + gb[q][0];
+        const float gf = sG[(1 * MR + row) * 17 + u] + gb[q][1];
+        const float gg = sG[(2 * MR + row) * 17 + u] + gb[q][2];
+        const float go = sG[(3 * MR + row) * 17 + u] + gb[q][3];
+        const float cn = sigmoidf_(gf) * c_prev[q] + sigmoidf_(gi) * tanhf_(gg);
+        const float hn = sigmoidf_(go) * tanhf_(cn);
+        const bool reset = a.search_len && a.horizon > 0 && (slen[q] % a.horizon) == 0;  // mcts_ctree.py:859-863
+        a.h_out[(size_t)b * H + unit] = reset ? 0.0f : hn;
+        a.c_out[(size_t)b * H + unit] = reset ? 0.0f : cn;
+        const float hb = a.bn_scale ? fmaxf(hn * bns[q] + bnt[q], 0.0f) : hn;
+        a.hbn_out[(size_t)b * H + unit] = hb;
+        if constexpr (SH) sHb[row * 17 + u] = hb;
+    }
+    if constexpr (SH) {
+        // value | policy heads, first layer: [32 rows x 36] x [36 x this wave's 16 of the 64 hidden columns], one MFMA chain per 16-row half
+        {
+            f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const float bw = sh_bv[ks >> 2][ks & 3];
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sA2[(lane & 15) * 40 + 4 * ks + (lane >> 4)], bw, p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sA2[(16 + (lane & 15)) * 40 + 4 * ks + (lane >> 4)], bw, p1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sP[(4 * (lane >> 4) + q) * 96 + (wv >> 1) * 32 + 16 * (wv & 1) + (lane & 15)] = p0[q];
+                sP[(16 + 4 * (lane >> 4) + q) * 96 + (wv >> 1) * 32 + 16 * (wv & 1) + (lane & 15)] = p1[q];
+            }
+        }
+        __syncthreads();   // relu(bn(h')) of all 32 x 16 (row, unit) pairs is in sHb
+        {   // value-prefix head, first layer: wave (half = wv >> 1, column half = wv & 1): [16 rows x 16 units] x [16 x 16 hidden columns]
+            const int half = wv >> 1;
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sHb[(16 * half + (lane & 15)) * 17 + 4 * ks + (lane >> 4)], sh_brv[ks], pacc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sP[(16 * half + 4 * (lane >> 4) + q) * 96 + 64 + 16 * (wv & 1) + (lane & 15)] = pacc[q];
+        }
+        __syncthreads();
+        // the block goes out as whole 128-byte lines: (row, head) = 32 floats at [root][head][unit tile][32]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + NTHR * i;   // 32 rows x 24 float4
+            const int row = idx / 24, c4 = idx % 24;
+            if (r0 + row < a.B)
+                *reinterpret_cast<f32x4 *>(a.sh_part + ((size_t)(r0 + row) * 3 + (c4 >> 3)) * (gridDim.x * 32) + (size_t)tile * 32 + (c4 & 7) * 4) =
+                    *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4);
+        }
+    }
+    lz_stamp_end(a.stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
 // heads.  grid = (ceil(B/4), nheads), block = 256: four roots share every weight fetch.
 // ------------------------------------------------------------------------------------------------
 constexpr int EPB = 4;
@@ -2615,6 +2815,14 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     // under the other's MFMAs; measured 0.6 us per launch faster than 32-row tiles (LZ_LSTM_ROWS32=1) although the gate weights
     // are streamed twice as often
     static const char *big_rows = getenv("LZ_LSTM_ROWS32");
+    static const char *lstm3 = getenv("LZ_LSTM3");   // the pipelined 32-row kernel (A/B switch while it is being qualified)
+    if (nkb == 68 && !xf && !big_rows && lstm3 && a.KX == 576 && a.H == 512 && a.B >= 32) {
+        const dim3 g3(a.H / 16, (a.B + 31) / 32);
+        const size_t l3 = (size_t)32 * ((size_t)nkb * 16 + 4) * 4;
+        if (a.sh_part && a.sh_kc == 1152) hipLaunchKernelGGL((k_lstm3<68, true>), g3, block, l3, s, a);
+        else hipLaunchKernelGGL((k_lstm3<68, false>), g3, block, l3, s, a);
+        return true;
+    }
     if (nkb == 68 && !xf && !big_rows) {
         static const char *nosplit = getenv("LZ_LSTM_NOSPLIT");  // the one-burst staging (A/B timing, parity: both forms are bit-identical)
         if (a.KX == 576 && !nosplit && a.sh_part && a.H == 512 && a.sh_kc == 1152)

@@ -1307,6 +1307,14 @@ extern "C" int lz_debug_read_tree_ts(unsigned long long *h_out)   // LZ_DEBUG_TR
     LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_ts, 16 * 8, hipMemcpyDeviceToHost));   // [0..6] the tree wave, [8..14] head wave 1 (split heads)
     return LZ_OK;
 }
+static unsigned long long *g_tree_sep_ts = nullptr;
+extern "C" int lz_debug_read_tree_sep_ts(unsigned long long *h_out)   // LZ_DEBUG_TREE_SEP_TS=1: [64 roots][8] stamps of the last separate tree step
+{
+    LZ_REQUIRE(g_tree_sep_ts != nullptr && h_out != nullptr, "LZ_DEBUG_TREE_SEP_TS was not set");
+    LZ_HIP_CHECK(hipDeviceSynchronize());
+    LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_sep_ts, 64 * 8 * 8, hipMemcpyDeviceToHost));
+    return LZ_OK;
+}
 static bool dbg_skip(char k)
 {
     const char *v = getenv("LZ_DEBUG_SKIP");
@@ -1460,6 +1468,12 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     }
     if (r->stamps_on && r->stamps)   // {start, end} x {chain, LSTM} per pool slot, cleared per search
         hipLaunchKernelGGL(k_stamp_init, dim3((unsigned)((t.NN * 4 + 255) / 256)), dim3(256), 0, s, r->stamps, t.NN * 4);
+#ifdef LZ_DEBUG_KNOBS
+    if (getenv("LZ_DEBUG_TREE_SEP_TS")) {
+        if (!g_tree_sep_ts) (void)lz_dev_malloc((void **)&g_tree_sep_ts, 64 * 8 * 8);
+        ta.dbg_ts = g_tree_sep_ts;
+    }
+#endif
     ta.fresh_minmax = 1;   // ... which the first selection starts itself
     lz_tree_launch_traverse(t, ta, delta, r->d_to_play, s);
     ta.fresh_minmax = 0;
@@ -1536,7 +1550,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

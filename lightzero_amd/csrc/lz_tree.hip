@@ -142,11 +142,25 @@ __global__ __launch_bounds__(64) void k_backprop_traverse(lz_tree_dev t, int new
     leaf_in<NC, VARIANT> L;
     load_leaf<NC, VARIANT>(t, b, vps, values, logits, nullptr, horizon, nullptr, L);
     const int vtp = vtp_in[b];
+#ifdef LZ_DEBUG_KNOBS
+    const bool stamp = a.dbg_ts && b < 64 && threadIdx.x == 0;
+#define LZ_SEP_TS(i) do { if (stamp) a.dbg_ts[b * 8 + i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LZ_SEP_TS(i) do { } while (0)
+#endif
+    LZ_SEP_TS(0);
+    LZ_SEP_TS(1);
     dev_backprop<NC, VARIANT, false>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_SEP_TS(2);
     dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp);
+    LZ_SEP_TS(3);
+#ifdef LZ_DEBUG_KNOBS
+    if (stamp) { a.dbg_ts[b * 8 + 4] = (unsigned long long)L.d; a.dbg_ts[b * 8 + 5] = (unsigned long long)t.res_search_len[b]; }
+#endif
+#undef LZ_SEP_TS
 }
 
 // ReZero (search_with_reuse): cbatch_traverse_with_reuse / cbatch_backpropagate_with_reuse (cnode.cpp:603-649, 965-1072)
@@ -628,7 +642,14 @@ static void launch_bt_v(const lz_tree_dev &t, int idx, float discount, const flo
     // path lengths are bounded by the node count, so the previous path fits the same [nn] arrays
     const char *no_lds = getenv("LZ_TREE_NO_LDS");  // parity tests compare the two instantiations
     const size_t lds = lz_tree_lds_bytes(t, idx);
-    if (!no_lds && lds <= lz_tree_lds_limit(16 * 1024) && lds <= 64 * 1024 && nchunks(t.A) <= 2) {
+    // LZ_TREE_LDS_LIMIT_SEPARATE (experiments): a larger LDS budget for the separate launch than for the chain's fused prologue
+    // (lz_chain_fusable keeps lz_tree_lds_limit).  Measured on BASELINE configs[2] (trees up to 40 KB): 78.5 ms per step with 64 KB
+    // against 79.9 ms with the default -- staging a large tree costs what the walk's LDS hits save.  What bounds the walk (debug stamps,
+    // tools/tree_sep_timing.py: 2.4 k cycles per level at depth 48) is instruction issue of ONE wave per SIMD, not memory: a one-level
+    // lookahead (every child's children requested under the scoring) and a per-launch table of the visit-count factors -- both
+    // bit-exact -- left the launch at 73.8 us (73.5 before) and were taken out again.
+    static const size_t sep_limit = []() { const char *v = getenv("LZ_TREE_LDS_LIMIT_SEPARATE"); return v && *v ? (size_t)strtoul(v, nullptr, 0) : (size_t)0; }();
+    if (!no_lds && lds <= std::max(lz_tree_lds_limit(16 * 1024), sep_limit) && lds <= 64 * 1024 && nchunks(t.A) <= 2) {
         if (nchunks(t.A) == 1) hipLaunchKernelGGL((k_backprop_traverse_lds<1, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
         else hipLaunchKernelGGL((k_backprop_traverse_lds<2, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
         return;
