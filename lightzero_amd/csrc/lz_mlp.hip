@@ -19,7 +19,8 @@ struct DenseW {
 };
 
 struct lz_mlp_model {
-    int OBS = 0, L = 0, H = 0, A = 0, ENC = 0, PA = 0, SUP = 0, Wmax = 0;
+    int OBS = 0, L = 0, H = 0, A = 0, ENC = 0, PA = 0, SUP = 0, RSUP = 0, Wmax = 0;   // RSUP: the reward head's support (MuZeroModelMLP may have its own)
+    float rsup_min = 0.0f;
     bool lstm = false, res = false, continuous = false;
     int enc_mode = 2;  // lz_dense_job.x2_mode of the action encoding
     std::vector<DenseW> rep, dyn1, dyn2, rew, common, val, pol;
@@ -121,6 +122,8 @@ int lz_mlp_finalize(lz_engine *e)
     const int act = c.activation == 1 ? 2 : 1;
     MlpBuilder mb{b, m, act};
     M.OBS = c.obs_c; M.L = c.num_channels; M.A = c.action_space_size; M.SUP = c.support_size;
+    M.RSUP = c.reward_support_size > 0 ? c.reward_support_size : c.support_size;   // (lz_model_create admits it for model_type 2 only)
+    M.rsup_min = c.reward_support_size > 0 ? c.reward_support_min : c.support_min;
     M.lstm = c.model_type != 2;
     M.H = M.lstm ? c.lstm_hidden_size : 0;
     M.res = c.res_connection_in_dynamics != 0;
@@ -197,7 +200,7 @@ int lz_mlp_finalize(lz_engine *e)
         if (M.rep.empty() || M.rep.front().K != M.OBS || M.rep.back().N != M.L) b.err = "representation network shape mismatch";
         else if (M.dyn1.empty() || M.dyn1.front().K != M.L + M.ENC || M.dyn1.back().N != M.L) b.err = "dynamics network shape mismatch (latent + action encoding)";
         else if (M.res && (M.dyn2.empty() || M.dyn2.back().N != M.L)) b.err = "fc_dynamics_2 shape mismatch";
-        else if (M.rew.empty() || M.rew.back().N != M.SUP || M.rew.front().K != (M.lstm ? M.H : M.L)) b.err = "reward head shape mismatch";
+        else if (M.rew.empty() || M.rew.back().N != M.RSUP || M.rew.front().K != (M.lstm ? M.H : M.L)) b.err = "reward head shape mismatch";
         else if (M.val.empty() || M.val.back().N != M.SUP) b.err = "value head shape mismatch";
         else if (M.pol.empty() || M.pol.back().N != M.PA) b.err = "policy head shape mismatch";
         else if (M.common.empty() || M.common.back().N != M.L) b.err = "fc_prediction_common shape mismatch";
@@ -234,7 +237,7 @@ int lz_mlp_ensure_pools(lz_roots *r)
     if (int rc = lz_roots_release_pools_if_stale(r)) return rc;
     if (r->pool_slab) return LZ_OK;
     const lz_mlp_model &M = *r->eng->model->mlp;
-    const size_t B = r->t.B, NN = r->t.NN, L = M.L, H = M.H, PA = M.PA, W = M.Wmax, SUP = M.SUP;
+    const size_t B = r->t.B, NN = r->t.NN, L = M.L, H = M.H, PA = M.PA, W = M.Wmax, SUP = std::max(M.SUP, M.RSUP);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up_(off + bytes, 256); return o; };
     const size_t o_lat = take(NN * B * L * 4), o_h = take(NN * B * H * 4), o_c = take(NN * B * H * 4), o_vp = take(NN * B * 4),
@@ -477,7 +480,7 @@ void lz_mlp_recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     Act rout;
     const int lrw = P.chain(le + 1, M.rew, rin, r->mt[12], r->mt[1], r->dbg_logits[1], &rout);
     lz_rowfinal_job rf{};
-    rf.logits = r->dbg_logits[1]; rf.N = M.SUP; rf.support_min = c.support_min; rf.out_scalar = r->sim_vp + (size_t)slot * B;
+    rf.logits = r->dbg_logits[1]; rf.N = M.RSUP; rf.support_min = M.rsup_min; rf.out_scalar = r->sim_vp + (size_t)slot * B;
     // both row finishers (value, value prefix / reward) share the last launch
     const int lfin = std::max(lrw, lvv) + 1;
     P.add_final(lfin, vf);

@@ -52,8 +52,8 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->model_type >= 0 && cfg->model_type <= 4, "model_type must be 0 (EfficientZeroModel), 1 (MuZeroModel), 2 (MuZeroModelMLP), 3 (EfficientZeroModelMLP) or 4 (SampledEfficientZeroModelMLP)");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->reward_support_size >= 0 && cfg->reward_support_size <= 768, "reward_support_size must be in [0, 768] (0 = the value support)");
-    LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
-               "a reward support of its own: MuZeroModel (conv) only (the EfficientZero driver transforms the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
+    LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || cfg->model_type == 2 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
+               "a reward support of its own: the MuZero models only (the EfficientZero drivers transform the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {
         // vector observations: obs_c = observation_shape, num_channels = latent_state_dim; the layer widths come from the tensors
         LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_h == 1 && cfg->obs_w == 1, "MLP models take obs_c = observation_shape, obs_h = obs_w = 1");

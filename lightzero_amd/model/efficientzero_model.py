@@ -54,8 +54,15 @@ class EfficientZeroModel(object):
         if value_support_range[2] != 1. or reward_support_range[2] != 1.:
             raise NotImplementedError("supports with step 1")
         if tuple(reward_support_range) != tuple(value_support_range) and self._model_type != 1:
-            # the reference's EfficientZero driver transforms the value prefix with the VALUE handle (mcts_ctree.py:839-841)
-            raise NotImplementedError("EfficientZero: reward and value supports must be equal (MuZeroModel takes a reward support of its own)")
+            # The reference's EfficientZero driver transforms the value prefix with the VALUE handle (mcts_ctree.py:839-841):
+            # reward_support_range only sizes the value-prefix head.  Another range of the SAME size therefore behaves exactly like
+            # equal supports (in the reference and here); another size fails in the reference's own driver with a shape error.
+            rs = int(round((reward_support_range[1] - reward_support_range[0]) / reward_support_range[2]))
+            vs = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
+            if rs != vs:
+                raise NotImplementedError("EfficientZero: a reward support of another SIZE than the value support fails in the reference's own "
+                                          "driver (the value handle is applied to the value prefix, mcts_ctree.py:839-841); MuZeroModel takes one")
+            reward_support_range = value_support_range
         if not (reward_head_channels == value_head_channels == policy_head_channels):
             raise NotImplementedError("head channel counts must be equal")
         self.observation_shape = tuple(observation_shape)

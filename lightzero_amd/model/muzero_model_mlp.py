@@ -21,8 +21,19 @@ class _EngineModelMLP(EfficientZeroModel):
                  sigma_type='conditioned', bound_type=None, engine=None, **kwargs):
         if not categorical_distribution or state_norm:
             raise NotImplementedError("engine model: categorical_distribution=True, state_norm=False")
-        if tuple(reward_support_range) != tuple(value_support_range) or value_support_range[2] != 1.:
-            raise NotImplementedError("reward and value supports must be equal with step 1")
+        if value_support_range[2] != 1. or reward_support_range[2] != 1.:
+            raise NotImplementedError("supports with step 1")
+        rsize = int(round((reward_support_range[1] - reward_support_range[0]) / reward_support_range[2]))
+        vsize = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
+        own_reward_support = tuple(reward_support_range) != tuple(value_support_range)
+        if own_reward_support and self._uses_lstm:
+            # The reference's EfficientZero drivers transform the value prefix with the VALUE handle (mcts_ctree.py:839-841,
+            # mcts_ctree_sampled.py): reward_support_range only sizes the head.  Equal sizes behave exactly like equal supports there
+            # (and here); unequal sizes fail in the reference with a shape error.
+            if rsize != vsize:
+                raise NotImplementedError("EfficientZero: a reward support of another SIZE than the value support fails in the reference's own "
+                                          "driver (the value handle is applied to the value prefix, mcts_ctree.py:839-841)")
+            own_reward_support = False
         if norm_type not in ('BN', 'LN'):
             raise NotImplementedError("norm_type must be 'BN' or 'LN'")
         if continuous_action_space and sigma_type != 'conditioned':
@@ -34,7 +45,7 @@ class _EngineModelMLP(EfficientZeroModel):
         self.continuous_action_space = bool(continuous_action_space)
         self.num_of_sampled_actions = int(num_of_sampled_actions)
         self.value_support_size = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
-        self.reward_support_size = self.value_support_size
+        self.reward_support_size = rsize
         self._policy_width = 2 * self.action_space_size if self.continuous_action_space else self.action_space_size
         self._engine = engine if engine is not None else L.engine_for_new_model()
         enc = 2 if self.continuous_action_space else (0 if discrete_action_encoding_type == 'one_hot' else 1)
@@ -42,6 +53,8 @@ class _EngineModelMLP(EfficientZeroModel):
                          self.lstm_hidden_size, 0, 0, self.value_support_size, float(value_support_range[0]), 1e-5, 0,
                          self._activation, 1 if res_connection_in_dynamics else 0, enc, self.num_of_sampled_actions, 0,
                          1 if bound_type == 'tanh' else 0, 1e-5)
+        if own_reward_support:   # MuZeroModelMLP: the MuZero driver transforms rewards with the REWARD handle (mcts_ctree.py:340-346)
+            cfg.reward_support_size, cfg.reward_support_min = rsize, float(reward_support_range[0])
         self._create(cfg)
 
     def _latent_shape(self):

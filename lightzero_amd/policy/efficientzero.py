@@ -217,12 +217,12 @@ class EfficientZeroPolicy(object):
         (header)`` does the per-step bookkeeping of muzero_collector.py:588-620 for all envs at once.  No per-env Python loop:
         one np.nonzero, one Dirichlet draw, one read-back."""
         from .. import shard
-        if bool(_g(self._cfg, "collect_with_pure_policy", False)):
-            raise NotImplementedError("forward_collect_rows runs the search; collect_with_pure_policy is served by _forward_collect")
         self.collect_epsilon = epsilon
         model = self._collect_model
         B, A = data.shape[0], model.action_space_size
         mask = np.asarray(action_mask)
+        if bool(_g(self._cfg, "collect_with_pure_policy", False)):
+            return self._pure_policy_rows(data, mask, rows_out, to_play, timestep, frame_floats)
         roots = self._roots_cache.get(B)
         if roots is None:
             roots = self._roots(B, [np.nonzero(mask[j])[0].tolist() for j in range(B)])
@@ -263,6 +263,52 @@ class EfficientZeroPolicy(object):
                 header[explore, shard.F_ACTION] = acts
                 import torch
                 rows_out[torch.as_tensor(explore, device=rows_out.device), shard.F_ACTION] = torch.as_tensor(acts, device=rows_out.device)
+        return header
+
+    def _pure_policy_rows(self, data, mask, rows_out, to_play, timestep, frame_floats):
+        """``collect_with_pure_policy`` on the rows path (efficientzero.py:597,644-655; muzero_collector.py:98-99,505,596): no search -- the
+        action is drawn from softmax(policy logits over the legal actions), the stored search statistics are the collector's
+        ``temp_visit_list`` (zeros) and the predicted value (``store_search_stats(temp_visit_list, pred_value)``).  One inference, one
+        vectorised draw for all envs, the rows assembled on the device (header upload + the newest frame sliced from ``data``)."""
+        import torch
+        from .. import shard
+        model = self._collect_model
+        B, A = data.shape[0], model.action_space_size
+        roots = self._roots_cache.get(B)
+        if roots is None:
+            roots = self._roots(B, [np.nonzero(mask[j])[0].tolist() for j in range(B)])
+        model.initial_inference(data, roots, fetch=False)
+        pred = np.zeros(B, np.float32)
+        logits = np.zeros((B, A), np.float32)
+        L.check(L.lib().lz_roots_get_root_outputs(roots._h, pred, logits.reshape(-1)))
+        legal = mask != 0
+        # torch.softmax over the legal entries (float32: max-subtracted exponentials), renormalised in float64 like the reference's
+        # ``policy_values / np.sum(policy_values)``; one inverse-CDF draw per env instead of np.random.choice per env
+        z = np.where(legal, logits, -np.inf).astype(np.float32)
+        e = np.exp(z - z.max(1, keepdims=True)).astype(np.float32)
+        p = (e / e.sum(1, keepdims=True)).astype(np.float64)
+        p /= p.sum(1, keepdims=True)
+        u = L.rs().rand(B)
+        actions = np.minimum((np.cumsum(p, 1) < u[:, None]).sum(1), A - 1)
+        # a draw can only land on a legal action (zero-probability entries add nothing to the CDF); guard the float edge u ~ 1
+        last_legal = A - 1 - np.argmax(legal[:, ::-1], 1)
+        actions = np.where(legal[np.arange(B), actions], actions, last_legal)
+        tp = np.asarray(list(to_play) if len(to_play) == B else [to_play[0]] * B, np.float32)
+        header = np.zeros((B, shard.HEADER + 2 * A), np.float32)
+        header[:, shard.F_ACTION] = actions
+        header[:, shard.F_ROOT_VALUE] = pred      # 'searched_value': pred_values (efficientzero.py:651)
+        header[:, shard.F_PRED_VALUE] = pred
+        header[:, shard.F_TO_PLAY] = tp
+        header[:, shard.F_TIMESTEP] = -1 if timestep is None else np.asarray(timestep, np.float32)
+        header[:, shard.F_N_LEGAL] = legal.sum(1)
+        header[:, shard.HEADER + A:shard.HEADER + 2 * A] = mask   # child visits stay zero (temp_visit_list), entropy 0
+        if rows_out is not None:
+            if frame_floats is None:
+                frame_floats = rows_out.shape[1] - shard.HEADER - 2 * A
+            HW = shard.HEADER + 2 * A
+            rows_out[:, :HW] = torch.from_numpy(header).to(rows_out.device, non_blocking=True)
+            if frame_floats > 0 and hasattr(data, "data_ptr"):
+                rows_out[:, HW:HW + frame_floats] = data.reshape(B, -1)[:, -frame_floats:].to(rows_out.device)
         return header
 
     def _forward_eval(self, data, action_mask, to_play=[-1], ready_env_id=None, **kwargs):

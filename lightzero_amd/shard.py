@@ -30,6 +30,19 @@ def shard_range(n_envs, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def plan_gpus(total_envs, max_gpus, roots_per_gpu_full=256):
+    """How many of the ``max_gpus`` devices a batch of ``total_envs`` roots should be sharded over.  The conv models' chain launch is ONE
+    workgroup per root, so below one root per CU (256 on MI355X) a GPU's matrix pipes idle in proportion: measured on BASELINE
+    configs[3] (Go 9x9, 200 simulations), 64 / 128 / 256 roots per GPU take 19.1 / 19.5 / 20.4 ms per step -- the same time for a
+    quarter of the work -- and the chain runs at 0.22 / 0.86 of the fp32-matrix peak at 64 / 256 roots (profiles/r03_cfg3*.json).
+    So: the fewest GPUs that still give every GPU at most ``roots_per_gpu_full`` roots ... unless that leaves GPUs that would each get a
+    full share anyway.  -> (n_gpus, [roots per rank]); 512 envs on an 8-GPU node -> 2 GPUs x 256 (12.5k env-steps/s per GPU instead of
+    8 x 3.4k), 2048 envs -> 8 x 256."""
+    total_envs, max_gpus = int(total_envs), max(1, int(max_gpus))
+    n = min(max_gpus, max(1, -(-total_envs // int(roots_per_gpu_full))))
+    return n, [hi - lo for lo, hi in (shard_range(total_envs, q, n) for q in range(n))]
+
+
 def row_width(action_space_size, frame_floats, extra_words=0):
     """``extra_words``: the block the sampled / Gumbel families add between the action mask and the frame (root_sampled_actions
     [K * D] / improved_policy_probs [A], game_segment.py:254-258); ``action_space_size`` = K for Sampled-EfficientZero rows"""

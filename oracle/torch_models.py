@@ -473,15 +473,18 @@ def _encode_action(action, latent, continuous, action_space_size, encoding):
 class MuZeroModelMLP(nn.Module):  # lzero/model/muzero_model_mlp.py:13-338 (inference graph only)
     def __init__(self, observation_shape=4, action_space_size=2, latent_state_dim=128, reward_head_hidden_channels=(32,),
                  value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,), support_range=(-300., 301., 1.),
-                 norm_type="BN", discrete_action_encoding_type="one_hot", res_connection_in_dynamics=False):
+                 norm_type="BN", discrete_action_encoding_type="one_hot", res_connection_in_dynamics=False,
+                 reward_support_range=None, value_support_range=None):
         super().__init__()
         self.action_space_size, self.encoding = action_space_size, discrete_action_encoding_type
-        self.support_size = len(torch.arange(*support_range))
+        # muzero_model_mlp.py:73-74: the two heads are sized by their own supports
+        self.support_size = len(torch.arange(*(value_support_range or support_range)))
+        self.reward_support_size = len(torch.arange(*(reward_support_range or value_support_range or support_range)))
         enc = action_space_size if discrete_action_encoding_type == "one_hot" else 1
         act = nn.ReLU(inplace=True)
         self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, None, norm_type)
         self.dynamics_network = MZDynamicsNetworkMLP(enc, latent_state_dim + enc, list(reward_head_hidden_channels),
-                                                     self.support_size, act, norm_type, res_connection_in_dynamics)
+                                                     self.reward_support_size, act, norm_type, res_connection_in_dynamics)
         self.prediction_network = PredictionNetworkMLP(action_space_size, latent_state_dim, list(value_head_hidden_channels),
                                                        list(policy_head_hidden_channels), self.support_size, act, norm_type)
 

@@ -36,6 +36,10 @@ CASES = {
                                                        reward_support_range=(-2., 3., 1.), value_support_range=(-10., 11., 1.)), B=6, seed=24),
     # BASELINE configs[0]: CartPole MuZeroModelMLP
     "mz_mlp_cartpole": dict(family="mz_mlp", kw=dict(observation_shape=4, action_space_size=2, latent_state_dim=128), B=8, seed=15),
+    # MuZeroModelMLP with a reward support of its own (muzero_model_mlp.py:73-74; the MuZero driver transforms rewards with the REWARD
+    # handle, mcts_ctree.py:60-63,340-346)
+    "mz_mlp_supports": dict(family="mz_mlp", kw=dict(observation_shape=6, action_space_size=3, latent_state_dim=128,
+                                                     reward_support_range=(-5., 6., 1.), value_support_range=(-20., 21., 1.)), B=7, seed=34),
     "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),
     # 8x8 boards without downsample (64 channels): the 8x8 Winograd chain of the 64x64 Atari latents serves them
     "mz_board8": dict(family="mz", kw=dict(observation_shape=(3, 8, 8), action_space_size=65, downsample=False, num_res_blocks=2), B=6, seed=28),

@@ -177,3 +177,47 @@ def test_device_rows_of_the_sampled_and_gumbel_families_equal_host_packer():
         assert np.array_equal(ggot[:, col], gwant[:, col]), col
     assert np.array_equal(ggot[:, shard.HEADER:], gwant[:, shard.HEADER:])
     assert np.array_equal(ggot[:, :shard.HEADER + 3 * A], ghdr)
+
+
+def test_forward_collect_rows_with_pure_policy():
+    """``collect_with_pure_policy`` on the rows path (efficientzero.py:597,644-655; muzero_collector.py:98-99,505,596): no search; the
+    action is drawn from softmax(policy logits over the legal actions) -- the SAME draw distribution as the dict-returning forward --,
+    searched value = predicted value, the stored visit statistics are the collector's zero list; the device rows carry the header and
+    the newest frame."""
+    from lightzero_amd import shard
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    B, A, F = 64, 6, 96 * 96
+    model = _model(A, seed=2)
+    pol = EfficientZeroPolicy(dict(CFG, collect_with_pure_policy=True), model)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(8)).cuda().contiguous()
+    rng = np.random.default_rng(5)
+    mask = (rng.random((B, A)) < 0.6).astype(np.float32)
+    mask[np.arange(B), rng.integers(0, A, size=B)] = 1
+    rows = torch.zeros(B, shard.row_width(A, F), device="cuda")
+    np.random.seed(3)
+    hdr = pol.forward_collect_rows(obs, mask, rows, temperature=1.0, to_play=[-1] * B, timestep=list(range(B)))
+    out = pol._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=[-1] * B)
+    HW = shard.HEADER + 2 * A
+    got = rows.cpu().numpy()
+    assert np.array_equal(got[:, :HW], hdr)
+    assert np.array_equal(got[:, HW:], obs[:, 3].reshape(B, -1).cpu().numpy())          # the newest frame
+    acts = hdr[:, shard.F_ACTION].astype(int)
+    assert all(mask[i, acts[i]] == 1 for i in range(B))
+    pred = np.array([float(np.asarray(out[i]["predicted_value"]).reshape(-1)[0]) for i in range(B)], np.float32)
+    assert np.array_equal(hdr[:, shard.F_PRED_VALUE], pred) and np.array_equal(hdr[:, shard.F_ROOT_VALUE], pred)
+    assert (hdr[:, shard.HEADER:shard.HEADER + A] == 0).all() and (hdr[:, shard.F_ENTROPY] == 0).all()
+    assert np.array_equal(hdr[:, shard.HEADER + A:HW], mask) and np.array_equal(hdr[:, shard.F_N_LEGAL], mask.sum(1))
+    assert np.array_equal(hdr[:, shard.F_TIMESTEP], np.arange(B, dtype=np.float32))
+    # the draw follows softmax(logits over the legal actions): 400 draws of one env against its probabilities
+    logits = np.array(out[0]["predicted_policy_logits"], np.float64)
+    z = np.where(mask[0] != 0, logits, -np.inf)
+    p = np.exp(z - z.max()); p /= p.sum()
+    one = obs[:1].repeat(B, 1, 1, 1).contiguous()
+    m1 = np.repeat(mask[:1], B, 0)
+    cnt = np.zeros(A)
+    for k in range(7):
+        h = pol.forward_collect_rows(one, m1, rows, temperature=1.0, to_play=[-1] * B)
+        cnt += np.bincount(h[:, shard.F_ACTION].astype(int), minlength=A)
+    n = cnt.sum()
+    assert (cnt[mask[0] == 0] == 0).all()
+    assert np.all(np.abs(cnt / n - p) < 4.5 * np.sqrt(p * (1 - p) / n) + 1e-3), (cnt / n, p)

@@ -93,3 +93,15 @@ def test_all_gather_rows_gloo_world2(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK" in r.stdout
+
+
+def test_plan_gpus_keeps_a_full_share_per_gpu():
+    """BASELINE configs[3] (512 envs, 8 GPUs available) -> 2 GPUs x 256 roots; configs[4] (256 envs, 4 GPUs) -> 1 GPU; bigger batches
+    spread over the whole node, uneven totals by shard_range"""
+    from lightzero_amd import shard
+    assert shard.plan_gpus(512, 8) == (2, [256, 256])
+    assert shard.plan_gpus(256, 4) == (1, [256])
+    assert shard.plan_gpus(2048, 8) == (8, [256] * 8)
+    assert shard.plan_gpus(4096, 8) == (8, [512] * 8)
+    assert shard.plan_gpus(700, 8) == (3, [234, 233, 233])
+    assert shard.plan_gpus(10, 8) == (1, [10])
