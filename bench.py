@@ -329,7 +329,7 @@ def main():
         if args.refresh_every and (i + 1) % args.refresh_every == 0:
             # weight refresh inside the loop: one flat broadcast from rank 0, then the device tensors are overwritten in place
             # (same buffers: the captured search graphs stay valid)
-            fresh = shard.broadcast_state_dict(weights, src=0)
+            fresh = shard.broadcast_state_dict(weights, src=0, on_device=True)   # RCCL: tensors stay on the device until the library stages them
             for mdl in models:
                 mdl.load_state_dict(fresh)
 

@@ -260,6 +260,9 @@ typedef struct lz_model_cfg {
  * kernels and uploads them.  Replaces policy._collect_model.load_state_dict (muzero.py:1036-1058 format). */
 int lz_model_create(lz_engine *e, const lz_model_cfg *cfg);
 int lz_model_set_tensor(lz_engine *e, const char *name, const float *h_data, const int64_t *shape, int ndim);
+/* the same from a device tensor (weight refresh after an RCCL broadcast: no host round trip in the caller; the library copies it to its
+ * host-side staging on the engine's stream -- the re-layout of lz_model_finalize is host code).  The producing stream must be done with d_data. */
+int lz_model_set_tensor_device(lz_engine *e, const char *name, const float *d_data, const int64_t *shape, int ndim);
 int lz_model_finalize(lz_engine *e);
 /* Identity of the model an engine currently holds: incremented by every lz_model_create.  A host-side model object records
  * it and refuses to run once another model took its engine (one model per engine). */

@@ -93,6 +93,7 @@ def lib():
         "lz_roots_select_action": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, c_i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")],
         "lz_model_create": [P, ctypes.POINTER(ModelCfg)],
         "lz_model_set_tensor": [P, ctypes.c_char_p, c_f32p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
+        "lz_model_set_tensor_device": [P, ctypes.c_char_p, P, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
         "lz_model_finalize": [P],
         "lz_initial_inference": [P, P],
         "lz_initial_inference_host": [P, c_f32p],

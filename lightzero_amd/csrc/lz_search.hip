@@ -125,6 +125,26 @@ extern "C" int lz_model_set_tensor(lz_engine *e, const char *name, const float *
     return LZ_OK;
 }
 
+// The same from a DEVICE tensor (a weight refresh whose state_dict arrived by an RCCL broadcast: shard.broadcast_state_dict(...,
+// on_device=True)): the copy into the host-side staging map happens here, on the engine's stream, instead of as one
+// flat.cpu().numpy() + per-tensor slicing in the caller.  The re-layout of lz_model_finalize itself is host code.
+// The caller has made sure the producing stream is done with d_data.
+extern "C" int lz_model_set_tensor_device(lz_engine *e, const char *name, const float *d_data, const int64_t *shape, int ndim)
+{
+    LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
+    LZ_REQUIRE(name && d_data && (shape || ndim == 0) && ndim >= 0 && ndim <= 4, "bad tensor argument");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.resize(n);
+    LZ_HIP_CHECK(hipMemcpyAsync(t.data.data(), d_data, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    LZ_HIP_CHECK(hipStreamSynchronize(e->stream));   // (pageable destination; the vector is moved into the map below)
+    e->model->raw[name] = std::move(t);
+    e->model->finalized = false;
+    return LZ_OK;
+}
+
 extern "C" int lz_model_finalize(lz_engine *e)
 {
     LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");

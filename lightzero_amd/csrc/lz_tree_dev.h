@@ -228,21 +228,20 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
                 masks[c] = __ballot(j == pos || (j > pos && score[c] >= thr));
                 cnt += __builtin_popcountll(masks[c]);
             }
-            int r = 0;
-            if (cnt > 1) {  // a single candidate (the usual case once visits differ) needs no draw
+            if (cnt > 1) {  // a single candidate (the usual case once visits differ) is the first arg-max: `pos` stays, no draw, no scan
                 const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
-                r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt) without a 64-bit division
-            }
+                int r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt) without a 64-bit division
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                uint64_t mk = masks[c];
-                const int pc = __builtin_popcountll(mk);
-                if (r >= 0 && r < pc) {
-                    for (int q = 0; q < r; ++q) mk &= mk - 1;
-                    pos = c * 64 + __builtin_ctzll(mk);
-                    r = -1;
-                } else if (r >= pc) {
-                    r -= pc;
+                for (int c = 0; c < NC; ++c) {
+                    uint64_t mk = masks[c];
+                    const int pc = __builtin_popcountll(mk);
+                    if (r >= 0 && r < pc) {
+                        for (int q = 0; q < r; ++q) mk &= mk - 1;
+                        pos = c * 64 + __builtin_ctzll(mk);
+                        r = -1;
+                    } else if (r >= pc) {
+                        r -= pc;
+                    }
                 }
             }
         }

@@ -106,8 +106,18 @@ class EfficientZeroModel(object):
         Calling it again on a loaded model is a weight refresh (collector after a learner update): tensors are overwritten in
         place on the device, roots and their captured search graphs stay valid."""
         self._check_owner()
+        synced = False
         for name, value in state_dict.items():
             if name.endswith("num_batches_tracked"):
+                continue
+            if getattr(value, "is_cuda", False) and str(value.dtype) == "torch.float32" and value.is_contiguous():
+                # a device tensor (shard.broadcast_state_dict(..., on_device=True)): handed over by pointer, no host copy here
+                if not synced:
+                    import torch
+                    torch.cuda.current_stream().synchronize()   # the collective / whoever produced the tensors is done
+                    synced = True
+                shape = (ctypes.c_int64 * max(value.dim(), 1))(*value.shape)
+                L.check(L.lib().lz_model_set_tensor_device(self._engine, name.encode(), value.data_ptr(), shape, value.dim()))
                 continue
             arr = value.detach().cpu().numpy() if hasattr(value, "detach") else np.asarray(value)
             arr = np.ascontiguousarray(arr, dtype=np.float32)

@@ -158,10 +158,12 @@ def all_gather_rows_equal(rows_t, out=None, async_op=False):
     return out, work
 
 
-def broadcast_state_dict(state_dict, src=0, device=None):
+def broadcast_state_dict(state_dict, src=0, device=None, on_device=False):
     """Weight refresh across ranks: rank ``src`` holds the new ``state_dict`` (name -> array-like, reference names), every other
     rank passes its current one (same names and shapes; only used as the layout).  One flat float32 broadcast (RCCL on cuda
-    tensors, gloo on cpu).  Returns name -> numpy float32 arrays, ready for ``model.load_state_dict`` (in-place re-ingest)."""
+    tensors, gloo on cpu).  Returns name -> numpy float32 arrays, ready for ``model.load_state_dict`` (in-place re-ingest) -- or,
+    with ``on_device=True`` and an RCCL broadcast, name -> views of the flat CUDA buffer: ``load_state_dict`` then hands them to the
+    library by pointer (``lz_model_set_tensor_device``), no ``.cpu()`` and no per-tensor numpy copies on the Python side."""
     import torch
     import torch.distributed as dist
     names = sorted(k for k in state_dict if not k.endswith("num_batches_tracked"))
@@ -178,6 +180,12 @@ def broadcast_state_dict(state_dict, src=0, device=None):
     if dist.get_rank() == src:
         flat.copy_(torch.from_numpy(np.concatenate([arr(state_dict[k]).reshape(-1) for k in names])))
     dist.broadcast(flat, src=src)
+    if on_device and flat.is_cuda:
+        out, off = {}, 0
+        for k, sh, n in zip(names, shapes, sizes):
+            out[k] = flat[off:off + n].view(*sh) if len(sh) else flat[off:off + n].view(())
+            off += n
+        return out
     host = flat.cpu().numpy()
     out, off = {}, 0
     for k, s, n in zip(names, shapes, sizes):
