@@ -26,6 +26,10 @@ CONFIGS = {
                  workload="BASELINE.json configs[0]: CartPole-v0 MuZero, MuZeroModelMLP (obs 4, latent 128), 25 sims, 8 envs"),
     "cfg2": dict(index=2, cmd=["tools/bench_conv_configs.py", "--envs", "1024", "--sims", "400", "--steps", "4", "--warmup", "1"], prof_steps="1",
                  chain_flop=CHAIN_ATARI_MZ, workload="BASELINE.json configs[2]: Atari Breakout MuZero, obs 4x96x96, 400 sims, 1024 envs, A = 4"),
+    # the same batch as two 512-root sub-batches on two engines / HIP streams: one half's latency-bound HBM tree step
+    # runs under the other half's chain as far as the register file allows (the chain launch holds 248 VGPRs x 2 waves per SIMD)
+    "cfg2_2streams": dict(index=2, cmd=["tools/bench_conv_configs.py", "--envs", "1024", "--sims", "400", "--steps", "4", "--warmup", "1", "--streams", "2"], prof_steps="1",
+                          chain_flop=CHAIN_ATARI_MZ, workload="BASELINE.json configs[2] as two 512-root sub-batches on two streams: Atari Breakout MuZero, 400 sims, 1024 envs, A = 4"),
     "cfg3": dict(index=3, cmd=["tools/bench_conv_configs.py", "--go", "--envs", "64", "--sims", "200", "--steps", "10", "--warmup", "2"], prof_steps="3",
                  chain_flop=CHAIN_GO, workload="BASELINE.json configs[3], one GPU's share: Go 9x9 MuZero, obs 17x9x9, A = 82, 200 sims, 64 of the 512 envs (8 GPUs)"),
     "cfg3_256": dict(index=3, cmd=["tools/bench_conv_configs.py", "--go", "--envs", "256", "--sims", "200", "--steps", "6", "--warmup", "1"], prof_steps="2",

@@ -20,3 +20,7 @@ cd $ROOT
 # the per-dispatch traces are large: keep the summaries
 find $R -name "*kernel_trace.csv" -delete
 tail -c 600 $R/bench_n1.json; echo; ls -R $R | head -30
+# the tree kernels' HBM traffic on BASELINE configs[2] (row n2) and the other configurations' lines, same box, same sources
+bash tools/tree_traffic.sh $R/tree > $R/tree.log 2>&1
+timeout 900 python tools/config_lines.py $R/cfg > $R/cfg.log 2>&1; tail -8 $R/cfg.log
+timeout 120 python __graft_entry__.py --smoke 2>&1 | tail -1

@@ -148,6 +148,8 @@ def main():
     # the other BASELINE configurations, measured by tools/config_lines.py into <run>/cfg/
     for f in sorted(glob.glob(os.path.join(run, "cfg", "cfg*.json"))):
         shutil.copy(f, os.path.join(prof, "%s_%s" % (tag, os.path.basename(f))))
+    if os.path.isdir(os.path.join(run, "tree", "stats")):   # tools/tree_traffic.sh ran in the same profiling run
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tree_traffic.py"), os.path.join(run, "tree"), tag], check=True, stdout=subprocess.DEVNULL)
     man["files"] = sorted(f for f in os.listdir(prof) if f.startswith(tag + "_"))
     json.dump(man, open(os.path.join(prof, "%s_manifest.json" % tag), "w"), indent=1, sort_keys=True)
     if man["csrc_sha256"] != man["csrc_sha256_here"]:

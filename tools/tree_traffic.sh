@@ -4,7 +4,7 @@
 # budget the step runs as k_backprop_traverse<1, 1> on the HBM node arrays.  Three separate rocprofv3 passes (kernel trace + stats;
 # --pmc FETCH_SIZE; --pmc WRITE_SIZE -- counters never share a run with another trace domain), then tools/tree_traffic.py summarises.
 #   on the GPU box:  tools/tree_traffic.sh gpurun_out/<run>      here:  python tools/tree_traffic.py gpurun_out/<run> r04
-R=$GRAFT_REPO_ROOT/${1:-gpurun_out/tree}; mkdir -p $R
+R=$1; case $R in /*) ;; *) R=$GRAFT_REPO_ROOT/${R:-gpurun_out/tree};; esac; mkdir -p $R
 CMD="python $GRAFT_REPO_ROOT/tools/bench_conv_configs.py --envs 1024 --sims 400 --steps 1 --warmup 1"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- $CMD > $R/line.json 2> /dev/null
