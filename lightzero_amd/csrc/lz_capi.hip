@@ -106,6 +106,11 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static int ensure_stage(lz_roots *r, size_t bytes)
 {
+    // an upload that was left in flight (lz_roots_upload_legal) still reads the pinned buffer: every other user waits for it here
+    if (r->stage_pending) {
+        LZ_HIP_CHECK(hipEventSynchronize(r->stage_done));
+        r->stage_pending = false;
+    }
     if (bytes <= r->stage_bytes) return LZ_OK;
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);
@@ -212,7 +217,12 @@ int lz_roots_upload_legal(lz_roots *r, const int32_t *h_legal_flat, const int32_
     hipStream_t s = r->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(t.legal, hl, (size_t)B * A * 4, hipMemcpyHostToDevice, s));
     LZ_HIP_CHECK(hipMemcpyAsync(t.n_legal, hn, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    // No synchronisation: the policy surface re-arms the roots (reset_mask) right after launching the initial inference, and a wait
+    // here parked the host for the whole representation tower (0.53 ms per collect step, tools/prof_policy.py) before it could enqueue
+    // the prepare and the search.  The pinned buffer is protected by an event instead (ensure_stage).
+    if (!r->stage_done) LZ_HIP_CHECK(hipEventCreateWithFlags(&r->stage_done, hipEventDisableTiming));
+    LZ_HIP_CHECK(hipEventRecord(r->stage_done, s));
+    r->stage_pending = true;
     return LZ_OK;
 }
 
@@ -280,6 +290,7 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     if (r->d_results) (void)hipFree(r->d_results);
     if (r->h_results) (void)hipHostFree(r->h_results);
     if (r->prep_done) (void)hipEventDestroy(r->prep_done);
+    if (r->stage_done) (void)hipEventDestroy(r->stage_done);
     if (r->d_reuse) (void)hipFree(r->d_reuse);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);

@@ -128,6 +128,8 @@ struct lz_roots {
     void *h_stage = nullptr;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    hipEvent_t stage_done = nullptr;   // recorded behind an upload from h_stage that was left in flight (lz_roots_upload_legal)
+    bool stage_pending = false;
     // ---- fused search state (allocated on first lz_initial_inference), all in HBM
     void *pool_slab = nullptr;
     uint64_t pool_model_uid = 0;    // the model (lz_engine::model_uid) whose shapes sized pool_slab / d_obs / d_results
