@@ -18,7 +18,8 @@ Per differing root:
   scalar_delta     max |value or value_prefix difference| fed to the two trees for this root before first_sim (post h^-1: the reference
                    formula's quantum is ~1.3e-4)
   minmax_range     max(value_delta_max, max - min) of the root's min-max statistics, oracle side: scores carry Q / range
-  class            "near_tie" (both gaps <= 1e-5) | "quantum" (the score shift gap_oracle + gap_device is within 4 x scalar_delta / range:
+  logit_delta      max |policy logit difference| fed to the two trees for this root before first_sim (priors)
+  class            "near_tie" (both gaps <= 1e-5) | "quantum" (the score shift gap_oracle + gap_device is within 4 x scalar_delta / range + 16 x logit_delta:
                    a one-step difference of the post-transform scalars, amplified by the min-max normalisation, explains the flip) |
                    "unexplained" (flagged: would be a bug)
 """
@@ -76,21 +77,23 @@ def attribute(tree, cfg, A, legal, noise, logits_oracle, logits_device, rec_orac
     gap_o, gap_d = so[ao] - so[ad], sd[ad] - sd[ao]
     top = sorted(so.values(), reverse=True)
     delta = 0.0
+    ldelta = float(np.max(np.abs(np.asarray(logits_oracle, np.float64) - np.asarray(logits_device, np.float64))))
     for s in range(s0):
         delta = max(delta, abs(float(rec_oracle[s]["value"][b]) - float(rec_device[s]["value"][b])),
                     abs(float(rec_oracle[s]["value_prefix"][b]) - float(rec_device[s]["value_prefix"][b])))
+        ldelta = max(ldelta, float(np.max(np.abs(np.asarray(rec_oracle[s]["policy_logits"][b], np.float64) - np.asarray(rec_device[s]["policy_logits"][b], np.float64)))))
     mn, mx = ro.get_minmax()[0]
     rng = max(cfg["value_delta_max"], float(mx) - float(mn)) if mx > mn else 1.0
     shift = gap_o + gap_d
     if max(gap_o, gap_d) <= 1e-5:
         cls = "near_tie"
-    elif shift <= 4.0 * delta / rng + 1e-5:
+    elif shift <= 4.0 * delta / rng + 16.0 * ldelta + 1e-5:   # (priors move with the logits; pb_c sqrt(N) / (n + 1) stays below ~10 here)
         cls = "quantum"
     else:
         cls = "unexplained"
     return dict(root=int(b), first_sim=int(s0), level=int(lv), node_latent=int(po[lv][0]), action_oracle=int(ao), action_device=int(ad),
                 gap_oracle=float(gap_o), gap_device=float(gap_d), best_two_oracle=float(top[0] - top[1]) if len(top) > 1 else None,
-                scalar_delta=float(delta), minmax_range=float(rng), score_shift=float(shift), **{"class": cls})
+                scalar_delta=float(delta), logit_delta=float(ldelta), minmax_range=float(rng), score_shift=float(shift), **{"class": cls})
 
 
 def summarize(entries, n_roots, n_same):
