@@ -36,6 +36,7 @@ FLOP_RECURRENT = 18381312        # per env per simulation
 FLOP_INITIAL = 292222912         # per env-step
 FLOP_CHAIN = 2 * 36 * 64 * (70 + 4 * 64) * 9 + 2 * 36 * 64 * 48  # dyn conv 70->64 + 4 convs 64->64 + three 1x1 64->16 = 13,741,056 per env
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense peak (the --fast arm)
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
 MANIFEST = "r04_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
@@ -186,6 +187,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast", action="store_true",
+                    help="FAST MODE arm (BASELINE.md section 2, last arm): bf16 MFMA for the recurrent chain's convolutions and the LSTM gate "
+                         "product, statistical parity only -- a separate number, never the parity-mode headline (the default run)")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the 256 envs of a GPU into this many independent sub-batches, each on its own engine "
                          "(HIP stream): the MFMA-bound conv chain of one overlaps the latency-bound tree / LSTM / head "
@@ -262,7 +266,7 @@ def main():
     for k in range(NS):
         e = L.default_engine(device_index) if k == 0 else L.new_engine(device_index)
         engs.append(e)
-        models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e).load_state_dict(weights))
+        models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e, fast_mode=args.fast).load_state_dict(weights))
     eng = engs[0]
     g = torch.Generator().manual_seed(1000 + rank)
     obs_cpu = torch.rand(ENVS, 4, 96, 96, generator=g)
@@ -525,6 +529,20 @@ def main():
                                    "pairs around each launch of %d eagerly launched steps as a cross-check" % (max(prof_steps, 5), prof_steps),
                          "algorithmic_flop_per_launch": EPS * FLOP_CHAIN},
         }
+        if args.fast:
+            out["metric"] += " -- FAST MODE"
+            out["dtype"] = "bf16"
+            out["config"]["mode"] = ("fast mode (EfficientZeroModel(fast_mode=True), lz_model_cfg.precision = 1): bf16 MFMA with fp32 accumulation for the recurrent "
+                                     "chain's 3x3 convolutions (k_chain_b) and the LSTM gate product (k_lstm_b); representation tower, normalisation, cell, heads "
+                                     "and tree in fp32; statistical parity only (tests/test_fast_mode_gpu.py) -- NOT the parity-mode headline")
+            rf = out["roofline"]
+            rf["kernel"] = "k_chain_b (the same launch as k_chain_w with the 3x3 convolutions in the direct form on v_mfma_f32_16x16x32_bf16)"
+            rf["peak"] = PEAK_BF16_MATRIX_TFLOPS
+            rf["frac"] = (achieved / PEAK_BF16_MATRIX_TFLOPS) if achieved else None
+            rf["bound"] = "latency (tree step + weight stream of 74 KB per layer and CU); the matrix pipe is idle most of the launch"
+            for k in ("traffic", "achieved_profiled", "frac_profile", "avg_launch_us_profile"):
+                rf[k] = None
+            rf["traffic_unit"] = rf["profile"] = "fast mode: no committed PMC / rocprofv3 pass"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["config"]["policy_surface_env_steps_per_s"] = policy_surface(models[0], obs)

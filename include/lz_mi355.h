@@ -250,6 +250,11 @@ typedef struct lz_model_cfg {
      * driver sends the value prefix through the VALUE handle (mcts_ctree.py:839-841), so there the two must be equal. */
     int reward_support_size;
     float reward_support_min;
+    /* 0: parity mode -- fp32 arithmetic throughout (the default; every parity claim is about this mode).
+     * 1: fast mode (last arm; reported separately, statistical parity only): the 3x3 convolutions of the recurrent
+     *    chain and the LSTM gate product run on bf16 MFMA (weights and the multiplied activations rounded to bf16, fp32 accumulation,
+     *    fp32 normalisation / cell / heads / tree).  EfficientZeroModel with the 6x6x64 latent only. */
+    int precision;
 } lz_model_cfg;
 
 /* One model per engine (creating another replaces it: roots of the old one re-size their pools on the next inference).

@@ -2,6 +2,7 @@
 // (lz_search.hip) and the vector-observation / MLP (lz_mlp.hip) model families.
 #pragma once
 #include <math.h>
+#include <string.h>
 
 #include <algorithm>
 #include <map>
@@ -21,6 +22,7 @@ struct ConvW {
     float *wf = nullptr;  // MFMA-fragment order [cout/16][9][cin/16][64 lanes][4] for the LDS-resident conv chain
     float *uf = nullptr;  // Winograd F(2x2, 3x3) transform U = G g G^T of the same weights, [cout/16][16][cin/16][64 lanes][4] (tower convs)
     float *uc = nullptr;  // the same transform in the order of the LDS-resident Winograd chain (k_chain_w): [16 points][cin/4][64 = cout][4]
+    void *wb = nullptr;   // fast mode: bf16 fragments of the direct form for k_chain_b, [2 k halves][cout/16][9 taps][64 lanes][8 bf16]
     int cin = 0, cout = 0;
 };
 struct MlpW {
@@ -54,6 +56,7 @@ struct lz_model {
     float *act_table = nullptr;
     C1W rew_c;
     float *lstm_w = nullptr, *lstm_wf = nullptr, *lstm_b = nullptr, *vp_s = nullptr, *vp_t = nullptr;
+    void *lstm_wb = nullptr;   // fast mode: the gate weights as bf16 fragments (k_lstm_b)
     MlpW fc_reward;
     // prediction
     C1W val_c, pol_c;
@@ -161,7 +164,40 @@ struct Builder {
         ConvW c = conv(p + ".0.weight", p + ".1", cout, cin, cin);
         if (winograd) c.uf = wino(p + ".0.weight", cout, cin);
         if (wchain) c.uc = wino_chain(p + ".0.weight", cout, cin, cin);
+        if (wchain && m->cfg.precision == 1) c.wb = bf16_chain(p + ".0.weight", cout, cin, cin);
         return c;
+    }
+    // fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
+    static uint16_t bf16_rne(float f)
+    {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    float *upload_u16(const std::vector<uint16_t> &v)
+    {
+        std::vector<float> f((v.size() + 1) / 2, 0.0f);
+        memcpy(f.data(), v.data(), v.size() * 2);
+        return upload(f);
+    }
+    // fast mode, k_chain_b: wave (nt, kh) multiplies the 16-channel output tile nt by input channels 32 kh .. + 31 of tap t; lane (n = l & 15,
+    // kq = l >> 4) holds W[co = 16 nt + n][ci = 32 kh + 8 kq + j][t], j = 0..7 -- the B operand of v_mfma_f32_16x16x32_bf16
+    void *bf16_chain(const std::string &wname, int cout, int cin_total, int cin)
+    {
+        const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
+        if (!w || cout != 64 || cin != 64) return nullptr;
+        std::vector<uint16_t> f((size_t)2 * 4 * 9 * 64 * 8);
+        for (int kh = 0; kh < 2; ++kh)
+            for (int nt = 0; nt < 4; ++nt)
+                for (int t = 0; t < 9; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = nt * 16 + (lane & 15), ci = kh * 32 + (lane >> 4) * 8 + j;
+                            f[((((size_t)kh * 4 + nt) * 9 + t) * 64 + lane) * 8 + j] = bf16_rne(w->data[((size_t)co * cin_total + ci) * 9 + t]);
+                        }
+        return upload_u16(f);
     }
     static void wino_u(const float *g, double (&U)[4][4])  // U = G g G^T, binary64
     {

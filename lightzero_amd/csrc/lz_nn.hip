@@ -1469,6 +1469,257 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
 }
 
 // ------------------------------------------------------------------------------------------------
+// FAST MODE (lz_model_cfg::precision = 1; BASELINE.md section 2, arm "fast mode": reported separately, statistical parity only).
+// The same chain as k_chain_w -- same arguments, same prologue (tree step on wave 0, split heads on waves 1-7), same 1x1 head convolutions
+// -- with the 3x3 convolutions in the direct form on v_mfma_f32_16x16x32_bf16: weights and the A operand (activations) rounded to bf16
+// (RNE), fp32 accumulation, fp32 BatchNorm / action table / residual / ReLU, fp32 latents in the pool.  The matrix work shrinks to 27
+// MFMAs per wave and layer, so no Winograd transform (whose weights are 1.78x the bytes): a layer streams 74 KB of weights per
+// workgroup instead of 262 KB.  Work split: wave (nt = w & 3, kh = w >> 2) owns the 16-channel output tile nt for ALL pixels (three
+// 16-pixel row tiles, 36 rows used) over input channels 32 kh .. 32 kh + 31 of every tap: its 9 weight fragments of a layer (one per tap,
+// 16 B per lane) sit in registers and the next layer's are requested at the layer's start; the two k halves meet in LDS.  Activations live in
+// LDS twice: fp32 (residual, action table add, head convs, pool) and a bf16 copy [pixel][72] that serves the A operand with ONE
+// ds_read_b128 per (row tile, tap) (pitch 144 B: the 16 rows of a fragment fall into distinct bank quads).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+
+template <int GW, int GH, int TREE = 0, bool HEADS = false>
+__global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_arg<TREE>::type step)
+{
+    constexpr int NW = 8, PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
+    constexpr int PB = 72;                               // bf16 per pixel of the bf16 copies (64 + pad)
+    static_assert(MT <= 3 && HW % 4 == 0, "up to 48 pixels");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 fp32 activation buffers of BUF floats (the staged tree first), then
+    float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
+    float *sSS = sTab + HW * PS;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
+    float *sMisc = sSS + LZ_CHAIN_MAX_LAYERS * 128;     // 128 floats: the tree step's selection
+    float *sP = sMisc + 128;                            // [4 nt][MT][64 lanes][4] partial sums of the kh = 1 waves (prologue: head scratch)
+    __bf16 *sB = reinterpret_cast<__bf16 *>(sP + 4 * MT * 256);   // 4 x [HW + 1][PB] bf16 copies of the activation buffers
+    constexpr int BB = (HW + 1) * PB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv & 3, kh = wv >> 2;
+    const int b = blockIdx.x;
+    lz_stamp_begin(a.stamp);
+    // weights: [layer][kh][nt][tap][64 lanes][8 bf16]
+    auto wfrag = [&](int L, int t) { return reinterpret_cast<const bf16x8 *>(a.layer[L].wb)[(((size_t)kh * 4 + nt) * 9 + t) * 64 + lane]; };
+    bf16x8 wc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wc[t] = wfrag(0, t);
+    // 1x1 head convolutions at the end of the kernel (as in k_chain_w)
+    constexpr bool C1SPLIT = (HW % 16) != 0 && (HW % 16) <= 4 && HW / 16 == 2;
+    const int nj = max(a.nc1, 1);
+    const int c1j = C1SPLIT ? wv % nj : min(wv, nj - 1);
+    float4 c1w[4];
+    float4 c1b, c1s, c1t;
+    {
+        const lz_c1_job &jb = a.c1[c1j];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(jb.w + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
+        c1b = *reinterpret_cast<const float4 *>(jb.bias + (lane >> 4) * 4);
+        c1s = *reinterpret_cast<const float4 *>(jb.scale + (lane >> 4) * 4);
+        c1t = *reinterpret_cast<const float4 *>(jb.shift + (lane >> 4) * 4);
+    }
+    int g_slot = 0, g_action = 0;
+    if constexpr (TREE != 0) {
+        int32_t *s_sel = reinterpret_cast<int32_t *>(sMisc + 120);
+        float *s_leaf = sP;
+        int32_t *s_ctr = reinterpret_cast<int32_t *>(sP + 80);
+        float *s_red = sP + 96;
+        bool heads_on = false;
+        if constexpr (HEADS) {
+            heads_on = step.sh.on != 0;
+            if (heads_on) {
+                if (tid < 8) s_ctr[tid] = 0;
+                __syncthreads();
+            }
+        }
+        if (wv == 0) {
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(3);
+            dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
+                                      heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(0);
+        } else {
+            if constexpr (HEADS) {
+                const int hw = wv < 4 ? wv - 1 : (wv == 4 ? 6 : wv - 2);
+                if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
+            }
+            for (int i = tid - 64; i < a.nlayers * 128; i += NTHR - 64) {
+                const int L = i >> 7, r = i & 127;
+                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+            }
+        }
+        __syncthreads();
+        g_slot = s_sel[0];
+        g_action = s_sel[1];
+    } else {
+        if (a.gather_ix) g_slot = a.gather_ix[b];
+        if (a.act_table) g_action = a.action[b];
+    }
+    {
+        const float *src = a.in + (size_t)b * HW * 64 + (size_t)g_slot * a.slot_stride;
+        constexpr int NU = (HW * 16 + NTHR - 1) / NTHR;
+        float4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = min(u * NTHR + tid, HW * 16 - 1);
+            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
+        }
+        float4 tv[NU];
+        const bool tabl = a.act_table != nullptr;
+        {
+            const float *tsrc = tabl ? a.act_table + (size_t)g_action * HW * 64 : src;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = min(u * NTHR + tid, HW * 16 - 1);
+                tv[u] = *reinterpret_cast<const float4 *>(tsrc + (size_t)idx * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = u * NTHR + tid;
+            if (idx < HW * 16) {
+                *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
+                bf16x4 h;
+                h[0] = (__bf16)v[u].x; h[1] = (__bf16)v[u].y; h[2] = (__bf16)v[u].z; h[3] = (__bf16)v[u].w;
+                *reinterpret_cast<bf16x4 *>(sB + (idx >> 4) * PB + (idx & 15) * 4) = h;
+                if (tabl) *reinterpret_cast<float4 *>(sTab + (idx >> 4) * PS + (idx & 15) * 4) = tv[u];
+            }
+        }
+        // the all-zero pixel of every buffer (fp32: the head convolutions' padding rows; bf16: the halo)
+        if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
+        if (tid >= 64 && tid < 64 + 4 * 9) {
+            const int i = tid - 64;
+            *reinterpret_cast<float4 *>(sB + (i / 9) * BB + HW * PB + (i % 9) * 8) = vzero4();
+        }
+        if (TREE == 0) {
+            for (int i = tid; i < a.nlayers * 128; i += NTHR) {
+                const int L = i >> 7, r = i & 127;
+                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+            }
+        }
+    }
+    // ---- per-lane geometry, the same for every layer: A rows of this lane = pixels 16 mt + (lane & 15); tap (dy, dx) reads pixel
+    // m + dy GW + dx when it is inside the image, the zero pixel otherwise (one validity bit per (row tile, tap))
+    unsigned valid = 0;
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + (lane & 15), y = m / GW, x = m - y * GW;
+        abase[mt] = (m * PB + kh * 32 + (lane >> 4) * 8) * 2;   // bytes
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (m < HW && yy >= 0 && yy < GH && xx >= 0 && xx < GW) valid |= 1u << (mt * 9 + t);
+        }
+    }
+    const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
+    const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
+    __syncthreads();
+
+    for (int L = 0; L < a.nlayers; ++L) {
+        const lz_chain_layer &ly = a.layer[L];
+        const char *sBin = reinterpret_cast<const char *>(sB + ly.in * BB);
+        float *sOut = smem + ly.out * BUF;
+        __bf16 *sBout = sB + ly.out * BB;
+        const int Ln = L + 1 < a.nlayers ? L + 1 : L;
+        bf16x8 wn[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wn[t] = wfrag(Ln, t);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sBin + off);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wc[t], acc[mt], 0, 0, 0);
+            }
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            const int co = nt * 16 + (lane & 15);
+            const float sc = sSS[L * 128 + co], sh = sSS[L * 128 + 64 + co];
+            const bool tab = ly.act != 0, hasres = ly.res >= 0, relu = ly.relu != 0;
+            const float *sRes = smem + max(ly.res, 0) * BUF;
+            float *go = ly.gout ? ly.gout + (size_t)b * HW * 64 : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 other = *reinterpret_cast<const f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mt * 16 + 4 * (lane >> 4) + q;
+                    if (m < HW) {
+                        float v = acc[mt][q] + other[q];
+                        if (tab) v += sTab[m * PS + co];
+                        v = v * sc + sh;
+                        if (hasres) v += sRes[m * PS + co];
+                        v = relu ? fmaxf(v, 0.0f) : v;
+                        sOut[m * PS + co] = v;
+                        sBout[m * PB + co] = (__bf16)v;
+                        if (go) go[m * 64 + co] = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wc[t] = wn[t];
+        __syncthreads();
+    }
+    // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU in fp32, as in k_chain_w
+    auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {
+        float4 v;
+        v.x = fmaxf((acc[0] + c1b.x) * c1s.x + c1t.x, 0.0f);
+        v.y = fmaxf((acc[1] + c1b.y) * c1s.y + c1t.y, 0.0f);
+        v.z = fmaxf((acc[2] + c1b.z) * c1s.z + c1t.z, 0.0f);
+        v.w = fmaxf((acc[3] + c1b.w) * c1s.w + c1t.w, 0.0f);
+        *reinterpret_cast<float4 *>(jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + cq * 4) = v;
+    };
+    auto c1_tile = [&](int job, int i) {
+        const float *sIn = smem + a.c1_in[job] * BUF + kq4;
+        const int row = i * 16 + (lane & 15);
+        const int off = (row < HW) ? row * PS : zoff;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 xf = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(c1w[g], j), vget(xf, j), acc, 0, 0, 0);
+        }
+        if (row < HW) c1_store(a.c1[job], row, lane >> 4, acc);
+    };
+    auto c1_rem = [&](int job) {
+        const float *sIn = smem + a.c1_in[job] * BUF + kq4;
+        const int row = (HW / 16) * 16 + (lane & 3);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 xf = *reinterpret_cast<const float4 *>(sIn + row * PS + g * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vget(c1w[g], j), vget(xf, j), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = xor32_sum(xor16_sum(acc[q]));
+        const int cg = (lane >> 2) & 3;
+        if ((lane >> 4) == cg) c1_store(a.c1[job], row, cg, acc);
+    };
+    if constexpr (C1SPLIT) {
+        if (wv < a.nc1) { c1_tile(c1j, 0); c1_rem(c1j); }
+        else if (wv < 2 * a.nc1) c1_tile(c1j, 1);
+    } else if (wv < a.nc1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) c1_tile(wv, i);
+    }
+    lz_stamp_end(a.stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same chain for narrow networks (num_channels = 32 | 16: the reference's gomoku / tictactoe configs,
 // zoo/board_games/gomoku/config/gomoku_muzero_bot_mode_config.py:41-42, tictactoe/...:33-34).  One workgroup per root, activations in
 // LDS across layers; C / 16 output-channel tiles, so the four waves split as (N-tile, M-group): with 32 channels two waves share
@@ -2020,6 +2271,159 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #ifdef LZ_DEBUG_KNOBS
                 if (a.debug_hot_weights & 4) continue;
 #endif
+                if (r0 + row < a.B)
+                    *reinterpret_cast<f32x4 *>(a.sh_part + ((size_t)(r0 + row) * 3 + (c4 >> 3)) * (gridDim.x * 32) + (size_t)tile * 32 + (c4 & 7) * 4) =
+                        *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4);
+            }
+        }
+    }
+    lz_stamp_end(a.stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST MODE (lz_model_cfg::precision = 1): k_lstm2<68, 0, 16, 36, SH> with the gate product on v_mfma_f32_16x16x32_bf16 -- the rows
+// [x | h] are rounded to bf16 while they are staged ([16][K + 8] bf16 in LDS: one ds_read_b128 per A fragment), the gate weights are bf16
+// fragments [H/16][4 gates][K/32][64 lanes][8] (lz_lstm_args::wb), accumulation / cell / BatchNorm / split-head partials in fp32 as in
+// k_lstm2.  34 MFMAs per wave instead of 272; a workgroup streams 139 KB of weights instead of 278 KB.
+// ------------------------------------------------------------------------------------------------
+template <bool SH>
+__global__ __launch_bounds__(256) void k_lstm_b(lz_lstm_args a)
+{
+    constexpr int NKB = 68, KXB = 36, K = NKB * 16, NS = K / 32, SX = KXB / 2, PB = K + 8, R = 12, MR = 16;
+    constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // bf16 [16][PB]; reused (fp32) for the gate exchange
+    __bf16 *sR = reinterpret_cast<__bf16 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x, r0 = blockIdx.y * MR;
+    const int H = a.H, KX = a.KX;
+    const size_t slot = (size_t)a.B * H;
+    lz_stamp_begin(a.stamp);
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(a.wb) + ((size_t)(tile * 4 + wv) * NS) * 64 + lane;
+    bf16x8 wq[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)s * 64];
+    f32x4 sh_av = {0.f, 0.f, 0.f, 0.f}, sh_bv[3], sh_brv;
+    auto sh_request = [&]() {
+        const int row = min(tid / 9, 15), c4 = tid % 9;
+        const int bb = min(r0 + row, a.B - 1);
+        sh_av = *reinterpret_cast<const f32x4 *>(a.sh_pv + (size_t)bb * a.sh_kc + 36 * tile + 4 * c4);
+        const float *bp = a.sh_w1c + (((size_t)tile * 4 + wv) * 64 + lane) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sh_bv[i] = *reinterpret_cast<const f32x4 *>(bp + 4 * i);
+        sh_brv = *reinterpret_cast<const f32x4 *>(a.sh_w1r + (((size_t)tile * 2 + (wv & 1)) * 64 + lane) * 4);
+    };
+    float c_prev[NQ], gb[NQ][4], bns[NQ], bnt[NQ];
+    int slen[NQ];
+    const float *bnsp = a.bn_scale ? a.bn_scale : a.bias, *bntp = a.bn_scale ? a.bn_shift : a.bias;
+    const int32_t *slp = a.search_len ? a.search_len : a.gather_ix;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
+        const int b = min(r0 + row, a.B - 1), unit = tile * 16 + u;
+        c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + 4 * unit);
+        gb[q][0] = b4.x; gb[q][1] = b4.y; gb[q][2] = b4.z; gb[q][3] = b4.w;
+        bns[q] = bnsp[unit]; bnt[q] = bntp[unit];
+        slen[q] = slp[b];
+    }
+    // stage the rows: 16 threads per row; the x columns first, the h columns (a dependent pool gather) arrive under the x part's MFMAs
+    constexpr int K4 = K / 4, NXS = KXB * 4 / TPR, NHS = (K4 - KXB * 4) / TPR;
+    static_assert((KXB * 4) % TPR == 0 && (K4 - KXB * 4) % TPR == 0 && (KXB % 2) == 0, "whole thread strides, whole 32-column steps");
+    f32x4 hv[NHS];
+    auto put = [&](__bf16 *dst, const f32x4 &v) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4 *>(dst) = h;
+    };
+    {
+        const int row = tid / TPR, part = tid % TPR;
+        const int b = min(r0 + row, a.B - 1);
+        const float *xrow = a.x + (size_t)b * KX;
+        const float *hrow = a.h_pool + (size_t)a.gather_ix[b] * slot + (size_t)b * H;
+        __bf16 *dst = sR + row * PB;
+        f32x4 xv[NXS];
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(xrow + (part + TPR * i) * 4);
+#pragma unroll
+        for (int i = 0; i < NHS; ++i) hv[i] = *reinterpret_cast<const f32x4 *>(hrow + (part + TPR * i) * 4);
+        if constexpr (SH) sh_request();
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) put(dst + (part + TPR * i) * 4, xv[i]);
+    }
+    __syncthreads();
+    const __bf16 *sA = sR + (lane & 15) * PB + (lane >> 4) * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s == SX) {  // the h columns have arrived behind the x part's MFMAs: into LDS, then on
+            const int row = tid / TPR, part = tid % TPR;
+            __bf16 *dst = sR + row * PB + KXB * 16;
+#pragma unroll
+            for (int i = 0; i < NHS; ++i) put(dst + (part + TPR * i) * 4, hv[i]);
+            __syncthreads();
+        }
+        const bf16x8 bfr = wq[s % R];
+        if (s + R < NS) wq[s % R] = wp[(size_t)(s + R) * 64];
+        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sA + s * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc0, 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done reading the staged rows: the buffer becomes the gate exchange [4][16][17]
+    float *sG = smem;
+    float *sHb = smem + 4 * MR * 17;
+    float *sA2 = sHb + 16 * 17;
+    float *sP = sA2 + 16 * 40;
+    if constexpr (SH) {
+        if (tid < 144) *reinterpret_cast<f32x4 *>(sA2 + (tid / 9) * 40 + (tid % 9) * 4) = sh_av;
+    }
+    {
+        const int col = lane & 15, rq = 4 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sG[(wv * MR + rq + q) * 17 + col] = acc0[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
+        const int b = r0 + row;
+        if (b >= a.B) { if constexpr (SH) sHb[row * 17 + u] = 0.0f; continue; }
+        const int unit = tile * 16 + u;
+        const float gi = sG[(0 * MR + row) * 17 + u] + gb[q][0];
+        const float gf = sG[(1 * MR + row) * 17 + u] + gb[q][1];
+        const float gg = sG[(2 * MR + row) * 17 + u] + gb[q][2];
+        const float go = sG[(3 * MR + row) * 17 + u] + gb[q][3];
+        const float cn = sigmoidf_(gf) * c_prev[q] + sigmoidf_(gi) * tanhf_(gg);
+        const float hn = sigmoidf_(go) * tanhf_(cn);
+        const bool reset = a.search_len && a.horizon > 0 && (slen[q] % a.horizon) == 0;  // mcts_ctree.py:859-863
+        a.h_out[(size_t)b * H + unit] = reset ? 0.0f : hn;
+        a.c_out[(size_t)b * H + unit] = reset ? 0.0f : cn;
+        const float hb = a.bn_scale ? fmaxf(hn * bns[q] + bnt[q], 0.0f) : hn;
+        a.hbn_out[(size_t)b * H + unit] = hb;
+        if constexpr (SH) sHb[row * 17 + u] = hb;
+    }
+    if constexpr (SH) {
+        {
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks)
+                pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sA2[(lane & 15) * 40 + 4 * ks + (lane >> 4)], sh_bv[ks >> 2][ks & 3], pacc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sP[(4 * (lane >> 4) + q) * 96 + (wv >> 1) * 32 + 16 * (wv & 1) + (lane & 15)] = pacc[q];
+        }
+        __syncthreads();
+        if (wv < 2) {
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sHb[(lane & 15) * 17 + 4 * ks + (lane >> 4)], sh_brv[ks], pacc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sP[(4 * (lane >> 4) + q) * 96 + 64 + 16 * wv + (lane & 15)] = pacc[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHR * i;
+            if (idx < 16 * 24) {
+                const int row = idx / 24, c4 = idx % 24;
                 if (r0 + row < a.B)
                     *reinterpret_cast<f32x4 *>(a.sh_part + ((size_t)(r0 + row) * 3 + (c4 >> 3)) * (gridDim.x * 32) + (size_t)tile * 32 + (c4 & 7) * 4) =
                         *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4);
@@ -2721,6 +3125,24 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         return;
     }
     auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + extra) * 4; };
+    // fast mode (lz_model_cfg::precision = 1): every layer carries bf16 fragments -> k_chain_b
+    {
+        bool fast = a.gw == 6 && a.gh == 6 && a.nlayers > 0 && !a.tstamp;
+        for (int i = 0; i < a.nlayers; ++i) fast = fast && a.layer[i].wb != nullptr;
+        if (fast) {
+            constexpr int hw = 36, mt = 3;
+            const size_t lds = (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 4 * mt * 256) * 4 + (size_t)4 * (hw + 1) * 72 * 2;
+            const dim3 g(a.B), blk(512);
+            if (step) {
+                if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on) hipLaunchKernelGGL((k_chain_b<6, 6, 1, true>), g, blk, lds, s, a, *step);
+                else if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_b<6, 6, 1, false>), g, blk, lds, s, a, *step);
+                else hipLaunchKernelGGL((k_chain_b<6, 6, 2, false>), g, blk, lds, s, a, *step);
+            } else {
+                hipLaunchKernelGGL((k_chain_b<6, 6>), g, blk, lds, s, a, no_step{});
+            }
+            return;
+        }
+    }
     // 6x6 / 8x8 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
     static const char *direct = getenv("LZ_CHAIN_DIRECT");
     bool wino = !direct && ((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) && a.nlayers > 0;
@@ -2801,6 +3223,13 @@ void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out)
 static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
 {
     static const char *off = getenv("LZ_LSTM_CHUNKED");
+    if (a.wb) {   // fast mode (lz_model_finalize builds the bf16 fragments for this shape only): 576 + 512 columns, no input transform
+        const dim3 g(a.H / 16, (a.B + 15) / 16);
+        const size_t lds = std::max((size_t)16 * (68 * 16 + 8) * 2, (size_t)(4 * 16 * 17 + 16 * 17 + 16 * 40 + 16 * 96) * 4);
+        if (a.sh_part && a.sh_kc == 1152) hipLaunchKernelGGL((k_lstm_b<true>), g, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_lstm_b<false>), g, dim3(256), lds, s, a);
+        return true;
+    }
     if (!a.wf || (a.H & 15) || (a.KX & 15)) return false;
     if (off && !a.x_ln_g && !a.x_act) return false;  // the chunked kernel has no input transform
     const int nkb = (a.KX + a.H) / 16;

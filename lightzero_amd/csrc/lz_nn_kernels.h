@@ -61,6 +61,7 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s);
 struct lz_chain_layer {
     const float *wf;       // fragment-packed weights [4][9][4][64][4]  (N-tile, tap, 16-channel group, lane, 4 floats)
     const float *uc;       // optional: Winograd F(2x2,3x3) weights [16 points][16 channel quads][64 = cout][4] (k_chain_w, 6x6 grids)
+    const void *wb;        // optional (fast mode, lz_model_cfg::precision = 1): bf16 MFMA fragments [2 k halves][4 N-tiles][9 taps][64 lanes][8] (k_chain_b, 6x6 grids)
     const float *scale, *shift;  // [64] folded BatchNorm
     int in, out, res;      // LDS buffer indices (0..3); res < 0: no residual
     int relu, act;         // act: add the one-hot-action table before BN (dynamics conv)
@@ -124,6 +125,7 @@ struct lz_lstm_args {
     const float *wcat;       // [4H][KX+H], row n = 4*unit + gate (gate order i,f,g,o)
     const float *wf;         // the same matrix in MFMA-fragment order [H/16][4 gates][(KX+H)/16][64 lanes][4] (lz_lstm_pack_fragments);
                              // null => only the chunked kernel can run
+    const void *wb;          // fast mode (lz_model_cfg::precision = 1; KX = 576, H = 512): bf16 fragments [H/16][4 gates][(KX+H)/32][64 lanes][8] -> k_lstm_b
     const float *bias;       // [4H] same order (b_ih + b_hh)
     const float *bn_scale, *bn_shift;  // [H]; null => hbn_out = h' (no norm / activation)
     const int32_t *search_len;  // [B] (reset when search_len % horizon == 0); may be null => no reset

@@ -52,6 +52,8 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->model_type >= 0 && cfg->model_type <= 4, "model_type must be 0 (EfficientZeroModel), 1 (MuZeroModel), 2 (MuZeroModelMLP), 3 (EfficientZeroModelMLP) or 4 (SampledEfficientZeroModelMLP)");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->reward_support_size >= 0 && cfg->reward_support_size <= 768, "reward_support_size must be in [0, 768] (0 = the value support)");
+    LZ_REQUIRE(cfg->precision == 0 || (cfg->precision == 1 && cfg->model_type == 0 && cfg->downsample && cfg->obs_h == 96 && cfg->num_channels == 64),
+               "precision must be 0 (fp32, parity mode) or 1 (bf16 fast mode: EfficientZeroModel with the 96x96 -> 6x6x64 latent)");
     LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || cfg->model_type == 2 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
                "a reward support of its own: the MuZero models only (the EfficientZero drivers transform the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {
@@ -227,6 +229,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
         const std::string d = "dynamics_network.";
         m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + AE, C);
         if (wchain) m->dyn.uc = b.wino_chain(d + "conv.weight", C, C + AE, C);
+        if (wchain && c.precision == 1) m->dyn.wb = b.bf16_chain(d + "conv.weight", C, C + AE, C);
         // one-hot action planes: plane a is all ones inside the 6x6 latent, so its contribution to output
         // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image.  not_one_hot: ONE plane holding
         // action / action_space_size (fp32, like the reference's expand(...) / A): entry a = the in-bounds taps of W[co][C] times that
@@ -279,6 +282,20 @@ extern "C" int lz_model_finalize(lz_engine *e)
                 std::vector<float> wf(wc.size());
                 lz_lstm_pack_fragments(wc.data(), H, K, wf.data());
                 m->lstm_wf = b.upload(wf);
+            }
+            m->lstm_wb = nullptr;
+            if (c.precision == 1 && KX == 576 && H == 512) {
+                // k_lstm_b: wave = gate g of unit tile t, lane (n = l & 15, kq = l >> 4) holds W[4 (16 t + n) + g][32 s + 8 kq + j], j = 0..7
+                const int NS = K / 32;
+                std::vector<uint16_t> wb((size_t)4 * H * K);
+                for (int t = 0; t < H / 16; ++t)
+                    for (int g = 0; g < 4; ++g)
+                        for (int st = 0; st < NS; ++st)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j)
+                                    wb[((((size_t)(t * 4 + g) * NS + st) * 64) + lane) * 8 + j] =
+                                        Builder::bf16_rne(wc[(size_t)(4 * (16 * t + (lane & 15)) + g) * K + 32 * st + 8 * (lane >> 4) + j]);
+                m->lstm_wb = b.upload_u16(wb);
             }
         }
         std::vector<float> sc, sh;
@@ -429,7 +446,7 @@ __global__ void k_zero2(float4 *__restrict__ a, float4 *__restrict__ b, size_t n
 static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu, int act, float *gout)
 {
     lz_chain_layer l{};
-    l.wf = w.wf; l.uc = w.uc; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
+    l.wf = w.wf; l.uc = w.uc; l.wb = w.wb; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
     return l;
 }
 
@@ -1434,7 +1451,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     }
     // ---- value prefix LSTM (+ BN1d + ReLU), then the three head MLPs with h^-1 fused
     lz_lstm_args l{};
-    l.x = r->t_rx; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = m->lstm_w; l.wf = m->lstm_wf; l.bias = m->lstm_b;
+    l.x = r->t_rx; l.h_pool = r->h_pool; l.c_pool = r->c_pool; l.gather_ix = t.res_ix; l.wcat = m->lstm_w; l.wf = m->lstm_wf; l.wb = m->lstm_wb; l.bias = m->lstm_b;
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;

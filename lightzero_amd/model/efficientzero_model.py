@@ -43,7 +43,10 @@ class EfficientZeroModel(object):
                  reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
                  reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
                  categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
-                 engine=None, **kwargs):
+                 engine=None, fast_mode=False, **kwargs):
+        """``fast_mode=True`` (not a reference argument): lz_model_cfg.precision = 1 -- the recurrent chain's 3x3 convolutions and the LSTM
+        gate product on bf16 MFMA (fp32 accumulation, fp32 everything else); statistical parity only, reported separately from the
+        parity-mode numbers (last arm).  EfficientZeroModel, 6x6x64 latent."""
         if not 1 <= int(num_res_blocks) <= 3 or norm_type != 'BN' or not categorical_distribution \
                 or discrete_action_encoding_type not in ('one_hot', 'not_one_hot'):
             raise NotImplementedError("engine model: num_res_blocks in 1..3, norm_type='BN', categorical_distribution=True, "
@@ -84,6 +87,11 @@ class EfficientZeroModel(object):
         cfg.action_encoding = 0 if discrete_action_encoding_type == 'one_hot' else 1
         if tuple(reward_support_range) != tuple(value_support_range):
             cfg.reward_support_size, cfg.reward_support_min = self.reward_support_size, float(reward_support_range[0])
+        self.fast_mode = bool(fast_mode)
+        if self.fast_mode:
+            if self._model_type != 0 or not downsample or self.num_channels != 64 or self.observation_shape[1:] != (96, 96):
+                raise NotImplementedError("fast_mode: EfficientZeroModel with the 96x96 -> 6x6x64 latent")
+            cfg.precision = 1
         self._create(cfg)
 
     def _create(self, cfg):
