@@ -23,6 +23,7 @@ struct ConvW {
     float *uf = nullptr;  // Winograd F(2x2, 3x3) transform U = G g G^T of the same weights, [cout/16][16][cin/16][64 lanes][4] (tower convs)
     float *uc = nullptr;  // the same transform in the order of the LDS-resident Winograd chain (k_chain_w): [16 points][cin/4][64 = cout][4]
     void *wb = nullptr;   // fast mode: bf16 fragments of the direct form for k_chain_b, [2 k halves][cout/16][9 taps][64 lanes][8 bf16]
+    void *wt = nullptr;   // fast mode: bf16 fragments for the tower kernel k_conv_bf, [cout/16][9 taps x cin/32][64 lanes][8 bf16]
     int cin = 0, cout = 0;
 };
 struct MlpW {
@@ -181,6 +182,23 @@ struct Builder {
         std::vector<float> f((v.size() + 1) / 2, 0.0f);
         memcpy(f.data(), v.data(), v.size() * 2);
         return upload(f);
+    }
+    // fast mode, k_conv_bf: lane (n = l & 15, kq = l >> 4) of k step (tap t, 32-channel block kc) holds W[co = 16 nt + n][ci = 32 kc + 8 kq + j][t]
+    void *bf16_tower(const std::string &wname, int cout, int cin)
+    {
+        const HostTensor *w = get(wname, {cout, cin, 3, 3});
+        if (!w || (cin & 31) || (cout & 15)) return nullptr;
+        const int KC = cin / 32, KS = 9 * KC;
+        std::vector<uint16_t> f((size_t)cout * cin * 9);
+        for (int nt = 0; nt < cout / 16; ++nt)
+            for (int t = 0; t < 9; ++t)
+                for (int kc = 0; kc < KC; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = nt * 16 + (lane & 15), ci = kc * 32 + (lane >> 4) * 8 + j;
+                            f[((((size_t)nt * KS + t * KC + kc) * 64) + lane) * 8 + j] = bf16_rne(w->data[((size_t)co * cin + ci) * 9 + t]);
+                        }
+        return upload_u16(f);
     }
     // fast mode, k_chain_b: wave (nt, kh) multiplies the 16-channel output tile nt by input channels 32 kh .. + 31 of tap t; lane (n = l & 15,
     // kq = l >> 4) holds W[co = 16 nt + n][ci = 32 kh + 8 kq + j][t], j = 0..7 -- the B operand of v_mfma_f32_16x16x32_bf16

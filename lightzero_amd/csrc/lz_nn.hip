@@ -1477,8 +1477,8 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
 // workgroup instead of 262 KB.  Work split: wave (nt = w & 3, kh = w >> 2) owns the 16-channel output tile nt for ALL pixels (three
 // 16-pixel row tiles, 36 rows used) over input channels 32 kh .. 32 kh + 31 of every tap: its 9 weight fragments of a layer (one per tap,
 // 16 B per lane) sit in registers and the next layer's are requested at the layer's start; the two k halves meet in LDS.  Activations live in
-// LDS twice: fp32 (residual, action table add, head convs, pool) and a bf16 copy [pixel][72] that serves the A operand with ONE
-// ds_read_b128 per (row tile, tap) (pitch 144 B: the 16 rows of a fragment fall into distinct bank quads).
+// LDS twice: fp32 (residual, action table add, head convs, pool) and a bf16 copy [pixel][80] that serves the pixel operand with ONE
+// conflict-free ds_read_b128 per (pixel tile, tap).
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
@@ -1487,7 +1487,8 @@ template <int GW, int GH, int TREE = 0, bool HEADS = false>
 __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_arg<TREE>::type step)
 {
     constexpr int NW = 8, PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
-    constexpr int PB = 72;                               // bf16 per pixel of the bf16 copies (64 + pad)
+    constexpr int PB = 80;                               // bf16 per pixel of the bf16 copies: 64 + pad.  160 B = 10 bank quads: the 16-lane groups ds_read_b128 is
+                                                         // served in ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) then hit 16 distinct quads (144 B: 2-way conflicts)
     static_assert(MT <= 3 && HW % 4 == 0, "up to 48 pixels");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 fp32 activation buffers of BUF floats (the staged tree first), then
     float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
@@ -1499,11 +1500,26 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv & 3, kh = wv >> 2;
     const int b = blockIdx.x;
     lz_stamp_begin(a.stamp);
+    // per-layer parameters: lane L keeps layer L's (a scalar load from the argument block at the top of every layer is a round trip the
+    // layer then waits for); v_readlane hands them out
+    const lz_chain_layer &myl = a.layer[min(lane, LZ_CHAIN_MAX_LAYERS - 1)];
+    const unsigned long long my_wb = (unsigned long long)myl.wb, my_gout = (unsigned long long)myl.gout;
+    const int my_flags = myl.in | (myl.out << 2) | ((myl.res + 1) << 4) | ((myl.relu != 0) << 7) | ((myl.act != 0) << 8);
+    auto lane64 = [&](unsigned long long v, int L) {
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), L);
+        return ((unsigned long long)hi << 32) | lo;
+    };
     // weights: [layer][kh][nt][tap][64 lanes][8 bf16]
-    auto wfrag = [&](int L, int t) { return reinterpret_cast<const bf16x8 *>(a.layer[L].wb)[(((size_t)kh * 4 + nt) * 9 + t) * 64 + lane]; };
+    const size_t wofs = (((size_t)kh * 4 + nt) * 9) * 64 + lane;
     bf16x8 wc[9];
+    auto load_w0 = [&]() {
+        const bf16x8 *w0 = reinterpret_cast<const bf16x8 *>(a.layer[0].wb) + wofs;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wc[t] = wfrag(0, t);
+        for (int t = 0; t < 9; ++t) wc[t] = w0[t * 64];
+    };
+    // the first layer's weights: at once without a tree step; with one, the head waves request theirs when their head is done and the tree
+    // wave after the step, together with the latent gather (36 more live registers across the prologue spill)
+    if constexpr (TREE == 0) load_w0();
     // 1x1 head convolutions at the end of the kernel (as in k_chain_w)
     constexpr bool C1SPLIT = (HW % 16) != 0 && (HW % 16) <= 4 && HW / 16 == 2;
     const int nj = max(a.nc1, 1);
@@ -1543,14 +1559,17 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
                 const int hw = wv < 4 ? wv - 1 : (wv == 4 ? 6 : wv - 2);
                 if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
             }
+            load_w0();
             for (int i = tid - 64; i < a.nlayers * 128; i += NTHR - 64) {
                 const int L = i >> 7, r = i & 127;
                 sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
             }
         }
         __syncthreads();
+        if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
         g_slot = s_sel[0];
         g_action = s_sel[1];
+        if (wv == 0) load_w0();
     } else {
         if (a.gather_ix) g_slot = a.gather_ix[b];
         if (a.act_table) g_action = a.action[b];
@@ -1587,9 +1606,9 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
         }
         // the all-zero pixel of every buffer (fp32: the head convolutions' padding rows; bf16: the halo)
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
-        if (tid >= 64 && tid < 64 + 4 * 9) {
+        if (tid >= 64 && tid < 64 + 4 * (PB / 8)) {
             const int i = tid - 64;
-            *reinterpret_cast<float4 *>(sB + (i / 9) * BB + HW * PB + (i % 9) * 8) = vzero4();
+            *reinterpret_cast<float4 *>(sB + (i / (PB / 8)) * BB + HW * PB + (i % (PB / 8)) * 8) = vzero4();
         }
         if (TREE == 0) {
             for (int i = tid; i < a.nlayers * 128; i += NTHR) {
@@ -1615,62 +1634,128 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
     const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
     __syncthreads();
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[6] = __builtin_readcyclecounter(); }
 
-    for (int L = 0; L < a.nlayers; ++L) {
-        const lz_chain_layer &ly = a.layer[L];
-        const char *sBin = reinterpret_cast<const char *>(sB + ly.in * BB);
-        float *sOut = smem + ly.out * BUF;
-        __bf16 *sBout = sB + ly.out * BB;
-        const int Ln = L + 1 < a.nlayers ? L + 1 : L;
+    // output geometry of this lane, the same for every layer.  The MFMAs run TRANSPOSED (weights as the A operand): D[channel][pixel], so a
+    // lane ends up with four consecutive channels co4 .. co4 + 3 of ONE pixel -- 16 contiguous bytes in every [pixel][channel] array
+    const int co4 = nt * 16 + 4 * (lane >> 4);
+    const int nlayers = a.nlayers;
+    for (int L = 0; L < nlayers; ++L) {
+        const int flags = __builtin_amdgcn_readlane(my_flags, L);
+        const int Ln = L + 1 < nlayers ? L + 1 : L;
+        const char *sBin = reinterpret_cast<const char *>(sB + (flags & 3) * BB);
+        float *sOut = smem + ((flags >> 2) & 3) * BUF;
+        __bf16 *sBout = sB + ((flags >> 2) & 3) * BB;
+        // the next layer's weights first: they have this whole layer to arrive (left to the scheduler the requests sink behind the
+        // MFMAs and every layer starts by waiting for its weights: 2.8 us per layer, measured)
         bf16x8 wn[9];
+        {
+            const bf16x8 *w1 = reinterpret_cast<const bf16x8 *>(lane64(my_wb, Ln)) + wofs;
+#ifdef LZ_DEBUG_KNOBS
+            if (a.debug_flags & 16) {   // 16 = no weight stream (the registers keep the first layer's)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wn[t] = wfrag(Ln, t);
+                for (int t = 0; t < 9; ++t) wn[t] = wc[t];
+            } else
+#endif
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wn[t] = w1[t * 64];
+        }
+        // pixel fragments by kernel row (3 taps x MT row tiles = one group): two groups are requested before the first MFMA, the third
+        // goes into the first group's registers behind its MFMAs -- one LDS latency per layer instead of one per fragment
+        auto read_group = [&](int g, bf16x8 (&af)[3][MT]) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int t = 3 * g + tt;
+                const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
+                    af[tt][mt] = *reinterpret_cast<const bf16x8 *>(sBin + off);
+                }
+            }
+        };
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto mma_group = [&](int g, const bf16x8 (&af)[3][MT]) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
+            for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sBin + off);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wc[t], acc[mt], 0, 0, 0);
-            }
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[3 * g + tt], af[tt][mt], acc[mt], 0, 0, 0);
+        };
+        bf16x8 a0[3][MT], a1[3][MT];
+#ifdef LZ_DEBUG_KNOBS
+        if (!(a.debug_flags & 4)) {   // timing experiments (debug build; results are then wrong): 4 = no pixel reads / MFMAs
+#endif
+        read_group(0, a0);
+        read_group(1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_group(2, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(2, a0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef LZ_DEBUG_KNOBS
         }
-        if (kh == 1) {
+#endif
+        // ---- the two k halves meet in LDS: the kh = 0 wave of an output tile finishes pixel tiles 0 and 2 (pixels 0..15, 32..35), the
+        // kh = 1 wave pixel tile 1 -- each leaves its partial sums of the OTHER wave's tiles in sP[nt][mt]
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
-        }
+        for (int mt = 0; mt < MT; ++mt)
+            if ((mt == 1) != (kh == 1)) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
         __syncthreads();
-        if (kh == 0) {
-            const int co = nt * 16 + (lane & 15);
-            const float sc = sSS[L * 128 + co], sh = sSS[L * 128 + 64 + co];
-            const bool tab = ly.act != 0, hasres = ly.res >= 0, relu = ly.relu != 0;
-            const float *sRes = smem + max(ly.res, 0) * BUF;
-            float *go = ly.gout ? ly.gout + (size_t)b * HW * 64 : nullptr;
+#ifdef LZ_DEBUG_KNOBS
+        if (!(a.debug_flags & 8))     // 8 = no epilogue
+#endif
+        {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + co4), sh = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + 64 + co4);
+            const bool tab = (flags >> 8) & 1, relu = (flags >> 7) & 1;
+            const int res = ((flags >> 4) & 7) - 1;
+            const float *sRes = smem + max(res, 0) * BUF;
+            float *go = reinterpret_cast<float *>(lane64(my_gout, L));
+            if (go) go += (size_t)b * HW * 64;
+            // every LDS read of the epilogue before its first write (the compiler must assume they alias)
+            constexpr int NF = MT > 2 ? 2 : 1;     // pixel tiles this wave may finish: {0, 2} | {1}
+            f32x4 other[NF], tvv[NF], rvv[NF];
+            int mpix[NF];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 other = *reinterpret_cast<const f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4);
+            for (int f = 0; f < NF; ++f) {
+                const int mt = kh == 1 ? 1 : 2 * f;
+                mpix[f] = mt * 16 + (lane & 15);
+                const int m = min(mpix[f], HW - 1);
+                other[f] = *reinterpret_cast<const f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4);
+                tvv[f] = *reinterpret_cast<const f32x4 *>(sTab + m * PS + co4);
+                rvv[f] = *reinterpret_cast<const f32x4 *>(sRes + m * PS + co4);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                if (kh == 1 && f > 0) continue;
+                const f32x4 mine = kh == 1 ? acc[1] : (f == 0 ? acc[0] : acc[MT - 1]);
+                f32x4 o;
+                bf16x4 ob;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int m = mt * 16 + 4 * (lane >> 4) + q;
-                    if (m < HW) {
-                        float v = acc[mt][q] + other[q];
-                        if (tab) v += sTab[m * PS + co];
-                        v = v * sc + sh;
-                        if (hasres) v += sRes[m * PS + co];
-                        v = relu ? fmaxf(v, 0.0f) : v;
-                        sOut[m * PS + co] = v;
-                        sBout[m * PB + co] = (__bf16)v;
-                        if (go) go[m * 64 + co] = v;
-                    }
+                    float v = mine[q] + other[f][q];
+                    v += tab ? tvv[f][q] : 0.0f;
+                    v = v * sc[q] + sh[q];
+                    v += res >= 0 ? rvv[f][q] : 0.0f;
+                    o[q] = relu ? fmaxf(v, 0.0f) : v;
+                    ob[q] = (__bf16)o[q];
+                }
+                if (mpix[f] < HW) {
+                    *reinterpret_cast<f32x4 *>(sOut + mpix[f] * PS + co4) = o;
+                    *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + co4) = ob;
+                    if (go) *reinterpret_cast<f32x4 *>(go + mpix[f] * 64 + co4) = o;
                 }
             }
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) wc[t] = wn[t];
         __syncthreads();
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L < 8) step.ts[16 + L] = __builtin_readcyclecounter(); }
     }
     // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU in fp32, as in k_chain_w
     auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {
@@ -1716,7 +1801,135 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 #pragma unroll
         for (int i = 0; i < MT; ++i) c1_tile(wv, i);
     }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[24] = __builtin_readcyclecounter(); }
     lz_stamp_end(a.stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST MODE: 3x3 convolution of the representation tower (48^2, 24^2, 12^2 grids; stride 1 | 2) on v_mfma_f32_16x16x32_bf16.
+// One tile = TR output rows x the full width of one image = 96 output pixels (six 16-pixel MFMA column tiles); the input halo of the tile
+// -- (TR - 1) STRIDE + 3 rows x (Wout - 1) STRIDE + 3 columns x CIN -- is read from the fp32 NHWC tensor, rounded to bf16 and laid out
+// [row][column][CIN + pad] in LDS (pixel pitch 6 | 10 | 5 bank quads: conflict-free ds_read_b128 for stride 1 | 2).  The MFMAs run
+// transposed (weights = A operand, pixels = B operand: D[channel][pixel]), so a lane ends with four consecutive output channels of one
+// pixel and the epilogue (BatchNorm, residual, ReLU) stores 16 contiguous bytes.  Workgroups are PERSISTENT: wave (nt, mg) keeps all
+// 9 CIN / 32 weight fragments of its 16-channel tile nt in registers and walks the tiles blockIdx.x, + gridDim.x, ...; two workgroups
+// per CU overlap one's staging with the other's MFMAs.  fp32 accumulation, fp32 activations in HBM.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void k_conv_bf(lz_conv_args a, int ntiles, int TR)
+{
+    constexpr int NT = COUT / 16, MG = 4 / NT;          // waves = NT channel tiles x MG pixel groups
+    constexpr int MTW = 6 / MG;                         // 16-pixel tiles per wave (96 pixels per workgroup tile)
+    constexpr int KC = CIN / 32, KS = 9 * KC;           // k steps of 32: (tap, 32-channel block)
+    constexpr int PBq = STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10), PB = PBq * 8;   // pixel pitch in bf16
+    static_assert(CIN * 2 <= PB * 2 && (CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "shapes of the tower");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16 *sH = reinterpret_cast<__bf16 *>(smem);      // [HR][HC][PB]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv % NT, mg = wv / NT;
+    const int Wout = a.Wout, Hout = a.Hout, Win = a.Win, Hin = a.Hin;
+    const int HR = (TR - 1) * STRIDE + 3, HC = (Wout - 1) * STRIDE + 3;
+    const int bands = (Hout + TR - 1) / TR;
+    // ---- this wave's weights: [nt][ks][64 lanes][8 bf16]
+    bf16x8 wq[KS];
+    {
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(a.wb) + (size_t)nt * KS * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) wq[k] = wp[(size_t)k * 64];
+    }
+    const int co4 = nt * 16 + 4 * (lane >> 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + co4), sh = *reinterpret_cast<const f32x4 *>(a.shift + co4);
+    // pixel geometry of this lane's B columns (the same for every tile): pixel p = 16 (mg MTW + i) + (lane & 15) of the tile
+    int pbase[MTW], prow[MTW], pcol[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int p = 16 * (mg * MTW + i) + (lane & 15);
+        prow[i] = p / Wout; pcol[i] = p - prow[i] * Wout;
+        pbase[i] = ((prow[i] * STRIDE) * HC + pcol[i] * STRIDE) * PB + (lane >> 4) * 8;   // halo position of tap (0, 0), this lane's k group
+    }
+    constexpr int C4 = CIN / 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / bands, band = tile - img * bands;
+        const int oy0 = band * TR, iy0 = oy0 * STRIDE - 1;
+        // ---- residual rows of this lane's outputs: requested before the staging loads (consumed in the epilogue)
+        f32x4 rv[MTW];
+        bool pok[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            pok[i] = oy0 + prow[i] < Hout;
+            const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + co4;
+            rv[i] = a.residual ? *reinterpret_cast<const f32x4 *>(a.residual + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- stage the halo: fp32 -> bf16, zero outside the image
+        {
+            const int n4 = HR * HC * C4;
+            const float *src = a.in + (size_t)img * Hin * Win * CIN;
+            constexpr int UB = 8;
+            for (int i0 = 0; i0 < n4; i0 += UB * 256) {
+                f32x4 v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int idx = min(i0 + u * 256 + tid, n4 - 1);
+                    const int pix = idx / C4, c4 = idx - pix * C4, hr = pix / HC, hc = pix - hr * HC;
+                    const int iy = iy0 + hr, ix = hc - 1;
+                    const bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(src + ((size_t)min(max(iy, 0), Hin - 1) * Win + min(max(ix, 0), Win - 1)) * CIN + c4 * 4);
+                    v[u] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int idx = i0 + u * 256 + tid;
+                    if (idx < n4) {
+                        const int pix = idx / C4, c4 = idx - pix * C4;
+                        bf16x4 h;
+                        h[0] = (__bf16)v[u][0]; h[1] = (__bf16)v[u][1]; h[2] = (__bf16)v[u][2]; h[3] = (__bf16)v[u][3];
+                        *reinterpret_cast<bf16x4 *>(sH + pix * PB + c4 * 4) = h;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- products: tap by tap, the MTW pixel fragments of a k step are requested together
+        f32x4 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * HC + (t % 3)) * PB;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                bf16x8 bf[MTW];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) bf[i] = *reinterpret_cast<const bf16x8 *>(sH + pbase[i] + toff + kc * 32);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t * KC + kc], bf[i], acc[i], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: BatchNorm, residual, ReLU; four consecutive channels of one pixel per lane
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = acc[i][q] * sc[q] + sh[q];
+                v += rv[i][q];
+                o[q] = a.relu ? fmaxf(v, 0.0f) : v;
+            }
+            if (pok[i]) *reinterpret_cast<f32x4 *>(a.out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + co4) = o;
+        }
+        __syncthreads();   // the halo buffer is rewritten by the next tile
+    }
+}
+
+template <int CIN, int COUT, int STRIDE>
+static void launch_conv_bf(const lz_conv_args &a, hipStream_t s)
+{
+    const int TR = 96 / a.Wout;
+    const int HR = (TR - 1) * STRIDE + 3, HC = (a.Wout - 1) * STRIDE + 3;
+    constexpr int PB = (STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10)) * 8;
+    const size_t lds = (size_t)HR * HC * PB * 2;
+    const int ntiles = a.B * ((a.Hout + TR - 1) / TR);
+    const int grid = ntiles < 512 ? ntiles : 512;   // persistent: two workgroups per CU
+    hipLaunchKernelGGL((k_conv_bf<CIN, COUT, STRIDE>), dim3(grid), dim3(256), lds, s, a, ntiles, TR);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2282,14 +2495,14 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 
 // ------------------------------------------------------------------------------------------------
 // FAST MODE (lz_model_cfg::precision = 1): k_lstm2<68, 0, 16, 36, SH> with the gate product on v_mfma_f32_16x16x32_bf16 -- the rows
-// [x | h] are rounded to bf16 while they are staged ([16][K + 8] bf16 in LDS: one ds_read_b128 per A fragment), the gate weights are bf16
+// [x | h] are rounded to bf16 while they are staged ([16][K + 16] bf16 in LDS: one ds_read_b128 per A fragment), the gate weights are bf16
 // fragments [H/16][4 gates][K/32][64 lanes][8] (lz_lstm_args::wb), accumulation / cell / BatchNorm / split-head partials in fp32 as in
 // k_lstm2.  34 MFMAs per wave instead of 272; a workgroup streams 139 KB of weights instead of 278 KB.
 // ------------------------------------------------------------------------------------------------
 template <bool SH>
 __global__ __launch_bounds__(256) void k_lstm_b(lz_lstm_args a)
 {
-    constexpr int NKB = 68, KXB = 36, K = NKB * 16, NS = K / 32, SX = KXB / 2, PB = K + 8, R = 12, MR = 16;
+    constexpr int NKB = 68, KXB = 36, K = NKB * 16, NS = K / 32, SX = KXB / 2, PB = K + 16, R = 12, MR = 16;   // row pitch = 10 mod 16 bank quads: conflict-free ds_read_b128
     constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // bf16 [16][PB]; reused (fp32) for the gate exchange
     __bf16 *sR = reinterpret_cast<__bf16 *>(smem);
@@ -3024,6 +3237,12 @@ void lz_launch_hinv_nn(const float *d_in, float *d_out, int64_t n, hipStream_t s
 
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s)
 {
+    // fast mode (lz_model_cfg::precision = 1): the layer carries bf16 fragments
+    if (a.wb && !a.gather_ix && !a.act_table && (96 % a.Wout) == 0 && a.Wout <= 96) {
+        if (cin == 32 && a.Cout == 32 && stride == 1) { launch_conv_bf<32, 32, 1>(a, s); return; }
+        if (cin == 32 && a.Cout == 64 && stride == 2) { launch_conv_bf<32, 64, 2>(a, s); return; }
+        if (cin == 64 && a.Cout == 64 && stride == 1) { launch_conv_bf<64, 64, 1>(a, s); return; }
+    }
     // stride-1 convolutions of the tower: Winograd F(2x2, 3x3) when the transformed weights exist (LZ_CONV_DIRECT=1: the direct form)
     static const char *direct = getenv("LZ_CONV_DIRECT");
     if (a.uf && !direct && stride == 1 && !a.gather_ix && !a.act_table && a.Hout >= 12 && (a.Hout & 1) == 0 && (a.Wout & 1) == 0) {
@@ -3131,7 +3350,7 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         for (int i = 0; i < a.nlayers; ++i) fast = fast && a.layer[i].wb != nullptr;
         if (fast) {
             constexpr int hw = 36, mt = 3;
-            const size_t lds = (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 4 * mt * 256) * 4 + (size_t)4 * (hw + 1) * 72 * 2;
+            const size_t lds = (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 4 * mt * 256) * 4 + (size_t)4 * (hw + 1) * 80 * 2;
             const dim3 g(a.B), blk(512);
             if (step) {
                 if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on) hipLaunchKernelGGL((k_chain_b<6, 6, 1, true>), g, blk, lds, s, a, *step);
@@ -3225,7 +3444,7 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     static const char *off = getenv("LZ_LSTM_CHUNKED");
     if (a.wb) {   // fast mode (lz_model_finalize builds the bf16 fragments for this shape only): 576 + 512 columns, no input transform
         const dim3 g(a.H / 16, (a.B + 15) / 16);
-        const size_t lds = std::max((size_t)16 * (68 * 16 + 8) * 2, (size_t)(4 * 16 * 17 + 16 * 17 + 16 * 40 + 16 * 96) * 4);
+        const size_t lds = std::max((size_t)16 * (68 * 16 + 16) * 2, (size_t)(4 * 16 * 17 + 16 * 17 + 16 * 40 + 16 * 96) * 4);
         if (a.sh_part && a.sh_kc == 1152) hipLaunchKernelGGL((k_lstm_b<true>), g, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((k_lstm_b<false>), g, dim3(256), lds, s, a);
         return true;

@@ -15,6 +15,7 @@ struct lz_conv_args {
     const float *w;         // packed [Cout/16][9][16][CIN]
     const float *wf;        // optional MFMA-fragment order [Cout/16][9][CIN/16][64 lanes][4] (big-grid kernel)
     const float *uf;        // optional Winograd F(2x2,3x3) weights U = G g G^T in fragment order [Cout/16][16 points][CIN/16][64 lanes][4]
+    const void *wb;         // optional (fast mode): bf16 MFMA fragments [Cout/16][9 taps x CIN/32][64 lanes][8] (k_conv_bf)
     const float *scale;     // [Cout] folded eval-mode BN scale (1 when no norm)
     const float *shift;     // [Cout]
     const float *act_table; // optional [A][Hout*Wout][Cout]: contribution of the one-hot action planes

@@ -216,6 +216,14 @@ extern "C" int lz_model_finalize(lz_engine *e)
         m->r2b = b.resconv(d + "resblocks2.0", 2, C, C, true);
         m->r3a = b.resconv(d + "resblocks3.0", 1, C, C, true);
         m->r3b = b.resconv(d + "resblocks3.0", 2, C, C, true);
+        if (c.precision == 1) {   // fast mode: the tower's convolutions on bf16 MFMA (k_conv_bf)
+            auto rc = [&](const std::string &blk, int idx) { return d + blk + ".conv" + std::to_string(idx) + ".0.weight"; };
+            m->r1a.wt = b.bf16_tower(rc("resblocks1.0", 1), C2, C2); m->r1b.wt = b.bf16_tower(rc("resblocks1.0", 2), C2, C2);
+            m->dn1.wt = b.bf16_tower(rc("downsample_block", 1), C, C2); m->dn2.wt = b.bf16_tower(rc("downsample_block", 2), C, C);
+            m->dn3.wt = b.bf16_tower(d + "downsample_block.conv3.0.weight", C, C2);
+            m->r2a.wt = b.bf16_tower(rc("resblocks2.0", 1), C, C); m->r2b.wt = b.bf16_tower(rc("resblocks2.0", 2), C, C);
+            m->r3a.wt = b.bf16_tower(rc("resblocks3.0", 1), C, C); m->r3b.wt = b.bf16_tower(rc("resblocks3.0", 2), C, C);
+        }
         }
         m->rep_res.clear();
         for (int i = 0; i < NRB; ++i) {
@@ -432,7 +440,7 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
                  int relu, hipStream_t s)
 {
     lz_conv_args a{};
-    a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
+    a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.wb = w.wt; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
 }
@@ -1341,7 +1349,7 @@ extern "C" int lz_debug_read_tree_ts(unsigned long long *h_out)   // LZ_DEBUG_TR
 {
     LZ_REQUIRE(g_tree_ts != nullptr && h_out != nullptr, "LZ_DEBUG_TREE_TS was not set");
     LZ_HIP_CHECK(hipDeviceSynchronize());
-    LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_ts, 16 * 8, hipMemcpyDeviceToHost));   // [0..6] the tree wave, [8..14] head wave 1 (split heads)
+    LZ_HIP_CHECK(hipMemcpy(h_out, g_tree_ts, 32 * 8, hipMemcpyDeviceToHost));   // [0..6] the tree wave, [8..14] head wave 1 (split heads), [16..31] k_chain_b: layer ends, kernel end
     return LZ_OK;
 }
 static unsigned long long *g_tree_sep_ts = nullptr;
@@ -1565,7 +1573,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
                 if (defer) split_heads_for(r, slot, step.sh);
 #ifdef LZ_DEBUG_KNOBS
                 if (getenv("LZ_DEBUG_TREE_TS")) {   // timing experiments only: stamps of root 0's step in the last fused launch
-                    if (!g_tree_ts) (void)lz_dev_malloc((void **)&g_tree_ts, 16 * 8);
+                    if (!g_tree_ts) (void)lz_dev_malloc((void **)&g_tree_ts, 32 * 8);
                     step.ts = g_tree_ts;
                 }
 #endif

@@ -54,6 +54,27 @@ def test_recurrent_step_is_within_bf16_roundoff_of_the_fp32_engine():
     assert not np.array_equal(of.latent_state.numpy(), op.latent_state.numpy())
 
 
+def test_initial_inference_is_within_bf16_roundoff_of_the_fp32_engine():
+    """the representation tower on k_conv_bf (eleven 3x3 convolutions deep) + the chain's residual blocks on k_chain_b"""
+    from lightzero_amd import _lib as L
+    ref, par, fast = _models()
+    B = 21
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(6))
+    op, of = par.initial_inference(obs), fast.initial_inference(obs)
+    lat = []
+    for m in (par, fast):
+        own = m._own_roots(B, "infer", 2)
+        x = np.zeros((B, 64, 6, 6), np.float32)
+        L.check(L.lib().lz_roots_read_latent(own._h, 0, x.reshape(-1)))
+        lat.append(x)
+    with torch.no_grad():
+        want = ref.initial_inference(obs).latent_state.numpy()
+    assert _rel(lat[0], want) < 1e-4            # (the parity engine: fp32)
+    assert 1e-5 < _rel(lat[1], want) < 3e-2     # fast: bf16 round-off, eleven layers deep -- and not the fp32 path
+    assert _rel(of.policy_logits, op.policy_logits) < 5e-2
+    assert float(np.abs(of.value.numpy() - op.value.numpy()).max()) < 0.02 * float(np.abs(op.value.numpy()).max())
+
+
 def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 

@@ -1,0 +1,8 @@
+# fast mode (bench.py --fast): tests, in-graph stamps of the chain / LSTM launches, phase stamps of the last fused chain launch (debug library)
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_fast_mode_gpu.py -m gpu -q -s 2>&1 | grep -v "^$\|amdgpu.ids" | tail -4
+for i in 1 2; do
+timeout 200 python bench.py --fast --no-cpu-baseline --sustain-s 0 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('fast: value %.0f  ms/step %.3f  chain %.2f (exec %.2f)  lstm %.2f (exec %.2f)  per-sim %.2f' % (d['value'], d['ms_per_step'], r['avg_launch_us'], r['avg_exec_us'], r['lstm_launch_us'], r['lstm_exec_us'], r['per_simulation_us']))"
+done
+LZ_TOOL_FAST=1 timeout 200 python tools/tree_timing.py 2>&1 | grep -v amdgpu.ids
