@@ -173,6 +173,49 @@ def policy_surface(model, obs, steps=10):
     return ENVS * steps / (time.perf_counter() - t0)
 
 
+def fast_mode_arm(weights, obs, steps, warmup, seed=7):
+    """The FAST MODE arm beside the parity-mode headline (last arm): the same step -- initial inference, device
+    Dirichlet noise + prepare, 50 simulations, select_action + row packing, header read-back -- on EfficientZeroModel(fast_mode=True)
+    (bf16 MFMA products, fp32 accumulation; statistical parity only, tests/test_fast_mode_gpu.py).  A separate number, never `value`."""
+    from lightzero_amd import _lib as L, shard
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    lib = L.lib()
+    eng = L.new_engine(int(os.environ.get("LOCAL_RANK", "0")))
+    model = EfficientZeroModel(action_space_size=ACTIONS, engine=eng, fast_mode=True).load_state_dict(weights)
+    n = obs.shape[0]
+    roots = ez_tree.Roots(n, [list(range(ACTIONS))] * n, action_space_size=ACTIONS, max_simulations=SIMS, engine=eng)
+    roots.set_tiebreak(1, seed=seed)
+    roots._ensure(ACTIONS)
+    to_play = L.i32([-1] * n)
+    W, HW = shard.row_width(ACTIONS, FRAME), shard.HEADER + 2 * ACTIONS
+    rows = torch.zeros(n, W, device="cuda")
+    timestep = np.zeros(n, np.int32)
+    torch.cuda.synchronize()
+
+    def one(i):
+        L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
+        L.check(lib.lz_roots_prepare_from_inference_dirichlet(roots._h, CFG["root_noise_weight"], CFG["root_dirichlet_alpha"], to_play))
+        L.check(lib.lz_search(roots._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], CFG["lstm_horizon_len"], CFG["value_delta_max"]))
+        timestep[:] = i
+        h = np.zeros((n, HW), np.float32); lg = np.zeros((n, ACTIONS), np.float32)
+        L.check(lib.lz_roots_collect_rows(roots._h, 1.0, 0, (i * 1315423911 + 5) & (2 ** 62 - 1), None, FRAME, timestep.ctypes.data, rows.data_ptr(), W, h, lg.ctypes.data))
+        return h
+    for i in range(warmup):
+        one(i)
+    L.check(lib.lz_engine_synchronize(eng))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        h = one(warmup + i)
+    L.check(lib.lz_engine_synchronize(eng))
+    dt = time.perf_counter() - t0
+    assert (np.array(roots.get_distributions()).sum(1) == SIMS).all()
+    return dict(env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3, steps=steps, warmup=warmup, dtype="bf16 products, f32 accumulation",
+                note="FAST MODE arm (EfficientZeroModel(fast_mode=True)): representation tower, recurrent chain and LSTM gate product on bf16 MFMA "
+                     "(k_conv_bf, k_chain_b, k_lstm_b); heads, normalisation, cell and tree in fp32; statistical parity only -- reported "
+                     "separately from the parity-mode `value` (BASELINE.md section 2, last arm)")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -543,6 +586,11 @@ def main():
             for k in ("traffic", "achieved_profiled", "frac_profile", "avg_launch_us_profile"):
                 rf[k] = None
             rf["traffic_unit"] = rf["profile"] = "fast mode: no committed PMC / rocprofv3 pass"
+        if world == 1 and not args.fast and NS == 1:
+            try:
+                out["fast_mode"] = fast_mode_arm(weights, obs, args.steps, args.warmup)
+            except Exception as e:   # a secondary arm never takes the measured line down with it
+                out["fast_mode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["config"]["policy_surface_env_steps_per_s"] = policy_surface(models[0], obs)

@@ -2242,11 +2242,15 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // (Measured and dropped: one 8-wave 32-row workgroup per CU -- (gate, row tile) waves sharing every weight fragment through L1,
 // 411 KB instead of 684 KB through the CU -- 13.9 us against 13.6 us for two 4-wave 16-row workgroups: the kernel is bound by
 // the matrix pipe (17.4 k MFMA cycles per SIMD) plus its serial staging / epilogue, not by the L1 fill rate.)
+// row pitch of the staged [x | h] rows = K + 8 floats = 4 NKB + 2 bank quads: the A fragments are ds_read_b128 of 16 rows x 4 k groups, served in
+// the 16-lane groups {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS) -- a pitch of 2 (mod 4) quads puts each group on 16 distinct bank
+// quads; K + 4 (1 mod 4 quads) was a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT: 43 % of the LDS cycles of this kernel)
+constexpr int LSTM_PAD = 8;
 template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
     static_assert(!SH || MR == 16, "the split-head partials are written for 16-row workgroups");
-    constexpr int K = NKB * 16, PS = K + 4, R = 12;
+    constexpr int K = NKB * 16, PS = K + LSTM_PAD, R = 12;
     constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
     constexpr bool TWO = MR == 32;                         // a wave computes both 16-row tiles of a 32-row workgroup
     static_assert(MR == 32 || (MR == 16 && XV == 0), "the input transform is written for 8 staging lanes per row");
@@ -2665,7 +2669,7 @@ __global__ __launch_bounds__(256) void k_lstm_b(lz_lstm_args a)
 template <int NKB, bool SH>
 __global__ __launch_bounds__(256) void k_lstm3(lz_lstm_args a)
 {
-    constexpr int K = NKB * 16, PS = K + 4, R = 12, MR = 32, NTHR = 256;
+    constexpr int K = NKB * 16, PS = K + LSTM_PAD, R = 12, MR = 32, NTHR = 256;
     constexpr int CH = 16, NCH = (NKB + CH - 1) / CH;   // k-steps per staging chunk; chunks
     constexpr int K4 = K / 4, F4C = CH * 4, NLD = F4C / 8;   // float4 per row; per row and chunk; per thread and chunk (8 threads per row)
     constexpr int NQ = MR * 16 / NTHR;                  // (row, unit) pairs per thread in the cell epilogue
@@ -3453,10 +3457,10 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     if (off && !a.x_ln_g && !a.x_act) return false;  // the chunked kernel has no input transform
     const int nkb = (a.KX + a.H) / 16;
     dim3 grid(a.H / 16, (a.B + 31) / 32), block(256);
-    const size_t lds = (size_t)32 * ((size_t)nkb * 16 + 4) * 4;
+    const size_t lds = (size_t)32 * ((size_t)nkb * 16 + LSTM_PAD) * 4;
     const bool xf = a.x_ln_g || a.x_act;
     if (nkb == 96 && !xf) {  // 1024 + 512 (EfficientZero conv on 64x64 observations: 8x8 latent): 16-row tiles, 98.5 KB of LDS
-        hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+        hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
         return true;
     }
     // 16-row tiles (70 KB of LDS, 512 workgroups at 256 roots): two workgroups per CU, so one's staging and cell epilogue run
@@ -3466,7 +3470,7 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     static const char *lstm3 = getenv("LZ_LSTM3");   // the pipelined 32-row kernel (A/B switch while it is being qualified)
     if (nkb == 68 && !xf && !big_rows && lstm3 && a.KX == 576 && a.H == 512 && a.B >= 32) {
         const dim3 g3(a.H / 16, (a.B + 31) / 32);
-        const size_t l3 = (size_t)32 * ((size_t)nkb * 16 + 4) * 4;
+        const size_t l3 = (size_t)32 * ((size_t)nkb * 16 + LSTM_PAD) * 4;
         if (a.sh_part && a.sh_kc == 1152) hipLaunchKernelGGL((k_lstm3<68, true>), g3, block, l3, s, a);
         else hipLaunchKernelGGL((k_lstm3<68, false>), g3, block, l3, s, a);
         return true;
@@ -3474,15 +3478,15 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     if (nkb == 68 && !xf && !big_rows) {
         static const char *nosplit = getenv("LZ_LSTM_NOSPLIT");  // the one-burst staging (A/B timing, parity: both forms are bit-identical)
         if (a.KX == 576 && !nosplit && a.sh_part && a.H == 512 && a.sh_kc == 1152)
-            hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
-        else if (a.KX == 576 && !nosplit) hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
-        else hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + 4) * 4, s, a);
+            hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        else if (a.KX == 576 && !nosplit) hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        else hipLaunchKernelGGL((k_lstm2<68, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
         return true;
     }
     if (nkb == 41 && !xf) { hipLaunchKernelGGL((k_lstm2<41>), grid, block, lds, s, a); return true; }   // 16 x 9 + 512 (TicTacToe EfficientZero)
     if ((nkb == 74 || nkb == 113) && !xf) {   // 16 x 42 + 512 (6x7 boards), 16 x 81 + 512 (9x9 boards): 16-row tiles (116 KB of LDS at 9x9)
         const dim3 g16(a.H / 16, (a.B + 15) / 16);
-        const size_t l16 = (size_t)16 * ((size_t)nkb * 16 + 4) * 4;
+        const size_t l16 = (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4;
         if (nkb == 74) hipLaunchKernelGGL((k_lstm2<74, 0, 16>), g16, block, l16, s, a);
         else hipLaunchKernelGGL((k_lstm2<113, 0, 16>), g16, block, l16, s, a);
         return true;
