@@ -177,6 +177,7 @@ def fast_mode_arm(weights, obs, steps, warmup, seed=7):
     """The FAST MODE arm beside the parity-mode headline (last arm): the same step -- initial inference, device
     Dirichlet noise + prepare, 50 simulations, select_action + row packing, header read-back -- on EfficientZeroModel(fast_mode=True)
     (bf16 MFMA products, fp32 accumulation; statistical parity only, tests/test_fast_mode_gpu.py).  A separate number, never `value`."""
+    import torch
     from lightzero_amd import _lib as L, shard
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
