@@ -468,7 +468,11 @@ __global__ __launch_bounds__(256) void k_conv_wino(lz_conv_args a)
 // first DownSample layer: conv3x3 / stride 2 from NCHW observations, + BN + ReLU.  One thread per
 // output pixel computes all Cout channels from the (<= 9*C)-value patch; weights broadcast from LDS.
 // ------------------------------------------------------------------------------------------------
-template <int C, int COUT>
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+
+// OUTBF (fast mode): the output tensor is bf16 NHWC (the tower keeps its activations in bf16 there)
+template <int C, int COUT, bool OUTBF = false>
 __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ obs, const float *__restrict__ w,
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
                                                     float *__restrict__ out, int B, int H, int W)
@@ -509,8 +513,15 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ ob
             for (int c = 0; c < 8; ++c) acc[c] += xs * wr[c];
         }
     }
-    float *o = out + (size_t)m * COUT + g * 8;
     const float *sc = scale + g * 8, *sh = shift + g * 8;
+    if constexpr (OUTBF) {
+        bf16x8 v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (__bf16)fmaxf(acc[c] * sc[c] + sh[c], 0.f);
+        *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(out) + (size_t)m * COUT + g * 8) = v;
+        return;
+    }
+    float *o = out + (size_t)m * COUT + g * 8;
 #pragma unroll
     for (int c = 0; c < 8; c += 4) {
         float4 v;
@@ -577,6 +588,40 @@ __global__ __launch_bounds__(256) void k_avgpool(const float *__restrict__ in, f
     }
     s.x /= 9.0f; s.y /= 9.0f; s.z /= 9.0f; s.w /= 9.0f;
     *reinterpret_cast<float4 *>(out + (size_t)pix * C + c4 * 4) = s;
+}
+
+// the same pooling on a bf16 NHWC input (fast mode), 8 channels per thread; OUTBF: bf16 output, otherwise fp32 (the chain's input)
+template <bool OUTBF>
+__global__ __launch_bounds__(256) void k_avgpool_bf(const __bf16 *__restrict__ in, void *__restrict__ out, int B, int Hin, int Win, int C)
+{
+    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2, C8 = C / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * Ho * Wo * C8) return;
+    const int c8 = (int)(idx % C8);
+    const int64_t pix = idx / C8;
+    const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+    float sacc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sacc[c] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = 2 * y + t / 3 - 1, ix = 2 * x + t % 3 - 1;
+        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(in + (((size_t)b * Hin + iy) * Win + ix) * C + c8 * 8);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sacc[c] += (float)v[c];
+        }
+    }
+    if constexpr (OUTBF) {
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (__bf16)(sacc[c] / 9.0f);
+        *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(out) + (size_t)pix * C + c8 * 8) = o;
+    } else {
+        float *o = reinterpret_cast<float *>(out) + (size_t)pix * C + c8 * 8;
+        *reinterpret_cast<float4 *>(o) = make_float4(sacc[0] / 9.0f, sacc[1] / 9.0f, sacc[2] / 9.0f, sacc[3] / 9.0f);
+        *reinterpret_cast<float4 *>(o + 4) = make_float4(sacc[4] / 9.0f, sacc[5] / 9.0f, sacc[6] / 9.0f, sacc[7] / 9.0f);
+    }
 }
 
 // conv1x1 (64 -> 16) + bias + BN + ReLU as a small MFMA GEMM: 144 pixels x 16 channels per workgroup, the 4
@@ -1480,9 +1525,6 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
 // LDS twice: fp32 (residual, action table add, head convs, pool) and a bf16 copy [pixel][80] that serves the pixel operand with ONE
 // conflict-free ds_read_b128 per (pixel tile, tap).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
-
 template <int GW, int GH, int TREE = 0, bool HEADS = false>
 __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_arg<TREE>::type step)
 {
@@ -1808,12 +1850,13 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 // ------------------------------------------------------------------------------------------------
 // FAST MODE: 3x3 convolution of the representation tower (48^2, 24^2, 12^2 grids; stride 1 | 2) on v_mfma_f32_16x16x32_bf16.
 // One tile = TR output rows x the full width of one image = 96 output pixels (six 16-pixel MFMA column tiles); the input halo of the tile
-// -- (TR - 1) STRIDE + 3 rows x (Wout - 1) STRIDE + 3 columns x CIN -- is read from the fp32 NHWC tensor, rounded to bf16 and laid out
+// -- (TR - 1) STRIDE + 3 rows x (Wout - 1) STRIDE + 3 columns x CIN -- is copied from the bf16 NHWC tensor and laid out
 // [row][column][CIN + pad] in LDS (pixel pitch 6 | 10 | 5 bank quads: conflict-free ds_read_b128 for stride 1 | 2).  The MFMAs run
 // transposed (weights = A operand, pixels = B operand: D[channel][pixel]), so a lane ends with four consecutive output channels of one
-// pixel and the epilogue (BatchNorm, residual, ReLU) stores 16 contiguous bytes.  Workgroups are PERSISTENT: wave (nt, mg) keeps all
-// 9 CIN / 32 weight fragments of its 16-channel tile nt in registers and walks the tiles blockIdx.x, + gridDim.x, ...; two workgroups
-// per CU overlap one's staging with the other's MFMAs.  fp32 accumulation, fp32 activations in HBM.
+// pixel and the epilogue (BatchNorm, residual, ReLU) stores them together.  Workgroups are PERSISTENT: wave (nt, mg) keeps all
+// 9 CIN / 32 weight fragments of its 16-channel tile nt in registers and walks the tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's halo is
+// requested into registers before this tile's MFMAs and lands in the other of two LDS buffers (one barrier per tile).  fp32 accumulation; the
+// tower's activations are bf16 NHWC tensors in HBM in this mode (lz_conv_args::act_bf16: input, residual, output).
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int STRIDE>
 __global__ __launch_bounds__(256) void k_conv_bf(lz_conv_args a, int ntiles, int TR)
@@ -1822,13 +1865,18 @@ __global__ __launch_bounds__(256) void k_conv_bf(lz_conv_args a, int ntiles, int
     constexpr int MTW = 6 / MG;                         // 16-pixel tiles per wave (96 pixels per workgroup tile)
     constexpr int KC = CIN / 32, KS = 9 * KC;           // k steps of 32: (tap, 32-channel block)
     constexpr int PBq = STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10), PB = PBq * 8;   // pixel pitch in bf16
-    static_assert(CIN * 2 <= PB * 2 && (CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "shapes of the tower");
+    constexpr int C8 = CIN / 8, NLD = STRIDE == 2 ? 7 : 5;   // 16-byte pieces per pixel; pieces per thread and halo (launch_conv_bf checks the bound)
+    static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "shapes of the tower");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16 *sH = reinterpret_cast<__bf16 *>(smem);      // [HR][HC][PB]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv % NT, mg = wv / NT;
     const int Wout = a.Wout, Hout = a.Hout, Win = a.Win, Hin = a.Hin;
     const int HR = (TR - 1) * STRIDE + 3, HC = (Wout - 1) * STRIDE + 3;
     const int bands = (Hout + TR - 1) / TR;
+    const int n8 = HR * HC * C8;
+    __bf16 *sH0 = reinterpret_cast<__bf16 *>(smem);     // two halo buffers [HR][HC][PB]
+    const int hbuf = ((HR * HC * PB + 7) & ~7);
+    const __bf16 *in = reinterpret_cast<const __bf16 *>(a.in), *res = reinterpret_cast<const __bf16 *>(a.residual);
+    __bf16 *out = reinterpret_cast<__bf16 *>(a.out);
     // ---- this wave's weights: [nt][ks][64 lanes][8 bf16]
     bf16x8 wq[KS];
     {
@@ -1846,48 +1894,53 @@ __global__ __launch_bounds__(256) void k_conv_bf(lz_conv_args a, int ntiles, int
         prow[i] = p / Wout; pcol[i] = p - prow[i] * Wout;
         pbase[i] = ((prow[i] * STRIDE) * HC + pcol[i] * STRIDE) * PB + (lane >> 4) * 8;   // halo position of tap (0, 0), this lane's k group
     }
-    constexpr int C4 = CIN / 4;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // halo geometry of this thread's 16-byte pieces (the same for every tile): piece u = (pixel, 8-channel block)
+    int hsrc[NLD], hdst[NLD], hrow[NLD];
+    bool hcol_ok[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int idx = min(u * 256 + tid, n8 - 1);
+        const int pix = idx / C8, c8 = idx - pix * C8, hr = pix / HC, hc = pix - hr * HC, ix = hc - 1;
+        hrow[u] = hr;
+        hcol_ok[u] = (ix >= 0) & (ix < Win);
+        hsrc[u] = min(max(ix, 0), Win - 1) * CIN + c8 * 8;
+        hdst[u] = (u * 256 + tid < n8) ? pix * PB + c8 * 8 : -1;
+    }
+    bf16x8 pv[NLD];
+    auto prefetch = [&](int tile) {   // the whole halo of a tile in flight at once (clamped addresses, zero outside the image by select)
+        const int img = tile / bands, band = tile - img * bands, iy0 = band * TR * STRIDE - 1;
+        const __bf16 *src = in + (size_t)img * Hin * Win * CIN;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int iy = iy0 + hrow[u];
+            const bf16x8 t = *reinterpret_cast<const bf16x8 *>(src + (size_t)min(max(iy, 0), Hin - 1) * Win * CIN + hsrc[u]);
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            pv[u] = ((iy >= 0) & (iy < Hin) & hcol_ok[u]) ? t : z;
+        }
+    };
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int img = tile / bands, band = tile - img * bands;
-        const int oy0 = band * TR, iy0 = oy0 * STRIDE - 1;
-        // ---- residual rows of this lane's outputs: requested before the staging loads (consumed in the epilogue)
-        f32x4 rv[MTW];
+        const int oy0 = band * TR;
+        __bf16 *sH = sH0 + buf * hbuf;
+        // ---- the prefetched halo into this tile's LDS buffer (double-buffered: one barrier per tile)
+#pragma unroll
+        for (int u = 0; u < NLD; ++u)
+            if (hdst[u] >= 0) *reinterpret_cast<bf16x8 *>(sH + hdst[u]) = pv[u];
+        // ---- residual rows of this lane's outputs (consumed in the epilogue)
+        bf16x4 rv[MTW];
         bool pok[MTW];
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             pok[i] = oy0 + prow[i] < Hout;
             const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + co4;
-            rv[i] = a.residual ? *reinterpret_cast<const f32x4 *>(a.residual + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- stage the halo: fp32 -> bf16, zero outside the image
-        {
-            const int n4 = HR * HC * C4;
-            const float *src = a.in + (size_t)img * Hin * Win * CIN;
-            constexpr int UB = 8;
-            for (int i0 = 0; i0 < n4; i0 += UB * 256) {
-                f32x4 v[UB];
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int idx = min(i0 + u * 256 + tid, n4 - 1);
-                    const int pix = idx / C4, c4 = idx - pix * C4, hr = pix / HC, hc = pix - hr * HC;
-                    const int iy = iy0 + hr, ix = hc - 1;
-                    const bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(src + ((size_t)min(max(iy, 0), Hin - 1) * Win + min(max(ix, 0), Win - 1)) * CIN + c4 * 4);
-                    v[u] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int idx = i0 + u * 256 + tid;
-                    if (idx < n4) {
-                        const int pix = idx / C4, c4 = idx - pix * C4;
-                        bf16x4 h;
-                        h[0] = (__bf16)v[u][0]; h[1] = (__bf16)v[u][1]; h[2] = (__bf16)v[u][2]; h[3] = (__bf16)v[u][3];
-                        *reinterpret_cast<bf16x4 *>(sH + pix * PB + c4 * 4) = h;
-                    }
-                }
-            }
+            const bf16x4 z = {0, 0, 0, 0};
+            rv[i] = res ? *reinterpret_cast<const bf16x4 *>(res + o) : z;
         }
         __syncthreads();
+        // ---- the next tile's halo travels while this one is multiplied
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         // ---- products: tap by tap, the MTW pixel fragments of a k step are requested together
         f32x4 acc[MTW];
 #pragma unroll
@@ -1907,16 +1960,15 @@ __global__ __launch_bounds__(256) void k_conv_bf(lz_conv_args a, int ntiles, int
         // ---- epilogue: BatchNorm, residual, ReLU; four consecutive channels of one pixel per lane
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            f32x4 o;
+            bf16x4 ob;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = acc[i][q] * sc[q] + sh[q];
-                v += rv[i][q];
-                o[q] = a.relu ? fmaxf(v, 0.0f) : v;
+                v += (float)rv[i][q];
+                ob[q] = (__bf16)(a.relu ? fmaxf(v, 0.0f) : v);
             }
-            if (pok[i]) *reinterpret_cast<f32x4 *>(a.out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + co4) = o;
+            if (pok[i]) *reinterpret_cast<bf16x4 *>(out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + co4) = ob;
         }
-        __syncthreads();   // the halo buffer is rewritten by the next tile
     }
 }
 
@@ -1926,7 +1978,7 @@ static void launch_conv_bf(const lz_conv_args &a, hipStream_t s)
     const int TR = 96 / a.Wout;
     const int HR = (TR - 1) * STRIDE + 3, HC = (a.Wout - 1) * STRIDE + 3;
     constexpr int PB = (STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10)) * 8;
-    const size_t lds = (size_t)HR * HC * PB * 2;
+    const size_t lds = (size_t)2 * (((size_t)HR * HC * PB + 7) & ~(size_t)7) * 2;
     const int ntiles = a.B * ((a.Hout + TR - 1) / TR);
     const int grid = ntiles < 512 ? ntiles : 512;   // persistent: two workgroups per CU
     hipLaunchKernelGGL((k_conv_bf<CIN, COUT, STRIDE>), dim3(grid), dim3(256), lds, s, a, ntiles, TR);
@@ -3242,7 +3294,7 @@ void lz_launch_hinv_nn(const float *d_in, float *d_out, int64_t n, hipStream_t s
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s)
 {
     // fast mode (lz_model_cfg::precision = 1): the layer carries bf16 fragments
-    if (a.wb && !a.gather_ix && !a.act_table && (96 % a.Wout) == 0 && a.Wout <= 96) {
+    if (a.wb && a.act_bf16 && !a.gather_ix && !a.act_table && (a.Wout == 48 || a.Wout == 24 || a.Wout == 12)) {   // (the halo of these grids fits the kernel's per-thread piece count)
         if (cin == 32 && a.Cout == 32 && stride == 1) { launch_conv_bf<32, 32, 1>(a, s); return; }
         if (cin == 32 && a.Cout == 64 && stride == 2) { launch_conv_bf<32, 64, 2>(a, s); return; }
         if (cin == 64 && a.Cout == 64 && stride == 1) { launch_conv_bf<64, 64, 1>(a, s); return; }
@@ -3276,10 +3328,14 @@ void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s
 }
 
 void lz_launch_conv_first(const float *obs, const float *w, const float *scale, const float *shift, float *out, int B,
-                          int C, int H, int W, int Cout, hipStream_t s)
+                          int C, int H, int W, int Cout, hipStream_t s, int out_bf16)
 {
     const int64_t M = (int64_t)B * (H / 2) * (W / 2);
     dim3 grid((unsigned)((M + 63) / 64)), block(256);
+    if (out_bf16) {   // fast mode: 4 x 96 x 96 observations only (lz_model_create)
+        hipLaunchKernelGGL((k_conv_first<4, 32, true>), grid, block, 0, s, obs, w, scale, shift, out, B, H, W);
+        return;
+    }
     if (C == 4 && Cout == 32) hipLaunchKernelGGL((k_conv_first<4, 32>), grid, block, 0, s, obs, w, scale, shift, out, B, H, W);
     else if (C == 1 && Cout == 32) hipLaunchKernelGGL((k_conv_first<1, 32>), grid, block, 0, s, obs, w, scale, shift, out, B, H, W);
     else if (C == 3 && Cout == 32) hipLaunchKernelGGL((k_conv_first<3, 32>), grid, block, 0, s, obs, w, scale, shift, out, B, H, W);
@@ -3298,9 +3354,16 @@ void lz_launch_conv_in(const float *obs, const float *w, const float *scale, con
     else if (Cout == 16) hipLaunchKernelGGL(k_conv_in<16>, grid, dim3(256), lds, s, obs, w, scale, shift, out, B, C, H, W);
 }
 
-void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s)
+void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s, int in_bf16, int out_bf16)
 {
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
+    if (in_bf16) {
+        const int64_t n8 = (int64_t)B * Ho * Wo * (C / 8);
+        const dim3 g((unsigned)((n8 + 255) / 256));
+        if (out_bf16) hipLaunchKernelGGL((k_avgpool_bf<true>), g, dim3(256), 0, s, reinterpret_cast<const __bf16 *>(in), (void *)out, B, Hin, Win, C);
+        else hipLaunchKernelGGL((k_avgpool_bf<false>), g, dim3(256), 0, s, reinterpret_cast<const __bf16 *>(in), (void *)out, B, Hin, Win, C);
+        return;
+    }
     const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, Hin, Win, C);
 }

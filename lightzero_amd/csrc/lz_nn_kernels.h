@@ -16,6 +16,7 @@ struct lz_conv_args {
     const float *wf;        // optional MFMA-fragment order [Cout/16][9][CIN/16][64 lanes][4] (big-grid kernel)
     const float *uf;        // optional Winograd F(2x2,3x3) weights U = G g G^T in fragment order [Cout/16][16 points][CIN/16][64 lanes][4]
     const void *wb;         // optional (fast mode): bf16 MFMA fragments [Cout/16][9 taps x CIN/32][64 lanes][8] (k_conv_bf)
+    int act_bf16;           // with wb: in / residual / out are bf16 NHWC tensors (the fast tower keeps its activations in bf16), not fp32
     const float *scale;     // [Cout] folded eval-mode BN scale (1 when no norm)
     const float *shift;     // [Cout]
     const float *act_table; // optional [A][Hout*Wout][Cout]: contribution of the one-hot action planes
@@ -31,14 +32,14 @@ void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s
 
 // first layer of DownSample: conv3x3 stride 2 from NCHW obs [B][C][H][W] (C <= 4... any small C) to NHWC
 void lz_launch_conv_first(const float *obs_nchw, const float *w /*[9][C][Cout]*/, const float *scale,
-                          const float *shift, float *out, int B, int C, int H, int W, int Cout, hipStream_t s);
+                          const float *shift, float *out, int B, int C, int H, int W, int Cout, hipStream_t s, int out_bf16 = 0);
 
 // first layer of a no-downsample representation network: conv3x3 stride 1 from NCHW obs to NHWC [B][H*W][64] + BN + ReLU
 void lz_launch_conv_in(const float *obs_nchw, const float *w /*[9][C][Cout]*/, const float *scale, const float *shift,
                        float *out, int B, int C, int H, int W, int Cout, hipStream_t s);
 
 // AvgPool2d(kernel 3, stride 2, pad 1, count_include_pad) on NHWC
-void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s);
+void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s, int in_bf16 = 0, int out_bf16 = 0);   // (bf16 tensors: fast mode)
 
 // conv1x1 (64 -> 16 channels per job) + bias + BN + ReLU on NHWC [npix][64] as a small MFMA GEMM; up to 4
 // independent jobs (e.g. reward / value / policy head convolutions) share one launch (blockIdx.y = job).

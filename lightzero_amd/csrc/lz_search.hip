@@ -437,9 +437,10 @@ static int ensure_ws(lz_model *m, int B)
 }
 
 static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
-                 int relu, hipStream_t s)
+                 int relu, hipStream_t s, int act_bf16 = 0)
 {
     lz_conv_args a{};
+    a.act_bf16 = act_bf16;
     a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.wb = w.wt; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
@@ -597,32 +598,33 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
 #define LZ_STAGE() do { if (m->debug_stop == ++stage) { LZ_HIP_CHECK(hipStreamSynchronize(s)); return LZ_OK; } } while (0)
     // grid sizes for 96 | 64 observations: S1 = 48 | 32, S2 = 24 | 16, S3 = 12 | 8, then 6 | (no second pooling)
     const int S1 = c.obs_h / 2, S2 = (S1 + 1) / 2, S3 = (S2 + 1) / 2;
-    lz_launch_conv_first(d_obs, m->first_w, m->first_s, m->first_t, w0, B, c.obs_c, c.obs_h, c.obs_w, C / 2, s);  // S1 x S1 x 32
+    const int bf = c.precision == 1 ? 1 : 0;   // fast mode: the tower's activations are bf16 NHWC tensors (in the same workspaces), fp32 again out of the last pooling
+    lz_launch_conv_first(d_obs, m->first_w, m->first_s, m->first_t, w0, B, c.obs_c, c.obs_h, c.obs_w, C / 2, s, bf);  // S1 x S1 x 32
     LZ_STAGE();
-    conv(m->r1a, w0, w1, B, S1, S1, 1, nullptr, 1, s);
+    conv(m->r1a, w0, w1, B, S1, S1, 1, nullptr, 1, s, bf);
     LZ_STAGE();
-    conv(m->r1b, w1, w2, B, S1, S1, 1, w0, 1, s);            // w2: S1 x S1 x 32
+    conv(m->r1b, w1, w2, B, S1, S1, 1, w0, 1, s, bf);            // w2: S1 x S1 x 32
     LZ_STAGE();
-    conv(m->dn1, w2, w0, B, S1, S2, 2, nullptr, 1, s);       // w0: S2 x S2 x 64
+    conv(m->dn1, w2, w0, B, S1, S2, 2, nullptr, 1, s, bf);       // w0: S2 x S2 x 64
     LZ_STAGE();
-    conv(m->dn3, w2, w1, B, S1, S2, 2, nullptr, 0, s);       // w1: identity path (no norm, no act)
+    conv(m->dn3, w2, w1, B, S1, S2, 2, nullptr, 0, s, bf);       // w1: identity path (no norm, no act)
     LZ_STAGE();
-    conv(m->dn2, w0, w2, B, S2, S2, 1, w1, 1, s);            // w2: S2 x S2 x 64
+    conv(m->dn2, w0, w2, B, S2, S2, 1, w1, 1, s, bf);            // w2: S2 x S2 x 64
     LZ_STAGE();
-    conv(m->r2a, w2, w0, B, S2, S2, 1, nullptr, 1, s);
+    conv(m->r2a, w2, w0, B, S2, S2, 1, nullptr, 1, s, bf);
     LZ_STAGE();
-    conv(m->r2b, w0, w1, B, S2, S2, 1, w2, 1, s);            // w1
+    conv(m->r2b, w0, w1, B, S2, S2, 1, w2, 1, s, bf);            // w1
     LZ_STAGE();
-    lz_launch_avgpool(w1, w0, B, S2, S2, C, s);               // w0: S3 x S3 x 64
+    lz_launch_avgpool(w1, w0, B, S2, S2, C, s, bf, bf);               // w0: S3 x S3 x 64
     LZ_STAGE();
-    conv(m->r3a, w0, w1, B, S3, S3, 1, nullptr, 1, s);
+    conv(m->r3a, w0, w1, B, S3, S3, 1, nullptr, 1, s, bf);
     LZ_STAGE();
-    conv(m->r3b, w1, w2, B, S3, S3, 1, w0, 1, s);            // w2
+    conv(m->r3b, w1, w2, B, S3, S3, 1, w0, 1, s, bf);            // w2
     LZ_STAGE();
     if (c.obs_h == 64) {                                      // common.py:358-359: no second pooling
         LZ_HIP_CHECK(hipMemcpyAsync(w0, w2, (size_t)B * S3 * S3 * C * 4, hipMemcpyDeviceToDevice, s));
     } else {
-        lz_launch_avgpool(w2, w0, B, S3, S3, C, s);           // w0: 6x6x64
+        lz_launch_avgpool(w2, w0, B, S3, S3, C, s, bf, 0);           // w0: 6x6x64
     }
     LZ_STAGE();
     }
