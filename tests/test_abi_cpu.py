@@ -56,3 +56,25 @@ def test_release_library_has_no_skip_work_knobs():
     for knob in (b"LZ_DEBUG_SKIP", b"LZ_DEBUG_CHAIN_LAYERS", b"LZ_DEBUG_CHAIN_TS", b"LZ_DEBUG_LSTM_ROWS", b"LZ_DEBUG_LSTM_HOTW", b"LZ_DEBUG_HEADS_TS", b"LZ_DEBUG_TREE_TS"):
         assert knob not in blob, knob
     assert not hasattr(ctypes.CDLL(build.LIB), "lz_debug_read_chain_ts")
+
+
+def test_ctypes_model_cfg_mirrors_the_header_struct_field_by_field():
+    """lz_model_cfg crosses the boundary by value of its layout: the ctypes mirror (lightzero_amd/_lib.py) must list the header's fields in
+    the header's order with the header's types -- a field added on one side only shifts every field behind it silently."""
+    from lightzero_amd import _lib as L
+    src = open(os.path.join(ROOT, "include", "lz_mi355.h")).read()
+    body = re.search(r"typedef struct lz_model_cfg \{(.*?)\} lz_model_cfg;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        assert typ in ("int", "float"), decl
+        fields += [(n.strip(), typ) for n in names.split(",")]
+    want = {"int": ctypes.c_int, "float": ctypes.c_float}
+    mirror = [(n, t) for n, t in L.ModelCfg._fields_]
+    assert [n for n, _ in mirror] == [n for n, _ in fields]
+    assert all(t is want[ht] for (_, t), (_, ht) in zip(mirror, fields))
+    assert ctypes.sizeof(L.ModelCfg) == 4 * len(fields)
