@@ -234,12 +234,14 @@ typedef struct lz_model_cfg {
     float bn_eps;           /* 1e-5 */
     int downsample;         /* 1: DownSample tower, 96x96 obs -> 6x6 latent (Atari); 0: latent grid = obs grid (board games,
                                e.g. Go 9x9: obs 17x9x9) */
-    /* ---- MLP model family only (model_type >= 2); the layer widths are taken from the tensors themselves */
+    /* ---- MLP model family (model_type >= 2; the layer widths are taken from the tensors themselves) -- and `activation` also the conv Sampled EfficientZero */
     int activation;         /* 0 ReLU, 1 GELU(approximate='tanh') */
     int res_connection_in_dynamics;
     int action_encoding;    /* 0 one_hot, 1 not_one_hot (action / action_space_size; also on the conv models: ONE action plane,
                                efficientzero_model.py:355-369), 2 continuous (the action vector) */
-    int num_of_sampled_actions;  /* K (model_type 4) */
+    int num_of_sampled_actions;  /* K (model_type 4); model_type 0 with K > 0 = SampledEfficientZeroModel (conv, sampled_efficientzero_model.py:17) with DISCRETE
+                                    actions: the EfficientZero network searched by the sampled tree (roots: A = K, discrete size = action_space_size); it
+                                    alone may set activation = 1 (GELU, its default) and head_hidden up to 256 (its default) on a conv model */
     int sigma_type;         /* 0 conditioned */
     int bound_type;         /* 0 None, 1 tanh on mu */
     float ln_eps;           /* 1e-5 */

@@ -32,6 +32,12 @@ struct MlpW {
     float *w1 = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2 = nullptr /* [32 / 4][NOUT][4], hidden width padded to the compiled 32 */, *b2 = nullptr;
     int K1 = 0, NOUT = 0;
 };
+// head MLP (Linear - BN1d - act - Linear) of the convolutional Sampled EfficientZero for the dense-layer kernels (k_dense, lz_dense.hip): any
+// hidden width that is a multiple of 16 up to 256 (the reference's default), ReLU or GELU; weights in k_dense's fragment order
+struct WideHead {
+    float *w1f = nullptr, *b1 = nullptr, *s1 = nullptr, *t1 = nullptr, *w2f = nullptr, *b2 = nullptr;
+    int K1 = 0, HID = 0, NOUT = 0;
+};
 struct C1W {
     float *w = nullptr, *b = nullptr, *s = nullptr, *t = nullptr;
 };
@@ -62,6 +68,8 @@ struct lz_model {
     // prediction
     C1W val_c, pol_c;
     MlpW fc_value, fc_policy;
+    bool wide_heads = false;             // conv Sampled EfficientZero: the three heads run as dense layers + row finishers (lz_search.hip::wide_heads)
+    WideHead wh_value, wh_policy, wh_reward;
     // split heads (EfficientZero, 6x6 latent; lz_search.hip): the first layers of the three head MLPs as MFMA B fragments for the
     // LSTM launch, sliced by LSTM unit tile u -- sh_w1c [H/16][9][4][64]: rows 36 u .. 36 u + 35 of the combined [value | policy]
     // head input (the 1x1-conv outputs t_pv, 1152 floats per root) x 64 hidden units (value 0..31 | policy 32..63, zero where the
@@ -272,6 +280,44 @@ struct Builder {
         c.s = upload(sc);
         c.t = upload(sh);
         return c;
+    }
+    // [N][K] row-major -> k_dense's MFMA-fragment order [Np/16][Kp/16][64 lanes][4] (lane (n = l & 15, g = l >> 4) holds W[n0 + n][k0 + 4 g .. + 3])
+    float *pack_dense(const std::vector<float> &w, int N, int K)
+    {
+        const int Np = (N + 15) & ~15, Kp = (K + 15) & ~15, KB = Kp / 16;
+        std::vector<float> f((size_t)Np * Kp, 0.0f);
+        for (int nt = 0; nt < Np / 16; ++nt)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nt * 16 + (lane & 15), k = kb * 16 + (lane >> 4) * 4 + q;
+                        if (n < N && k < K) f[(((size_t)nt * KB + kb) * 64 + lane) * 4 + q] = w[(size_t)n * K + k];
+                    }
+        return upload(f);
+    }
+    // the same head for the dense-layer kernels (conv Sampled EfficientZero); conv_flat as in mlp() below
+    WideHead wide_head(const std::string &prefix, int K1, int HID, int NOUT, bool conv_flat, int HC, int HW)
+    {
+        WideHead o;
+        o.K1 = K1; o.HID = HID; o.NOUT = NOUT;
+        const HostTensor *w1 = get(prefix + ".0.weight", {HID, K1}), *b1 = get(prefix + ".0.bias", {HID}),
+                         *w2 = get(prefix + ".3.weight", {NOUT, HID}), *b2 = get(prefix + ".3.bias", {NOUT});
+        std::vector<float> sc, sh;
+        bn(prefix + ".1", HID, sc, sh);
+        if (!w1 || !b1 || !w2 || !b2) return o;
+        std::vector<float> w1p(w1->data);
+        if (conv_flat) {
+            for (int u = 0; u < HID; ++u)
+                for (int p = 0; p < HW; ++p)
+                    for (int c = 0; c < HC; ++c) w1p[(size_t)u * K1 + p * HC + c] = w1->data[(size_t)u * K1 + c * HW + p];
+        }
+        o.w1f = pack_dense(w1p, HID, K1);
+        o.b1 = upload(b1->data);
+        o.s1 = upload(sc);
+        o.t1 = upload(sh);
+        o.w2f = pack_dense(w2->data, NOUT, HID);
+        o.b2 = upload(b2->data);
+        return o;
     }
     // Linear - BN1d - ReLU - Linear; conv_flat: K1 = HC*HW in the reference's (channel, pixel) order ->
     // permute the columns to this engine's (pixel, channel) order

@@ -34,6 +34,21 @@ __device__ __forceinline__ float vget(const float4 &v, int j) { return j == 0 ? 
 __device__ __forceinline__ float vget(const float2 &v, int j) { return j == 0 ? v.x : v.y; }
 __device__ __forceinline__ float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// The activation of a network: ReLU (every shipped EfficientZero / MuZero conv configuration) or GELU(approximate='tanh') -- the default of the
+// convolutional Sampled EfficientZero (sampled_efficientzero_model.py:40), which its Atari configuration keeps.  GELU instances are separate
+// template instantiations (bool GELU): the ReLU kernels' code does not change.  tanh(y) = 1 - 2 / (1 + e^{2y}) on the hardware exp / rcp as in
+// lz_dense.hip (|error| < 3e-7 absolute).
+__device__ __forceinline__ float gelu_tanh_(float u)
+{
+    const float y = 0.7978845608028654f * (u + 0.044715f * u * u * u);
+    const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * y));
+    return 0.5f * u * (1.0f + t);
+}
+template <bool GELU> __device__ __forceinline__ float act_(float v) { if constexpr (GELU) return gelu_tanh_(v); else return fmaxf(v, 0.0f); }
+// (the reference's class mixes them: its representation network keeps ReLU, its dynamics network takes the model's activation, its prediction
+// network keeps GELU -- sampled_efficientzero_model.py:177-218 passes `activation` to the dynamics network only -- so the chain's GELU instance
+// reads a code per layer and per 1x1 job)
+
 // ------------------------------------------------------------------------------------------------
 // 3x3 convolution as implicit GEMM.  grid = (ceil(B*Hout*Wout / 144), Cout / 16), block = 256.
 // ------------------------------------------------------------------------------------------------
@@ -1133,7 +1148,7 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
 #undef LZ_HPS
 }
 
-template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? (GW * GH > 36 ? 8 : 16) : 32), bool HEADS = false>
+template <int GW, int GH, int NW, bool TS = false, int TREE = 0, int RING = (NW == 8 ? (GW * GH > 36 ? 8 : 16) : 32), bool HEADS = false, bool GELU = false>
 __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename step_arg<TREE>::type step)
 {
     constexpr int PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
@@ -1452,7 +1467,8 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
             v += tv[n];
             v = v * sc + sh;
             v += rv[n];
-            v = relu ? fmaxf(v, 0.0f) : v;
+            if constexpr (GELU) v = ly.relu == 2 ? gelu_tanh_(v) : (relu ? fmaxf(v, 0.0f) : v);   // per-layer code (lz_chain_layer::relu)
+            else v = relu ? fmaxf(v, 0.0f) : v;
             outv[n] = v;
             if (wv + NW * n < HW) sOut[cpix[n]] = v;
         }
@@ -1471,10 +1487,14 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     // scattered 4-byte stores per lane: 2 k cycles of the kernel's tail)
     auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {   // c1b / c1s / c1t are those of channel quad cq
         float4 v;
-        v.x = fmaxf((acc[0] + c1b.x) * c1s.x + c1t.x, 0.0f);
-        v.y = fmaxf((acc[1] + c1b.y) * c1s.y + c1t.y, 0.0f);
-        v.z = fmaxf((acc[2] + c1b.z) * c1s.z + c1t.z, 0.0f);
-        v.w = fmaxf((acc[3] + c1b.w) * c1s.w + c1t.w, 0.0f);
+        v.x = (acc[0] + c1b.x) * c1s.x + c1t.x;
+        v.y = (acc[1] + c1b.y) * c1s.y + c1t.y;
+        v.z = (acc[2] + c1b.z) * c1s.z + c1t.z;
+        v.w = (acc[3] + c1b.w) * c1s.w + c1t.w;
+        bool g = false;
+        if constexpr (GELU) g = jb.act == 2;   // per-job code (lz_c1_job::act)
+        if (g) { v.x = gelu_tanh_(v.x); v.y = gelu_tanh_(v.y); v.z = gelu_tanh_(v.z); v.w = gelu_tanh_(v.w); }
+        else { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
         store_wt(jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + cq * 4, (f32x4){v.x, v.y, v.z, v.w});
     };
     auto c1_tile = [&](int job, int i) {   // 16 pixels from 16 i
@@ -2311,7 +2331,7 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // the 16-lane groups {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS) -- a pitch of 2 (mod 4) quads puts each group on 16 distinct bank
 // quads; K + 4 (1 mod 4 quads) was a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT: 43 % of the LDS cycles of this kernel)
 constexpr int LSTM_PAD = 8;
-template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false>
+template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false, bool GELU = false>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
     static_assert(!SH || MR == 16, "the split-head partials are written for 16-row workgroups");
@@ -2519,7 +2539,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         const bool reset = a.search_len && a.horizon > 0 && (slen[q] % a.horizon) == 0;  // mcts_ctree.py:859-863
         store_wt(a.h_out + (size_t)b * H + unit, reset ? 0.0f : hn);
         store_wt(a.c_out + (size_t)b * H + unit, reset ? 0.0f : cn);
-        const float hb = a.bn_scale ? fmaxf(hn * bns[q] + bnt[q], 0.0f) : hn;
+        const float hb = a.bn_scale ? act_<GELU>(hn * bns[q] + bnt[q]) : hn;
         store_wt(a.hbn_out + (size_t)b * H + unit, hb);
         if constexpr (SH) sHb[row * 17 + u] = hb;
     }
@@ -3391,6 +3411,7 @@ void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
 {
     if (a.C != 0 && a.C != 64) return false;  // the narrow chain has no fused instance
+    if (a.gelu) return false;                 // GELU networks have the plain chain instance only
     if (!((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) || a.tstamp || !a.gather_ix || !a.act_table) return false;
     if (step.t.A > 64 || step.t.B != a.B) return false;
     if (step.t.variant != LZ_TREE_EFFICIENTZERO && step.t.variant != LZ_TREE_MUZERO) return false;
@@ -3444,7 +3465,7 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
     }
     // 6x6 / 8x8 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
     static const char *direct = getenv("LZ_CHAIN_DIRECT");
-    bool wino = !direct && ((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) && a.nlayers > 0;
+    bool wino = (!direct || a.gelu) && ((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) && a.nlayers > 0;   // (only k_chain_w reads the GELU codes)
     for (int i = 0; i < a.nlayers; ++i) wino = wino && a.layer[i].uc != nullptr;
     if (wino) {
         static const char *w4 = getenv("LZ_CHAIN_W4");  // 4 waves (one per SIMD) instead of 8
@@ -3453,6 +3474,11 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         const size_t lds = (size_t)(4 * (hw + 1) * 68 + (big ? 0 : hw * 68) + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 16 * nt * 68 +
                                     (big ? 0 : nw * nt * 2 * 64)) * 4;
         const dim3 g(a.B), blk(nw * 64);
+        if (a.gelu) {   // GELU networks (conv Sampled EfficientZero): never tree-fused (lz_chain_fusable), 8 waves
+            if (a.gw == 6) hipLaunchKernelGGL((k_chain_w<6, 6, 8, false, 0, 16, false, true>), g, dim3(512), lds, s, a, no_step{});
+            else hipLaunchKernelGGL((k_chain_w<8, 8, 8, false, 0, 8, false, true>), g, dim3(512), lds, s, a, no_step{});
+            return;
+        }
 #define LZ_W(GWv, NWv) \
         if (step) { \
             if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on && GWv == 6 && NWv == 8) hipLaunchKernelGGL((k_chain_w<6, 6, 8, false, 1, 16, true>), g, blk, lds, s, a, *step); \
@@ -3536,7 +3562,12 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     const size_t lds = (size_t)32 * ((size_t)nkb * 16 + LSTM_PAD) * 4;
     const bool xf = a.x_ln_g || a.x_act;
     if (nkb == 96 && !xf) {  // 1024 + 512 (EfficientZero conv on 64x64 observations: 8x8 latent): 16-row tiles, 98.5 KB of LDS
-        hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        if (a.gelu) hipLaunchKernelGGL((k_lstm2<96, 0, 16, 0, false, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        else hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        return true;
+    }
+    if (nkb == 68 && !xf && a.gelu && a.KX == 576) {   // the same LSTM with GELU behind its BatchNorm (conv Sampled EfficientZero, 6x6 latent)
+        hipLaunchKernelGGL((k_lstm2<68, 0, 16, 36, false, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
         return true;
     }
     // 16-row tiles (70 KB of LDS, 512 workgroups at 256 roots): two workgroups per CU, so one's staging and cell epilogue run

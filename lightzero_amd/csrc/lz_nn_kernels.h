@@ -49,6 +49,7 @@ struct lz_c1_job {
     const float *bias, *scale, *shift;  // [16]
     float *out;           // out[pix * out_stride + out_off + c]
     int out_stride, out_off;
+    int act;              // k_chain_w's GELU instance (lz_chain_args::gelu): 2 = GELU(tanh) instead of ReLU for this job
 };
 struct lz_c1_args {
     lz_c1_job job[4];
@@ -66,7 +67,7 @@ struct lz_chain_layer {
     const void *wb;        // optional (fast mode, lz_model_cfg::precision = 1): bf16 MFMA fragments [2 k halves][4 N-tiles][9 taps][64 lanes][8] (k_chain_b, 6x6 grids)
     const float *scale, *shift;  // [64] folded BatchNorm
     int in, out, res;      // LDS buffer indices (0..3); res < 0: no residual
-    int relu, act;         // act: add the one-hot-action table before BN (dynamics conv)
+    int relu, act;         // relu: 0 none, 1 ReLU, 2 GELU(tanh) (2 only with lz_chain_args::gelu); act: add the one-hot-action table before BN (dynamics conv)
     float *gout;           // optional global NHWC [B][36][64] copy of the output (latent pool slot)
 };
 #define LZ_CHAIN_MAX_LAYERS 14   // dynamics conv + 2 k convs of the dynamics blocks + 2 k of the prediction blocks, num_res_blocks k <= 3
@@ -84,6 +85,7 @@ struct lz_chain_args {
     int nc1;
     int B;
     int gw, gh;                  // latent grid (6x6 Atari with downsample, 9x9 Go); compiled instances: 6x6, 9x9
+    int gelu;                    // 1: some layer / 1x1 job of this launch uses GELU(tanh) (relu = 2 / act = 2): the kernel instance that reads those codes
     unsigned long long *tstamp;  // debugging: s_memtime stamps of workgroup 0 / wave 0 (null in production)
     int debug_flags;             // timing experiments of the debug build (results are then wrong): 1 = no latent gather, 2 = no action-table slice
     unsigned long long *stamp;   // optional [2]: {start of the first workgroup, end of the last workgroup (by block id)} in s_memrealtime ticks (100 MHz,
@@ -135,6 +137,7 @@ struct lz_lstm_args {
     float *h_out, *c_out;    // [B][H] destination slot of the pools
     float *hbn_out;          // [B][H] relu(bn(h'))
     int B, KX, H;
+    int gelu;                // 1: hbn_out = gelu(bn(h')) instead of relu(bn(h')) (k_lstm2 instances of the conv Sampled EfficientZero)
     int debug_hot_weights;   // timing experiment of the debug build only (see k_lstm2); 0 in production
     // split heads (optional, sh_part != null; EfficientZero 6x6 instance only): the FIRST layers of the three head MLPs are
     // computed here as partial sums, one block per (16-row tile, unit tile u) -- the value-prefix head's over this workgroup's own 16

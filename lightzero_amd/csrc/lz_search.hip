@@ -95,7 +95,12 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
                    "without downsample the compiled latent grids are 9x9 (Go), 8x8 and 4x4 (2048) with 64 channels, 6x7 (Connect4), 6x6 (gomoku) and, for the narrow models, 3x3 (tictactoe)");
         LZ_REQUIRE(cfg->obs_c >= 1 && cfg->obs_c <= 64, "obs_c must be in [1, 64]");
     }
-    LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden >= 1 && cfg->head_hidden <= 32, "head_channels must be 16 and head_hidden at most 32");
+    const bool conv_sampled = cfg->model_type == 0 && cfg->num_of_sampled_actions > 0;
+    LZ_REQUIRE(cfg->num_of_sampled_actions == 0 || (conv_sampled && cfg->num_of_sampled_actions <= 64 && cfg->downsample && cfg->obs_c == 4 && cfg->num_channels == 64),
+               "num_of_sampled_actions on a conv model = SampledEfficientZeroModel (conv): EfficientZero network + sampled tree, discrete actions, K in [1, 64], 4-channel downsampled observations");
+    LZ_REQUIRE(cfg->activation == 0 || conv_sampled, "conv models: GELU (activation 1) exists for the convolutional Sampled EfficientZero only");
+    LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden >= 1 && (cfg->head_hidden <= 32 || (conv_sampled && cfg->head_hidden <= 256 && cfg->head_hidden % 16 == 0)),
+               "head_channels must be 16 and head_hidden at most 32 (conv Sampled EfficientZero: a multiple of 16 up to 256)");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
     LZ_REQUIRE(cfg->action_space_size > 0 && cfg->action_space_size <= 256, "action_space_size must be in [1, 256]");
     LZ_REQUIRE(cfg->action_encoding == 0 || cfg->action_encoding == 1, "conv models: action_encoding 0 (one_hot) or 1 (not_one_hot)");
@@ -310,7 +315,8 @@ extern "C" int lz_model_finalize(lz_engine *e)
         b.bn(d + "norm_value_prefix", H, sc, sh);
         m->vp_s = b.upload(sc);
         m->vp_t = b.upload(sh);
-        m->fc_reward = b.mlp(d + "fc_reward_head", H, HID, SUP, false, HC, HW);
+        if (c.num_of_sampled_actions > 0) m->wh_reward = b.wide_head(d + "fc_reward_head", H, HID, SUP, false, HC, HW);   // conv Sampled EfficientZero
+        else m->fc_reward = b.mlp(d + "fc_reward_head", H, HID, SUP, false, HC, HW);
         }
     }
     // ---- prediction (common.py:1081-1216)
@@ -323,8 +329,14 @@ extern "C" int lz_model_finalize(lz_engine *e)
         }
         m->val_c = b.conv1x1(d + "conv1x1_value", d + "norm_value", HC, C);
         m->pol_c = b.conv1x1(d + "conv1x1_policy", d + "norm_policy", HC, C);
+        m->wide_heads = c.model_type == 0 && c.num_of_sampled_actions > 0;
+        if (m->wide_heads) {   // conv Sampled EfficientZero: hidden width up to 256, ReLU | GELU -> dense-layer kernels
+            m->wh_value = b.wide_head(d + "fc_value", HC * HW, HID, SUP, true, HC, HW);
+            m->wh_policy = b.wide_head(d + "fc_policy", HC * HW, HID, A, true, HC, HW);
+        } else {
         m->fc_value = b.mlp(d + "fc_value", HC * HW, HID, SUP, true, HC, HW);
         m->fc_policy = b.mlp(d + "fc_policy", HC * HW, HID, A, true, HC, HW);
+        }
     }
     // ---- split heads (see enqueue_search): first layers of the three head MLPs as per-unit-tile MFMA fragments for the LSTM launch
     m->sh_w1c = m->sh_w1r = nullptr;
@@ -387,14 +399,22 @@ int lz_roots_release_pools_if_stale(lz_roots *r)
     return LZ_OK;
 }
 
+// width of a policy row of the model behind these roots: the MLP families say it themselves (2 D for continuous Sampled EfficientZero); a conv
+// model's is its action space -- which for the conv Sampled EfficientZero (discrete actions, K sampled per node) is NOT the roots' A = K
+static size_t policy_width_of(const lz_model *m, const lz_tree_dev &t)
+{
+    if (m->cfg.model_type >= 2) return (size_t)lz_mlp_policy_width(m);
+    return t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO ? (size_t)m->cfg.action_space_size : (size_t)t.A;
+}
+
 static int ensure_pools(lz_roots *r)
 {
     if (int rc = lz_roots_release_pools_if_stale(r)) return rc;
     if (r->pool_slab) return LZ_OK;
     lz_model *m = r->eng->model;
     const lz_model_cfg &c = m->cfg;
-    const size_t B = r->t.B, NN = r->t.NN, A = r->t.A, C = c.num_channels, HW = m->HWl, H = c.model_type == 0 ? c.lstm_hidden_size : 0,
-                 HC = c.head_channels, SUP = std::max(c.support_size, c.reward_support_size);
+    const size_t B = r->t.B, NN = r->t.NN, A = std::max((size_t)r->t.A, policy_width_of(m, r->t)), C = c.num_channels, HW = m->HWl,
+                 H = c.model_type == 0 ? c.lstm_hidden_size : 0, HC = c.head_channels, SUP = std::max(c.support_size, c.reward_support_size);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_lat = take(NN * B * HW * C * 4), o_h = take(NN * B * H * 4), o_c = take(NN * B * H * 4),
@@ -436,6 +456,12 @@ static int ensure_ws(lz_model *m, int B)
     return LZ_OK;
 }
 
+// activation codes (1 ReLU, 2 GELU(tanh)) of the dynamics and the prediction network.  Every model here is ReLU throughout, except the conv
+// Sampled EfficientZero: its class passes `activation` (default GELU) to the dynamics network ONLY -- the prediction network keeps its own
+// default GELU and the representation network its default ReLU (sampled_efficientzero_model.py:177-218; common.py:718)
+static int act_dyn(const lz_model_cfg &c) { return (c.model_type == 0 && c.num_of_sampled_actions > 0 && c.activation == 1) ? 2 : 1; }
+static int act_pred(const lz_model_cfg &c) { return (c.model_type == 0 && c.num_of_sampled_actions > 0) ? 2 : 1; }
+
 static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
                  int relu, hipStream_t s, int act_bf16 = 0)
 {
@@ -462,14 +488,15 @@ static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu
 // appends the 2 k convolutions of k residual blocks (ding ResBlock 'basic': conv-bn-relu, conv-bn, + input, relu) to a chain.  x = LDS
 // buffer of the input, keep = a buffer that must survive the blocks (-1: none), gout_last = optional HBM copy of the last block's
 // output.  Returns the buffer that holds the output.
-static int chain_blocks(lz_chain_args &ca, const std::vector<ConvW> &blocks, int x, int keep, float *gout_last)
+// `relu` = the activation code of the blocks' network: 1 ReLU, 2 GELU(tanh) (conv Sampled EfficientZero; needs ca.gelu)
+static int chain_blocks(lz_chain_args &ca, const std::vector<ConvW> &blocks, int x, int keep, float *gout_last, int relu = 1)
 {
     const int k = (int)blocks.size() / 2;
     for (int i = 0; i < k; ++i) {
         int f[2], n = 0;
         for (int b = 0; b < 4 && n < 2; ++b) if (b != x && b != keep) f[n++] = b;
-        ca.layer[ca.nlayers++] = chlayer(blocks[2 * i], x, f[0], -1, 1, 0, nullptr);
-        ca.layer[ca.nlayers++] = chlayer(blocks[2 * i + 1], f[0], f[1], x, 1, 0, i == k - 1 ? gout_last : nullptr);
+        ca.layer[ca.nlayers++] = chlayer(blocks[2 * i], x, f[0], -1, relu, 0, nullptr);
+        ca.layer[ca.nlayers++] = chlayer(blocks[2 * i + 1], f[0], f[1], x, relu, 0, i == k - 1 ? gout_last : nullptr);
         x = f[1];
     }
     return x;
@@ -514,12 +541,46 @@ static int ensure_head_debug(lz_roots *r)
 static float *hd_logits_at(lz_roots *r, int slot, int which) { return r->hd_logits + ((size_t)slot * 2 + which) * r->t.B * r->hd_sup; }
 static float *hd_expect_at(lz_roots *r, int slot, int which) { return r->hd_expect + ((size_t)slot * 2 + which) * r->t.B; }
 
+// The heads of the convolutional Sampled EfficientZero (hidden width up to 256, ReLU | GELU): dense layers + row finishers of the MLP family's
+// kernels -- first layers (value | policy [| value prefix]) in one k_dense launch, second layers in another, then softmax . support -> h^-1.
+// The 1x1 head convolutions wrote their outputs to two contiguous [B][HW * HC] halves of t_pv (chain_args_for / lz_initial_inference).
+static void wide_heads(lz_roots *r, float *out_value, float *out_logits, bool with_vp, float *out_vp, hipStream_t s)
+{
+    lz_model *m = r->eng->model;
+    const lz_model_cfg &c = m->cfg;
+    const int B = r->t.B, HW = m->HWl, HC = c.head_channels;
+    const int acts[3] = {act_pred(c), act_pred(c), act_dyn(c)};   // lz_dense_job.act: 1 ReLU, 2 GELU(tanh); the value-prefix head belongs to the dynamics network
+    const WideHead *w[3] = {&m->wh_value, &m->wh_policy, &m->wh_reward};
+    const float *x[3] = {r->t_pv, r->t_pv + (size_t)B * HW * HC, r->t_hbn};
+    float *hid[3] = {r->t_x1, r->t_x2, r->t_x3};
+    float *lg[3] = {r->dbg_logits[0], out_logits, r->dbg_logits[1]};
+    const int n = with_vp ? 3 : 2;
+    lz_dense_args a1{}, a2{};
+    a1.B = a2.B = B;
+    a1.njobs = a2.njobs = n;
+    for (int i = 0; i < n; ++i) {
+        lz_dense_job &j = a1.job[i];
+        j.x = x[i]; j.K1 = w[i]->K1; j.wf = w[i]->w1f; j.bias = w[i]->b1; j.scale = w[i]->s1; j.shift = w[i]->t1; j.N = w[i]->HID; j.act = acts[i];
+        j.out = hid[i];
+        lz_dense_job &k = a2.job[i];
+        k.x = hid[i]; k.K1 = w[i]->HID; k.wf = w[i]->w2f; k.bias = w[i]->b2; k.N = w[i]->NOUT; k.act = 0; k.out = lg[i];
+    }
+    lz_launch_dense(a1, s);
+    lz_launch_dense(a2, s);
+    lz_rowfinal_args f{};
+    f.B = B;
+    f.job[f.njobs++] = lz_rowfinal_job{r->dbg_logits[0], m->wh_value.NOUT, c.support_min, out_value};
+    if (with_vp) f.job[f.njobs++] = lz_rowfinal_job{r->dbg_logits[1], m->wh_reward.NOUT, c.support_min, out_vp};
+    lz_launch_rowfinal(f, s);
+}
+
 // the head MLPs (value, policy[, value prefix]) in one launch; inputs are the 1x1-conv outputs t_pv / the LSTM output.
 // slot = the pool slot the outputs belong to (head debug buffers)
 static void heads(lz_roots *r, int slot, float *out_value, float *out_logits, float *dbg_value_logits, bool with_vp, float *out_vp,
                   float *dbg_vp_logits, hipStream_t s)
 {
     lz_model *m = r->eng->model;
+    if (m->wide_heads) { wide_heads(r, out_value, out_logits, with_vp, out_vp, s); return; }
     const lz_model_cfg &c = m->cfg;
     const int B = r->t.B, HW = m->HWl, HC = c.head_channels;
     lz_head_desc h[3];
@@ -565,9 +626,10 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     if (!m || !m->finalized) { lz_set_error("no finalized model on this engine"); return LZ_ERR_STATE; }
     {
         const int mt = m->cfg.model_type;
-        const int want = (mt == 0 || mt == 3) ? LZ_TREE_EFFICIENTZERO : (mt == 4 ? LZ_TREE_SAMPLED_EFFICIENTZERO : LZ_TREE_MUZERO);
+        const bool conv_sampled = mt == 0 && m->cfg.num_of_sampled_actions > 0;   // SampledEfficientZeroModel (conv), discrete actions
+        const int want = conv_sampled ? LZ_TREE_SAMPLED_EFFICIENTZERO : (mt == 0 || mt == 3) ? LZ_TREE_EFFICIENTZERO : (mt == 4 ? LZ_TREE_SAMPLED_EFFICIENTZERO : LZ_TREE_MUZERO);
         LZ_REQUIRE(r->t.variant == want || (want == LZ_TREE_MUZERO && r->t.variant == LZ_TREE_GUMBEL_MUZERO), "tree variant does not match the model type (EfficientZero model <-> EZ tree, MuZero model <-> MZ tree, sampled model <-> sampled tree)");
-        if (mt == 4) {
+        if (mt == 4 || conv_sampled) {
             const bool cont = m->cfg.action_encoding == 2;
             LZ_REQUIRE(r->t.A == m->cfg.num_of_sampled_actions, "sampled roots: num_of_sampled_actions differs from the model's");
             LZ_REQUIRE(cont ? (r->t.disc_A == 0 && r->t.D == m->cfg.action_space_size) : (r->t.disc_A == m->cfg.action_space_size),
@@ -635,10 +697,16 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
         lz_chain_args ca{};
         ca.in = w0; ca.B = B; ca.gw = m->GW; ca.gh = m->GH; ca.C = C;
         const int x_lat = chain_blocks(ca, m->rep_res, 0, -1, r->latent_pool);
-        const int x_p = chain_blocks(ca, m->pred_res, x_lat, -1, nullptr);
+        const int x_p = chain_blocks(ca, m->pred_res, x_lat, -1, nullptr, act_pred(c));
         ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = x_p;
         ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = x_p;
         ca.nc1 = 2;
+        if (m->wide_heads) {   // dense-layer heads read two contiguous [B][HW * HC] blocks
+            ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, c.head_channels, 0);
+            ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv + (size_t)B * m->HWl * c.head_channels, c.head_channels, 0);
+        }
+        ca.c1[0].act = ca.c1[1].act = act_pred(c);
+        ca.gelu = act_pred(c) == 2;
         lz_launch_chain(ca, s);
     }
     if (H > 0) {   // reward_hidden_state_roots = zeros (efficientzero_model.py:229-236): slot 0 of both pools, one launch
@@ -698,7 +766,7 @@ extern "C" int lz_roots_adopt_inference(lz_roots *dst, lz_roots *src)
     if (rc != LZ_OK) return rc;
     const size_t B = dst->t.B, C = m->cfg.num_channels, HW = m->HWl;
     const size_t H = m->cfg.model_type >= 2 ? (size_t)lz_mlp_hidden_size(m) : (size_t)(m->cfg.model_type == 0 ? m->cfg.lstm_hidden_size : 0);
-    const size_t PA = m->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(m) : (size_t)dst->t.A;
+    const size_t PA = policy_width_of(m, dst->t);
     hipStream_t s = dst->eng->stream;
     LZ_HIP_CHECK(hipMemcpyAsync(dst->latent_pool, src->latent_pool, B * HW * C * 4, hipMemcpyDeviceToDevice, s));
     if (H) {
@@ -719,7 +787,7 @@ extern "C" int lz_roots_adopt_inference(lz_roots *dst, lz_roots *src)
 extern "C" int lz_roots_get_root_outputs(lz_roots *r, float *h_pred_values, float *h_policy_logits)
 {
     LZ_REQUIRE(r != nullptr && r->inferred, "lz_initial_inference has not run on these roots");
-    const size_t B = r->t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)r->t.A;
+    const size_t B = r->t.B, A = policy_width_of(r->eng->model, r->t);
     hipStream_t s = r->eng->stream;
     if (h_pred_values) LZ_HIP_CHECK(hipMemcpyAsync(h_pred_values, r->sim_value, B * 4, hipMemcpyDeviceToHost, s));
     if (h_policy_logits) LZ_HIP_CHECK(hipMemcpyAsync(h_policy_logits, r->sim_logits, B * A * 4, hipMemcpyDeviceToHost, s));
@@ -739,7 +807,7 @@ static int search_results(lz_roots *r, int32_t *h_out_dist, int32_t *h_out_count
     LZ_REQUIRE(!select || (temperature > 0.0 && h_action_pos != nullptr && h_entropy != nullptr), "select_action needs a positive temperature and output arrays");
     const lz_tree_dev &t = r->t;
     const size_t B = t.B, A = t.A;
-    const size_t PA = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : A;
+    const size_t PA = policy_width_of(r->eng->model, r->t);
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
     // layout of the result block: entropy [B] f64 | dist [B][A] | count [B] | action pos [B] | values [B] | pred values [B] | logits [B][PA]
@@ -958,7 +1026,7 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
     const lz_tree_dev &t = r->t;
     lz_model *m = r->eng->model;
     const size_t B = t.B, A = t.A;
-    const size_t PA = m->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(m) : A;
+    const size_t PA = policy_width_of(m, r->t);
     const int obs_floats = m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
     if (!d_obs) d_obs = r->last_obs;
     LZ_REQUIRE(frame_floats >= 0 && frame_floats <= obs_floats && (frame_floats == 0 || d_obs != nullptr), "frame_floats exceeds the observation / no observation known");
@@ -1090,7 +1158,7 @@ extern "C" int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int det
     lz_model *m = r->eng->model;
     const bool sampled = t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO;
     const size_t B = t.B, A = t.A;
-    const size_t PA = m->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(m) : A;
+    const size_t PA = policy_width_of(m, r->t);
     const int obs_floats = m->cfg.obs_c * m->cfg.obs_h * m->cfg.obs_w;
     if (!d_obs) d_obs = r->last_obs;
     LZ_REQUIRE(frame_floats >= 0 && frame_floats <= obs_floats && (frame_floats == 0 || d_obs != nullptr), "frame_floats exceeds the observation / no observation known");
@@ -1392,13 +1460,20 @@ static void chain_args_for(lz_roots *r, int sim, lz_chain_args &ca)
     ca = lz_chain_args{};
     ca.in = r->latent_pool; ca.gather_ix = t.res_ix; ca.slot_stride = (int64_t)lat_slot;
     ca.act_table = m->act_table; ca.action = t.res_last_action; ca.B = (int)B; ca.gw = m->GW; ca.gh = m->GH; ca.C = (int)C;
-    ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, 1, 1, nullptr);
-    const int x_lat = chain_blocks(ca, m->dyn_res, 1, -1, next_latent);   // the next latent state: kept for the reward 1x1 conv
-    const int x_p = chain_blocks(ca, m->pred_res, x_lat, x_lat, nullptr);
+    ca.layer[ca.nlayers++] = chlayer(m->dyn, 0, 1, 0, act_dyn(c), 1, nullptr);
+    const int x_lat = chain_blocks(ca, m->dyn_res, 1, -1, next_latent, act_dyn(c));   // the next latent state: kept for the reward 1x1 conv
+    const int x_p = chain_blocks(ca, m->pred_res, x_lat, x_lat, nullptr, act_pred(c));
     ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, 2 * c.head_channels, 0); ca.c1_in[0] = x_p;
     ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv, 2 * c.head_channels, c.head_channels); ca.c1_in[1] = x_p;
     ca.c1[2] = c1job(m->rew_c, nullptr, r->t_rx, c.head_channels, 0); ca.c1_in[2] = x_lat;
     ca.nc1 = 3;
+    if (m->wide_heads) {   // dense-layer heads read two contiguous [B][HW * HC] blocks
+        ca.c1[0] = c1job(m->val_c, nullptr, r->t_pv, c.head_channels, 0);
+        ca.c1[1] = c1job(m->pol_c, nullptr, r->t_pv + B * HW * c.head_channels, c.head_channels, 0);
+    }
+    ca.c1[0].act = ca.c1[1].act = act_pred(c);
+    ca.c1[2].act = act_dyn(c);
+    ca.gelu = act_pred(c) == 2 || act_dyn(c) == 2;
 }
 
 // split heads: what the chain launch that follows simulation `leaf_slot - 1` needs to finish that simulation's heads (lz_split_heads)
@@ -1426,7 +1501,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     if (m->cfg.model_type >= 2) { lz_mlp_recurrent(r, sim, horizon, s); return; }
     const lz_model_cfg &c = m->cfg;
     const lz_tree_dev &t = r->t;
-    const size_t B = t.B, A = t.A, HW = m->HWl, H = c.lstm_hidden_size;
+    const size_t B = t.B, A = policy_width_of(m, t), HW = m->HWl, H = c.lstm_hidden_size;
     const int slot = sim + 1;
     // ---- dynamics conv over [latent | one-hot action] + BN + latent + ReLU, dynamics residual block (-> latent pool
     // slot), prediction residual block and the three 1x1 head convs (efficientzero_model.py:527-558, common.py:1189-1203):
@@ -1465,6 +1540,7 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     l.bn_scale = m->vp_s; l.bn_shift = m->vp_t; l.search_len = t.res_search_len; l.horizon = horizon;
     l.h_out = r->h_pool + (size_t)slot * B * H; l.c_out = r->c_pool + (size_t)slot * B * H; l.hbn_out = r->t_hbn;
     l.B = (int)B; l.KX = c.head_channels * (int)HW; l.H = (int)H;
+    l.gelu = act_dyn(c) == 2;
     if (defer_heads) {   // split heads: the first layers of the head MLPs ride on this launch, the next chain launch finishes them
         l.sh_pv = r->t_pv; l.sh_kc = 2 * c.head_channels * (int)HW; l.sh_w1c = m->sh_w1c; l.sh_w1r = m->sh_w1r;
         l.sh_part = r->sh_part;
@@ -1486,7 +1562,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
 {
     const lz_tree_dev &t = r->t;
     const size_t B = t.B;
-    const size_t A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
+    const size_t A = policy_width_of(r->eng->model, t);
     ta.counter = 0;
     if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
         lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
@@ -1677,7 +1753,7 @@ extern "C" int lz_gsearch(lz_roots *r, int num_simulations, int max_num_consider
     int rc = lz_groots_set_considered(r, num_simulations, max_num_considered_actions, s);
     if (rc != LZ_OK) return rc;
     const lz_tree_dev &t = r->t;
-    const size_t B = t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
+    const size_t B = t.B, A = policy_width_of(r->eng->model, t);
     auto enqueue = [&]() {
         lz_tree_launch_minmax_reset(t, s);
         lz_gtree_launch_traverse(t, discount_factor, s);
@@ -1722,7 +1798,7 @@ extern "C" int lz_search_with_reuse(lz_roots *r, int num_simulations, int pb_c_b
     LZ_HIP_CHECK(hipSetDevice(r->eng->device));
     hipStream_t s = r->eng->stream;
     const lz_tree_dev &t = r->t;
-    const size_t B = t.B, A = mt >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)t.A;
+    const size_t B = t.B, A = policy_width_of(r->eng->model, t);
     if (!r->d_reuse) LZ_HIP_CHECK(lz_dev_malloc((void **)&r->d_reuse, (2 * B + (size_t)t.NN) * 4));
     int32_t *d_ta = (int32_t *)r->d_reuse;
     float *d_rv = (float *)(d_ta + B);
@@ -1846,7 +1922,7 @@ extern "C" int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_p
 {
     LZ_REQUIRE(r != nullptr && r->pool_slab != nullptr, "no pools");
     LZ_REQUIRE(slot >= 0 && slot < r->t.NN, "slot out of range");
-    const size_t B = r->t.B, A = r->eng->model->cfg.model_type >= 2 ? (size_t)lz_mlp_policy_width(r->eng->model) : (size_t)r->t.A;
+    const size_t B = r->t.B, A = policy_width_of(r->eng->model, r->t);
     hipStream_t s = r->eng->stream;
     if (h_value_prefix) LZ_HIP_CHECK(hipMemcpyAsync(h_value_prefix, r->sim_vp + slot * B, B * 4, hipMemcpyDeviceToHost, s));
     if (h_value) LZ_HIP_CHECK(hipMemcpyAsync(h_value, r->sim_value + slot * B, B * 4, hipMemcpyDeviceToHost, s));

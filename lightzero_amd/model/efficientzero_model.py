@@ -302,6 +302,10 @@ class EfficientZeroModel(object):
         if cont:
             af = host(action).reshape(B, -1)
             L.check(lib.lz_recurrent_inference(r._h, zeros, None, af.ctypes.data, None, 0, 1))
+        elif int(getattr(self, "num_of_sampled_actions", 0) or 0) > 0:
+            # sampled roots with a discrete action space carry an action as the float of its index (lz_recurrent_inference)
+            af = host(action, np.int64).reshape(B, 1).astype(np.float32)
+            L.check(lib.lz_recurrent_inference(r._h, zeros, None, af.ctypes.data, None, 0, 1))
         else:
             a = host(action, np.int64).reshape(B).astype(np.int32)
             L.check(lib.lz_recurrent_inference(r._h, zeros, a.ctypes.data, None, None, 0, 1))

@@ -240,6 +240,59 @@ class EfficientZeroModel(nn.Module):  # efficientzero_model.py:20-382 (inference
         return EZNetworkOutput(value, value_prefix, policy_logits, next_latent_state, reward_hidden_state)
 
 
+def _swap_activation(mod, make):
+    """every nn.ReLU of a module tree (attributes and nn.Sequential members) replaced by make()"""
+    for name, child in mod.named_children():
+        if isinstance(child, nn.ReLU):
+            setattr(mod, name, make())
+        else:
+            _swap_activation(child, make)
+
+
+class SampledPredictionNetwork(PredictionNetwork):  # sampled_efficientzero_model.py:490-660, discrete actions, norm_type='BN'
+    """the same prediction network; the reference names the two head MLPs fc_value_head / fc_policy_head (:587-623)"""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.fc_value_head, self.fc_policy_head = self.fc_value, self.fc_policy
+        del self.fc_value, self.fc_policy
+
+    def forward(self, latent_state):
+        for b in self.resblocks:
+            latent_state = b(latent_state)
+        value = self.activation(self.norm_value(self.conv1x1_value(latent_state)))
+        policy = self.activation(self.norm_policy(self.conv1x1_policy(latent_state)))
+        value = self.fc_value_head(value.reshape(-1, self.flat_value))
+        policy = self.fc_policy_head(policy.reshape(-1, self.flat_policy))
+        return policy, value
+
+
+class SampledEfficientZeroModel(EfficientZeroModel):  # lzero/model/sampled_efficientzero_model.py:17-485, discrete actions, norm_type='BN'
+    """With ``continuous_action_space=False`` the reference's conv Sampled EfficientZero has the EfficientZero network's layers (same tower, same
+    dynamics network :353-445, MLP policy head over the action space :610-623) under its own defaults -- GELU(approximate='tanh') everywhere
+    (:40) and 256-wide head MLPs (:29-31) -- and other names for the prediction heads.  Checked against the reference module itself in
+    tests/test_torch_models_vs_reference.py."""
+
+    def __init__(self, observation_shape=(4, 64, 64), action_space_size=6, num_of_sampled_actions=6, continuous_action_space=False,
+                 norm_type='BN', activation=None, reward_head_hidden_channels=(256,), value_head_hidden_channels=(256,),
+                 policy_head_hidden_channels=(256,), **kw):
+        assert not continuous_action_space and norm_type == 'BN', "restated for discrete actions and BatchNorm (the reference's Atari configuration)"
+        super().__init__(observation_shape=observation_shape, action_space_size=action_space_size,
+                         reward_head_hidden_channels=reward_head_hidden_channels, value_head_hidden_channels=value_head_hidden_channels,
+                         policy_head_hidden_channels=policy_head_hidden_channels, **kw)
+        self.num_of_sampled_actions = num_of_sampled_actions
+        self.continuous_action_space = False
+        p = self.prediction_network
+        self.prediction_network = SampledPredictionNetwork(
+            action_space_size, len(p.resblocks), p.conv1x1_value.in_channels, p.conv1x1_value.out_channels, p.conv1x1_policy.out_channels,
+            p.fc_value[0].out_features, p.fc_policy[0].out_features, p.fc_value[-1].out_features, p.flat_value, p.flat_policy)
+        # sampled_efficientzero_model.py:177-218 hands `activation` to the dynamics network ONLY: the representation network keeps its default
+        # ReLU (common.py:718) and the prediction network its default GELU (sampled_efficientzero_model.py:508)
+        _swap_activation(self.prediction_network, lambda: nn.GELU(approximate='tanh'))
+        if activation is None or isinstance(activation, nn.GELU) or (isinstance(activation, str) and activation.lower() == 'gelu'):
+            _swap_activation(self.dynamics_network, lambda: nn.GELU(approximate='tanh'))
+
+
 class MZDynamicsNetwork(nn.Module):  # lzero/model/muzero_model.py:419-538
     def __init__(self, action_encoding_dim, num_res_blocks, num_channels, reward_head_channels, reward_hidden,
                  support_size, flat_reward):

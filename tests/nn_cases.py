@@ -64,19 +64,29 @@ CASES = {
                                                    continuous_action_space=True), B=8, seed=17),
     "sez_mlp_disc": dict(family="sez_mlp", kw=dict(observation_shape=6, action_space_size=5, num_of_sampled_actions=3,
                                                    continuous_action_space=False), B=8, seed=18),
+    # the convolutional Sampled EfficientZero with discrete actions, the reference's Atari configuration as shipped
+    # (zoo/atari/config/atari_sampled_efficientzero_config.py:36-45: 4 x 64 x 64 observations, K sampled actions, one_hot, norm_type='BN'; the class
+    # defaults stay: GELU(tanh) activations, 256-wide head MLPs): the EfficientZero layers, searched by the sampled tree
+    "sez_atari64": dict(family="sez", kw=dict(observation_shape=(4, 64, 64), action_space_size=6, num_of_sampled_actions=5, downsample=True,
+                                              continuous_action_space=False, norm_type='BN'), B=5, seed=35),
+    "sez_atari96_relu32": dict(family="sez", kw=dict(observation_shape=(4, 96, 96), action_space_size=9, num_of_sampled_actions=4, downsample=True,
+                                                     continuous_action_space=False, norm_type='BN', activation="relu",
+                                                     reward_head_hidden_channels=[32], value_head_hidden_channels=[32],
+                                                     policy_head_hidden_channels=[32]), B=4, seed=36),
 }
 STEPS = 3  # recurrent inferences chained after the initial one (teacher-forced on the reference's own states)
 
 
 def oracle_class(tm, family):
     return {"ez": tm.EfficientZeroModel, "mz": tm.MuZeroModel, "mz_mlp": tm.MuZeroModelMLP, "ez_mlp": tm.EfficientZeroModelMLP,
-            "sez_mlp": tm.SampledEfficientZeroModelMLP}[family]
+            "sez_mlp": tm.SampledEfficientZeroModelMLP, "sez": tm.SampledEfficientZeroModel}[family]
 
 
 def reference_class(ref, family):
     return {"ez": ref.efficientzero_model.EfficientZeroModel, "mz": ref.muzero_model.MuZeroModel,
             "mz_mlp": ref.muzero_model_mlp.MuZeroModelMLP, "ez_mlp": ref.efficientzero_model_mlp.EfficientZeroModelMLP,
-            "sez_mlp": ref.sampled_efficientzero_model_mlp.SampledEfficientZeroModelMLP}[family]
+            "sez_mlp": ref.sampled_efficientzero_model_mlp.SampledEfficientZeroModelMLP,
+            "sez": ref.sampled_efficientzero_model.SampledEfficientZeroModel}[family]
 
 
 def engine_class(family):
@@ -85,8 +95,9 @@ def engine_class(family):
     from lightzero_amd.model.muzero_model_mlp import MuZeroModelMLP
     from lightzero_amd.model.efficientzero_model_mlp import EfficientZeroModelMLP
     from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
+    from lightzero_amd.model.sampled_efficientzero_model import SampledEfficientZeroModel
     return {"ez": EfficientZeroModel, "mz": MuZeroModel, "mz_mlp": MuZeroModelMLP, "ez_mlp": EfficientZeroModelMLP,
-            "sez_mlp": SampledEfficientZeroModelMLP}[family]
+            "sez_mlp": SampledEfficientZeroModelMLP, "sez": SampledEfficientZeroModel}[family]
 
 
 def reference_kwargs(case):
@@ -96,11 +107,14 @@ def reference_kwargs(case):
         kw["self_supervised_learning_loss"] = False
     else:
         kw["self_supervised_learning_loss"] = False
+    if kw.get("activation") == "relu":   # (the cases name it; the reference takes the module)
+        import torch.nn as nn
+        kw["activation"] = nn.ReLU(inplace=True)
     return kw
 
 
 def has_lstm(family):
-    return family in ("ez", "ez_mlp", "sez_mlp")
+    return family in ("ez", "ez_mlp", "sez_mlp", "sez")
 
 
 def inputs(case):

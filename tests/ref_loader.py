@@ -3,7 +3,7 @@ only) under a private package name, with tests/ref_stubs standing in for DI-engi
 
     ref = load()            # None when /root/reference is absent (the GPU box)
     ref.common, ref.efficientzero_model, ref.muzero_model, ref.muzero_model_mlp, ref.efficientzero_model_mlp,
-    ref.sampled_efficientzero_model_mlp, ref.scaling_transform, ref.game_segment (lzero/mcts/buffer/game_segment.py)
+    ref.sampled_efficientzero_model_mlp, ref.sampled_efficientzero_model, ref.scaling_transform, ref.game_segment (lzero/mcts/buffer/game_segment.py)
 """
 import importlib
 import importlib.util
@@ -42,7 +42,7 @@ def load():
     sys.modules["lzref_model"] = pkg
     ns = types.SimpleNamespace()
     for name in ("utils", "common", "efficientzero_model", "muzero_model", "muzero_model_mlp", "efficientzero_model_mlp",
-                 "sampled_efficientzero_model_mlp"):
+                 "sampled_efficientzero_model_mlp", "sampled_efficientzero_model"):
         setattr(ns, name, importlib.import_module("lzref_model." + name))
     spec = importlib.util.spec_from_file_location("lzref_scaling_transform", os.path.join(REF, "policy", "scaling_transform.py"))
     mod = importlib.util.module_from_spec(spec)

@@ -169,6 +169,40 @@ def test_configs4_sampled_efficientzero_full_size_device_draws_replay_exactly(co
     _sampled_replay(model, roots, S, lambda e: node_actions2[e], noises, [-1] * B, continuous, A_disc=A)
 
 
+def test_conv_sampled_efficientzero_atari_config_replays_exactly():
+    """The convolutional Sampled EfficientZero as the reference ships it for Atari (zoo/atari/config/atari_sampled_efficientzero_config.py:
+    4 x 64 x 64 observations, discrete actions, K = 5 sampled without replacement, norm_type='BN', the class defaults GELU / 256-wide heads):
+    the fused search on the device (draws inside the captured graph) replays exactly through the oracle sampled tree with the device's own
+    draws and network outputs -- visit counts, root values, per-simulation records."""
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    from lightzero_amd.model.sampled_efficientzero_model import SampledEfficientZeroModel
+    B, S, A, K = 96, 40, 6, 5
+    kw = dict(observation_shape=(4, 64, 64), action_space_size=A, num_of_sampled_actions=K, downsample=True, continuous_action_space=False, norm_type='BN')
+    ref = tm.synthetic_init(tm.SampledEfficientZeroModel(**kw), seed=41)
+    model = SampledEfficientZeroModel(**kw).load_state_dict(ref.state_dict())
+    cfg = dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5,
+               root_noise_weight=0.25, model=dict(action_space_size=A, num_of_sampled_actions=K, continuous_action_space=False))
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
+    roots.set_tiebreak(0, seed=99)
+    obs = torch.rand(B, 4, 64, 64, generator=torch.Generator().manual_seed(33)).cuda().contiguous()
+    noises = np.random.default_rng(6).dirichlet([0.3] * K, size=B).astype(np.float32)
+    out = model.initial_inference(obs, roots)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    node_actions = [roots.get_node_actions(e) for e in range(S + 1)]
+    assert all(np.isfinite(a).all() for a in node_actions)
+    ora, _ = _sampled_replay(model, roots, S, lambda e: node_actions[e], noises, [-1] * B, False, A_disc=A)
+    tr = np.zeros((S, B, 4), np.int32)
+    L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+    assert np.array_equal(ora["records"][:, :, [0, 2]], tr[:, :, [0, 2]]), "per-simulation (parent slot, search length) records differ"
+    assert np.array_equal(ora["root_actions"].view(np.uint32), node_actions[0].view(np.uint32))
+    assert (np.asarray(roots.get_distributions()).sum(1) == S).all()
+
+
 def test_configs4_sampled_efficientzero_full_size_injected_draws_replay_exactly():
     """the other direction at the same size: draws made by the ORACLE's generator (the reference's minstd_rand0 /
     normal_distribution restated, seeded by set_clock) are injected into the fused device search (lz_sroots_set_given)"""

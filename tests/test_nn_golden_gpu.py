@@ -35,6 +35,10 @@ def _roots_for(case, model, B):
         K = kw["num_of_sampled_actions"]
         return ezs_tree.Roots(B, [[-1] * K] * B, kw["action_space_size"], K, kw.get("continuous_action_space", True),
                               max_simulations=4, engine=model.engine)
+    if fam == "sez":   # the convolutional Sampled EfficientZero (discrete actions): the sampled tree over the model's action space
+        from lightzero_amd.mcts.ctree.ctree_sampled_efficientzero import ezs_tree
+        K, A = kw["num_of_sampled_actions"], kw["action_space_size"]
+        return ezs_tree.Roots(B, [list(range(A))] * B, A, K, False, max_simulations=4, engine=model.engine)
     if fam in ("ez", "ez_mlp"):
         from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
     else:
@@ -66,7 +70,7 @@ def check_case(name, case, g, sd, record="golden/", bounds=None):
     model = nn_cases.engine_class(fam)(**ekw).load_state_dict(sd)
     roots = _roots_for(case, model, B)
     obs, actions = nn_cases.inputs(case)
-    if fam != "sez_mlp":   # (the sampled roots create their device handle in the constructor)
+    if fam not in ("sez_mlp", "sez"):   # (the sampled roots create their device handle in the constructor)
         roots._bind_engine(model.engine)
         roots._ensure(kw["action_space_size"])
     L.check(lib.lz_roots_enable_trace(roots._h, 1))   # the heads also write their support-wide logits
@@ -96,7 +100,7 @@ def check_case(name, case, g, sd, record="golden/", bounds=None):
         else:
             a = np.ascontiguousarray(a, np.int32)
             af = np.ascontiguousarray(a, np.float32)  # sampled roots with a discrete action space carry the index as a float
-            if fam == "sez_mlp":
+            if fam in ("sez_mlp", "sez"):
                 L.check(lib.lz_recurrent_inference(roots._h, zeros, None, af.ctypes.data, None, 0, 1))
             else:
                 L.check(lib.lz_recurrent_inference(roots._h, zeros, a.ctypes.data, None, None, 0, 1))
