@@ -151,3 +151,52 @@ def test_collect_gumbel_muzero():
         for a, mk, ip in zip(seg["action_segment"][:v], seg["action_mask_segment"], seg["improved_policy_probs"][:v]):
             assert mk[int(a)] == 1 and int(a) == int(np.argmax(np.where(mk == 1.0, ip, 0.0)))   # gumbel_muzero.py:591-592
             assert abs(float(ip.sum()) - 1.0) < 1e-4
+
+
+class FrameEnv64:
+    """synthetic Atari-shaped env with 64 x 64 frames (the reference's shipped Atari observation size), discrete actions"""
+    def __init__(self, n, A, seed):
+        self.env_num, self.A, self.rng, self.t = n, A, np.random.default_rng(seed), np.zeros(n, np.int64)
+        self.actions = []
+
+    def _obs(self):
+        n = self.env_num
+        return dict(observation=self.rng.random((n, 1, 64, 64)).astype(np.float32), action_mask=np.ones((n, self.A), np.float32),
+                    to_play=np.full(n, -1), timestep=self.t.copy())
+
+    def reset(self):
+        self.t[:] = 0
+        return self._obs()
+
+    def step(self, actions, active):
+        self.actions.append(np.array(actions))
+        self.t += 1
+        done = (self.rng.random(self.env_num) < 0.1) & active
+        self.t[done] = 0
+        return self._obs(), self.rng.standard_normal(self.env_num).astype(np.float32), done, dict(reset_obs=self._obs(), eval_episode_return=self.rng.standard_normal(self.env_num))
+
+
+def test_collect_conv_sampled_efficientzero_on_frames():
+    """the convolutional Sampled EfficientZero (discrete actions on pixel frames: the reference's Atari configuration) through the collector: device-resident
+    frame stack, the env is stepped with the chosen one of the root's K sampled actions, the segments store them"""
+    from oracle import torch_models as tm
+    from lightzero_amd.model.sampled_efficientzero_model import SampledEfficientZeroModel
+    from lightzero_amd.policy.sampled_efficientzero import SampledEfficientZeroPolicy
+    from lightzero_amd.worker import MuZeroVectorCollector
+    n, A_, K = 16, 6, 5
+    kw = dict(observation_shape=(4, 64, 64), action_space_size=A_, num_of_sampled_actions=K, downsample=True, continuous_action_space=False, norm_type='BN')
+    model = SampledEfficientZeroModel(**kw).load_state_dict(tm.synthetic_init(tm.SampledEfficientZeroModel(**kw), seed=4).state_dict())
+    cfg = dict(num_simulations=8, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5, root_noise_weight=0.25,
+               root_dirichlet_alpha=0.3, game_segment_length=5, num_unroll_steps=2, td_steps=2, sampled_algo=True,
+               model=dict(frame_stack_num=4, action_space_size=A_, num_of_sampled_actions=K, continuous_action_space=False))
+    env = FrameEnv64(n, A_, 7)
+    col = MuZeroVectorCollector(env, SampledEfficientZeroPolicy(cfg, model), cfg, device="cuda")
+    segs, meta = col.collect(n_episode=n + 3)
+    assert col.total_episode_count >= n + 3 and len(segs) >= n + 3
+    assert all(np.all((a >= 0) & (a < A_)) for a in env.actions)
+    for seg in segs:
+        v = seg["valid_transition_count"]
+        for a, sa in zip(np.asarray(seg["action_segment"])[:v], np.asarray(seg["root_sampled_actions"])[:v]):
+            assert int(np.asarray(a).reshape(-1)[0]) in np.asarray(sa).reshape(-1).astype(np.int64).tolist()   # the stored action is one of the root's K
+        for cv in seg["child_visit_segment"][:v]:
+            assert len(cv) == K and abs(float(np.sum(cv)) - 1.0) < 1e-5
