@@ -52,8 +52,9 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->model_type >= 0 && cfg->model_type <= 4, "model_type must be 0 (EfficientZeroModel), 1 (MuZeroModel), 2 (MuZeroModelMLP), 3 (EfficientZeroModelMLP) or 4 (SampledEfficientZeroModelMLP)");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->reward_support_size >= 0 && cfg->reward_support_size <= 768, "reward_support_size must be in [0, 768] (0 = the value support)");
-    LZ_REQUIRE(cfg->precision == 0 || (cfg->precision == 1 && cfg->model_type == 0 && cfg->downsample && cfg->obs_h == 96 && cfg->num_channels == 64),
-               "precision must be 0 (fp32, parity mode) or 1 (bf16 fast mode: EfficientZeroModel with the 96x96 -> 6x6x64 latent)");
+    LZ_REQUIRE(cfg->precision == 0 || (cfg->precision == 1 && (cfg->model_type == 0 || cfg->model_type == 1) && cfg->num_of_sampled_actions == 0 &&
+                                        cfg->downsample && cfg->obs_h == 96 && cfg->obs_c == 4 && cfg->num_channels == 64),
+               "precision must be 0 (fp32, parity mode) or 1 (bf16 fast mode: EfficientZeroModel / MuZeroModel with the 4x96x96 -> 6x6x64 latent)");
     LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || cfg->model_type == 2 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
                "a reward support of its own: the MuZero models only (the EfficientZero drivers transform the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {

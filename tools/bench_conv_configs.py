@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--obs", type=int, choices=[96, 64], default=96)
     ap.add_argument("--go", action="store_true", help="BASELINE configs[3] per-GPU share instead: Go 9x9 MuZero (obs 17x9x9, no downsample, "
                     "A = 82, two players); use with --envs 64 --sims 200")
+    ap.add_argument("--fast", action="store_true", help="fast mode (bf16 matrix products; 4x96x96 observations): a separate arm, statistical parity only")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches, each on its own engine / HIP stream: the "
                     "latency-bound tree step of one overlaps the MFMA-bound network step of another")
     a = ap.parse_args()
@@ -54,6 +55,8 @@ def main():
         weights = efficientzero_state_dict(seed=0, action_space_size=A, muzero=a.family == "mz", latent_pixels=36 if a.obs == 96 else 64,
                                            support_size=int(sup[1] - sup[0]))
         mkw = dict(observation_shape=(4, a.obs, a.obs), action_space_size=A, reward_support_range=sup, value_support_range=sup)
+        if a.fast:
+            mkw["fast_mode"] = True
         obs = torch.rand(B, 4, a.obs, a.obs, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
     torch.cuda.synchronize()
     legal = [list(range(A))] * EPS
@@ -89,7 +92,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     assert (np.asarray(res[0]).sum(1) == S).all()
-    print(json.dumps({"workload": "Go 9x9 MuZero conv (configs[3] share)" if a.go else "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS,
+    print(json.dumps({"workload": "Go 9x9 MuZero conv (configs[3] share)" if a.go else "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS, "mode": "fast (bf16 products)" if a.fast else "parity (fp32)",
                       "ms_per_step": dt * 1e3, "env_steps_per_s": B / dt, "mcts_sims_per_s": B * S / dt}))
 
 
