@@ -255,7 +255,7 @@ typedef struct lz_model_cfg {
     /* 0: parity mode -- fp32 arithmetic throughout (the default; every parity claim is about this mode).
      * 1: fast mode (last arm; reported separately, statistical parity only): the 3x3 convolutions of the recurrent
      *    chain and the LSTM gate product run on bf16 MFMA (weights and the multiplied activations rounded to bf16, fp32 accumulation,
-     *    fp32 normalisation / cell / heads / tree).  EfficientZeroModel / MuZeroModel (conv) with 4x96x96 observations and the 6x6x64 latent only. */
+     *    fp32 normalisation / cell / heads / tree).  EfficientZeroModel / MuZeroModel (conv) on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64 latent) observations only. */
     int precision;
 } lz_model_cfg;
 

@@ -639,6 +639,16 @@ __global__ __launch_bounds__(256) void k_avgpool_bf(const __bf16 *__restrict__ i
     }
 }
 
+// fast mode, 64x64 observations: the tower ends without a second pooling (common.py:358-359), so its bf16 output becomes the chain's fp32 input here
+__global__ __launch_bounds__(256) void k_bf16_to_f32(const __bf16 *__restrict__ in, float *__restrict__ out, size_t n8)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(in + i * 8);
+    *reinterpret_cast<float4 *>(out + i * 8) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    *reinterpret_cast<float4 *>(out + i * 8 + 4) = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+}
+
 // conv1x1 (64 -> 16) + bias + BN + ReLU as a small MFMA GEMM: 144 pixels x 16 channels per workgroup, the 4
 // waves split K = 64 into 16-channel groups (one operand fetch + 4 MFMAs per tile per wave).
 __global__ __launch_bounds__(256) void k_conv1x1(lz_c1_args a)
@@ -1564,7 +1574,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     constexpr int NW = 8, PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
     constexpr int PB = 80;                               // bf16 per pixel of the bf16 copies: 64 + pad.  160 B = 10 bank quads: the 16-lane groups ds_read_b128 is
                                                          // served in ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) then hit 16 distinct quads (144 B: 2-way conflicts)
-    static_assert(MT <= 3 && HW % 4 == 0, "up to 48 pixels");
+    static_assert(MT <= 4 && HW % 4 == 0 && (!HEADS || MT == 3), "up to 64 pixels; split heads on the 6x6 latent only");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 fp32 activation buffers of BUF floats (the staged tree first), then
     float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
     float *sSS = sTab + HW * PS;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
@@ -1694,7 +1704,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     }
     // ---- per-lane geometry, the same for every layer: A rows of this lane = pixels 16 mt + (lane & 15); tap (dy, dx) reads pixel
     // m + dy GW + dx when it is inside the image, the zero pixel otherwise (one validity bit per (row tile, tap))
-    unsigned valid = 0;
+    unsigned long long valid = 0;
     int abase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1703,7 +1713,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if (m < HW && yy >= 0 && yy < GH && xx >= 0 && xx < GW) valid |= 1u << (mt * 9 + t);
+            if (m < HW && yy >= 0 && yy < GH && xx >= 0 && xx < GW) valid |= 1ull << (mt * 9 + t);
         }
     }
     const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
@@ -1758,6 +1768,30 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[3 * g + tt], af[tt][mt], acc[mt], 0, 0, 0);
         };
+        if constexpr (MT == 4) {
+            // 8x8 latent: four pixel tiles per tap; a three-tap-deep ring (two 12-fragment groups do not fit the register file beside the weights)
+            auto read_tap = [&](int t, bf16x8 (&af)[MT]) {
+                const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
+                    af[mt] = *reinterpret_cast<const bf16x8 *>(sBin + off);
+                }
+            };
+            bf16x8 ring[3][MT];
+            read_tap(0, ring[0]);
+            read_tap(1, ring[1]);
+            read_tap(2, ring[2]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], ring[t % 3][mt], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 3 < 9) read_tap(t + 3, ring[t % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         bf16x8 a0[3][MT], a1[3][MT];
 #ifdef LZ_DEBUG_KNOBS
         if (!(a.debug_flags & 4)) {   // timing experiments (debug build; results are then wrong): 4 = no pixel reads / MFMAs
@@ -1776,11 +1810,12 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 #ifdef LZ_DEBUG_KNOBS
         }
 #endif
-        // ---- the two k halves meet in LDS: the kh = 0 wave of an output tile finishes pixel tiles 0 and 2 (pixels 0..15, 32..35), the
-        // kh = 1 wave pixel tile 1 -- each leaves its partial sums of the OTHER wave's tiles in sP[nt][mt]
+        }
+        // ---- the two k halves meet in LDS: the kh = 0 wave of an output tile finishes the even pixel tiles (6x6: pixels 0..15, 32..35), the
+        // kh = 1 wave the odd ones -- each leaves its partial sums of the OTHER wave's tiles in sP[nt][mt]
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            if ((mt == 1) != (kh == 1)) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
+            if ((mt & 1) != kh) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
         __syncthreads();
 #ifdef LZ_DEBUG_KNOBS
         if (!(a.debug_flags & 8))     // 8 = no epilogue
@@ -1793,12 +1828,12 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
             float *go = reinterpret_cast<float *>(lane64(my_gout, L));
             if (go) go += (size_t)b * HW * 64;
             // every LDS read of the epilogue before its first write (the compiler must assume they alias)
-            constexpr int NF = MT > 2 ? 2 : 1;     // pixel tiles this wave may finish: {0, 2} | {1}
+            constexpr int NF = (MT + 1) / 2;       // pixel tiles this wave may finish: kh, kh + 2 (< MT)
             f32x4 other[NF], tvv[NF], rvv[NF];
             int mpix[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const int mt = kh == 1 ? 1 : 2 * f;
+                const int mt = min(kh + 2 * f, MT - 1);
                 mpix[f] = mt * 16 + (lane & 15);
                 const int m = min(mpix[f], HW - 1);
                 other[f] = *reinterpret_cast<const f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4);
@@ -1807,8 +1842,8 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                if (kh == 1 && f > 0) continue;
-                const f32x4 mine = kh == 1 ? acc[1] : (f == 0 ? acc[0] : acc[MT - 1]);
+                if (kh + 2 * f >= MT) continue;
+                const f32x4 mine = kh == 1 ? acc[(1 + 2 * f < MT) ? 1 + 2 * f : MT - 1] : acc[2 * f];
                 f32x4 o;
                 bf16x4 ob;
 #pragma unroll
@@ -2588,10 +2623,11 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 // fragments [H/16][4 gates][K/32][64 lanes][8] (lz_lstm_args::wb), accumulation / cell / BatchNorm / split-head partials in fp32 as in
 // k_lstm2.  34 MFMAs per wave instead of 272; a workgroup streams 139 KB of weights instead of 278 KB.
 // ------------------------------------------------------------------------------------------------
-template <bool SH>
+template <bool SH, int NKB = 68, int KXB = 36>   // 68 / 36: 16 x 36 + 512 columns (6x6 latent); 96 / 64: 16 x 64 + 512 (8x8 latent)
 __global__ __launch_bounds__(256) void k_lstm_b(lz_lstm_args a)
 {
-    constexpr int NKB = 68, KXB = 36, K = NKB * 16, NS = K / 32, SX = KXB / 2, PB = K + 16, R = 12, MR = 16;   // row pitch = 10 mod 16 bank quads: conflict-free ds_read_b128
+    constexpr int K = NKB * 16, NS = K / 32, SX = KXB / 2, PB = K + 16, R = 12, MR = 16;   // row pitch = 2 (mod 4) bank quads: conflict-free ds_read_b128
+    static_assert(!SH || NKB == 68, "the split-head partials exist for the 6x6 latent");
     constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // bf16 [16][PB]; reused (fp32) for the gate exchange
     __bf16 *sR = reinterpret_cast<__bf16 *>(smem);
@@ -3327,7 +3363,7 @@ void lz_launch_hinv_nn(const float *d_in, float *d_out, int64_t n, hipStream_t s
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s)
 {
     // fast mode (lz_model_cfg::precision = 1): the layer carries bf16 fragments
-    if (a.wb && a.act_bf16 && !a.gather_ix && !a.act_table && (a.Wout == 48 || a.Wout == 24 || a.Wout == 12)) {   // (the halo of these grids fits the kernel's per-thread piece count)
+    if (a.wb && a.act_bf16 && !a.gather_ix && !a.act_table && (a.Wout == 48 || a.Wout == 24 || a.Wout == 12 || a.Wout == 32 || a.Wout == 16 || a.Wout == 8)) {   // (the halo of these grids -- 96x96 and 64x64 observations -- fits the kernel's per-thread piece count)
         if (cin == 32 && a.Cout == 32 && stride == 1) { launch_conv_bf<32, 32, 1>(a, s); return; }
         if (cin == 32 && a.Cout == 64 && stride == 2) { launch_conv_bf<32, 64, 2>(a, s); return; }
         if (cin == 64 && a.Cout == 64 && stride == 1) { launch_conv_bf<64, 64, 1>(a, s); return; }
@@ -3401,6 +3437,12 @@ void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, Hin, Win, C);
 }
 
+void lz_launch_bf16_to_f32(const void *in, float *out, size_t n, hipStream_t s)
+{
+    const size_t n8 = n / 8;
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16 *>(in), out, n8);
+}
+
 void lz_launch_conv1x1(const lz_c1_args &a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_conv1x1, dim3((a.npix + 143) / 144, a.njobs), dim3(256), 0, s, a);
@@ -3447,12 +3489,18 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
     auto lds_of = [](int hw, int extra) { return (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + extra) * 4; };
     // fast mode (lz_model_cfg::precision = 1): every layer carries bf16 fragments -> k_chain_b
     {
-        bool fast = a.gw == 6 && a.gh == 6 && a.nlayers > 0 && !a.tstamp;
+        bool fast = ((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) && a.nlayers > 0 && !a.tstamp;
         for (int i = 0; i < a.nlayers; ++i) fast = fast && a.layer[i].wb != nullptr;
         if (fast) {
-            constexpr int hw = 36, mt = 3;
+            const int hw = a.gw * a.gh, mt = (hw + 15) / 16;
             const size_t lds = (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 4 * mt * 256) * 4 + (size_t)4 * (hw + 1) * 80 * 2;
             const dim3 g(a.B), blk(512);
+            if (a.gw == 8) {   // 8x8 latent (64x64 observations): no split heads
+                if (step && step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_b<8, 8, 1, false>), g, blk, lds, s, a, *step);
+                else if (step) hipLaunchKernelGGL((k_chain_b<8, 8, 2, false>), g, blk, lds, s, a, *step);
+                else hipLaunchKernelGGL((k_chain_b<8, 8>), g, blk, lds, s, a, no_step{});
+                return;
+            }
             if (step) {
                 if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on) hipLaunchKernelGGL((k_chain_b<6, 6, 1, true>), g, blk, lds, s, a, *step);
                 else if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_b<6, 6, 1, false>), g, blk, lds, s, a, *step);
@@ -3548,10 +3596,12 @@ void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out)
 static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
 {
     static const char *off = getenv("LZ_LSTM_CHUNKED");
-    if (a.wb) {   // fast mode (lz_model_finalize builds the bf16 fragments for this shape only): 576 + 512 columns, no input transform
+    if (a.wb) {   // fast mode (lz_model_finalize builds the bf16 fragments for these shapes only): 576 | 1024 + 512 columns, no input transform
         const dim3 g(a.H / 16, (a.B + 15) / 16);
-        const size_t lds = std::max((size_t)16 * (68 * 16 + 16) * 2, (size_t)(4 * 16 * 17 + 16 * 17 + 16 * 40 + 16 * 96) * 4);
-        if (a.sh_part && a.sh_kc == 1152) hipLaunchKernelGGL((k_lstm_b<true>), g, dim3(256), lds, s, a);
+        const int nkb = (a.KX + a.H) / 16;
+        const size_t lds = std::max((size_t)16 * ((size_t)nkb * 16 + 16) * 2, (size_t)(4 * 16 * 17 + 16 * 17 + 16 * 40 + 16 * 96) * 4);
+        if (a.KX == 1024) hipLaunchKernelGGL((k_lstm_b<false, 96, 64>), g, dim3(256), lds, s, a);
+        else if (a.sh_part && a.sh_kc == 1152) hipLaunchKernelGGL((k_lstm_b<true>), g, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((k_lstm_b<false>), g, dim3(256), lds, s, a);
         return true;
     }

@@ -41,6 +41,9 @@ void lz_launch_conv_in(const float *obs_nchw, const float *w /*[9][C][Cout]*/, c
 // AvgPool2d(kernel 3, stride 2, pad 1, count_include_pad) on NHWC
 void lz_launch_avgpool(const float *in, float *out, int B, int Hin, int Win, int C, hipStream_t s, int in_bf16 = 0, int out_bf16 = 0);   // (bf16 tensors: fast mode)
 
+// fast mode: n bf16 values (n a multiple of 8) -> fp32
+void lz_launch_bf16_to_f32(const void *in, float *out, size_t n, hipStream_t s);
+
 // conv1x1 (64 -> 16 channels per job) + bias + BN + ReLU on NHWC [npix][64] as a small MFMA GEMM; up to 4
 // independent jobs (e.g. reward / value / policy head convolutions) share one launch (blockIdx.y = job).
 struct lz_c1_job {

@@ -53,8 +53,9 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->reward_support_size >= 0 && cfg->reward_support_size <= 768, "reward_support_size must be in [0, 768] (0 = the value support)");
     LZ_REQUIRE(cfg->precision == 0 || (cfg->precision == 1 && (cfg->model_type == 0 || cfg->model_type == 1) && cfg->num_of_sampled_actions == 0 &&
-                                        cfg->downsample && cfg->obs_h == 96 && cfg->obs_c == 4 && cfg->num_channels == 64),
-               "precision must be 0 (fp32, parity mode) or 1 (bf16 fast mode: EfficientZeroModel / MuZeroModel with the 4x96x96 -> 6x6x64 latent)");
+                                        cfg->downsample && (cfg->obs_h == 96 || cfg->obs_h == 64) && cfg->obs_c == 4 && cfg->num_channels == 64 &&
+                                        (cfg->model_type == 1 || cfg->lstm_hidden_size == 512)),
+               "precision must be 0 (fp32, parity mode) or 1 (bf16 fast mode: EfficientZeroModel (LSTM 512) / MuZeroModel with 4x96x96 -> 6x6x64 or 4x64x64 -> 8x8x64)");
     LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || cfg->model_type == 2 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
                "a reward support of its own: the MuZero models only (the EfficientZero drivers transform the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {
@@ -298,7 +299,7 @@ extern "C" int lz_model_finalize(lz_engine *e)
                 m->lstm_wf = b.upload(wf);
             }
             m->lstm_wb = nullptr;
-            if (c.precision == 1 && KX == 576 && H == 512) {
+            if (c.precision == 1 && (KX == 576 || KX == 1024) && H == 512) {
                 // k_lstm_b: wave = gate g of unit tile t, lane (n = l & 15, kq = l >> 4) holds W[4 (16 t + n) + g][32 s + 8 kq + j], j = 0..7
                 const int NS = K / 32;
                 std::vector<uint16_t> wb((size_t)4 * H * K);
@@ -685,7 +686,8 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     conv(m->r3b, w1, w2, B, S3, S3, 1, w0, 1, s, bf);            // w2
     LZ_STAGE();
     if (c.obs_h == 64) {                                      // common.py:358-359: no second pooling
-        LZ_HIP_CHECK(hipMemcpyAsync(w0, w2, (size_t)B * S3 * S3 * C * 4, hipMemcpyDeviceToDevice, s));
+        if (bf) lz_launch_bf16_to_f32(w2, w0, (size_t)B * S3 * S3 * C, s);
+        else LZ_HIP_CHECK(hipMemcpyAsync(w0, w2, (size_t)B * S3 * S3 * C * 4, hipMemcpyDeviceToDevice, s));
     } else {
         lz_launch_avgpool(w2, w0, B, S3, S3, C, s, bf, 0);           // w0: 6x6x64
     }

@@ -89,9 +89,9 @@ class EfficientZeroModel(object):
             cfg.reward_support_size, cfg.reward_support_min = self.reward_support_size, float(reward_support_range[0])
         self.fast_mode = bool(fast_mode)
         if self.fast_mode:
-            if self._model_type not in (0, 1) or not downsample or self.num_channels != 64 or self.observation_shape != (4, 96, 96) \
-                    or getattr(self, "num_of_sampled_actions", 0):
-                raise NotImplementedError("fast_mode: EfficientZeroModel / MuZeroModel with the 4x96x96 -> 6x6x64 latent")
+            if self._model_type not in (0, 1) or not downsample or self.num_channels != 64 \
+                    or self.observation_shape not in ((4, 96, 96), (4, 64, 64)) or getattr(self, "num_of_sampled_actions", 0):
+                raise NotImplementedError("fast_mode: EfficientZeroModel / MuZeroModel on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64) observations")
             cfg.precision = 1
         self._create(cfg)
 

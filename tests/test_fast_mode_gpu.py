@@ -204,3 +204,65 @@ def test_muzero_conv_fast_mode_statistics_and_exact_replay():
     # (this synthetic model's root values are small and close together: 3 % of their mean, correlation 0.89 measured; the visit distributions
     # are what a consumer sees: 82 % of the roots identical, mean total-variation distance 0.005)
     assert stats["value_rel"] < 0.06 and stats["value_corr"] > 0.8 and stats["tv_mean"] < 0.02 and stats["identical"] > 0.7, stats
+
+
+def test_fast_mode_on_the_shipped_atari_shape_64x64():
+    """the reference's shipped Atari EfficientZero configuration (4 x 64 x 64 frames -> 8 x 8 x 64 latent, supports (-50, 51, 1)): k_chain_b<8, 8> (four
+    pixel tiles per tap), k_lstm_b<96, 64> (16 x 64 + 512 columns), the tower's k_conv_bf on the 32^2 / 16^2 / 8^2 grids"""
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from test_exact_replay_gpu import _search_and_replay
+    sup = (-50., 51., 1.)
+    kw = dict(observation_shape=(4, 64, 64), action_space_size=A, reward_support_range=sup, value_support_range=sup)
+    ref = tm.synthetic_init(tm.EfficientZeroModel(**kw), seed=14)
+    par = EfficientZeroModel(engine=L.new_engine(0), **kw).load_state_dict(ref.state_dict())
+    fast = EfficientZeroModel(engine=L.new_engine(0), fast_mode=True, **kw).load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(15)
+    # single steps against the fp32 engine
+    Bs = 23
+    obs = torch.rand(Bs, 4, 64, 64, generator=g)
+    with torch.no_grad():
+        lat = ref.initial_inference(obs).latent_state
+    h = (torch.randn(1, Bs, 512, generator=g) * 0.3, torch.randn(1, Bs, 512, generator=g) * 0.3)
+    act = torch.randint(0, A, (Bs,), generator=g)
+    op, of = par.recurrent_inference(lat, h, act), fast.recurrent_inference(lat, h, act)
+    assert 1e-6 < _rel(of.latent_state, op.latent_state) < 3e-2
+    assert _rel(of.reward_hidden_state[0], op.reward_hidden_state[0]) < 3e-2 and _rel(of.reward_hidden_state[1], op.reward_hidden_state[1]) < 3e-2
+    assert _rel(of.policy_logits, op.policy_logits) < 5e-2 and _rel(of.value, op.value) < 5e-2 and _rel(of.value_prefix, op.value_prefix) < 5e-2
+    oi, fi = par.initial_inference(obs), fast.initial_inference(obs)
+    assert _rel(fi.policy_logits, oi.policy_logits) < 5e-2
+    # the 8x8 chain's arithmetic is the stated one: torch fp32 convolutions on bf16-rounded operands (as in the 6x6 test above)
+    import torch.nn.functional as F
+    dn = ref.dynamics_network
+    with torch.no_grad():
+        onehot = torch.zeros(Bs, A, 8, 8)
+        onehot[torch.arange(Bs), act] = 1.0
+        w = dn.conv.weight
+        x = F.conv2d(_bf16(lat), _bf16(w[:, :64]), padding=1) + F.conv2d(onehot, w[:, 64:], padding=1)
+        x = F.relu(dn.norm_common(x) + lat)
+        for blk in dn.resblocks:
+            y = F.relu(blk.conv1[1](F.conv2d(_bf16(x), _bf16(blk.conv1[0].weight), padding=1)))
+            y = blk.conv2[1](F.conv2d(_bf16(y), _bf16(blk.conv2[0].weight), padding=1))
+            x = F.relu(y + x)
+    err = float((of.latent_state - x).abs().max()), float(x.abs().max())
+    assert err[0] < 2e-4 * (1.0 + err[1]), err
+    # a search: statistics against parity mode, exact replay of the fast graph
+    B, S = 128, 50
+    obs = torch.rand(B, 4, 64, 64, generator=g).cuda().contiguous()
+    rng = np.random.default_rng(3)
+    noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    legal = [list(range(A))] * B
+    res = {}
+    for name, m in (("par", par), ("fast", fast)):
+        roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=m.engine)
+        roots.set_tiebreak(0)
+        d, v, _ = _search_and_replay("ez", m, roots, obs, legal, [-1] * B, noises, S, 0.997)
+        res[name] = (np.array(d), np.asarray(v))
+    tv = 0.5 * np.abs(res["fast"][0] / S - res["par"][0] / S).sum(1)
+    stats = dict(value_rel=float(np.abs(res["fast"][1] - res["par"][1]).mean() / (np.abs(res["par"][1]).mean() + 1e-9)),
+                 tv_mean=float(tv.mean()), identical=float((tv == 0).mean()))
+    print("EfficientZero 64x64, fast vs parity, %d x %d:" % (B, S), stats)
+    # (measured on this synthetic model: 48 % of the roots identical, mean total-variation distance 0.033 = 1.6 of 50 visits, values 5 % apart)
+    assert stats["value_rel"] < 0.08 and stats["tv_mean"] < 0.06 and stats["identical"] > 0.35, stats
