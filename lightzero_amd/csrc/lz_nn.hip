@@ -3517,7 +3517,7 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
     for (int i = 0; i < a.nlayers; ++i) wino = wino && a.layer[i].uc != nullptr;
     if (wino) {
         static const char *w4 = getenv("LZ_CHAIN_W4");  // 4 waves (one per SIMD) instead of 8
-        const int hw = a.gw * a.gh, nt = hw / 4, nw = (w4 && a.gw == 6) ? 4 : 8;   // (8x8 has no 4-wave instance)
+        const int hw = a.gw * a.gh, nt = hw / 4, nw = (w4 && a.gw == 6 && !a.gelu) ? 4 : 8;   // (8x8 has no 4-wave instance)
         const bool big = hw > 36;
         const size_t lds = (size_t)(4 * (hw + 1) * 68 + (big ? 0 : hw * 68) + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 16 * nt * 68 +
                                     (big ? 0 : nw * nt * 2 * 64)) * 4;
