@@ -36,6 +36,13 @@ CONFIGS = {
                      chain_flop=CHAIN_GO, workload="BASELINE.json configs[3] on 2 GPUs instead of 8: Go 9x9 MuZero, 256 of the 512 envs on this GPU (one chain workgroup per CU)"),
     "cfg3_all": dict(index=3, cmd=["tools/bench_conv_configs.py", "--go", "--envs", "512", "--sims", "200", "--steps", "4", "--warmup", "1"], prof_steps="1",
                      chain_flop=CHAIN_GO, workload="BASELINE.json configs[3], all 512 envs on one GPU: Go 9x9 MuZero, obs 17x9x9, A = 82, 200 sims"),
+    # FAST MODE arms (bf16 matrix products; statistical parity only) and the reference's shipped Atari shape (64x64 frames -> 8x8 latent)
+    "cfg2_fast": dict(index=2, cmd=["tools/bench_conv_configs.py", "--envs", "1024", "--sims", "400", "--steps", "4", "--warmup", "1", "--fast"], prof_steps="1", dtype="bf16",
+                      workload="FAST MODE arm of BASELINE.json configs[2]: Atari Breakout MuZero, obs 4x96x96, 400 sims, 1024 envs, A = 4"),
+    "cfg_atari64": dict(index=1, cmd=["tools/bench_conv_configs.py", "--family", "ez", "--obs", "64", "--envs", "256", "--sims", "50", "--actions", "6", "--steps", "20"], prof_steps="5",
+                        workload="the reference's shipped Atari EfficientZero shape (zoo/atari/config/atari_efficientzero_config.py: 4x64x64 frames -> 8x8 latent, supports (-50, 51)), 50 sims, 256 envs, A = 6"),
+    "cfg_atari64_fast": dict(index=1, cmd=["tools/bench_conv_configs.py", "--family", "ez", "--obs", "64", "--envs", "256", "--sims", "50", "--actions", "6", "--steps", "20", "--fast"], prof_steps="5", dtype="bf16",
+                             workload="FAST MODE arm of the shipped Atari EfficientZero shape (4x64x64 frames -> 8x8 latent), 50 sims, 256 envs, A = 6"),
     "cfg4": dict(index=4, cmd=["tools/bench_mlp_configs.py", "--config", "4", "--envs", "64", "--steps", "50"], prof_steps="20",
                  workload="BASELINE.json configs[4], one GPU's share: DMC cartpole-swingup Sampled EfficientZero (obs 5, action dim 1, K = 20), 50 sims, 64 of the 256 envs (4 GPUs)"),
     "cfg4_all": dict(index=4, cmd=["tools/bench_mlp_configs.py", "--config", "4", "--envs", "256", "--steps", "50"], prof_steps="20",
@@ -98,7 +105,7 @@ def main():
                                  "wavefront of dependent instructions per root; no roofline applies, the launch count per simulation does")
         d = {"metric": "self-play env-steps/sec (search only: initial inference -> prepare -> fused search -> read-back, inputs in HBM)",
              "value": line["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": 1, "ms_per_step": line["ms_per_step"], "higher_is_better": True,
-             "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+             "dtype": c.get("dtype", "f32"), "data": "synthetic", "vs_baseline": None,
              "config": {"workload": c["workload"], "baseline_config_index": c["index"], "envs": line["envs"], "num_simulations": line["num_simulations"],
                         "mcts_sims_per_s": line["mcts_sims_per_s"], "tool": " ".join(c["cmd"])},
              "roofline": roof, "kernels": table, "csrc_sha256": csrc_digest()}
