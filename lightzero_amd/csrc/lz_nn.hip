@@ -1008,7 +1008,10 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
 // stores written through while the kernel still runs.  Nobody reads them back inside the launch.
 __device__ __forceinline__ void store_wt(float *p, const f32x4 &v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    // The s_nop belongs to the store: a VMEM store of more than 64 bits reads its data registers late, and a VALU write to them within two wait
+    // states corrupts the stored value (gfx940 hazard).  The compiler's hazard recognizer covers its own stores but cannot see into inline
+    // assembly -- found when an experiment's register allocation reused the data registers as the next store's address (6 % of the rows wrong).
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_wt(float *p, float v)
 {
