@@ -173,13 +173,18 @@ class EfficientZeroModel(object):
             while len(cache) >= self._OWN_ROOTS_MAX:   # a driver whose ready-env count varies: keep the few most recent batch sizes
                 _, old = cache.popitem(last=False)
                 old.clear()   # destroyed, not parked: its pools go back to the device
-            A = self.action_space_size
-            r = self._tree().Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=max_simulations, engine=self._engine)
-            r._bind_engine(self._engine)
-            r._ensure(A)
+            r = self._new_own_roots(B, max_simulations)
             if trace:
                 L.check(L.lib().lz_roots_enable_trace(r._h, 1))   # the heads also write their support-wide logits
             cache[(slot, B)] = r
+        return r
+
+    def _new_own_roots(self, B, max_simulations):
+        """a fresh roots handle of this model's tree family on its engine (the sampled families override it)"""
+        A = self.action_space_size
+        r = self._tree().Roots(B, [list(range(A))] * B, action_space_size=A, max_simulations=max_simulations, engine=self._engine)
+        r._bind_engine(self._engine)
+        r._ensure(A)
         return r
 
     def _run_initial(self, obs, roots):

@@ -60,20 +60,14 @@ class _EngineModelMLP(EfficientZeroModel):
     def _latent_shape(self):
         return (self.latent_state_dim,)
 
-    def _own_roots(self, B, slot, max_simulations, trace=False):
+    def _new_own_roots(self, B, max_simulations):
         if self._model_type != 4:
-            return super()._own_roots(B, slot, max_simulations, trace)
-        cache = self.__dict__.setdefault("_own", {})
-        r = cache.get((slot, B))
-        if r is None:  # Sampled EfficientZero: the sampled tree's handle (K actions per node)
-            from ..mcts.ctree.ctree_sampled_efficientzero import ezs_tree
-            K = self.num_of_sampled_actions
-            r = ezs_tree.Roots(B, [[-1] * K] * B, self.action_space_size, K, self.continuous_action_space, max_simulations=max_simulations,
-                               engine=self._engine)
-            if trace:
-                L.check(L.lib().lz_roots_enable_trace(r._h, 1))
-            cache[(slot, B)] = r
-        return r
+            return super()._new_own_roots(B, max_simulations)
+        # Sampled EfficientZero: the sampled tree's handle (K actions per node); kept in the model's bounded LRU like every other (_own_roots)
+        from ..mcts.ctree.ctree_sampled_efficientzero import ezs_tree
+        K = self.num_of_sampled_actions
+        return ezs_tree.Roots(B, [[-1] * K] * B, self.action_space_size, K, self.continuous_action_space, max_simulations=max_simulations,
+                              engine=self._engine)
 
 
 class MuZeroModelMLP(_EngineModelMLP):

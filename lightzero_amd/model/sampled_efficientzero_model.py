@@ -72,15 +72,8 @@ class SampledEfficientZeroModel(EfficientZeroModel):
             ren[k2] = v
         return super().load_state_dict(ren, strict)
 
-    def _own_roots(self, B, slot, max_simulations, trace=False):
-        from .. import _lib as L
-        cache = self.__dict__.setdefault("_own", {})
-        r = cache.get((slot, B))
-        if r is None:   # the sampled tree's handle (K actions per node, discrete action space)
-            from ..mcts.ctree.ctree_sampled_efficientzero import ezs_tree
-            K, A = self.num_of_sampled_actions, self.action_space_size
-            r = ezs_tree.Roots(B, [list(range(A))] * B, A, K, False, max_simulations=max_simulations, engine=self._engine)
-            if trace:
-                L.check(L.lib().lz_roots_enable_trace(r._h, 1))
-            cache[(slot, B)] = r
-        return r
+    def _new_own_roots(self, B, max_simulations):
+        # the sampled tree's handle (K actions per node, discrete action space); kept in the model's bounded LRU (_own_roots)
+        from ..mcts.ctree.ctree_sampled_efficientzero import ezs_tree
+        K, A = self.num_of_sampled_actions, self.action_space_size
+        return ezs_tree.Roots(B, [list(range(A))] * B, A, K, False, max_simulations=max_simulations, engine=self._engine)

@@ -211,3 +211,17 @@ def test_conv_sampled_efficientzero_policy_surface_and_vector_collector_rows():
     ev1, ev2 = pol._forward_eval(obs, to_play=[-1] * B), pol._forward_eval(obs, to_play=[-1] * B)
     assert all(sum(ev1[i]["visit_count_distributions"]) == S for i in range(B))
     assert all(np.isfinite(ev1[i]["searched_value"]) for i in range(B)) and len(ev2) == B
+
+
+def test_sampled_models_keep_a_bounded_number_of_own_roots_handles():
+    """initial_inference(obs) without roots / recurrent_inference on arrays leave their state in handles the MODEL owns, one per batch size; a driver
+    whose ready-env count varies must not accumulate them: the sampled families go through the same bounded LRU as every other model"""
+    import torch
+    from oracle import torch_models as tm
+    from lightzero_amd.model.sampled_efficientzero_model_mlp import SampledEfficientZeroModelMLP
+    kw = dict(observation_shape=5, action_space_size=1, num_of_sampled_actions=8, continuous_action_space=True)
+    model = SampledEfficientZeroModelMLP(**kw).load_state_dict(tm.synthetic_init(tm.SampledEfficientZeroModelMLP(**kw), seed=2).state_dict())
+    for B in range(3, 12):
+        out = model.initial_inference(torch.randn(B, 5))
+        assert tuple(out.policy_logits.shape) == (B, 2)
+    assert len(model._own) <= model._OWN_ROOTS_MAX
