@@ -312,8 +312,9 @@ void lz_launch_dense(const lz_dense_args &a, hipStream_t s)
     } else if (k1max <= 640) {
         if (xf) hipLaunchKernelGGL((k_dense<10, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_dense<10, false>), grid, block, lds, s, a);
-    } else {   // up to 1024 columns, no deferred transform: the first head layers of the conv Sampled EfficientZero on an 8x8 latent (16 x 64)
-        hipLaunchKernelGGL((k_dense<16, false>), grid, block, lds, s, a);
+    } else {   // up to 1024 columns: the first head layers of the conv Sampled EfficientZero on an 8x8 latent (16 x 64)
+        if (xf) hipLaunchKernelGGL((k_dense<16, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_dense<16, false>), grid, block, lds, s, a);
     }
 }
 

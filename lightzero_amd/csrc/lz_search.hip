@@ -527,6 +527,7 @@ static int ensure_head_debug(lz_roots *r)
     if (!r->head_debug || r->hd_logits) return LZ_OK;
     const lz_model_cfg &c = r->eng->model->cfg;
     LZ_REQUIRE(c.model_type < 2, "head debug buffers exist for the conv models only");
+    LZ_REQUIRE(!r->eng->model->wide_heads, "head debug buffers: not with the dense-layer heads of the conv Sampled EfficientZero (its support-wide logits: lz_roots_read_debug_logits)");
     const size_t B = r->t.B, NN = r->t.NN, SUP = std::max(c.support_size, c.reward_support_size);
     const size_t n = NN * 2 * B * (SUP + 1);
     hipError_t err = lz_dev_malloc((void **)&r->hd_logits, n * 4);
