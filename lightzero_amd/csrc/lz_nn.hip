@@ -548,6 +548,87 @@ __global__ __launch_bounds__(256) void k_conv_first(const float *__restrict__ ob
     }
 }
 
+// The same layer for 4-channel observations on the matrix pipe (round 4): a workgroup owns TR = 96 / Wo output rows of one image = 96 output
+// pixels (six 16-pixel MFMA column tiles); the 2 TR + 1 input rows of the four NCHW planes it needs arrive as whole coalesced rows (16-byte
+// loads) in LDS [plane][row][4 + W] -- the VALU kernel above reads its 36 inputs per thread as stride-2 four-byte loads, four threads per pixel
+// re-reading them.  k = the 4 input planes of one tap (v_mfma_f32_16x16x4_f32, weights as the A operand: D[channel][pixel]), 9 taps accumulate;
+// a lane ends with four consecutive output channels of one pixel.  Wave (nt, mg): output-channel tile nt, pixel tiles 3 mg .. 3 mg + 2.
+template <bool OUTBF>
+__global__ __launch_bounds__(256) void k_conv_first_mm(const float *__restrict__ obs, const float *__restrict__ w, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, float *__restrict__ out, int B, int H, int W, int TR)
+{
+    constexpr int C = 4, COUT = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [C][2 TR + 1][W + 8]: column 4 + ix (column 3 = ix -1, zero)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv & 1, mg = wv >> 1;
+    const int Ho = H / 2, Wo = W / 2, bands = (Ho + TR - 1) / TR, NR = 2 * TR + 1, WP = W + 8;
+    const int img = blockIdx.x / bands, band = blockIdx.x - img * bands, oy0 = band * TR, iy0 = 2 * oy0 - 1;
+    // ---- weights: lane (co = 16 nt + (l & 15), ci = l >> 4) of tap t: w[t][ci][co]
+    float wq[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wq[t] = w[(t * C + (lane >> 4)) * COUT + nt * 16 + (lane & 15)];
+    const int co4 = nt * 16 + 4 * (lane >> 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + co4), sh = *reinterpret_cast<const f32x4 *>(shift + co4);
+    // ---- stage the rows (zero outside the image)
+    {
+        const int W4 = W / 4, n4 = C * NR * W4;
+        const float *src = obs + (size_t)img * C * H * W;
+        for (int i0 = 0; i0 < n4; i0 += 2 * 256) {
+            f32x4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = min(i0 + u * 256 + tid, n4 - 1), c4 = idx % W4, rr = idx / W4, r = rr % NR, ci = rr / NR, iy = iy0 + r;
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(src + ((size_t)ci * H + min(max(iy, 0), H - 1)) * W + c4 * 4);
+                v[u] = (iy >= 0 && iy < H) ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = i0 + u * 256 + tid;
+                if (idx < n4) {
+                    const int c4 = idx % W4, rr = idx / W4;
+                    *reinterpret_cast<f32x4 *>(smem + rr * WP + 4 + c4 * 4) = v[u];
+                }
+            }
+        }
+        if (tid < C * NR) smem[tid * WP + 3] = 0.0f;   // ix = -1
+    }
+    __syncthreads();
+    // ---- products
+    f32x4 acc[3];
+    int pbase[3], prow[3], pcol[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int p = 16 * (3 * mg + i) + (lane & 15);
+        prow[i] = p / Wo; pcol[i] = p - prow[i] * Wo;
+        pbase[i] = ((lane >> 4) * NR + 2 * prow[i]) * WP + 3 + 2 * pcol[i];   // plane l >> 4, tap (0, 0)
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float px[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) px[i] = smem[pbase[i] + (t / 3) * WP + (t % 3)];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], px[i], acc[i], 0, 0, 0);
+    }
+    // ---- BatchNorm + ReLU, four consecutive channels of one pixel per lane
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (oy0 + prow[i] >= Ho) continue;
+        const size_t o = (((size_t)img * Ho + oy0 + prow[i]) * Wo + pcol[i]) * COUT + co4;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc[i][q] * sc[q] + sh[q], 0.0f);
+        if constexpr (OUTBF) {
+            bf16x4 hb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hb[q] = (__bf16)v[q];
+            *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(out) + o) = hb;
+        } else {
+            *reinterpret_cast<f32x4 *>(out + o) = v;
+        }
+    }
+}
+
 // first layer of a no-downsample RepresentationNetwork (board games, common.py:735-741,768-771): conv3x3 stride 1 from
 // NCHW observations [B][C][H][W] to NHWC [B][H*W][64], + BN + ReLU.  thread = (pixel, 8 output channels).
 // COUT = 64 | 32 | 16 output channels: COUT / 8 threads per pixel
@@ -3404,6 +3485,14 @@ void lz_launch_conv_first(const float *obs, const float *w, const float *scale, 
 {
     const int64_t M = (int64_t)B * (H / 2) * (W / 2);
     dim3 grid((unsigned)((M + 63) / 64)), block(256);
+    static const char *valu = getenv("LZ_CONV_FIRST_VALU");   // A/B switch: the VALU kernel (another summation order, same tolerance)
+    if (C == 4 && Cout == 32 && !valu && (W == 96 || W == 64) && H == W) {   // the Atari shapes: rows through LDS, taps on the matrix pipe
+        const int TR = 96 / (W / 2), bands = (H / 2 + TR - 1) / TR;
+        const size_t lds = (size_t)4 * (2 * TR + 1) * (W + 8) * 4;
+        if (out_bf16) hipLaunchKernelGGL((k_conv_first_mm<true>), dim3(B * bands), block, lds, s, obs, w, scale, shift, out, B, H, W, TR);
+        else hipLaunchKernelGGL((k_conv_first_mm<false>), dim3(B * bands), block, lds, s, obs, w, scale, shift, out, B, H, W, TR);
+        return;
+    }
     if (out_bf16) {   // fast mode: 4 x 96 x 96 observations only (lz_model_create)
         hipLaunchKernelGGL((k_conv_first<4, 32, true>), grid, block, 0, s, obs, w, scale, shift, out, B, H, W);
         return;
