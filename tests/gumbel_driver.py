@@ -20,7 +20,18 @@ def make_inputs(case):
     c.update(case)
     rng = np.random.default_rng(c["seed"])
     B, A, S = c["B"], c["A"], c["S"]
-    legal = fixture_legal_actions() if c["legal"] == "fixture" else [list(range(A)) for _ in range(B)]
+    if c["legal"] == "fixture":
+        legal = fixture_legal_actions()
+        assert len(legal) == B, "the fixture's legal lists are for %d roots" % len(legal)
+    elif c["legal"] == "random":      # ragged lists, at least one action each (a generator of its own: the other arrays do not move)
+        lr = np.random.default_rng(c["seed"] + 77777)
+        legal = []
+        for _ in range(B):
+            k = lr.random(A) < 0.5
+            k[lr.integers(0, A)] = True
+            legal.append(np.nonzero(k)[0].tolist())
+    else:
+        legal = [list(range(A)) for _ in range(B)]
     z = 0.0 if c["zero"] else 1.0
     c["legal_list"] = legal
     c["root_logits"] = (z * rng.standard_normal((B, A))).astype(np.float32)

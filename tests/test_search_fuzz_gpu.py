@@ -8,10 +8,13 @@ import torch
 
 from test_exact_replay_gpu import _ez_model, _mz_model, _search_and_replay
 
+# LZ_FUZZ_SEED_OFFSET=n shifts every seeded sweep of this file to seeds n .. n + count - 1 (ad-hoc wider sweeps; the committed suite runs 0)
+_OFF = int(__import__("os").environ.get("LZ_FUZZ_SEED_OFFSET", "0"))
+
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 10))
 def test_random_efficientzero_search_replays_exactly(seed):
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
     r = np.random.default_rng(1200 + seed)
@@ -33,7 +36,7 @@ def test_random_efficientzero_search_replays_exactly(seed):
     _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, float(r.choice([0.997, 0.99])), trace=bool(seed % 2))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 12))
 def test_random_two_player_board_search_replays_exactly(seed):
     from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
     r = np.random.default_rng(1300 + seed)
@@ -64,7 +67,7 @@ def test_random_two_player_board_search_replays_exactly(seed):
     _search_and_replay("ez" if ez else "mz", model, roots, obs, legal, to_play, noises, S, 1.0, trace=True)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
 def test_random_mlp_model_search_replays_exactly(seed):
     """vector-observation models (MuZeroModelMLP / EfficientZeroModelMLP): random observation widths, latent widths, action counts"""
     from oracle import torch_models as tm
@@ -101,7 +104,7 @@ def test_random_mlp_model_search_replays_exactly(seed):
     _search_and_replay(variant, model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 3))
 def test_tictactoe_efficientzero_two_player_replays_exactly(seed):
     """the reference's TicTacToe EfficientZero configuration (16-channel model, value-prefix LSTM on 16 x 9 + 512 inputs), two players"""
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
@@ -149,7 +152,7 @@ def test_minigrid_sized_models_replay_exactly(family):
     _search_and_replay(family, model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
 def test_random_sampled_efficientzero_search_replays_exactly(seed):
     """Sampled EfficientZero fused loop, device-side draws (the production path) read back per node and injected into the oracle:
     continuous (D = 1..3) and discrete (K of A without replacement) action spaces, random K, batch, simulations, observation width"""
@@ -182,7 +185,7 @@ def test_random_sampled_efficientzero_search_replays_exactly(seed):
     _sampled_replay(model, roots, S, lambda e: node_actions[e], noises, [-1] * B, continuous, A_disc=A)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
 def test_random_gumbel_search_replays_exactly(seed):
     """lz_gsearch (Gumbel MuZero) on conv and vector-observation MuZero models: random action counts, considered-action counts m,
     simulation budgets, ragged legal masks, noise on / off -- records, visit counts, root values, improved policies, completed Q-values"""
@@ -234,7 +237,7 @@ def test_random_gumbel_search_replays_exactly(seed):
         assert np.array_equal(o[k].view(np.uint32), np.asarray(got, np.float32).view(np.uint32)), "%s not bit-equal" % k
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
 def test_random_rezero_search_with_reuse_replays_exactly(seed):
     """lz_search_with_reuse (ReZero): EfficientZero Atari models and two-player MuZero board models, random shapes, ragged legal lists,
     random true actions / reuse values (roots that select their true action skip the network for that simulation)"""

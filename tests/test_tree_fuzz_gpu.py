@@ -8,6 +8,9 @@ import pytest
 import tree_driver as td
 from test_tree_gpu import _dev_mod, _run_dev
 
+# LZ_FUZZ_SEED_OFFSET=n shifts every seeded sweep of this file to seeds n .. n + count - 1 (ad-hoc wider sweeps; the committed suite runs 0)
+_OFF = int(__import__("os").environ.get("LZ_FUZZ_SEED_OFFSET", "0"))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -21,7 +24,7 @@ def _case(seed):
                 scale=float(r.choice([1.0, 5.0, 0.1])), zero=bool(r.random() < 0.1))
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 48))
 def test_random_configuration_matches_the_oracle(seed):
     from oracle import ctree as octree
     case = _case(seed)
@@ -33,7 +36,7 @@ def test_random_configuration_matches_the_oracle(seed):
     assert np.array_equal(ora["minmax"].view(np.uint32), dev["minmax"].view(np.uint32)), "min/max stats differ: %r" % (case,)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 16))
 def test_random_reuse_configuration_matches_the_oracle(seed):
     """ReZero: batch_traverse_with_reuse / batch_backpropagate_with_reuse (some roots skip inference) on random configurations"""
     from oracle import ctree as octree
@@ -57,7 +60,7 @@ def test_random_reuse_configuration_matches_the_oracle(seed):
     assert dev["inferences"] == ora["inferences"]
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 16))
 def test_random_sampled_tree_configuration_matches_the_oracle(seed):
     """Sampled EfficientZero tree (continuous and discrete action spaces) with the oracle's draws injected"""
     import sampled_driver as sd
@@ -90,7 +93,7 @@ def test_random_sampled_tree_configuration_matches_the_oracle(seed):
     sd.assert_same(ora, dev, repr(case))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 16))
 def test_random_gumbel_tree_configuration_matches_the_oracle(seed):
     import gumbel_driver as gd
     from oracle import ctree as octree
@@ -98,8 +101,10 @@ def test_random_gumbel_tree_configuration_matches_the_oracle(seed):
     r = np.random.default_rng(8000 + seed)
     A = int(r.integers(2, 40))
     case = dict(B=int(r.integers(1, 40)), A=A, S=int(r.integers(1, 64)), m=int(r.integers(1, min(A, 16) + 1)), seed=400 + seed,
-                legal=[None, "fixture"][int(r.integers(0, 2))] if A == 9 else None, noise_w=[0.25, None][int(r.integers(0, 2))],
+                legal=[None, "random"][int(r.integers(0, 2))] if A == 9 else None, noise_w=[0.25, None][int(r.integers(0, 2))],
                 discount=float(r.choice([0.997, 1.0])), zero=bool(r.random() < 0.1))
+    if case["legal"] is None and seed % 3 == 1:
+        case["legal"] = "random"      # ragged legal lists on a third of the seeds (full lists otherwise)
     c = gd.make_inputs(case)
     dev = gd.run_tree(gdev(c), c)
     ora = gd.run_tree(octree.gmz_tree, c, roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
