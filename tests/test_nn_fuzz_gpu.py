@@ -115,3 +115,28 @@ def test_random_model_configuration_matches_the_torch_restatement(seed):
     except (L.LzError, ValueError, NotImplementedError) as e:
         assert len(str(e)) > 20, repr(e)
         pytest.skip("refused by the engine: %s" % e)
+
+
+def _sez_case(seed):
+    r = np.random.default_rng(4500 + seed)
+    hw, hid, A = int(r.choice([64, 96])), int(r.choice([32, 64, 128, 256])), int(r.integers(2, 19))
+    sup = SUPPORTS[int(r.integers(0, 2))]
+    kw = dict(observation_shape=(4, hw, hw), action_space_size=A, num_of_sampled_actions=int(r.integers(1, A + 1)), downsample=True,
+              continuous_action_space=False, norm_type='BN', num_res_blocks=int(r.integers(1, 4)), reward_support_range=sup, value_support_range=sup,
+              reward_head_hidden_channels=[hid], value_head_hidden_channels=[hid], policy_head_hidden_channels=[hid])
+    if r.random() < 0.5:
+        kw["activation"] = "relu"
+    return dict(family="sez", kw=kw, B=int(r.integers(1, 41)), seed=700 + seed)
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
+def test_random_conv_sampled_model_matches_the_torch_restatement(seed):
+    """the convolutional Sampled EfficientZero (round 4: GELU(tanh) / ReLU dynamics, GELU prediction network, head widths 32..256)"""
+    from oracle import torch_models as tm
+    case = _sez_case(seed)
+    model = tm.synthetic_init(nn_cases.oracle_class(tm, "sez")(**case["kw"]), seed=case["seed"]).eval()
+    g32 = _oracle_outputs(case, model)
+    cost = _fp32_cost(g32, _oracle_outputs(case, copy.deepcopy(model).double(), forced=g32))
+    bounds = {k: max(parity_record.BOUNDS[k], 3.0 * cost[k]) for k in cost}
+    print("fp32 cost of this network (torch fp32 vs binary64):", cost)
+    check_case("fuzz_sez%02d" % seed, case, g32, model.state_dict(), record="fuzz/", bounds=bounds)

@@ -269,3 +269,44 @@ def test_random_rezero_search_with_reuse_replays_exactly(seed):
     true_action = [int(l[r.integers(0, len(l))]) for l in legal]
     reuse_value = r.standard_normal(B).astype(np.float32).tolist()
     _reuse_replay(variant, model, roots, mcts, obs, legal, to_play, noises, S, disc, true_action, reuse_value)
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
+def test_random_conv_sampled_efficientzero_search_replays_exactly(seed):
+    """the convolutional Sampled EfficientZero (discrete actions on pixels, round 4): random batch / action / sample counts, both
+    observation shapes, GELU and ReLU dynamics, head widths 32..256, 1..3 residual blocks; the device's own draws replayed through the
+    oracle sampled tree (tests/test_exact_replay_families_gpu.py::test_conv_sampled_efficientzero_atari_config_replays_exactly)"""
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    from lightzero_amd.model.sampled_efficientzero_model import SampledEfficientZeroModel
+    from test_exact_replay_families_gpu import _sampled_replay
+    r = np.random.default_rng(1900 + seed)
+    B, S, A = int(r.integers(1, 200)), int(r.integers(1, 50)), int(r.integers(2, 19))
+    K = int(r.integers(1, A + 1))
+    hw, hid = int(r.choice([64, 96])), int(r.choice([32, 64, 128, 256]))
+    kw = dict(observation_shape=(4, hw, hw), action_space_size=A, num_of_sampled_actions=K, downsample=True, continuous_action_space=False,
+              norm_type='BN', num_res_blocks=int(r.integers(1, 4)), reward_head_hidden_channels=[hid], value_head_hidden_channels=[hid],
+              policy_head_hidden_channels=[hid])
+    if seed % 2:
+        kw["activation"] = "relu"
+    sup = [(-300., 301., 1.), (-50., 51., 1.)][int(r.integers(0, 2))]
+    kw.update(reward_support_range=sup, value_support_range=sup)
+    ref = tm.synthetic_init(tm.SampledEfficientZeroModel(**kw), seed=seed)
+    model = SampledEfficientZeroModel(**kw).load_state_dict(ref.state_dict())
+    cfg = dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5, root_noise_weight=0.25,
+               model=dict(action_space_size=A, num_of_sampled_actions=K, continuous_action_space=False))
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
+    roots.set_tiebreak(0, seed=5 + seed)
+    obs = torch.rand(B, 4, hw, hw, generator=torch.Generator().manual_seed(seed)).cuda().contiguous()
+    noises = r.dirichlet([0.3] * K, size=B).astype(np.float32)
+    out = model.initial_inference(obs, roots)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    node_actions = [roots.get_node_actions(e) for e in range(S + 1)]
+    assert all(np.isfinite(a).all() for a in node_actions)
+    ora, _ = _sampled_replay(model, roots, S, lambda e: node_actions[e], noises, [-1] * B, False, A_disc=A)
+    assert np.array_equal(ora["root_actions"].view(np.uint32), node_actions[0].view(np.uint32))
+    assert (np.asarray(roots.get_distributions()).sum(1) == S).all()
