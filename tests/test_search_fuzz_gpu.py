@@ -310,3 +310,18 @@ def test_random_conv_sampled_efficientzero_search_replays_exactly(seed):
     ora, _ = _sampled_replay(model, roots, S, lambda e: node_actions[e], noises, [-1] * B, False, A_disc=A)
     assert np.array_equal(ora["root_actions"].view(np.uint32), node_actions[0].view(np.uint32))
     assert (np.asarray(roots.get_distributions()).sum(1) == S).all()
+
+
+@pytest.mark.parametrize("B,S", [(3001, 12), (1, 120)])
+def test_batch_extremes_replay_exactly(B, S):
+    """far more roots than any shipped configuration (3,001: twelve workgroups per CU, a ragged last LSTM / head tile), and one root searched deep"""
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    r = np.random.default_rng(77)
+    A = 6
+    model = _ez_model(A, seed=3)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(5)).cuda().contiguous()
+    legal = [list(range(A))] * B
+    noises = [r.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=False)
