@@ -40,20 +40,23 @@ def record(test, worst, extra=None, bounds=None):
     """worst: {tensor class: worst |d| / (1 + |x|)}; merged (max) into this variant's JSON.  ``bounds``: a test that asserts other bounds
     than ``BOUNDS`` (the randomised model sweep ties them to what fp32 loses against binary64 on each network) records them with its
     entry; such entries are summarised separately (tools/refresh_profiles.py)"""
+    import fcntl
     path = _path()
-    try:
-        data = json.load(open(path))
-    except Exception:
-        data = {"variant": variant(), "unit": "max |device - reference| / (1 + |reference|)", "bounds": BOUNDS, "tests": {}}
-    ent = data["tests"].setdefault(test, {})
-    for k, v in worst.items():
-        ent[k] = max(float(v), float(ent.get(k, 0.0)))
-    if extra:
-        ent.update(extra)
-    if bounds:
-        ent["bounds"] = {k: float(v) for k, v in bounds.items()}
-    with open(path, "w") as f:
-        json.dump(data, f, indent=1, sort_keys=True)
+    with open(path + ".lock", "w") as lock:     # pytest-xdist workers share the variant's file: read-modify-write under a lock
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            data = json.load(open(path))
+        except Exception:
+            data = {"variant": variant(), "unit": "max |device - reference| / (1 + |reference|)", "bounds": BOUNDS, "tests": {}}
+        ent = data["tests"].setdefault(test, {})
+        for k, v in worst.items():
+            ent[k] = max(float(v), float(ent.get(k, 0.0)))
+        if extra:
+            ent.update(extra)
+        if bounds:
+            ent["bounds"] = {k: float(v) for k, v in bounds.items()}
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
 
 
 def check(test, worst, extra=None, bounds=None):
