@@ -61,35 +61,46 @@ def build(force=False, verbose=False, debug_knobs=False):
     hdrs.append(os.path.join(os.path.dirname(PKG), "include", "lz_mi355.h"))
     objs = []
     relink = force or not os.path.exists(LIB)
+
+    def compile_unit(src, extra, sp, op):
+        # -Rpass-analysis=kernel-resource-usage: per-kernel registers / scratch as compiler remarks.  A kernel that falls
+        # back to scratch memory (an array the optimiser could not keep in registers) costs a round trip per access on
+        # these latency-bound kernels and was once a silent 5 % regression: refuse it.
+        cmd = [HIPCC] + COMMON + dflags + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", op]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+        diag = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l and not re.match(r"^\s*(\d+ \|.*|\| +\^)\s*$", l))
+        if diag.strip():
+            sys.stderr.write(diag + "\n")
+        if res.returncode != 0:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
+        name = None
+        for line in res.stderr.splitlines():
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and int(m.group(1)) > 0 and not (debug_knobs and os.environ.get("LZ_BUILD_ALLOW_SCRATCH")):  # experiments with the timing instances only
+                os.remove(op)
+                raise RuntimeError("%s: kernel %s uses %s bytes of scratch per lane" % (src, name, m.group(1)))
+
+    stale = []
     for src, extra in UNITS:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
         op = sp[:-4] + osuffix
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
-            # -Rpass-analysis=kernel-resource-usage: per-kernel registers / scratch as compiler remarks.  A kernel that falls
-            # back to scratch memory (an array the optimiser could not keep in registers) costs a round trip per access on
-            # these latency-bound kernels and was once a silent 5 % regression: refuse it.
-            cmd = [HIPCC] + COMMON + dflags + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", op]
-            if verbose:
-                print(" ".join(cmd))
-            res = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
-            diag = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l and not re.match(r"^\s*(\d+ \|.*|\| +\^)\s*$", l))
-            if diag.strip():
-                sys.stderr.write(diag + "\n")
-            if res.returncode != 0:
-                raise subprocess.CalledProcessError(res.returncode, cmd)
-            name = None
-            for line in res.stderr.splitlines():
-                m = re.search(r"remark: Function Name: (\S+)", line)
-                if m:
-                    name = m.group(1)
-                m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-                if m and int(m.group(1)) > 0 and not (debug_knobs and os.environ.get("LZ_BUILD_ALLOW_SCRATCH")):  # experiments with the timing instances only
-                    os.remove(op)
-                    raise RuntimeError("%s: kernel %s uses %s bytes of scratch per lane" % (src, name, m.group(1)))
-            relink = True
+            stale.append((src, extra, sp, op))
         objs.append(op)
+    if stale:
+        # the translation units are independent: compile them side by side (lz_nn.hip alone is two thirds of a full build)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 1)) as ex:
+            for f in [ex.submit(compile_unit, *u) for u in stale]:
+                f.result()
+        relink = True
     if relink or any(_newer(o, LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:
