@@ -35,6 +35,34 @@ class HbmToken(object):
         return "<HBM-resident %s of %d roots>" % (self.what, self.roots.num)
 
 
+def unwrap_checkpoint(state_dict, which="model"):
+    """The weight-ingest format of the path: a LightZero checkpoint is the policy's learn-mode state
+    ``{'model': ..., 'target_model': ..., 'optimizer': ...}`` (lzero/policy/muzero.py:1043-1047, saved by DI-engine's learner with
+    ``last_iter`` etc. beside it).  Returns the bare reference-keyed state_dict of ``which`` ('model': the online network the collector
+    plays with; 'target_model': the one reanalyze uses); a bare state_dict passes through.  DistributedDataParallel's ``module.`` and
+    torch.compile's ``_orig_mod.`` key prefixes are stripped.  Anything else (a dict without tensors at its leaves) is refused."""
+    sd = state_dict
+    if isinstance(sd, dict) and which in sd and isinstance(sd[which], dict):
+        sd = sd[which]
+    elif isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict):
+        raise KeyError("checkpoint has no %r entry (keys: %s)" % (which, sorted(sd)))
+    if not hasattr(sd, "items"):
+        raise TypeError("state_dict must be a mapping of reference parameter names to tensors / arrays")
+    out = {}
+    for k, v in sd.items():
+        if isinstance(v, dict):
+            raise TypeError("state_dict entry %r is a dict: pass the checkpoint itself, or its 'model' entry" % (k,))
+        k2 = str(k)
+        stripped = True
+        while stripped:
+            stripped = False
+            for pre in ("module.", "_orig_mod."):
+                if k2.startswith(pre):
+                    k2, stripped = k2[len(pre):], True
+        out[k2] = v
+    return out
+
+
 class EfficientZeroModel(object):
     _model_type = 0  # lz_model_cfg.model_type
 
@@ -111,10 +139,12 @@ class EfficientZeroModel(object):
         return self._engine
 
     def load_state_dict(self, state_dict, strict=True):
-        """state_dict: reference key -> array-like (torch tensors or numpy), e.g. a LightZero checkpoint's ``model``.
+        """state_dict: reference key -> array-like (torch tensors or numpy), e.g. a LightZero checkpoint's ``model`` -- or the
+        checkpoint itself as ``torch.load`` returns it (see ``unwrap_checkpoint``).
         Calling it again on a loaded model is a weight refresh (collector after a learner update): tensors are overwritten in
         place on the device, roots and their captured search graphs stay valid."""
         self._check_owner()
+        state_dict = unwrap_checkpoint(state_dict)
         synced = False
         for name, value in state_dict.items():
             if name.endswith("num_batches_tracked"):

@@ -9,7 +9,7 @@ import numpy as np
 
 from .. import _lib as L
 from ..mcts.tree_search.mcts_ctree import EfficientZeroMCTSCtree as MCTSCtree
-from .utils import select_action
+from .utils import CheckpointIngest, select_action
 
 
 def _g(cfg, name, default=None):
@@ -38,7 +38,7 @@ class _HbmTokens(object):
         self.reward_hidden_state = ("hbm-pool", roots)
 
 
-class EfficientZeroPolicy(object):
+class EfficientZeroPolicy(CheckpointIngest):
     def __init__(self, cfg, model):
         """cfg: the reference policy config (dict / EasyDict-like): num_simulations, discount_factor,
         lstm_horizon_len, root_dirichlet_alpha, root_noise_weight, pb_c_base, pb_c_init, value_delta_max, ...

@@ -6,10 +6,10 @@ import numpy as np
 from .. import _lib as L
 from ..mcts.tree_search.mcts_ctree import GumbelMuZeroMCTSCtree as MCTSCtree
 from .efficientzero import _g, _mcts_seed
-from .utils import select_action
+from .utils import CheckpointIngest, select_action
 
 
-class GumbelMuZeroPolicy(object):
+class GumbelMuZeroPolicy(CheckpointIngest):
     def __init__(self, cfg, model):
         self._cfg = cfg
         self._collect_model = model

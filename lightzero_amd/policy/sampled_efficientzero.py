@@ -10,10 +10,10 @@ import numpy as np
 from .. import _lib as L
 from ..mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree as MCTSCtree, _inverse_scalar_transform
 from .efficientzero import _g, _mcts_seed
-from .utils import select_action
+from .utils import CheckpointIngest, select_action
 
 
-class SampledEfficientZeroPolicy(object):
+class SampledEfficientZeroPolicy(CheckpointIngest):
     def __init__(self, cfg, model):
         self._cfg = cfg
         self._collect_model = model
