@@ -72,9 +72,10 @@ class EfficientZeroModel(object):
                  reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
                  categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
                  engine=None, fast_mode=False, **kwargs):
-        """``fast_mode=True`` (not a reference argument): lz_model_cfg.precision = 1 -- the recurrent chain's 3x3 convolutions and the LSTM
-        gate product on bf16 MFMA (fp32 accumulation, fp32 everything else); statistical parity only, reported separately from the
-        parity-mode numbers (last arm).  EfficientZeroModel, 6x6x64 latent."""
+        """``fast_mode=True`` (not a reference argument): lz_model_cfg.precision = 1 -- the 3x3 convolutions of the representation tower and
+        of the recurrent chain and the LSTM gate product on bf16 MFMA (fp32 accumulation; heads, h^-1 and the tree unchanged); statistical
+        parity only, reported separately from the parity-mode numbers (last arm).  EfficientZeroModel /
+        MuZeroModel on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64) observations."""
         if not 1 <= int(num_res_blocks) <= 3 or norm_type != 'BN' or not categorical_distribution \
                 or discrete_action_encoding_type not in ('one_hot', 'not_one_hot'):
             raise NotImplementedError("engine model: num_res_blocks in 1..3, norm_type='BN', categorical_distribution=True, "
