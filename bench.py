@@ -39,7 +39,7 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 /
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense peak (the --fast arm)
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
-MANIFEST = "r04_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
+MANIFEST = "r05_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
 
 
 def _profile_manifest():
@@ -173,18 +173,19 @@ def policy_surface(model, obs, steps=10):
     return ENVS * steps / (time.perf_counter() - t0)
 
 
-def fast_mode_arm(weights, obs, steps, warmup, seed=7):
-    """The FAST MODE arm beside the parity-mode headline (last arm): the same step -- initial inference, device
-    Dirichlet noise + prepare, 50 simulations, select_action + row packing, header read-back -- on EfficientZeroModel(fast_mode=True)
-    (bf16 MFMA products, fp32 accumulation; statistical parity only, tests/test_fast_mode_gpu.py).  A separate number, never `value`."""
+def search_arm(weights, obs_list, steps, warmup, fast=False, seed=7, stamps=True):
+    """One secondary arm: the headline's step -- initial inference, device Dirichlet noise + prepare, 50 simulations, select_action + row
+    packing, header read-back -- on a model of its own (own engine) carrying ``weights``; observations cycle through ``obs_list``.
+    Returns env-steps/s, the search-path depths of the last timed step (lz_roots_get_node_depths: depth of the node each simulation
+    expanded == that simulation's search length) and, with ``stamps``, the launch periods from the in-graph s_memrealtime stamps."""
     import torch
     from lightzero_amd import _lib as L, shard
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
     lib = L.lib()
     eng = L.new_engine(int(os.environ.get("LOCAL_RANK", "0")))
-    model = EfficientZeroModel(action_space_size=ACTIONS, engine=eng, fast_mode=True).load_state_dict(weights)
-    n = obs.shape[0]
+    model = EfficientZeroModel(action_space_size=ACTIONS, engine=eng, fast_mode=fast).load_state_dict(weights)
+    n = obs_list[0].shape[0]
     roots = ez_tree.Roots(n, [list(range(ACTIONS))] * n, action_space_size=ACTIONS, max_simulations=SIMS, engine=eng)
     roots.set_tiebreak(1, seed=seed)
     roots._ensure(ACTIONS)
@@ -195,26 +196,226 @@ def fast_mode_arm(weights, obs, steps, warmup, seed=7):
     torch.cuda.synchronize()
 
     def one(i):
-        L.check(lib.lz_initial_inference(roots._h, obs.data_ptr()))
+        L.check(lib.lz_initial_inference(roots._h, obs_list[i % len(obs_list)].data_ptr()))
         L.check(lib.lz_roots_prepare_from_inference_dirichlet(roots._h, CFG["root_noise_weight"], CFG["root_dirichlet_alpha"], to_play))
         L.check(lib.lz_search(roots._h, SIMS, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], CFG["lstm_horizon_len"], CFG["value_delta_max"]))
         timestep[:] = i
         h = np.zeros((n, HW), np.float32); lg = np.zeros((n, ACTIONS), np.float32)
         L.check(lib.lz_roots_collect_rows(roots._h, 1.0, 0, (i * 1315423911 + 5) & (2 ** 62 - 1), None, FRAME, timestep.ctypes.data, rows.data_ptr(), W, h, lg.ctypes.data))
-        return h
+        return h, lg
     for i in range(warmup):
         one(i)
     L.check(lib.lz_engine_synchronize(eng))
     t0 = time.perf_counter()
     for i in range(steps):
-        h = one(warmup + i)
+        h, lg = one(warmup + i)
     L.check(lib.lz_engine_synchronize(eng))
     dt = time.perf_counter() - t0
     assert (np.array(roots.get_distributions()).sum(1) == SIMS).all()
-    return dict(env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3, steps=steps, warmup=warmup, dtype="bf16 products, f32 accumulation",
-                note="FAST MODE arm (EfficientZeroModel(fast_mode=True)): representation tower, recurrent chain and LSTM gate product on bf16 MFMA "
-                     "(k_conv_bf, k_chain_b, k_lstm_b); heads, normalisation, cell and tree in fp32; statistical parity only -- reported "
-                     "separately from the parity-mode `value` (BASELINE.md section 2, last arm)")
+    out = dict(env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3, steps=steps, warmup=warmup)
+    out.update(_depth_stats(lib, L, roots, n))
+    e = np.exp(lg - lg.max(1, keepdims=True))
+    out["root_prior_max_prob_mean"] = float((e / e.sum(1, keepdims=True)).max(1).mean())   # before the Dirichlet noise
+    if stamps:
+        try:
+            out.update(_stamp_periods(lib, L, roots, eng, one, warmup, 3))
+        except Exception as ex:
+            out["stamps_error"] = repr(ex)
+    return out
+
+
+def _depth_stats(lib, L, roots, n):
+    """search-path depth (== CSearchResults::search_lens of every simulation) of the search the roots hold"""
+    d = np.zeros((n, SIMS), np.int32)
+    L.check(lib.lz_roots_get_node_depths(roots._h, SIMS, d.reshape(-1)))
+    return dict(search_depth_mean=float(d.mean()), search_depth_max=int(d.max()), search_depth_last10_mean=float(d[:, -10:].mean()),
+                search_depth_hist=np.bincount(d.reshape(-1), minlength=1).tolist())
+
+
+def _stamp_periods(lib, L, roots, eng, one, first_step, nsteps):
+    """launch periods of the graph-replayed search from the in-graph s_memrealtime stamps (lz_roots_enable_stamps): the search graph is
+    re-captured with the stamp pointers, `nsteps` steps are replayed after two warm-ups"""
+    L.check(lib.lz_roots_enable_stamps(roots._h, 1))
+    per, lper = [], []
+    st = np.zeros((SIMS, 4), np.uint64)
+    for i in range(2 + nsteps):
+        one(first_step + i)
+        L.check(lib.lz_engine_synchronize(eng))
+        if i < 2:
+            continue
+        L.check(lib.lz_roots_read_stamps(roots._h, SIMS, st))
+        t = st.astype(np.int64) * 10e-3   # microseconds
+        per.append(t[1:SIMS - 1, 2] - t[1:SIMS - 1, 0]); lper.append(t[2:SIMS, 0] - t[1:SIMS - 1, 2])
+    L.check(lib.lz_roots_enable_stamps(roots._h, 0))
+    per, lper = np.concatenate(per), np.concatenate(lper)
+    return dict(chain_period_us=float(per.mean()), lstm_period_us=float(lper.mean()), per_simulation_us=float(per.mean() + lper.mean()))
+
+
+def fast_mode_arm(weights, obs_list, steps, warmup):
+    """The FAST MODE arm beside the parity-mode headline (last arm): the same step on
+    EfficientZeroModel(fast_mode=True) (bf16 MFMA products, fp32 accumulation; statistical parity only, tests/test_fast_mode_gpu.py).
+    A separate number, never `value`."""
+    out = search_arm(weights, obs_list, steps, warmup, fast=True)
+    out.update(dtype="bf16 products, f32 accumulation",
+               note="FAST MODE arm (EfficientZeroModel(fast_mode=True)): representation tower, recurrent chain and LSTM gate product on bf16 MFMA "
+                    "(k_conv_bf, k_chain_b, k_lstm_b); heads, normalisation, cell and tree in fp32; statistical parity only -- reported "
+                    "separately from the parity-mode `value` (BASELINE.md section 2, last arm)")
+    return out
+
+
+def depth_sweep(weights, obs_list, steps, warmup, scales=(1, 4, 10)):
+    """the section-8d recipe (head layers drawn at N(0, 0.05)) gives near-uniform root priors and the shallowest trees 50
+    simulations can build; a trained agent's prior is sharp and its search paths are deeper.  The same step with the policy head's
+    and the value head's last layer scaled (lightzero_amd.model.synthetic.sharpen_state_dict): env-steps/s, search-path depth, and the
+    chain launch's period (the tree step is that launch's prologue) per scale.  `value` stays on scale 1 = the 8d recipe."""
+    from lightzero_amd.model.synthetic import sharpen_state_dict
+    arms = {}
+    for sc in scales:
+        try:
+            arms[str(sc)] = search_arm(sharpen_state_dict(weights, float(sc)), obs_list, steps, warmup)
+        except Exception as e:   # a secondary arm never takes the measured line down with it
+            arms[str(sc)] = {"error": repr(e)}
+    base = arms.get("1", {}).get("env_steps_per_s")
+    for sc, a in arms.items():
+        if base and "env_steps_per_s" in a:
+            a["vs_scale_1"] = a["env_steps_per_s"] / base
+    return dict(arms=arms, scaled="prediction_network.fc_policy.3 and fc_value.3 (weight and bias) x scale",
+                note="scale 1 = SURVEY 8d's recipe (what `value` is measured on); each arm is the headline's step on its own engine, "
+                     "%d timed steps after %d warm-ups, stochastic tie-break, device-side Dirichlet noise" % (steps, warmup))
+
+
+def weight_refresh(model, weights, roots, step, first_step, reps=10):
+    """What ONE weight refresh of a collector costs (in the reference the collector searches with the learner's own
+    nn.Module, lzero/policy/muzero.py:1049-1061 -- fresh weights are free there): model.load_state_dict of the full EfficientZero Atari
+    state_dict on an engine with live roots and a captured search graph -- (a) from host arrays, as a checkpoint arrives, (b) from
+    device tensors, as shard.broadcast_state_dict(on_device=True) hands them over.  Wall time of the call plus the engine
+    synchronisation behind it, median of `reps`; then one step to show the roots are still live."""
+    import torch
+    from lightzero_amd import _lib as L
+    lib = L.lib()
+    eng = model.engine
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in weights.items()}
+    torch.cuda.synchronize()
+    out = {}
+    for key, sd in (("weight_refresh_ms", weights), ("weight_refresh_device_ms", dev)):
+        ts = []
+        for _ in range(reps):
+            L.check(lib.lz_engine_synchronize(eng))
+            t0 = time.perf_counter()
+            model.load_state_dict(sd)
+            L.check(lib.lz_engine_synchronize(eng))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[key] = float(np.median(ts))
+        out[key + "_min_max"] = [float(min(ts)), float(max(ts))]
+    step(first_step)   # the same roots, the same captured graph
+    L.check(lib.lz_engine_synchronize(eng))
+    out["weight_refresh_note"] = ("one model.load_state_dict of the %d-tensor EfficientZero Atari state_dict (%.1f MB) on an engine with live roots: "
+                                  "host arrays / device tensors; median of %d" % (len(weights), sum(v.size for v in weights.values()) * 4 / 1e6, reps))
+    return out
+
+
+def collector_surface(model, n_warm_eps=ENVS, n_eps=ENVS + ENVS // 2):
+    """env-steps/s through lightzero_amd.worker.MuZeroVectorCollector.collect: the collect loop of muzero_collector.py
+    :416-760 -- policy rows, env.step, segment bookkeeping, rollover / pool, device-resident frame stack -- over a synthetic vector env
+    (frames from a pre-generated pool, episodes of ~150 steps), while every env is active."""
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    from lightzero_amd.worker import MuZeroVectorCollector
+    B, A = ENVS, ACTIONS
+
+    class _Env:
+        def __init__(self):
+            self.env_num, self.rng, self.k = B, np.random.default_rng(0), 0
+            self.pool = [np.random.default_rng(i).random((B, 1, 96, 96), dtype=np.float32) for i in range(4)]
+            self.mask, self.tp = np.ones((B, A), np.float32), np.full(B, -1)
+
+        def _obs(self):
+            self.k += 1
+            return dict(observation=self.pool[self.k % 4], action_mask=self.mask, to_play=self.tp)
+
+        def reset(self):
+            return self._obs()
+
+        def step(self, actions, active):
+            done = (self.rng.random(B) < 1.0 / 150) & active
+            return self._obs(), np.zeros(B, np.float32), done, dict(reset_obs=self._obs(), eval_episode_return=np.zeros(B))
+    ccfg = dict(CFG, game_segment_length=400, num_unroll_steps=5, td_steps=5, model=dict(frame_stack_num=4, action_space_size=A))
+    col = MuZeroVectorCollector(_Env(), EfficientZeroPolicy(ccfg, model), ccfg, device="cuda")
+    col.collect(n_episode=n_warm_eps)          # warm-up: handles, graphs
+    t0 = time.perf_counter()
+    l0 = col.total_loop_steps
+    col.collect(n_episode=n_eps)
+    dt = time.perf_counter() - t0
+    return B * (col.total_loop_steps - l0) / dt
+
+
+def _cpu_worker(spec):
+    """one process of the whole-host CPU arm: `idx,nproc,threads,batches` -- this process's contiguous block of the 256 envs, the
+    reference pipeline at `threads` torch threads, pinned to its own cores; protocol on stdout / stdin: READY -> go -> one line of JSON"""
+    import torch
+    idx, nproc, threads, batches = (int(x) for x in spec.split(","))
+    try:
+        ncpu = os.cpu_count() or 1
+        cores = [c for c in range(idx * threads, (idx + 1) * threads) if c < ncpu]
+        if cores:
+            os.sched_setaffinity(0, cores)
+    except Exception:
+        pass
+    torch.set_num_threads(threads)
+    from lightzero_amd.model.synthetic import efficientzero_state_dict
+    weights = efficientzero_state_dict(seed=0, action_space_size=ACTIONS)
+    g = torch.Generator().manual_seed(1000)
+    obs = torch.rand(ENVS, 4, 96, 96, generator=g)
+    lo, hi = idx * ENVS // nproc, (idx + 1) * ENVS // nproc
+    sub = obs[lo:hi].contiguous()
+    noises = [z.tolist() for z in np.random.default_rng(idx).dirichlet([CFG["root_dirichlet_alpha"]] * ACTIONS, size=hi - lo).astype(np.float32)]
+    run, kind_tree = _baseline_pipeline(weights, "cpu")
+    run(sub[:4], noises)          # warm-up
+    sys.stdout.write("READY\n"); sys.stdout.flush()
+    sys.stdin.readline()
+    t0 = time.time()
+    for _ in range(batches):
+        run(sub, noises)
+    t1 = time.time()
+    sys.stdout.write(json.dumps(dict(idx=idx, envs=hi - lo, t0=t0, t1=t1, kind_tree=kind_tree)) + "\n"); sys.stdout.flush()
+
+
+def cpu_baseline_whole_host(threads, rank, batches=3, budget_s=120.0):
+    """The same reference pipeline with ALL physical cores busy: N = host_cores // threads processes (threads = the torch
+    thread count that won cpu_baseline's sweep), each pinned to its own `threads` cores and running the pipeline on its contiguous block
+    of the 256 envs; all start together after their warm-ups; value = 256 envs x batches / (latest end - earliest start)."""
+    phys, thr = host_cores()
+    nproc = max(1, min(phys // max(threads, 1), ENVS // 4))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d,%d" % (i, nproc, threads, batches)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True,
+                              env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+             for i in range(nproc)]
+    try:
+        deadline = time.time() + budget_s
+        for p in procs:
+            line = p.stdout.readline()
+            if line.strip() != "READY" or time.time() > deadline:
+                raise RuntimeError("worker did not come up: %r" % line)
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                p.kill()
+    span = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+    envs = sum(r["envs"] for r in res)
+    return dict(value=envs * batches / span, unit="env-steps/s", cores=nproc * threads, processes=nproc, threads_per_process=threads,
+                host_cores=phys, host_threads=thr, kind="port", batches=batches, span_s=span,
+                per_process_s=[round(r["t1"] - r["t0"], 3) for r in res],
+                sample="%d processes x %d torch threads (each pinned to its own cores) x %d batches of its %d-env block of the 256 envs x 50 sims; "
+                       "%s + restated driver + torch fp32 model; all processes start together; value = envs x batches / (latest end - earliest start)"
+                       % (nproc, threads, batches, ENVS // nproc, res[0]["kind_tree"]))
 
 
 def _free_port():
@@ -244,6 +445,9 @@ def main():
     ap.add_argument("--noise", choices=["device", "host"], default="device",
                     help="device = Dirichlet root noise drawn by a kernel inside the step (north_star); host = np.random.dirichlet "
                          "inside the step + upload, like efficientzero.py:599-602")
+    ap.add_argument("--obs-batches", type=int, default=4, help="distinct synthetic observation batches in HBM, cycled by step")
+    ap.add_argument("--no-depth-sweep", action="store_true", help="skip the prior-sharpness arms (config.depth_sweep)")
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: one process of the whole-host CPU arm
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra steps after the timed region for config.sustained_env_steps_per_s")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for every step's all-gather instead of overlapping it with the next search")
     ap.add_argument("--total-envs", type=int, default=0,
@@ -258,6 +462,9 @@ def main():
                          "collective kernel holding even one CU during it costs that launch a second round; 'none' = no ordering")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region: every rank verifies the pooled rows block by block")
     args = ap.parse_args()
+    if args.cpu_worker:
+        _cpu_worker(args.cpu_worker)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
@@ -313,8 +520,13 @@ def main():
         models.append(EfficientZeroModel(action_space_size=ACTIONS, engine=e, fast_mode=args.fast).load_state_dict(weights))
     eng = engs[0]
     g = torch.Generator().manual_seed(1000 + rank)
-    obs_cpu = torch.rand(ENVS, 4, 96, 96, generator=g)
-    obs = obs_cpu.cuda().contiguous()
+    # NOBS distinct observation batches, resident in HBM, cycled by step: no step searches the batch the previous one searched
+    # (one tensor fed to every step); batch 0 is also what the CPU baselines run on
+    NOBS = max(1, args.obs_batches)
+    obs_pool_cpu = [torch.rand(ENVS, 4, 96, 96, generator=g) for _ in range(NOBS)]
+    obs_cpu = obs_pool_cpu[0]
+    obs_pool = [o.cuda().contiguous() for o in obs_pool_cpu]
+    obs = obs_pool[0]
     rng = np.random.default_rng(rank)
     total = args.warmup + args.steps
     legal = [list(range(ACTIONS))] * EPS
@@ -325,7 +537,7 @@ def main():
         r._ensure(ACTIONS)
         roots_l.append(r)
     to_play = L.i32([-1] * EPS)
-    obs_parts = [obs[k * EPS:(k + 1) * EPS].contiguous() for k in range(NS)]
+    obs_parts = [[o[k * EPS:(k + 1) * EPS].contiguous() for o in obs_pool] for k in range(NS)]
     W = shard.row_width(ACTIONS, FRAME)
     HW = shard.HEADER + 2 * ACTIONS
     # double-buffered: step i's all-gather reads one.  Uneven blocks (strong scaling): every buffer has the largest block's rows, the
@@ -349,7 +561,7 @@ def main():
             torch.cuda.current_stream().synchronize()
             pending[buf] = None
         for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
-            L.check(lib.lz_initial_inference(r._h, obs_parts[k].data_ptr()))
+            L.check(lib.lz_initial_inference(r._h, obs_parts[k][i % NOBS].data_ptr()))
             if fence_mode == "tower" and pending[buf ^ 1] is not None:
                 # the previous step's all-gather has had the tower to itself (thousands of workgroups: a few CUs less cost it a per
                 # cent); the search -- 256 workgroups that each need a whole CU -- starts behind it
@@ -423,6 +635,7 @@ def main():
     dist_chk = np.zeros((EPS, ACTIONS), np.int32); cnt_chk = np.zeros(EPS, np.int32)
     L.check(lib.lz_roots_get_distributions(roots_l[0]._h, dist_chk, cnt_chk))
     assert (dist_chk.sum(1) == SIMS).all(), "search did not run all simulations"
+    depth_main = _depth_stats(lib, L, roots_l[0], EPS)   # the trees of the LAST TIMED step (sub-batch 0)
     gather_check = None
     if args.check_gather and dist_on:
         # every rank: the pooled rows of the last step, block q, must be rank q's own rows (exchanged once more, as float64 checksums
@@ -587,19 +800,39 @@ def main():
             for k in ("traffic", "achieved_profiled", "frac_profile", "avg_launch_us_profile"):
                 rf[k] = None
             rf["traffic_unit"] = rf["profile"] = "fast mode: no committed PMC / rocprofv3 pass"
+        out["config"].update(search_depth_mean=depth_main["search_depth_mean"], search_depth_max=depth_main["search_depth_max"],
+                             search_depth_last10_mean=depth_main["search_depth_last10_mean"], search_depth_hist=depth_main["search_depth_hist"],
+                             search_depth_note="depth of the node each of the 50 simulations expanded (== its search-path length), all roots of "
+                                               "the last timed step; observations: %d distinct batches cycled by step" % NOBS,
+                             obs_batches=NOBS)
         if world == 1 and not args.fast and NS == 1:
             try:
-                out["fast_mode"] = fast_mode_arm(weights, obs, args.steps, args.warmup)
+                out["fast_mode"] = fast_mode_arm(weights, obs_pool, args.steps, args.warmup)
             except Exception as e:   # a secondary arm never takes the measured line down with it
                 out["fast_mode"] = {"error": repr(e)}
+            if not args.no_depth_sweep:
+                out["config"]["depth_sweep"] = depth_sweep(weights, obs_pool, args.steps, args.warmup)
+            try:
+                out["config"].update(weight_refresh(models[0], weights, roots_l[0], step, args.warmup))
+            except Exception as e:
+                out["config"]["weight_refresh_ms"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["config"]["policy_surface_env_steps_per_s"] = policy_surface(models[0], obs)
             except Exception as e:
                 out["config"]["policy_surface_env_steps_per_s"] = repr(e)
+            try:
+                out["config"]["collector_env_steps_per_s"] = collector_surface(models[0])
+            except Exception as e:
+                out["config"]["collector_env_steps_per_s"] = repr(e)
             noises0 = [z.tolist() for z in rng.dirichlet([CFG["root_dirichlet_alpha"]] * ACTIONS, size=ENVS).astype(np.float32)]
             out["cpu_baseline"] = cpu_baseline(weights, obs_cpu, noises0)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            try:
+                out["cpu_baseline_whole_host"] = cpu_baseline_whole_host(out["cpu_baseline"]["cores"], rank)
+                out["config"]["speedup_vs_cpu_baseline_whole_host"] = value / out["cpu_baseline_whole_host"]["value"]
+            except Exception as e:
+                out["cpu_baseline_whole_host"] = {"error": repr(e)}
             try:
                 out["deployed_baseline"] = deployed_baseline(weights, obs_cpu, noises0)
                 out["config"]["speedup_vs_deployed_baseline_min_median_max"] = [value / x for x in out["deployed_baseline"]["env_steps_per_s_min_median_max"][::-1]]

@@ -358,6 +358,11 @@ int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float pb_c_init, 
  * kernels also write their support-wide logits (lz_roots_read_debug_logits); on & 2: head debug buffers too (lz_roots_read_head_debug) */
 int lz_roots_enable_trace(lz_roots *r, int on);
 int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_out /* [S][B][4] ix, action, search_len, to_play */);
+/* depth in its tree of the node every simulation expanded == that simulation's search-path length (CSearchResults::search_lens,
+ * cnode.h:66-80, which the reference keeps for the latest simulation only): h_out [root_num][num_simulations], node s + 1 of root i
+ * at h_out[i * num_simulations + s].  Valid after a search of the EfficientZero / MuZero tree (not the sampled / Gumbel trees);
+ * no tracing needed -- the depths are part of the node records (lz_tree_dev::node_link).  bench.py reports their mean / max. */
+int lz_roots_get_node_depths(lz_roots *r, int num_simulations, int32_t *h_out);
 int lz_roots_read_sim_outputs(lz_roots *r, int slot, float *h_value_prefix, float *h_value, float *h_policy_logits);
 int lz_roots_read_latent(lz_roots *r, int slot, float *h_out_nchw);
 int lz_roots_read_hidden(lz_roots *r, int slot, float *h_h, float *h_c);

@@ -107,6 +107,7 @@ def lib():
         "lz_roots_enable_trace": [P, ctypes.c_int],
         "lz_roots_read_trace": [P, ctypes.c_int, c_i32p],
         "lz_roots_read_sim_outputs": [P, ctypes.c_int, c_f32p, c_f32p, c_f32p],
+        "lz_roots_get_node_depths": [P, ctypes.c_int, c_i32p],
         "lz_roots_read_latent": [P, ctypes.c_int, c_f32p],
         "lz_roots_read_hidden": [P, ctypes.c_int, c_f32p, c_f32p],
         "lz_roots_read_debug_logits": [P, ctypes.c_int, c_f32p],
@@ -197,7 +198,9 @@ def process_seed():
     lock-step)."""
     import hashlib
     rank = int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")))
-    st = np.random.get_state()
+    # the calling thread's own stream when it has installed one (random_source: the pipelined collector's env groups) -- the global
+    # stream is advanced by whichever thread steps the other group's envs, so hashing IT would make the seed depend on thread timing
+    st = rs().get_state()
     h = hashlib.blake2b(digest_size=8)
     h.update(np.asarray(st[1]).tobytes())
     h.update(np.asarray([st[2], _seed_counter[0]], np.int64).tobytes())

@@ -90,6 +90,8 @@ struct lz_tree_dev {
     float *gumbel;              // [A]         gumbel_scale * extreme_value(mt19937(0)): the same prefix for every node (cnode.cpp:86-89)
     int32_t *considered;        // [NN]        get_sequence_of_considered_visits(min(m, S), S) of the current search
     int32_t *node_bidx;         // [B][NN]     CNode::batch_index (== b except under ReZero's packed inference batches)
+    uint64_t *node_link;        // [B][NN]     parent node | action at the parent | depth of every expanded node (lz_link_pack; root 0):
+                                //             lets every node of a tree be scored at once (dev_traverse_par)
     int32_t *res_noinf;         // [B]         ReZero: the last traverse ended on an already expanded node (reference index -1)
     // Sampled EfficientZero (variant 2, continuous actions): A == K sampled actions per node
     int D;                      // action dimension
@@ -190,6 +192,8 @@ struct lz_traverse_args {
     uint64_t seed;
     uint32_t counter;
     int fresh_minmax = 0;      // k_traverse only: the first selection of a search starts a fresh CMinMaxStats (cminimax.cpp:6-10) itself
+    int serial = 0;            // 1 (LZ_TRAVERSE_SERIAL): the LDS tree step walks level by level (dev_traverse) even where the
+                               // tree-parallel selection (dev_traverse_par) applies -- A/B runs and the bit-identity test
     unsigned long long *dbg_ts = nullptr;  // timing experiments (debug build, LZ_DEBUG_TREE_SEP_TS): [64 roots][8] cycle stamps of k_backprop_traverse
 };
 // one expand + backup + next-selection step for every root (dev_step_lds in lz_tree_dev.h), as run by k_backprop_traverse_lds

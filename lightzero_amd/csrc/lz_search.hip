@@ -101,6 +101,10 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->num_of_sampled_actions == 0 || (conv_sampled && cfg->num_of_sampled_actions <= 64 && cfg->downsample && cfg->obs_c == 4 && cfg->num_channels == 64),
                "num_of_sampled_actions on a conv model = SampledEfficientZeroModel (conv): EfficientZero network + sampled tree, discrete actions, K in [1, 64], 4-channel downsampled observations");
     LZ_REQUIRE(cfg->activation == 0 || conv_sampled, "conv models: GELU (activation 1) exists for the convolutional Sampled EfficientZero only");
+    // the value-prefix LSTM applies GELU behind its BatchNorm in two instances only (6x6 and 8x8 latents, hidden 512): any other shape would
+    // silently compute relu(bn(h')) where the reference's DynamicsNetwork computes GELU
+    LZ_REQUIRE(!(conv_sampled && cfg->activation == 1) || cfg->lstm_hidden_size == 512,
+               "conv Sampled EfficientZero with GELU: lstm_hidden_size must be 512 (the value-prefix LSTM's GELU instances)");
     LZ_REQUIRE(cfg->head_channels == 16 && cfg->head_hidden >= 1 && (cfg->head_hidden <= 32 || (conv_sampled && cfg->head_hidden <= 256 && cfg->head_hidden % 16 == 0)),
                "head_channels must be 16 and head_hidden at most 32 (conv Sampled EfficientZero: a multiple of 16 up to 256)");
     LZ_REQUIRE(cfg->model_type == 1 || (cfg->lstm_hidden_size % 64 == 0 && cfg->lstm_hidden_size > 0), "lstm_hidden_size must be a multiple of 64");
@@ -1673,7 +1677,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
 static uint64_t graph_knobs()
 {
     uint64_t knobs = 0;
-    const char *names[] = {"LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256",
+    const char *names[] = {"LZ_TRAVERSE_SERIAL", "LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256",
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
@@ -1729,6 +1733,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     lz_traverse_args ta;
     ta.pb_c_base = pb_c_base; ta.pb_c_init = pb_c_init; ta.discount = discount_factor; ta.players = r->players;
     ta.tiebreak = r->tiebreak; ta.seed = r->seed; ta.counter = 0;
+    ta.serial = getenv("LZ_TRAVERSE_SERIAL") ? 1 : 0;
     const bool use_graph = !r->eng->prof_on && !getenv("LZ_NO_GRAPH");
     if (!use_graph) {
         enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
@@ -1919,6 +1924,22 @@ extern "C" int lz_roots_read_trace(lz_roots *r, int num_simulations, int32_t *h_
             int32_t *o = h_out + ((size_t)sim * B + b) * 4;
             o[0] = p[b]; o[1] = p[2 * B + b]; o[2] = p[3 * B + b]; o[3] = p[4 * B + b];
         }
+    return LZ_OK;
+}
+
+extern "C" int lz_roots_get_node_depths(lz_roots *r, int num_simulations, int32_t *h_out)
+{
+    LZ_REQUIRE(r != nullptr && h_out != nullptr, "NULL argument");
+    LZ_REQUIRE(num_simulations >= 1 && num_simulations < r->t.NN, "num_simulations out of range");
+    LZ_REQUIRE(r->t.variant == LZ_TREE_EFFICIENTZERO || r->t.variant == LZ_TREE_MUZERO, "node depths are kept by the EfficientZero / MuZero tree only");
+    const size_t B = r->t.B, NN = r->t.NN;
+    std::vector<uint64_t> tmp(B * NN);
+    hipStream_t s = r->eng->stream;
+    LZ_HIP_CHECK(hipMemcpyAsync(tmp.data(), r->t.node_link, tmp.size() * 8, hipMemcpyDeviceToHost, s));
+    LZ_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; ++b)
+        for (int sim = 0; sim < num_simulations; ++sim)
+            h_out[b * num_simulations + sim] = (int32_t)(tmp[b * NN + sim + 1] & 0xffffffull);
     return LZ_OK;
 }
 

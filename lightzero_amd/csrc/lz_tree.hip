@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void k_prepare(lz_tree_dev t, float noise_w, co
         t.node_to_play[o] = to_play[b];
         t.node_best[o] = -1;
         t.node_bidx[o] = b;   // CNode::batch_index of the root (cnode.cpp:334)
+        t.node_link[o] = 0;   // the root: no parent, depth 0
         t.root_visit[b] = 1;  // visit_count += 1 (cnode.cpp:341)
         t.root_vsum[b] = 0.0f;
         // every prepare starts a new env-step: the random streams keyed by the epoch (stochastic tie-breaks, device-side Dirichlet

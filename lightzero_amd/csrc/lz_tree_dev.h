@@ -15,7 +15,14 @@
 #define LZ_FLOAT_MIN (-LZ_FLOAT_MAX)
 
 // bytes of the staged arrays of dev_step_lds for `idx` + 1 nodes, rounded up to 16
-__host__ __device__ static inline size_t lz_tree_lds_bytes_raw(int A, int idx) { return (((size_t)(idx + 1) * ((size_t)A * 20 + 20)) + 15) / 16 * 16; }
+__host__ __device__ static inline size_t lz_tree_lds_bytes_raw(int A, int idx) { return (((size_t)(idx + 1) * ((size_t)A * 20 + 28)) + 15) / 16 * 16; }
+
+// lz_tree_dev::node_link: how an expanded node hangs in its tree -- parent node (24 bits) | action at the parent (16 bits) | depth (24 bits;
+// root = 0).  Written once when the node is expanded; the tree-parallel selection (dev_traverse_par) reads it.
+__host__ __device__ static inline uint64_t lz_link_pack(int parent, int act, int depth)
+{
+    return ((uint64_t)(uint32_t)parent << 40) | ((uint64_t)((uint32_t)act & 0xffffu) << 24) | (uint64_t)((uint32_t)depth & 0xffffffu);
+}
 
 namespace {
 
@@ -57,6 +64,7 @@ struct tview {
     float *node_vp;          // [NN]
     int32_t *node_reset, *node_to_play;
     const int32_t *path_node, *path_act;  // [NN] path of the previous traverse (read by the backup)
+    uint64_t *link;          // [NN] LDS copy of node_link (null on the HBM view: dev_backprop then writes the HBM array only)
     float4 *g_edge;          // write-through targets in HBM (WT instantiation), same indexing
     int32_t *g_child;
     float *g_node_vp;
@@ -85,6 +93,7 @@ __device__ __forceinline__ tview global_view(const lz_tree_dev &t, int b)
     v.node_to_play = v.g_node_to_play = t.node_to_play + n;
     v.path_node = t.path_node + n;
     v.path_act = t.path_act + n;
+    v.link = nullptr;
     return v;
 }
 
@@ -286,6 +295,180 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
 }
 
 // ------------------------------------------------------------------------------------------------
+// traverse, tree-parallel form (trees of at most 64 expanded nodes with at most AU actions, on the LDS copy): the same
+// cbatch_traverse (cnode.cpp:886-963), but EVERY expanded node picks its child at once -- lane n owns node n -- and the walk from
+// the root then only follows the choices.  dev_traverse scores one node per level with 6 of 64 lanes busy (A = 6) and ~600
+// dependent instructions per level, so a search path of depth d costs ~2.4 k cycles x d; here the cost is one pass over the
+// tree whatever the depth:
+//   A  lane n reads its node's A edges and sums compute_mean_q's total / count IN THE LANE, in legal-list order
+//      (cnode.cpp:173-212: the same additions in the same order as the v_readlane replay of dev_traverse);
+//   B  parent_q chains down the tree: mean_q[n] = (mean_q[parent] + total[n]) / (count[n] + 1), one ds_bpermute + one
+//      division per LEVEL of the tree for all nodes of that level (node_link carries parent and depth);
+//   C  cucb_score (cnode.cpp:756-814) of every child and cselect_child's arg-max / tie list (cnode.cpp:651-695) in the lane,
+//      children in list order; the tie-break draw is keyed by the node's depth exactly like the level counter of the walk;
+//   D  the walk: two v_readlane per level.
+// Every float operation of a node is the one dev_traverse performs for that node, in the same order => bit-identical selections
+// (tests/test_tree_gpu.py / test_exact_replay_gpu.py run both; LZ_TRAVERSE_SERIAL=1 selects the per-level walk).
+// s_tab: [64] log((n + base + 1) / base) + init, then [64] sqrt(n) -- the exploration factors of a node with visit count n + 1.
+template <int AU, int VARIANT>
+__device__ __forceinline__ void dev_traverse_par(const lz_tree_dev &t, const tview &v, const tscal<1> &sc, const lz_traverse_args &a,
+                                                 float delta_max, int vtp, int nn, const float *s_tab, int32_t *s_out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = t.A, NN = t.NN;
+    const float mn = sc.mn, mx = sc.mx, discount = a.discount;
+    const bool nvalid = lane < nn;
+    const int n = nvalid ? lane : nn - 1;           // (idle lanes recompute the last node: every address stays inside the staged tree)
+    const bool is_root = n == 0;
+    // ---- A: this node's record, its link, its children.  Below the root child j is action j: the A records are consecutive
+    // (immediate offsets; for A < AU the reads run on into the next node's records -- or, behind the last node, into the arrays
+    // that follow the edges in the staged tree -- and everything beyond the list is masked below).  The root's children are its legal
+    // list: when that is the identity (every Atari root) the root is a node like any other, else lane 0 takes its addresses from
+    // the list.
+    const uint64_t link = v.link[n];
+    const int parent = (int)(link >> 40), act_in = (int)((link >> 24) & 0xffffu), depth_n = (int)(link & 0xffffffu);
+    const float node_vp = v.node_vp[n];
+    const int node_reset = v.node_reset[n];
+    const int cnt_n = is_root ? sc.n_root : A;      // children in the list: the legal root actions | every action
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f e[AU];
+    int chd[AU];
+    const bool ident = sc.n_root == A && __ballot(lane < A && sc.root_act[0] != lane) == 0;   // wave-uniform
+    if (ident) {
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            e[j] = *reinterpret_cast<const v4f *>(v.edge + (size_t)n * A + j);
+            chd[j] = v.child[(size_t)n * A + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            const int ra = rl_i(sc.root_act[0], j);  // legal[j] of the root (0 beyond the list)
+            const int aj = is_root ? ra : j;
+            e[j] = *reinterpret_cast<const v4f *>(v.edge + (size_t)n * A + aj);
+            chd[j] = v.child[(size_t)n * A + aj];
+        }
+    }
+    const int chd_a0 = v.child[(size_t)n * A];      // child of action 0: where a node without any comparable score goes (cnode.cpp:687-693)
+    // visit count of the edge that leads here (the walk's node_visit); the root carries its own
+    const int in_vis_e = __float_as_int(v.edge[(size_t)parent * A + act_in].y);
+    const int in_vis = is_root ? sc.root_visit : in_vis_e;
+    float prior[AU], val[AU], tr[AU];
+    int vis[AU];
+    float total = 0.0f;
+    int nv = 0;
+#pragma unroll
+    for (int j = 0; j < AU; ++j) {
+        prior[j] = e[j].x;
+        vis[j] = __float_as_int(e[j].y);
+        // CNode::value cnode.cpp:223-239.  (Branch-free on purpose: the division runs on a harmless denominator where the
+        // count is 0 and a select drops it -- one instruction stream for all lanes instead of a divergent branch per child.)
+        const float qv = e[j].z / (float)max(vis[j], 1);
+        val[j] = (vis[j] == 0) ? 0.0f : qv;
+        if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+            const float dv = e[j].w - node_vp;
+            tr[j] = (node_reset == 1) ? e[j].w : dv;
+        } else {
+            tr[j] = e[j].w;
+        }
+        const float qsa = tr[j] + discount * val[j];
+        const bool visited = j < cnt_n && vis[j] > 0;   // total_unsigned_q += qsa in legal-list order
+        const float t2 = total + qsa;
+        total = visited ? t2 : total;
+        nv += visited ? 1 : 0;
+    }
+    // ---- B: mean_q of every node, level by level (the root's parent_q is 0)
+    const float rden = (float)(nv + 1);
+    float mq = (is_root && nv > 0) ? total / (float)nv : (0.0f + total) / rden;
+    for (int lvl = 1; __ballot(nvalid && depth_n >= lvl) != 0; ++lvl) {
+        const float pq = __int_as_float(__builtin_amdgcn_ds_bpermute(parent << 2, __float_as_int(mq)));
+        const float m2 = (pq + total) / rden;
+        mq = (depth_n == lvl) ? m2 : mq;
+    }
+    // ---- C: cucb_score of every child, cselect_child
+    const int ti = min(max(in_vis - 1, 0), 63);
+    const float pbc0 = s_tab[ti], sq = s_tab[64 + ti];
+    float score[AU];
+    float best = -__builtin_inff();
+    const float mm_d = mx - mn;
+    const bool mm_on = mm_d > 0;
+    const float mm_den = (mm_d < delta_max) ? delta_max : mm_d;
+#pragma unroll
+    for (int j = 0; j < AU; ++j) {
+        float pb_c = pbc0 * (sq / (float)(vis[j] + 1));
+        const float prior_score = pb_c * prior[j];
+        const float vq = (a.players == 1) ? tr[j] + discount * val[j] : tr[j] + discount * (-val[j]);
+        float value_score = (vis[j] == 0) ? mq : vq;
+        // CMinMaxStats::normalize (cminimax.cpp:33-45), branch-free: mm_den is the denominator the reference divides by when
+        // maximum > minimum (wave-uniform), the quotient is dropped otherwise
+        const float nq = (value_score - mn) / mm_den;
+        value_score = mm_on ? nq : value_score;
+        value_score = (value_score < 0) ? 0.0f : ((value_score > 1) ? 1.0f : value_score);
+        const float ucb = prior_score + value_score;
+        score[j] = (j < cnt_n) ? ucb : -__builtin_inff();
+        best = fmaxf(best, score[j]);
+    }
+    int pos = -1;   // front of the tie list == first arg-max in list order
+#pragma unroll
+    for (int j = AU - 1; j >= 0; --j) pos = (score[j] == best) ? j : pos;
+    const bool ok = pos >= 0 && best > LZ_FLOAT_MIN;
+    if (a.tiebreak == LZ_TIE_RANDOM) {
+        // tie list = [first arg-max] + later entries with score >= max - 1e-6 (cnode.cpp:675-685)
+        const float thr = best - 0.000001f;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < AU; ++j) cnt += (j == pos || (j > pos && score[j] >= thr)) ? 1 : 0;
+        const bool draw = ok && cnt > 1;
+        if (__ballot(draw)) {   // (a single candidate -- the usual case once visits differ -- needs no draw)
+            const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)sc.epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth_n);
+            int r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt)
+            int pick = pos;
+#pragma unroll
+            for (int j = 0; j < AU; ++j) {
+                const bool member = j == pos || (j > pos && score[j] >= thr);
+                pick = (member && r == 0) ? j : pick;
+                r -= member ? 1 : 0;
+            }
+            pos = draw ? pick : pos;
+        }
+    }
+    int sel_child = chd_a0;
+#pragma unroll
+    for (int j = 0; j < AU; ++j) sel_child = (ok && pos == j) ? chd[j] : sel_child;
+    int sel_act = ok ? pos : 0;   // below the root (and at a root with the identity list) the action IS the list position
+    if (!ident) {                 // the root's action comes from its legal list
+        const int p0 = rl_i(sel_act, 0), ok0 = (int)(__ballot(ok) & 1ull);
+        const int a0 = ok0 ? rl_i(sc.root_act[0], p0) : 0;
+        sel_act = (lane == 0) ? a0 : sel_act;
+    }
+    // ---- D: the walk
+    int node = 0, depth = 0, last_action = -1;
+    int my_node = 0, my_act = 0;
+    for (;;) {
+        const int action = rl_i(sel_act, node), nxt = rl_i(sel_child, node);
+        if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
+        if (lane == depth) { my_node = node; my_act = action; }
+        last_action = action;
+        depth += 1;
+        if (nxt < 0 || depth >= 64) break;  // reached an unexpanded child: the leaf  (a path has at most nn <= 64 nodes)
+        node = nxt;
+    }
+    if (lane < depth) {
+        t.path_node[(size_t)b * NN + lane] = my_node;
+        t.path_act[(size_t)b * NN + lane] = my_act;
+        t.node_best[(size_t)b * NN + my_node] = my_act;
+    }
+    if (lane == 0) {
+        t.res_ix[b] = node;
+        t.res_iy[b] = b;
+        t.res_last_action[b] = last_action;
+        t.res_search_len[b] = depth;
+        t.res_vtp[b] = vtp;
+        if (s_out) { s_out[0] = node; s_out[1] = last_action; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backpropagate: cbatch_backpropagate (cnode.cpp:577-601) = expand the leaf, then cbackpropagate.
 // d = search length of the path, lg[] = this lane's policy logits of the leaf, sc carries root visit / value sum and
 // the min-max statistics in and out.
@@ -336,6 +519,9 @@ __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &
         }
     } else if (lane == 0) {
         t.node_bidx[(size_t)b * NN + new_node] = bidx < 0 ? b : bidx;
+        const uint64_t lk = lz_link_pack(parent, pact, d);
+        t.node_link[(size_t)b * NN + new_node] = lk;
+        if (v.link) v.link[new_node] = lk;
         v.child[(size_t)parent * A + pact] = new_node;
         v.node_vp[new_node] = vp_b;
         v.node_reset[new_node] = reset;
@@ -479,14 +665,17 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     const int A = t.A;
     const int nn = new_node + 1;        // nodes 0 .. new_node exist after this step
     float4 *s_edge = s_tree;                                              // [nn][A]
-    int32_t *s_child = reinterpret_cast<int32_t *>(s_edge + (size_t)nn * A);   // [nn][A]
+    uint64_t *s_link = reinterpret_cast<uint64_t *>(s_edge + (size_t)nn * A);  // [nn] node_link (parent | action | depth)
+    int32_t *s_child = reinterpret_cast<int32_t *>(s_link + nn);         // [nn][A]
     float *s_vp = reinterpret_cast<float *>(s_child + (size_t)nn * A);    // [nn]
     int32_t *s_reset = reinterpret_cast<int32_t *>(s_vp + nn);
     int32_t *s_tp = s_reset + nn;
     int32_t *s_pn = s_tp + nn;
     int32_t *s_pa = s_pn + nn;
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_tree + lz_tree_lds_bytes_raw(A, new_node) / 16);  // 32 entries, 16-byte aligned
+    float *s_tab = reinterpret_cast<float *>(s_exp + 32);                 // [2][64] exploration factors by visit count (dev_traverse_par)
     const tview g = global_view(t, b);
+    const uint64_t *g_link = t.node_link + (size_t)b * t.NN;
     // ---- one round trip: everything the step reads.  All requests are unconditional (clamped indices) and issued before
     // the first use: a predicated load, or a wave-uniform read of a loaded value in between, would split this into
     // several dependent HBM/L2 round trips (~0.6 us each).
@@ -518,10 +707,12 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     }
     float nv0[UN];
     int32_t nr0[UN], nt0[UN], pn0[UN], pa0[UN];
+    uint64_t lk0[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int i = min(u * 64 + lane, new_node - 1);
         nv0[u] = g.node_vp[i]; nr0[u] = g.node_reset[i]; nt0[u] = g.node_to_play[i]; pn0[u] = g.path_node[i]; pa0[u] = g.path_act[i];
+        lk0[u] = g_link[i];
     }
     // tables that take software exp / log table fetches and the sqrt out of the dependent chains below: the 2^(i/32) table of
     // lz_expf goes to LDS, and lane n computes the exploration factors of a node with visit count n + 1 (N = n <= new_node)
@@ -538,8 +729,10 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int i = u * 64 + lane;
-        if (i < new_node) { s_vp[i] = nv0[u]; s_reset[i] = nr0[u]; s_tp[i] = nt0[u]; s_pn[i] = pn0[u]; s_pa[i] = pa0[u]; }
+        if (i < new_node) { s_vp[i] = nv0[u]; s_reset[i] = nr0[u]; s_tp[i] = nt0[u]; s_pn[i] = pn0[u]; s_pa[i] = pa0[u]; s_link[i] = lk0[u]; }
     }
+    s_tab[lane] = tab_pbc;
+    s_tab[64 + lane] = tab_sq;
     for (int i0 = UE * 64; i0 < ne; i0 += UE * 64) {  // trees beyond 512 edges / 128 nodes: further batches
         v4f e[UE];
         int32_t ch[UE];
@@ -558,15 +751,17 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     for (int i0 = UN * 64; i0 < new_node; i0 += UN * 64) {
         float nv[UN];
         int32_t nr[UN], nt[UN], pn[UN], pa[UN];
+        uint64_t lk[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = min(i0 + u * 64 + lane, new_node - 1);
             nv[u] = g.node_vp[i]; nr[u] = g.node_reset[i]; nt[u] = g.node_to_play[i]; pn[u] = g.path_node[i]; pa[u] = g.path_act[i];
+            lk[u] = g_link[i];
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * 64 + lane;
-            if (i < new_node) { s_vp[i] = nv[u]; s_reset[i] = nr[u]; s_tp[i] = nt[u]; s_pn[i] = pn[u]; s_pa[i] = pa[u]; }
+            if (i < new_node) { s_vp[i] = nv[u]; s_reset[i] = nr[u]; s_tp[i] = nt[u]; s_pn[i] = pn[u]; s_pa[i] = pa[u]; s_link[i] = lk[u]; }
         }
     }
     if (s_leaf) {   // the tree is staged; now the leaf's network outputs, once the waves that compute them say so
@@ -597,13 +792,23 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     LZ_TTS(2);
     tview v = g;
     v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
-    v.path_node = s_pn; v.path_act = s_pa;
+    v.path_node = s_pn; v.path_act = s_pa; v.link = s_link;
     dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset, false, -1, s_exp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     LZ_TTS(3);
-    dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
+    // trees of at most 64 nodes and 8 actions (every Atari-sized search of up to 63 simulations): all nodes scored at once
+    if constexpr (NC == 1) {
+        if (use_tab && A <= 8 && !a.serial) {
+            if (A <= 4) dev_traverse_par<4, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out);
+            else if (A <= 6) dev_traverse_par<6, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out);
+            else dev_traverse_par<8, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out);
+        }
+        else dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
+    } else {
+        dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
+    }
     LZ_TTS(4);
 #undef LZ_TTS
 }
@@ -611,8 +816,8 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
 }  // namespace
 
 // LDS bytes of the staged tree of one root after `idx` nodes exist besides the new one (dev_step_lds): the arrays, rounded up to
-// 16 bytes, then the 32-entry exp table
-static inline size_t lz_tree_lds_bytes(const lz_tree_dev &t, int idx) { return lz_tree_lds_bytes_raw(t.A, idx) + 32 * 8; }
+// 16 bytes, then the 32-entry exp table and the two 64-entry exploration-factor tables
+static inline size_t lz_tree_lds_bytes(const lz_tree_dev &t, int idx) { return lz_tree_lds_bytes_raw(t.A, idx) + 32 * 8 + 128 * 4; }
 
 // Largest staged tree (bytes per root) the LDS step is used for; beyond it the step walks the HBM arrays.  Staging costs
 // O(tree) per simulation but every level of the walk then costs an LDS instead of an HBM round trip.

@@ -436,6 +436,11 @@ def make_module(variant, has_deterministic_flag):
                 if shrink:
                     self._S = int(num_simulations)
                 self._replay_prepare()
+            if src_roots._h is None:   # e.g. evicted from the model's bounded handle cache (EfficientZeroModel._own_roots) since the inference
+                raise L.LzError("the HBM token is stale: the roots handle that held this inference was released%s -- call model.initial_inference(obs) "
+                                "again (the model keeps the %s most recent (kind, batch size) handles)"
+                                % (" by %s's handle cache" % src_roots._evicted_from if getattr(src_roots, "_evicted_from", None) else "",
+                                   getattr(model, "_OWN_ROOTS_MAX", "few")))
             L.check(L.lib().lz_roots_adopt_inference(self._h, src_roots._h))
             self._inferred_by = model
             self._touched = True

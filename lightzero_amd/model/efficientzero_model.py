@@ -146,16 +146,16 @@ class EfficientZeroModel(object):
         place on the device, roots and their captured search graphs stay valid."""
         self._check_owner()
         state_dict = unwrap_checkpoint(state_dict)
-        synced = False
+        synced = set()
         for name, value in state_dict.items():
             if name.endswith("num_batches_tracked"):
                 continue
             if getattr(value, "is_cuda", False) and str(value.dtype) == "torch.float32" and value.is_contiguous():
                 # a device tensor (shard.broadcast_state_dict(..., on_device=True)): handed over by pointer, no host copy here
-                if not synced:
+                if value.device not in synced:
                     import torch
-                    torch.cuda.current_stream().synchronize()   # the collective / whoever produced the tensors is done
-                    synced = True
+                    torch.cuda.current_stream(value.device).synchronize()   # whoever produced the tensors ON THEIR DEVICE is done
+                    synced.add(value.device)
                 shape = (ctypes.c_int64 * max(value.dim(), 1))(*value.shape)
                 L.check(L.lib().lz_model_set_tensor_device(self._engine, name.encode(), value.data_ptr(), shape, value.dim()))
                 continue
@@ -204,6 +204,7 @@ class EfficientZeroModel(object):
             while len(cache) >= self._OWN_ROOTS_MAX:   # a driver whose ready-env count varies: keep the few most recent batch sizes
                 _, old = cache.popitem(last=False)
                 old.clear()   # destroyed, not parked: its pools go back to the device
+                old._evicted_from = type(self).__name__   # an HbmToken that still points here fails with a message, not on a dead handle
             r = self._new_own_roots(B, max_simulations)
             if trace:
                 L.check(L.lib().lz_roots_enable_trace(r._h, 1))   # the heads also write their support-wide logits

@@ -65,6 +65,8 @@ class SampledEfficientZeroModel(EfficientZeroModel):
 
     def load_state_dict(self, state_dict, strict=True):
         """the reference's key names (prediction_network.fc_value_head.* / fc_policy_head.*) -> the EfficientZero network's"""
+        from .efficientzero_model import unwrap_checkpoint
+        state_dict = unwrap_checkpoint(state_dict)   # a whole checkpoint {'model', 'target_model', 'optimizer'}: rename INSIDE its 'model' dict
         ren = {}
         for k, v in state_dict.items():
             k2 = k.replace("prediction_network.fc_value_head.", "prediction_network.fc_value.") \

@@ -71,6 +71,20 @@ def efficientzero_state_dict(seed=0, observation_channels=4, action_space_size=6
     return sd
 
 
+def sharpen_state_dict(sd, policy_scale=1.0, value_scale=None):
+    """A copy of ``sd`` whose policy head's last layer (``prediction_network.fc_policy.3``: weight and bias) is multiplied by
+    ``policy_scale`` and whose value head's last layer by ``value_scale`` (default: the same factor).  The section-8d recipe draws those
+    layers at N(0, 0.05): root priors come out near-uniform (max-prob ~0.24 of 6 actions) and 50 simulations build trees of depth 2-3.
+    A trained agent's prior is sharp; x10 gives max-prob ~0.9 and search paths of depth 4-10 (bench.py's ``depth_sweep`` arms and the
+    sharp-prior parity cases use it).  Works on numpy or torch values."""
+    value_scale = policy_scale if value_scale is None else value_scale
+    out = dict(sd)
+    for head, k in (("prediction_network.fc_policy.3", policy_scale), ("prediction_network.fc_value.3", value_scale)):
+        for part in (".weight", ".bias"):
+            out[head + part] = sd[head + part] * k
+    return out
+
+
 def muzero_state_dict(seed=0, **kw):
     return efficientzero_state_dict(seed=seed, muzero=True, **kw)
 

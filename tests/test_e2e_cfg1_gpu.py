@@ -2,13 +2,12 @@
 the FULL oracle pipeline (reference-style driver + torch fp32 model + CPU ctree) on the same observations, weights and Dirichlet noise,
 deterministic tie-break on both sides.
 
-Recorded (profiles/rNN_parity.json, entry "e2e/ez_atari96/B256_S50"), not gated at 100 %: the fraction of roots whose visit
+Recorded (profiles/rNN_parity.json, entry "e2e/ez_atari96/B256_S50") and gated at >= 98 % (sharp-prior case: 95 %): the fraction of roots whose visit
 distributions coincide, and for EVERY differing root the first simulation whose selection differed with the pUCT scores of the two
 competing actions on both sides (tests/e2e_attrib.py).  The two pipelines feed their trees network outputs that differ by <= 1e-5
 before the inverse scalar transform (tests/test_nn_gpu.py) and by whole steps of the reference formula's own ~1.3e-4 quantum after it;
 the tree itself is bit-exact on identical inputs (tests/test_exact_replay_gpu.py).  So a root may differ only where two scores were
-that close: every differing root is classified, an "unexplained" one is flagged (recorded and warned about, not gated: the torch side of
-the comparison differs from host to host).
+that close: every differing root is classified, and an "unexplained" one fails the test.
 mcts_ctree.py:839-842 (the scalars the tree is fed), cnode.cpp:651-695 / 756-814 (the selection)."""
 import json
 import os
@@ -37,15 +36,21 @@ def _device_records(roots, lib, L, B, A, S):
     return rec
 
 
-@pytest.mark.parametrize("B,S,seed", [(256, 50, 5), (256, 50, 11)])
-def test_cfg1_full_size_vs_oracle_pipeline(B, S, seed):
+@pytest.mark.parametrize("B,S,seed,sharp", [(256, 50, 5, 1.0), (256, 50, 11, 1.0), (256, 50, 7, 10.0)])
+def test_cfg1_full_size_vs_oracle_pipeline(B, S, seed, sharp):
+    """sharp = 10: the policy head's and the value head's last layers x 10 (lightzero_amd.model.synthetic.sharpen_state_dict) -- a
+    trained agent's sharp prior: root max-prob ~0.9 instead of ~0.24, search paths of depth 4-10 instead of 2-3 (VERDICT r4 weak #3:
+    the 8d recipe only ever builds the shallowest trees)."""
     from oracle import ctree as octree, search as osearch, torch_models as tm
     from lightzero_amd import _lib as L
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
     from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.model.synthetic import sharpen_state_dict
     A = 6
     cfg = dict(CFG, num_simulations=S)
     ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A))
+    if sharp != 1.0:
+        ref.load_state_dict(sharpen_state_dict(ref.state_dict(), sharp))
     model = EfficientZeroModel(action_space_size=A).load_state_dict(ref.state_dict())
     obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(seed))
     rng = np.random.default_rng(seed)
@@ -83,11 +88,14 @@ def test_cfg1_full_size_vs_oracle_pipeline(B, S, seed):
     for e in entries:
         print("  root %(root)d: first differing simulation %(first_sim)d, level %(level)d, gaps %(gap_oracle).3g / %(gap_device).3g, "
               "best two (oracle) %(best_two_oracle).3g, scalar delta %(scalar_delta).3g, range %(minmax_range).3g -> %(class)s" % e)
-    parity_record.record("e2e/ez_atari96/B%d_S%d/seed%d" % (B, S, seed), {}, extra=summ)
-    assert same.mean() >= 0.9
-    # recorded, not gated (the torch side of the comparison is not the same on every host: its square root, its thread partitioning): an
-    # "unexplained" root shows up in profiles/rNN_parity.json and in this warning, and is the thing to look at
+    depth = np.stack([r["search_len"] for r in rec_d])   # [S][B]
+    summ["search_depth_mean"], summ["search_depth_max"] = float(depth.mean()), int(depth.max())
+    parity_record.record("e2e/ez_atari96/B%d_S%d/seed%d%s" % (B, S, seed, "" if sharp == 1.0 else "/sharp%g" % sharp), {}, extra=summ)
+    # Gated at the evidence: 256 / 256 identical roots were measured on two seeds with the 8d recipe, so the gate is
+    # 98 % there; the sharp-prior case walks deeper (more recurrent steps between the two pipelines' scalars) and is held to 95 %.
+    # A differing root that is NOT a near-tie or one quantum of the post-transform scalars fails the test.
+    assert same.mean() >= (0.98 if sharp == 1.0 else 0.95), "only %d / %d roots have identical visit distributions" % (int(same.sum()), B)
+    if sharp != 1.0:
+        assert depth.max() >= 5, "the sharp-prior case did not build deeper trees (max search length %d)" % depth.max()
     bad = [e for e in entries if e["class"] == "unexplained"]
-    if bad:
-        import warnings
-        warnings.warn("differing roots not explained by a near-tie or one quantum of the post-transform scalars: %r" % bad)
+    assert not bad, "differing roots not explained by a near-tie or one quantum of the post-transform scalars: %r" % bad

@@ -312,6 +312,63 @@ def test_tree_step_in_the_chain_prologue_is_bit_identical_to_the_separate_launch
         assert np.abs(v1 - v2)[ok].max() < 2e-3
 
 
+@pytest.mark.parametrize("tiebreak", [0, 1])
+@pytest.mark.parametrize("family,A,ragged", [("ez", 6, True), ("ez", 6, False), ("mz", 4, False), ("ez", 8, True), ("mz", 5, True), ("ez", 3, True)])
+def test_tree_parallel_selection_is_bit_identical_to_the_level_walk(family, A, ragged, tiebreak):
+    """dev_traverse_par (every expanded node of a tree scored at once, lane = node; trees of <= 64 nodes, <= 8 actions) against
+    dev_traverse (one level of the path at a time, lane = child; LZ_TRAVERSE_SERIAL=1) inside the same fused launch sequence:
+    identical visit distributions, root values / min-max statistics (bitwise), trajectories and per-simulation records -- for
+    the deterministic AND the stochastic tie-break (the draw is keyed by the node's depth in both), identity and ragged root legal
+    lists, every compiled child count (4, 6, 8) with a smaller action space inside it, and sharp priors (deep paths)."""
+    import os
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.model.synthetic import sharpen_state_dict
+    B, S = 67, 50
+    if family == "ez":
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+        from lightzero_amd.model.efficientzero_model import EfficientZeroModel as M
+        ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=A)
+    else:
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as tree
+        from lightzero_amd.model.muzero_model import MuZeroModel as M
+        ref = tm.synthetic_init(tm.MuZeroModel(action_space_size=A), seed=A)
+    sd = ref.state_dict()
+    if A in (6, 5):
+        sd = sharpen_state_dict(sd, 8.0)   # deep paths
+    model = M(action_space_size=A).load_state_dict(sd)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(40 + A)).cuda().contiguous()
+    rng = np.random.default_rng(50 + A)
+    mask = (rng.random((B, A)) < 0.7) if ragged else np.ones((B, A), bool)
+    mask[:, A - 1] = True
+    legal = [np.nonzero(m)[0].tolist() for m in mask]
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    res = []
+    for serial in (True, False):
+        os.environ.pop("LZ_TRAVERSE_SERIAL", None)
+        if serial:
+            os.environ["LZ_TRAVERSE_SERIAL"] = "1"
+        try:
+            roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+            roots.set_tiebreak(tiebreak, seed=91)
+            L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+            model.initial_inference(obs, roots)
+            roots.prepare_from_inference(0.25, noises, [-1] * B)
+            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 5 if family == "ez" else 0, 0.01))
+            tr = np.zeros((S, B, 4), np.int32)
+            L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+            res.append((roots.get_distributions(), np.asarray(roots.get_values(), np.float32).view(np.uint32),
+                        roots.get_trajectories(), roots.get_minmax().view(np.uint32), tr))
+        finally:
+            os.environ.pop("LZ_TRAVERSE_SERIAL", None)
+    a, b = res
+    assert all(sum(d) == S for d in b[0])
+    assert np.array_equal(a[4], b[4]), "per-simulation (slot, action, search length, to_play) records differ"
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+    if A in (6, 5):
+        assert b[4][:, :, 2].max() >= 5   # the sharp prior did walk deep
+
+
 def test_config2_full_size_deep_trees_properties():
     """BASELINE.json configs[2] at full size: Atari MuZero (conv), 1024 roots x 400 simulations, A = 4 -- the trees outgrow
     the LDS budget part-way through the search (tree step in the chain prologue -> separate HBM launch).  Size-independent

@@ -111,6 +111,42 @@ def test_configs1_full_size_production_path_replays_exactly():
     assert all(np.array_equal(a["v"], b["v"]) and np.array_equal(a["logits"], b["logits"]) for a, b in zip(sims1, sims2))
 
 
+def test_configs1_sharp_prior_deep_paths_replay_exactly():
+    """VERDICT r4 #1c: the 8d recipe's near-uniform priors only ever build paths of depth <= 3 at configs[1].  The same 256 x 50 search
+    with the policy and value heads' last layers x 10 (a trained agent's sharp prior; search paths up to ~10 deep, so the tree step
+    spends most of its time below the root) through the same gate -- with the records of every simulation, and with the
+    stochastic-tie-break graph's sibling, the level-by-level walk (LZ_TRAVERSE_SERIAL=1), required to give the identical search."""
+    import os
+    from oracle import torch_models as tm
+    from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.model.synthetic import sharpen_state_dict
+    B, A, S = 256, 6, 50
+    sd = sharpen_state_dict(tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=0).state_dict(), 10.0)
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(sd)
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(31)).cuda().contiguous()
+    rng = np.random.default_rng(13)
+    noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
+    legal = [list(range(A))] * B
+    roots = ez_tree.Roots(B, legal, action_space_size=A, max_simulations=S, engine=model.engine)
+    roots.set_tiebreak(0)
+    d1, v1, _ = _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
+    from lightzero_amd import _lib as L
+    depth = np.zeros((B, S), np.int32)
+    L.check(L.lib().lz_roots_get_node_depths(roots._h, S, depth.reshape(-1)))
+    tr = np.zeros((S, B, 4), np.int32)
+    L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+    assert np.array_equal(depth, tr[:, :, 2].T), "lz_roots_get_node_depths differs from the traced search lengths"
+    assert depth.max() >= 6 and depth.mean() > 3.0, "sharp priors did not deepen the search (mean %.2f, max %d)" % (depth.mean(), depth.max())
+    os.environ["LZ_TRAVERSE_SERIAL"] = "1"
+    try:
+        roots.reset(legal)
+        d2, v2, _ = _search_and_replay("ez", model, roots, obs, legal, [-1] * B, noises, S, 0.997, trace=True)
+    finally:
+        os.environ.pop("LZ_TRAVERSE_SERIAL", None)
+    assert d1 == d2 and np.array_equal(v1.view(np.uint32), v2.view(np.uint32))
+
+
 def test_reanalyze_shaped_batch_replays_exactly():
     """game_buffer_efficientzero.py:325-409 -- batch_size * (unroll + 1) = 256 * 6 = 1536 roots, no noise."""
     from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree

@@ -70,9 +70,22 @@ def main():
                                "Winograd convolution chain. reads: latent gather 2.36 MB + 1.31 MB of transformed weights once per XCD L2 (8 x: "
                                "L2 does not survive a kernel boundary) + the staged trees; writes: next latent 2.36 MB + head-conv outputs "
                                "1.77 MB + tree write-through. Algorithmic bytes of the chain 7.8 MB (activations in and out + the weights once)."}}
-    for key in ("k_chain_w<6, 6, 8, false, 0", "k_heads_mm", "k_lstm2<68, 0, 16, 36, true>", "k_conv_wino<64, 64, 16>", "k_conv_wino<32, 32, 32>",
-                "k_conv3x3_big<32, 64, 2, 48>", "k_conv_first", "k_avgpool", "k_pack_rows"):
-        out[key] = {"fetch_size_kb": mean(key, "FETCH_SIZE"), "write_size_kb": mean(key, "WRITE_SIZE")}
+    # every other kernel of the step, under the name the profiler printed (looking kernels up by last round's template
+    # signature left the LSTM's and the row kernel's entries null): one entry per kernel family = its instantiation with the largest total time
+    fams = {}
+    for n in tot:
+        sn = short(n)
+        fam = sn.split("<")[0]
+        if not fam.startswith("k_") or sn == fused:
+            continue
+        if fam not in fams or tot[n] > tot[fams[fam][0]]:
+            fams[fam] = (n, sn)
+    for fam, (n, sn) in sorted(fams.items()):
+        fs, ws = mean(sn, "FETCH_SIZE"), mean(sn, "WRITE_SIZE")
+        if fs is None and ws is None:
+            continue
+        out[sn] = {"fetch_size_kb": fs, "write_size_kb": ws, "avg_us": round(dur.get(n, 0.0), 2),
+                   "hbm_bytes_per_launch": int(round((2 * (fs or 0.0) + (ws or 0.0)) * 1024))}
     json.dump(out, open(os.path.join(prof, "%s_traffic.json" % tag), "w"), indent=1)
     # the bench line of the same run read the PREVIOUS traffic file (bench.py takes roofline.traffic from profiles/): carry this run's
     # counters instead, so that the committed line and the committed counters belong together
