@@ -314,18 +314,21 @@ def weight_refresh(model, weights, roots, step, first_step, reps=10):
     return out
 
 
-def collector_surface(model, n_warm_eps=ENVS, n_eps=ENVS + ENVS // 2):
+def collector_surface(model, groups=1, n_warm_eps=ENVS, n_eps=ENVS + ENVS // 2):
     """env-steps/s through lightzero_amd.worker.MuZeroVectorCollector.collect: the collect loop of muzero_collector.py
-    :416-760 -- policy rows, env.step, segment bookkeeping, rollover / pool, device-resident frame stack -- over a synthetic vector env
-    (frames from a pre-generated pool, episodes of ~150 steps), while every env is active."""
+    :416-760 -- policy rows, env.step, segment bookkeeping, rollover / pool, device-resident frame stack -- over `groups` synthetic vector
+    envs of 256 envs each (frames from a pre-generated pool in pinned host memory, episodes of ~150 steps), while every env is active.
+    One group: a step cannot start before the previous step's actions have stepped the environments, so the device waits for the
+    host's share of the loop; two groups: the device searches for one while the host steps the other (what a deployment does)."""
+    import torch
     from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
     from lightzero_amd.worker import MuZeroVectorCollector
     B, A = ENVS, ACTIONS
 
     class _Env:
-        def __init__(self):
-            self.env_num, self.rng, self.k = B, np.random.default_rng(0), 0
-            self.pool = [np.random.default_rng(i).random((B, 1, 96, 96), dtype=np.float32) for i in range(4)]
+        def __init__(self, seed):
+            self.env_num, self.rng, self.k = B, np.random.default_rng(seed), 0
+            self.pool = [torch.from_numpy(np.random.default_rng(100 * seed + i).random((B, 1, 96, 96), dtype=np.float32)).pin_memory().numpy() for i in range(4)]
             self.mask, self.tp = np.ones((B, A), np.float32), np.full(B, -1)
 
         def _obs(self):
@@ -339,11 +342,13 @@ def collector_surface(model, n_warm_eps=ENVS, n_eps=ENVS + ENVS // 2):
             done = (self.rng.random(B) < 1.0 / 150) & active
             return self._obs(), np.zeros(B, np.float32), done, dict(reset_obs=self._obs(), eval_episode_return=np.zeros(B))
     ccfg = dict(CFG, game_segment_length=400, num_unroll_steps=5, td_steps=5, model=dict(frame_stack_num=4, action_space_size=A))
-    col = MuZeroVectorCollector(_Env(), EfficientZeroPolicy(ccfg, model), ccfg, device="cuda")
-    col.collect(n_episode=n_warm_eps)          # warm-up: handles, graphs
+    envs = [_Env(g) for g in range(groups)]
+    pols = [EfficientZeroPolicy(ccfg, model) for _ in range(groups)]
+    col = MuZeroVectorCollector(envs[0] if groups == 1 else envs, pols[0] if groups == 1 else pols, ccfg, device="cuda")
+    col.collect(n_episode=groups * n_warm_eps)          # warm-up: handles, graphs
     t0 = time.perf_counter()
     l0 = col.total_loop_steps
-    col.collect(n_episode=n_eps)
+    col.collect(n_episode=groups * n_eps)
     dt = time.perf_counter() - t0
     return B * (col.total_loop_steps - l0) / dt
 
@@ -379,12 +384,7 @@ def _cpu_worker(spec):
     sys.stdout.write(json.dumps(dict(idx=idx, envs=hi - lo, t0=t0, t1=t1, kind_tree=kind_tree)) + "\n"); sys.stdout.flush()
 
 
-def cpu_baseline_whole_host(threads, rank, batches=3, budget_s=120.0):
-    """The same reference pipeline with ALL physical cores busy: N = host_cores // threads processes (threads = the torch
-    thread count that won cpu_baseline's sweep), each pinned to its own `threads` cores and running the pipeline on its contiguous block
-    of the 256 envs; all start together after their warm-ups; value = 256 envs x batches / (latest end - earliest start)."""
-    phys, thr = host_cores()
-    nproc = max(1, min(phys // max(threads, 1), ENVS // 4))
+def _whole_host_run(nproc, threads, batches, budget_s):
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d,%d" % (i, nproc, threads, batches)],
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True,
                               env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
@@ -404,18 +404,44 @@ def cpu_baseline_whole_host(threads, rank, batches=3, budget_s=120.0):
                 p.stdin.close()
             except Exception:
                 pass
+        for p in procs:
             try:
                 p.wait(timeout=30)
             except Exception:
                 p.kill()
     span = max(r["t1"] for r in res) - min(r["t0"] for r in res)
     envs = sum(r["envs"] for r in res)
-    return dict(value=envs * batches / span, unit="env-steps/s", cores=nproc * threads, processes=nproc, threads_per_process=threads,
-                host_cores=phys, host_threads=thr, kind="port", batches=batches, span_s=span,
-                per_process_s=[round(r["t1"] - r["t0"], 3) for r in res],
-                sample="%d processes x %d torch threads (each pinned to its own cores) x %d batches of its %d-env block of the 256 envs x 50 sims; "
-                       "%s + restated driver + torch fp32 model; all processes start together; value = envs x batches / (latest end - earliest start)"
-                       % (nproc, threads, batches, ENVS // nproc, res[0]["kind_tree"]))
+    return dict(value=envs * batches / span, processes=nproc, threads_per_process=threads, cores=nproc * threads, span_s=span,
+                slowest_process_s=max(r["t1"] - r["t0"] for r in res), kind_tree=res[0]["kind_tree"])
+
+
+def cpu_baseline_whole_host(threads, rank, batches=3, budget_s=150.0):
+    """The same reference pipeline with ALL physical cores busy: N processes x T torch threads with N x T = the host's
+    physical cores, each process pinned to its own T cores and running the pipeline on its contiguous block of the 256 envs; all start
+    together after their warm-ups; rate = 256 envs x batches / (latest end - earliest start).  (N, T) is swept -- T = the thread count
+    that won cpu_baseline's single-process sweep, then 4 and 1 (the small per-simulation operators of this model scale better across
+    processes than across threads) -- within the time budget; `value` = the best configuration, every configuration is listed."""
+    phys, thr = host_cores()
+    t_start = time.time()
+    runs, seen = [], set()
+    for t in (max(threads, 1), 4, 1):
+        nproc = max(1, min(phys // t, ENVS // 2))
+        if (nproc, t) in seen or (runs and time.time() - t_start > 0.5 * budget_s):
+            continue
+        seen.add((nproc, t))
+        try:
+            runs.append(_whole_host_run(nproc, t, batches, budget_s))
+        except Exception as e:
+            runs.append(dict(processes=nproc, threads_per_process=t, error=repr(e)))
+    ok = [r for r in runs if "value" in r]
+    if not ok:
+        raise RuntimeError("no whole-host configuration completed: %r" % runs)
+    best = max(ok, key=lambda r: r["value"])
+    return dict(value=best["value"], unit="env-steps/s", cores=best["cores"], processes=best["processes"], threads_per_process=best["threads_per_process"],
+                host_cores=phys, host_threads=thr, kind="port", batches=batches, configurations=runs,
+                sample="best of %s (processes x torch threads, each process pinned to its own cores), %d batches of each process's block of the 256 envs x 50 "
+                       "sims; %s + restated driver + torch fp32 model; all processes start together; value = envs x batches / (latest end - earliest start); %.0f s"
+                       % ([(r["processes"], r["threads_per_process"]) for r in runs], batches, best["kind_tree"], time.time() - t_start))
 
 
 def _free_port():
@@ -821,10 +847,11 @@ def main():
                 out["config"]["policy_surface_env_steps_per_s"] = policy_surface(models[0], obs)
             except Exception as e:
                 out["config"]["policy_surface_env_steps_per_s"] = repr(e)
-            try:
-                out["config"]["collector_env_steps_per_s"] = collector_surface(models[0])
-            except Exception as e:
-                out["config"]["collector_env_steps_per_s"] = repr(e)
+            for key, ng in (("collector_env_steps_per_s", 1), ("collector_2groups_env_steps_per_s", 2)):
+                try:
+                    out["config"][key] = collector_surface(models[0], ng)
+                except Exception as e:
+                    out["config"][key] = repr(e)
             noises0 = [z.tolist() for z in rng.dirichlet([CFG["root_dirichlet_alpha"]] * ACTIONS, size=ENVS).astype(np.float32)]
             out["cpu_baseline"] = cpu_baseline(weights, obs_cpu, noises0)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

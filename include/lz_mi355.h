@@ -271,6 +271,19 @@ int lz_model_set_tensor(lz_engine *e, const char *name, const float *h_data, con
  * host-side staging on the engine's stream -- the re-layout of lz_model_finalize is host code).  The producing stream must be done with d_data. */
 int lz_model_set_tensor_device(lz_engine *e, const char *name, const float *d_data, const int64_t *shape, int ndim);
 int lz_model_finalize(lz_engine *e);
+/* Weight REFRESH of a loaded convolutional fp32 model without the host (a collector after a learner update; in the reference the collector
+ * plays with the learner's own nn.Module, lzero/policy/muzero.py:1049-1061, lzero/entry/train_muzero.py:187-212 -- fresh weights are free there).
+ * lz_model_flat_layout / _entry: the model's state_dict tensors (no num_batches_tracked) in name order with their offsets in ONE flat fp32
+ * buffer.  lz_model_refresh_flat: that buffer (device pointer when on_device != 0, else host) -> every kernel layout (MFMA-fragment orders,
+ * Winograd U = G g G^T in binary64, folded BatchNorm, action table, ...) by kernels on the engine's stream; bit-identical to
+ * lz_model_set_tensor + lz_model_finalize of the same tensors; same device buffers (captured search graphs stay valid); no host
+ * synchronisation.  LZ_ERR_STATE (with the reason) where no device-side refresh exists (MLP models, fast mode): use the calls above. */
+int lz_model_flat_layout(lz_engine *e, int64_t *out_tensors, int64_t *out_floats);
+int lz_model_flat_entry(lz_engine *e, int64_t i, char *name_buf, int64_t name_buf_len, int64_t *out_offset, int64_t *out_size);
+int lz_model_flat_host_buffer(lz_engine *e, float **out);   /* pinned staging for a host-side flat state_dict; passing it to lz_model_refresh_flat skips a copy */
+int lz_model_refresh_flat(lz_engine *e, const float *flat, int64_t n_floats, int on_device);
+/* FNV-1a over every device weight buffer (parity tests of the refresh path) */
+int lz_model_weights_digest(lz_engine *e, uint64_t *out);
 /* Identity of the model an engine currently holds: incremented by every lz_model_create.  A host-side model object records
  * it and refuses to run once another model took its engine (one model per engine). */
 uint64_t lz_engine_model_uid(lz_engine *e);
@@ -335,6 +348,14 @@ int lz_rows_extra_words(lz_roots *r);
 int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor, const float *d_obs,
                              int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, float *h_header,
                              float *h_policy_logits);
+/* The same in two halves: _begin enqueues select_action + the row packing behind the search and returns at once; _end waits for THOSE
+ * rows only (an event, not the stream: the search of another roots handle may already be queued behind them on the same engine -- the
+ * vectorised collector keeps the device busy with one env group while the host steps the other's environments,
+ * muzero_collector.py:557-692 is a strictly serial loop) and copies the header words (and the root policy logits when they were asked
+ * for) out.  One pair in flight per roots handle. */
+int lz_roots_collect_rows_begin(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor, const float *d_obs,
+                                int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, int want_logits);
+int lz_roots_collect_rows_end(lz_roots *r, float *h_header, float *h_policy_logits);
 /* Roots.prepare / prepare_no_noise with the policy logits of lz_initial_inference (value prefix 0 for
  * EfficientZero, efficientzero_model.py:238).  h_noises_flat as in lz_roots_prepare (NULL: no noise). */
 int lz_roots_prepare_from_inference(lz_roots *r, float root_noise_weight, const float *h_noises_flat,

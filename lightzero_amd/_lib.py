@@ -95,6 +95,11 @@ def lib():
         "lz_model_set_tensor": [P, ctypes.c_char_p, c_f32p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
         "lz_model_set_tensor_device": [P, ctypes.c_char_p, P, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
         "lz_model_finalize": [P],
+        "lz_model_flat_layout": [P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)],
+        "lz_model_flat_entry": [P, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)],
+        "lz_model_flat_host_buffer": [P, ctypes.POINTER(ctypes.POINTER(ctypes.c_float))],
+        "lz_model_refresh_flat": [P, P, ctypes.c_int64, ctypes.c_int],
+        "lz_model_weights_digest": [P, ctypes.POINTER(ctypes.c_uint64)],
         "lz_initial_inference": [P, P],
         "lz_initial_inference_host": [P, c_f32p],
         "lz_roots_get_root_outputs": [P, c_f32p, c_f32p],
@@ -123,6 +128,8 @@ def lib():
         "lz_wino_weights": [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p],
         "lz_rows_extra_words": [P],
         "lz_roots_collect_rows_ex": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_float, P, ctypes.c_int, P, P, ctypes.c_int, c_f32p, P],
+        "lz_roots_collect_rows_begin": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_float, P, ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int],
+        "lz_roots_collect_rows_end": [P, c_f32p, P],
         "lz_roots_collect_rows": [P, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, P, ctypes.c_int, P, P, ctypes.c_int, c_f32p, P],
     }
     for name, argtypes in sig.items():

@@ -291,6 +291,7 @@ extern "C" int lz_roots_destroy(lz_roots *r)
     if (r->h_results) (void)hipHostFree(r->h_results);
     if (r->prep_done) (void)hipEventDestroy(r->prep_done);
     if (r->stage_done) (void)hipEventDestroy(r->stage_done);
+    if (r->rows_done) (void)hipEventDestroy(r->rows_done);
     if (r->d_reuse) (void)hipFree(r->d_reuse);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_stage) (void)hipFree(r->d_stage);

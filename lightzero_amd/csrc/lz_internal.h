@@ -173,6 +173,11 @@ struct lz_roots {
     size_t prep_bytes = 0;           // upload can stay asynchronous
     hipEvent_t prep_done = nullptr;  // recorded after that upload: the buffer is rewritten only once it has fired
     void *d_results = nullptr, *h_results = nullptr;  // lz_roots_get_search_results: one packed block, device + pinned host
+    // env-step rows in flight (lz_roots_collect_rows_begin / _end): the event behind the row kernel and where the header words land
+    hipEvent_t rows_done = nullptr;
+    bool rows_pending = false, rows_logits = false;
+    float *rows_hh = nullptr;
+    size_t rows_B = 0, rows_hw = 0, rows_pa = 0;
     int g_sims = -1, g_m = -1;      // Gumbel MuZero: (num_simulations, max_num_considered_actions) of the uploaded visit table
     void *d_reuse = nullptr;        // ReZero fused search: true_action [B] | reuse_value [B] | per-simulation inference counts [NN]
     float *d_given = nullptr;       // Sampled-EZ parity runs: [records][B][K][D] injected draws (record 0 = roots, s + 1 = simulation s)

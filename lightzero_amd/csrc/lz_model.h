@@ -42,9 +42,64 @@ struct C1W {
     float *w = nullptr, *b = nullptr, *s = nullptr, *t = nullptr;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Weight refresh on the device (lz_model_refresh_flat).  In the reference the collector searches with the learner's own nn.Module
+// (lzero/policy/muzero.py:1049-1061): fresh weights cost nothing.  Here the weights live in kernel layouts, so a refresh re-lays them
+// out -- lz_model_finalize does that on the host.  The SAME packer code (Builder below) is run once more in RECORDING mode on tensors
+// that hold, instead of values, the CODE of their own elements: source space = [1.0f | the raw state_dict tensors, flat, in name
+// order | derived tensors]; element i of the space has code (float)(i + 1), the literal 0.0f stays "zero" and the literal 1.0f is the
+// code of the constant at index 0 -- so every pure re-ordering (fragment orders, transposes, column permutations, zero / one padding)
+// runs unchanged and what it "uploads" is, read back as integers, the gather map of that device buffer.  The arithmetic packers
+// (BatchNorm folding, Winograd U = G g G^T in binary64, the one-hot action table, the LSTM bias sum) register a DERIVED tensor computed
+// by a kernel of its own (same operations, same order, contraction off: bit-identical to the host) and hand out its codes.  A refresh is
+// then: the flat state_dict into the source buffer (one copy), four small kernels for the derived tensors, one gather kernel over
+// all weight buffers -- on the engine's stream, no host synchronisation, same buffers (captured graphs stay valid).
+struct RefreshRec {
+    std::vector<std::string> names;          // raw tensors in flat order (std::map order == Python's sorted())
+    std::vector<int64_t> offsets, sizes;     // in floats within the raw region
+    int64_t raw_floats = 0, derived_floats = 0;
+    struct Bn { int32_t w, b, mu, var, n, out; float eps; };
+    struct Wino { int32_t w, cout, cin_total, cin, out; };          // out: U[cout][cin][16] (point = 4 i + j)
+    struct Act { int32_t w, A, AE, C, SW, SH, out; };               // out: [A][SH * SW][C]
+    struct Add { int32_t a, b, n, out; };
+    std::vector<Bn> bn;
+    std::vector<Wino> wino;
+    std::vector<Act> act;
+    std::vector<Add> add;
+    std::vector<int32_t> idx;                // concatenated gather maps (-1: 0.0f)
+    struct Slot { float *dst; int64_t start, count; };
+    std::vector<Slot> slots;
+    bool ok = true;
+    std::string why;
+    int64_t derived(int64_t n) { const int64_t o = 1 + raw_floats + derived_floats; derived_floats += n; return o; }   // source index of a new derived region
+    static float code(int64_t src_index) { return (float)(src_index + 1); }
+    static int64_t index_of(float code) { return (int64_t)code - 1; }
+    void fail(const std::string &w) { if (ok) { ok = false; why = w; } }
+};
+struct RefreshProgram {
+    bool tried = false, usable = false;
+    std::string why;
+    std::vector<std::string> names;
+    std::vector<int64_t> offsets, sizes;
+    int64_t raw_floats = 0, src_floats = 0, out_floats = 0;
+    float *d_src = nullptr;
+    int32_t *d_idx = nullptr;
+    void *d_slots = nullptr;    // RefreshRec::Slot[n_slots]
+    int n_slots = 0;
+    void *d_bn = nullptr, *d_wino = nullptr, *d_act = nullptr, *d_add = nullptr;
+    int n_bn = 0, n_wino = 0, n_act = 0, n_add = 0;
+    int64_t wino_items = 0, act_items = 0;   // largest op, for the grid
+    int bn_max = 0, add_max = 0;
+    size_t n_allocs = 0;                     // the weight buffers the program was recorded for (lz_model::allocs.size())
+    void *h_pin = nullptr;                   // pinned staging for a host-side flat state_dict
+};
+
 struct lz_model {
     lz_model_cfg cfg{};
     std::map<std::string, HostTensor> raw;
+    bool raw_stale = false;              // a device refresh replaced the weights without passing through `raw`: lz_model_set_tensor
+                                         // brings `raw` up to date from the source buffer first
+    RefreshProgram refresh;
     bool finalized = false;
     std::vector<void *> allocs;          // device weight buffers in upload order
     std::vector<size_t> alloc_bytes;     // their sizes: a re-finalize with the same shapes copies in place (pointers stay valid,
@@ -88,6 +143,9 @@ namespace {
 struct Builder {
     lz_model *m;
     std::string err;
+    RefreshRec *rec = nullptr;   // recording mode: tensors hold codes, upload() records gather maps (see RefreshRec)
+    // source index of element 0 of a (shadow) tensor
+    int32_t src0(const HostTensor *t) const { return t && !t->data.empty() ? (int32_t)RefreshRec::index_of(t->data[0]) : -1; }
     const HostTensor *get(const std::string &name, std::initializer_list<int64_t> shape)
     {
         auto it = m->raw.find(name);
@@ -106,6 +164,20 @@ struct Builder {
     {
         const size_t bytes = v.size() * 4;
         float *d = nullptr;
+        if (rec) {   // the buffer of this position exists (same configuration, same shapes): record what it is gathered from
+            if (m->alloc_cursor >= m->allocs.size() || m->alloc_bytes[m->alloc_cursor] != bytes) {
+                rec->fail("weight buffer layout changed between the finalize and its recording");
+                m->alloc_cursor++;
+                return nullptr;
+            }
+            d = (float *)m->allocs[m->alloc_cursor++];
+            rec->slots.push_back(RefreshRec::Slot{d, (int64_t)rec->idx.size(), (int64_t)v.size()});
+            for (float c : v) {
+                if (!(c >= 0.0f && c < 16777216.0f && c == floorf(c))) { rec->fail("a packer produced a value that is not an element code"); c = 0.0f; }
+                rec->idx.push_back((int32_t)c - 1);
+            }
+            return d;
+        }
         if (m->alloc_cursor < m->allocs.size() && m->alloc_bytes[m->alloc_cursor] == bytes) {
             d = (float *)m->allocs[m->alloc_cursor];
         } else {
@@ -129,6 +201,12 @@ struct Builder {
         scale.assign(n, 1.0f);
         shift.assign(n, 0.0f);
         if (!w || !b || !mu || !var) return;
+        if (rec) {   // derived tensor [scale n | shift n], computed by k_refresh_bn with the expressions below
+            const int64_t o = rec->derived(2 * (int64_t)n);
+            rec->bn.push_back(RefreshRec::Bn{src0(w), src0(b), src0(mu), src0(var), n, (int32_t)o, m->cfg.bn_eps});
+            for (int i = 0; i < n; ++i) { scale[i] = RefreshRec::code(o + i); shift[i] = RefreshRec::code(o + n + i); }
+            return;
+        }
         for (int i = 0; i < n; ++i) {
             const float inv = 1.0f / sqrtf(var->data[i] + m->cfg.bn_eps);
             scale[i] = w->data[i] * inv;
@@ -241,12 +319,15 @@ struct Builder {
         const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
         if (!w || cout != 64 || (cin & 3)) return nullptr;
         std::vector<float> f((size_t)16 * cin * cout);
+        const int64_t o = rec ? rec->derived((int64_t)cout * cin * 16) : 0;   // derived tensor U[cout][cin][16] (k_refresh_wino)
+        if (rec) rec->wino.push_back(RefreshRec::Wino{src0(w), cout, cin_total, cin, (int32_t)o});
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci) {
                 double U[4][4];
-                wino_u(&w->data[((size_t)co * cin_total + ci) * 9], U);
+                if (!rec) wino_u(&w->data[((size_t)co * cin_total + ci) * 9], U);
                 for (int p = 0; p < 16; ++p)
-                    f[((((size_t)p * (cin / 4) + ci / 4) * cout) + co) * 4 + (ci & 3)] = (float)U[p / 4][p % 4];
+                    f[((((size_t)p * (cin / 4) + ci / 4) * cout) + co) * 4 + (ci & 3)] =
+                        rec ? RefreshRec::code(o + ((int64_t)co * cin + ci) * 16 + p) : (float)U[p / 4][p % 4];
             }
         return upload(f);
     }
@@ -258,13 +339,16 @@ struct Builder {
         if (!w) return nullptr;
         const int G = cin / 16;
         std::vector<float> f((size_t)cout * cin * 16);
+        const int64_t o = rec ? rec->derived((int64_t)cout * cin * 16) : 0;
+        if (rec) rec->wino.push_back(RefreshRec::Wino{src0(w), cout, cin, cin, (int32_t)o});
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci) {
                 double U[4][4];
-                wino_u(&w->data[((size_t)co * cin + ci) * 9], U);
+                if (!rec) wino_u(&w->data[((size_t)co * cin + ci) * 9], U);
                 const int nt = co / 16, n = co % 16, gq = ci / 16, kq = (ci % 16) / 4, jj = ci % 4, lane = kq * 16 + n;
                 for (int p = 0; p < 16; ++p)
-                    f[((((size_t)nt * 16 + p) * G + gq) * 64 + lane) * 4 + jj] = (float)U[p / 4][p % 4];
+                    f[((((size_t)nt * 16 + p) * G + gq) * 64 + lane) * 4 + jj] =
+                        rec ? RefreshRec::code(o + ((int64_t)co * cin + ci) * 16 + p) : (float)U[p / 4][p % 4];
             }
         return upload(f);
     }

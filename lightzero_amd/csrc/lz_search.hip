@@ -21,9 +21,11 @@
 #include "lz_model.h"
 #include "lz_mlp.h"
 
+static void refresh_program_free(lz_model *m);
 void lz_model_destroy(lz_model *m)
 {
     if (!m) return;
+    refresh_program_free(m);
     for (void *p : m->allocs) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (m->ws[i]) (void)hipFree(m->ws[i]);
     if (m->mlp) lz_mlp_model_destroy(m->mlp);
@@ -125,10 +127,13 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     return LZ_OK;
 }
 
+static int refresh_materialize_raw(lz_engine *e);
+
 extern "C" int lz_model_set_tensor(lz_engine *e, const char *name, const float *h_data, const int64_t *shape, int ndim)
 {
     LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
     LZ_REQUIRE(name && h_data && (shape || ndim == 0) && ndim >= 0 && ndim <= 4, "bad tensor argument");
+    if (e->model->raw_stale) { if (int rc = refresh_materialize_raw(e)) return rc; }
     HostTensor t;
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
@@ -147,6 +152,7 @@ extern "C" int lz_model_set_tensor_device(lz_engine *e, const char *name, const 
     LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
     LZ_REQUIRE(name && d_data && (shape || ndim == 0) && ndim >= 0 && ndim <= 4, "bad tensor argument");
     LZ_HIP_CHECK(hipSetDevice(e->device));
+    if (e->model->raw_stale) { if (int rc = refresh_materialize_raw(e)) return rc; }
     HostTensor t;
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
@@ -157,6 +163,9 @@ extern "C" int lz_model_set_tensor_device(lz_engine *e, const char *name, const 
     e->model->finalized = false;
     return LZ_OK;
 }
+
+static void finalize_conv_layouts(lz_model *m, Builder &b);
+static void refresh_program_free(lz_model *m);
 
 extern "C" int lz_model_finalize(lz_engine *e)
 {
@@ -181,12 +190,29 @@ extern "C" int lz_model_finalize(lz_engine *e)
         }
     } gen_bump{e, m};
     if (m->cfg.model_type >= 2) return lz_mlp_finalize(e);
+    Builder b{m, ""};
+    finalize_conv_layouts(m, b);
+    if (!b.err.empty()) {
+        lz_set_error("lz_model_finalize: %s", b.err.c_str());
+        return LZ_ERR_STATE;
+    }
+    LZ_HIP_CHECK(hipDeviceSynchronize());  // weight uploads went through the null stream; the engine stream does not order against it
+    m->finalized = true;
+    m->raw_stale = false;
+    if (m->refresh.tried && m->refresh.n_allocs != m->allocs.size()) refresh_program_free(m);   // (other shapes: recorded for other buffers)
+    if (m->realloc_happened) refresh_program_free(m);
+    return LZ_OK;
+}
+
+// every device layout of a convolutional model's weights, in a fixed upload order (Builder::upload).  Runs in two modes: on the
+// state_dict's values (lz_model_finalize) and on element codes (Builder::rec: the recording pass of the device-side refresh, lz_model.h)
+static void finalize_conv_layouts(lz_model *m, Builder &b)
+{
     const lz_model_cfg &c = m->cfg;
     const int C = c.num_channels, C2 = C / 2, A = c.action_space_size, HC = c.head_channels, HID = c.head_hidden,
               H = c.lstm_hidden_size, HW = m->HWl, SUP = c.support_size, NRB = c.num_res_blocks > 0 ? c.num_res_blocks : 1;
     const int RSUP = c.reward_support_size > 0 ? c.reward_support_size : SUP;
     const int AE = c.action_encoding == 1 ? 1 : A;   // action planes of the dynamics convolution's input (efficientzero_model.py:105-108)
-    Builder b{m, ""};
     const bool wchain = C == 64 && ((m->GW == 6 && m->GH == 6) || (m->GW == 8 && m->GH == 8));  // these chains run on Winograd-transformed weights (k_chain_w)
     // ---- representation (common.py:266-365, :706-787)
     {
@@ -256,6 +282,11 @@ extern "C" int lz_model_finalize(lz_engine *e)
         if (w) {
             const int SW = m->GW, SH = m->GH;
             std::vector<float> tab((size_t)A * HW * C);
+            if (b.rec) {   // derived tensor, already in the table's own order (k_refresh_act evaluates the loop below)
+                const int64_t o = b.rec->derived((int64_t)tab.size());
+                b.rec->act.push_back(RefreshRec::Act{b.src0(w), A, AE, C, SW, SH, (int32_t)o});
+                for (size_t i = 0; i < tab.size(); ++i) tab[i] = RefreshRec::code(o + (int64_t)i);
+            } else
             for (int a = 0; a < A; ++a)
                 for (int y = 0; y < SH; ++y)
                     for (int x = 0; x < SW; ++x)
@@ -287,13 +318,15 @@ extern "C" int lz_model_finalize(lz_engine *e)
                          *bih = b.get(d + "lstm.bias_ih_l0", {4 * H}), *bhh = b.get(d + "lstm.bias_hh_l0", {4 * H});
         if (wih && whh && bih && bhh) {
             std::vector<float> wc((size_t)4 * H * K), bc((size_t)4 * H);
+            const int64_t o_bias = b.rec ? b.rec->derived(4 * (int64_t)H) : 0;   // derived tensor bias_ih + bias_hh in the reference's row order
+            if (b.rec) b.rec->add.push_back(RefreshRec::Add{b.src0(bih), b.src0(bhh), 4 * H, (int32_t)o_bias});
             for (int g = 0; g < 4; ++g)
                 for (int u = 0; u < H; ++u) {
                     const int src = g * H + u, dst = 4 * u + g;
                     for (int p = 0; p < HW; ++p)
                         for (int ch = 0; ch < HC; ++ch) wc[(size_t)dst * K + p * HC + ch] = wih->data[(size_t)src * KX + ch * HW + p];
                     for (int k = 0; k < H; ++k) wc[(size_t)dst * K + KX + k] = whh->data[(size_t)src * H + k];
-                    bc[dst] = bih->data[src] + bhh->data[src];
+                    bc[dst] = b.rec ? RefreshRec::code(o_bias + src) : bih->data[src] + bhh->data[src];
                 }
             m->lstm_w = b.upload(wc);
             m->lstm_b = b.upload(bc);
@@ -372,12 +405,263 @@ extern "C" int lz_model_finalize(lz_engine *e)
             m->sh_w1r = b.upload(wr);
         }
     }
-    if (!b.err.empty()) {
-        lz_set_error("lz_model_finalize: %s", b.err.c_str());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side weight refresh (RefreshRec / RefreshProgram in lz_model.h): the derived-tensor kernels and the gather.
+// The arithmetic below is the host packers' (Builder::bn, Builder::wino_u, the action table and the LSTM bias of
+// finalize_conv_layouts), operation by operation, with FMA contraction off: tests/test_weight_refresh_gpu.py holds the refreshed
+// buffers bit-equal to a host finalize of the same state_dict.
+#pragma clang fp contract(off)
+__global__ void k_refresh_bn(float *src, const RefreshRec::Bn *ops)
+{
+    const RefreshRec::Bn o = ops[blockIdx.x];
+    for (int i = threadIdx.x; i < o.n; i += blockDim.x) {
+        const float inv = 1.0f / sqrtf(src[o.var + i] + o.eps);
+        const float scale = src[o.w + i] * inv;
+        src[o.out + i] = scale;
+        src[o.out + o.n + i] = src[o.b + i] - src[o.mu + i] * scale;
+    }
+}
+__global__ void k_refresh_add(float *src, const RefreshRec::Add *ops)
+{
+    const RefreshRec::Add o = ops[blockIdx.x];
+    for (int i = threadIdx.x; i < o.n; i += blockDim.x) src[o.out + i] = src[o.a + i] + src[o.b + i];
+}
+// U = G g G^T per (cout, cin) filter in binary64, rounded once (Builder::wino_u); one thread per filter
+__global__ void k_refresh_wino(float *src, const RefreshRec::Wino *ops)
+{
+    const RefreshRec::Wino o = ops[blockIdx.y];
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= o.cout * o.cin) return;
+    const int co = f / o.cin, ci = f - co * o.cin;
+    const float *g = src + o.w + ((size_t)co * o.cin_total + ci) * 9;
+    const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    double t[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[i][k] = Gm[i][0] * g[0 * 3 + k] + Gm[i][1] * g[1 * 3 + k] + Gm[i][2] * g[2 * 3 + k];
+    float *out = src + o.out + (size_t)f * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = (float)(t[i][0] * Gm[j][0] + t[i][1] * Gm[j][1] + t[i][2] * Gm[j][2]);
+}
+// the one-hot (or single-plane) action table: sum of the in-bounds taps of the action's input plane, per (action, pixel, channel)
+__global__ void k_refresh_act(float *src, const RefreshRec::Act *ops)
+{
+    const RefreshRec::Act o = ops[blockIdx.y];
+    const int HW = o.SW * o.SH, n = o.A * HW * o.C;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = i % o.C, pix = (i / o.C) % HW, a = i / (o.C * HW), y = pix / o.SW, x = pix - y * o.SW;
+    float acc = 0.0f;
+    const float plane = o.AE == 1 ? (float)a / (float)o.A : 1.0f;
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy >= 0 && iy < o.SH && ix >= 0 && ix < o.SW) acc += src[o.w + ((size_t)co * (o.C + o.AE) + o.C + (o.AE == 1 ? 0 : a)) * 9 + t] * plane;
+    }
+    src[o.out + i] = acc;
+}
+#pragma clang fp contract(fast)
+// every weight buffer from the source space: slot s covers idx[start .. start + count)
+__global__ void k_refresh_gather(const float *__restrict__ src, const int32_t *__restrict__ idx, const RefreshRec::Slot *__restrict__ slots, int n_slots, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = n_slots - 1;   // the slot that holds element i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (slots[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const int32_t k = idx[i];
+    slots[lo].dst[i - slots[lo].start] = k < 0 ? 0.0f : src[k];
+}
+
+static void refresh_program_free(lz_model *m)
+{
+    RefreshProgram &p = m->refresh;
+    for (void *q : {(void *)p.d_src, (void *)p.d_idx, p.d_slots, p.d_bn, p.d_wino, p.d_act, p.d_add}) if (q) (void)hipFree(q);
+    if (p.h_pin) (void)hipHostFree(p.h_pin);
+    p = RefreshProgram{};
+}
+
+// the recording pass: finalize_conv_layouts once more, on element codes (see RefreshRec)
+static int refresh_program_build(lz_engine *e)
+{
+    lz_model *m = e->model;
+    RefreshProgram &p = m->refresh;
+    refresh_program_free(m);
+    p.tried = true;
+    p.n_allocs = m->allocs.size();
+    if (m->cfg.model_type >= 2) { p.why = "vector-observation (MLP) models re-lay their weights out on the host"; return LZ_OK; }
+    if (m->cfg.precision != 0) { p.why = "fast mode (bf16 fragments) re-lays its weights out on the host"; return LZ_OK; }
+    if (!m->finalized || m->raw_stale) { p.why = "no finalized host copy of the weights to record from"; return LZ_OK; }
+    RefreshRec rec;
+    std::map<std::string, HostTensor> shadow;
+    for (const auto &kv : m->raw) {   // std::map order == sorted names == the flat layout
+        HostTensor t;
+        t.shape = kv.second.shape;
+        const int64_t n = (int64_t)kv.second.data.size();
+        rec.names.push_back(kv.first); rec.offsets.push_back(rec.raw_floats); rec.sizes.push_back(n);
+        t.data.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) t.data[(size_t)i] = RefreshRec::code(1 + rec.raw_floats + i);
+        rec.raw_floats += n;
+        shadow[kv.first] = std::move(t);
+    }
+    m->raw.swap(shadow);
+    const size_t cursor = m->alloc_cursor;
+    const bool realloc_flag = m->realloc_happened;
+    m->alloc_cursor = 0;
+    Builder b{m, ""};
+    b.rec = &rec;
+    finalize_conv_layouts(m, b);
+    m->raw.swap(shadow);
+    if (m->alloc_cursor != m->allocs.size()) rec.fail("the recording pass produced another number of weight buffers");
+    m->alloc_cursor = cursor;
+    m->realloc_happened = realloc_flag;
+    if (!b.err.empty()) rec.fail(b.err);
+    const int64_t src_floats = 1 + rec.raw_floats + rec.derived_floats;
+    if (src_floats + 1 >= (int64_t)1 << 24) rec.fail("more than 2^24 source elements: codes are no longer exact in binary32");
+    if (!rec.ok) { p.why = rec.why; return LZ_OK; }
+    p.names = rec.names; p.offsets = rec.offsets; p.sizes = rec.sizes;
+    p.raw_floats = rec.raw_floats; p.src_floats = src_floats; p.out_floats = (int64_t)rec.idx.size();
+    auto up = [&](void **d, const void *h, size_t bytes) -> bool {
+        if (!bytes) return true;
+        if (lz_dev_malloc(d, bytes) != hipSuccess) return false;
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = lz_dev_malloc((void **)&p.d_src, (size_t)src_floats * 4) == hipSuccess;
+    const float one = 1.0f;
+    ok = ok && hipMemcpy(p.d_src, &one, 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && up((void **)&p.d_idx, rec.idx.data(), rec.idx.size() * 4);
+    ok = ok && up(&p.d_slots, rec.slots.data(), rec.slots.size() * sizeof(RefreshRec::Slot));
+    ok = ok && up(&p.d_bn, rec.bn.data(), rec.bn.size() * sizeof(RefreshRec::Bn));
+    ok = ok && up(&p.d_wino, rec.wino.data(), rec.wino.size() * sizeof(RefreshRec::Wino));
+    ok = ok && up(&p.d_act, rec.act.data(), rec.act.size() * sizeof(RefreshRec::Act));
+    ok = ok && up(&p.d_add, rec.add.data(), rec.add.size() * sizeof(RefreshRec::Add));
+    if (!ok) { refresh_program_free(m); p.tried = true; p.why = "out of device memory for the refresh program"; return LZ_OK; }
+    p.n_slots = (int)rec.slots.size(); p.n_bn = (int)rec.bn.size(); p.n_wino = (int)rec.wino.size(); p.n_act = (int)rec.act.size(); p.n_add = (int)rec.add.size();
+    for (const auto &o : rec.wino) p.wino_items = std::max<int64_t>(p.wino_items, (int64_t)o.cout * o.cin);
+    for (const auto &o : rec.act) p.act_items = std::max<int64_t>(p.act_items, (int64_t)o.A * o.SW * o.SH * o.C);
+    p.n_allocs = m->allocs.size();
+    p.usable = true;
+    return LZ_OK;
+}
+
+static int refresh_ready(lz_engine *e)
+{
+    LZ_REQUIRE(e != nullptr && e->model != nullptr, "no model: call lz_model_create first");
+    LZ_REQUIRE(e->model->finalized, "the model has not been loaded yet: the first load goes through lz_model_set_tensor + lz_model_finalize");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    if (!e->model->refresh.tried) { if (int rc = refresh_program_build(e)) return rc; }
+    if (!e->model->refresh.usable) {
+        lz_set_error("no device-side refresh for this model: %s", e->model->refresh.why.c_str());
         return LZ_ERR_STATE;
     }
-    LZ_HIP_CHECK(hipDeviceSynchronize());  // weight uploads went through the null stream; the engine stream does not order against it
-    m->finalized = true;
+    return LZ_OK;
+}
+
+extern "C" int lz_model_flat_layout(lz_engine *e, int64_t *out_tensors, int64_t *out_floats)
+{
+    if (int rc = refresh_ready(e)) return rc;
+    if (out_tensors) *out_tensors = (int64_t)e->model->refresh.names.size();
+    if (out_floats) *out_floats = e->model->refresh.raw_floats;
+    return LZ_OK;
+}
+
+extern "C" int lz_model_flat_entry(lz_engine *e, int64_t i, char *name_buf, int64_t name_buf_len, int64_t *out_offset, int64_t *out_size)
+{
+    if (int rc = refresh_ready(e)) return rc;
+    const RefreshProgram &p = e->model->refresh;
+    LZ_REQUIRE(i >= 0 && i < (int64_t)p.names.size() && name_buf && name_buf_len > 0, "entry index out of range");
+    snprintf(name_buf, (size_t)name_buf_len, "%s", p.names[(size_t)i].c_str());
+    LZ_REQUIRE((int64_t)p.names[(size_t)i].size() < name_buf_len, "name buffer too short");
+    if (out_offset) *out_offset = p.offsets[(size_t)i];
+    if (out_size) *out_size = p.sizes[(size_t)i];
+    return LZ_OK;
+}
+
+// the pinned host staging buffer of the flat state_dict (raw_floats floats), free to be written: the upload of the previous refresh out
+// of it has completed when this returns
+extern "C" int lz_model_flat_host_buffer(lz_engine *e, float **out)
+{
+    if (int rc = refresh_ready(e)) return rc;
+    RefreshProgram &p = e->model->refresh;
+    LZ_REQUIRE(out != nullptr, "NULL argument");
+    if (!p.h_pin) LZ_HIP_CHECK(hipHostMalloc(&p.h_pin, (size_t)p.raw_floats * 4, hipHostMallocDefault));
+    else LZ_HIP_CHECK(hipStreamSynchronize(e->stream));
+    *out = (float *)p.h_pin;
+    return LZ_OK;
+}
+
+// flat: the model's state_dict tensors (without num_batches_tracked), fp32, concatenated in name order (lz_model_flat_entry) -- a device
+// pointer (on_device != 0: e.g. the buffer an RCCL broadcast filled; the caller has made sure its producer is done) or a host pointer.
+// Everything is enqueued on the engine's stream: searches launched before see the old weights, searches launched after the new ones.
+extern "C" int lz_model_refresh_flat(lz_engine *e, const float *flat, int64_t n_floats, int on_device)
+{
+    if (int rc = refresh_ready(e)) return rc;
+    lz_model *m = e->model;
+    RefreshProgram &p = m->refresh;
+    LZ_REQUIRE(flat != nullptr && n_floats == p.raw_floats, "flat state_dict of another size than the model's tensors");
+    hipStream_t s = e->stream;
+    if (on_device) {
+        LZ_HIP_CHECK(hipMemcpyAsync(p.d_src + 1, flat, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        // through pinned staging, so that the copy is one asynchronous DMA (a pageable source is staged piecewise by the runtime).  A
+        // caller that filled the staging buffer itself (lz_model_flat_host_buffer) passes its address: no second copy.
+        if (flat != (const float *)p.h_pin) {
+            float *pin = nullptr;
+            if (int rc = lz_model_flat_host_buffer(e, &pin)) return rc;   // (waits for the previous upload out of this buffer)
+            memcpy(pin, flat, (size_t)n_floats * 4);
+        }
+        LZ_HIP_CHECK(hipMemcpyAsync(p.d_src + 1, p.h_pin, (size_t)n_floats * 4, hipMemcpyHostToDevice, s));
+    }
+    if (p.n_bn) hipLaunchKernelGGL(k_refresh_bn, dim3((unsigned)p.n_bn), dim3(256), 0, s, p.d_src, (const RefreshRec::Bn *)p.d_bn);
+    if (p.n_add) hipLaunchKernelGGL(k_refresh_add, dim3((unsigned)p.n_add), dim3(256), 0, s, p.d_src, (const RefreshRec::Add *)p.d_add);
+    if (p.n_wino) hipLaunchKernelGGL(k_refresh_wino, dim3((unsigned)((p.wino_items + 255) / 256), (unsigned)p.n_wino), dim3(256), 0, s, p.d_src, (const RefreshRec::Wino *)p.d_wino);
+    if (p.n_act) hipLaunchKernelGGL(k_refresh_act, dim3((unsigned)((p.act_items + 255) / 256), (unsigned)p.n_act), dim3(256), 0, s, p.d_src, (const RefreshRec::Act *)p.d_act);
+    hipLaunchKernelGGL(k_refresh_gather, dim3((unsigned)((p.out_floats + 255) / 256)), dim3(256), 0, s, p.d_src, p.d_idx, (const RefreshRec::Slot *)p.d_slots, p.n_slots, p.out_floats);
+    LZ_HIP_CHECK(hipGetLastError());
+    m->raw_stale = true;
+    return LZ_OK;
+}
+
+// `raw` (the host copy lz_model_finalize reads) after device-side refreshes: read it back from the source buffer
+static int refresh_materialize_raw(lz_engine *e)
+{
+    lz_model *m = e->model;
+    RefreshProgram &p = m->refresh;
+    LZ_REQUIRE(p.usable && p.d_src, "the host copy of the weights is stale and there is no source buffer to restore it from");
+    std::vector<float> flat((size_t)p.raw_floats);
+    LZ_HIP_CHECK(hipMemcpyAsync(flat.data(), p.d_src + 1, flat.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    LZ_HIP_CHECK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < p.names.size(); ++i) {
+        auto it = m->raw.find(p.names[i]);
+        if (it == m->raw.end() || (int64_t)it->second.data.size() != p.sizes[i]) continue;
+        memcpy(it->second.data.data(), flat.data() + p.offsets[i], (size_t)p.sizes[i] * 4);
+    }
+    m->raw_stale = false;
+    return LZ_OK;
+}
+
+// FNV-1a over every device weight buffer in upload order (tests: a device-side refresh must leave exactly the bytes a host finalize
+// of the same state_dict leaves)
+extern "C" int lz_model_weights_digest(lz_engine *e, uint64_t *out)
+{
+    LZ_REQUIRE(e != nullptr && e->model != nullptr && out != nullptr, "NULL argument");
+    LZ_HIP_CHECK(hipSetDevice(e->device));
+    LZ_HIP_CHECK(hipStreamSynchronize(e->stream));
+    uint64_t h = 1469598103934665603ull;
+    std::vector<unsigned char> buf;
+    for (size_t i = 0; i < e->model->allocs.size(); ++i) {
+        buf.resize(e->model->alloc_bytes[i]);
+        if (buf.empty()) continue;
+        LZ_HIP_CHECK(hipMemcpy(buf.data(), e->model->allocs[i], buf.size(), hipMemcpyDeviceToHost));
+        for (unsigned char c : buf) { h ^= c; h *= 1099511628211ull; }
+    }
+    *out = h;
     return LZ_OK;
 }
 
@@ -1023,11 +1307,37 @@ extern "C" int lz_wino_weights(const float *w, int cout, int cin, float *u)
     return LZ_OK;
 }
 
-extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
-                                     int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
-                                     float *h_header, float *h_policy_logits)
+// The read-back of the env-step rows is split in two so that a caller can keep the device busy: *_enqueue launches select_action + the
+// row packing behind the search and records an event; collect_rows_finish waits for THAT event (not for the stream: another roots
+// handle's search may already be queued behind it on the same engine -- the vectorised collector's env groups) and hands the header
+// words over.  lz_roots_collect_rows[_ex] = enqueue + finish.
+static int collect_rows_finish(lz_roots *r, float *h_header, float *h_policy_logits)
 {
-    LZ_REQUIRE(r != nullptr && d_rows != nullptr && h_header != nullptr, "NULL argument");
+    LZ_REQUIRE(r != nullptr && h_header != nullptr, "NULL argument");
+    LZ_REQUIRE(r->rows_pending, "no env-step rows in flight: call lz_roots_collect_rows_begin first");
+    LZ_HIP_CHECK(hipEventSynchronize(r->rows_done));
+    r->rows_pending = false;
+    memcpy(h_header, r->rows_hh, r->rows_B * r->rows_hw * 4);
+    if (h_policy_logits) {
+        LZ_REQUIRE(r->rows_logits, "the rows were enqueued without the policy logits");
+        memcpy(h_policy_logits, r->rows_hh + r->rows_B * r->rows_hw, r->rows_B * r->rows_pa * 4);
+    }
+    return LZ_OK;
+}
+static int collect_rows_mark(lz_roots *r, float *hh, size_t B, size_t hw, size_t pa, bool logits, hipStream_t s)
+{
+    if (!r->rows_done) LZ_HIP_CHECK(hipEventCreateWithFlags(&r->rows_done, hipEventDisableTiming));
+    LZ_HIP_CHECK(hipEventRecord(r->rows_done, s));
+    r->rows_hh = hh; r->rows_B = B; r->rows_hw = hw; r->rows_pa = pa; r->rows_logits = logits; r->rows_pending = true;
+    return LZ_OK;
+}
+
+static int collect_rows_enqueue(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
+                                int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, bool want_logits)
+{
+    LZ_REQUIRE(r != nullptr && d_rows != nullptr, "NULL argument");
+    LZ_REQUIRE(!r->rows_pending, "env-step rows already in flight: call lz_roots_collect_rows_end first");
+    float *h_policy_logits = want_logits ? (float *)1 : nullptr;   // (only its null-ness is used below)
     LZ_REQUIRE(r->prepared && r->inferred && r->pool_slab != nullptr, "roots not searched through the fused path");
     LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "sampled roots: use lz_roots_get_search_results + the lz_sroots_* getters");
     LZ_REQUIRE(temperature > 0.0, "select_action needs a positive temperature");
@@ -1059,10 +1369,7 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
                            r->sim_logits, (int)PA, r->d_to_play, h_timestep ? (const int32_t *)r->h_results : nullptr, d_obs, obs_floats,
                            frame_floats, d_rows, row_words, hh, h_policy_logits ? hh + B * hw : nullptr);
         LZ_HIP_CHECK(hipGetLastError());
-        LZ_HIP_CHECK(hipStreamSynchronize(s));
-        memcpy(h_header, hh, B * hw * 4);
-        if (h_policy_logits) memcpy(h_policy_logits, hh + B * hw, B * PA * 4);
-        return LZ_OK;
+        return collect_rows_mark(r, hh, B, hw, PA, want_logits, s);
     }
     double *d_ent = (double *)r->d_results;
     int32_t *d_dist = (int32_t *)(d_ent + B), *d_cnt = d_dist + B * A, *d_pos = d_cnt + B, *d_ts = d_pos + B;
@@ -1083,10 +1390,16 @@ extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int determ
         LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
         LZ_HIP_CHECK(hipMemcpyAsync(hh + B * hw, d_lg, B * PA * 4, hipMemcpyDeviceToHost, s));
     }
-    LZ_HIP_CHECK(hipStreamSynchronize(s));
-    memcpy(h_header, hh, B * hw * 4);
-    if (h_policy_logits) memcpy(h_policy_logits, hh + B * hw, B * PA * 4);
-    return LZ_OK;
+    return collect_rows_mark(r, hh, B, hw, PA, want_logits, s);
+}
+
+extern "C" int lz_roots_collect_rows(lz_roots *r, double temperature, int deterministic, uint64_t seed, const float *d_obs,
+                                     int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
+                                     float *h_header, float *h_policy_logits)
+{
+    LZ_REQUIRE(h_header != nullptr, "NULL argument");
+    if (int rc = collect_rows_enqueue(r, temperature, deterministic, seed, d_obs, frame_floats, h_timestep, d_rows, row_words, h_policy_logits != nullptr)) return rc;
+    return collect_rows_finish(r, h_header, h_policy_logits);
 }
 
 // ---- env-step rows of the two further families that ship: an EXTRA block between the action mask and the frame carries what
@@ -1153,13 +1466,14 @@ extern "C" int lz_rows_extra_words(lz_roots *r)
     return 0;
 }
 
-extern "C" int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor,
-                                        const float *d_obs, int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
-                                        float *h_header, float *h_policy_logits)
+static int collect_rows_enqueue_ex(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor,
+                                   const float *d_obs, int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, bool want_logits)
 {
-    LZ_REQUIRE(r != nullptr && d_rows != nullptr && h_header != nullptr, "NULL argument");
+    LZ_REQUIRE(r != nullptr && d_rows != nullptr, "NULL argument");
     const int E = lz_rows_extra_words(r);
-    if (E == 0) return lz_roots_collect_rows(r, temperature, deterministic, seed, d_obs, frame_floats, h_timestep, d_rows, row_words, h_header, h_policy_logits);
+    if (E == 0) return collect_rows_enqueue(r, temperature, deterministic, seed, d_obs, frame_floats, h_timestep, d_rows, row_words, want_logits);
+    LZ_REQUIRE(!r->rows_pending, "env-step rows already in flight: call lz_roots_collect_rows_end first");
+    float *h_policy_logits = want_logits ? (float *)1 : nullptr;   // (only its null-ness is used below)
     LZ_REQUIRE(r->prepared && r->inferred && r->pool_slab != nullptr, "roots not searched through the fused path");
     LZ_REQUIRE(temperature > 0.0, "select_action needs a positive temperature");
     const lz_tree_dev &t = r->t;
@@ -1210,10 +1524,27 @@ extern "C" int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int det
         LZ_HIP_CHECK(hipMemcpyAsync(d_lg, r->sim_logits, B * PA * 4, hipMemcpyDeviceToDevice, s));
         LZ_HIP_CHECK(hipMemcpyAsync(hh + B * hw, d_lg, B * PA * 4, hipMemcpyDeviceToHost, s));
     }
-    LZ_HIP_CHECK(hipStreamSynchronize(s));
-    memcpy(h_header, hh, B * hw * 4);
-    if (h_policy_logits) memcpy(h_policy_logits, hh + B * hw, B * PA * 4);
-    return LZ_OK;
+    return collect_rows_mark(r, hh, B, hw, PA, want_logits, s);
+}
+
+extern "C" int lz_roots_collect_rows_ex(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor,
+                                        const float *d_obs, int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words,
+                                        float *h_header, float *h_policy_logits)
+{
+    LZ_REQUIRE(h_header != nullptr, "NULL argument");
+    if (int rc = collect_rows_enqueue_ex(r, temperature, deterministic, seed, discount_factor, d_obs, frame_floats, h_timestep, d_rows, row_words, h_policy_logits != nullptr)) return rc;
+    return collect_rows_finish(r, h_header, h_policy_logits);
+}
+
+extern "C" int lz_roots_collect_rows_begin(lz_roots *r, double temperature, int deterministic, uint64_t seed, float discount_factor,
+                                           const float *d_obs, int frame_floats, const int32_t *h_timestep, float *d_rows, int row_words, int want_logits)
+{
+    return collect_rows_enqueue_ex(r, temperature, deterministic, seed, discount_factor, d_obs, frame_floats, h_timestep, d_rows, row_words, want_logits != 0);
+}
+
+extern "C" int lz_roots_collect_rows_end(lz_roots *r, float *h_header, float *h_policy_logits)
+{
+    return collect_rows_finish(r, h_header, h_policy_logits);
 }
 
 extern "C" int lz_sroots_set_given(lz_roots *r, const float *h_draws, int records)

@@ -375,6 +375,26 @@ def make_module(variant, has_deterministic_flag):
                                                   hdr, lg.ctypes.data))
             return hdr, lg
 
+        def collect_rows_begin(self, temperature, deterministic, d_rows_ptr, row_words, frame_floats, timestep=None, seed=None,
+                               d_obs_ptr=None, discount=0.997, want_logits=False):
+            """first half of ``collect_rows`` (lz_roots_collect_rows_begin): select_action + row packing ENQUEUED behind the search, nothing
+            waited for -- the caller may enqueue other work (another env group's search) or do host work before ``collect_rows_end``"""
+            if seed is None:
+                seed = int(L.rs().randint(0, 2 ** 62))
+            ts = None if timestep is None else L.i32(timestep)
+            L.check(L.lib().lz_roots_collect_rows_begin(self._h, float(temperature), 1 if deterministic else 0, int(seed), float(discount), d_obs_ptr,
+                                                        int(frame_floats), None if ts is None else ts.ctypes.data, d_rows_ptr, int(row_words),
+                                                        1 if want_logits else 0))
+
+        def collect_rows_end(self, policy_width=None, want_logits=False):
+            """second half: waits for the rows enqueued by ``collect_rows_begin`` (their event only) -> (headers [B, 8 + 2A + extra], logits | None)"""
+            B, A = self.root_num, self._A
+            E = int(L.lib().lz_rows_extra_words(self._h))
+            hdr = np.zeros((B, 8 + 2 * A + E), np.float32)
+            lg = np.zeros((B, policy_width or A), np.float32) if want_logits else None
+            L.check(L.lib().lz_roots_collect_rows_end(self._h, hdr, None if lg is None else lg.ctypes.data))
+            return hdr, lg
+
         def select_action(self, temperature=1, deterministic=True, seed=None):
             """select_action (lzero/policy/utils.py:637-661) for every root on the device: returns (action positions
             [root_num], entropies in bits [root_num]).  deterministic=False draws from N^(1/T) with the engine's

@@ -146,6 +146,8 @@ class EfficientZeroModel(object):
         place on the device, roots and their captured search graphs stay valid."""
         self._check_owner()
         state_dict = unwrap_checkpoint(state_dict)
+        if self._loaded and self._refresh_on_device(state_dict):
+            return self
         synced = set()
         for name, value in state_dict.items():
             if name.endswith("num_batches_tracked"):
@@ -166,6 +168,71 @@ class EfficientZeroModel(object):
         L.check(L.lib().lz_model_finalize(self._engine))
         self._loaded = True
         return self
+
+    def _engine_waits_for_torch(self, device):
+        """order the engine's stream behind what torch has enqueued on its current stream of ``device`` (an event the engine's stream
+        waits for) -- the host does not wait: a collector that uploads the next frames asynchronously goes straight on to enqueue the search"""
+        import torch
+        ext = self.__dict__.setdefault("_ext_streams", {})
+        key = (device.type, device.index)
+        if key not in ext:
+            ext[key] = torch.cuda.ExternalStream(L.lib().lz_engine_stream(self._engine), device=device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ext[key].wait_event(ev)
+
+    def _refresh_on_device(self, sd):
+        """A weight REFRESH (the model is loaded already) through lz_model_refresh_flat: the state_dict as ONE flat fp32 buffer in the
+        library's name order -> every kernel layout by kernels on the engine's stream (bit-identical to the host re-layout; DESIGN
+        section 7).  Device tensors that already are consecutive views of one buffer (shard.broadcast_state_dict(on_device=True)) are
+        passed by pointer, other device tensors through one torch.cat, host arrays through the library's pinned staging buffer.
+        False: not applicable here (MLP family, fast mode, other names / shapes than the loaded ones) -> the caller's host path."""
+        lib = L.lib()
+        lay = self.__dict__.get("_flat_layout")
+        if lay is None:
+            nt, nf = ctypes.c_int64(0), ctypes.c_int64(0)
+            if lib.lz_model_flat_layout(self._engine, ctypes.byref(nt), ctypes.byref(nf)) != 0:
+                self._flat_layout = False
+                return False
+            ent, buf = [], ctypes.create_string_buffer(512)
+            for i in range(nt.value):
+                off, size = ctypes.c_int64(0), ctypes.c_int64(0)
+                L.check(lib.lz_model_flat_entry(self._engine, i, buf, 512, ctypes.byref(off), ctypes.byref(size)))
+                ent.append((buf.value.decode(), off.value, size.value))
+            lay = self._flat_layout = (ent, nf.value)
+        if lay is False:
+            return False
+        ent, total = lay
+        if sum(1 for k in sd if not k.endswith("num_batches_tracked")) != len(ent):
+            return False
+        vals = []
+        for name, off, size in ent:
+            v = sd.get(name)
+            if v is None or int(np.prod(np.shape(v))) != size:
+                return False
+            vals.append(v)
+        if all(getattr(v, "is_cuda", False) and str(v.dtype) == "torch.float32" and v.is_contiguous() for v in vals):
+            import torch
+            dev = vals[0].device
+            base = vals[0].data_ptr()
+            if all(v.device == dev and v.data_ptr() == base + 4 * off for v, (_, off, _) in zip(vals, ent)):
+                flat, ptr = vals, base      # consecutive views of one flat buffer (an RCCL broadcast): no copy at all
+            else:
+                flat = torch.cat([v.reshape(-1) for v in vals])
+                ptr = flat.data_ptr()
+            # the engine's stream waits for whatever produced the tensors on torch's stream -- an event, not a host synchronisation
+            self._engine_waits_for_torch(dev)
+            L.check(lib.lz_model_refresh_flat(self._engine, ptr, total, 1))
+            self._flat_keep = flat          # alive until the next refresh: the copy out of it is asynchronous
+            return True
+        pin = ctypes.POINTER(ctypes.c_float)()
+        L.check(lib.lz_model_flat_host_buffer(self._engine, ctypes.byref(pin)))
+        host = np.ctypeslib.as_array(pin, shape=(total,))
+        for v, (_, off, size) in zip(vals, ent):
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            host[off:off + size] = a.reshape(-1)    # (casts to float32 where the source is another type)
+        L.check(lib.lz_model_refresh_flat(self._engine, ctypes.cast(pin, ctypes.c_void_p), total, 0))
+        return True
 
     _is_lz_engine_model = True
     training = False    # torch.nn.Module.training of a model in eval() mode (the reference's _forward_eval reads it)
@@ -226,8 +293,7 @@ class EfficientZeroModel(object):
             if tuple(obs.shape) != (B,) + oshape or not obs.is_contiguous() or str(obs.dtype) != "torch.float32":
                 raise ValueError("obs must be a contiguous float32 [B, *observation_shape] tensor")
             if getattr(obs, "is_cuda", False):
-                import torch
-                torch.cuda.current_stream().synchronize()  # torch produced obs on its own stream
+                self._engine_waits_for_torch(obs.device)   # torch produced obs on its own stream
                 L.check(L.lib().lz_initial_inference(roots._h, obs.data_ptr()))
             else:
                 L.check(L.lib().lz_initial_inference_host(roots._h, np.ascontiguousarray(obs.numpy(), np.float32).reshape(-1)))

@@ -209,20 +209,32 @@ class EfficientZeroPolicy(CheckpointIngest):
 
     def forward_collect_rows(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None,
                              epsilon=0.25):
+        """``forward_collect_rows_begin`` + ``forward_collect_rows_end`` (see there)"""
+        return self.forward_collect_rows_end(self.forward_collect_rows_begin(data, action_mask, rows_out, temperature=temperature, to_play=to_play,
+                                                                             timestep=timestep, frame_floats=frame_floats, epsilon=epsilon))
+
+    def forward_collect_rows_begin(self, data, action_mask, rows_out, temperature=1, to_play=[-1], timestep=None, frame_floats=None,
+                                   epsilon=0.25):
         """The collect forward for a vectorised collector: same search as ``_forward_collect`` (engine model, device
         tensors), but what comes back is not a dict per env: ``rows_out`` -- a float32 [B, W] tensor IN HBM (W =
         shard.row_width(A, frame_floats)) -- receives the packed env-step rows (action, search statistics, action mask, to_play,
         newest observation frame: the GameSegment field set) straight from the device, and the return value is the [B, 8 + 2A]
         header block on the host: ``header[:, shard.F_ACTION]`` steps the environments, ``GameSegmentBatch.store_search_stats_rows
         (header)`` does the per-step bookkeeping of muzero_collector.py:588-620 for all envs at once.  No per-env Python loop:
-        one np.nonzero, one Dirichlet draw, one read-back."""
+        one np.nonzero, one Dirichlet draw, one read-back.
+
+        Two halves: ``_begin`` ENQUEUES the whole forward -- representation network, noise, prepare, the 50 simulations,
+        select_action + row packing -- and returns a ticket without waiting for the device; ``_end(ticket)`` waits for those rows (their
+        event, not the stream) and returns the header.  Between the two the caller does host work (segment bookkeeping of the previous
+        step) or enqueues ANOTHER env group's forward behind this one, so the device never waits for the host
+        (lightzero_amd.worker.MuZeroVectorCollector)."""
         from .. import shard
         self.collect_epsilon = epsilon
         model = self._collect_model
         B, A = data.shape[0], model.action_space_size
         mask = np.asarray(action_mask)
         if bool(_g(self._cfg, "collect_with_pure_policy", False)):
-            return self._pure_policy_rows(data, mask, rows_out, to_play, timestep, frame_floats)
+            return dict(done=self._pure_policy_rows(data, mask, rows_out, to_play, timestep, frame_floats))
         roots = self._roots_cache.get(B)
         if roots is None:
             roots = self._roots(B, [np.nonzero(mask[j])[0].tolist() for j in range(B)])
@@ -250,8 +262,16 @@ class EfficientZeroPolicy(CheckpointIngest):
         eps_greedy = bool(_g(eps_cfg, "eps_greedy_exploration_in_collect", False))
         # the observation pointer is passed explicitly: the library's cached pointer of the last initial inference would outlive a
         # tensor the caller's allocator has recycled in between
-        header, _ = roots.collect_rows(temperature, eps_greedy, rows_out.data_ptr(), rows_out.shape[1], frame_floats, timestep=timestep,
-                                       d_obs_ptr=data.data_ptr() if hasattr(data, "data_ptr") and getattr(data, "is_cuda", False) else None)
+        roots.collect_rows_begin(temperature, eps_greedy, rows_out.data_ptr(), rows_out.shape[1], frame_floats, timestep=timestep,
+                                 d_obs_ptr=data.data_ptr() if hasattr(data, "data_ptr") and getattr(data, "is_cuda", False) else None)
+        return dict(roots=roots, rows_out=rows_out, mask=mask, eps_greedy=eps_greedy, epsilon=epsilon, B=B, data=data)   # (data: kept alive while the device reads it)
+
+    def forward_collect_rows_end(self, ticket):
+        from .. import shard
+        if "done" in ticket:
+            return ticket["done"]
+        roots, rows_out, mask, eps_greedy, epsilon, B = (ticket[k] for k in ("roots", "rows_out", "mask", "eps_greedy", "epsilon", "B"))
+        header, _ = roots.collect_rows_end()
         if eps_greedy:
             # efficientzero.py:622-632: arg-max of the visit counts, replaced by a uniformly random LEGAL action with probability
             # collect_epsilon -- for all envs at once; the action word of the device rows is patched too

@@ -79,6 +79,11 @@ class _Group(object):
 
     def run_policy(self):
         """the policy forward of this step (search + select_action + rows on the device); no env or segment state is touched"""
+        return self.policy_end(self.policy_begin())
+
+    def policy_begin(self):
+        """ENQUEUE this step's policy forward (representation network, noise, the simulations, select_action + rows) and return a ticket
+        without waiting for the device (policies without a split forward run it whole in ``policy_end``)"""
         c = self.col
         if c._device is not None and self.rows_out is not None:
             import torch
@@ -89,14 +94,33 @@ class _Group(object):
             data = st.reshape(self.n, c._stack * ch, h, w)
         else:
             data = st.reshape(self.n, -1)
-        def forward():
-            return np.asarray(self.policy.forward_collect_rows(data, self.mask, self.rows_out, temperature=self.temperature, to_play=self.to_play.tolist(),
-                                                               timestep=self.timestep.astype(np.int32), frame_floats=self.F, epsilon=self.epsilon))
+        kw = dict(temperature=self.temperature, to_play=self.to_play.tolist(), timestep=self.timestep.astype(np.int32), frame_floats=self.F, epsilon=self.epsilon)
+        split = hasattr(self.policy, "forward_collect_rows_begin")
+
+        def begin():
+            if split:
+                return ("ticket", self.policy.forward_collect_rows_begin(data, self.mask, self.rows_out, **kw))
+            return ("call", (data, kw))
         if self.rs is None:      # a single group: the global np.random stream, like the reference
-            return forward()
+            return begin()
         from .. import _lib as L
-        with L.random_source(self.rs):   # pipelined groups: this group's own stream (the forward runs on a worker thread)
-            return forward()
+        with L.random_source(self.rs):   # several groups: this group's own host-side stream
+            return begin()
+
+    def policy_end(self, ticket):
+        """wait for the forward ``policy_begin`` enqueued -> the [n, 8 + 2 A (+ extra)] header block"""
+        kind, t = ticket
+
+        def end():
+            if kind == "ticket":
+                return np.asarray(self.policy.forward_collect_rows_end(t))
+            data, kw = t
+            return np.asarray(self.policy.forward_collect_rows(data, self.mask, self.rows_out, **kw))
+        if self.rs is None:
+            return end()
+        from .. import _lib as L
+        with L.random_source(self.rs):
+            return end()
 
     def step_envs(self, header):
         """First half of a collector step: env.step with the chosen actions and everything that determines the NEXT policy forward -- the
@@ -168,13 +192,14 @@ class _Group(object):
 class MuZeroVectorCollector(object):
     def __init__(self, env, policy, policy_config, device=None, rows_on_device=True, pipeline=True):
         """``env`` / ``policy``: one vectorised env and one policy -- or two lists of the same length (env GROUPS, one policy object per
-        group, all on the same engine model): ``collect`` then pipelines the groups -- while the device searches for one group (the
-        policy forward runs on a worker thread; the library calls release the GIL) the host steps the environments of the other and
-        does its segment bookkeeping, so the GPU goes from one group's search straight into the next one's.  Every group by itself runs
+        group, all on the same engine model): ``collect`` then pipelines the groups -- every group keeps one forward ENQUEUED on the
+        engine's stream (``forward_collect_rows_begin`` does not wait for the device), so while the device searches for one group the
+        host steps the environments of the other and does its segment bookkeeping, and the GPU goes from one group's search straight
+        into the next one's.  Every group by itself runs
         the loop of the single-group form (same transcript -> same pooled segments; with more than one group every group draws its host-side
         random numbers from a stream of its own, seeded from np.random at the start of ``collect``, so a seeded run is reproducible as long as the
-        envs do not share the global np.random stream across groups either); only one forward is in flight at any time, so
-        the engine sees the same serialised call sequence."""
+        envs do not share the global np.random stream across groups either); everything runs on the calling thread and the engine's one
+        stream serialises the groups' forwards in the order they were enqueued."""
         self._groups_env = list(env) if isinstance(env, (list, tuple)) else [env]
         self._groups_policy = list(policy) if isinstance(policy, (list, tuple)) else [policy]
         assert len(self._groups_env) == len(self._groups_policy), "one policy object per env group"
@@ -187,7 +212,7 @@ class MuZeroVectorCollector(object):
         self._default_n_episode = _g(policy_config, "n_episode", None)
         self._device = device
         self._rows_on_device = rows_on_device and device is not None
-        self._pipeline = bool(pipeline)   # single group: launch the next forward before this step's segment bookkeeping (see collect)
+        self._pipeline = bool(pipeline)   # single group: enqueue the next forward before this step's segment bookkeeping (see collect)
         self.episode_info = []          # {'reward', 'step', 'visit_entropy'} per finished episode (muzero_collector.py:659-666)
         self.total_envstep_count = 0
         self.total_episode_count = 0
@@ -238,41 +263,34 @@ class MuZeroVectorCollector(object):
             while not g.finish(g.run_policy()):
                 pass
         elif G == 1:
-            # One group, software-pipelined: the forward of step t + 1 is launched (on a worker thread: the library calls release the
-            # GIL) as soon as step t's env.step has produced its inputs, and step t's segment bookkeeping runs under it.  Same calls on
-            # the same data in the same order per object; the global np.random stream is still used strictly alternately (the forward
-            # draws between submit and result, the environments afterwards).
-            from concurrent.futures import ThreadPoolExecutor
+            # One group, software-pipelined on ONE thread: the forward of step t + 1 is enqueued (policy_begin returns without waiting
+            # for the device) as soon as step t's env.step has produced its inputs, step t's segment bookkeeping runs while the
+            # device searches, then policy_end waits for the rows.  Same calls on the same data in the same order per object; the
+            # host-side random draws happen in the order of the plain loop (noise and seeds in begin, eps-greedy in end, the
+            # environments afterwards).
             g = groups[0]
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                fut = pool.submit(g.run_policy)
-                while True:
-                    rec = g.step_envs(fut.result())
-                    if not g.done:
-                        fut = pool.submit(g.run_policy)
-                    g.book(rec)
-                    if g.done:
-                        break
+            tk = g.policy_begin()
+            while True:
+                rec = g.step_envs(g.policy_end(tk))
+                if not g.done:
+                    tk = g.policy_begin()
+                g.book(rec)
+                if g.done:
+                    break
         else:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                live = list(groups)
-                cur = live[0]
-                fut = pool.submit(cur.run_policy)
-                while True:
-                    header = fut.result()
-                    others = [g for g in live if g is not cur]
-                    nxt = others[(live.index(cur)) % len(others)] if others else None   # round robin over the other live groups
-                    if nxt is not None:
-                        fut = pool.submit(nxt.run_policy)     # the device starts on the next group ...
-                    if cur.finish(header):                    # ... while this group's envs are stepped and its segments updated
-                        live.remove(cur)
-                    if nxt is None:
-                        if not live:
-                            break
-                        fut = pool.submit(cur.run_policy)     # a single group left: the plain loop
-                        nxt = cur
-                    cur = nxt
+            # Several env groups: every live group has ONE forward enqueued on the engine's stream at any time, so the device goes from
+            # one group's search straight into the next one's while the host -- one thread -- waits for the oldest forward (its own
+            # event: lz_roots_collect_rows_end), steps that group's environments, enqueues its next forward behind the others' and does
+            # its segment bookkeeping.  (Round 4 kept one forward in flight on a worker thread: the device idled from one group's
+            # read-back to the next group's launch, ~0.4 ms of every 3.3 ms step.)
+            import collections
+            queue = collections.deque((g, g.policy_begin()) for g in groups)
+            while queue:
+                g, tk = queue.popleft()
+                rec = g.step_envs(g.policy_end(tk))
+                if not g.done:
+                    queue.append((g, g.policy_begin()))
+                g.book(rec)
         self.group_results = []
         segs_all, meta_all = [], []
         for g in groups:

@@ -85,8 +85,8 @@ def test_collect_equals_the_reference_loop_on_reference_segments(mode, n_episode
 
 @pytest.mark.parametrize("groups", [2, 3])
 def test_pipelined_env_groups_each_equal_the_reference_loop(groups):
-    """env groups: the policy forward of one group runs on a worker thread while the host steps the other group's envs; every group's
-    transcript still replays exactly through the reference loop, and the engine-facing calls never overlap"""
+    """env groups: the collector interleaves the groups (one forward enqueued per group, the host steps one group's envs while the device
+    searches for another); every group's transcript still replays exactly through the reference loop, and the engine-facing calls never overlap"""
     ref = ref_loader.load()
     if ref is None:
         pytest.skip("/root/reference not present")
@@ -96,7 +96,7 @@ def test_pipelined_env_groups_each_equal_the_reference_loop(groups):
     pols = [StubPolicy(np.random.default_rng(140 + g)) for g in range(groups)]
     in_flight, overlaps, threads = [0], [0], set()
     lock = threading.Lock()
-    for p in pols:   # the forwards run off the main thread and one at a time
+    for p in pols:   # the forwards run one at a time
         inner = p.forward_collect_rows
 
         def spy(*a, _inner=inner, **kw):
@@ -113,7 +113,9 @@ def test_pipelined_env_groups_each_equal_the_reference_loop(groups):
     col = MuZeroVectorCollector(envs, pols, cfg, device=None)
     n_episode = 9 * groups + 1
     segs_v, meta_v = col.collect(n_episode=n_episode)
-    assert overlaps[0] == 0 and threading.current_thread().name not in threads
+    # round 5: no worker thread any more -- a policy with a split forward keeps one forward ENQUEUED per group (forward_collect_rows_begin
+    # returns without waiting for the device); a policy without one (this stub) runs whole where the collector waits for the group
+    assert overlaps[0] == 0 and threads == {threading.current_thread().name}
     share = [n_episode // groups + (1 if g < n_episode % groups else 0) for g in range(groups)]
     assert len(col.group_results) == groups and sum(len(r[0]) for r in col.group_results) == len(segs_v)
     for g in range(groups):
