@@ -374,7 +374,9 @@ def _cpu_worker(spec):
     sub = obs[lo:hi].contiguous()
     noises = [z.tolist() for z in np.random.default_rng(idx).dirichlet([CFG["root_dirichlet_alpha"]] * ACTIONS, size=hi - lo).astype(np.float32)]
     run, kind_tree = _baseline_pipeline(weights, "cpu")
-    run(sub[:4], noises)          # warm-up
+    run(sub[:4], noises)          # warm-up: imports, threads ...
+    run(sub, noises)              # ... and this batch size's operator set-up (oneDNN builds its primitives per shape: the first batch of a new
+                                  # size is several times slower than the following ones)
     sys.stdout.write("READY\n"); sys.stdout.flush()
     sys.stdin.readline()
     t0 = time.time()
@@ -615,9 +617,13 @@ def main():
         if args.refresh_every and (i + 1) % args.refresh_every == 0:
             # weight refresh inside the loop: one flat broadcast from rank 0, then the device tensors are overwritten in place
             # (same buffers: the captured search graphs stay valid)
-            fresh = shard.broadcast_state_dict(weights, src=0, on_device=True)   # RCCL: tensors stay on the device until the library stages them
+            fresh = shard.broadcast_state_dict(weights_flat, src=0, on_device=True)   # RCCL: one flat device buffer, handed to the library by pointer
             for mdl in models:
-                mdl.load_state_dict(fresh)
+                mdl.load_state_dict(fresh)   # device-side re-layout on the engine's stream (lz_model_refresh_flat): no host synchronisation
+
+    # the learner's weights as they reach a collector rank: ONE flat fp32 buffer in HBM (across ranks the in-place RCCL broadcast of that
+    # buffer; a learner in the same process flattens its parameters once per update) -- built outside the timed loop, refreshed inside it
+    weights_flat = shard.flat_state_dict(weights, "cuda") if args.refresh_every else None
 
     def drain():
         for b in (0, 1):

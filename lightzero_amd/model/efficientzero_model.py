@@ -203,6 +203,14 @@ class EfficientZeroModel(object):
         if lay is False:
             return False
         ent, total = lay
+        flat = getattr(sd, "flat", None)
+        if flat is not None and getattr(flat, "is_cuda", False) and tuple(getattr(sd, "layout", ())) == tuple(ent) and flat.numel() == total \
+                and str(flat.dtype) == "torch.float32" and flat.is_contiguous():
+            # a shard.FlatStateDict in this model's own layout: the buffer goes over by pointer, no walk over the tensors
+            self._engine_waits_for_torch(flat.device)
+            L.check(lib.lz_model_refresh_flat(self._engine, flat.data_ptr(), total, 1))
+            self._flat_keep = flat
+            return True
         if sum(1 for k in sd if not k.endswith("num_batches_tracked")) != len(ent):
             return False
         vals = []

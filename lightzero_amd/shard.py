@@ -158,6 +158,38 @@ def all_gather_rows_equal(rows_t, out=None, async_op=False):
     return out, work
 
 
+class FlatStateDict(dict):
+    """name -> views of ONE flat float32 buffer in name order (what ``broadcast_state_dict(on_device=True)`` returns): ``flat`` is that
+    buffer, ``layout`` the (name, offset, size) triples.  ``model.load_state_dict`` recognises it and hands the buffer to the library by
+    pointer without walking the tensors (lz_model_refresh_flat)."""
+    flat = None
+    layout = ()
+
+
+def flat_state_dict(state_dict, device="cuda"):
+    """the ``FlatStateDict`` of a reference-keyed state_dict on ``device``: one concatenation + one upload (a learner in the same process
+    can hand its weights to the collector's engine model this way; across ranks ``broadcast_state_dict(on_device=True)`` builds the same)"""
+    import torch
+    names = sorted(k for k in state_dict if not k.endswith("num_batches_tracked"))
+
+    def t(v):
+        return v.detach().reshape(-1).float() if hasattr(v, "detach") else torch.from_numpy(np.ascontiguousarray(np.asarray(v), dtype=np.float32).reshape(-1))
+    flat = torch.cat([t(state_dict[k]).to(device) for k in names]) if any(getattr(state_dict[k], "is_cuda", False) for k in names) \
+        else torch.cat([t(state_dict[k]) for k in names]).to(device)
+    return _flat_views(flat, names, [tuple(np.shape(state_dict[k])) for k in names])
+
+
+def _flat_views(flat, names, shapes):
+    out, off, lay = FlatStateDict(), 0, []
+    for k, sh in zip(names, shapes):
+        n = int(np.prod(sh)) if len(sh) else 1
+        out[k] = flat[off:off + n].view(*sh) if len(sh) else flat[off:off + n].view(())
+        lay.append((k, off, n))
+        off += n
+    out.flat, out.layout = flat, tuple(lay)
+    return out
+
+
 def broadcast_state_dict(state_dict, src=0, device=None, on_device=False):
     """Weight refresh across ranks: rank ``src`` holds the new ``state_dict`` (name -> array-like, reference names), every other
     rank passes its current one (same names and shapes; only used as the layout).  One flat float32 broadcast (RCCL on cuda
@@ -173,19 +205,25 @@ def broadcast_state_dict(state_dict, src=0, device=None, on_device=False):
     shapes = [tuple(np.shape(state_dict[k])) for k in names]
     sizes = [int(np.prod(s)) if len(s) else 1 for s in shapes]
     if not dist.is_available() or not dist.is_initialized() or _single_rank(dist):
+        if on_device and torch.cuda.is_available():
+            if isinstance(state_dict, FlatStateDict) and getattr(state_dict.flat, "is_cuda", False):
+                return state_dict        # already one flat device buffer (nothing to broadcast to)
+            return flat_state_dict(state_dict, "cuda")
         return {k: arr(state_dict[k]) for k in names}
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-    if dist.get_rank() == src:
-        flat.copy_(torch.from_numpy(np.concatenate([arr(state_dict[k]).reshape(-1) for k in names])))
+    if isinstance(state_dict, FlatStateDict) and state_dict.flat is not None and state_dict.flat.device.type == torch.device(device).type \
+            and state_dict.flat.numel() == sum(sizes):
+        # already one flat buffer in name order on the collective's device (a learner's flat_state_dict, or the result of the previous
+        # broadcast on the receiving ranks): broadcast it in place -- no concatenation, no staging
+        flat = state_dict.flat
+    else:
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        if dist.get_rank() == src:
+            flat.copy_(torch.from_numpy(np.concatenate([arr(state_dict[k]).reshape(-1) for k in names])))
     dist.broadcast(flat, src=src)
     if on_device and flat.is_cuda:
-        out, off = {}, 0
-        for k, sh, n in zip(names, shapes, sizes):
-            out[k] = flat[off:off + n].view(*sh) if len(sh) else flat[off:off + n].view(())
-            off += n
-        return out
+        return _flat_views(flat, names, shapes)
     host = flat.cpu().numpy()
     out, off = {}, 0
     for k, s, n in zip(names, shapes, sizes):

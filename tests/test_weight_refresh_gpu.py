@@ -111,6 +111,11 @@ def test_device_side_refresh_leaves_the_bytes_a_host_finalize_leaves(family):
     assert _digest(model) == want
     model.load_state_dict({k: sd0[k].cuda() for k in names})          # scattered device tensors: one torch.cat
     assert _digest(model) == d0
+    from lightzero_amd import shard
+    fsd = shard.flat_state_dict(sd1, "cuda")                          # shard.FlatStateDict: the buffer goes over by pointer, no walk
+    assert [n for n, _, _ in fsd.layout] == [n for n, _, _ in model._flat_layout[0]]
+    model.load_state_dict(fsd)
+    assert _digest(model) == want
 
 
 def test_host_path_after_device_refreshes_sees_the_refreshed_weights():
