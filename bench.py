@@ -82,6 +82,26 @@ def _baseline_pipeline(weights, device):
     return run, kind_tree
 
 
+def cpu_allowance():
+    """how many cores this PROCESS may actually use: the scheduler affinity mask and the cgroup CPU quota (cpu.max of cgroup v2 /
+    cfs_quota_us of v1) -- a container that sees all 256 hardware threads of the host in /proc/cpuinfo may still be throttled to a
+    fraction of them (the signature: the torch-thread sweep collapsing beyond the quota)."""
+    out = dict(affinity=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), quota=None)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            out["quota"] = float(q) / float(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                out["quota"] = q / p
+        except Exception:
+            pass
+    return out
+
+
 def host_cores():
     """(physical cores, hardware threads) of the host: distinct (physical id, core id) pairs of /proc/cpuinfo"""
     threads = os.cpu_count() or 1
@@ -135,7 +155,7 @@ def cpu_baseline(weights, obs_cpu, noises, budget_s=30.0):
     torch.set_num_threads(allc)
     med = float(np.median(times))
     phys, thr = host_cores()
-    return dict(value=ENVS / med, unit="env-steps/s", cores=best, host_cores=phys, host_threads=thr, kind="port",
+    return dict(value=ENVS / med, unit="env-steps/s", cores=best, host_cores=phys, host_threads=thr, cpu_allowance=cpu_allowance(), kind="port",
                 thread_sweep_env_steps_per_s={str(k): round(v, 1) for k, v in sweep.items()},
                 batches=len(times), batch_s_min_median_max=[min(times), med, max(times)],
                 cores_note="cores = the torch intra-op thread count that won the sweep (the tree and the Python driver are one thread); "
@@ -424,10 +444,12 @@ def cpu_baseline_whole_host(threads, rank, batches=3, budget_s=150.0):
     that won cpu_baseline's single-process sweep, then 4 and 1 (the small per-simulation operators of this model scale better across
     processes than across threads) -- within the time budget; `value` = the best configuration, every configuration is listed."""
     phys, thr = host_cores()
+    allow = cpu_allowance()
+    budget = int(min(phys, allow["affinity"], allow["quota"] or phys))    # the cores this container may really keep busy
     t_start = time.time()
     runs, seen = [], set()
     for t in (max(threads, 1), 4, 1):
-        nproc = max(1, min(phys // t, ENVS // 2))
+        nproc = max(1, min(budget // t, ENVS // 2))
         if (nproc, t) in seen or (runs and time.time() - t_start > 0.5 * budget_s):
             continue
         seen.add((nproc, t))
@@ -440,7 +462,7 @@ def cpu_baseline_whole_host(threads, rank, batches=3, budget_s=150.0):
         raise RuntimeError("no whole-host configuration completed: %r" % runs)
     best = max(ok, key=lambda r: r["value"])
     return dict(value=best["value"], unit="env-steps/s", cores=best["cores"], processes=best["processes"], threads_per_process=best["threads_per_process"],
-                host_cores=phys, host_threads=thr, kind="port", batches=batches, configurations=runs,
+                host_cores=phys, host_threads=thr, cpu_allowance=allow, core_budget=budget, kind="port", batches=batches, configurations=runs,
                 sample="best of %s (processes x torch threads, each process pinned to its own cores), %d batches of each process's block of the 256 envs x 50 "
                        "sims; %s + restated driver + torch fp32 model; all processes start together; value = envs x batches / (latest end - earliest start); %.0f s"
                        % ([(r["processes"], r["threads_per_process"]) for r in runs], batches, best["kind_tree"], time.time() - t_start))

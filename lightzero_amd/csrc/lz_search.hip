@@ -2008,7 +2008,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
 static uint64_t graph_knobs()
 {
     uint64_t knobs = 0;
-    const char *names[] = {"LZ_TRAVERSE_SERIAL", "LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256",
+    const char *names[] = {"LZ_TRAVERSE_SERIAL", "LZ_TREE_NO_WG", "LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_LDS_LIMIT", "LZ_LSTM_CHUNKED", "LZ_HEADS_256",
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif

@@ -231,6 +231,239 @@ __global__ __launch_bounds__(64) void k_backprop_traverse_lds(lz_tree_dev t, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_tree_step_wg: the separate tree step (expand + backup of simulation s, selection of s + 1) for trees that have outgrown the LDS
+// budget of the fused prologue -- BASELINE configs[2]: 1024 roots x 400 simulations, A = 4, paths ~50 deep.  k_backprop_traverse
+// walks such a path with ONE wave of ~600 dependent instructions per level (2.4 k cycles x depth 48: 72 us per launch, 22 % of that
+// configuration's GPU time, 4 of 64 lanes busy).  Here a workgroup of four waves owns the root:
+//   0  wave 0: expand + backup on the HBM arrays (dev_backprop, unchanged);
+//   1  all waves: EVERY expanded node at once (thread = node, as in dev_traverse_par): compute_mean_q's total / count in list order,
+//      cucb_score of every visited child in full and the prior term of every unvisited one (all they lack is the node's mean_q, which
+//      chains down the search path), and -- for a node whose children are all visited -- cselect_child itself; per node 48 bytes of
+//      results in LDS (record, child scores, child ids);
+//   2  wave 0: the walk -- per level one LDS record, mean_q = (parent_q + total) / (count + 1), then either the stored choice or
+//      prior + normalised mean_q for the unvisited children and the arg-max over <= 8 lanes.
+// Same float operations per node and level as dev_traverse, in the same order: bit-identical (the configs[2] exact-replay and
+// fused-vs-separate tests run through it; LZ_TRAVERSE_SERIAL=1 keeps k_backprop_traverse).
+template <int AU, int VARIANT>
+__global__ __launch_bounds__(256) void k_tree_step_wg(lz_tree_dev t, int new_node, float discount, const float *__restrict__ vps,
+                                                      const float *__restrict__ values, const float *__restrict__ logits, int horizon,
+                                                      lz_traverse_args a, float delta_max, const int32_t *__restrict__ vtp_in)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_wg[];
+    const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int A = t.A, NN = t.NN, nn = new_node + 1;
+    // LDS: rec [nn] {total, count (int), sel_act (int; -1: not all children visited), sel_child (int)} | sc [nn][AU] | chd [nn][AU] | scalars
+    float4 *s_rec = s_wg;
+    float *s_sc = reinterpret_cast<float *>(s_rec + nn);
+    int32_t *s_chd = reinterpret_cast<int32_t *>(s_sc + (size_t)nn * AU);
+    int32_t *s_um = s_chd + (size_t)nn * AU;          // [nn] bit j: child j is in the list and unvisited; bits 8..15: children in the list
+    float *s_f = reinterpret_cast<float *>(s_um + nn);   // [0] min [1] max [2] root value sum
+    int32_t *s_i = reinterpret_cast<int32_t *>(s_f + 4); // [0] root visit count [1] n_root [2] epoch [3] child of the root's action 0
+    const tview v = global_view(t, b);
+    int vtp = 0;
+    if (wv == 0) {
+        tscal<1> sc;
+        load_scalars<1>(t, b, sc);
+        leaf_in<1, VARIANT> L;
+        load_leaf<1, VARIANT>(t, b, vps, values, logits, nullptr, horizon, nullptr, L);
+        vtp = vtp_in[b];
+        dev_backprop<1, VARIANT, false>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset);
+        if (lane == 0) {
+            s_f[0] = sc.mn; s_f[1] = sc.mx; s_f[2] = sc.root_vsum;
+            s_i[0] = sc.root_visit; s_i[1] = sc.n_root; s_i[2] = (int32_t)sc.epoch;
+        }
+    }
+    __syncthreads();   // the backup's stores (edges of the path, the new node) are visible to the workgroup; scalars in LDS
+    const float mn = s_f[0], mx = s_f[1];
+    const int root_visit = s_i[0], n_root = s_i[1];
+    const uint32_t epoch = (uint32_t)s_i[2];
+    const float mm_d = mx - mn;
+    const bool mm_on = mm_d > 0;
+    const float mm_den = (mm_d < delta_max) ? delta_max : mm_d;
+    const float base = (float)a.pb_c_base;
+    const uint64_t hkey = mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    // ---- 1: every expanded node
+    for (int n0 = 0; n0 < nn; n0 += 256) {
+        const bool nvalid = n0 + tid < nn;
+        const int n = nvalid ? n0 + tid : nn - 1;
+        const bool is_root = n == 0;
+        const uint64_t link = t.node_link[(size_t)b * NN + n];
+        const int parent = (int)(link >> 40), act_in = (int)((link >> 24) & 0xffffu), depth_n = (int)(link & 0xffffffu);
+        const float node_vp = v.node_vp[n];
+        const int node_reset = v.node_reset[n];
+        const int cnt_n = is_root ? n_root : A;
+        v4f e[AU];
+        int chd[AU];
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            const int lj = t.legal[(size_t)b * A + min(j, A - 1)];   // the root's children are its legal list (wave-uniform loads)
+            const int aj = is_root ? ((j < n_root) ? lj : 0) : min(j, A - 1);
+            e[j] = *reinterpret_cast<const v4f *>(v.edge + (size_t)n * A + aj);
+            chd[j] = v.child[(size_t)n * A + aj];
+        }
+        const int chd_a0 = v.child[(size_t)n * A];
+        const int in_vis_e = __float_as_int(v.edge[(size_t)parent * A + act_in].y);
+        const int in_vis = is_root ? root_visit : in_vis_e;
+        float prior[AU], val[AU], tr[AU];
+        int vis[AU];
+        float total = 0.0f;
+        int nv = 0;
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            prior[j] = e[j].x;
+            vis[j] = __float_as_int(e[j].y);
+            const float qv = e[j].z / (float)max(vis[j], 1);
+            val[j] = (vis[j] == 0) ? 0.0f : qv;
+            if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+                const float dv = e[j].w - node_vp;
+                tr[j] = (node_reset == 1) ? e[j].w : dv;
+            } else {
+                tr[j] = e[j].w;
+            }
+            const float qsa = tr[j] + discount * val[j];
+            const bool visited = j < cnt_n && vis[j] > 0;
+            const float t2 = total + qsa;
+            total = visited ? t2 : total;
+            nv += visited ? 1 : 0;
+        }
+        const float N = (float)(in_vis - 1);
+        const float pbc0 = lz_logf((N + base + 1) / base) + a.pb_c_init, sq = sqrtf(N);
+        float score[AU];
+        float best = -__builtin_inff();
+        int um = 0;
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            float pb_c = pbc0 * (sq / (float)(vis[j] + 1));
+            const float prior_score = pb_c * prior[j];
+            const float vq = (a.players == 1) ? tr[j] + discount * val[j] : tr[j] + discount * (-val[j]);
+            const float nq = (vq - mn) / mm_den;
+            float value_score = mm_on ? nq : vq;
+            value_score = (value_score < 0) ? 0.0f : ((value_score > 1) ? 1.0f : value_score);
+            const bool unvis = vis[j] == 0;
+            const float ucb = unvis ? prior_score : prior_score + value_score;   // an unvisited child lacks its value term: the walk adds it
+            score[j] = (j < cnt_n) ? ucb : -__builtin_inff();
+            um |= (j < cnt_n && unvis) ? (1 << j) : 0;
+            best = fmaxf(best, score[j]);
+        }
+        // a node whose listed children are all visited: cselect_child now (the walk only follows it)
+        int pos = -1;
+#pragma unroll
+        for (int j = AU - 1; j >= 0; --j) pos = (score[j] == best) ? j : pos;
+        const bool ok = pos >= 0 && best > LZ_FLOAT_MIN;
+        if (a.tiebreak == LZ_TIE_RANDOM) {
+            const float thr = best - 0.000001f;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < AU; ++j) cnt += (j == pos || (j > pos && score[j] >= thr)) ? 1 : 0;
+            const bool draw = ok && cnt > 1 && um == 0;
+            if (__ballot(draw)) {
+                const uint64_t h = mix64(hkey ^ (uint64_t)depth_n);
+                int r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);
+                int pick = pos;
+#pragma unroll
+                for (int j = 0; j < AU; ++j) {
+                    const bool member = j == pos || (j > pos && score[j] >= thr);
+                    pick = (member && r == 0) ? j : pick;
+                    r -= member ? 1 : 0;
+                }
+                pos = draw ? pick : pos;
+            }
+        }
+        int sel_child = chd_a0, sel_pos = 0;
+#pragma unroll
+        for (int j = 0; j < AU; ++j)
+            if (ok && pos == j) { sel_child = chd[j]; sel_pos = j; }
+        if (nvalid) {
+            // sel < 0: some listed child is unvisited, the walk decides.  (list position, not action: the root maps it through its list)
+            const int sel = (um == 0) ? (ok ? sel_pos : 0x10000) : -1;    // 0x10000: no comparable score -> action 0 (cnode.cpp:687-693)
+            float4 r4;
+            r4.x = total; r4.y = __int_as_float(nv); r4.z = __int_as_float(sel); r4.w = __int_as_float(sel_child);
+            s_rec[n] = r4;
+            s_um[n] = um | (cnt_n << 8);
+#pragma unroll
+            for (int j = 0; j < AU; ++j) { s_sc[(size_t)n * AU + j] = score[j]; s_chd[(size_t)n * AU + j] = chd[j]; }
+            if (is_root) s_i[3] = chd_a0;
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    // ---- 2: the walk (wave 0; lane j = child j of the current node where a node still has unvisited children)
+    int node = 0, depth = 0, last_action = -1;
+    int my_node = 0, my_act = 0;
+    auto flush_path = [&](int base_k, int count) {
+        if (lane < count) {
+            t.path_node[(size_t)b * NN + base_k + lane] = my_node;
+            t.path_act[(size_t)b * NN + base_k + lane] = my_act;
+            t.node_best[(size_t)b * NN + my_node] = my_act;
+        }
+    };
+    float parent_q = 0.0f;
+    const int lact = (lane < A) ? t.legal[(size_t)b * A + lane] : 0;   // the root's list: position -> action
+    for (;;) {
+        const float4 r4 = s_rec[node];
+        const float total = r4.x;
+        const int nv = __float_as_int(r4.y), sel = __float_as_int(r4.z);
+        const bool is_root = node == 0;
+        float mean_q;
+        if (is_root && nv > 0) mean_q = total / (float)nv;
+        else mean_q = (parent_q + total) / (float)(nv + 1);
+        parent_q = mean_q;
+        int pos, nxt;
+        bool ok;
+        if (sel >= 0) {   // all children visited: chosen in phase 1
+            ok = sel != 0x10000;
+            pos = ok ? sel : 0;
+            nxt = __float_as_int(r4.w);
+        } else {
+            const int umc = s_um[node], cnt_n = umc >> 8;
+            const int jj = min(lane, AU - 1);
+            const float scj = s_sc[(size_t)node * AU + jj];
+            const int chj = s_chd[(size_t)node * AU + jj];
+            float u = mm_on ? (mean_q - mn) / mm_den : mean_q;     // CMinMaxStats::normalize of the unvisited children's value term
+            u = (u < 0) ? 0.0f : ((u > 1) ? 1.0f : u);
+            const bool unvis = (umc >> jj) & 1;
+            const float ucb = unvis ? scj + u : scj;
+            const float score = (lane < cnt_n && lane < AU) ? ucb : -__builtin_inff();
+            const float best = row0_max(score);
+            uint64_t mask = __ballot(score == best);
+            pos = mask ? __builtin_ctzll(mask) : -1;
+            if (a.tiebreak == LZ_TIE_RANDOM && pos >= 0) {
+                const float thr = best - 0.000001f;
+                uint64_t mk = __ballot(lane == pos || (lane > pos && score >= thr));
+                const int cnt = __builtin_popcountll(mk);
+                if (cnt > 1) {
+                    const uint64_t h = mix64(hkey ^ (uint64_t)depth);
+                    const int r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);
+                    for (int q = 0; q < r; ++q) mk &= mk - 1;
+                    pos = __builtin_ctzll(mk);
+                }
+            }
+            ok = pos >= 0 && best > LZ_FLOAT_MIN;
+            if (ok) nxt = rl_i(chj, pos);
+            else { pos = 0; nxt = is_root ? s_i[3] : rl_i(chj, 0); }
+        }
+        const int action = ok ? (is_root ? rl_i(lact, pos) : pos) : 0;
+        if (a.players > 1) vtp = (vtp == 1) ? 2 : 1;  // cnode.cpp:932-943
+        if (lane == (depth & 63)) { my_node = node; my_act = action; }
+        last_action = action;
+        depth += 1;
+        if ((depth & 63) == 0) flush_path(depth - 64, 64);
+        if (nxt < 0 || depth >= nn) break;  // reached an unexpanded child: the leaf
+        node = nxt;
+    }
+    flush_path((depth - 1) & ~63, depth - ((depth - 1) & ~63));
+    if (lane == 0) {
+        t.res_ix[b] = node;
+        t.res_iy[b] = b;
+        t.res_last_action[b] = last_action;
+        t.res_search_len[b] = depth;
+        t.res_vtp[b] = vtp;
+    }
+}
+static inline size_t lz_tree_step_wg_lds(int A_unroll, int nn) { return (size_t)nn * (16 + 8 * (size_t)A_unroll + 4) + 64; }
+
+// ------------------------------------------------------------------------------------------------
 // Gumbel MuZero (lzero/mcts/ctree/ctree_gumbel_muzero/lib/cnode.cpp).  Lane = legal position of the current node.
 // ------------------------------------------------------------------------------------------------
 // sum of v over the lanes of `mask`, added in lane order (the reference accumulates in index order)
@@ -654,6 +887,17 @@ static void launch_bt_v(const lz_tree_dev &t, int idx, float discount, const flo
         if (nchunks(t.A) == 1) hipLaunchKernelGGL((k_backprop_traverse_lds<1, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
         else hipLaunchKernelGGL((k_backprop_traverse_lds<2, V>), dim3(t.B), dim3(64), lds, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
         return;
+    }
+    // deep trees with few actions (BASELINE configs[2]): a workgroup per root scores every node at once (k_tree_step_wg)
+    if (t.A <= 8 && !a.serial && !getenv("LZ_TREE_NO_WG")) {
+        const int AU = t.A <= 4 ? 4 : (t.A <= 6 ? 6 : 8);
+        const size_t wl = lz_tree_step_wg_lds(AU, idx + 1);
+        if (wl <= 64 * 1024) {
+            if (AU == 4) hipLaunchKernelGGL((k_tree_step_wg<4, V>), dim3(t.B), dim3(256), wl, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
+            else if (AU == 6) hipLaunchKernelGGL((k_tree_step_wg<6, V>), dim3(t.B), dim3(256), wl, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
+            else hipLaunchKernelGGL((k_tree_step_wg<8, V>), dim3(t.B), dim3(256), wl, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp);
+            return;
+        }
     }
     switch (nchunks(t.A)) {
     case 1: hipLaunchKernelGGL((k_backprop_traverse<1, V>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, horizon, a, delta, vtp); break;

@@ -145,6 +145,8 @@ class EfficientZeroModel(object):
         Calling it again on a loaded model is a weight refresh (collector after a learner update): tensors are overwritten in
         place on the device, roots and their captured search graphs stay valid."""
         self._check_owner()
+        if self._loaded and getattr(state_dict, "flat", None) is not None and self._refresh_on_device(state_dict):
+            return self     # a shard.FlatStateDict in this model's layout: by pointer, before anything walks its tensors
         state_dict = unwrap_checkpoint(state_dict)
         if self._loaded and self._refresh_on_device(state_dict):
             return self
@@ -203,8 +205,10 @@ class EfficientZeroModel(object):
         if lay is False:
             return False
         ent, total = lay
+        if not self.__dict__.get("_flat_layout_key"):
+            self._flat_layout_key = tuple(ent)
         flat = getattr(sd, "flat", None)
-        if flat is not None and getattr(flat, "is_cuda", False) and tuple(getattr(sd, "layout", ())) == tuple(ent) and flat.numel() == total \
+        if flat is not None and getattr(flat, "is_cuda", False) and (getattr(sd, "layout", None) is self._flat_layout_key or tuple(getattr(sd, "layout", ())) == self._flat_layout_key) and flat.numel() == total \
                 and str(flat.dtype) == "torch.float32" and flat.is_contiguous():
             # a shard.FlatStateDict in this model's own layout: the buffer goes over by pointer, no walk over the tensors
             self._engine_waits_for_torch(flat.device)

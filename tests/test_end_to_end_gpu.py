@@ -369,6 +369,63 @@ def test_tree_parallel_selection_is_bit_identical_to_the_level_walk(family, A, r
         assert b[4][:, :, 2].max() >= 5   # the sharp prior did walk deep
 
 
+@pytest.mark.parametrize("tiebreak", [0, 1])
+@pytest.mark.parametrize("family,A,ragged,S,two_player", [("mz", 4, False, 300, False), ("ez", 6, True, 90, False), ("mz", 8, True, 120, True), ("ez", 3, True, 70, False)])
+def test_workgroup_tree_step_is_bit_identical_to_the_one_wave_step(family, A, ragged, S, two_player, tiebreak):
+    """k_tree_step_wg (deep trees: a workgroup per root, every expanded node scored at once, the walk follows stored choices / adds the
+    mean-Q term for unvisited children) against k_backprop_traverse (one wave, level by level; LZ_TREE_NO_WG=1) -- the tree step kept
+    out of the chain launch and out of LDS (LZ_NO_TREE_FUSE=1, LZ_TREE_NO_LDS=1) so that EVERY simulation runs the kernel under test:
+    identical per-simulation records, visit distributions, root values and min-max statistics (bitwise), for both tie-break rules,
+    ragged root lists, two players, trees of more than 256 nodes, sharp priors (deep paths)."""
+    import os
+    from oracle import torch_models as tm
+    from lightzero_amd import _lib as L
+    from lightzero_amd.model.synthetic import sharpen_state_dict
+    B = 37
+    if family == "ez":
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
+        from lightzero_amd.model.efficientzero_model import EfficientZeroModel as M
+        ref = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=20 + A)
+    else:
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as tree
+        from lightzero_amd.model.muzero_model import MuZeroModel as M
+        ref = tm.synthetic_init(tm.MuZeroModel(action_space_size=A), seed=20 + A)
+    model = M(action_space_size=A).load_state_dict(sharpen_state_dict(ref.state_dict(), 6.0))
+    obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(60 + A)).cuda().contiguous()
+    rng = np.random.default_rng(70 + A)
+    mask = (rng.random((B, A)) < 0.7) if ragged else np.ones((B, A), bool)
+    mask[:, A - 1] = True
+    legal = [np.nonzero(m)[0].tolist() for m in mask]
+    noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+    to_play = rng.integers(1, 3, size=B).tolist() if two_player else [-1] * B
+    res = []
+    knobs = ("LZ_NO_TREE_FUSE", "LZ_TREE_NO_LDS", "LZ_TREE_NO_WG")
+    for one_wave in (True, False):
+        for k in knobs:
+            os.environ.pop(k, None)
+        os.environ["LZ_NO_TREE_FUSE"] = os.environ["LZ_TREE_NO_LDS"] = "1"
+        if one_wave:
+            os.environ["LZ_TREE_NO_WG"] = "1"
+        try:
+            roots = tree.Roots(B, legal, action_space_size=A, max_simulations=S)
+            roots.set_tiebreak(tiebreak, seed=93)
+            model.initial_inference(obs, roots)
+            L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+            roots.prepare_from_inference(0.25, noises, to_play)
+            L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997 if not two_player else 1.0, 5 if family == "ez" else 0, 0.01))
+            tr = np.zeros((S, B, 4), np.int32)
+            L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+            res.append((roots.get_distributions(), np.asarray(roots.get_values(), np.float32).view(np.uint32),
+                        roots.get_trajectories(), roots.get_minmax().view(np.uint32), tr))
+        finally:
+            for k in knobs:
+                os.environ.pop(k, None)
+    a, b = res
+    assert all(sum(d) == S for d in b[0])
+    assert np.array_equal(a[4], b[4]), "per-simulation (slot, action, search length, to_play) records differ"
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+
+
 def test_config2_full_size_deep_trees_properties():
     """BASELINE.json configs[2] at full size: Atari MuZero (conv), 1024 roots x 400 simulations, A = 4 -- the trees outgrow
     the LDS budget part-way through the search (tree step in the chain prologue -> separate HBM launch).  Size-independent
@@ -388,9 +445,9 @@ def test_config2_full_size_deep_trees_properties():
     legal = [list(range(A))] * B
     roots = mz_tree.Roots(B, legal, action_space_size=A, max_simulations=S)
     res = []
-    for env in (None, None, "1"):
+    for env in (None, None, "LZ_NO_TREE_FUSE", "LZ_TREE_NO_WG"):   # LZ_TREE_NO_WG: the one-wave HBM tree step instead of k_tree_step_wg
         if env:
-            os.environ["LZ_NO_TREE_FUSE"] = env
+            os.environ[env] = "1"
         roots.reset(legal)
         roots.set_tiebreak(0)
         model.initial_inference(obs, roots, fetch=False)
@@ -398,7 +455,8 @@ def test_config2_full_size_deep_trees_properties():
         L.check(L.lib().lz_search(roots._h, S, 19652, 1.25, 0.997, 0, 0.01))
         dist, cnt, val, pred, lg = roots.get_search_results()
         res.append((dist.copy(), val.copy().view(np.uint32)))
-    os.environ.pop("LZ_NO_TREE_FUSE", None)
+        for k in ("LZ_NO_TREE_FUSE", "LZ_TREE_NO_WG"):
+            os.environ.pop(k, None)
     d0, v0 = res[0]
     assert (d0.sum(1) == S).all() and (d0 >= 0).all()
     assert np.isfinite(v0.view(np.float32)).all()

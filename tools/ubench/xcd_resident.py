@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 lib = ctypes.CDLL(os.path.join(HERE, "libxcdresident.so"))
 P = ctypes.c_void_p
-lib.xcd_resident_run.argtypes = [P, P, P, P, P, P, P, P] + [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_float)]
+lib.xcd_resident_run.argtypes = [P, P, P, P, P, P, P, P] + [ctypes.c_int] * 8 + [ctypes.POINTER(ctypes.c_float)]
 S = 50
 VA, VB = 272, 512
 ctl = torch.zeros(16 + 2 + 512, dtype=torch.int32, device="cuda")
