@@ -3552,11 +3552,11 @@ bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step)
     // the staged tree lives in the four activation buffers (4 x 37 x 68 floats = 40 KB) until the latent is loaded over it;
     // staging more than 16 KB per root and simulation was measured slower than walking the HBM arrays (configs[2], 400 sims)
     const size_t room = (size_t)4 * (a.gw * a.gh + 1) * 68 * 4, lim = lz_tree_lds_limit(16 * 1024);
-    // MuZero batches of more than two roots per CU (BASELINE configs[2]: 1024 roots) whose trees have outgrown one node per lane: the
-    // prologue's one-wave step is serial time on a CU that queues four workgroups, while the separate workgroup-parallel step
-    // (k_tree_step_wg: A <= 8) runs every root at once -- measured 68.9 -> 67.3 ms per 1024 x 400 step with the step kept separate.
+    // MuZero batches of more than two roots per CU (BASELINE configs[2]: 1024 roots): the prologue's one-wave step is serial time on a
+    // CU that queues four workgroups, while the separate workgroup-parallel step (k_tree_step_wg: A <= 8) runs every root at once --
+    // measured 68.9 -> 67.3 ms per 1024 x 400 step with the step kept separate for all simulations.
     // (EfficientZero keeps the fused form at every batch size: its split heads ride on the same prologue.)
-    if (step.t.variant == LZ_TREE_MUZERO && step.t.B > 512 && step.t.A <= 8 && step.new_node >= 64 && !step.a.serial && !getenv("LZ_TREE_LDS_LIMIT")) return false;
+    if (step.t.variant == LZ_TREE_MUZERO && step.t.B > 512 && step.t.A <= 8 && !step.a.serial && !getenv("LZ_TREE_LDS_LIMIT") && !getenv("LZ_TREE_NO_WG")) return false;
     return lz_tree_lds_bytes(step.t, step.new_node) <= (lim < room ? lim : room);
 }
 

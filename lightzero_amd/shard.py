@@ -207,6 +207,9 @@ def broadcast_state_dict(state_dict, src=0, device=None, on_device=False):
     library by pointer (``lz_model_set_tensor_device``), no ``.cpu()`` and no per-tensor numpy copies on the Python side."""
     import torch
     import torch.distributed as dist
+    if on_device and isinstance(state_dict, FlatStateDict) and getattr(state_dict.flat, "is_cuda", False) \
+            and (not dist.is_available() or not dist.is_initialized() or _single_rank(dist)):
+        return state_dict        # one rank, already one flat device buffer: nothing to broadcast, nothing to walk
     names = sorted(k for k in state_dict if not k.endswith("num_batches_tracked"))
 
     def arr(v):
