@@ -24,6 +24,9 @@ struct ConvW {
     float *uc = nullptr;  // the same transform in the order of the LDS-resident Winograd chain (k_chain_w): [16 points][cin/4][64 = cout][4]
     void *wb = nullptr;   // fast mode: bf16 fragments of the direct form for k_chain_b, [2 k halves][cout/16][9 taps][64 lanes][8 bf16]
     void *wt = nullptr;   // fast mode: bf16 fragments for the tower kernel k_conv_bf, [cout/16][9 taps x cin/32][64 lanes][8 bf16]
+    void *w3 = nullptr;   // parity mode: the same fragments split exactly into three bf16 planes (hi | mid | lo) for k_conv_s3,
+                          // [cout/16][9 taps x cin/32][3 planes][64 lanes][8 bf16]
+    float *w3f = nullptr; // the fp32 values of those fragments in the same order [cout/16][ks][64 lanes][8] (what a device-side refresh gathers; k_refresh_split3 turns it into w3)
     int cin = 0, cout = 0;
 };
 struct MlpW {
@@ -62,6 +65,8 @@ struct RefreshRec {
     struct Wino { int32_t w, cout, cin_total, cin, out; };          // out: U[cout][cin][16] (point = 4 i + j)
     struct Act { int32_t w, A, AE, C, SW, SH, out; };               // out: [A][SH * SW][C]
     struct Add { int32_t a, b, n, out; };
+    struct Split3 { const float *src; void *dst; int64_t n; };      // a gathered fp32 fragment buffer -> its three bf16 planes (k_conv_s3), after the gather
+    std::vector<Split3> split3;
     std::vector<Bn> bn;
     std::vector<Wino> wino;
     std::vector<Act> act;
@@ -86,8 +91,9 @@ struct RefreshProgram {
     int32_t *d_idx = nullptr;
     void *d_slots = nullptr;    // RefreshRec::Slot[n_slots]
     int n_slots = 0;
-    void *d_bn = nullptr, *d_wino = nullptr, *d_act = nullptr, *d_add = nullptr;
-    int n_bn = 0, n_wino = 0, n_act = 0, n_add = 0;
+    void *d_bn = nullptr, *d_wino = nullptr, *d_act = nullptr, *d_add = nullptr, *d_split3 = nullptr;
+    int n_bn = 0, n_wino = 0, n_act = 0, n_add = 0, n_split3 = 0;
+    int64_t split3_items = 0;
     int64_t wino_items = 0, act_items = 0;   // largest op, for the grid
     int bn_max = 0, add_max = 0;
     size_t n_allocs = 0;                     // the weight buffers the program was recorded for (lz_model::allocs.size())
@@ -193,6 +199,17 @@ struct Builder {
         if (bytes && hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { if (err.empty()) err = "hipMemcpy failed for weights"; return nullptr; }
         return d;
     }
+    // recording pass: the buffer at this upload position is produced by a kernel of its own (not by the gather): claim it, no map
+    void *claim(size_t bytes_raw)
+    {
+        const size_t bytes = ((bytes_raw + 3) / 4) * 4;   // upload_u16 rounds up to whole floats
+        if (m->alloc_cursor >= m->allocs.size() || m->alloc_bytes[m->alloc_cursor] != bytes) {
+            rec->fail("weight buffer layout changed between the finalize and its recording");
+            m->alloc_cursor++;
+            return nullptr;
+        }
+        return m->allocs[m->alloc_cursor++];
+    }
     // eval-mode BatchNorm -> y = x*scale + shift
     void bn(const std::string &prefix, int n, std::vector<float> &scale, std::vector<float> &shift)
     {
@@ -285,6 +302,50 @@ struct Builder {
                             f[((((size_t)nt * KS + t * KC + kc) * 64) + lane) * 8 + j] = bf16_rne(w->data[((size_t)co * cin + ci) * 9 + t]);
                         }
         return upload_u16(f);
+    }
+    // parity mode, k_conv_s3: the k_conv_bf fragment order with every weight split exactly into three bf16 terms (hi = rne(w), mid =
+    // rne(w - hi), lo = rne(w - hi - mid)); lane (n = l & 15, kq = l >> 4) of k step (tap t, 32-channel block kc) holds
+    // W[co = 16 nt + n][ci = 32 kc + 8 kq + j][t], j = 0..7, three planes per k step.  The fp32 values in the same order are kept on the
+    // device too (w3f): a device-side refresh gathers them and k_refresh_split3 rebuilds the planes.
+    static void split3(float w, uint16_t &h, uint16_t &m, uint16_t &l)
+    {
+        auto tof = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+        h = bf16_rne(w);
+        const float r1 = w - tof(h);
+        m = bf16_rne(r1);
+        const float r2 = r1 - tof(m);
+        l = bf16_rne(r2);
+    }
+    void split3_tower(const std::string &wname, int cout, int cin, ConvW &c)
+    {
+        const HostTensor *w = get(wname, {cout, cin, 3, 3});
+        if (!w || (cin & 31) || (cout & 15)) return;
+        const int KC = cin / 32, KS = 9 * KC;
+        std::vector<float> f((size_t)cout * cin * 9);
+        for (int nt = 0; nt < cout / 16; ++nt)
+            for (int t = 0; t < 9; ++t)
+                for (int kc = 0; kc < KC; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = nt * 16 + (lane & 15), ci = kc * 32 + (lane >> 4) * 8 + j;
+                            f[((((size_t)nt * KS + t * KC + kc) * 64) + lane) * 8 + j] = w->data[((size_t)co * cin + ci) * 9 + t];
+                        }
+        c.w3f = upload(f);
+        // the three planes: values on the host path; on the recording pass only the buffer is claimed (k_refresh_split3 fills it from w3f)
+        std::vector<uint16_t> p3(f.size() * 3);
+        if (!rec) {
+            const size_t per = (size_t)64 * 8;
+            for (size_t blk = 0; blk < f.size() / per; ++blk)
+                for (size_t e = 0; e < per; ++e) {
+                    uint16_t h, m, l;
+                    split3(f[blk * per + e], h, m, l);
+                    p3[(blk * 3 + 0) * per + e] = h; p3[(blk * 3 + 1) * per + e] = m; p3[(blk * 3 + 2) * per + e] = l;
+                }
+            c.w3 = upload_u16(p3);
+        } else {
+            c.w3 = claim(p3.size() * 2);
+            if (c.w3 && c.w3f) rec->split3.push_back(RefreshRec::Split3{c.w3f, c.w3, (int64_t)f.size()});
+        }
     }
     // fast mode, k_chain_b: wave (nt, kh) multiplies the 16-channel output tile nt by input channels 32 kh .. + 31 of tap t; lane (n = l & 15,
     // kq = l >> 4) holds W[co = 16 nt + n][ci = 32 kh + 8 kq + j][t], j = 0..7 -- the B operand of v_mfma_f32_16x16x32_bf16

@@ -2137,6 +2137,194 @@ static void launch_conv_bf(const lz_conv_args &a, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// PARITY MODE (fp32 accuracy), round 5: the tower's 3x3 convolutions as SPLIT-bf16 products on v_mfma_f32_16x16x32_bf16.
+// An fp32 number is EXACTLY the sum of three bf16 numbers (hi = rne(x), mid = rne(x - hi), lo = rne(x - hi - mid): 3 x 8 significant
+// bits).  With both operands split, x w = sum of nine bf16 x bf16 products -- each exact in the fp32 accumulator -- of which the three
+// smallest (mid lo, lo mid, lo lo: below 2^-24 of the product) are dropped: six MFMAs per k-step of 32, fp32 accumulation.  The error of
+// a dot product is that of an fp32 FMA chain (measured on a 576-term product against binary64: 7e-7 relative, torch's own fp32 GEMM
+// 1.3e-6); the tower's output stays inside north_star's 1e-5 (1 + |x|) of the reference modules (tests/test_nn_golden_gpu.py,
+// test_nn_gpu.py) -- this is NOT the fast mode (one bf16 product, statistical parity only).  Why: the bf16 pipe runs 16x the fp32-matrix
+// rate, so six products cost 0.375 of the direct fp32 form and 0.84 of the Winograd F(2x2, 3x3) form these layers used (k_conv_wino), without
+// its transforms (VALU + LDS work that was half of those kernels' time): the tower is compute-bound (weights are reused over thousands of
+// pixels), unlike the recurrent chain and the LSTM, which are bound by their weight stream -- there three planes of bf16 are MORE bytes
+// than fp32 Winograd weights and the split would lose.
+// Structure = k_conv_bf: persistent workgroups, tile = TR output rows x the image width = 96 output pixels, the halo of a tile staged
+// in LDS ([3 planes][row][column][CIN + pad] bf16, conflict-free pixel pitch), transposed MFMAs (weights = A operand), BatchNorm /
+// residual / ReLU on four consecutive channels of a pixel per lane.  Differences: activations are the parity mode's fp32 NHWC tensors
+// (split while they are staged: the NEXT tile's raw halo is requested into registers before this tile's products), and the weights --
+// three planes, [nt][k step][plane][64 lanes][8 bf16] -- stream from L2 one k-step ahead (216 registers would be needed to keep a
+// 64-channel layer's resident).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const __bf16 hq = (__bf16)v[q];
+        const float r1 = v[q] - (float)hq;
+        const __bf16 mq = (__bf16)r1;
+        const float r2 = r1 - (float)mq;
+        h[q] = hq; m[q] = mq; l[q] = (__bf16)r2;
+    }
+}
+
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2 ? 1 : 2))) void k_conv_s3(lz_conv_args a, int ntiles, int TR)
+{
+    constexpr int NT = COUT / 16, MG = 4 / NT;          // waves = NT channel tiles x MG pixel groups
+    constexpr int MTW = 6 / MG;                         // 16-pixel tiles per wave (96 pixels per workgroup tile)
+    constexpr int KC = CIN / 32, KS = 9 * KC;           // k steps of 32: (tap, 32-channel block)
+    constexpr int PBq = STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10), PB = PBq * 8;   // pixel pitch in bf16 (k_conv_bf's: conflict-free ds_read_b128)
+    constexpr int C4 = CIN / 4, NLD = STRIDE == 2 ? 14 : (CIN == 32 ? 7 : 10);  // 16-byte fp32 pieces per pixel; pieces per thread and halo (the launcher checks the bound)
+    static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64) && MTW % 3 == 0, "shapes of the tower");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv % NT, mg = wv / NT;
+    const int Wout = a.Wout, Hout = a.Hout, Win = a.Win, Hin = a.Hin;
+    const int HR = (TR - 1) * STRIDE + 3, HC = (Wout - 1) * STRIDE + 3;
+    const int bands = (Hout + TR - 1) / TR;
+    const int n4 = HR * HC * C4;
+    const int hplane = ((HR * HC * PB + 7) & ~7);       // bf16 per plane
+    __bf16 *sH = reinterpret_cast<__bf16 *>(smem);      // [3 planes][HR][HC][PB]
+    const float *in = a.in, *res = a.residual;
+    float *out = a.out;
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(a.w3) + (size_t)nt * KS * 3 * 64 + lane;   // [nt][ks][plane][64 lanes]
+    const int co4 = nt * 16 + 4 * (lane >> 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + co4), sh = *reinterpret_cast<const f32x4 *>(a.shift + co4);
+    int pbase[MTW], prow[MTW], pcol[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int p = 16 * (mg * MTW + i) + (lane & 15);
+        prow[i] = p / Wout; pcol[i] = p - prow[i] * Wout;
+        pbase[i] = ((prow[i] * STRIDE) * HC + pcol[i] * STRIDE) * PB + (lane >> 4) * 8;   // halo position of tap (0, 0), this lane's k group
+    }
+    // per piece two words (registers are what bounds this kernel's occupancy): source offset inside a row, and
+    // (LDS offset + 1: 0 = no piece) | halo row << 20 | column inside the image << 30
+    int hsrc[NLD], hpk[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int idx = min(u * 256 + tid, n4 - 1);
+        const int pix = idx / C4, c4 = idx - pix * C4, hr = pix / HC, hc = pix - hr * HC, ix = hc - 1;
+        hsrc[u] = min(max(ix, 0), Win - 1) * CIN + c4 * 4;
+        hpk[u] = ((u * 256 + tid < n4) ? pix * PB + c4 * 4 + 1 : 0) | (hr << 20) | (((ix >= 0) & (ix < Win)) ? (1 << 30) : 0);
+    }
+    f32x4 pv[NLD];
+    auto prefetch = [&](int tile) {   // the whole fp32 halo of a tile in flight at once (clamped addresses, zero outside the image by select)
+        const int img = tile / bands, band = tile - img * bands, iy0 = band * TR * STRIDE - 1;
+        const float *src = in + (size_t)img * Hin * Win * CIN;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int iy = iy0 + ((hpk[u] >> 20) & 0x3ff);
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(src + (size_t)min(max(iy, 0), Hin - 1) * Win * CIN + hsrc[u]);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pv[u] = ((iy >= 0) & (iy < Hin) & ((hpk[u] >> 30) & 1)) ? t : z;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / bands, band = tile - img * bands;
+        const int oy0 = band * TR;
+        // ---- the prefetched halo, split into its three bf16 planes, into LDS (one buffer: the barrier below the products frees it)
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            bf16x4 h, m, l;
+            split3_bf16(pv[u], h, m, l);
+            const int hd = (hpk[u] & 0xfffff) - 1;
+            if (hd >= 0) {
+                *reinterpret_cast<bf16x4 *>(sH + hd) = h;
+                *reinterpret_cast<bf16x4 *>(sH + hplane + hd) = m;
+                *reinterpret_cast<bf16x4 *>(sH + 2 * hplane + hd) = l;
+            }
+        }
+        // the first k-step's weights (three planes)
+        bf16x8 wc[3], wn[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wc[pl] = wp[(size_t)pl * 64];
+        __syncthreads();
+        // ---- the next tile's halo travels while this one is multiplied
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        f32x4 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // The k loop is NOT unrolled (fully unrolled it took 256 + 180 registers: one wave per SIMD): a k-step is 3 weight fragments (one
+        // step ahead) and, per group of three pixel tiles, 9 LDS reads + 18 MFMAs -- two waves per SIMD hide each other's LDS round trips.
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+            const int t = ks / KC, kc = ks - t * KC, ty = t / 3;
+            const int toff = (ty * HC + (t - 3 * ty)) * PB + kc * 32;
+            const int ksn = min(ks + 1, KS - 1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wn[pl] = wp[(size_t)(ksn * 3 + pl) * 64];
+#pragma unroll
+            for (int g = 0; g < MTW / 3; ++g) {
+                bf16x8 bh[3], bm[3], bl[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    bh[i] = *reinterpret_cast<const bf16x8 *>(sH + pbase[3 * g + i] + toff);
+                    bm[i] = *reinterpret_cast<const bf16x8 *>(sH + hplane + pbase[3 * g + i] + toff);
+                    bl[i] = *reinterpret_cast<const bf16x8 *>(sH + 2 * hplane + pbase[3 * g + i] + toff);
+                }
+                // six of the nine cross products, the small ones first; product-major so that consecutive MFMAs write different accumulators
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], bm[i], acc[3 * g + i], 0, 0, 0);   // mid x mid
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2], bh[i], acc[3 * g + i], 0, 0, 0);   // lo  x hi
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], bl[i], acc[3 * g + i], 0, 0, 0);   // hi  x lo
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], bh[i], acc[3 * g + i], 0, 0, 0);   // mid x hi
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], bm[i], acc[3 * g + i], 0, 0, 0);   // hi  x mid
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], bh[i], acc[3 * g + i], 0, 0, 0);   // hi  x hi
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wc[pl] = wn[pl];
+        }
+        // ---- epilogue: BatchNorm, residual, ReLU; four consecutive channels of one pixel per lane.  (The residual is requested here, not
+        // before the products: 24 more live registers across the k loop cost the second wave per SIMD, which hides this round trip.)
+        f32x4 rv[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + co4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rv[i] = res ? *reinterpret_cast<const f32x4 *>(res + o) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            f32x4 ov;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = acc[i][q] * sc[q] + sh[q];
+                v += rv[i][q];
+                ov[q] = a.relu ? fmaxf(v, 0.0f) : v;
+            }
+            if (oy0 + prow[i] < Hout) *reinterpret_cast<f32x4 *>(out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + co4) = ov;
+        }
+        __syncthreads();   // every wave is done with this tile's halo: the next one may be written
+    }
+}
+
+template <int CIN, int COUT, int STRIDE>
+static bool launch_conv_s3(const lz_conv_args &a, hipStream_t s)
+{
+    if (96 % a.Wout != 0) return false;
+    const int TR = 96 / a.Wout;
+    const int HR = (TR - 1) * STRIDE + 3, HC = (a.Wout - 1) * STRIDE + 3;
+    constexpr int PB = (STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10)) * 8;
+    constexpr int NLD = STRIDE == 2 ? 14 : (CIN == 32 ? 7 : 10);
+    if (HR * HC * (CIN / 4) > NLD * 256) return false;          // the halo must fit the kernel's per-thread piece count
+    const size_t lds = (size_t)3 * (((size_t)HR * HC * PB + 7) & ~(size_t)7) * 2;
+    if (lds > 150 * 1024) return false;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_conv_s3<CIN, COUT, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    const int ntiles = a.B * ((a.Hout + TR - 1) / TR);
+    const int per_cu = lds > 76 * 1024 ? 1 : 2;
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;   // persistent
+    hipLaunchKernelGGL((k_conv_s3<CIN, COUT, STRIDE>), dim3(grid), dim3(256), lds, s, a, ntiles, TR);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same chain for narrow networks (num_channels = 32 | 16: the reference's gomoku / tictactoe configs,
 // zoo/board_games/gomoku/config/gomoku_muzero_bot_mode_config.py:41-42, tictactoe/...:33-34).  One workgroup per root, activations in
 // LDS across layers; C / 16 output-channel tiles, so the four waves split as (N-tile, M-group): with 32 channels two waves share
@@ -3452,8 +3640,16 @@ void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s
         if (cin == 32 && a.Cout == 64 && stride == 2) { launch_conv_bf<32, 64, 2>(a, s); return; }
         if (cin == 64 && a.Cout == 64 && stride == 1) { launch_conv_bf<64, 64, 1>(a, s); return; }
     }
-    // stride-1 convolutions of the tower: Winograd F(2x2, 3x3) when the transformed weights exist (LZ_CONV_DIRECT=1: the direct form)
+    // parity mode, round 5: the tower's convolutions as split-bf16 products (k_conv_s3: fp32 accuracy on the bf16 matrix pipe); LZ_CONV_NO_SPLIT=1
+    // keeps the fp32-matrix kernels below (Winograd / direct) -- the A/B switch of tests/test_kernel_variants_gpu.py
+    static const char *nosplit = getenv("LZ_CONV_NO_SPLIT");
     static const char *direct = getenv("LZ_CONV_DIRECT");
+    if (a.w3 && !a.act_bf16 && !nosplit && !direct && !a.gather_ix && !a.act_table && !a.residual_gather) {
+        if (cin == 32 && a.Cout == 32 && stride == 1 && launch_conv_s3<32, 32, 1>(a, s)) return;
+        if (cin == 32 && a.Cout == 64 && stride == 2 && launch_conv_s3<32, 64, 2>(a, s)) return;
+        if (cin == 64 && a.Cout == 64 && stride == 1 && launch_conv_s3<64, 64, 1>(a, s)) return;
+    }
+    // stride-1 convolutions of the tower: Winograd F(2x2, 3x3) when the transformed weights exist (LZ_CONV_DIRECT=1: the direct form)
     if (a.uf && !direct && stride == 1 && !a.gather_ix && !a.act_table && a.Hout >= 12 && (a.Hout & 1) == 0 && (a.Wout & 1) == 0) {
         // tiles per workgroup: 32 for the 32-channel layers (one (tile, channel-quad) item per thread); 16 for the 64-channel layers
         // (16 accumulator tiles of 4 registers + one item per thread = 148 registers, three workgroups per CU: 48 us per layer on

@@ -17,6 +17,8 @@ struct lz_conv_args {
     const float *uf;        // optional Winograd F(2x2,3x3) weights U = G g G^T in fragment order [Cout/16][16 points][CIN/16][64 lanes][4]
     const void *wb;         // optional (fast mode): bf16 MFMA fragments [Cout/16][9 taps x CIN/32][64 lanes][8] (k_conv_bf)
     int act_bf16;           // with wb: in / residual / out are bf16 NHWC tensors (the fast tower keeps its activations in bf16), not fp32
+    const void *w3;         // optional (parity mode): the weights split EXACTLY into three bf16 planes, [Cout/16][9 taps x CIN/32][3 planes][64 lanes][8]
+                            // (k_conv_s3: six split-bf16 products per k-step = fp32 accuracy on the bf16 matrix pipe; activations stay fp32 tensors)
     const float *scale;     // [Cout] folded eval-mode BN scale (1 when no norm)
     const float *shift;     // [Cout]
     const float *act_table; // optional [A][Hout*Wout][Cout]: contribution of the one-hot action planes

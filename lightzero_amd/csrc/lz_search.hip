@@ -253,6 +253,14 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
         m->r2b = b.resconv(d + "resblocks2.0", 2, C, C, true);
         m->r3a = b.resconv(d + "resblocks3.0", 1, C, C, true);
         m->r3b = b.resconv(d + "resblocks3.0", 2, C, C, true);
+        if (c.precision == 0 && C == 64) {   // parity mode: the tower's convolutions as split-bf16 products (k_conv_s3: fp32 accuracy on the bf16 matrix pipe)
+            auto rc = [&](const std::string &blk, int idx) { return d + blk + ".conv" + std::to_string(idx) + ".0.weight"; };
+            b.split3_tower(rc("resblocks1.0", 1), C2, C2, m->r1a); b.split3_tower(rc("resblocks1.0", 2), C2, C2, m->r1b);
+            b.split3_tower(rc("downsample_block", 1), C, C2, m->dn1); b.split3_tower(rc("downsample_block", 2), C, C, m->dn2);
+            b.split3_tower(d + "downsample_block.conv3.0.weight", C, C2, m->dn3);
+            b.split3_tower(rc("resblocks2.0", 1), C, C, m->r2a); b.split3_tower(rc("resblocks2.0", 2), C, C, m->r2b);
+            b.split3_tower(rc("resblocks3.0", 1), C, C, m->r3a); b.split3_tower(rc("resblocks3.0", 2), C, C, m->r3b);
+        }
         if (c.precision == 1) {   // fast mode: the tower's convolutions on bf16 MFMA (k_conv_bf)
             auto rc = [&](const std::string &blk, int idx) { return d + blk + ".conv" + std::to_string(idx) + ".0.weight"; };
             m->r1a.wt = b.bf16_tower(rc("resblocks1.0", 1), C2, C2); m->r1b.wt = b.bf16_tower(rc("resblocks1.0", 2), C2, C2);
@@ -464,6 +472,25 @@ __global__ void k_refresh_act(float *src, const RefreshRec::Act *ops)
     }
     src[o.out + i] = acc;
 }
+// a gathered fp32 fragment buffer -> its three bf16 planes (Builder::split3_tower: hi = rne(w), mid = rne(w - hi), lo = rne(w - hi - mid)),
+// blocks of 64 lanes x 8: [block][plane][512]
+__global__ void k_refresh_split3(const RefreshRec::Split3 *ops)
+{
+    const RefreshRec::Split3 o = ops[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= o.n) return;
+    const float w = o.src[i];
+    const __bf16 h = (__bf16)w;
+    const float r1 = w - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    __bf16 *dst = reinterpret_cast<__bf16 *>(o.dst);
+    const int64_t blk = i >> 9, e = i & 511;
+    dst[(blk * 3 + 0) * 512 + e] = h;
+    dst[(blk * 3 + 1) * 512 + e] = m;
+    dst[(blk * 3 + 2) * 512 + e] = l;
+}
 #pragma clang fp contract(fast)
 // every weight buffer from the source space: slot s covers idx[start .. start + count)
 __global__ void k_refresh_gather(const float *__restrict__ src, const int32_t *__restrict__ idx, const RefreshRec::Slot *__restrict__ slots, int n_slots, int64_t total)
@@ -482,7 +509,7 @@ __global__ void k_refresh_gather(const float *__restrict__ src, const int32_t *_
 static void refresh_program_free(lz_model *m)
 {
     RefreshProgram &p = m->refresh;
-    for (void *q : {(void *)p.d_src, (void *)p.d_idx, p.d_slots, p.d_bn, p.d_wino, p.d_act, p.d_add}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)p.d_src, (void *)p.d_idx, p.d_slots, p.d_bn, p.d_wino, p.d_act, p.d_add, p.d_split3}) if (q) (void)hipFree(q);
     if (p.h_pin) (void)hipHostFree(p.h_pin);
     p = RefreshProgram{};
 }
@@ -541,10 +568,13 @@ static int refresh_program_build(lz_engine *e)
     ok = ok && up(&p.d_wino, rec.wino.data(), rec.wino.size() * sizeof(RefreshRec::Wino));
     ok = ok && up(&p.d_act, rec.act.data(), rec.act.size() * sizeof(RefreshRec::Act));
     ok = ok && up(&p.d_add, rec.add.data(), rec.add.size() * sizeof(RefreshRec::Add));
+    ok = ok && up(&p.d_split3, rec.split3.data(), rec.split3.size() * sizeof(RefreshRec::Split3));
     if (!ok) { refresh_program_free(m); p.tried = true; p.why = "out of device memory for the refresh program"; return LZ_OK; }
     p.n_slots = (int)rec.slots.size(); p.n_bn = (int)rec.bn.size(); p.n_wino = (int)rec.wino.size(); p.n_act = (int)rec.act.size(); p.n_add = (int)rec.add.size();
     for (const auto &o : rec.wino) p.wino_items = std::max<int64_t>(p.wino_items, (int64_t)o.cout * o.cin);
     for (const auto &o : rec.act) p.act_items = std::max<int64_t>(p.act_items, (int64_t)o.A * o.SW * o.SH * o.C);
+    p.n_split3 = (int)rec.split3.size();
+    for (const auto &o : rec.split3) p.split3_items = std::max<int64_t>(p.split3_items, o.n);
     p.n_allocs = m->allocs.size();
     p.usable = true;
     return LZ_OK;
@@ -623,6 +653,7 @@ extern "C" int lz_model_refresh_flat(lz_engine *e, const float *flat, int64_t n_
     if (p.n_wino) hipLaunchKernelGGL(k_refresh_wino, dim3((unsigned)((p.wino_items + 255) / 256), (unsigned)p.n_wino), dim3(256), 0, s, p.d_src, (const RefreshRec::Wino *)p.d_wino);
     if (p.n_act) hipLaunchKernelGGL(k_refresh_act, dim3((unsigned)((p.act_items + 255) / 256), (unsigned)p.n_act), dim3(256), 0, s, p.d_src, (const RefreshRec::Act *)p.d_act);
     hipLaunchKernelGGL(k_refresh_gather, dim3((unsigned)((p.out_floats + 255) / 256)), dim3(256), 0, s, p.d_src, p.d_idx, (const RefreshRec::Slot *)p.d_slots, p.n_slots, p.out_floats);
+    if (p.n_split3) hipLaunchKernelGGL(k_refresh_split3, dim3((unsigned)((p.split3_items + 255) / 256), (unsigned)p.n_split3), dim3(256), 0, s, (const RefreshRec::Split3 *)p.d_split3);
     LZ_HIP_CHECK(hipGetLastError());
     m->raw_stale = true;
     return LZ_OK;
@@ -757,7 +788,7 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
 {
     lz_conv_args a{};
     a.act_bf16 = act_bf16;
-    a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.wb = w.wt; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
+    a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.wb = w.wt; a.w3 = w.w3; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
 }
@@ -2012,7 +2043,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

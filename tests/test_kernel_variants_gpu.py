@@ -1,5 +1,5 @@
 """GPU: the alternative kernel paths behind the LZ_* switches of INTEGRATION.md §2d (direct-form chain / tower, 4-wave Winograd chain, VALU
-heads, unsplit LSTM staging, the pipelined 32-row LSTM kernel, separate tree launch) must meet the same reference-module goldens as the default path.  The switches are read
+heads, unsplit LSTM staging, the fp32-matrix (Winograd) tower instead of the split-bf16 one, the level-by-level tree walk, the pipelined 32-row LSTM kernel, separate tree launch) must meet the same reference-module goldens as the default path.  The switches are read
 once per process, so every variant runs tests/test_nn_golden_gpu.py in a process of its own."""
 import os
 import subprocess
@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_CONV_FIRST_VALU", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_LSTM_NOSPLIT", "LZ_NO_TREE_FUSE", "LZ_NO_GRAPH", "LZ_LSTM3"]
+VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_TRAVERSE_SERIAL", "LZ_CONV_FIRST_VALU", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_LSTM_NOSPLIT", "LZ_NO_TREE_FUSE", "LZ_NO_GRAPH", "LZ_LSTM3"]
 
 
 @pytest.mark.gpu

@@ -45,7 +45,7 @@ def main():
         pass
     tot = sum(float(r["TotalDurationNs"]) for r in rows.values()) or 1.0
     for name, r in sorted(rows.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
-        if not any(k in name for k in ("k_backprop", "k_traverse", "k_prepare", "k_chain", "k_heads", "k_readout", "k_collect")):
+        if not any(k in name for k in ("k_backprop", "k_traverse", "k_tree_step_wg", "k_prepare", "k_chain", "k_heads", "k_readout", "k_collect")):
             continue
         f = acc.get(name, {}).get("FETCH_SIZE"); w = acc.get(name, {}).get("WRITE_SIZE")
         fk = sum(f) / len(f) if f else None; wk = sum(w) / len(w) if w else None
@@ -57,6 +57,11 @@ def main():
             ent["hbm_bytes_per_launch"] = int(b)
             ent["hbm_gb_per_s"] = round(b / (us * 1e-6) / 1e9, 1)
             ent["frac_of_hbm_peak"] = round(b / (us * 1e-6) / 1e9 / PEAK_GBS, 4)
+        if "k_tree_step_wg" in name:
+            ent["algorithmic_bytes_note"] = ("round 5: a workgroup per root scores EVERY expanded node each simulation (thread = node): per root and simulation "
+                                             "nodes x (A x 20 B of edge + child records + 24 B of node record) read once + the path's statistics written; at "
+                                             "simulation s that is (s + 1) x 104 B for A = 4 -> ~21 KB per root at the mean tree size of a 400-simulation search, "
+                                             "~21 MB per launch for %d roots; DESIGN.md section 3.1c" % B)
         if "k_backprop_traverse" in name:
             ent["algorithmic_bytes_note"] = ("per root and simulation: depth x (A x 20 B of edge + child records read + 16 B of statistics written) with "
                                              "depth ~13..54 over these simulations -> ~3 MB per launch for %d roots; measured traffic above that is "
