@@ -26,6 +26,8 @@ struct ConvW {
     void *wt = nullptr;   // fast mode: bf16 fragments for the tower kernel k_conv_bf, [cout/16][9 taps x cin/32][64 lanes][8 bf16]
     void *w3 = nullptr;   // parity mode: the same fragments split exactly into three bf16 planes (hi | mid | lo) for k_conv_s3,
                           // [cout/16][9 taps x cin/32][3 planes][64 lanes][8 bf16]
+    void *w3c = nullptr;  // parity mode, 6x6 chain (k_chain_s3): [2 k halves][cout/16][9 taps][3 planes][64 lanes][8 bf16]; w3cf = its fp32 values (refresh)
+    float *w3cf = nullptr;
     float *w3f = nullptr; // the fp32 values of those fragments in the same order [cout/16][ks][64 lanes][8] (what a device-side refresh gathers; k_refresh_split3 turns it into w3)
     int cin = 0, cout = 0;
 };
@@ -269,6 +271,7 @@ struct Builder {
         if (winograd) c.uf = wino(p + ".0.weight", cout, cin);
         if (wchain) c.uc = wino_chain(p + ".0.weight", cout, cin, cin);
         if (wchain && m->cfg.precision == 1) c.wb = bf16_chain(p + ".0.weight", cout, cin, cin);
+        if (wchain && m->cfg.precision == 0 && m->GW == 6 && m->GH == 6) split3_chain(p + ".0.weight", cout, cin, cin, c);
         return c;
     }
     // fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
@@ -345,6 +348,37 @@ struct Builder {
         } else {
             c.w3 = claim(p3.size() * 2);
             if (c.w3 && c.w3f) rec->split3.push_back(RefreshRec::Split3{c.w3f, c.w3, (int64_t)f.size()});
+        }
+    }
+    // parity mode, k_chain_s3: k_chain_b's fragment order ([kh][nt][tap][64 lanes][8]: lane (n = l & 15, kq = l >> 4) holds
+    // W[co = 16 nt + n][ci = 32 kh + 8 kq + j][t]) with every weight split into three bf16 planes per (kh, nt, tap) block
+    void split3_chain(const std::string &wname, int cout, int cin_total, int cin, ConvW &c)
+    {
+        const HostTensor *w = get(wname, {cout, cin_total, 3, 3});
+        if (!w || cout != 64 || cin != 64) return;
+        std::vector<float> f((size_t)2 * 4 * 9 * 64 * 8);
+        for (int kh = 0; kh < 2; ++kh)
+            for (int nt = 0; nt < 4; ++nt)
+                for (int t = 0; t < 9; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = nt * 16 + (lane & 15), ci = kh * 32 + (lane >> 4) * 8 + j;
+                            f[((((size_t)kh * 4 + nt) * 9 + t) * 64 + lane) * 8 + j] = w->data[((size_t)co * cin_total + ci) * 9 + t];
+                        }
+        c.w3cf = upload(f);
+        std::vector<uint16_t> p3(f.size() * 3);
+        if (!rec) {
+            const size_t per = (size_t)64 * 8;
+            for (size_t blk = 0; blk < f.size() / per; ++blk)
+                for (size_t e = 0; e < per; ++e) {
+                    uint16_t h, m2, l;
+                    split3(f[blk * per + e], h, m2, l);
+                    p3[(blk * 3 + 0) * per + e] = h; p3[(blk * 3 + 1) * per + e] = m2; p3[(blk * 3 + 2) * per + e] = l;
+                }
+            c.w3c = upload_u16(p3);
+        } else {
+            c.w3c = claim(p3.size() * 2);
+            if (c.w3c && c.w3cf) rec->split3.push_back(RefreshRec::Split3{c.w3cf, c.w3c, (int64_t)f.size()});
         }
     }
     // fast mode, k_chain_b: wave (nt, kh) multiplies the 16-channel output tile nt by input channels 32 kh .. + 31 of tap t; lane (n = l & 15,

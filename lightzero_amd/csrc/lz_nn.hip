@@ -1999,6 +1999,348 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     lz_stamp_end(a.stamp);
 }
 
+__device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const __bf16 hq = (__bf16)v[q];
+        const float r1 = v[q] - (float)hq;
+        const __bf16 mq = (__bf16)r1;
+        const float r2 = r1 - (float)mq;
+        h[q] = hq; m[q] = mq; l[q] = (__bf16)r2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PARITY MODE (fp32 accuracy), round 5: the recurrent chain on the 6x6 latent as SPLIT-bf16 products -- k_chain_b's launch (tree step on
+// wave 0, split-head finish on waves 1-7, five 3x3 layers in the DIRECT form with the activations resident in LDS, 1x1 head convolutions)
+// with every operand split EXACTLY into three bf16 terms and six of the nine cross products per k-step (see k_conv_s3 for the arithmetic:
+// the error of a dot product is that of an fp32 FMA chain; tests/test_nn_gpu.py holds every simulation of a 256 x 50 search to 1e-5 (1 + |x|)
+// of the torch fp32 modules).  Why it is faster than the fp32 Winograd chain (k_chain_w), although both are bound by the weight stream of
+// one root per CU: three bf16 planes of the direct form are 221 KB per layer against 262 KB of transformed fp32 weights, the six products
+// are 5.2 k matrix cycles per SIMD and layer against 6.1 k, and the Winograd input / output transforms -- 3.7 k cycles of LDS-bound work
+// per layer, four barriers -- are gone (one exchange of the two k halves and the epilogue remain).
+// ------------------------------------------------------------------------------------------------
+template <int GW, int GH, int TREE = 0, bool HEADS = false>
+__global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step_arg<TREE>::type step)
+{
+    constexpr int NW = 8, PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
+    constexpr int PB = 80;                               // bf16 per pixel of the bf16 copies: 64 + pad.  160 B = 10 bank quads: the 16-lane groups ds_read_b128 is
+                                                         // served in ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) then hit 16 distinct quads (144 B: 2-way conflicts)
+    static_assert(MT == 3 && HW % 4 == 0, "the 6x6 latent (three 16-pixel tiles)");
+    constexpr int NPL = 3;                               // bf16 planes of every activation / weight: hi | mid | lo (exact three-term split of fp32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 fp32 activation buffers of BUF floats (the staged tree first), then
+    float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
+    float *sSS = sTab + HW * PS;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
+    float *sMisc = sSS + LZ_CHAIN_MAX_LAYERS * 128;     // 128 floats: the tree step's selection
+    float *sP = sMisc + 128;                            // [4 nt][MT][64 lanes][4] partial sums of the kh = 1 waves (prologue: head scratch)
+    __bf16 *sB = reinterpret_cast<__bf16 *>(sP + 4 * MT * 256);   // 4 buffers x 3 planes x [HW + 1][PB]: the split of the activation buffers
+    constexpr int BB = (HW + 1) * PB;                   // one plane
+    constexpr int BB3 = NPL * BB;                       // one buffer
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv & 3, kh = wv >> 2;
+    const int b = blockIdx.x;
+    lz_stamp_begin(a.stamp);
+    // per-layer parameters: lane L keeps layer L's (a scalar load from the argument block at the top of every layer is a round trip the
+    // layer then waits for); v_readlane hands them out
+    const lz_chain_layer &myl = a.layer[min(lane, LZ_CHAIN_MAX_LAYERS - 1)];
+    const unsigned long long my_wb = (unsigned long long)myl.w3, my_gout = (unsigned long long)myl.gout;
+    const int my_flags = myl.in | (myl.out << 2) | ((myl.res + 1) << 4) | ((myl.relu != 0) << 7) | ((myl.act != 0) << 8);
+    auto lane64 = [&](unsigned long long v, int L) {
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), L);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    // weights: [layer][kh][nt][tap][plane][64 lanes][8 bf16]; a layer's 27 fragments per wave do not stay in registers (108 of them, and as
+    // many again for the next layer): they stream through a ring of RT taps x 3 planes that runs across layer boundaries -- tap t + RT is
+    // requested when tap t's products are issued (18 MFMAs = 288 cycles per tap and wave, two waves per SIMD: RT = 3 covers an L2 round trip)
+    constexpr int RT = 3;
+    const size_t wofs = (((size_t)kh * 4 + nt) * 9) * NPL * 64 + lane;
+    bf16x8 wr[RT][NPL];
+    auto load_tap = [&](const void *wl, int t, bf16x8 (&dst)[NPL]) {
+        const bf16x8 *w0 = reinterpret_cast<const bf16x8 *>(wl) + wofs + (size_t)t * NPL * 64;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) dst[pl] = w0[pl * 64];
+    };
+    auto load_w0 = [&]() {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) load_tap(a.layer[0].w3, t, wr[t]);
+    };
+    // the first layer's weights: at once without a tree step; with one, the head waves request theirs when their head is done and the tree
+    // wave after the step, together with the latent gather (36 more live registers across the prologue spill)
+    if constexpr (TREE == 0) load_w0();
+    // 1x1 head convolutions at the end of the kernel (as in k_chain_w)
+    constexpr bool C1SPLIT = (HW % 16) != 0 && (HW % 16) <= 4 && HW / 16 == 2;
+    const int nj = max(a.nc1, 1);
+    const int c1j = C1SPLIT ? wv % nj : min(wv, nj - 1);
+    float4 c1w[4];
+    float4 c1b, c1s, c1t;
+    {
+        const lz_c1_job &jb = a.c1[c1j];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(jb.w + (size_t)(lane & 15) * 64 + g * 16 + (lane >> 4) * 4);
+        c1b = *reinterpret_cast<const float4 *>(jb.bias + (lane >> 4) * 4);
+        c1s = *reinterpret_cast<const float4 *>(jb.scale + (lane >> 4) * 4);
+        c1t = *reinterpret_cast<const float4 *>(jb.shift + (lane >> 4) * 4);
+    }
+    int g_slot = 0, g_action = 0;
+    if constexpr (TREE != 0) {
+        int32_t *s_sel = reinterpret_cast<int32_t *>(sMisc + 120);
+        float *s_leaf = sP;
+        int32_t *s_ctr = reinterpret_cast<int32_t *>(sP + 80);
+        float *s_red = sP + 96;
+        bool heads_on = false;
+        if constexpr (HEADS) {
+            heads_on = step.sh.on != 0;
+            if (heads_on) {
+                if (tid < 8) s_ctr[tid] = 0;
+                __syncthreads();
+            }
+        }
+        if (wv == 0) {
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(3);
+            dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
+                                      heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(0);
+        } else {
+            if constexpr (HEADS) {
+                const int hw = wv < 4 ? wv - 1 : (wv == 4 ? 6 : wv - 2);
+                if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
+            }
+            load_w0();
+            for (int i = tid - 64; i < a.nlayers * 128; i += NTHR - 64) {
+                const int L = i >> 7, r = i & 127;
+                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+            }
+        }
+        __syncthreads();
+        if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
+        g_slot = s_sel[0];
+        g_action = s_sel[1];
+        if (wv == 0) load_w0();
+    } else {
+        if (a.gather_ix) g_slot = a.gather_ix[b];
+        if (a.act_table) g_action = a.action[b];
+    }
+    {
+        const float *src = a.in + (size_t)b * HW * 64 + (size_t)g_slot * a.slot_stride;
+        constexpr int NU = (HW * 16 + NTHR - 1) / NTHR;
+        float4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = min(u * NTHR + tid, HW * 16 - 1);
+            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
+        }
+        float4 tv[NU];
+        const bool tabl = a.act_table != nullptr;
+        {
+            const float *tsrc = tabl ? a.act_table + (size_t)g_action * HW * 64 : src;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = min(u * NTHR + tid, HW * 16 - 1);
+                tv[u] = *reinterpret_cast<const float4 *>(tsrc + (size_t)idx * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = u * NTHR + tid;
+            if (idx < HW * 16) {
+                *reinterpret_cast<float4 *>(smem + (idx >> 4) * PS + (idx & 15) * 4) = v[u];
+                bf16x4 h, m3, l3;
+                split3_bf16((f32x4){v[u].x, v[u].y, v[u].z, v[u].w}, h, m3, l3);
+                *reinterpret_cast<bf16x4 *>(sB + (idx >> 4) * PB + (idx & 15) * 4) = h;
+                *reinterpret_cast<bf16x4 *>(sB + BB + (idx >> 4) * PB + (idx & 15) * 4) = m3;
+                *reinterpret_cast<bf16x4 *>(sB + 2 * BB + (idx >> 4) * PB + (idx & 15) * 4) = l3;
+                if (tabl) *reinterpret_cast<float4 *>(sTab + (idx >> 4) * PS + (idx & 15) * 4) = tv[u];
+            }
+        }
+        // the all-zero pixel of every buffer (fp32: the head convolutions' padding rows; bf16: the halo)
+        if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
+        if (tid >= 64 && tid < 64 + 4 * NPL * (PB / 8)) {   // 12 (buffer, plane) pairs x 10 16-byte pieces
+            const int i = tid - 64;
+            *reinterpret_cast<float4 *>(sB + (i / (PB / 8)) * BB + HW * PB + (i % (PB / 8)) * 8) = vzero4();
+        }
+        if (TREE == 0) {
+            for (int i = tid; i < a.nlayers * 128; i += NTHR) {
+                const int L = i >> 7, r = i & 127;
+                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
+            }
+        }
+    }
+    // ---- per-lane geometry, the same for every layer: A rows of this lane = pixels 16 mt + (lane & 15); tap (dy, dx) reads pixel
+    // m + dy GW + dx when it is inside the image, the zero pixel otherwise (one validity bit per (row tile, tap))
+    unsigned long long valid = 0;
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + (lane & 15), y = m / GW, x = m - y * GW;
+        abase[mt] = (m * PB + kh * 32 + (lane >> 4) * 8) * 2;   // bytes
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (m < HW && yy >= 0 && yy < GH && xx >= 0 && xx < GW) valid |= 1ull << (mt * 9 + t);
+        }
+    }
+    const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
+    const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
+    __syncthreads();
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[6] = __builtin_readcyclecounter(); }
+
+    // output geometry of this lane, the same for every layer.  The MFMAs run TRANSPOSED (weights as the A operand): D[channel][pixel], so a
+    // lane ends up with four consecutive channels co4 .. co4 + 3 of ONE pixel -- 16 contiguous bytes in every [pixel][channel] array
+    const int co4 = nt * 16 + 4 * (lane >> 4);
+    const int nlayers = a.nlayers;
+    for (int L = 0; L < nlayers; ++L) {
+        const int flags = __builtin_amdgcn_readlane(my_flags, L);
+        const int Ln = L + 1 < nlayers ? L + 1 : L;
+        const char *sBin = reinterpret_cast<const char *>(sB + (flags & 3) * BB3);
+        float *sOut = smem + ((flags >> 2) & 3) * BUF;
+        __bf16 *sBout = sB + ((flags >> 2) & 3) * BB3;
+        const void *wl_cur = reinterpret_cast<const void *>(lane64(my_wb, L)), *wl_nxt = reinterpret_cast<const void *>(lane64(my_wb, Ln));
+        // pixel fragments of a tap: 3 row tiles x 3 planes; the next tap's are requested before this tap's 18 MFMAs
+        auto read_tap = [&](int t, bf16x8 (&af)[NPL][MT]) {
+            const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) af[pl][mt] = *reinterpret_cast<const bf16x8 *>(sBin + off + pl * BB * 2);
+            }
+        };
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[2][NPL][MT];
+        read_tap(0, fa[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) read_tap(t + 1, fa[(t + 1) & 1]);
+            const bf16x8 (&x)[NPL][MT] = fa[t & 1];
+            bf16x8 w[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) w[pl] = wr[t % RT][pl];
+            // the ring slot is free: tap t + RT of this layer, or the first taps of the next one
+            if (t + RT < 9) load_tap(wl_cur, t + RT, wr[t % RT]);
+            else load_tap(wl_nxt, t + RT - 9, wr[t % RT]);
+            __builtin_amdgcn_sched_barrier(0);
+            // six of the nine cross products (hi mid lo = planes 0 1 2), small ones first; product-major: consecutive MFMAs write different accumulators
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1][mt], acc[mt], 0, 0, 0);   // mid x mid
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0][mt], acc[mt], 0, 0, 0);   // lo  x hi
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2][mt], acc[mt], 0, 0, 0);   // hi  x lo
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0][mt], acc[mt], 0, 0, 0);   // mid x hi
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1][mt], acc[mt], 0, 0, 0);   // hi  x mid
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0][mt], acc[mt], 0, 0, 0);   // hi  x hi
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the two k halves meet in LDS: the kh = 0 wave of an output tile finishes the even pixel tiles (6x6: pixels 0..15, 32..35), the
+        // kh = 1 wave the odd ones -- each leaves its partial sums of the OTHER wave's tiles in sP[nt][mt]
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if ((mt & 1) != kh) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
+        __syncthreads();
+#ifdef LZ_DEBUG_KNOBS
+        if (!(a.debug_flags & 8))     // 8 = no epilogue
+#endif
+        {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + co4), sh = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + 64 + co4);
+            const bool tab = (flags >> 8) & 1, relu = (flags >> 7) & 1;
+            const int res = ((flags >> 4) & 7) - 1;
+            const float *sRes = smem + max(res, 0) * BUF;
+            float *go = reinterpret_cast<float *>(lane64(my_gout, L));
+            if (go) go += (size_t)b * HW * 64;
+            // every LDS read of the epilogue before its first write (the compiler must assume they alias)
+            constexpr int NF = (MT + 1) / 2;       // pixel tiles this wave may finish: kh, kh + 2 (< MT)
+            f32x4 other[NF], tvv[NF], rvv[NF];
+            int mpix[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int mt = min(kh + 2 * f, MT - 1);
+                mpix[f] = mt * 16 + (lane & 15);
+                const int m = min(mpix[f], HW - 1);
+                other[f] = *reinterpret_cast<const f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4);
+                tvv[f] = *reinterpret_cast<const f32x4 *>(sTab + m * PS + co4);
+                rvv[f] = *reinterpret_cast<const f32x4 *>(sRes + m * PS + co4);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                if (kh + 2 * f >= MT) continue;
+                const f32x4 mine = kh == 1 ? acc[(1 + 2 * f < MT) ? 1 + 2 * f : MT - 1] : acc[2 * f];
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = mine[q] + other[f][q];
+                    v += tab ? tvv[f][q] : 0.0f;
+                    v = v * sc[q] + sh[q];
+                    v += res >= 0 ? rvv[f][q] : 0.0f;
+                    o[q] = relu ? fmaxf(v, 0.0f) : v;
+                }
+                bf16x4 oh, om, ol;
+                split3_bf16(o, oh, om, ol);
+                if (mpix[f] < HW) {
+                    *reinterpret_cast<f32x4 *>(sOut + mpix[f] * PS + co4) = o;
+                    *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + co4) = oh;
+                    *reinterpret_cast<bf16x4 *>(sBout + BB + mpix[f] * PB + co4) = om;
+                    *reinterpret_cast<bf16x4 *>(sBout + 2 * BB + mpix[f] * PB + co4) = ol;
+                    if (go) store_wt(go + mpix[f] * 64 + co4, o);
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L < 8) step.ts[16 + L] = __builtin_readcyclecounter(); }
+    }
+    // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU in fp32, as in k_chain_w
+    auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {
+        float4 v;
+        v.x = fmaxf((acc[0] + c1b.x) * c1s.x + c1t.x, 0.0f);
+        v.y = fmaxf((acc[1] + c1b.y) * c1s.y + c1t.y, 0.0f);
+        v.z = fmaxf((acc[2] + c1b.z) * c1s.z + c1t.z, 0.0f);
+        v.w = fmaxf((acc[3] + c1b.w) * c1s.w + c1t.w, 0.0f);
+        store_wt(jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + cq * 4, (f32x4){v.x, v.y, v.z, v.w});
+    };
+    auto c1_tile = [&](int job, int i) {
+        const float *sIn = smem + a.c1_in[job] * BUF + kq4;
+        const int row = i * 16 + (lane & 15);
+        const int off = (row < HW) ? row * PS : zoff;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 xf = *reinterpret_cast<const float4 *>(sIn + off + g * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(c1w[g], j), vget(xf, j), acc, 0, 0, 0);
+        }
+        if (row < HW) c1_store(a.c1[job], row, lane >> 4, acc);
+    };
+    auto c1_rem = [&](int job) {
+        const float *sIn = smem + a.c1_in[job] * BUF + kq4;
+        const int row = (HW / 16) * 16 + (lane & 3);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 xf = *reinterpret_cast<const float4 *>(sIn + row * PS + g * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vget(c1w[g], j), vget(xf, j), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = xor32_sum(xor16_sum(acc[q]));
+        const int cg = (lane >> 2) & 3;
+        if ((lane >> 4) == cg) c1_store(a.c1[job], row, cg, acc);
+    };
+    if constexpr (C1SPLIT) {
+        if (wv < a.nc1) { c1_tile(c1j, 0); c1_rem(c1j); }
+        else if (wv < 2 * a.nc1) c1_tile(c1j, 1);
+    } else if (wv < a.nc1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) c1_tile(wv, i);
+    }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[24] = __builtin_readcyclecounter(); }
+    lz_stamp_end(a.stamp);
+}
+
 // ------------------------------------------------------------------------------------------------
 // FAST MODE: 3x3 convolution of the representation tower (48^2, 24^2, 12^2 grids; stride 1 | 2) on v_mfma_f32_16x16x32_bf16.
 // One tile = TR output rows x the full width of one image = 96 output pixels (six 16-pixel MFMA column tiles); the input halo of the tile
@@ -2155,18 +2497,6 @@ static void launch_conv_bf(const lz_conv_args &a, hipStream_t s)
 // three planes, [nt][k step][plane][64 lanes][8 bf16] -- stream from L2 one k-step ahead (216 registers would be needed to keep a
 // 64-channel layer's resident).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const __bf16 hq = (__bf16)v[q];
-        const float r1 = v[q] - (float)hq;
-        const __bf16 mq = (__bf16)r1;
-        const float r2 = r1 - (float)mq;
-        h[q] = hq; m[q] = mq; l[q] = (__bf16)r2;
-    }
-}
-
 template <int CIN, int COUT, int STRIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2 ? 1 : 2))) void k_conv_s3(lz_conv_args a, int ntiles, int TR)
 {
@@ -3804,8 +4134,35 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
             return;
         }
     }
-    // 6x6 / 8x8 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
+    // parity mode, 6x6 grid, every layer with split-bf16 planes: k_chain_s3 (LZ_CHAIN_NO_SPLIT=1 keeps the fp32-matrix chains below)
     static const char *direct = getenv("LZ_CHAIN_DIRECT");
+    {
+        static const char *nosplit = getenv("LZ_CHAIN_NO_SPLIT");
+        bool s3 = !nosplit && !direct && !getenv("LZ_CHAIN_W4") && a.gw == 6 && a.gh == 6 && a.nlayers > 0 && !a.tstamp && !a.gelu && (a.C == 0 || a.C == 64);
+        for (int i = 0; i < a.nlayers; ++i) s3 = s3 && a.layer[i].w3 != nullptr;
+        if (s3) {
+            const int hw = 36, mt = 3;
+            const size_t lds = (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 4 * mt * 256) * 4 + (size_t)3 * 4 * (hw + 1) * 80 * 2;
+            const dim3 g(a.B), blk(512);
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void *)k_chain_s3<6, 6, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_chain_s3<6, 6, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_chain_s3<6, 6, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_chain_s3<6, 6, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr = true;
+            }
+            if (step) {
+                if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on) hipLaunchKernelGGL((k_chain_s3<6, 6, 1, true>), g, blk, lds, s, a, *step);
+                else if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_s3<6, 6, 1, false>), g, blk, lds, s, a, *step);
+                else hipLaunchKernelGGL((k_chain_s3<6, 6, 2, false>), g, blk, lds, s, a, *step);
+            } else {
+                hipLaunchKernelGGL((k_chain_s3<6, 6>), g, blk, lds, s, a, no_step{});
+            }
+            return;
+        }
+    }
+    // 6x6 / 8x8 grids whose layers all carry Winograd-transformed weights: k_chain_w (LZ_CHAIN_DIRECT=1: the direct form)
     bool wino = (!direct || a.gelu) && ((a.gw == 6 && a.gh == 6) || (a.gw == 8 && a.gh == 8)) && a.nlayers > 0;   // (only k_chain_w reads the GELU codes)
     for (int i = 0; i < a.nlayers; ++i) wino = wino && a.layer[i].uc != nullptr;
     if (wino) {

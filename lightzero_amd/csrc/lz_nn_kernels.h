@@ -70,6 +70,7 @@ struct lz_chain_layer {
     const float *wf;       // fragment-packed weights [4][9][4][64][4]  (N-tile, tap, 16-channel group, lane, 4 floats)
     const float *uc;       // optional: Winograd F(2x2,3x3) weights [16 points][16 channel quads][64 = cout][4] (k_chain_w, 6x6 grids)
     const void *wb;        // optional (fast mode, lz_model_cfg::precision = 1): bf16 MFMA fragments [2 k halves][4 N-tiles][9 taps][64 lanes][8] (k_chain_b, 6x6 grids)
+    const void *w3;        // optional (parity mode, 6x6 grids): the same fragments split exactly into three bf16 planes, [2][4][9 taps][3 planes][64 lanes][8] (k_chain_s3)
     const float *scale, *shift;  // [64] folded BatchNorm
     int in, out, res;      // LDS buffer indices (0..3); res < 0: no residual
     int relu, act;         // relu: 0 none, 1 ReLU, 2 GELU(tanh) (2 only with lz_chain_args::gelu); act: add the one-hot-action table before BN (dynamics conv)

@@ -283,6 +283,7 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
         m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + AE, C);
         if (wchain) m->dyn.uc = b.wino_chain(d + "conv.weight", C, C + AE, C);
         if (wchain && c.precision == 1) m->dyn.wb = b.bf16_chain(d + "conv.weight", C, C + AE, C);
+        if (wchain && c.precision == 0 && m->GW == 6 && m->GH == 6) b.split3_chain(d + "conv.weight", C, C + AE, C, m->dyn);
         // one-hot action planes: plane a is all ones inside the 6x6 latent, so its contribution to output
         // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image.  not_one_hot: ONE plane holding
         // action / action_space_size (fp32, like the reference's expand(...) / A): entry a = the in-bounds taps of W[co][C] times that
@@ -802,7 +803,7 @@ __global__ void k_zero2(float4 *__restrict__ a, float4 *__restrict__ b, size_t n
 static lz_chain_layer chlayer(const ConvW &w, int in, int out, int res, int relu, int act, float *gout)
 {
     lz_chain_layer l{};
-    l.wf = w.wf; l.uc = w.uc; l.wb = w.wb; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
+    l.wf = w.wf; l.uc = w.uc; l.wb = w.wb; l.w3 = w.w3c; l.scale = w.scale; l.shift = w.shift; l.in = in; l.out = out; l.res = res; l.relu = relu; l.act = act; l.gout = gout;
     return l;
 }
 
@@ -2043,7 +2044,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_TRAVERSE_SERIAL", "LZ_CONV_FIRST_VALU", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_LSTM_NOSPLIT", "LZ_NO_TREE_FUSE", "LZ_NO_GRAPH", "LZ_LSTM3"]
+VARIANTS = ["LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_NO_SPLIT", "LZ_TRAVERSE_SERIAL", "LZ_CONV_FIRST_VALU", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_LSTM_NOSPLIT", "LZ_NO_TREE_FUSE", "LZ_NO_GRAPH", "LZ_LSTM3"]
 
 
 @pytest.mark.gpu
