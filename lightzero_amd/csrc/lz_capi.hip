@@ -137,7 +137,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
                  o_reset = take(nBN * 4), o_tp = take(nBN * 4), o_best = take(nBN * 4), o_rv = take((size_t)B * 4),
                  o_rs = take((size_t)B * 4), o_legal = take((size_t)B * A * 4), o_nl = take((size_t)B * 4),
                  o_mm = take((size_t)B * 8), o_pn = take(nBN * 4), o_pa = take(nBN * 4), o_res = take((size_t)B * 4 * 5),
-                 o_ep = take(256), o_rep = take(D ? nBNA * 4 : 0), o_nch = take(D ? nBN * 4 : 0),
+                 o_ep = take(256 + 512), o_rep = take(D ? nBNA * 4 : 0), o_nch = take(D ? nBN * 4 : 0),
                  o_act = take(D ? nBNA * D * 4 : 0), o_laf = take(D ? (size_t)B * D * 4 : 0),
                  o_bidx = take(nBN * 4), o_noinf = take((size_t)B * 4), o_link = take(nBN * 8),
                  o_raw = take(variant == LZ_TREE_GUMBEL_MUZERO ? nBN * 4 : 0), o_gum = take(variant == LZ_TREE_GUMBEL_MUZERO ? (size_t)A * 4 : 0),
@@ -160,6 +160,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.rep = D ? (int32_t *)(base + o_rep) : nullptr; t.nchild = D ? (int32_t *)(base + o_nch) : nullptr;
     t.actions = D ? (float *)(base + o_act) : nullptr; t.res_last_action_f = D ? (float *)(base + o_laf) : nullptr;
     t.rng_epoch = (uint32_t *)(base + o_ep);
+    r->explore_tab = (float *)(base + o_ep + 256);
     t.node_bidx = (int32_t *)(base + o_bidx); t.res_noinf = (int32_t *)(base + o_noinf); t.node_link = (uint64_t *)(base + o_link);
     // no kernel may depend on what the allocator handed back (epoch, legal lists, results).  On the engine's own stream: that
     // stream is non-blocking, so a null-stream memset queued behind another library's work (torch's default stream) could land

@@ -139,6 +139,7 @@ struct lz_roots {
     float *latent_pool = nullptr;   // [NN][B][HW][C]   NHWC latent of every expanded node
     float *h_pool = nullptr;        // [NN][B][H]       LSTM state pools (EfficientZero)
     float *c_pool = nullptr;
+    float *explore_tab = nullptr;   // [128] lz_traverse_args::tab of the running search (inside the slab)
     float *sim_vp = nullptr;        // [NN][B]          value prefix / reward of node n (after h^-1)
     float *sim_value = nullptr;     // [NN][B]
     float *sim_logits = nullptr;    // [NN][B][A]
@@ -199,6 +200,8 @@ struct lz_traverse_args {
     int fresh_minmax = 0;      // k_traverse only: the first selection of a search starts a fresh CMinMaxStats (cminimax.cpp:6-10) itself
     int serial = 0;            // 1 (LZ_TRAVERSE_SERIAL): the LDS tree step walks level by level (dev_traverse) even where the
                                // tree-parallel selection (dev_traverse_par) applies -- A/B runs and the bit-identity test
+    const float *tab = nullptr;  // [2][64] exploration factors by visit count n (lz_tree_launch_explore_tab): log((n + base + 1) / base) + init | sqrt(n);
+                               // null: dev_step_lds computes them itself (a software logf + two table fetches in front of every step)
     unsigned long long *dbg_ts = nullptr;  // timing experiments (debug build, LZ_DEBUG_TREE_SEP_TS): [64 roots][8] cycle stamps of k_backprop_traverse
 };
 // one expand + backup + next-selection step for every root (dev_step_lds in lz_tree_dev.h), as run by k_backprop_traverse_lds
@@ -220,6 +223,7 @@ struct lz_tree_step {
 void lz_launch_select_action(const lz_tree_dev &t, double inv_temperature, int deterministic, uint64_t seed, int32_t *d_pos,
                              double *d_ent, hipStream_t s);
 void lz_tree_launch_minmax_reset(const lz_tree_dev &t, hipStream_t s);
+void lz_tree_launch_explore_tab(float *out, int pb_c_base, float pb_c_init, hipStream_t s);   // out[0..63], out[64..127]: see lz_traverse_args::tab
 void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int noises_ragged,
                             const int32_t *d_noise_off, const float *d_vp, const float *d_logits,
                             const int32_t *d_to_play, hipStream_t s);

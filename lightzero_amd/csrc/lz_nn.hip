@@ -1083,6 +1083,14 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// A pointer rebuilt from an integer (v_readlane of a per-layer address kept in a lane) is a FLAT pointer to the compiler: its loads become
+// flat_load, which count on vmcnt AND lgkmcnt and may return out of order with LDS traffic, so every wait on them is s_waitcnt vmcnt(0)
+// lgkmcnt(0) -- a full drain of the weight stream in the middle of the MFMA loop (seen in the ISA of k_chain_s3 and k_chain_b).  Say that
+// the address is global.
+typedef __attribute__((address_space(1))) const bf16x8 gbl_bf16x8;
+__device__ __forceinline__ gbl_bf16x8 *as_global_bf16x8(unsigned long long addr) { return (gbl_bf16x8 *)addr; }
+__device__ __forceinline__ bf16x8 gload(gbl_bf16x8 *p) { return *p; }
+
 // Write-through stores (sc0 sc1) for the big per-launch outputs of the recurrent loop (next latent, head-convolution rows, LSTM state, head
 // partials: 4-5 MB per launch).  What a kernel leaves dirty in L2 is written back at the kernel boundary, in front of the next launch: measured
 // (fast mode, same box, in-graph stamps) the gap behind the chain launch 3.4 -> 2.9 us and behind the LSTM launch 2.5 -> 1.95 us with these
@@ -1104,11 +1112,11 @@ __device__ __forceinline__ void store_wt(float *p, float v)
 // workgroups: a first version that folded every workgroup's times in by atomics cost the 512-workgroup LSTM launch 3 us.
 __device__ __forceinline__ void lz_stamp_begin(unsigned long long *st)
 {
-    if (st && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) st[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    if (st && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) lz_stamp_store(st, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 __device__ __forceinline__ void lz_stamp_end(unsigned long long *st)
 {
-    if (st && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) st[1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    if (st && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) lz_stamp_store(st + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---- split heads: the head MLPs of the PREVIOUS simulation's leaf, finished by waves 1..7 of the root's workgroup while wave 0 stages
@@ -1125,7 +1133,7 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
                                                   float *s_red, unsigned long long *ts = nullptr)
 {
     const bool stamp = ts && b == 0 && hw == 0 && lane == 0;   // timing experiments (debug build): stamps of head wave 1 of root 0
-#define LZ_HPS(i) do { if (stamp) ts[8 + i] = __builtin_readcyclecounter(); } while (0)
+#define LZ_HPS(i) do { if (stamp) lz_stamp_store(ts + 8 + (i), __builtin_readcyclecounter()); } while (0)
     LZ_HPS(0);
     const int head = hw < 3 ? 0 : (hw < 6 ? 2 : 1);   // 0 value, 1 policy, 2 value prefix (the order of lz_split_heads' arrays)
     const int gw = hw < 6 ? hw % 3 : 0, grp = hw < 3 ? 0 : 1;
@@ -1333,7 +1341,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
             }
         }
         __syncthreads();
-        if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
+        if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (5), __builtin_readcyclecounter());
         g_slot = s_sel[0];
         g_action = s_sel[1];
         if (wv == 0) fill_ring();
@@ -1426,7 +1434,7 @@ __global__ __launch_bounds__(NW * 64) void k_chain_w(lz_chain_args a, typename s
     LZ_TS();
     __syncthreads();
     LZ_TS();
-    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[6] = __builtin_readcyclecounter(); }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (6), __builtin_readcyclecounter()); }
 
     for (int L = 0; L < a.nlayers; ++L) {
         const lz_chain_layer &ly = a.layer[L];
@@ -1735,7 +1743,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
             }
         }
         __syncthreads();
-        if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
+        if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (5), __builtin_readcyclecounter());
         g_slot = s_sel[0];
         g_action = s_sel[1];
         if (wv == 0) load_w0();
@@ -1803,7 +1811,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
     const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
     __syncthreads();
-    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[6] = __builtin_readcyclecounter(); }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (6), __builtin_readcyclecounter()); }
 
     // output geometry of this lane, the same for every layer.  The MFMAs run TRANSPOSED (weights as the A operand): D[channel][pixel], so a
     // lane ends up with four consecutive channels co4 .. co4 + 3 of ONE pixel -- 16 contiguous bytes in every [pixel][channel] array
@@ -1819,7 +1827,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
         // MFMAs and every layer starts by waiting for its weights: 2.8 us per layer, measured)
         bf16x8 wn[9];
         {
-            const bf16x8 *w1 = reinterpret_cast<const bf16x8 *>(lane64(my_wb, Ln)) + wofs;
+            gbl_bf16x8 *w1 = as_global_bf16x8(lane64(my_wb, Ln)) + wofs;
 #ifdef LZ_DEBUG_KNOBS
             if (a.debug_flags & 16) {   // 16 = no weight stream (the registers keep the first layer's)
 #pragma unroll
@@ -1949,7 +1957,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 #pragma unroll
         for (int t = 0; t < 9; ++t) wc[t] = wn[t];
         __syncthreads();
-        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L < 8) step.ts[16 + L] = __builtin_readcyclecounter(); }
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L < 8) lz_stamp_store(step.ts + (16 + L), __builtin_readcyclecounter()); }
     }
     // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU in fp32, as in k_chain_w
     auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {
@@ -1995,7 +2003,7 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 #pragma unroll
         for (int i = 0; i < MT; ++i) c1_tile(wv, i);
     }
-    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[24] = __builtin_readcyclecounter(); }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (24), __builtin_readcyclecounter()); }
     lz_stamp_end(a.stamp);
 }
 
@@ -2025,19 +2033,23 @@ template <int GW, int GH, int TREE = 0, bool HEADS = false>
 __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step_arg<TREE>::type step)
 {
     constexpr int NW = 8, PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
-    constexpr int PB = 80;                               // bf16 per pixel of the bf16 copies: 64 + pad.  160 B = 10 bank quads: the 16-lane groups ds_read_b128 is
+    constexpr int PB = 80;                               // bf16 per pixel of the bf16 planes: 64 + pad.  160 B = 10 bank quads: the 16-lane groups ds_read_b128 is
                                                          // served in ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) then hit 16 distinct quads (144 B: 2-way conflicts)
     static_assert(MT == 3 && HW % 4 == 0, "the 6x6 latent (three 16-pixel tiles)");
     constexpr int NPL = 3;                               // bf16 planes of every activation / weight: hi | mid | lo (exact three-term split of fp32)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 fp32 activation buffers of BUF floats (the staged tree first), then
-    float *sTab = smem + 4 * BUF;                       // [HW][PS] one-hot-action table slice of this root's action
-    float *sSS = sTab + HW * PS;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
+    float *sSS = smem + 4 * BUF;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
     float *sMisc = sSS + LZ_CHAIN_MAX_LAYERS * 128;     // 128 floats: the tree step's selection
-    float *sP = sMisc + 128;                            // [4 nt][MT][64 lanes][4] partial sums of the kh = 1 waves (prologue: head scratch)
-    __bf16 *sB = reinterpret_cast<__bf16 *>(sP + 4 * MT * 256);   // 4 buffers x 3 planes x [HW + 1][PB]: the split of the activation buffers
+    float *sP = sMisc + 128;                            // [2 tile pairs][6 tiles][3 other waves][64 lanes][4] partial sums (prologue: head scratch)
+    __bf16 *sB = reinterpret_cast<__bf16 *>(sP + 2 * 6 * 3 * 256);   // 4 buffers x 3 planes x [HW + 1][PB]: the split of the activation buffers
     constexpr int BB = (HW + 1) * PB;                   // one plane
     constexpr int BB3 = NPL * BB;                       // one buffer
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv & 3, kh = wv >> 2;
+    // Wave roles.  What bounds this launch is the LDS read path (and behind it the weight stream), not the matrix pipe: with one 16-channel
+    // output tile per wave every pixel fragment was read by four waves (648 KB of ds_read_b128 per layer and CU, 125 B/clk at the matrix rate).
+    // So a wave owns TWO output-channel tiles (np: tiles 2 np, 2 np + 1) for all three pixel tiles, one half of the input channels (kh) and one
+    // half of the taps (th = 0: taps 0-4, th = 1: taps 5-8; waves w and w + 4 share a SIMD, so every SIMD gets 5 + 4 taps): each pixel fragment
+    // feeds 12 MFMAs instead of 6, the LDS read traffic halves.  Four waves hold partial sums of the same six output tiles; they meet in LDS.
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, np = wv & 1, kh = (wv >> 1) & 1, th = wv >> 2, widx = wv >> 1;   // widx = kh + 2 th
     const int b = blockIdx.x;
     lz_stamp_begin(a.stamp);
     // per-layer parameters: lane L keeps layer L's (a scalar load from the argument block at the top of every layer is a round trip the
@@ -2049,24 +2061,40 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), L);
         return ((unsigned long long)hi << 32) | lo;
     };
-    // weights: [layer][kh][nt][tap][plane][64 lanes][8 bf16]; a layer's 27 fragments per wave do not stay in registers (108 of them, and as
-    // many again for the next layer): they stream through a ring of RT taps x 3 planes that runs across layer boundaries -- tap t + RT is
-    // requested when tap t's products are issued (18 MFMAs = 288 cycles per tap and wave, two waves per SIMD: RT = 3 covers an L2 round trip)
-    constexpr int RT = 3;
-    const size_t wofs = (((size_t)kh * 4 + nt) * 9) * NPL * 64 + lane;
-    bf16x8 wr[RT][NPL];
-    auto load_tap = [&](const void *wl, int t, bf16x8 (&dst)[NPL]) {
-        const bf16x8 *w0 = reinterpret_cast<const bf16x8 *>(wl) + wofs + (size_t)t * NPL * 64;
+    // weights: [layer][kh][nt][tap][plane][64 lanes][8 bf16].  A wave's fragments of a layer (2 tiles x 5 | 4 taps x 3 planes) stream through
+    // a ring of RT taps: a slot is refilled right behind the products that read it -- with the same layer's tap RT further on, or, for the
+    // last RT taps, with the NEXT layer's first taps (so the stream runs through the partial-sum exchange and the epilogue)
+    constexpr int RT = 2;
+    const int t0 = th ? 5 : 0;
+    const size_t wofs0 = (((size_t)kh * 4 + 2 * np) * 9) * NPL * 64 + lane, wofs1 = wofs0 + (size_t)9 * NPL * 64;
+    bf16x8 wr[RT][2][NPL];
+    auto load_w = [&](gbl_bf16x8 *wl, int t, int pl, bf16x8 (&dst)[2][NPL]) {
+        gbl_bf16x8 *w0 = wl + (size_t)(t * NPL + pl) * 64;
+        dst[0][pl] = w0[wofs0];
+        dst[1][pl] = w0[wofs1];
+    };
+    auto load_tap = [&](gbl_bf16x8 *wl, int t, bf16x8 (&dst)[2][NPL]) {
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) dst[pl] = w0[pl * 64];
+        for (int pl = 0; pl < NPL; ++pl) load_w(wl, t, pl, dst);
     };
     auto load_w0 = [&]() {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) load_tap(a.layer[0].w3, t, wr[t]);
+        for (int i = 0; i < RT; ++i) load_tap(as_global_bf16x8((unsigned long long)a.layer[0].w3), t0 + i, wr[i]);
+    };
+    // L2 does not keep anything across a kernel boundary, so the first workgroup of an XCD to ask for a weight line waits for the memory side
+    // (Infinity Cache), and with the 32 workgroups of an XCD running in step all of them wait with it: the stream then runs at the miss
+    // latency.  The workgroups of an XCD (blockIdx % 8: the dispatcher deals them round-robin) therefore touch one 32nd of every layer's
+    // lines each while the tree step runs -- one load instruction per layer and workgroup, results unused -- and the layers find them in L2.
+    auto prefetch_weights = [&](int L) {
+        if (L >= a.nlayers) return;
+        const int nr = min(max((int)gridDim.x >> 3, 1), 32), r = (b >> 3) % nr;
+        constexpr int LINES = 2 * 4 * 9 * NPL * 64 * 16 / 128;       // 128-byte lines of a layer
+        const char *w = reinterpret_cast<const char *>(a.layer[L].w3);
+        for (int ln = r + lane * nr; ln < LINES; ln += 64 * nr) (void)*reinterpret_cast<const volatile int *>(w + (size_t)ln * 128);
     };
     // the first layer's weights: at once without a tree step; with one, the head waves request theirs when their head is done and the tree
-    // wave after the step, together with the latent gather (36 more live registers across the prologue spill)
-    if constexpr (TREE == 0) load_w0();
+    // wave after the step, together with the latent gather
+    if constexpr (TREE == 0) { load_w0(); prefetch_weights(wv); prefetch_weights(wv + 8); }
     // 1x1 head convolutions at the end of the kernel (as in k_chain_w)
     constexpr bool C1SPLIT = (HW % 16) != 0 && (HW % 16) <= 4 && HW / 16 == 2;
     const int nj = max(a.nc1, 1);
@@ -2107,19 +2135,30 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
                 if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
             }
             load_w0();
+            prefetch_weights(wv - 1); prefetch_weights(wv + 6);
             for (int i = tid - 64; i < a.nlayers * 128; i += NTHR - 64) {
                 const int L = i >> 7, r = i & 127;
                 sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
             }
         }
         __syncthreads();
-        if (step.ts && b == 0 && tid == 0) step.ts[5] = __builtin_readcyclecounter();
+        if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (5), __builtin_readcyclecounter());
         g_slot = s_sel[0];
         g_action = s_sel[1];
         if (wv == 0) load_w0();
     } else {
         if (a.gather_ix) g_slot = a.gather_ix[b];
         if (a.act_table) g_action = a.action[b];
+    }
+    // the action table's rows of the output tiles this wave finishes (the dynamics convolution adds them): requested with the latent, so that
+    // the layers' only vector-memory traffic is the weight stream and no wait of theirs has to drain it
+    f32x4 tvv[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int q = min(widx + 4 * f, 5), ntl = q / 3, mt = q - 3 * ntl;
+        const int m = min(mt * 16 + (lane & 15), HW - 1), c4 = (2 * np + ntl) * 16 + 4 * (lane >> 4);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        tvv[f] = a.act_table ? *reinterpret_cast<const f32x4 *>(a.act_table + (size_t)g_action * HW * 64 + m * 64 + c4) : z;
     }
     {
         const float *src = a.in + (size_t)b * HW * 64 + (size_t)g_slot * a.slot_stride;
@@ -2129,16 +2168,6 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         for (int u = 0; u < NU; ++u) {
             const int idx = min(u * NTHR + tid, HW * 16 - 1);
             v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
-        }
-        float4 tv[NU];
-        const bool tabl = a.act_table != nullptr;
-        {
-            const float *tsrc = tabl ? a.act_table + (size_t)g_action * HW * 64 : src;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int idx = min(u * NTHR + tid, HW * 16 - 1);
-                tv[u] = *reinterpret_cast<const float4 *>(tsrc + (size_t)idx * 4);
-            }
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -2150,10 +2179,9 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
                 *reinterpret_cast<bf16x4 *>(sB + (idx >> 4) * PB + (idx & 15) * 4) = h;
                 *reinterpret_cast<bf16x4 *>(sB + BB + (idx >> 4) * PB + (idx & 15) * 4) = m3;
                 *reinterpret_cast<bf16x4 *>(sB + 2 * BB + (idx >> 4) * PB + (idx & 15) * 4) = l3;
-                if (tabl) *reinterpret_cast<float4 *>(sTab + (idx >> 4) * PS + (idx & 15) * 4) = tv[u];
             }
         }
-        // the all-zero pixel of every buffer (fp32: the head convolutions' padding rows; bf16: the halo)
+        // the all-zero pixel of every buffer (fp32: the head convolutions' padding rows; bf16: the halo of every plane)
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
         if (tid >= 64 && tid < 64 + 4 * NPL * (PB / 8)) {   // 12 (buffer, plane) pairs x 10 16-byte pieces
             const int i = tid - 64;
@@ -2166,7 +2194,7 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
             }
         }
     }
-    // ---- per-lane geometry, the same for every layer: A rows of this lane = pixels 16 mt + (lane & 15); tap (dy, dx) reads pixel
+    // ---- per-lane geometry, the same for every layer: B columns of this lane = pixels 16 mt + (lane & 15); tap (dy, dx) reads pixel
     // m + dy GW + dx when it is inside the image, the zero pixel otherwise (one validity bit per (row tile, tap))
     unsigned long long valid = 0;
     int abase[MT];
@@ -2183,11 +2211,12 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
     const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
     const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
     __syncthreads();
-    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[6] = __builtin_readcyclecounter(); }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (6), __builtin_readcyclecounter()); }
 
-    // output geometry of this lane, the same for every layer.  The MFMAs run TRANSPOSED (weights as the A operand): D[channel][pixel], so a
-    // lane ends up with four consecutive channels co4 .. co4 + 3 of ONE pixel -- 16 contiguous bytes in every [pixel][channel] array
-    const int co4 = nt * 16 + 4 * (lane >> 4);
+    // The MFMAs run TRANSPOSED (weights as the A operand): D[channel][pixel], so a lane ends up with four consecutive channels of ONE pixel --
+    // 16 contiguous bytes in every [pixel][channel] array.  Output tile q = 3 ntl + mt of this wave's pair (ntl = 0 | 1); tile q is FINISHED by
+    // the wave with widx == q % 4 (two tiles for widx 0 and 1, one for 2 and 3); the other three leave their partial sums in
+    // sP[np][q][rank among the others]
     const int nlayers = a.nlayers;
     for (int L = 0; L < nlayers; ++L) {
         const int flags = __builtin_amdgcn_readlane(my_flags, L);
@@ -2195,103 +2224,146 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         const char *sBin = reinterpret_cast<const char *>(sB + (flags & 3) * BB3);
         float *sOut = smem + ((flags >> 2) & 3) * BUF;
         __bf16 *sBout = sB + ((flags >> 2) & 3) * BB3;
-        const void *wl_cur = reinterpret_cast<const void *>(lane64(my_wb, L)), *wl_nxt = reinterpret_cast<const void *>(lane64(my_wb, Ln));
-        // pixel fragments of a tap: 3 row tiles x 3 planes; the next tap's are requested before this tap's 18 MFMAs
-        auto read_tap = [&](int t, bf16x8 (&af)[NPL][MT]) {
+        gbl_bf16x8 *wl_cur = as_global_bf16x8(lane64(my_wb, L)), *wl_nxt = as_global_bf16x8(lane64(my_wb, Ln));
+        const bool tab = (flags >> 8) & 1, relu = (flags >> 7) & 1;
+        const int res = ((flags >> 4) & 7) - 1;
+        // operands of the epilogue that do not depend on the products -- folded-BN scale / shift and the residual of the tiles this wave
+        // finishes -- are read here: the LDS pipe has room under the products, the epilogue is bound by it (24 registers held for it)
+        const float *sRes = smem + max(res, 0) * BUF;
+        f32x4 rvv[2], scv[2], shv[2];
+        int mpix[2], c4v[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int q = min(widx + 4 * f, 5), ntl = q / 3, mt = q - 3 * ntl;
+            mpix[f] = mt * 16 + (lane & 15);
+            c4v[f] = (2 * np + ntl) * 16 + 4 * (lane >> 4);
+            rvv[f] = *reinterpret_cast<const f32x4 *>(sRes + min(mpix[f], HW - 1) * PS + c4v[f]);
+            scv[f] = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + c4v[f]);
+            shv[f] = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + 64 + c4v[f]);
+        }
+        // pixel fragments of a tap: 3 row tiles of one plane
+        auto read_x = [&](int t, int pl, bf16x8 (&af)[NPL][MT]) {
             const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) af[pl][mt] = *reinterpret_cast<const bf16x8 *>(sBin + off + pl * BB * 2);
+                af[pl][mt] = *reinterpret_cast<const bf16x8 *>(sBin + off + pl * BB * 2);
             }
         };
-        f32x4 acc[MT];
+        f32x4 acc[2][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 fa[2][NPL][MT];
-        read_tap(0, fa[0]);
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) read_tap(t + 1, fa[(t + 1) & 1]);
-            const bf16x8 (&x)[NPL][MT] = fa[t & 1];
-            bf16x8 w[NPL];
+            for (int mt = 0; mt < MT; ++mt) acc[n][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // One tap = six of the nine cross products (hi mid lo = planes 0 1 2; the three left out are below 2^-32 of the result), 6 MFMAs each,
+        // consecutive MFMAs writing different accumulators.  Neither the pixel fragments nor the ring slot are double-buffered (they would
+        // not fit: 256 registers at two waves per SIMD): the order of the products frees x[lo] after the first, w[lo] after the third, x[mid]
+        // after the fourth, w[mid] after the fifth, and each is re-requested right there -- the next tap's pixel plane from LDS, the ring
+        // slot's next occupant from L2 (this layer's tap RT further on, or, behind the slot's last use in this layer, the next layer's tap)
+        auto prod = [&](const bf16x8 (&w)[2][NPL], int wp, const bf16x8 (&x)[NPL][MT], int xp) {
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) w[pl] = wr[t % RT][pl];
-            // the ring slot is free: tap t + RT of this layer, or the first taps of the next one
-            if (t + RT < 9) load_tap(wl_cur, t + RT, wr[t % RT]);
-            else load_tap(wl_nxt, t + RT - 9, wr[t % RT]);
-            __builtin_amdgcn_sched_barrier(0);
-            // six of the nine cross products (hi mid lo = planes 0 1 2), small ones first; product-major: consecutive MFMAs write different accumulators
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1][mt], acc[mt], 0, 0, 0);   // mid x mid
+                for (int mt = 0; mt < MT; ++mt) acc[n][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n][wp], x[xp][mt], acc[n][mt], 0, 0, 0);
+        };
+        auto taps = [&](auto ntaps_c, int tb) {
+            constexpr int NTAP = decltype(ntaps_c)::value;
+            bf16x8 x[NPL][MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0][mt], acc[mt], 0, 0, 0);   // lo  x hi
+            for (int pl = NPL - 1; pl >= 0; --pl) read_x(tb, pl, x);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2][mt], acc[mt], 0, 0, 0);   // hi  x lo
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0][mt], acc[mt], 0, 0, 0);   // mid x hi
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1][mt], acc[mt], 0, 0, 0);   // hi  x mid
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0][mt], acc[mt], 0, 0, 0);   // hi  x hi
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- the two k halves meet in LDS: the kh = 0 wave of an output tile finishes the even pixel tiles (6x6: pixels 0..15, 32..35), the
-        // kh = 1 wave the odd ones -- each leaves its partial sums of the OTHER wave's tiles in sP[nt][mt]
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            if ((mt & 1) != kh) *reinterpret_cast<f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4) = acc[mt];
-        __syncthreads();
-#ifdef LZ_DEBUG_KNOBS
-        if (!(a.debug_flags & 8))     // 8 = no epilogue
+            for (int i = 0; i < NTAP; ++i) {
+                bf16x8 (&w)[2][NPL] = wr[i % RT];
+                const bool more = i + 1 < NTAP;
+                gbl_bf16x8 *wl = (i + RT < NTAP) ? wl_cur : wl_nxt;
+                const int wt = (i + RT < NTAP) ? tb + i + RT : tb + i % RT;
+#if defined(LZ_DEBUG_KNOBS) && defined(LZ_DEBUG_S3_SKIP)   // timing experiments (results are then wrong; the branches also cost ~60 % per layer): 16 = no weight stream, 4 = no MFMAs, 32 = no pixel-fragment reads
+                const bool dW = !(a.debug_flags & 16), dM = !(a.debug_flags & 4), dX = !(a.debug_flags & 32);
+#else
+                constexpr bool dW = true, dM = true, dX = true;
 #endif
+                if (dM) prod(w, 0, x, 2);                           // hi  x lo
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && dX) read_x(tb + i + 1, 2, x);
+                if (dM) prod(w, 1, x, 1);                           // mid x mid
+                if (dM) prod(w, 2, x, 0);                           // lo  x hi
+                __builtin_amdgcn_sched_barrier(0);
+                if (dW) load_w(wl, wt, 2, w);
+                if (dM) prod(w, 0, x, 1);                           // hi  x mid
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && dX) read_x(tb + i + 1, 1, x);
+                if (dM) prod(w, 1, x, 0);                           // mid x hi
+                __builtin_amdgcn_sched_barrier(0);
+                if (dW) load_w(wl, wt, 1, w);
+                if (dM) prod(w, 0, x, 0);                           // hi  x hi
+                __builtin_amdgcn_sched_barrier(0);
+                if (dW) load_w(wl, wt, 0, w);
+                if (more && dX) read_x(tb + i + 1, 0, x);
+            }
+        };
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L == 2) lz_stamp_store(step.ts + (25), __builtin_readcyclecounter()); }
+        if (th == 0) taps(std::integral_constant<int, 5>{}, 0);
+        else taps(std::integral_constant<int, 4>{}, 5);
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L == 2) lz_stamp_store(step.ts + (26), __builtin_readcyclecounter()); }
+        // ---- the four partial sums of an output tile meet in LDS: every wave leaves the tiles it does not finish
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int fin = q & 3;
+            if (fin != widx) {
+                const int rank = widx < fin ? widx : widx - 1;
+                *reinterpret_cast<f32x4 *>(sP + (((np * 6 + q) * 3 + rank) * 64 + lane) * 4) = acc[q / 3][q % 3];
+            }
+        }
+        __syncthreads();
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L == 2) lz_stamp_store(step.ts + (27), __builtin_readcyclecounter()); }
         {
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + co4), sh = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + 64 + co4);
-            const bool tab = (flags >> 8) & 1, relu = (flags >> 7) & 1;
-            const int res = ((flags >> 4) & 7) - 1;
-            const float *sRes = smem + max(res, 0) * BUF;
             float *go = reinterpret_cast<float *>(lane64(my_gout, L));
             if (go) go += (size_t)b * HW * 64;
             // every LDS read of the epilogue before its first write (the compiler must assume they alias)
-            constexpr int NF = (MT + 1) / 2;       // pixel tiles this wave may finish: kh, kh + 2 (< MT)
-            f32x4 other[NF], tvv[NF], rvv[NF];
-            int mpix[NF];
+            f32x4 oth[2][3];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int mt = min(kh + 2 * f, MT - 1);
-                mpix[f] = mt * 16 + (lane & 15);
-                const int m = min(mpix[f], HW - 1);
-                other[f] = *reinterpret_cast<const f32x4 *>(sP + ((nt * MT + mt) * 64 + lane) * 4);
-                tvv[f] = *reinterpret_cast<const f32x4 *>(sTab + m * PS + co4);
-                rvv[f] = *reinterpret_cast<const f32x4 *>(sRes + m * PS + co4);
+            for (int f = 0; f < 2; ++f) {
+                const int q = min(widx + 4 * f, 5);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) oth[f][r] = *reinterpret_cast<const f32x4 *>(sP + (((np * 6 + q) * 3 + r) * 64 + lane) * 4);
             }
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                if (kh + 2 * f >= MT) continue;
-                const f32x4 mine = kh == 1 ? acc[(1 + 2 * f < MT) ? 1 + 2 * f : MT - 1] : acc[2 * f];
+            for (int f = 0; f < 2; ++f) {
+                if (widx + 4 * f >= 6) continue;             // waves 2 and 3 of a pair finish one tile
+                const int q = widx + 4 * f;
+                f32x4 mine = acc[0][0];
+#pragma unroll
+                for (int qq = 0; qq < 6; ++qq) mine = (qq == q) ? acc[qq / 3][qq % 3] : mine;
+                // the four partial sums in the fixed order of the waves' indices (kh + 2 th): the finisher's own stands at position widx
+                f32x4 p[4];
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const int rank = w4 < widx ? w4 : w4 - 1;
+                    p[w4] = (w4 == widx) ? mine : oth[f][min(max(rank, 0), 2)];
+                }
                 f32x4 o;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = mine[q] + other[f][q];
-                    v += tab ? tvv[f][q] : 0.0f;
-                    v = v * sc[q] + sh[q];
-                    v += res >= 0 ? rvv[f][q] : 0.0f;
-                    o[q] = relu ? fmaxf(v, 0.0f) : v;
+                for (int c = 0; c < 4; ++c) {
+                    float v = ((p[0][c] + p[1][c]) + p[2][c]) + p[3][c];
+                    v += tab ? tvv[f][c] : 0.0f;
+                    v = v * scv[f][c] + shv[f][c];
+                    v += res >= 0 ? rvv[f][c] : 0.0f;
+                    o[c] = relu ? fmaxf(v, 0.0f) : v;
                 }
                 bf16x4 oh, om, ol;
                 split3_bf16(o, oh, om, ol);
                 if (mpix[f] < HW) {
-                    *reinterpret_cast<f32x4 *>(sOut + mpix[f] * PS + co4) = o;
-                    *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + co4) = oh;
-                    *reinterpret_cast<bf16x4 *>(sBout + BB + mpix[f] * PB + co4) = om;
-                    *reinterpret_cast<bf16x4 *>(sBout + 2 * BB + mpix[f] * PB + co4) = ol;
-                    if (go) store_wt(go + mpix[f] * 64 + co4, o);
+                    *reinterpret_cast<f32x4 *>(sOut + mpix[f] * PS + c4v[f]) = o;
+                    *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + c4v[f]) = oh;
+                    *reinterpret_cast<bf16x4 *>(sBout + BB + mpix[f] * PB + c4v[f]) = om;
+                    *reinterpret_cast<bf16x4 *>(sBout + 2 * BB + mpix[f] * PB + c4v[f]) = ol;
+                    if (go) store_wt(go + mpix[f] * 64 + c4v[f], o);
                 }
             }
         }
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L == 2) lz_stamp_store(step.ts + (29), __builtin_readcyclecounter()); }
         __syncthreads();
-        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L < 8) step.ts[16 + L] = __builtin_readcyclecounter(); }
+        if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L < 8) lz_stamp_store(step.ts + (16 + L), __builtin_readcyclecounter()); }
     }
     // 1x1 head convolutions (64 -> 16) + bias + BN + ReLU in fp32, as in k_chain_w
     auto c1_store = [&](const lz_c1_job &jb, int row, int cq, const f32x4 &acc) {
@@ -2337,7 +2409,7 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
 #pragma unroll
         for (int i = 0; i < MT; ++i) c1_tile(wv, i);
     }
-    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) step.ts[24] = __builtin_readcyclecounter(); }
+    if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (24), __builtin_readcyclecounter()); }
     lz_stamp_end(a.stamp);
 }
 
@@ -4142,7 +4214,7 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         for (int i = 0; i < a.nlayers; ++i) s3 = s3 && a.layer[i].w3 != nullptr;
         if (s3) {
             const int hw = 36, mt = 3;
-            const size_t lds = (size_t)(4 * (hw + 1) * 68 + hw * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 4 * mt * 256) * 4 + (size_t)3 * 4 * (hw + 1) * 80 * 2;
+            const size_t lds = (size_t)(4 * (hw + 1) * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * mt * 256) * 4 + (size_t)3 * 4 * (hw + 1) * 80 * 2;
             const dim3 g(a.B), blk(512);
             static bool attr = false;
             if (!attr) {

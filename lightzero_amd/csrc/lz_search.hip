@@ -1935,6 +1935,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     const size_t B = t.B;
     const size_t A = policy_width_of(r->eng->model, t);
     ta.counter = 0;
+    if (r->explore_tab) { lz_tree_launch_explore_tab(r->explore_tab, ta.pb_c_base, ta.pb_c_init, s); ta.tab = r->explore_tab; }
     if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
         lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
         // SampledEfficientZeroMCTSCtree.search (mcts_ctree_sampled.py:480-600): the leaf's K actions are drawn on the

@@ -813,6 +813,20 @@ __global__ void lz_k_trajectories(lz_tree_dev t, int32_t *__restrict__ out, int 
 
 static inline int nchunks(int A) { return (A + 63) / 64; }
 
+// The exploration factors of a node with visit count n = lane (cnode.cpp:720-727: pb_c = log((N + base + 1) / base) + init, times sqrt(N)): the
+// same 64 values for every root and every simulation of a search, so they are computed once per search here instead of in front of every
+// tree step (dev_step_lds), where the software logf and its two table fetches sat in front of the staging of the tree
+__global__ __launch_bounds__(64) void k_explore_tab(float *out, int pb_c_base, float pb_c_init)
+{
+    const float nf = (float)threadIdx.x;
+    out[threadIdx.x] = lz_logf((nf + (float)pb_c_base + 1) / (float)pb_c_base) + pb_c_init;
+    out[64 + threadIdx.x] = sqrtf(nf);
+}
+void lz_tree_launch_explore_tab(float *out, int pb_c_base, float pb_c_init, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_explore_tab, dim3(1), dim3(64), 0, s, out, pb_c_base, pb_c_init);
+}
+
 void lz_tree_launch_minmax_reset(const lz_tree_dev &t, hipStream_t s)
 {
     hipLaunchKernelGGL(k_minmax_reset, dim3((t.B + 255) / 256), dim3(256), 0, s, t);

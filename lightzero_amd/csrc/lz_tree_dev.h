@@ -82,6 +82,16 @@ struct tscal {
     uint32_t epoch;
 };
 
+// The store of a timing stamp, kept out of the compiler's sight.  An ordinary global store -- even one under `if (stamp)` that never
+// executes in production -- in front of the step's loads makes the compiler treat all global memory as possibly clobbered: every
+// wave-uniform load behind it (n_legal[b], rng_epoch[0], vtp[b], ...) is then a vector load + v_readfirstlane with an s_waitcnt vmcnt(0)
+// in front, i.e. one DRAINED round trip per uniform value before the tree's own loads are even requested (two of them, ~1 us each, in
+// the ISA of the tree-fused chain kernels), instead of an s_load that returns beside them.  Nobody reads a stamp inside the launch.
+__device__ __forceinline__ void lz_stamp_store(unsigned long long *p, unsigned long long v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v));
+}
+
 __device__ __forceinline__ tview global_view(const lz_tree_dev &t, int b)
 {
     tview v;
@@ -660,7 +670,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
 {
     const int lane = threadIdx.x;
     const bool stamp = ts && b == 0 && lane == 0;   // timing experiments only (ts is null in production)
-#define LZ_TTS(i) do { if (stamp) ts[i] = __builtin_readcyclecounter(); } while (0)
+#define LZ_TTS(i) do { if (stamp) lz_stamp_store(ts + (i), __builtin_readcyclecounter()); } while (0)
     LZ_TTS(0);
     const int A = t.A;
     const int nn = new_node + 1;        // nodes 0 .. new_node exist after this step
@@ -679,18 +689,30 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     // ---- one round trip: everything the step reads.  All requests are unconditional (clamped indices) and issued before
     // the first use: a predicated load, or a wave-uniform read of a loaded value in between, would split this into
     // several dependent HBM/L2 round trips (~0.6 us each).
-    const int r_nroot = t.n_legal[b], r_visit = t.root_visit[b], r_d = t.res_search_len[b], r_tp = t.res_vtp[b];
-    const float r_vsum = t.root_vsum[b], r_mn = t.minmax[2 * b], r_mx = t.minmax[2 * b + 1];
-    float r_vp = s_leaf ? 0.0f : vps[b], r_val = s_leaf ? 0.0f : values[b];
-    const uint32_t r_epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;
-    const int vtp = vtp_in[b];
+    // The per-root scalars are wave-uniform loads.  Left to the compiler each becomes a vector load + v_readfirstlane placed right behind it,
+    // with an s_waitcnt vmcnt(0) in between (s_load is not selected: the barriers / fences in front may have clobbered memory as far as it
+    // knows) -- a drained round trip per value before the tree's loads are requested (ISA of the tree-fused chain kernels: two of them).  An
+    // index the compiler cannot see through (zero, from an asm) keeps them ordinary per-lane loads of this one batch; they are made uniform
+    // where they are used, after the staging.  For the same reason no request is conditional: null pointers are replaced by valid memory.
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    const int bz = b + z;
+    const int r_nroot = t.n_legal[bz], r_visit = t.root_visit[bz], r_d = t.res_search_len[bz], r_tp = t.res_vtp[bz];
+    const float r_vsum = t.root_vsum[bz], r_mn = t.minmax[2 * bz], r_mx = t.minmax[2 * bz + 1];
+    const float *vps_p = s_leaf ? t.root_vsum : vps, *val_p = s_leaf ? t.root_vsum : values;
+    const float *lg_p = s_leaf ? reinterpret_cast<const float *>(t.legal) : logits;
+    float r_vp = vps_p[bz], r_val = val_p[bz];
+    const uint32_t *ep_p = t.rng_epoch ? t.rng_epoch : reinterpret_cast<const uint32_t *>(t.n_legal);
+    const uint32_t r_epoch_raw = ep_p[z];
+    const uint32_t r_epoch = t.rng_epoch ? r_epoch_raw : 0u;
+    const int vtp_raw = vtp_in[bz];
     int r_act[NC];
     float r_lg[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int j = min(c * 64 + lane, A - 1);
         r_act[c] = t.legal[(size_t)b * A + j];
-        r_lg[c] = s_leaf ? 0.0f : logits[(size_t)b * A + j];
+        r_lg[c] = lg_p[(size_t)b * A + j];
     }
     const int ne = new_node * A;        // edges / child ids of the existing nodes 0 .. new_node - 1 (ne >= 1)
     // first batch of every array: all requests, then the table arithmetic (it runs while they are in flight), then the LDS stores;
@@ -716,11 +738,18 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     }
     // tables that take software exp / log table fetches and the sqrt out of the dependent chains below: the 2^(i/32) table of
     // lz_expf goes to LDS, and lane n computes the exploration factors of a node with visit count n + 1 (N = n <= new_node)
-    if (lane < 32) s_exp[lane] = lz_exp2f_tab((unsigned)lane);
+    const uint64_t etab = lz_exp2f_tab((unsigned)(lane & 31));   // (a fetch from the constant segment: requested with the rest, stored below)
     const bool use_tab = new_node < 64;
-    const float nf = (float)lane, tab_pbc = lz_logf((nf + (float)a.pb_c_base + 1) / (float)a.pb_c_base) + a.pb_c_init, tab_sq = sqrtf(nf);
+    const float *tabp = a.tab ? a.tab : t.root_vsum;              // per-search table (lz_tree_launch_explore_tab); unconditional requests again
+    float tab_pbc = tabp[a.tab ? lane : 0], tab_sq = tabp[a.tab ? 64 + lane : 0];
+    if (!a.tab) {
+        const float nf = (float)lane;
+        tab_pbc = lz_logf((nf + (float)a.pb_c_base + 1) / (float)a.pb_c_base) + a.pb_c_init;
+        tab_sq = sqrtf(nf);
+    }
     __builtin_amdgcn_sched_barrier(0);
     LZ_TTS(1);
+    if (lane < 32) s_exp[lane] = etab;
 #pragma unroll
     for (int u = 0; u < UE; ++u) {
         const int i = u * 64 + lane;
@@ -778,6 +807,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     leaf_in<NC, VARIANT> L;
     L.d = uni(r_d);
     L.to_play = uni(r_tp);
+    const int vtp = uni(vtp_raw);
     L.vp = r_vp; L.value = r_val;
     L.reset = (VARIANT == LZ_TREE_EFFICIENTZERO && horizon > 0) ? ((L.d % horizon == 0) ? 1 : 0) : 0;  // mcts_ctree.py:859
 #pragma unroll

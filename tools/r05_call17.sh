@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+echo "== tree_timing"; timeout 120 python tools/tree_timing.py 2>&1 | grep -v amdgpu.ids | head -15
+for v in "LZ_NOTHING=0" "LZ_NOTHING=1"; do echo "== bench $v"; env $v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-s 0 --no-depth-sweep 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done

@@ -47,3 +47,5 @@ if out[25]:
     print("layer 2: weights requested t=%d, MFMAs issued t=%d, barrier 1 passed t=%d, layer end t=%d" % tuple(int(out[i]) - int(ts[0]) for i in (25, 26, 27, 18)))
 if out[28]:
     print("layer 2 epilogue: reads done t=%d, writes issued t=%d, next weights in registers t=%d" % tuple(int(out[i]) - int(ts[0]) for i in (28, 29, 30)))
+elif out[29]:
+    print("layer 2 epilogue: writes issued t=%d" % (int(out[29]) - int(ts[0])))
