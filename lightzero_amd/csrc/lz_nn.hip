@@ -2257,9 +2257,11 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
             for (int mt = 0; mt < MT; ++mt) acc[n][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // One tap = six of the nine cross products (hi mid lo = planes 0 1 2; the three left out are below 2^-32 of the result), 6 MFMAs each,
         // consecutive MFMAs writing different accumulators.  Neither the pixel fragments nor the ring slot are double-buffered (they would
-        // not fit: 256 registers at two waves per SIMD): the order of the products frees x[lo] after the first, w[lo] after the third, x[mid]
-        // after the fourth, w[mid] after the fifth, and each is re-requested right there -- the next tap's pixel plane from LDS, the ring
-        // slot's next occupant from L2 (this layer's tap RT further on, or, behind the slot's last use in this layer, the next layer's tap)
+        // not fit: 256 registers at two waves per SIMD): the order of the products frees x[lo] after the first, w[hi] after the third, x[mid]
+        // after the fourth, w[mid] after the fifth, and each is re-requested right there -- the next tap's pixel plane from LDS (two to five
+        // products ahead of its use), the ring slot's next occupant from L2 (this layer's tap RT further on, or, behind the slot's last use in
+        // this layer, the next layer's tap): w[hi], the first plane the tap after next needs, gets a lead of a tap and a half (with the hi x hi
+        // product last it had one tap, 576 cycles for a wave running alone at the end of a layer: less than a loaded L2 round trip)
         auto prod = [&](const bf16x8 (&w)[2][NPL], int wp, const bf16x8 (&x)[NPL][MT], int xp) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -2285,19 +2287,19 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
                 if (dM) prod(w, 0, x, 2);                           // hi  x lo
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && dX) read_x(tb + i + 1, 2, x);
-                if (dM) prod(w, 1, x, 1);                           // mid x mid
-                if (dM) prod(w, 2, x, 0);                           // lo  x hi
-                __builtin_amdgcn_sched_barrier(0);
-                if (dW) load_w(wl, wt, 2, w);
                 if (dM) prod(w, 0, x, 1);                           // hi  x mid
+                if (dM) prod(w, 0, x, 0);                           // hi  x hi
+                __builtin_amdgcn_sched_barrier(0);
+                if (dW) load_w(wl, wt, 0, w);
+                if (dM) prod(w, 1, x, 1);                           // mid x mid
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && dX) read_x(tb + i + 1, 1, x);
                 if (dM) prod(w, 1, x, 0);                           // mid x hi
                 __builtin_amdgcn_sched_barrier(0);
                 if (dW) load_w(wl, wt, 1, w);
-                if (dM) prod(w, 0, x, 0);                           // hi  x hi
+                if (dM) prod(w, 2, x, 0);                           // lo  x hi
                 __builtin_amdgcn_sched_barrier(0);
-                if (dW) load_w(wl, wt, 0, w);
+                if (dW) load_w(wl, wt, 2, w);
                 if (more && dX) read_x(tb + i + 1, 0, x);
             }
         };
@@ -2572,29 +2574,41 @@ static void launch_conv_bf(const lz_conv_args &a, hipStream_t s)
 template <int CIN, int COUT, int STRIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2 ? 1 : 2))) void k_conv_s3(lz_conv_args a, int ntiles, int TR)
 {
-    constexpr int NT = COUT / 16, MG = 4 / NT;          // waves = NT channel tiles x MG pixel groups
-    constexpr int MTW = 6 / MG;                         // 16-pixel tiles per wave (96 pixels per workgroup tile)
+    // Wave roles.  A wave owns TWO 16-channel output tiles for three 16-pixel tiles: every pixel fragment read from LDS feeds 4 MFMAs
+    // (with one channel tile per wave it fed 2, and the LDS read pipe -- 324 KB per 96-pixel tile, 2.5 k cycles at 128 B/clk -- was as
+    // busy as the matrix pipe).  64 output channels: waves = 2 channel pairs x 2 pixel groups.  32 output channels (one pair): waves =
+    // 2 pixel groups x 2 halves of the taps (0-4 | 5-8), the two partial sums of an output tile meet in LDS, always in the order
+    // taps 0-4 + taps 5-8.
+    constexpr int NP = COUT / 32;
+    constexpr bool TSPLIT = NP == 1;
     constexpr int KC = CIN / 32, KS = 9 * KC;           // k steps of 32: (tap, 32-channel block)
     constexpr int PBq = STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10), PB = PBq * 8;   // pixel pitch in bf16 (k_conv_bf's: conflict-free ds_read_b128)
     constexpr int C4 = CIN / 4, NLD = STRIDE == 2 ? 14 : (CIN == 32 ? 7 : 10);  // 16-byte fp32 pieces per pixel; pieces per thread and halo (the launcher checks the bound)
-    static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64) && MTW % 3 == 0, "shapes of the tower");
+    static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "shapes of the tower");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = wv % NT, mg = wv / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int np = TSPLIT ? 0 : (wv & 1), mg = TSPLIT ? (wv & 1) : (wv >> 1);
+    // (two workgroups share a CU and wave i of both sits on SIMD i: the second one swaps the tap halves so that every SIMD gets 5 + 4 taps)
+    const int th = TSPLIT ? ((wv >> 1) ^ ((blockIdx.x >> 8) & 1)) : 0;
+    const int ks_begin = TSPLIT ? (th ? 5 * KC : 0) : 0, ks_end = TSPLIT ? (th ? KS : 5 * KC) : KS;
     const int Wout = a.Wout, Hout = a.Hout, Win = a.Win, Hin = a.Hin;
     const int HR = (TR - 1) * STRIDE + 3, HC = (Wout - 1) * STRIDE + 3;
     const int bands = (Hout + TR - 1) / TR;
     const int n4 = HR * HC * C4;
     const int hplane = ((HR * HC * PB + 7) & ~7);       // bf16 per plane
     __bf16 *sH = reinterpret_cast<__bf16 *>(smem);      // [3 planes][HR][HC][PB]
+    float *sX = reinterpret_cast<float *>(sH + 3 * hplane);   // TSPLIT: [pixel group][sending half][3 tiles][64 lanes][4] partial sums
     const float *in = a.in, *res = a.residual;
     float *out = a.out;
-    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(a.w3) + (size_t)nt * KS * 3 * 64 + lane;   // [nt][ks][plane][64 lanes]
-    const int co4 = nt * 16 + 4 * (lane >> 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + co4), sh = *reinterpret_cast<const f32x4 *>(a.shift + co4);
-    int pbase[MTW], prow[MTW], pcol[MTW];
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(a.w3) + (size_t)(2 * np) * KS * 3 * 64 + lane;   // [nt][ks][plane][64 lanes]; the pair's second tile: + KS * 3 * 64
+    // folded-BatchNorm scale | shift wait in LDS for the epilogue (16 registers across the k loop otherwise: the 64-channel instance spilled)
+    float *sSS = sX + (TSPLIT ? 4 * 3 * 256 : 0);              // [2][COUT]
+    if (tid < 2 * COUT) sSS[tid] = tid < COUT ? a.scale[tid] : a.shift[tid - COUT];
+    const int co4b = (2 * np) * 16 + 4 * (lane >> 4);          // first channel of this lane in the pair's first tile (second: + 16)
+    int pbase[3], prow[3], pcol[3];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int p = 16 * (mg * MTW + i) + (lane & 15);
+    for (int i = 0; i < 3; ++i) {
+        const int p = 16 * (mg * 3 + i) + (lane & 15);
         prow[i] = p / Wout; pcol[i] = p - prow[i] * Wout;
         pbase[i] = ((prow[i] * STRIDE) * HC + pcol[i] * STRIDE) * PB + (lane >> 4) * 8;   // halo position of tap (0, 0), this lane's k group
     }
@@ -2620,9 +2634,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
             pv[u] = ((iy >= 0) & (iy < Hin) & ((hpk[u] >> 30) & 1)) ? t : z;
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    auto koff = [&](int ks) {         // halo offset (bf16) of k step ks = (tap, 32-channel block)
+        const int t = ks / KC, kc = ks - t * KC, ty = t / 3;
+        return (ty * HC + (t - 3 * ty)) * PB + kc * 32;
+    };
+    // Tile order: the workgroups of an XCD (block id % 8) walk ONE contiguous eighth of the tiles together, so the bands that share halo
+    // rows (a tile re-reads (HR - TR STRIDE) / HR of its neighbours' rows: half of them at TR = 2) are in flight on the same L2 at the same time;
+    // dealt round-robin, neighbouring bands sat on different XCDs and the overlap was fetched again from the memory side
+    const bool xcd_order = (gridDim.x & 7) == 0 && ntiles >= 64;
+    const int tper = xcd_order ? (ntiles + 7) >> 3 : ntiles, tstride = xcd_order ? (int)gridDim.x >> 3 : (int)gridDim.x;
+    const int tbase = xcd_order ? (blockIdx.x & 7) * tper : 0, tend = min(tbase + tper, ntiles);
+    int tile = tbase + (xcd_order ? (int)blockIdx.x >> 3 : (int)blockIdx.x);
+    if (tile < tend) prefetch(tile);
+    for (; tile < tend; tile += tstride) {
         const int img = tile / bands, band = tile - img * bands;
         const int oy0 = band * TR;
         // ---- the prefetched halo, split into its three bf16 planes, into LDS (one buffer: the barrier below the products frees it)
@@ -2637,72 +2661,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
                 *reinterpret_cast<bf16x4 *>(sH + 2 * hplane + hd) = l;
             }
         }
-        // the first k-step's weights (three planes)
-        bf16x8 wc[3], wn[3];
+        // the first k-step's weights (two channel tiles x three planes)
+        bf16x8 wc[2][3], wn[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) wc[pl] = wp[(size_t)pl * 64];
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wc[n][pl] = wp[((size_t)n * KS + ks_begin) * 3 * 64 + (size_t)pl * 64];
         __syncthreads();
         // ---- the next tile's halo travels while this one is multiplied
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-        f32x4 acc[MTW];
+        if (tile + tstride < tend) prefetch(tile + tstride);
+        f32x4 acc[2][3];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // The k loop is NOT unrolled (fully unrolled it took 256 + 180 registers: one wave per SIMD): a k-step is 3 weight fragments (one
-        // step ahead) and, per group of three pixel tiles, 9 LDS reads + 18 MFMAs -- two waves per SIMD hide each other's LDS round trips.
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[n][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // pixel fragments x[plane][tile]: single-buffered -- the order of the six products frees the lo plane after the first, the mid plane
+        // after the fourth, and the next k-step's are requested right there (k_chain_s3's schedule); the weights stay one k-step ahead
+        bf16x8 x[3][3];
+        auto read_x = [&](int off, int pl) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[pl][i] = *reinterpret_cast<const bf16x8 *>(sH + pl * hplane + pbase[i] + off);
+        };
+        auto prod = [&](int wp_, int xp) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[n][wp_], x[xp][i], acc[n][i], 0, 0, 0);
+        };
+        {
+            const int o0 = koff(ks_begin);
+            read_x(o0, 2); read_x(o0, 1); read_x(o0, 0);
+        }
+        // The k loop is NOT unrolled (registers): per k-step 6 weight fragments (one step ahead), 9 LDS reads, 36 MFMAs
 #pragma unroll 1
-        for (int ks = 0; ks < KS; ++ks) {
-            const int t = ks / KC, kc = ks - t * KC, ty = t / 3;
-            const int toff = (ty * HC + (t - 3 * ty)) * PB + kc * 32;
-            const int ksn = min(ks + 1, KS - 1);
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int ksn = min(ks + 1, ks_end - 1);
+            const int on = koff(ksn);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wn[pl] = wp[(size_t)(ksn * 3 + pl) * 64];
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int g = 0; g < MTW / 3; ++g) {
-                bf16x8 bh[3], bm[3], bl[3];
+                for (int pl = 0; pl < 3; ++pl) wn[n][pl] = wp[((size_t)n * KS + ksn) * 3 * 64 + (size_t)pl * 64];
+            // six of the nine cross products (hi mid lo = planes 0 1 2); consecutive MFMAs write different accumulators
+            prod(0, 2);                                   // hi  x lo
+            __builtin_amdgcn_sched_barrier(0);
+            read_x(on, 2);
+            prod(1, 1);                                   // mid x mid
+            prod(2, 0);                                   // lo  x hi
+            prod(0, 1);                                   // hi  x mid
+            __builtin_amdgcn_sched_barrier(0);
+            read_x(on, 1);
+            prod(1, 0);                                   // mid x hi
+            prod(0, 0);                                   // hi  x hi
+            __builtin_amdgcn_sched_barrier(0);
+            read_x(on, 0);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    bh[i] = *reinterpret_cast<const bf16x8 *>(sH + pbase[3 * g + i] + toff);
-                    bm[i] = *reinterpret_cast<const bf16x8 *>(sH + hplane + pbase[3 * g + i] + toff);
-                    bl[i] = *reinterpret_cast<const bf16x8 *>(sH + 2 * hplane + pbase[3 * g + i] + toff);
-                }
-                // six of the nine cross products, the small ones first; product-major so that consecutive MFMAs write different accumulators
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], bm[i], acc[3 * g + i], 0, 0, 0);   // mid x mid
+                for (int pl = 0; pl < 3; ++pl) wc[n][pl] = wn[n][pl];
+        }
+        // ---- 32 output channels: the wave of tap half h finishes channel tile h; its sums for the other tile go to its partner
+        if constexpr (TSPLIT) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2], bh[i], acc[3 * g + i], 0, 0, 0);   // lo  x hi
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4 *>(sX + (((mg * 2 + th) * 3 + i) * 64 + lane) * 4) = th ? acc[0][i] : acc[1][i];
+            __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], bl[i], acc[3 * g + i], 0, 0, 0);   // hi  x lo
+            for (int i = 0; i < 3; ++i) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(sX + (((mg * 2 + (1 - th)) * 3 + i) * 64 + lane) * 4);
+                const f32x4 mine = th ? acc[1][i] : acc[0][i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], bh[i], acc[3 * g + i], 0, 0, 0);   // mid x hi
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], bm[i], acc[3 * g + i], 0, 0, 0);   // hi  x mid
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[3 * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], bh[i], acc[3 * g + i], 0, 0, 0);   // hi  x hi
+                for (int q = 0; q < 4; ++q) acc[0][i][q] = th ? o[q] + mine[q] : mine[q] + o[q];   // taps 0-4 first
             }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wc[pl] = wn[pl];
         }
         // ---- epilogue: BatchNorm, residual, ReLU; four consecutive channels of one pixel per lane.  (The residual is requested here, not
-        // before the products: 24 more live registers across the k loop cost the second wave per SIMD, which hides this round trip.)
-        f32x4 rv[MTW];
+        // before the products: its registers across the k loop cost the second wave per SIMD, which hides this round trip.)
+        constexpr int NF = TSPLIT ? 1 : 2;
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + co4;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            rv[i] = res ? *reinterpret_cast<const f32x4 *>(res + o) : z;
-        }
+        for (int n = 0; n < NF; ++n) {
+            const int c4o = co4b + 16 * (TSPLIT ? th : n);
+            const f32x4 scn = *reinterpret_cast<const f32x4 *>(sSS + c4o), shn = *reinterpret_cast<const f32x4 *>(sSS + COUT + c4o);
+            f32x4 rv[3];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            f32x4 ov;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = acc[i][q] * sc[q] + sh[q];
-                v += rv[i][q];
-                ov[q] = a.relu ? fmaxf(v, 0.0f) : v;
+            for (int i = 0; i < 3; ++i) {
+                const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + c4o;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rv[i] = res ? *reinterpret_cast<const f32x4 *>(res + o) : z;
             }
-            if (oy0 + prow[i] < Hout) *reinterpret_cast<f32x4 *>(out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + co4) = ov;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 ov;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[n][i][q] * scn[q] + shn[q];
+                    v += rv[i][q];
+                    ov[q] = a.relu ? fmaxf(v, 0.0f) : v;
+                }
+                if (oy0 + prow[i] < Hout) *reinterpret_cast<f32x4 *>(out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + c4o) = ov;
+            }
         }
-        __syncthreads();   // every wave is done with this tile's halo: the next one may be written
+        __syncthreads();   // every wave is done with this tile's halo (and the exchange area): the next one may be written
     }
 }
 
@@ -2715,7 +2771,7 @@ static bool launch_conv_s3(const lz_conv_args &a, hipStream_t s)
     constexpr int PB = (STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10)) * 8;
     constexpr int NLD = STRIDE == 2 ? 14 : (CIN == 32 ? 7 : 10);
     if (HR * HC * (CIN / 4) > NLD * 256) return false;          // the halo must fit the kernel's per-thread piece count
-    const size_t lds = (size_t)3 * (((size_t)HR * HC * PB + 7) & ~(size_t)7) * 2;
+    const size_t lds = (size_t)3 * (((size_t)HR * HC * PB + 7) & ~(size_t)7) * 2 + (COUT == 32 ? 4 * 3 * 256 * 4 : 0) + 2 * COUT * 4;   // halo planes (+ the tap halves' exchange) + scale | shift
     if (lds > 150 * 1024) return false;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_conv_s3<CIN, COUT, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }

@@ -54,9 +54,10 @@ def main():
         v = t.get(counter) if t else None
         return round(sum(v) / len(v), 2) if v else None
 
-    # the roofline kernel: the k_chain_w instantiation with the largest total time (the fused tree-step + chain launch)
+    # the roofline kernel: the parity-mode chain instantiation with the largest total time (the fused tree-step + chain launch):
+    # k_chain_s3 since round 5 (k_chain_w when the run had LZ_CHAIN_NO_SPLIT=1)
     tot = {r["Name"]: float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats))}
-    fused = max((n for n in tot if "k_chain_w" in n), key=lambda n: tot[n])
+    fused = max((n for n in tot if "k_chain_s3" in n or "k_chain_w" in n), key=lambda n: tot[n])
     fused = short(fused)
     f, w = mean(fused, "FETCH_SIZE"), mean(fused, "WRITE_SIZE")
     out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and rocprofv3 --kernel-trace --pmc WRITE_SIZE (two separate passes) -- "
@@ -67,9 +68,10 @@ def main():
                        "kernel": fused,
                        "note": "the root's prologue (tree step on wave 0; split heads: the previous simulation's head MLPs finished on waves 1-7 "
                                "from the LSTM launch's 3.1 MB of first-layer partial sums + 0.16 MB of second-layer weights per XCD) + the "
-                               "Winograd convolution chain. reads: latent gather 2.36 MB + 1.31 MB of transformed weights once per XCD L2 (8 x: "
-                               "L2 does not survive a kernel boundary) + the staged trees; writes: next latent 2.36 MB + head-conv outputs "
-                               "1.77 MB + tree write-through. Algorithmic bytes of the chain 7.8 MB (activations in and out + the weights once)."}}
+                               "split-bf16 convolution chain. reads: latent gather 2.36 MB + 1.11 MB of weight planes (5 layers x 64 x 64 x 9 x "
+                               "3 bf16) once per XCD L2 (8 x: L2 does not survive a kernel boundary) + the staged trees; writes: next latent "
+                               "2.36 MB + head-conv outputs 1.77 MB + tree write-through. Algorithmic bytes of the chain 7.8 MB (activations "
+                               "in and out + the fp32 weights once)."}}
     # every other kernel of the step, under the name the profiler printed (looking kernels up by last round's template
     # signature left the LSTM's and the row kernel's entries null): one entry per kernel family = its instantiation with the largest total time
     fams = {}
@@ -107,8 +109,9 @@ def main():
     hdr = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY",
            "#   + separate passes --pmc FETCH_SIZE / --pmc WRITE_SIZE   -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline   (MI355X)",
            "# per-dispatch means.  Counters are summed over the 8 XCDs / 1024 SIMDs; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY count quad-cycles;",
-           "# SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (32 per v_mfma_f32_16x16x4_f32, 8 per v_mfma_f32_4x4x1_16b_f32);",
-           "# k_chain_w runs 768 4x4x1 MFMAs per SIMD and layer: 6,144 busy cycles where the direct form needed 10,368 for the same convolution.",
+           "# SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (32 per v_mfma_f32_16x16x4_f32, 16 per v_mfma_f32_16x16x32_bf16);",
+           "# k_chain_s3 runs 324 16x16x32 bf16 MFMAs per SIMD and layer (9 taps x 2 K halves x 6 plane products x 3 pixel tiles): 5,184 busy cycles;",
+           "# the fp32 Winograd form it replaced (k_chain_w) needed 6,144, the direct fp32 form 10,368 for the same convolution.",
            "# FETCH_SIZE / WRITE_SIZE in KB (FETCH_SIZE x 2 = bytes read on gfx950, see %s_traffic.json)." % tag]
     if busy and d_us:
         per_simd = busy / 1024.0
