@@ -2237,7 +2237,10 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
             const int q = min(widx + 4 * f, 5), ntl = q / 3, mt = q - 3 * ntl;
             mpix[f] = mt * 16 + (lane & 15);
             c4v[f] = (2 * np + ntl) * 16 + 4 * (lane >> 4);
-            rvv[f] = *reinterpret_cast<const f32x4 *>(sRes + min(mpix[f], HW - 1) * PS + c4v[f]);
+            {
+                const f32x4 rl = *reinterpret_cast<const f32x4 *>(sRes + min(mpix[f], HW - 1) * PS + c4v[f]), z = {0.f, 0.f, 0.f, 0.f};
+                rvv[f] = res >= 0 ? rl : z;
+            }
             scv[f] = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + c4v[f]);
             shv[f] = *reinterpret_cast<const f32x4 *>(sSS + L * 128 + 64 + c4v[f]);
         }
@@ -2321,46 +2324,52 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         {
             float *go = reinterpret_cast<float *>(lane64(my_gout, L));
             if (go) go += (size_t)b * HW * 64;
-            // every LDS read of the epilogue before its first write (the compiler must assume they alias)
-            f32x4 oth[2][3];
+            // The epilogue is VALU work on the SIMD both waves of a pair share (3 tiles per SIMD): with the wave's role a run-time value every
+            // accumulator / partial-sum pick was a chain of v_cndmask (about 120 VALU instructions per tile, 1.4 k cycles per layer on the
+            // busiest SIMD) -- so the role becomes a compile-time constant behind a scalar branch, the residual arrives masked, the
+            // action-table rows enter by an FMA with 0 | 1 and ReLU is a max with 0 | -inf: about 50.
+            const float tabf = tab ? 1.0f : 0.0f, floor_ = relu ? 0.0f : -__builtin_inff();
+            auto finish = [&](auto widx_c) {
+                constexpr int W = decltype(widx_c)::value;
+                constexpr int NFIN = W < 2 ? 2 : 1;          // waves 2 and 3 of a pair finish one tile
+                // every LDS read of the epilogue before its first write (the compiler must assume they alias)
+                f32x4 oth[NFIN][3];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const int q = min(widx + 4 * f, 5);
+                for (int f = 0; f < NFIN; ++f)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) oth[f][r] = *reinterpret_cast<const f32x4 *>(sP + (((np * 6 + q) * 3 + r) * 64 + lane) * 4);
-            }
+                    for (int r = 0; r < 3; ++r) oth[f][r] = *reinterpret_cast<const f32x4 *>(sP + (((np * 6 + W + 4 * f) * 3 + r) * 64 + lane) * 4);
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                if (widx + 4 * f >= 6) continue;             // waves 2 and 3 of a pair finish one tile
-                const int q = widx + 4 * f;
-                f32x4 mine = acc[0][0];
+                for (int f = 0; f < NFIN; ++f) {
+                    const int q = W + 4 * f;
+                    // the four partial sums in the fixed order of the waves' indices (kh + 2 th): the finisher's own stands at position W
+                    f32x4 p[4];
 #pragma unroll
-                for (int qq = 0; qq < 6; ++qq) mine = (qq == q) ? acc[qq / 3][qq % 3] : mine;
-                // the four partial sums in the fixed order of the waves' indices (kh + 2 th): the finisher's own stands at position widx
-                f32x4 p[4];
+                    for (int w4 = 0; w4 < 4; ++w4) p[w4] = (w4 == W) ? acc[q / 3][q % 3] : oth[f][w4 < W ? w4 : w4 - 1];
+                    f32x4 o;
 #pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) {
-                    const int rank = w4 < widx ? w4 : w4 - 1;
-                    p[w4] = (w4 == widx) ? mine : oth[f][min(max(rank, 0), 2)];
+                    for (int c = 0; c < 4; ++c) {
+                        float v = ((p[0][c] + p[1][c]) + p[2][c]) + p[3][c];
+                        v = __builtin_fmaf(tabf, tvv[f][c], v);
+                        v = v * scv[f][c] + shv[f][c];
+                        v += rvv[f][c];
+                        o[c] = fmaxf(v, floor_);
+                    }
+                    bf16x4 oh, om, ol;
+                    split3_bf16(o, oh, om, ol);
+                    if (mpix[f] < HW) {
+                        *reinterpret_cast<f32x4 *>(sOut + mpix[f] * PS + c4v[f]) = o;
+                        *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + c4v[f]) = oh;
+                        *reinterpret_cast<bf16x4 *>(sBout + BB + mpix[f] * PB + c4v[f]) = om;
+                        *reinterpret_cast<bf16x4 *>(sBout + 2 * BB + mpix[f] * PB + c4v[f]) = ol;
+                        if (go) store_wt(go + mpix[f] * 64 + c4v[f], o);
+                    }
                 }
-                f32x4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = ((p[0][c] + p[1][c]) + p[2][c]) + p[3][c];
-                    v += tab ? tvv[f][c] : 0.0f;
-                    v = v * scv[f][c] + shv[f][c];
-                    v += res >= 0 ? rvv[f][c] : 0.0f;
-                    o[c] = relu ? fmaxf(v, 0.0f) : v;
-                }
-                bf16x4 oh, om, ol;
-                split3_bf16(o, oh, om, ol);
-                if (mpix[f] < HW) {
-                    *reinterpret_cast<f32x4 *>(sOut + mpix[f] * PS + c4v[f]) = o;
-                    *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + c4v[f]) = oh;
-                    *reinterpret_cast<bf16x4 *>(sBout + BB + mpix[f] * PB + c4v[f]) = om;
-                    *reinterpret_cast<bf16x4 *>(sBout + 2 * BB + mpix[f] * PB + c4v[f]) = ol;
-                    if (go) store_wt(go + mpix[f] * 64 + c4v[f], o);
-                }
+            };
+            switch (__builtin_amdgcn_readfirstlane(widx)) {
+            case 0: finish(std::integral_constant<int, 0>{}); break;
+            case 1: finish(std::integral_constant<int, 1>{}); break;
+            case 2: finish(std::integral_constant<int, 2>{}); break;
+            default: finish(std::integral_constant<int, 3>{}); break;
             }
         }
         if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L == 2) lz_stamp_store(step.ts + (29), __builtin_readcyclecounter()); }
