@@ -829,6 +829,9 @@ def main():
                        "row_bytes_per_env_step": W * 4, "all_gather_bytes_per_step_per_rank": (world - 1) * NMAX * W * 4 if world > 1 else 0,
                        "all_gather_overlapped": bool(dist_on and backend == "nccl" and not args.sync_gather),
                        "all_gather_fence": fence_mode if (dist_on and backend == "nccl" and not args.sync_gather) else None,
+                       "arithmetic": "tree: binary32 (bit-exact with the reference's ctree); network: binary32 operands as three exact bf16 planes, six "
+                                     "plane products per k-step accumulated in binary32 on the bf16 matrix pipe (tower, recurrent chain), binary32 "
+                                     "matrix instructions elsewhere (LSTM, heads) -- within 1e-5 (1 + |x|) of the reference modules",
                        "debug_knobs": knobs},
             "roofline": {"bound": "mfma", "kernel": "k_chain_s3 (per root: [tree step of the root: expand + backup + next selection, one wave; the previous leaf's head MLPs on the other seven: prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 3x3 convolutions in the direct form as SPLIT-bf16 products on v_mfma_f32_16x16x32_bf16: every fp32 operand is the exact sum of three bf16 planes, six of the nine plane products are accumulated in fp32 -- fp32-level accuracy at 6 bf16 matrix FLOPs per algorithmic FLOP; 1 launch/simulation; achieved = the ALGORITHMIC convolution FLOPs of SURVEY 8d over the whole launch; peak = the bf16 dense peak / 6, the rate at which this form can deliver fp32-accurate FLOPs)",
                          "achieved": achieved, "peak": PEAK_SPLIT_BF16_TFLOPS, "unit": "TFLOP/s",
