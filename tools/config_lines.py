@@ -17,6 +17,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK = 157.3   # TFLOP/s, dense fp32 matrix (MI355X_MICROARCH.md)
+PEAK_SPLIT = 2500.0 / 6.0   # k_chain_s3: fp32 operands as three bf16 planes, six plane products per k-step on the bf16 pipe (2500 TFLOP/s dense)
+
+
+def chain_peak(kernel):
+    """(peak, extra fields) for a chain kernel's algorithmic fp32 FLOPs: the split-bf16 form is priced on the bf16 peak / 6"""
+    if "k_chain_s3" in kernel:
+        return PEAK_SPLIT, dict(peak_note="bf16 dense peak / 6 plane products (split-bf16 parity-mode chain)", fp32_matrix_peak=PEAK)
+    return PEAK, {}
 
 # name -> (BASELINE.json index, tool command, steps under the profiler, per-root algorithmic FLOP of the chain launch | None)
 CHAIN_ATARI_MZ = 2 * 36 * 64 * (68 + 4 * 64) * 9 + 2 * 36 * 64 * 48          # dyn conv 68 -> 64 (A = 4) + 4 convs 64 -> 64 + three 1x1 64 -> 16
@@ -97,8 +105,11 @@ def main():
             if "k_chain" in top["kernel"] and c.get("chain_flop"):
                 flop = c["chain_flop"] * line["envs"] // max(1, line.get("sub_batches", 1))
                 ach = flop / (top["avg_us"] * 1e-6) / 1e12
-                roof.update(bound="mfma", algorithmic_flop_per_launch=flop, achieved=ach, peak=PEAK, unit="TFLOP/s", frac=ach / PEAK,
-                            clock="rocprofv3 --kernel-trace average of this run")
+                pk, extra = chain_peak(top["kernel"])
+                roof.update(bound="mfma", algorithmic_flop_per_launch=flop, achieved=ach, peak=pk, unit="TFLOP/s", frac=ach / pk,
+                            clock="rocprofv3 --kernel-trace average of this run", **extra)
+                if extra:
+                    roof["frac_vs_fp32_matrix_peak"] = ach / PEAK
             else:
                 roof.update(bound="latency", achieved=None, peak=None, frac=None,
                             note="launch- / latency-bound kernel: a dense layer of <= 0.26 MB of weights and ~2 MFLOP, or a tree step of one "
