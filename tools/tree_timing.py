@@ -32,7 +32,7 @@ for i in range(1, 7):
     print("%-32s +%6d cycles   (t=%6d)" % (names[i], ts[i] - ts[i - 1], ts[i] - ts[0]))
 hs = out[8:15].astype(np.int64)
 if hs[0]:   # split heads: head wave 1 (value head, output group 0) of the same workgroup
-    hn = ["entered", "loads requested", "partials arrived", "hidden units", "second layer", "max barrier", "sum barrier", "scalar out"]
+    hn = ["entered", "-", "all requests issued", "partials arrived + hidden units", "second layer", "own softmax sums", "rendezvous of the three waves", "scalar out"]
     print("head wave 1 (value head): entered at t=%6d of the tree wave's clock" % (hs[0] - ts[0]))
     for i in range(1, 7):
         print("  %-30s +%6d cycles   (t=%6d)" % (hn[i + 1] if i < 6 else hn[7], hs[i] - hs[i - 1], hs[i] - ts[0]))
