@@ -2024,10 +2024,11 @@ __device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m
 // wave 0, split-head finish on waves 1-7, five 3x3 layers in the DIRECT form with the activations resident in LDS, 1x1 head convolutions)
 // with every operand split EXACTLY into three bf16 terms and six of the nine cross products per k-step (see k_conv_s3 for the arithmetic:
 // the error of a dot product is that of an fp32 FMA chain; tests/test_nn_gpu.py holds every simulation of a 256 x 50 search to 1e-5 (1 + |x|)
-// of the torch fp32 modules).  Why it is faster than the fp32 Winograd chain (k_chain_w), although both are bound by the weight stream of
-// one root per CU: three bf16 planes of the direct form are 221 KB per layer against 262 KB of transformed fp32 weights, the six products
+// of the torch fp32 modules; tests/test_split_bf16_cpu.py restates the arithmetic in numpy).  Why it is faster than the fp32 Winograd
+// chain (k_chain_w): three bf16 planes of the direct form are 221 KB per layer against 262 KB of transformed fp32 weights, the six products
 // are 5.2 k matrix cycles per SIMD and layer against 6.1 k, and the Winograd input / output transforms -- 3.7 k cycles of LDS-bound work
-// per layer, four barriers -- are gone (one exchange of the two k halves and the epilogue remain).
+// per layer, four barriers -- are gone; a layer is 8.05 k cycles (products 5.7 k, at 91 % of the matrix rate) against 11.3 k.  Wave roles,
+// the schedule of a tap and what the ISA showed on the way: DESIGN.md 3.2c.
 // ------------------------------------------------------------------------------------------------
 template <int GW, int GH, int TREE = 0, bool HEADS = false>
 __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step_arg<TREE>::type step)
@@ -2679,6 +2680,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
         __syncthreads();
         // ---- the next tile's halo travels while this one is multiplied
         if (tile + tstride < tend) prefetch(tile + tstride);
+        // The residual rows of the first channel tile this wave finishes are requested here where registers allow (32 output channels,
+        // stride 2): they do not depend on the products, and requested in the epilogue their round trip (another kernel wrote them) stands
+        // between the products and the store of every tile with only the co-resident workgroup to hide it (32 -> 32 at 48 x 48: 74.5 -> 71.9 us).
+        // The 64 -> 64 stride-1 instance has no 12 registers left across the k loop (it would spill): both of its tiles' rows are requested
+        // at the top of the epilogue.
+        auto res_request = [&](int c4o, f32x4 (&rv)[3]) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + c4o;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rv[i] = res ? *reinterpret_cast<const f32x4 *>(res + o) : z;
+            }
+        };
+        constexpr bool EARLY = TSPLIT || STRIDE == 2;
+        f32x4 rv0[3];
+        if constexpr (EARLY) res_request(co4b + 16 * (TSPLIT ? th : 0), rv0);
         f32x4 acc[2][3];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -2741,27 +2758,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
                 for (int q = 0; q < 4; ++q) acc[0][i][q] = th ? o[q] + mine[q] : mine[q] + o[q];   // taps 0-4 first
             }
         }
-        // ---- epilogue: BatchNorm, residual, ReLU; four consecutive channels of one pixel per lane.  (The residual is requested here, not
-        // before the products: its registers across the k loop cost the second wave per SIMD, which hides this round trip.)
+        // ---- epilogue: BatchNorm, residual, ReLU; four consecutive channels of one pixel per lane
         constexpr int NF = TSPLIT ? 1 : 2;
+        f32x4 rv1[3];
+        if constexpr (!EARLY) res_request(co4b + 16 * (TSPLIT ? th : 0), rv0);
+        if constexpr (NF == 2) res_request(co4b + 16, rv1);
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
             const int c4o = co4b + 16 * (TSPLIT ? th : n);
             const f32x4 scn = *reinterpret_cast<const f32x4 *>(sSS + c4o), shn = *reinterpret_cast<const f32x4 *>(sSS + COUT + c4o);
-            f32x4 rv[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const size_t o = (((size_t)img * Hout + min(oy0 + prow[i], Hout - 1)) * Wout + pcol[i]) * COUT + c4o;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                rv[i] = res ? *reinterpret_cast<const f32x4 *>(res + o) : z;
-            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f32x4 ov;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v = acc[n][i][q] * scn[q] + shn[q];
-                    v += rv[i][q];
+                    v += n == 0 ? rv0[i][q] : rv1[i][q];
                     ov[q] = a.relu ? fmaxf(v, 0.0f) : v;
                 }
                 if (oy0 + prow[i] < Hout) *reinterpret_cast<f32x4 *>(out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + c4o) = ov;
