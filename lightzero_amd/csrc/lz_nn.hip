@@ -1198,7 +1198,10 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
             s_leaf[2 + lane] = lg[0];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(s_ctr + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) {   // s_ctr[3]: the policy logits alone are out (the tree wave starts the new node's priors on them), s_ctr[2]: one more head done
+            __hip_atomic_fetch_add(s_ctr + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(s_ctr + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         return;
     }
     // ---- softmax . support -> inverse scalar transform.  Each of the head's three waves sums exp(logit - ITS OWN maximum); the three

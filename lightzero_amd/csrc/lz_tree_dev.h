@@ -485,34 +485,52 @@ __device__ __forceinline__ void dev_traverse_par(const lz_tree_dev &t, const tvi
 // ------------------------------------------------------------------------------------------------
 // no_expand (ReZero, cnode.cpp:626-630): the leaf is an already expanded node -- nothing is expanded, its own value prefix
 // stays, only is_reset is refreshed and value_b (the reuse value) is backed up.  bidx = the leaf's batch_index.
+// The new node's priors: softmax of the leaf's policy logits in the reference's order of operations (cnode.cpp:88-151: maximum, exp of the
+// differences by the libm-exact lz_expf, the sum over the actions in index order, one division per action).  Lane j of chunk c gets action
+// c * 64 + j's.  A function of the policy logits only.
+template <int NC>
+__device__ __forceinline__ void dev_expand_priors(const float (&lg)[NC], int A, const uint64_t *exptab, float (&pri)[NC])
+{
+    float e[NC];
+    float m = LZ_FLOAT_MIN;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) m = fmaxf(m, lg[c]);
+    m = wave_max(m);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) e[c] = lz_expf_core(lg[c] - m, exptab);
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int cnt = min(64, A - c * 64);
+        for (int j = 0; j < cnt; ++j) sum += rl_f(e[c], j);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) pri[c] = e[c] / sum;
+}
+
 template <int NC, int VARIANT, bool WT>
 __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &v, tscal<NC> &sc, int new_node, float discount,
                                              float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset,
-                                             bool no_expand = false, int bidx = -1, const uint64_t *exptab = nullptr)
+                                             bool no_expand = false, int bidx = -1, const uint64_t *exptab = nullptr,
+                                             const float *prior_in = nullptr)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
     // ---- CNode::expand (cnode.cpp:88-151): all A actions are legal below the root
     if (!no_expand) {
-        float e[NC];
-        float m = LZ_FLOAT_MIN;
+        float pri[NC];
+        if (prior_in) {   // dev_expand_priors ran already (dev_step_lds with split heads: on the policy logits, before value / value prefix were out)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) m = fmaxf(m, lg[c]);
-        m = wave_max(m);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) e[c] = lz_expf_core(lg[c] - m, exptab);
-        float sum = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int cnt = min(64, A - c * 64);
-            for (int j = 0; j < cnt; ++j) sum += rl_f(e[c], j);
+            for (int c = 0; c < NC; ++c) pri[c] = prior_in[c];
+        } else {
+            dev_expand_priors<NC>(lg, A, exptab, pri);
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = c * 64 + lane;
             if (j < A) {
                 const size_t o = (size_t)new_node * A + j;
-                const float4 ne = make_float4(e[c] / sum, __int_as_float(0), 0.0f, 0.0f);
+                const float4 ne = make_float4(pri[c], __int_as_float(0), 0.0f, 0.0f);
                 v.edge[o] = ne;
                 v.child[o] = -1;
                 if (WT) { v.g_edge[o] = ne; v.g_child[o] = -1; }
@@ -793,12 +811,26 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
             if (i < new_node) { s_vp[i] = nv[u]; s_reset[i] = nr[u]; s_tp[i] = nt[u]; s_pn[i] = pn[u]; s_pa[i] = pa[u]; s_link[i] = lk[u]; }
         }
     }
-    if (s_leaf) {   // the tree is staged; now the leaf's network outputs, once the waves that compute them say so
+    float pri_early[NC];
+    if (s_leaf) {
+        // The tree is staged; now the leaf's network outputs, once the waves that compute them say so.  The policy head is the first to
+        // finish (one wave, A outputs; the value and value-prefix heads are three waves of 601 outputs each and the second of them gets its
+        // weights 2.4 k cycles after the first: a CU's 64 B/clk): the new node's priors -- the software exp, the ordered sum and the
+        // divisions of the expansion -- are computed on the logits alone (s_leaf_flag[1]) while those two finish.
+        while (__hip_atomic_load(s_leaf_flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        float lg_m[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            r_lg[c] = s_leaf[2 + min(c * 64 + lane, A - 1)];
+            lg_m[c] = (c * 64 + lane < A) ? r_lg[c] : LZ_FLOAT_MIN;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the exp table in LDS was written by this wave's lanes above)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        dev_expand_priors<NC>(lg_m, A, s_exp, pri_early);
         while (__hip_atomic_load(s_leaf_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != leaf_ready) __builtin_amdgcn_s_sleep(1);
         r_vp = s_leaf[0];
         r_val = s_leaf[1];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) r_lg[c] = s_leaf[2 + min(c * 64 + lane, A - 1)];
     }
     // the same values load_scalars / load_leaf produce
     tscal<NC> sc;
@@ -823,7 +855,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     tview v = g;
     v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
     v.path_node = s_pn; v.path_act = s_pa; v.link = s_link;
-    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset, false, -1, s_exp);
+    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset, false, -1, s_exp, s_leaf ? pri_early : nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
