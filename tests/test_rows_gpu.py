@@ -125,6 +125,7 @@ def test_device_rows_of_the_sampled_and_gumbel_families_equal_host_packer():
     F, E = 5, K * D
     W = shard.row_width(K, F, E)
     rows = torch.zeros(B, W, device="cuda")
+    torch.cuda.synchronize()   # raw-pointer call on the engine's own stream: torch's zero-fill must have landed first
     hdr, pol = roots.collect_rows(1.0, True, rows.data_ptr(), W, F, timestep=list(range(B)), seed=9)
     got = rows.cpu().numpy()
     assert np.array_equal(got[:, :shard.HEADER + 2 * K + E], hdr) and np.array_equal(pol, out.policy_logits)
@@ -165,6 +166,7 @@ def test_device_rows_of_the_sampled_and_gumbel_families_equal_host_packer():
     F = 96 * 96
     W = shard.row_width(A, F, A)
     grows = torch.zeros(B, W, device="cuda")
+    torch.cuda.synchronize()   # raw-pointer call on the engine's own stream: torch's zero-fill must have landed first
     ghdr, _ = groots.collect_rows(1.0, True, grows.data_ptr(), W, F, discount=0.997)
     ggot = grows.cpu().numpy()
     o = {}

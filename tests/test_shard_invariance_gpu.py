@@ -39,6 +39,7 @@ def _run(model, obs, noise, S, A, frame):
     L.check(lib.lz_roots_read_latent(roots._h, S, lat.reshape(-1)))
     W = shard.row_width(A, frame)
     rows = torch.zeros(B, W, device="cuda")
+    torch.cuda.synchronize()   # the engine writes the rows on its own (non-blocking) stream: torch's zero-fill must have landed first
     hdr = np.zeros((B, shard.HEADER + 2 * A), np.float32); lg = np.zeros((B, A), np.float32)
     ts = np.arange(B, dtype=np.int32) * 0 + 7
     L.check(lib.lz_roots_collect_rows(roots._h, 1.0, 1, 12345, None, frame, ts.ctypes.data, rows.data_ptr(), W, hdr, lg.ctypes.data))
