@@ -21,6 +21,7 @@ UNITS = [
     ("lz_tree_sampled.hip", ["-ffp-contract=off"]),
     ("lz_capi.hip", []),
     ("lz_nn.hip", []),
+    ("lz_chain_s3g.hip", []),
     ("lz_dense.hip", []),
     ("lz_mlp.hip", []),
     ("lz_search.hip", []),

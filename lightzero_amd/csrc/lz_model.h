@@ -26,7 +26,7 @@ struct ConvW {
     void *wt = nullptr;   // fast mode: bf16 fragments for the tower kernel k_conv_bf, [cout/16][9 taps x cin/32][64 lanes][8 bf16]
     void *w3 = nullptr;   // parity mode: the same fragments split exactly into three bf16 planes (hi | mid | lo) for k_conv_s3,
                           // [cout/16][9 taps x cin/32][3 planes][64 lanes][8 bf16]
-    void *w3c = nullptr;  // parity mode, 6x6 chain (k_chain_s3): [2 k halves][cout/16][9 taps][3 planes][64 lanes][8 bf16]; w3cf = its fp32 values (refresh)
+    void *w3c = nullptr;  // parity mode, LDS-resident chains (k_chain_s3, k_chain_s3g): [2 k halves][cout/16][9 taps][3 planes][64 lanes][8 bf16]; w3cf = its fp32 values (refresh)
     float *w3cf = nullptr;
     float *w3f = nullptr; // the fp32 values of those fragments in the same order [cout/16][ks][64 lanes][8] (what a device-side refresh gathers; k_refresh_split3 turns it into w3)
     int cin = 0, cout = 0;
@@ -264,14 +264,14 @@ struct Builder {
         }
         return c;
     }
-    ConvW resconv(const std::string &prefix, int idx, int cout, int cin, bool winograd = false, bool wchain = false)  // ding ResBlock convN = Sequential(conv, bn[, act])
+    ConvW resconv(const std::string &prefix, int idx, int cout, int cin, bool winograd = false, bool wchain = false, bool s3chain = false)  // ding ResBlock convN = Sequential(conv, bn[, act])
     {
         const std::string p = prefix + ".conv" + std::to_string(idx);
         ConvW c = conv(p + ".0.weight", p + ".1", cout, cin, cin);
         if (winograd) c.uf = wino(p + ".0.weight", cout, cin);
         if (wchain) c.uc = wino_chain(p + ".0.weight", cout, cin, cin);
         if (wchain && m->cfg.precision == 1) c.wb = bf16_chain(p + ".0.weight", cout, cin, cin);
-        if (wchain && m->cfg.precision == 0 && m->GW == 6 && m->GH == 6) split3_chain(p + ".0.weight", cout, cin, cin, c);
+        if (s3chain) split3_chain(p + ".0.weight", cout, cin, cin, c);   // parity mode: k_chain_s3 (6x6) / k_chain_s3g (8x8, 9x9, 6x7, 4x4)
         return c;
     }
     // fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)

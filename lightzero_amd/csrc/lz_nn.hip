@@ -21,30 +21,10 @@
 #include "lz_hinv.h"
 #define LZ_TREE_DEV_RESTORE_FAST_CONTRACT
 #include "lz_tree_dev.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "lz_nn_dev.h"
 
 namespace {
 
-template <int VEC> struct vecf;
-template <> struct vecf<4> { typedef float4 type; };
-template <> struct vecf<2> { typedef float2 type; };
-
-__device__ __forceinline__ float vget(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
-__device__ __forceinline__ float vget(const float2 &v, int j) { return j == 0 ? v.x : v.y; }
-__device__ __forceinline__ float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-
-// The activation of a network: ReLU (every shipped EfficientZero / MuZero conv configuration) or GELU(approximate='tanh') -- the default of the
-// convolutional Sampled EfficientZero (sampled_efficientzero_model.py:40), which its Atari configuration keeps.  GELU instances are separate
-// template instantiations (bool GELU): the ReLU kernels' code does not change.  tanh(y) = 1 - 2 / (1 + e^{2y}) on the hardware exp / rcp as in
-// lz_dense.hip (|error| < 3e-7 absolute).
-__device__ __forceinline__ float gelu_tanh_(float u)
-{
-    const float y = 0.7978845608028654f * (u + 0.044715f * u * u * u);
-    const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * y));
-    return 0.5f * u * (1.0f + t);
-}
-template <bool GELU> __device__ __forceinline__ float act_(float v) { if constexpr (GELU) return gelu_tanh_(v); else return fmaxf(v, 0.0f); }
 // (the reference's class mixes them: its representation network keeps ReLU, its dynamics network takes the model's activation, its prediction
 // network keeps GELU -- sampled_efficientzero_model.py:177-218 passes `activation` to the dynamics network only -- so the chain's GELU instance
 // reads a code per layer and per 1x1 job)
@@ -483,8 +463,6 @@ __global__ __launch_bounds__(256) void k_conv_wino(lz_conv_args a)
 // first DownSample layer: conv3x3 / stride 2 from NCHW observations, + BN + ReLU.  One thread per
 // output pixel computes all Cout channels from the (<= 9*C)-value patch; weights broadcast from LDS.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
 
 // OUTBF (fast mode): the output tensor is bf16 NHWC (the tower keeps its activations in bf16 there)
 template <int C, int COUT, bool OUTBF = false>
@@ -799,9 +777,6 @@ __global__ __launch_bounds__(256) void k_conv1x1(lz_c1_args a)
 // TREE != 0: wave 0 first runs the root's tree step (dev_step_lds, variant TREE - 1) on an LDS copy of the tree placed in
 // the still unused activation buffers -- the per-simulation tree launch disappears, and the weight prefetch of the first
 // layer is in flight meanwhile.
-struct no_step {};
-template <int TREE> struct step_arg { typedef lz_tree_step type; };
-template <> struct step_arg<0> { typedef no_step type; };
 
 template <int GW, int GH, bool TS = false, int TREE = 0>
 __global__ __launch_bounds__(256) void k_chain(lz_chain_args a, typename step_arg<TREE>::type step)
@@ -1083,41 +1058,6 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-// A pointer rebuilt from an integer (v_readlane of a per-layer address kept in a lane) is a FLAT pointer to the compiler: its loads become
-// flat_load, which count on vmcnt AND lgkmcnt and may return out of order with LDS traffic, so every wait on them is s_waitcnt vmcnt(0)
-// lgkmcnt(0) -- a full drain of the weight stream in the middle of the MFMA loop (seen in the ISA of k_chain_s3 and k_chain_b).  Say that
-// the address is global.
-typedef __attribute__((address_space(1))) const bf16x8 gbl_bf16x8;
-__device__ __forceinline__ gbl_bf16x8 *as_global_bf16x8(unsigned long long addr) { return (gbl_bf16x8 *)addr; }
-__device__ __forceinline__ bf16x8 gload(gbl_bf16x8 *p) { return *p; }
-
-// Write-through stores (sc0 sc1) for the big per-launch outputs of the recurrent loop (next latent, head-convolution rows, LSTM state, head
-// partials: 4-5 MB per launch).  What a kernel leaves dirty in L2 is written back at the kernel boundary, in front of the next launch: measured
-// (fast mode, same box, in-graph stamps) the gap behind the chain launch 3.4 -> 2.9 us and behind the LSTM launch 2.5 -> 1.95 us with these
-// stores written through while the kernel still runs.  Nobody reads them back inside the launch.
-__device__ __forceinline__ void store_wt(float *p, const f32x4 &v)
-{
-    // The s_nop belongs to the store: a VMEM store of more than 64 bits reads its data registers late, and a VALU write to them within two wait
-    // states corrupts the stored value (gfx940 hazard).  The compiler's hazard recognizer covers its own stores but cannot see into inline
-    // assembly -- found when an experiment's register allocation reused the data registers as the next store's address (6 % of the rows wrong).
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store_wt(float *p, float v)
-{
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-
-// in-graph timing (bench.py): the FIRST workgroup of a launch stores the time it starts, the LAST one (by block id) the time it ends
-// (s_memrealtime: 100 MHz, independent of the shader clock); st == null in production (one wave-uniform branch).  Plain stores from two
-// workgroups: a first version that folded every workgroup's times in by atomics cost the 512-workgroup LSTM launch 3 us.
-__device__ __forceinline__ void lz_stamp_begin(unsigned long long *st)
-{
-    if (st && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) lz_stamp_store(st, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-}
-__device__ __forceinline__ void lz_stamp_end(unsigned long long *st)
-{
-    if (st && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) lz_stamp_store(st + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-}
 
 // ---- split heads: the head MLPs of the PREVIOUS simulation's leaf, finished by waves 1..7 of the root's workgroup while wave 0 stages
 // the root's tree (lz_split_heads).  hw = wave - 1: 0..2 value head, 3..5 value-prefix head (601 outputs over 3 waves x 64 lanes x <= 4),
@@ -2010,17 +1950,6 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
     lz_stamp_end(a.stamp);
 }
 
-__device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const __bf16 hq = (__bf16)v[q];
-        const float r1 = v[q] - (float)hq;
-        const __bf16 mq = (__bf16)r1;
-        const float r2 = r1 - (float)mq;
-        h[q] = hq; m[q] = mq; l[q] = (__bf16)r2;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // PARITY MODE (fp32 accuracy), round 5: the recurrent chain on the 6x6 latent as SPLIT-bf16 products -- k_chain_b's launch (tree step on
@@ -3927,14 +3856,15 @@ __device__ __forceinline__ float row16_max(float v)   // max over the 16 lanes o
     return v;
 }
 
-template <int MAXG>   // K1 <= 64 MAXG: 9 (6x6 latent: 16 x 36 head inputs, LSTM 512) | 16 (8x8 latent: 16 x 64)
+template <int MAXG>   // K1 <= 64 MAXG: 9 (6x6 latent: 16 x 36 head inputs, LSTM 512) | 16 (8x8 latent: 16 x 64) | 21 (9x9 board: 16 x 81)
 __global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
 {
     constexpr int HID = 32, MAXT = 5;   // NOUT <= 128 MAXT
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const lz_head_desc &h = hp.h[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n16 = lane & 15, kq = lane >> 4;
-    const int b0 = blockIdx.x * EPB, K1 = h.K1, NOUT = h.NOUT, NG1 = K1 >> 6;   // 16-wide k groups per k-quarter wave
+    const int b0 = blockIdx.x * EPB, K1 = h.K1, NOUT = h.NOUT, NG1 = ((K1 >> 4) + 3) >> 2;   // 16-wide k groups per k-quarter wave (the last quarter may hold fewer:
+                                                                                            // K1 = 16 x 81 on a 9x9 board = 21 + 21 + 21 + 18 groups)
     float *xs = smem;                    // [4][K1]
     float *part = xs + EPB * K1;         // [8 waves][4 roots][16 units]
     float *hid = part + 8 * 64;          // [4][32]
@@ -3952,11 +3882,12 @@ __global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
         xv[u] = *reinterpret_cast<const f32x4 *>(h.in + (size_t)b * h.env_stride + (k >> 4) * h.pix_stride + (k & 15));
     }
     const int kw = wv & 3, uh = wv >> 2;   // layer 1: this wave's k quarter and half of the hidden units
+    const int ng = max(0, min(NG1, (K1 >> 4) - kw * NG1));   // groups of this wave's quarter
     f32x4 w1f[MAXG];
     {
-        const float *wr = h.w1 + (size_t)(16 * uh + n16) * K1 + (size_t)kw * NG1 * 16 + kq * 4;
+        const float *wr = h.w1 + (size_t)(16 * uh + n16) * K1 + (size_t)(ng > 0 ? kw * NG1 * 16 : 0) + kq * 4;
 #pragma unroll
-        for (int g = 0; g < MAXG; ++g) w1f[g] = *reinterpret_cast<const f32x4 *>(wr + min(g, NG1 - 1) * 16);
+        for (int g = 0; g < MAXG; ++g) w1f[g] = *reinterpret_cast<const f32x4 *>(wr + min(g, max(ng - 1, 0)) * 16);
     }
     f32x4 w2f[MAXT][2];
     float b2v[MAXT];
@@ -3983,7 +3914,7 @@ __global__ __launch_bounds__(512) void k_heads_mm(head_pack hp, int B)
         const float *xa = xs + (lane & 3) * K1 + kw * NG1 * 16 + kq * 4;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
-            if (g < NG1) {   // wave-uniform
+            if (g < ng) {   // wave-uniform
                 const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + g * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], w1f[g][j], acc, 0, 0, 0);
@@ -4290,6 +4221,8 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
     static const char *direct = getenv("LZ_CHAIN_DIRECT");
     {
         static const char *nosplit = getenv("LZ_CHAIN_NO_SPLIT");
+        // the other grids (8x8, 9x9, 6x7, 4x4) and the GELU networks: k_chain_s3g (lz_chain_s3g.hip)
+        if (!nosplit && !direct && !getenv("LZ_CHAIN_W4") && lz_launch_chain_s3g(a, s, step)) return;
         bool s3 = !nosplit && !direct && !getenv("LZ_CHAIN_W4") && a.gw == 6 && a.gh == 6 && a.nlayers > 0 && !a.tstamp && !a.gelu && (a.C == 0 || a.C == 64);
         for (int i = 0; i < a.nlayers; ++i) s3 = s3 && a.layer[i].w3 != nullptr;
         if (s3) {
@@ -4495,11 +4428,14 @@ void lz_launch_heads(const lz_head_desc *heads, int nheads, int B, int HID, hipS
     static const char *valu = getenv("LZ_HEADS_VALU");   // the VALU kernel instead of the MFMA one
     if (HID != 32) return;
     bool mm = !valu && !narrow;
-    for (int i = 0; i < nheads && i < MAXH; ++i) mm = mm && (heads[i].K1 & 63) == 0 && heads[i].K1 <= 1024 && heads[i].NOUT <= 640;
+    // (round 6: K1 any multiple of 16 up to 1344 -- the 9x9 / 6x7 boards' 16 x 81 / 16 x 42 head inputs ran the VALU kernel: 11.6 us per launch at 256 Go roots)
+    static const char *mm64 = getenv("LZ_HEADS_MM64");   // the round-5 rule: multiples of 64 only
+    for (int i = 0; i < nheads && i < MAXH; ++i) mm = mm && (heads[i].K1 & (mm64 ? 63 : 15)) == 0 && heads[i].K1 <= (mm64 ? 1024 : 1344) && heads[i].K1 >= 64 && heads[i].NOUT <= 640;
     if (mm) {
         const size_t lds2 = ((size_t)EPB * k1max + 8 * 64 + EPB * 32 + 32 + 64) * 4;
         if (k1max <= 576) hipLaunchKernelGGL(k_heads_mm<9>, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
-        else hipLaunchKernelGGL(k_heads_mm<16>, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
+        else if (k1max <= 1024) hipLaunchKernelGGL(k_heads_mm<16>, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
+        else hipLaunchKernelGGL(k_heads_mm<21>, dim3((B + EPB - 1) / EPB, nheads), dim3(512), lds2, s, hp, B);
         return;
     }
     if (narrow) hipLaunchKernelGGL((k_heads<32, 256>), dim3((B + EPB - 1) / EPB, nheads), dim3(256), lds, s, hp, B);

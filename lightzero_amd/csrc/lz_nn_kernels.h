@@ -70,7 +70,7 @@ struct lz_chain_layer {
     const float *wf;       // fragment-packed weights [4][9][4][64][4]  (N-tile, tap, 16-channel group, lane, 4 floats)
     const float *uc;       // optional: Winograd F(2x2,3x3) weights [16 points][16 channel quads][64 = cout][4] (k_chain_w, 6x6 grids)
     const void *wb;        // optional (fast mode, lz_model_cfg::precision = 1): bf16 MFMA fragments [2 k halves][4 N-tiles][9 taps][64 lanes][8] (k_chain_b, 6x6 grids)
-    const void *w3;        // optional (parity mode, 6x6 grids): the same fragments split exactly into three bf16 planes, [2][4][9 taps][3 planes][64 lanes][8] (k_chain_s3)
+    const void *w3;        // optional (parity mode): the same fragments split exactly into three bf16 planes, [2][4][9 taps][3 planes][64 lanes][8] (k_chain_s3, k_chain_s3g)
     const float *scale, *shift;  // [64] folded BatchNorm
     int in, out, res;      // LDS buffer indices (0..3); res < 0: no residual
     int relu, act;         // relu: 0 none, 1 ReLU, 2 GELU(tanh) (2 only with lz_chain_args::gelu); act: add the one-hot-action table before BN (dynamics conv)
@@ -122,6 +122,10 @@ struct lz_split_heads {
 bool lz_chain_fusable(const lz_chain_args &a, const lz_tree_step &step);
 bool lz_chain_small_supported(int gw, int gh, int C);
 void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step = nullptr);
+// lz_chain_s3g.hip: the split-bf16 chain for the grids other than the 6x6 ReLU chain (8x8, 9x9, 6x7, 4x4; GELU networks on 6x6 / 8x8).
+// lz_launch_chain_s3g returns false when the launch is not this kernel's (lz_launch_chain then keeps its fp32 chains).
+bool lz_chain_s3g_supported(int gw, int gh, bool gelu, bool fused);
+bool lz_launch_chain_s3g(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step);
 
 // one LSTM step (nn.LSTM, 1 layer) fused with BatchNorm1d + ReLU of the output:
 //   gates = [x | h] . Wcat^T + bias ; c' = sig(f) c + sig(i) tanh(g) ; h' = sig(o) tanh(c')

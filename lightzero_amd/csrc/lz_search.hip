@@ -214,6 +214,8 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
     const int RSUP = c.reward_support_size > 0 ? c.reward_support_size : SUP;
     const int AE = c.action_encoding == 1 ? 1 : A;   // action planes of the dynamics convolution's input (efficientzero_model.py:105-108)
     const bool wchain = C == 64 && ((m->GW == 6 && m->GH == 6) || (m->GW == 8 && m->GH == 8));  // these chains run on Winograd-transformed weights (k_chain_w)
+    // parity mode: the chains' weights as three exact bf16 planes (k_chain_s3 on 6x6, k_chain_s3g on the other grids with an instance)
+    const bool s3chain = C == 64 && c.precision == 0 && ((m->GW == 6 && m->GH == 6) || lz_chain_s3g_supported(m->GW, m->GH, false, false));
     // ---- representation (common.py:266-365, :706-787)
     {
         if (!c.downsample) {
@@ -273,8 +275,8 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
         m->rep_res.clear();
         for (int i = 0; i < NRB; ++i) {
             const std::string p = "representation_network.resblocks." + std::to_string(i);
-            m->rep_res.push_back(b.resconv(p, 1, C, C, false, wchain));
-            m->rep_res.push_back(b.resconv(p, 2, C, C, false, wchain));
+            m->rep_res.push_back(b.resconv(p, 1, C, C, false, wchain, s3chain));
+            m->rep_res.push_back(b.resconv(p, 2, C, C, false, wchain, s3chain));
         }
     }
     // ---- dynamics (efficientzero_model.py:427-569)
@@ -283,7 +285,7 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
         m->dyn = b.conv(d + "conv.weight", d + "norm_common", C, C + AE, C);
         if (wchain) m->dyn.uc = b.wino_chain(d + "conv.weight", C, C + AE, C);
         if (wchain && c.precision == 1) m->dyn.wb = b.bf16_chain(d + "conv.weight", C, C + AE, C);
-        if (wchain && c.precision == 0 && m->GW == 6 && m->GH == 6) b.split3_chain(d + "conv.weight", C, C + AE, C, m->dyn);
+        if (s3chain) b.split3_chain(d + "conv.weight", C, C + AE, C, m->dyn);
         // one-hot action planes: plane a is all ones inside the 6x6 latent, so its contribution to output
         // (pixel p, channel co) is the sum of W[co][C+a][tap] over the taps that stay inside the image.  not_one_hot: ONE plane holding
         // action / action_space_size (fp32, like the reference's expand(...) / A): entry a = the in-bounds taps of W[co][C] times that
@@ -312,8 +314,8 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
         }
         m->dyn_res.clear();
         for (int i = 0; i < NRB; ++i) {
-            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C, false, wchain));
-            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C, false, wchain));
+            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C, false, wchain, s3chain));
+            m->dyn_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C, false, wchain, s3chain));
         }
         m->rew_c = b.conv1x1(d + "conv1x1_reward", d + "norm_reward", HC, C);
         if (c.model_type == 1) {
@@ -372,8 +374,8 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
         const std::string d = "prediction_network.";
         m->pred_res.clear();
         for (int i = 0; i < NRB; ++i) {
-            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C, false, wchain));
-            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C, false, wchain));
+            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 1, C, C, false, wchain, s3chain));
+            m->pred_res.push_back(b.resconv(d + "resblocks." + std::to_string(i), 2, C, C, false, wchain, s3chain));
         }
         m->val_c = b.conv1x1(d + "conv1x1_value", d + "norm_value", HC, C);
         m->pol_c = b.conv1x1(d + "conv1x1_policy", d + "norm_policy", HC, C);

@@ -91,7 +91,7 @@ def ez_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
         return roots.get_distributions(), roots.get_values(), pred_values.reshape(-1), policy_logits
 
 
-def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device="cpu", deterministic=None, ist=None):
+def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device="cpu", deterministic=None, ist=None, record=None):
     """MuZeroMCTSCtree.search  lzero/mcts/tree_search/mcts_ctree.py:267-368 (the reference calls
     recurrent_inference twice per simulation, :338 and :340-345, and discards the first result; it is called once
     here, which leaves the outputs unchanged)."""
@@ -117,13 +117,17 @@ def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device
             latent_state_batch_in_search_path.append(out.latent_state.detach().cpu().numpy())
             value = ist(out.value).detach().cpu().numpy()
             reward = ist(out.reward).detach().cpu().numpy()
+            if record is not None:   # (the reward under the EfficientZero records' key: tests/e2e_attrib.py reads both families)
+                record.append(dict(ix=list(ix_l), action=list(last_actions), search_len=list(results.get_search_len()),
+                                   value_prefix=reward.reshape(-1).copy(), value=value.reshape(-1).copy(),
+                                   policy_logits=out.policy_logits.detach().cpu().numpy().copy()))
             tree.batch_backpropagate(simulation_index + 1, discount_factor, reward.reshape(-1).tolist(),
                                      value.reshape(-1).tolist(), out.policy_logits.detach().cpu().numpy().tolist(),
                                      min_max_stats_lst, results, virtual_to_play_batch)
 
 
 def mz_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, device="cpu", roots_kwargs=None,
-                       deterministic=None):
+                       deterministic=None, record=None):
     """MuZeroPolicy._forward_collect up to get_distributions/get_values  lzero/policy/muzero.py:745-790."""
     ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
@@ -137,7 +141,7 @@ def mz_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
             roots.prepare(cfg["root_noise_weight"], noises, list(out.reward), policy_logits, list(to_play))
         else:
             roots.prepare_no_noise(list(out.reward), policy_logits, list(to_play))
-        mz_search(tree, roots, model, latent_state_roots, to_play, cfg, device, deterministic)
+        mz_search(tree, roots, model, latent_state_roots, to_play, cfg, device, deterministic, record=record)
         return roots.get_distributions(), roots.get_values(), pred_values.reshape(-1), policy_logits
 
 

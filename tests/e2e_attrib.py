@@ -33,37 +33,43 @@ def first_difference(rec_a, rec_b, b):
     return None
 
 
-def _replay_one(tree, cfg, A, S, legal, noise, root_logits, rec, b, upto):
+def _replay_one(tree, cfg, A, S, legal, noise, root_logits, rec, b, upto, kind="ez", to_play=-1):
+    """kind "ez": EfficientZero tree (value prefixes, reset flags); "mz": MuZero tree (rewards under the records' value_prefix key;
+    to_play 1 | 2 in two-player mode)"""
     roots = tree.Roots(1, [list(legal)], action_space_size=A, max_simulations=S)
     roots.set_tiebreak(0)
     if noise is not None:
-        roots.prepare(cfg["root_noise_weight"], [list(noise)], [0.0], [list(map(float, root_logits))], [-1])
+        roots.prepare(cfg["root_noise_weight"], [list(noise)], [0.0], [list(map(float, root_logits))], [int(to_play)])
     else:
-        roots.prepare_no_noise([0.0], [list(map(float, root_logits))], [-1])
+        roots.prepare_no_noise([0.0], [list(map(float, root_logits))], [int(to_play)])
     mm = tree.MinMaxStatsList(1)
     mm.set_delta(cfg["value_delta_max"])
     for s in range(upto):
         res = tree.ResultsWrapper(1)
-        ix, iy, la, vtp = tree.batch_traverse(roots, cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"], mm, res, [-1])
+        ix, iy, la, vtp = tree.batch_traverse(roots, cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"], mm, res, [int(to_play)])
         r = rec[s]
         assert ix[0] == int(r["ix"][b]) and la[0] == int(r["action"][b]), \
             "replaying root %d: simulation %d selected (%d, %d), the record says (%d, %d)" % (b, s, ix[0], la[0], r["ix"][b], r["action"][b])
         sl = res.get_search_len()[0]
         assert sl == int(r["search_len"][b])
-        tree.batch_backpropagate(s + 1, cfg["discount_factor"], [float(r["value_prefix"][b])], [float(r["value"][b])],
-                                 [list(map(float, r["policy_logits"][b]))], mm, res, [int(sl % cfg["lstm_horizon_len"] == 0)], vtp)
+        if kind == "ez":
+            tree.batch_backpropagate(s + 1, cfg["discount_factor"], [float(r["value_prefix"][b])], [float(r["value"][b])],
+                                     [list(map(float, r["policy_logits"][b]))], mm, res, [int(sl % cfg["lstm_horizon_len"] == 0)], vtp)
+        else:
+            tree.batch_backpropagate(s + 1, cfg["discount_factor"], [float(r["value_prefix"][b])], [float(r["value"][b])],
+                                     [list(map(float, r["policy_logits"][b]))], mm, res, vtp)
     return roots
 
 
-def attribute(tree, cfg, A, legal, noise, logits_oracle, logits_device, rec_oracle, rec_device, b):
+def attribute(tree, cfg, A, legal, noise, logits_oracle, logits_device, rec_oracle, rec_device, b, kind="ez", to_play=-1):
     """see the module docstring; returns None when every selection of root b coincides"""
     S = len(rec_oracle)
     s0 = first_difference(rec_oracle, rec_device, b)
     if s0 is None:
         return None
-    ro = _replay_one(tree, cfg, A, S, legal, noise, logits_oracle, rec_oracle, b, s0)
-    rd = _replay_one(tree, cfg, A, S, legal, noise, logits_device, rec_device, b, s0)
-    args = (0, cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"], 1)
+    ro = _replay_one(tree, cfg, A, S, legal, noise, logits_oracle, rec_oracle, b, s0, kind, to_play)
+    rd = _replay_one(tree, cfg, A, S, legal, noise, logits_device, rec_device, b, s0, kind, to_play)
+    args = (0, cfg["pb_c_base"], cfg["pb_c_init"], cfg["discount_factor"], 1 if int(to_play) == -1 else 2)
     po, pd = ro.probe(*args), rd.probe(*args)
     # each probe must end in the selection its own side recorded for simulation s0
     assert po[-1][0] == int(rec_oracle[s0]["ix"][b]) and po[-1][2] == int(rec_oracle[s0]["action"][b]), (po[-1], rec_oracle[s0]["ix"][b])

@@ -66,3 +66,20 @@ def check(test, worst, extra=None, bounds=None):
     b.update(bounds or {})
     bad = {k: (float(v), b[k]) for k, v in worst.items() if not float(v) < b[k]}
     assert not bad, "%s: worst |d|/(1+|x|) above the bound (measured, bound): %s   all: %s" % (test, bad, worst)
+
+
+def check_vs_truth(test, dev_vs_ref, dev_vs_truth, ref_vs_truth, extra=None):
+    """The same gate on a network whose own fp32 evaluation is not exact to 1e-5 (deep boards without an LSTM reset: the latent's magnitude
+    grows with every unrolled step).  ``dev_vs_ref``: device against the torch fp32 reference; ``dev_vs_truth`` / ``ref_vs_truth``: both
+    against a binary64 evaluation of the same network on the same teacher-forced inputs (the exact value up to 1e-16).  Asserted per tensor
+    class: the device is within the class bound of the EXACT value, and within bound + the reference's own distance from the exact value
+    of the reference (triangle inequality: two fp32 evaluations that are each d from the truth may be 2 d apart).  All three are recorded."""
+    ex = dict(extra or {})
+    ex["device_vs_binary64"] = {k: float(v) for k, v in dev_vs_truth.items()}
+    ex["torch_fp32_vs_binary64"] = {k: float(v) for k, v in ref_vs_truth.items()}
+    bounds = {k: BOUNDS[k] + float(ref_vs_truth.get(k, 0.0)) for k in dev_vs_ref}
+    record(test, dev_vs_ref, ex, bounds if any(float(ref_vs_truth.get(k, 0.0)) > 0 for k in dev_vs_ref) else None)
+    bad = {k: (float(v), BOUNDS[k]) for k, v in dev_vs_truth.items() if not float(v) < BOUNDS[k]}
+    assert not bad, "%s: the device is further than the bound from the binary64 evaluation (measured, bound): %s" % (test, bad)
+    bad = {k: (float(v), bounds[k]) for k, v in dev_vs_ref.items() if not float(v) < bounds[k]}
+    assert not bad, "%s: worst |d|/(1+|x|) above bound + the reference's own distance from binary64 (measured, bound): %s" % (test, bad)

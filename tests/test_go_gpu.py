@@ -13,6 +13,8 @@ A = 82
 # (observation_shape, action space): Go 9x9, and Connect4 (zoo/board_games/connect4/config/connect4_muzero_bot_mode_config.py:
 # 31-35: obs 3x6x7, 7 columns, 64 channels) -- a non-square grid with a padded last M-tile (42 = 2 x 16 + 10 pixels)
 GAMES = {"go": ((17, 9, 9), 82), "connect4": ((3, 6, 7), 7)}
+# measured (profiles/r06_parity.json, e2e/mz_go/*, e2e/mz_connect4/*); the gate sits one root below the measurement
+GATE_E2E = {"go": 0.95, "connect4": 0.95}
 
 
 def _setup(B, seed=0, game="go"):
@@ -40,7 +42,7 @@ def test_go_fused_search_vs_oracle(game):
     from oracle import ctree as octree, search as osearch, torch_models as tm
     from lightzero_amd import _lib as L
     from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
-    B, S = 16, CFG["num_simulations"]
+    B, S = 64, CFG["num_simulations"]
     (_, GH, GW), A = GAMES[game]
     ref, model, obs, legal, to_play, noises = _setup(B, game=game)
     lib = L.lib()
@@ -51,8 +53,11 @@ def test_go_fused_search_vs_oracle(game):
         o = ref.initial_inference(obs)
     lat0 = np.zeros((B, 64, GH, GW), np.float32)
     L.check(lib.lz_roots_read_latent(roots._h, 0, lat0.reshape(-1)))
-    assert np.abs(lat0 - o.latent_state.numpy()).max() < 2e-5
-    assert np.abs(out.policy_logits - o.policy_logits.numpy()).max() < 2e-5
+    import parity_record
+    def rel0(a, b):
+        return float((np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))).max())
+    parity_record.check("initial_inference/mz_%s/B%d" % (game, B), dict(latent=rel0(lat0, o.latent_state.numpy().astype(np.float64)),
+                                                                     policy=rel0(out.policy_logits, o.policy_logits.numpy().astype(np.float64))))
     roots.prepare_from_inference(CFG["root_noise_weight"], noises, to_play)
     L.check(lib.lz_roots_enable_trace(roots._h, 1))
     L.check(lib.lz_search(roots._h, S, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], 0, CFG["value_delta_max"]))
@@ -68,27 +73,40 @@ def test_go_fused_search_vs_oracle(game):
 
     def rel(a, b):
         return float((np.abs(a - b) / (1.0 + np.abs(b))).max())
+    # every simulation also in binary64 on the same teacher-forced inputs: no reset bounds these latents (they grow with the depth of the
+    # path), so torch's own fp32 result is several 1e-6 from the exact value of the network here -- parity_record.check_vs_truth
+    import copy
+    ref64 = copy.deepcopy(ref).double()
     worst = dict(lat=0.0, pol=0.0, rew=0.0, val=0.0)
+    d64, t64 = dict(latent=0.0, policy=0.0), dict(latent=0.0, policy=0.0)
     for s in range(S):
         ix, act = trace[s, :, 0], trace[s, :, 1]
         with torch.no_grad():
             q = ref.recurrent_inference(torch.from_numpy(lat[ix, ar]), torch.from_numpy(act).long())
+            q64 = ref64.recurrent_inference(torch.from_numpy(lat[ix, ar]).double(), torch.from_numpy(act).long())
         worst["lat"] = max(worst["lat"], rel(lat[s + 1], q.latent_state.numpy()))
         worst["pol"] = max(worst["pol"], rel(pol[s + 1], q.policy_logits.numpy()))
         worst["rew"] = max(worst["rew"], rel(rew[s + 1], ist(q.reward).reshape(-1).numpy()))
         worst["val"] = max(worst["val"], rel(val[s + 1], ist(q.value).reshape(-1).numpy()))
-    print("go worst |d| / (1 + |ref|):", worst)
+        l64, p64 = q64.latent_state.numpy(), q64.policy_logits.numpy()
+        d64["latent"] = max(d64["latent"], rel(lat[s + 1].astype(np.float64), l64)); d64["policy"] = max(d64["policy"], rel(pol[s + 1].astype(np.float64), p64))
+        t64["latent"] = max(t64["latent"], rel(q.latent_state.numpy().astype(np.float64), l64)); t64["policy"] = max(t64["policy"], rel(q.policy_logits.numpy().astype(np.float64), p64))
+    print("go worst |d| / (1 + |ref|):", worst, "device vs binary64:", d64, "torch fp32 vs binary64:", t64)
     import parity_record
-    parity_record.check("recurrent_teacher_forced/mz_%s/B%d_S%d" % (game, B, S),
-                        dict(latent=worst["lat"], policy=worst["pol"], reward=worst["rew"], value=worst["val"]), extra=dict(batch=B, simulations=S))
-    o_dist, o_val, _, _ = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, to_play, CFG,
-                                                     roots_kwargs=dict(action_space_size=A, max_simulations=S),
-                                                     deterministic=True)
-    d_dist = roots.get_distributions()
-    same = np.array([a == b for a, b in zip(o_dist, d_dist)])
-    print("go identical visit distributions: %d / %d" % (same.sum(), B))
+    name = "recurrent_teacher_forced/mz_%s/B%d_S%d" % (game, B, S)
+    parity_record.check_vs_truth(name, dict(latent=worst["lat"], policy=worst["pol"]), d64, t64, extra=dict(batch=B, simulations=S))
+    parity_record.check(name, dict(reward=worst["rew"], value=worst["val"]))
+    rec_o = []
+    o_dist, o_val, _, o_logits = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, to_play, CFG,
+                                                            roots_kwargs=dict(action_space_size=A, max_simulations=S),
+                                                            deterministic=True, record=rec_o)
+    d_dist, d_val = roots.get_distributions(), np.array(roots.get_values())
     assert [len(d) for d in d_dist] == [len(l) for l in legal]
-    assert same.mean() >= 0.8
+    # two-player searches: recorded + every differing root attributed (tests/e2e_common.py); gated at the evidence, not at 0.8
+    import e2e_common
+    e2e_common.attribute_and_gate("e2e/mz_%s/B%d_S%d" % (game, B, S), "mz", octree.mz_tree, CFG, A, legal, noises, to_play, o_logits,
+                                  np.asarray(out.policy_logits, np.float32), rec_o, e2e_common.device_records(roots, lib, L, B, A, S),
+                                  o_dist, d_dist, o_val, d_val, gate=GATE_E2E[game])
 
 
 def test_go_full_size_properties():

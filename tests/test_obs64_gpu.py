@@ -90,36 +90,45 @@ def test_efficientzero_64x64_networks_match_torch_teacher_forced():
     assert (np.array(roots.get_distributions()).sum(1) == S).all()
 
 
+# measured (profiles/r06_parity.json, e2e/ez_atari64/*, e2e/mz_atari64/*); the gate sits one root below the measurement
+GATE_E2E = 0.96
+
+
 @pytest.mark.parametrize("family", ["ez", "mz"])
 def test_64x64_fused_search_vs_oracle_pipeline(family):
     """the graph-captured search (tree step in the 8x8 chain's prologue) vs reference-style driver + torch model + CPU ctree
     oracle: >= 90 % of the roots with identical visit distributions, root values within 2e-3 on those."""
     from oracle import ctree as octree, search as osearch, torch_models as tm
     from lightzero_amd import _lib as L
-    B, A, S = 48, 6, CFG["num_simulations"]
+    B, A, S = 64, 6, CFG["num_simulations"]
     ref, model = _models(family, A, seed=1)
     obs = torch.rand(B, 4, 64, 64, generator=torch.Generator().manual_seed(6))
     rng = np.random.default_rng(1)
     noises = [rng.dirichlet([0.3] * A).astype(np.float32).tolist() for _ in range(B)]
     legal = [list(range(A))] * B
     kw = dict(roots_kwargs=dict(action_space_size=A, max_simulations=S))
+    rec_o = []
     if family == "ez":
         from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as dtree
-        o_dist, o_val, o_pred, o_logits = osearch.ez_forward_collect(octree.ez_tree, ref, obs, legal, noises, [-1] * B, CFG, **kw)
-        horizon = CFG["lstm_horizon_len"]
+        o_dist, o_val, o_pred, o_logits = osearch.ez_forward_collect(octree.ez_tree, ref, obs, legal, noises, [-1] * B, CFG, record=rec_o, **kw)
+        horizon, otree = CFG["lstm_horizon_len"], octree.ez_tree
     else:
         from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as dtree
-        o_dist, o_val, o_pred, o_logits = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, [-1] * B, CFG, **kw)
-        horizon = 0
+        o_dist, o_val, o_pred, o_logits = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, [-1] * B, CFG, deterministic=True, record=rec_o, **kw)
+        horizon, otree = 0, octree.mz_tree
     roots = dtree.Roots(B, legal, action_space_size=A, max_simulations=S)
     roots.set_tiebreak(0)
     out = model.initial_inference(obs.cuda().contiguous(), roots)
     roots.prepare_from_inference(CFG["root_noise_weight"], noises, [-1] * B)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
     L.check(L.lib().lz_search(roots._h, S, CFG["pb_c_base"], CFG["pb_c_init"], CFG["discount_factor"], horizon, CFG["value_delta_max"]))
     d_dist, d_val = roots.get_distributions(), np.array(roots.get_values())
     same = np.array([a == b for a, b in zip(o_dist, d_dist)])
-    print("identical visit distributions: %d / %d" % (same.sum(), B))
-    assert same.mean() >= 0.9
+    # recorded + every differing root attributed (tests/e2e_common.py); gated at the evidence, not at 0.9
+    import e2e_common
+    e2e_common.attribute_and_gate("e2e/%s_atari64/B%d_S%d" % (family, B, S), family, otree, CFG, A, legal, noises, [-1] * B, o_logits,
+                                  np.asarray(out.policy_logits, np.float32), rec_o, e2e_common.device_records(roots, L.lib(), L, B, A, S),
+                                  o_dist, d_dist, o_val, d_val, gate=GATE_E2E)
     assert_root_values_close(o_val, d_val, same)
     assert np.abs(o_pred - out.value).max() < 3e-4
     import parity_record

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--fast", action="store_true", help="fast mode (bf16 matrix products; 4x96x96 observations): a separate arm, statistical parity only")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches, each on its own engine / HIP stream: the "
                     "latency-bound tree step of one overlaps the MFMA-bound network step of another")
+    ap.add_argument("--chain-ts", action="store_true", help="debug build only (LZ_MI355_LIB=lightzero_amd/liblz_mi355_dbg.so LZ_DEBUG_CHAIN_TS=1 "
+                    "LZ_NO_GRAPH=1): print the cycle stamps of the last chain launch's workgroup 0 (k_chain_s3g)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -92,6 +94,16 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     assert (np.asarray(res[0]).sum(1) == S).all()
+    if a.chain_ts:
+        L.lib().lz_debug_read_chain_ts.argtypes = [ctypes.c_void_p]
+        out = np.zeros(64, np.uint64)
+        L.check(L.lib().lz_debug_read_chain_ts(out.ctypes.data))
+        n = int(out[0]); ts = out[1:1 + n].astype(np.int64)
+        names = ["start", "staged", "sync"] + [x for l in range(14) for x in ("L%d products" % l, "L%d exchange barrier" % l, "L%d epilogue" % l, "L%d barrier" % l)]
+        for i in range(1, n):
+            print("%-22s +%7d cycles   (t=%7d)" % (names[i] if i < n - 1 else "end (1x1 convs)", ts[i] - ts[i - 1], ts[i] - ts[0]), file=sys.stderr)
+        w0, w1 = out[32:40].astype(np.int64) - int(ts[0]), out[40:48].astype(np.int64) - int(ts[0])
+        print("layer 2 products per wave: start", w0.tolist(), "end", w1.tolist(), file=sys.stderr)
     print(json.dumps({"workload": "Go 9x9 MuZero conv (configs[3] share)" if a.go else "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS, "mode": "fast (bf16 products)" if a.fast else "parity (fp32)",
                       "ms_per_step": dt * 1e3, "env_steps_per_s": B / dt, "mcts_sims_per_s": B * S / dt}))
 
