@@ -44,9 +44,12 @@ constexpr size_t s3g_lds_bytes(int hw, int nlayers)
     return (size_t)S3G_NBUF * 3 * (hw + 1) * S3G_PB * 2 + (size_t)ngrp * nq * (nsh - 1) * 256 * 4 + 128 * 4 + (size_t)3 * S3G_C1 * 4 + (size_t)nlayers * 128 * 4;
 }
 
-template <int GW, int GH, int TREE = 0, bool GELU = false>
+// HEADS (EfficientZero, TREE == 1): split heads -- waves 1..7 finish the head MLPs of the previous simulation's leaf from the LSTM launch's
+// first-layer partials while wave 0 stages the tree (heads_in_prologue, lz_nn_dev.h): no head launch between two simulations
+template <int GW, int GH, int TREE = 0, bool GELU = false, bool HEADS = false>
 __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename step_arg<TREE>::type step)
 {
+    static_assert(!HEADS || TREE == 1, "split heads ride on the EfficientZero tree step");
     constexpr int NW = 8, HW = GW * GH, MT = (HW + 15) / 16, NTHR = NW * 64, PB = S3G_PB, NPL = 3;
     constexpr bool PIX = MT > 4;                         // the pixel-split layout
     static_assert(!PIX || (MT % 2) == 0, "pixel halves");
@@ -72,8 +75,10 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
 #ifdef LZ_DEBUG_KNOBS   // timing experiments (tools/bench_conv_configs.py --chain-ts): cycle stamps of workgroup 0 / wave 0
     int nts = 0;
 #define S3G_TS() do { if (a.tstamp && b == 0 && tid == 0) { lz_stamp_store(a.tstamp + 1 + nts, __builtin_readcyclecounter()); ++nts; } } while (0)
+#define S3G_TSF(slot) do { if (a.tstamp && b == 0 && tid == 0) lz_stamp_store(a.tstamp + (slot), __builtin_readcyclecounter()); } while (0)
 #else
 #define S3G_TS() do { } while (0)
+#define S3G_TSF(slot) do { } while (0)
 #endif
     S3G_TS();
     // per-layer parameters live in lanes (lane L: layer L) and are handed out by v_readlane: a scalar load from the argument block at the top
@@ -84,6 +89,37 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
     auto lane64 = [&](unsigned long long v, int L) {
         const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), L);
         return ((unsigned long long)hi << 32) | lo;
+    };
+    // the same for every pointer the prologue's staging loops and the 1x1 units follow (lane j < 3: job j): fetched through a per-thread index
+    // they were a vector load from the argument segment IN FRONT of each data load -- two dependent round trips behind the latent in the
+    // prologue, one per unit in the tail (stamps: 5 k cycles for two 1x1 units)
+    const unsigned long long my_scale = (unsigned long long)myl.scale, my_shift = (unsigned long long)myl.shift;
+    const lz_c1_job &myj = a.c1[min(lane, 2)];
+    const unsigned long long my_c1w = (unsigned long long)myj.w, my_c1bias = (unsigned long long)myj.bias, my_c1scale = (unsigned long long)myj.scale,
+                             my_c1shift = (unsigned long long)myj.shift, my_c1out = (unsigned long long)myj.out;
+    const int my_c1stride = myj.out_stride, my_c1off = myj.out_off, my_c1misc = (myj.act & 3) | (a.c1_in[min(lane, 2)] << 2);
+    // folded-BN tables -> LDS: 128 floats per layer; a wave's 64 threads stay inside one layer's scale or shift half
+    // (request and store are separate steps: without a tree step the requests go out BEFORE the wait for the selection, the stores come behind
+    // the latent's -- in one loop each table was a round trip of its own behind the latent, 1.1 k cycles each in the stamps)
+    constexpr int NSS = (LZ_CHAIN_MAX_LAYERS * 128 + NTHR - 65) / (NTHR - 64);
+    auto request_ss = [&](int first, int nthr, float (&v)[NSS]) {
+#pragma unroll
+        for (int k = 0; k < NSS; ++k) {
+            const int i = tid - first + k * nthr;
+            v[k] = 0.0f;
+            if (i < a.nlayers * 128) {
+                const int L = __builtin_amdgcn_readfirstlane(i >> 7), r = i & 127;
+                const float *sp = reinterpret_cast<const float *>(lane64(__builtin_amdgcn_readfirstlane(r >> 6) ? my_shift : my_scale, L));
+                v[k] = sp[r & 63];
+            }
+        }
+    };
+    auto store_ss = [&](int first, int nthr, const float (&v)[NSS]) {
+#pragma unroll
+        for (int k = 0; k < NSS; ++k) {
+            const int i = tid - first + k * nthr;
+            if (i < a.nlayers * 128) sSS[i] = v[k];
+        }
     };
     // weights: [layer][kh][channel tile][tap][plane][64 lanes][8 bf16] (Builder::split3_chain).  A wave's fragments of a layer stream through a
     // ring of RT taps; a slot is refilled right behind the products that read it -- with this layer's tap RT further on, or with the NEXT
@@ -112,39 +148,68 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
         for (int ln = r + lane * nr; ln < LINES; ln += 64 * nr) (void)*reinterpret_cast<const volatile int *>(w + (size_t)ln * 128);
     };
     // the 1x1 jobs' parameters -> LDS (requested in the tail they were an exposed L2 round trip per unit: 6.9 k of 71 k cycles on the 8x8 grid)
-    auto stage_c1 = [&](int first, int nthr) {
-        for (int i = tid - first; i < a.nc1 * (16 * 16 + 12); i += nthr) {        // float4 pieces: 256 of the weights + 12 of bias | scale | shift
-            const int j = i / 268, r = i - j * 268;
-            const lz_c1_job &jb = a.c1[j];
-            if (r < 256) *reinterpret_cast<float4 *>(sC1 + j * S3G_C1 + (r >> 4) * 68 + (r & 15) * 4) = *reinterpret_cast<const float4 *>(jb.w + r * 4);
-            else {
-                const int q = r - 256, which = q >> 2;
-                const float *src = which == 0 ? jb.bias : which == 1 ? jb.scale : jb.shift;
-                *reinterpret_cast<float4 *>(sC1 + j * S3G_C1 + 16 * 68 + q * 4) = *reinterpret_cast<const float4 *>(src + (q & 3) * 4);
-            }
+    auto request_c1 = [&](int first, float4 (&v)[3]) {          // (threads first .. first + 267 of every job's 268 float4 pieces: 256 of the weights + 12 of bias | scale | shift)
+        const int r = tid - first;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float *pw = reinterpret_cast<const float *>(lane64(my_c1w, j)), *pb = reinterpret_cast<const float *>(lane64(my_c1bias, j)),
+                        *ps = reinterpret_cast<const float *>(lane64(my_c1scale, j)), *pt = reinterpret_cast<const float *>(lane64(my_c1shift, j));
+            const int q = max(r - 256, 0), which = q >> 2;
+            const float *src = r < 256 ? pw + max(r, 0) * 4 : (which == 0 ? pb : which == 1 ? ps : pt) + (q & 3) * 4;
+            v[j] = (j < a.nc1 && r >= 0 && r < 268) ? *reinterpret_cast<const float4 *>(src) : vzero4();
         }
     };
+    auto store_c1 = [&](int first, const float4 (&v)[3]) {
+        const int r = tid - first;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < a.nc1 && r >= 0 && r < 268)
+                *reinterpret_cast<float4 *>(sC1 + j * S3G_C1 + (r < 256 ? (r >> 4) * 68 + (r & 15) * 4 : 16 * 68 + (r - 256) * 4)) = v[j];
+    };
     int g_slot = 0, g_action = 0;
+    float ssv[NSS];
+    float4 c1v[3];
     if constexpr (TREE == 0) {
-        // requests in the order of their use: the selection (the latent gather waits for it), the first weight fragments, the L2 warm-up
+        // requests in the order of their use: the selection (the latent gather waits for it), the first weight fragments, the tables, the L2 warm-up
         if (a.gather_ix) g_slot = a.gather_ix[b];
         if (a.act_table) g_action = a.action[b];
         load_w0();
+        request_ss(0, NTHR, ssv);
+        request_c1(0, c1v);
         for (int L = wv; L < a.nlayers; L += NW) prefetch_weights(L);
     }
     if constexpr (TREE != 0) {
         int32_t *s_sel = reinterpret_cast<int32_t *>(sMisc + 120);
+        // split heads: the partial-sum exchange is free until the first layer -- the leaf hand-over, the counters and the head waves' scratch
+        float *s_leaf = sP;
+        int32_t *s_ctr = reinterpret_cast<int32_t *>(sP + 80);
+        float *s_red = sP + 96;
+        bool heads_on = false;
+        if constexpr (HEADS) {
+            heads_on = step.sh.on != 0;
+            if (heads_on) {
+                if (tid < 8) s_ctr[tid] = 0;
+                __syncthreads();
+            }
+        }
         if (wv == 0) {
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(3);   // one wave of strictly dependent instructions: first wherever it competes with the head waves
             dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
-                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts);
+                                      step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
+                                      heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
+            if constexpr (HEADS) __builtin_amdgcn_s_setprio(0);
         } else {
+            if constexpr (HEADS) {
+                // head roles: waves 1-3 value, 5-7 value prefix, wave 4 -- which shares its SIMD with the tree wave -- the light policy head
+                const int hw = wv < 4 ? wv - 1 : (wv == 4 ? 6 : wv - 2);
+                if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
+            }
             load_w0();
             for (int L = wv - 1; L < a.nlayers; L += NW - 1) prefetch_weights(L);
-            stage_c1(64, NTHR - 64);
-            for (int i = tid - 64; i < a.nlayers * 128; i += NTHR - 64) {
-                const int L = i >> 7, r = i & 127;
-                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
-            }
+            request_ss(64, NTHR - 64, ssv);
+            request_c1(64, c1v);
+            store_ss(64, NTHR - 64, ssv);
+            store_c1(64, c1v);
         }
         __syncthreads();
         g_slot = s_sel[0];
@@ -174,11 +239,13 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
         const float *src = a.in + (size_t)b * HW * 64 + (size_t)g_slot * a.slot_stride;
         constexpr int NU = (HW * 16 + NTHR - 1) / NTHR;
         float4 v[NU];
+        S3G_TSF(50);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int idx = min(u * NTHR + tid, HW * 16 - 1);
             v[u] = *reinterpret_cast<const float4 *>(src + (size_t)idx * 4);
         }
+        S3G_TSF(51);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int idx = u * NTHR + tid;
@@ -190,14 +257,15 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
                 *reinterpret_cast<bf16x4 *>(dst + 2 * BB + (idx >> 4) * PB + (idx & 15) * 4) = l3;
             }
         }
+        S3G_TSF(52);
         // the all-zero halo pixel of every plane of every buffer
         if (tid < S3G_NBUF * NPL * (PB / 8)) *reinterpret_cast<float4 *>(sB + (tid / (PB / 8)) * BB + HW * PB + (tid % (PB / 8)) * 8) = vzero4();
         if (TREE == 0) {   // behind the latent: nothing in front of the first layer waits for these
-            for (int i = tid; i < a.nlayers * 128; i += NTHR) {
-                const int L = i >> 7, r = i & 127;
-                sSS[i] = (r < 64) ? a.layer[L].scale[r] : a.layer[L].shift[r - 64];
-            }
-            stage_c1(0, NTHR);
+            S3G_TSF(53);
+            store_ss(0, NTHR, ssv);
+            S3G_TSF(54);
+            store_c1(0, c1v);
+            S3G_TSF(55);
         }
     }
     // ---- per-lane geometry of the products: B columns of this lane = pixels 16 (mt0 + mtl) + (lane & 15); tap (dy, dx) reads pixel
@@ -388,14 +456,14 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
     // (the unit index as a SCALAR: the job descriptors then come by s_load instead of a vector load from the argument segment per field)
     for (int u = __builtin_amdgcn_readfirstlane(wv); u < a.nc1 * MT; u += NW) {
         const int job = u / MT, i = u - job * MT;
-        const lz_c1_job &jb = a.c1[job];
+        const int misc = __builtin_amdgcn_readlane(my_c1misc, job);
         const float *pc = sC1 + job * S3G_C1;
         float4 c1w[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) c1w[g] = *reinterpret_cast<const float4 *>(pc + (lane & 15) * 68 + g * 16 + kq4);
         const float4 c1b = *reinterpret_cast<const float4 *>(pc + 16 * 68 + kq4), c1s = *reinterpret_cast<const float4 *>(pc + 16 * 68 + 16 + kq4),
                      c1t = *reinterpret_cast<const float4 *>(pc + 16 * 68 + 32 + kq4);
-        const __bf16 *sIn = sB + a.c1_in[job] * BB3;
+        const __bf16 *sIn = sB + (misc >> 2) * BB3;
         const int row = i * 16 + (lane & 15);
         const int off = min(row, HW) * PB + kq4;
         bf16x4 xh[4], xm[4], xl[4];
@@ -405,14 +473,21 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
             xm[g] = *reinterpret_cast<const bf16x4 *>(sIn + BB + off + g * 16);
             xl[g] = *reinterpret_cast<const bf16x4 *>(sIn + 2 * BB + off + g * 16);
         }
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // two accumulators (k = 0..31 | 32..63, added at the end): sixteen dependent MFMAs were the longest chain of this phase
+        if (u < NW) S3G_TSF(56);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xf = ((float)xh[g][j] + (float)xm[g][j]) + (float)xl[g][j];
+                const float xf2 = ((float)xh[g + 2][j] + (float)xm[g + 2][j]) + (float)xl[g + 2][j];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(c1w[g], j), xf, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vget(c1w[g + 2], j), xf2, acc2, 0, 0, 0);
             }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += acc2[c];
+        if (u < NW) S3G_TSF(57);
         if (row < HW) {
             f32x4 v;
             v[0] = (acc[0] + c1b.x) * c1s.x + c1t.x;
@@ -421,17 +496,20 @@ __global__ __launch_bounds__(512) void k_chain_s3g(lz_chain_args a, typename ste
             v[3] = (acc[3] + c1b.w) * c1s.w + c1t.w;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if constexpr (GELU) v[c] = jb.act == 2 ? gelu_tanh_(v[c]) : fmaxf(v[c], 0.0f);
+                if constexpr (GELU) v[c] = (misc & 3) == 2 ? gelu_tanh_(v[c]) : fmaxf(v[c], 0.0f);
                 else v[c] = fmaxf(v[c], 0.0f);
             }
-            store_wt(jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + kq4, v);
+            store_wt(reinterpret_cast<float *>(lane64(my_c1out, job)) + ((size_t)b * HW + row) * __builtin_amdgcn_readlane(my_c1stride, job) +
+                         __builtin_amdgcn_readlane(my_c1off, job) + kq4, v);
         }
+        if (u < NW) S3G_TSF(58);
     }
     S3G_TS();
 #ifdef LZ_DEBUG_KNOBS
     if (a.tstamp && b == 0 && tid == 0) lz_stamp_store(a.tstamp, (unsigned long long)nts);
 #endif
 #undef S3G_TS
+#undef S3G_TSF
     lz_stamp_end(a.stamp);
 }
 
@@ -491,6 +569,7 @@ void s3g_launch(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step)
         (void)hipFuncSetAttribute((const void *)k_chain_s3g<GW, GH, 0, GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if constexpr (!GELU && GW == 8) {
             (void)hipFuncSetAttribute((const void *)k_chain_s3g<GW, GH, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            (void)hipFuncSetAttribute((const void *)k_chain_s3g<GW, GH, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
             (void)hipFuncSetAttribute((const void *)k_chain_s3g<GW, GH, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         }
         attr = true;
@@ -498,7 +577,8 @@ void s3g_launch(const lz_chain_args &a, hipStream_t s, const lz_tree_step *step)
     const dim3 g(a.B), blk(512);
     if constexpr (!GELU && GW == 8) {
         if (step) {
-            if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_s3g<GW, GH, 1, false>), g, blk, lds, s, a, *step);
+            if (step->t.variant == LZ_TREE_EFFICIENTZERO && step->sh.on) hipLaunchKernelGGL((k_chain_s3g<GW, GH, 1, false, true>), g, blk, lds, s, a, *step);
+            else if (step->t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_chain_s3g<GW, GH, 1, false>), g, blk, lds, s, a, *step);
             else hipLaunchKernelGGL((k_chain_s3g<GW, GH, 2, false>), g, blk, lds, s, a, *step);
             return;
         }

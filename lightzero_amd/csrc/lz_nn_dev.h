@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "lz_hinv.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
@@ -82,6 +84,140 @@ __device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m
         const float r2 = r1 - (float)mq;
         h[q] = hq; m[q] = mq; l[q] = (__bf16)r2;
     }
+}
+
+// ---- split heads: the head MLPs of the PREVIOUS simulation's leaf, finished by waves 1..7 of the root's workgroup while wave 0 stages
+// the root's tree (lz_split_heads).  hw = wave - 1: 0..2 value head, 3..5 value-prefix head (601 outputs over 3 waves x 64 lanes x <= 4),
+// 6 policy head.  Every wave first sums the first-layer partial blocks of the LSTM launch for its head (32 unit tiles, fixed order: two
+// halves of 16 sequentially, then half 0 + half 1), applies bias / BatchNorm / ReLU -> hidden unit j in lanes j and j + 32 -- and
+// has requested its second-layer weights right behind them.  The three waves of a categorical head meet ONCE in LDS (each sums
+// exp(logit - its own maximum); the first of them waits on a counter for the other two and rescales to the common maximum; wave 0 of
+// the workgroup is not part of this); the scalars go to the pool slot and to s_leaf, then s_ctr[2] counts the finished heads (3 = the
+// leaf is ready).  s_ctr[0..3] must be zero when this starts.  Measured (tools/tree_timing.py, root 0, simulation 49): the 155 KB of
+// second-layer weights of a root pass the CU's vector-memory path (64 B/clk) in ~4.4 k cycles, the scalars are out at ~8-10 k -- the
+// tree wave has staged its tree by ~7 k, so ~2-3 k cycles of this remain exposed in the launch.
+__device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int b, int A, int hw, int lane, float *s_leaf, int32_t *s_ctr,
+                                                  float *s_red, unsigned long long *ts = nullptr)
+{
+    const bool stamp = ts && b == 0 && hw == 0 && lane == 0;   // timing experiments (debug build): stamps of head wave 1 of root 0
+#define LZ_HPS(i) do { if (stamp) lz_stamp_store(ts + 8 + (i), __builtin_readcyclecounter()); } while (0)
+    LZ_HPS(0);
+    const int head = hw < 3 ? 0 : (hw < 6 ? 2 : 1);   // 0 value, 1 policy, 2 value prefix (the order of lz_split_heads' arrays)
+    const int gw = hw < 6 ? hw % 3 : 0, grp = hw < 3 ? 0 : 1;
+    const int NOUT = head == 1 ? A : sh.nout;
+    // ---- requests in the order of use (a wave's loads return in order): the first-layer partials of this root and head -- [32 unit
+    // tiles][32 hidden] contiguous; lane (ug = lane >> 3, jq = lane & 7) takes the hidden quad 4 jq .. + 3 of unit tiles ug, ug + 8,
+    // ug + 16, ug + 24 --, the first layer's bias / BatchNorm, then the second-layer weights of this lane's outputs
+    const int NU = sh.n_unit_tiles, ug = lane >> 3, jq = lane & 7;
+    const float *pp = sh.part + ((size_t)b * 3 + head) * (NU * 32) + ug * 32 + jq * 4;
+    f32x4 pv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pv[q] = *reinterpret_cast<const f32x4 *>(pp + (size_t)q * 8 * 32);
+    const f32x4 b1v = *reinterpret_cast<const f32x4 *>(sh.b1[head] + jq * 4), s1v = *reinterpret_cast<const f32x4 *>(sh.s1[head] + jq * 4),
+                t1v = *reinterpret_cast<const f32x4 *>(sh.t1[head] + jq * 4);
+    constexpr int NT = 4;
+    f32x4 w2[NT][8];
+    float lg[NT];
+    const int nstep = head == 1 ? 64 : 192, n0 = gw * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {   // unconditional, clamped: predicating the unused columns away (25 % of the requests) split the burst
+        const int n = min(n0 + nstep * t, NOUT - 1);   // into dependent pieces and was measured slower (heads out at 11.5 k instead of 8.2 k cycles)
+        lg[t] = sh.b2[head][n];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) w2[t][k4] = *reinterpret_cast<const f32x4 *>(sh.w2t[head] + ((size_t)k4 * NOUT + n) * 4);
+    }
+    LZ_HPS(1);
+    // ---- hidden units: the four partials of a lane in order, then the eight ug groups over lanes ^ 8, ^ 16, ^ 32 (a fixed order,
+    // the same in every lane of a column); bias, BatchNorm, ReLU; one copy per wave in LDS for the broadcast reads below
+    f32x4 hid4;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        float v = ((pv[0][c4] + pv[1][c4]) + pv[2][c4]) + pv[3][c4];
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8 = lane ^ 8
+        v = xor32_sum(xor16_sum(v));
+        hid4[c4] = fmaxf((v + b1v[c4]) * s1v[c4] + t1v[c4], 0.0f);
+    }
+    float *s_hid = s_red + 64 + hw * 32;
+    if (lane < 8) *reinterpret_cast<f32x4 *>(s_hid + lane * 4) = hid4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_HPS(2);
+    // ---- second layer: the hidden units come back as broadcast reads (same address in every lane)
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        const f32x4 h4 = *reinterpret_cast<const f32x4 *>(s_hid + k4 * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            lg[t] += (w2[t][k4][0] * h4[0] + w2[t][k4][1] * h4[1]) + (w2[t][k4][2] * h4[2] + w2[t][k4][3] * h4[3]);
+    }
+    LZ_HPS(3);
+    if (sh.dbg_logits && head != 1) {   // parity tests (tracing): the support-wide logits of this simulation's value / value-prefix head
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + nstep * t;
+            if (n < NOUT) sh.dbg_logits[((size_t)grp * sh.dbg_B + b) * NOUT + n] = lg[t];
+        }
+    }
+    if (head == 1) {   // policy logits
+        if (lane < A) {
+            sh.out_logits[(size_t)b * A + lane] = lg[0];
+            s_leaf[2 + lane] = lg[0];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {   // s_ctr[3]: the policy logits alone are out (the tree wave starts the new node's priors on them), s_ctr[2]: one more head done
+            __hip_atomic_fetch_add(s_ctr + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(s_ctr + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // ---- softmax . support -> inverse scalar transform.  Each of the head's three waves sums exp(logit - ITS OWN maximum); the three
+    // (maximum, sum, weighted sum) triples meet once in LDS and are rescaled to the common maximum: one rendezvous instead of two
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) m = (n0 + nstep * t < NOUT) ? fmaxf(m, lg[t]) : m;
+    m = wave_max(m);
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + nstep * t;
+        if (n < NOUT) {
+            const float ex = expf(lg[t] - m);
+            s0 += ex;
+            s1 += ex * (sh.support_min + (float)n);
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    float *red = s_red + grp * 16;
+    if (lane == 0) { red[4 * gw] = m; red[4 * gw + 1] = s0; red[4 * gw + 2] = s1; }
+    LZ_HPS(4);
+    if (gw != 0) {   // waves 1 and 2 of the head only contribute
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(s_ctr + grp, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    while (__hip_atomic_load(s_ctr + grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    LZ_HPS(5);
+    {
+        const float m1 = red[4], m2 = red[8];
+        const float M = fmaxf(fmaxf(m, m1), m2);
+        const float e0 = expf(m - M), e1 = expf(m1 - M), e2 = expf(m2 - M);
+        const float t0 = (s0 * e0 + red[5] * e1) + red[9] * e2, t1 = (s1 * e0 + red[6] * e1) + red[10] * e2;
+        // softmax . support, then InverseScalarTransform.__call__ (scaling_transform.py:82-92) in torch's fp32 op order (lz_hinv.h)
+        const float value = t1 / t0;
+        const float out = lz_inverse_scalar_transform(value);
+        if (sh.dbg_expect && lane == 0) sh.dbg_expect[(size_t)grp * sh.dbg_B + b] = value;   // parity tests (tracing): the pre-transform expectation
+        if (lane == 0) {
+            (head == 0 ? sh.out_value : sh.out_vp)[b] = out;
+            s_leaf[head == 0 ? 1 : 0] = out;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(s_ctr + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    LZ_HPS(6);
+#undef LZ_HPS
 }
 
 }  // namespace

@@ -390,13 +390,15 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
     }
     // ---- split heads (see enqueue_search): first layers of the three head MLPs as per-unit-tile MFMA fragments for the LSTM launch
     m->sh_w1c = m->sh_w1r = nullptr;
-    if (c.model_type == 0 && wchain && m->GW == 6 && HC == 16 && H == 512 && m->fc_value.h_w1.size() == (size_t)32 * HC * HW &&
+    // (8x8 latent, round 6: parity mode only -- k_chain_s3g's split-head instance; the fast-mode and fp32 8x8 chains keep the head launch)
+    if (c.model_type == 0 && wchain && (m->GW == 6 || (m->GW == 8 && c.precision == 0)) && HC == 16 && H == 512 && m->fc_value.h_w1.size() == (size_t)32 * HC * HW &&
         m->fc_policy.h_w1.size() == (size_t)32 * HC * HW && m->fc_reward.h_w1.size() == (size_t)32 * H) {
-        const int NU = H / 16, K1 = HC * HW, KS = 2 * K1 / NU;   // 32 unit tiles; 576; 36 combined input columns per tile
-        if (KS == 36) {
+        const int NU = H / 16, K1 = HC * HW, KS = 2 * K1 / NU;   // 32 unit tiles; 576 | 1024; 36 | 64 combined input columns per tile
+        if (KS == 36 || KS == 64) {
             // per unit tile u and wave (= 16-column tile nt of the 64 | 32 hidden columns): lane (n = lane & 15, kq = lane >> 4) holds the
-            // B operands of its 9 | 4 k-steps contiguously (12 | 4 floats: three | one float4 load)
-            std::vector<float> wc((size_t)NU * 4 * 64 * 12, 0.0f), wr((size_t)NU * 2 * 64 * 4);
+            // B operands of its 9 (16 on the 8x8 latent) | 4 k-steps contiguously (12 (16) | 4 floats: three (four) | one float4 load)
+            const int SB = KS == 36 ? 12 : 16;
+            std::vector<float> wc((size_t)NU * 4 * 64 * SB, 0.0f), wr((size_t)NU * 2 * 64 * 4);
             for (int u = 0; u < NU; ++u) {
                 for (int nt = 0; nt < 4; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
@@ -405,7 +407,7 @@ static void finalize_conv_layouts(lz_model *m, Builder &b)
                             float w = 0.0f;
                             if (col < 32 && c32 < HC) w = m->fc_value.h_w1[(size_t)col * K1 + pix * HC + c32];
                             if (col >= 32 && c32 >= HC) w = m->fc_policy.h_w1[(size_t)(col - 32) * K1 + pix * HC + (c32 - HC)];
-                            wc[(((size_t)u * 4 + nt) * 64 + lane) * 12 + ks] = w;
+                            wc[(((size_t)u * 4 + nt) * 64 + lane) * SB + ks] = w;
                         }
                 for (int nt = 0; nt < 2; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
@@ -1985,7 +1987,8 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     lz_model *mdl = r->eng->model;
     const bool split = fuse && mdl->cfg.model_type == 0 && mdl->sh_w1c && r->sh_part && t.A <= 64 && mdl->cfg.support_size <= 768 &&
                        mdl->cfg.lstm_hidden_size == 512 && t.variant == LZ_TREE_EFFICIENTZERO && !getenv("LZ_HEADS_LAUNCH") && !getenv("LZ_CHAIN_DIRECT") &&
-                       !getenv("LZ_CHAIN_W4") && !getenv("LZ_LSTM_NOSPLIT") && !getenv("LZ_LSTM_ROWS32") && !getenv("LZ_LSTM_CHUNKED")
+                       !getenv("LZ_CHAIN_W4") && !getenv("LZ_LSTM_NOSPLIT") && !getenv("LZ_LSTM_ROWS32") && !getenv("LZ_LSTM_CHUNKED") &&
+                       !(mdl->GW == 8 && getenv("LZ_CHAIN_NO_SPLIT"))   // (8x8: only k_chain_s3g has the split-head instance)
 #ifdef LZ_DEBUG_KNOBS
                        // recurrent() mutates the chain arguments under these switches AFTER the defer decision below was taken from the
                        // unmodified ones (a stamped / truncated chain is not fusable): a simulation could defer its heads to a launch

@@ -103,6 +103,8 @@ def main():
         for i in range(1, n):
             print("%-22s +%7d cycles   (t=%7d)" % (names[i] if i < n - 1 else "end (1x1 convs)", ts[i] - ts[i - 1], ts[i] - ts[0]), file=sys.stderr)
         w0, w1 = out[32:40].astype(np.int64) - int(ts[0]), out[40:48].astype(np.int64) - int(ts[0])
+        ex = out[50:59].astype(np.int64) - int(ts[0])
+        print("prologue: selection known %d, latent requested %d, latent in LDS %d, halo/zero %d, BN tables %d, 1x1 params %d | 1x1 unit 0: operands %d, MFMAs done %d, stored %d (end of layers %d)" % (tuple(ex.tolist()) + (int(ts[n - 2] - ts[0]),)), file=sys.stderr)
         print("layer 2 products per wave: start", w0.tolist(), "end", w1.tolist(), file=sys.stderr)
     print(json.dumps({"workload": "Go 9x9 MuZero conv (configs[3] share)" if a.go else "Atari %s conv, obs %dx%d" % ("MuZero" if a.family == "mz" else "EfficientZero", a.obs, a.obs), "envs": B, "num_simulations": S, "actions": A, "sub_batches": NS, "mode": "fast (bf16 products)" if a.fast else "parity (fp32)",
                       "ms_per_step": dt * 1e3, "env_steps_per_s": B / dt, "mcts_sims_per_s": B * S / dt}))
