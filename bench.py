@@ -40,7 +40,7 @@ PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense peak (the --
 PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MATRIX_TFLOPS / 6.0   # parity mode since round 5: fp32 operands as three bf16 planes, six plane products per k-step (k_chain_s3)
 CFG = dict(num_simulations=SIMS, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01,
            lstm_horizon_len=5, root_noise_weight=0.25, root_dirichlet_alpha=0.3)
-MANIFEST = "r05_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
+MANIFEST = "r06_manifest.json"     # profiles/: rocprofv3 numbers of the roofline kernel + the digest of the sources they were measured on
 
 
 def _profile_manifest():
@@ -81,6 +81,77 @@ def _baseline_pipeline(weights, device):
         osearch.ez_forward_collect(tree, ref_model, obs, [list(range(ACTIONS))] * n, noises[:n], [-1] * n, CFG, **kw)
         return time.perf_counter() - t0
     return run, kind_tree
+
+
+class ClockSampler(object):
+    """The GPU's shader clock while the bench runs (the headline moved 7 % between leases of identical sources; this puts the
+    clock the box sustained next to `value`).  Reads the amdgpu hwmon node freq1_input (sclk, Hz) of the card whose PCI address is the HIP
+    device's, every 4 ms on a thread; windows are cut out afterwards by wall-clock time.  A box without the node reports why."""
+
+    def __init__(self, device_index=0):
+        import glob
+        import threading
+        self.samples, self.path, self.note = [], None, None
+        self._stop = threading.Event()
+        self._thr = None
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(device_index)
+            bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        except Exception as e:
+            bus = None
+            self.note = "no PCI address for the HIP device: %r" % (e,)
+        cands = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+            dev = os.path.realpath(f.split("/hwmon/")[0])
+            cands.append((f, dev))
+        mine = [f for f, dev in cands if bus and bus in dev]
+        if mine:
+            self.path = mine[0]
+        elif cands:
+            self.path = [f for f, _ in cands]          # unknown mapping: the busiest card is ours (max over the cards per sample)
+            self.note = (self.note or "") + " PCI address %s not found among %d cards: max over all cards" % (bus, len(cands))
+        else:
+            self.note = "no /sys/class/drm/card*/device/hwmon/*/freq1_input on this box"
+
+    def _read(self):
+        def one(f):
+            try:
+                return int(open(f).read().strip()) / 1e6
+            except Exception:
+                return 0.0
+        return one(self.path) if isinstance(self.path, str) else max(one(f) for f in self.path)
+
+    def start(self):
+        import threading
+        if not self.path:
+            return self
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append((time.perf_counter(), self._read()))
+                self._stop.wait(0.004)
+        self._thr = threading.Thread(target=run, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thr:
+            self._thr.join(timeout=1.0)
+
+    def window(self, t_a, t_b):
+        v = [m for t, m in self.samples if t_a <= t <= t_b and m > 0]
+        if not v:
+            return None
+        return dict(sclk_mhz_mean=float(np.mean(v)), sclk_mhz_min=float(min(v)), sclk_mhz_max=float(max(v)), samples=len(v))
+
+    def report(self, windows):
+        out = {"source": ("amdgpu hwmon freq1_input (sclk) of %s, sampled every 4 ms" % (self.path if isinstance(self.path, str) else "%d cards (max)" % len(self.path)))
+               if self.path else None, "note": self.note}
+        for name, (t_a, t_b) in windows.items():
+            out[name] = self.window(t_a, t_b) if self.path else None
+        return out
 
 
 def cpu_allowance():
@@ -674,11 +745,14 @@ def main():
     sync_all()
     if dist_on:
         dist.barrier()
+    clocks = ClockSampler(device_index).start() if rank == 0 else None
+    clock_windows = {}
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
     sync_all()
     my_elapsed = time.perf_counter() - t0
+    clock_windows["timed_region"] = (t0, t0 + my_elapsed)
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -731,6 +805,9 @@ def main():
             step(total + j)
         sync_all()
         sustained = dict(env_steps_per_s=sum(counts) * n_s / (time.perf_counter() - t_s), steps=n_s, seconds=time.perf_counter() - t_s)
+        clock_windows["sustained"] = (t_s, time.perf_counter())
+    if clocks:
+        clocks.stop()
     # (b) the other tie-break arm (the parity tests pin "first": deterministic first arg-max; collection uses the reference's
     #     stochastic rule): same K steps after W warm-ups, the search graph re-captured for the other rule
     other = "first" if args.tiebreak == "random" else "random"
@@ -810,12 +887,13 @@ def main():
         achieved_prof = (EPS * FLOP_CHAIN) / (prof_us * 1e-6) / 1e12 if prof_us else None
         knobs = sorted(k for k in os.environ if k.startswith("LZ_"))
         out = {
-            "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4)",
+            "metric": "self-play env-steps/sec @50 sims, 256 envs per GPU (EfficientZero Atari 96x96x4; fp32 parity mode: network products as six exact bf16-plane products per k-step)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Atari Pong EfficientZero, obs 4x96x96, 50 sims, "
-                                   "256 envs per GPU, A=6, support 601, LSTM 512; synthetic obs, seed-0 random-init weights",
+                                   "256 envs per GPU, A=6, support 601, LSTM 512; synthetic obs, seed-0 random-init weights; dtype f32 = binary32 operands and "
+                                   "accumulators, the 3x3 convolutions' products evaluated as six exact bf16 x bf16 plane products per k-step (config.arithmetic)",
                        "envs_per_gpu": ENVS, "envs_per_rank": counts, "total_envs": sum(counts), "num_simulations": SIMS,
                        "weight_refresh_every": args.refresh_every, "gather_check": gather_check, "mcts_sims_per_s": value * SIMS,
                        "tiebreak": args.tiebreak, "tiebreak_%s_env_steps_per_s" % other: other_rate,
@@ -832,6 +910,7 @@ def main():
                        "arithmetic": "tree: binary32 (bit-exact with the reference's ctree); network: binary32 operands as three exact bf16 planes, six "
                                      "plane products per k-step accumulated in binary32 on the bf16 matrix pipe (tower, recurrent chain), binary32 "
                                      "matrix instructions elsewhere (LSTM, heads) -- within 1e-5 (1 + |x|) of the reference modules",
+                       "gpu_clock": clocks.report(clock_windows) if clocks else None,
                        "debug_knobs": knobs},
             "roofline": {"bound": "mfma", "kernel": "k_chain_s3 (per root: [tree step of the root: expand + backup + next selection, one wave; the previous leaf's head MLPs on the other seven: prologue] + dynamics conv + 2 residual blocks + 1x1 head convs on the 6x6x64 latent, LDS-resident; 3x3 convolutions in the direct form as SPLIT-bf16 products on v_mfma_f32_16x16x32_bf16: every fp32 operand is the exact sum of three bf16 planes, six of the nine plane products are accumulated in fp32 -- fp32-level accuracy at 6 bf16 matrix FLOPs per algorithmic FLOP; 1 launch/simulation; achieved = the ALGORITHMIC convolution FLOPs of SURVEY 8d over the whole launch; peak = the bf16 dense peak / 6, the rate at which this form can deliver fp32-accurate FLOPs)",
                          "achieved": achieved, "peak": PEAK_SPLIT_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -2917,13 +2917,18 @@ __global__ __launch_bounds__(256) void k_lstm(lz_lstm_args a)
 // quads; K + 4 (1 mod 4 quads) was a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT: 43 % of the LDS cycles of this kernel)
 constexpr int LSTM_PAD = 8;
 // SHK (split heads): columns of the combined 1x1-conv output rows per unit tile = 2 x 16 x HW / 32: 36 (6x6 latent) | 64 (8x8 latent, round 6)
-template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false, bool GELU = false, int SHK = 36>
+// OVL (with KXB > 0; round 6, the 8x8 latent's K = 1024 + 512): the h columns take the x columns' PLACE in LDS once the x part's products are
+// done (one more barrier) -- 16 rows x 1032 floats = 66 KB instead of 99 KB, so TWO workgroups fit a CU as on the 6x6 latent and one's
+// staging / cell epilogue runs under the other's matrix work (99 KB: one four-wave workgroup per CU, every phase exposed)
+template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false, bool GELU = false, int SHK = 36, bool OVL = false>
 __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 {
     static_assert(!SH || MR == 16, "the split-head partials are written for 16-row workgroups");
+    static_assert(!OVL || (KXB > 0 && MR == 16 && 2 * KXB >= NKB), "the overlay needs split staging and an x part at least as wide as the h part");
     static_assert(SHK == 36 || SHK == 64, "slice widths with a weight layout (finalize_conv_layouts)");
     constexpr int SHC4 = SHK / 4, SHB4 = (SHC4 + 3) / 4, SHP = SHK + 4;   // float4 per row slice; float4 of B operands per lane (9 -> 12 | 16 floats); LDS pitch
-    constexpr int K = NKB * 16, PS = K + LSTM_PAD, R = 12;
+    constexpr int K = NKB * 16, PS = (OVL ? KXB * 16 : K) + LSTM_PAD, R = 12;
+    constexpr int PSH = OVL ? (NKB - KXB) * 16 + LSTM_PAD : PS, HOFF = OVL ? 0 : KXB * 16;   // pitch / first column of the h columns' place
     constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
     constexpr bool TWO = MR == 32;                         // a wave computes both 16-row tiles of a 32-row workgroup
     static_assert(MR == 32 || (MR == 16 && XV == 0), "the input transform is written for 8 staging lanes per row");
@@ -3064,6 +3069,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     __syncthreads();
     const float *sA0 = smem + (mt * 16 + (lane & 15)) * PS + (lane >> 4) * 4;
     const float *sA1 = sA0 + (TWO ? 16 : 0) * PS;  // only a four-wave 32-row workgroup computes a second tile per wave
+    const float *sAh = OVL ? smem + (mt * 16 + (lane & 15)) * PSH + (lane >> 4) * 4 - KXB * 16 : sA0;   // (OVL: k step s >= KXB reads sAh + s * 16)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     float4 a0 = *reinterpret_cast<const float4 *>(sA0), a1 = *reinterpret_cast<const float4 *>(sA1);
 #pragma unroll
@@ -3071,11 +3077,12 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         if constexpr (KXB > 0) {
             if (s == KXB) {  // the h columns have arrived behind the x part's MFMAs: into LDS, then on
                 const int row = tid / TPR, part = tid % TPR;
-                float *dst = smem + row * PS + KXB * 16;
+                if constexpr (OVL) __syncthreads();   // every wave has read its last x fragment: their place is free
+                float *dst = smem + row * PSH + HOFF;
 #pragma unroll
                 for (int i = 0; i < NHS; ++i) *reinterpret_cast<f32x4 *>(dst + (part + TPR * i) * 4) = hv[i];
                 __syncthreads();
-                a0 = *reinterpret_cast<const float4 *>(sA0 + s * 16);
+                a0 = *reinterpret_cast<const float4 *>((OVL ? sAh : sA0) + s * 16);
                 a1 = *reinterpret_cast<const float4 *>(sA1 + s * 16);
             }
         }
@@ -3083,7 +3090,7 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         if (s + R < NKB) wq[s % R] = wp[(size_t)((s + R) * wmul + (s % R) * (1 - wmul)) * 64];
         float4 n0 = a0, n1 = a1;
         if (s + 1 < NKB && (KXB == 0 || s + 1 != KXB)) {
-            n0 = *reinterpret_cast<const float4 *>(sA0 + (s + 1) * 16);
+            n0 = *reinterpret_cast<const float4 *>(((OVL && s + 1 > KXB) ? sAh : sA0) + (s + 1) * 16);
             n1 = *reinterpret_cast<const float4 *>(sA1 + (s + 1) * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -4219,10 +4226,12 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     const bool xf = a.x_ln_g || a.x_act;
     if (nkb == 96 && !xf) {  // 1024 + 512 (EfficientZero conv on 64x64 observations: 8x8 latent): 16-row tiles, 98.5 KB of LDS
         if (a.gelu) hipLaunchKernelGGL((k_lstm2<96, 0, 16, 0, false, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
-        else if (a.sh_part && a.H == 512 && a.sh_kc == 2048)   // split heads on the 8x8 latent (round 6): the head MLPs' first layers ride on this launch
-            hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64, true, false, 64>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
-        else if (a.KX == 1024 && !getenv("LZ_LSTM_NOSPLIT"))   // x columns first, the h columns arrive under their products (as on the 6x6 latent)
-            hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        else if (a.sh_part && a.H == 512 && a.sh_kc == 2048) {   // split heads on the 8x8 latent (round 6): the head MLPs' first layers ride on this launch
+            static const char *noovl = getenv("LZ_LSTM_NO_OVL");   // A/B: the h columns beside the x columns (99 KB of LDS, one workgroup per CU)
+            if (noovl) hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64, true, false, 64, false>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+            else hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64, true, false, 64, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * (1024 + LSTM_PAD) * 4, s, a);
+        } else if (a.KX == 1024 && !getenv("LZ_LSTM_NOSPLIT"))   // x columns first, the h columns arrive under their products and take the x columns' place in LDS
+            hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64, false, false, 36, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * (1024 + LSTM_PAD) * 4, s, a);
         else hipLaunchKernelGGL((k_lstm2<96, 0, 16>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
         return true;
     }

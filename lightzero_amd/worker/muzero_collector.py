@@ -241,6 +241,14 @@ class MuZeroVectorCollector(object):
             st[torch.as_tensor(reset_rows, device=self._device)] = rf[:, None].expand(-1, self._stack, *rf.shape[1:])
         return st
 
+    @staticmethod
+    def _drain_ticket(group, ticket):
+        """wait for a forward that will not be consumed (error path) so that its roots handle is reusable; never raises"""
+        try:
+            group.policy_end(ticket)
+        except Exception:
+            pass
+
     def collect(self, n_episode=None, train_iter=0, policy_kwargs=None):
         """``n_episode``: episodes to collect in total; with env groups it is split evenly (the remainder to the first groups) and every
         group needs at least ``env_num`` of them, like the reference's single env manager (:449)."""
@@ -270,13 +278,21 @@ class MuZeroVectorCollector(object):
             # environments afterwards).
             g = groups[0]
             tk = g.policy_begin()
-            while True:
-                rec = g.step_envs(g.policy_end(tk))
-                if not g.done:
-                    tk = g.policy_begin()
-                g.book(rec)
-                if g.done:
-                    break
+            try:
+                while True:
+                    header = g.policy_end(tk)
+                    tk = None
+                    rec = g.step_envs(header)
+                    if not g.done:
+                        tk = g.policy_begin()
+                    g.book(rec)
+                    if g.done:
+                        break
+            finally:
+                # an exception in env.step / the bookkeeping must not leave a forward in flight: its roots handle would stay "rows pending"
+                # in the policy's handle cache and every later collect() would be refused
+                if tk is not None:
+                    self._drain_ticket(g, tk)
         else:
             # Several env groups: every live group has ONE forward enqueued on the engine's stream at any time, so the device goes from
             # one group's search straight into the next one's while the host -- one thread -- waits for the oldest forward (its own
@@ -284,13 +300,19 @@ class MuZeroVectorCollector(object):
             # its segment bookkeeping.  (Round 4 kept one forward in flight on a worker thread: the device idled from one group's
             # read-back to the next group's launch, ~0.4 ms of every 3.3 ms step.)
             import collections
-            queue = collections.deque((g, g.policy_begin()) for g in groups)
-            while queue:
-                g, tk = queue.popleft()
-                rec = g.step_envs(g.policy_end(tk))
-                if not g.done:
+            queue = collections.deque()
+            try:
+                for g in groups:
                     queue.append((g, g.policy_begin()))
-                g.book(rec)
+                while queue:
+                    g, tk = queue.popleft()
+                    rec = g.step_envs(g.policy_end(tk))
+                    if not g.done:
+                        queue.append((g, g.policy_begin()))
+                    g.book(rec)
+            finally:
+                while queue:   # (only after an exception: every other group's forward in flight is waited for and dropped)
+                    self._drain_ticket(*queue.popleft())
         self.group_results = []
         segs_all, meta_all = [], []
         for g in groups:

@@ -59,8 +59,10 @@ def test_hip_network_matches_reference_module_outputs(name):
     check_case(name, case, g, sd)
 
 
-def check_case(name, case, g, sd, record="golden/", bounds=None):
-    """engine model with the weights ``sd`` on the seeded inputs of ``case`` against the arrays ``g`` (the golden file's layout)"""
+def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None):
+    """engine model with the weights ``sd`` on the seeded inputs of ``case`` against the arrays ``g`` (the golden file's layout).
+    ``g64``: the same arrays from a binary64 evaluation of the same network on the same teacher-forced inputs -- the device's distance
+    from THEM is recorded next to its distance from the fp32 reference (entry field "device_vs_binary64") and returned under "vs64"."""
     from lightzero_amd import _lib as L
     lib = L.lib()
     fam, kw, B = case["family"], case["kw"], case["B"]
@@ -80,6 +82,11 @@ def check_case(name, case, g, sd, record="golden/", bounds=None):
     L.check(lib.lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
     worst = dict(latent=_rel(lat, g["init_latent"]), policy=_rel(out.policy_logits, g["init_policy"]),
                  scalar=_rel(out.value, g["init_value"]), logits=0.0, hc=0.0)
+    w64 = dict(latent=0.0, policy=0.0, logits=0.0, hc=0.0)
+    def up64(cls, dev, key):
+        if g64 is not None:
+            w64[cls] = max(w64[cls], _rel(np.asarray(dev, np.float64), np.asarray(g64[key], np.float64)))
+    up64("latent", lat, "init_latent"); up64("policy", out.policy_logits, "init_policy")
     SUP, RSUP = g["init_value_logits"].shape[1], g["s0_reward_logits"].shape[1]
     if conv:
         vl = np.zeros((B, SUP), np.float32)
@@ -109,17 +116,25 @@ def check_case(name, case, g, sd, record="golden/", bounds=None):
         L.check(lib.lz_roots_read_sim_outputs(roots._h, 1, rew, val, pol.reshape(-1)))
         worst["latent"] = max(worst["latent"], _rel(lat, g["s%d_latent" % s]))
         worst["policy"] = max(worst["policy"], _rel(pol, g["s%d_policy" % s]))
+        up64("latent", lat, "s%d_latent" % s); up64("policy", pol, "s%d_policy" % s)
         worst["scalar"] = max(worst["scalar"], _rel(rew, g["s%d_reward" % s]), _rel(val, g["s%d_value" % s]))
         if lstm:
             H = g["s%d_h" % s].shape[1]
             hh = np.zeros((B, H), np.float32); cc = np.zeros((B, H), np.float32)
             L.check(lib.lz_roots_read_hidden(roots._h, 1, hh.reshape(-1), cc.reshape(-1)))
             worst["hc"] = max(worst["hc"], _rel(hh, g["s%d_h" % s]), _rel(cc, g["s%d_c" % s]))
+            up64("hc", hh, "s%d_h" % s); up64("hc", cc, "s%d_c" % s)
         if conv:
             vl = np.zeros((B, SUP), np.float32); rl = np.zeros((B, RSUP), np.float32)
             L.check(lib.lz_roots_read_debug_logits(roots._h, 0, vl.reshape(-1)))
             L.check(lib.lz_roots_read_debug_logits(roots._h, 1, rl.reshape(-1)))
             worst["logits"] = max(worst["logits"], _rel(vl, g["s%d_value_logits" % s]), _rel(rl, g["s%d_reward_logits" % s]))
-    print(name, "worst relative differences:", worst)
-    parity_record.check(record + name, worst, extra=dict(batch=int(B), steps=int(nn_cases.STEPS)), bounds=bounds)
+            up64("logits", vl, "s%d_value_logits" % s); up64("logits", rl, "s%d_reward_logits" % s)
+    print(name, "worst relative differences:", worst, ("device vs binary64: %s" % w64) if g64 is not None else "")
+    extra = dict(batch=int(B), steps=int(nn_cases.STEPS))
+    if g64 is not None:
+        extra["device_vs_binary64"] = w64
+    parity_record.check(record + name, worst, extra=extra, bounds=bounds)
+    if g64 is not None:
+        worst = dict(worst, vs64=w64)
     return worst

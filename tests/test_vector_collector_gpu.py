@@ -75,6 +75,41 @@ def test_collect_with_the_engine_policy():
         assert m["priorities"] is not None and len(m["priorities"]) == seg["valid_transition_count"] and (m["priorities"] > 0).all()
 
 
+@pytest.mark.parametrize("groups", [1, 2])
+def test_an_exception_in_env_step_leaves_no_forward_in_flight(groups):
+    """the pipelined loops keep one forward per env group enqueued; an exception in env.step (or the bookkeeping) used to leave
+    its roots handle "rows pending" in the policy's handle cache, and every later collect() was refused.  The loops now wait for and drop
+    the outstanding forwards on the way out: the same collector collects again."""
+    from oracle import torch_models as tm
+    from lightzero_amd.model.efficientzero_model import EfficientZeroModel
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    from lightzero_amd.worker import MuZeroVectorCollector
+    sd = tm.synthetic_init(tm.EfficientZeroModel(action_space_size=A), seed=3).state_dict()
+    model = EfficientZeroModel(action_space_size=A).load_state_dict(sd)
+    cfg = dict(num_simulations=8, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5,
+               root_noise_weight=0.25, root_dirichlet_alpha=0.3, game_segment_length=L, num_unroll_steps=UNROLL, td_steps=TD,
+               use_priority=True, model=dict(frame_stack_num=STACK, action_space_size=A))
+
+    class Boom(RuntimeError):
+        pass
+
+    armed = [True]   # ONE failure over all groups: the first env to reach its third step raises
+
+    class FailingEnv(FrameEnv):
+        def step(self, actions, active):
+            if armed[0] and self.t.max() + 1 == 3:
+                armed[0] = False
+                raise Boom("env.step failed")
+            return FrameEnv.step(self, actions, active)
+    envs = [FailingEnv(5 + k) for k in range(groups)]
+    pols = [EfficientZeroPolicy(cfg, model) for _ in range(groups)]
+    col = MuZeroVectorCollector(envs if groups > 1 else envs[0], pols if groups > 1 else pols[0], cfg, device="cuda")
+    with pytest.raises(Boom):
+        col.collect(n_episode=N * groups, policy_kwargs=dict(temperature=1.0, epsilon=0.0))
+    segs, meta = col.collect(n_episode=N * groups, policy_kwargs=dict(temperature=1.0, epsilon=0.0))   # was: LzError "env-step rows already in flight"
+    assert len(segs) > 0 and len(segs) == len(meta)
+
+
 class VecObsEnv:
     """vector observations [n, obs_dim]; records the actions it is stepped with"""
     def __init__(self, n, obs_dim, A, seed, masks=False):

@@ -111,9 +111,22 @@ def main():
                 if extra:
                     roof["frac_vs_fp32_matrix_peak"] = ach / PEAK
             else:
-                roof.update(bound="latency", achieved=None, peak=None, frac=None,
-                            note="launch- / latency-bound kernel: a dense layer of <= 0.26 MB of weights and ~2 MFLOP, or a tree step of one "
-                                 "wavefront of dependent instructions per root; no roofline applies, the launch count per simulation does")
+                # a stated bound for the launch-bound families.  The floor of a simulation on ONE stream is its launch count x the
+                # period of an empty launch in a captured graph (1.7 us: tools/ubench/handoff.py measured 1.6-1.8 us per phase of 256 one-per-CU
+                # workgroups as separate launches) -- every launch of these families is a dependent step (dense level -> dense level -> LSTM ->
+                # row finisher -> tree step), their weights (<= 0.26 MB per layer, 3.6 MB per simulation) stay in L2 / MALL and their matrix work is
+                # ~2 MFLOP per layer.  frac = floor / measured time per simulation: how far the launch sequence is from being purely boundary-bound.
+                sims_total = float(c["prof_steps"]) * line["num_simulations"]
+                per_sim = sum(k["calls"] for k in table if not k["kernel"].startswith("__amd")) / sims_total
+                launches = int(round(per_sim))
+                floor_us = launches * 1.7
+                meas_us = line["ms_per_step"] * 1e3 / line["num_simulations"]
+                roof.update(bound="launch", unit="us per simulation", launches_per_simulation=launches, launch_period_us=1.7,
+                            peak=floor_us, achieved=meas_us, frac=floor_us / meas_us if meas_us else None,
+                            note="launch-bound family: floor = launches per simulation x 1.7 us (the period of an empty dependent launch on one stream, "
+                                 "tools/ubench/handoff.py); achieved = measured ms_per_step / simulations (includes the initial inference's share); "
+                                 "frac = floor / achieved.  A dense layer is <= 0.26 MB of weights and ~2 MFLOP, a tree step one wavefront of "
+                                 "dependent instructions per root: neither the HBM nor the MFMA roofline is within two orders of magnitude")
         d = {"metric": "self-play env-steps/sec (search only: initial inference -> prepare -> fused search -> read-back, inputs in HBM)",
              "value": line["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": 1, "ms_per_step": line["ms_per_step"], "higher_is_better": True,
              "dtype": c.get("dtype", "f32"), "data": "synthetic", "vs_baseline": None,
