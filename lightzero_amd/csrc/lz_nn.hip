@@ -4225,7 +4225,9 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
     const size_t lds = (size_t)32 * ((size_t)nkb * 16 + LSTM_PAD) * 4;
     const bool xf = a.x_ln_g || a.x_act;
     if (nkb == 96 && !xf) {  // 1024 + 512 (EfficientZero conv on 64x64 observations: 8x8 latent): 16-row tiles, 98.5 KB of LDS
-        if (a.gelu) hipLaunchKernelGGL((k_lstm2<96, 0, 16, 0, false, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
+        if (a.gelu && a.KX == 1024 && !getenv("LZ_LSTM_NOSPLIT"))
+            hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64, false, true, 36, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * (1024 + LSTM_PAD) * 4, s, a);
+        else if (a.gelu) hipLaunchKernelGGL((k_lstm2<96, 0, 16, 0, false, true>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);
         else if (a.sh_part && a.H == 512 && a.sh_kc == 2048) {   // split heads on the 8x8 latent (round 6): the head MLPs' first layers ride on this launch
             static const char *noovl = getenv("LZ_LSTM_NO_OVL");   // A/B: the h columns beside the x columns (99 KB of LDS, one workgroup per CU)
             if (noovl) hipLaunchKernelGGL((k_lstm2<96, 0, 16, 64, true, false, 64, false>), dim3(a.H / 16, (a.B + 15) / 16), block, (size_t)16 * ((size_t)nkb * 16 + LSTM_PAD) * 4, s, a);

@@ -206,8 +206,11 @@ def test_conv_sampled_efficientzero_policy_surface_and_vector_collector_rows():
         assert len(set(acts.tolist())) == K and all(0 <= a < A for a in acts)            # K distinct actions of the action space
         assert sum(o["visit_count_distributions"]) == S and len(o["visit_count_distributions"]) == K
         assert int(np.asarray(o["action"]).reshape(-1)[0]) in acts.tolist()
-        # the root predictions are the network's (GELU prediction network, 256-wide heads): against the torch restatement
-        assert np.allclose(np.asarray(o["predicted_policy_logits"]), want.policy_logits[i].numpy(), atol=2e-5, rtol=1e-5)
+    # the root predictions are the network's (GELU prediction network, 256-wide heads): against the torch restatement at north_star's 1e-5 (1 + |x|)
+    import parity_record
+    got = np.stack([np.asarray(out[i]["predicted_policy_logits"], np.float64) for i in range(B)])
+    wl = want.policy_logits.numpy().astype(np.float64)
+    parity_record.check("policy_surface/sez_atari64/root_policy/B%d" % B, {"policy": float(np.max(np.abs(got - wl) / (1.0 + np.abs(wl))))})
     ev1, ev2 = pol._forward_eval(obs, to_play=[-1] * B), pol._forward_eval(obs, to_play=[-1] * B)
     assert all(sum(ev1[i]["visit_count_distributions"]) == S for i in range(B))
     assert all(np.isfinite(ev1[i]["searched_value"]) for i in range(B)) and len(ev2) == B
