@@ -29,6 +29,7 @@ def chain_peak(kernel):
 # name -> (BASELINE.json index, tool command, steps under the profiler, per-root algorithmic FLOP of the chain launch | None)
 CHAIN_ATARI_MZ = 2 * 36 * 64 * (68 + 4 * 64) * 9 + 2 * 36 * 64 * 48          # dyn conv 68 -> 64 (A = 4) + 4 convs 64 -> 64 + three 1x1 64 -> 16
 CHAIN_GO = 2 * 81 * 64 * (146 + 4 * 64) * 9 + 2 * 81 * 64 * 48               # dyn conv (64 + 82) -> 64 on 9x9 + 4 convs + three 1x1
+CHAIN_ATARI64_EZ = 2 * 64 * 64 * (70 + 4 * 64) * 9 + 2 * 64 * 64 * 48        # EfficientZero on the 8x8 latent (A = 6): dyn conv 70 -> 64 + 4 convs + three 1x1
 CONFIGS = {
     "cfg0": dict(index=0, cmd=["tools/bench_mlp_configs.py", "--config", "0", "--steps", "50"], prof_steps="20",
                  workload="BASELINE.json configs[0]: CartPole-v0 MuZero, MuZeroModelMLP (obs 4, latent 128), 25 sims, 8 envs"),
@@ -47,7 +48,7 @@ CONFIGS = {
     # FAST MODE arms (bf16 matrix products; statistical parity only) and the reference's shipped Atari shape (64x64 frames -> 8x8 latent)
     "cfg2_fast": dict(index=2, cmd=["tools/bench_conv_configs.py", "--envs", "1024", "--sims", "400", "--steps", "4", "--warmup", "1", "--fast"], prof_steps="1", dtype="bf16",
                       workload="FAST MODE arm of BASELINE.json configs[2]: Atari Breakout MuZero, obs 4x96x96, 400 sims, 1024 envs, A = 4"),
-    "cfg_atari64": dict(index=1, cmd=["tools/bench_conv_configs.py", "--family", "ez", "--obs", "64", "--envs", "256", "--sims", "50", "--actions", "6", "--steps", "20"], prof_steps="5",
+    "cfg_atari64": dict(index=1, cmd=["tools/bench_conv_configs.py", "--family", "ez", "--obs", "64", "--envs", "256", "--sims", "50", "--actions", "6", "--steps", "20"], prof_steps="5", chain_flop=CHAIN_ATARI64_EZ,
                         workload="the reference's shipped Atari EfficientZero shape (zoo/atari/config/atari_efficientzero_config.py: 4x64x64 frames -> 8x8 latent, supports (-50, 51)), 50 sims, 256 envs, A = 6"),
     "cfg_atari64_fast": dict(index=1, cmd=["tools/bench_conv_configs.py", "--family", "ez", "--obs", "64", "--envs", "256", "--sims", "50", "--actions", "6", "--steps", "20", "--fast"], prof_steps="5", dtype="bf16",
                              workload="FAST MODE arm of the shipped Atari EfficientZero shape (4x64x64 frames -> 8x8 latent), 50 sims, 256 envs, A = 6"),
@@ -110,7 +111,7 @@ def main():
                             clock="rocprofv3 --kernel-trace average of this run", **extra)
                 if extra:
                     roof["frac_vs_fp32_matrix_peak"] = ach / PEAK
-            else:
+            elif "bench_mlp_configs" in c["cmd"][0]:
                 # a stated bound for the launch-bound families.  The floor of a simulation on ONE stream is its launch count x the
                 # period of an empty launch in a captured graph (1.7 us: tools/ubench/handoff.py measured 1.6-1.8 us per phase of 256 one-per-CU
                 # workgroups as separate launches) -- every launch of these families is a dependent step (dense level -> dense level -> LSTM ->
@@ -127,6 +128,8 @@ def main():
                                  "tools/ubench/handoff.py); achieved = measured ms_per_step / simulations (includes the initial inference's share); "
                                  "frac = floor / achieved.  A dense layer is <= 0.26 MB of weights and ~2 MFLOP, a tree step one wavefront of "
                                  "dependent instructions per root: neither the HBM nor the MFMA roofline is within two orders of magnitude")
+            else:
+                roof.update(bound="latency", achieved=None, peak=None, frac=None, note="latency-bound kernel at the top of this configuration's table")
         d = {"metric": "self-play env-steps/sec (search only: initial inference -> prepare -> fused search -> read-back, inputs in HBM)",
              "value": line["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": 1, "ms_per_step": line["ms_per_step"], "higher_is_better": True,
              "dtype": c.get("dtype", "f32"), "data": "synthetic", "vs_baseline": None,
