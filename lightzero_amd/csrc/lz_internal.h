@@ -167,6 +167,9 @@ struct lz_roots {
     const float *last_obs = nullptr; // the observation batch of the latest lz_initial_inference (caller's or d_obs): the newest
                                     // frame of every env-step row comes from here (lz_roots_collect_rows)
     float *sh_part = nullptr;       // split heads: [B][3 heads][H/16 unit tiles][32] first-layer partial sums of the head MLPs (LSTM launch)
+    void *fuse_ctl = nullptr;       // LZ_SIM_ONE_LAUNCH=1 (k_sim_fused): lz_res_ctl + one arrival counter per (launch, 16-root group); zeroed once per search
+    size_t fuse_ctl_bytes = 0;
+    bool fuse_used = false;         // the last enqueued search ran fused launches: lz_search checks lz_res_ctl::fault behind it
     float *mt[14] = {};             // MLP model family: [B][Wmax] scratch activations (lz_mlp.hip)
     std::vector<int32_t> h_n_legal;  // host copy of n_legal (noise offsets without a device round trip)
     std::vector<int32_t> h_to_play;  // to_play of the last HOST-side prepare (lz_roots_prepare & co.): lz_roots_adopt_inference

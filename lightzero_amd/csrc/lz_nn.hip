@@ -15,6 +15,7 @@
 // that every SIMD of every CU issues the same 324 MFMAs, and the partial tiles meet in LDS.  The input
 // halo and the 16-channel weight slice are staged in LDS once per workgroup with a +4-float pixel
 // pad, which makes every ds_read_b128 of an operand fragment bank-conflict free.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "lz_nn_kernels.h"
@@ -1829,8 +1830,16 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 // per layer, four barriers -- are gone; a layer is 8.05 k cycles (products 5.7 k, at 91 % of the matrix rate) against 11.3 k.  Wave roles,
 // the schedule of a tap and what the ISA showed on the way: DESIGN.md 3.2c.
 // ------------------------------------------------------------------------------------------------
-template <int GW, int GH, int TREE = 0, bool HEADS = false>
-__global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step_arg<TREE>::type step)
+// The launch's body as a device function: k_chain_s3 is the launch-per-simulation form (b = blockIdx.x), k_search_resident (below) calls it
+// once per simulation with RES = true -- `rs` then says which simulation of the resident launch this is (the per-simulation pointers are
+// linear in it), loads of data ANOTHER workgroup produced inside the launch (the LSTM phase's head partials) bypass this CU's L1 (sc1:
+// served by the XCD's L2, which the groups of 16 roots never leave), and the rows the LSTM phase reads leave as plain stores (they stay in
+// that L2; write-through sc1 stores drop the line).
+// RES: 0 the launch-per-simulation kernel | 1 k_sim_fused (only the head partials come from other workgroups of the launch: sc1 loads; the
+// outputs are read by LATER launches and stay write-through) | 2 a launch that loops over simulations (per-simulation offsets `rs`, plain
+// stores for what its own later phases read; not shipped: see k_sim_fused)
+template <int GW, int GH, int TREE, bool HEADS, int RES>
+__device__ __forceinline__ void chain_s3_body(const lz_chain_args &a, const typename step_arg<TREE>::type &step, const int b, const int nroots, const lz_res_sim &rs)
 {
     constexpr int NW = 8, PS = 68, HW = GW * GH, MT = (HW + 15) / 16, BUF = (HW + 1) * PS, NTHR = NW * 64;
     constexpr int PB = 80;                               // bf16 per pixel of the bf16 planes: 64 + pad.  160 B = 10 bank quads: the 16-lane groups ds_read_b128 is
@@ -1850,8 +1859,6 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
     // half of the taps (th = 0: taps 0-4, th = 1: taps 5-8; waves w and w + 4 share a SIMD, so every SIMD gets 5 + 4 taps): each pixel fragment
     // feeds 12 MFMAs instead of 6, the LDS read traffic halves.  Four waves hold partial sums of the same six output tiles; they meet in LDS.
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, np = wv & 1, kh = (wv >> 1) & 1, th = wv >> 2, widx = wv >> 1;   // widx = kh + 2 th
-    const int b = blockIdx.x;
-    lz_stamp_begin(a.stamp);
     // per-layer parameters: lane L keeps layer L's (a scalar load from the argument block at the top of every layer is a round trip the
     // layer then waits for); v_readlane hands them out
     const lz_chain_layer &myl = a.layer[min(lane, LZ_CHAIN_MAX_LAYERS - 1)];
@@ -1887,7 +1894,7 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
     // lines each while the tree step runs -- one load instruction per layer and workgroup, results unused -- and the layers find them in L2.
     auto prefetch_weights = [&](int L) {
         if (L >= a.nlayers) return;
-        const int nr = min(max((int)gridDim.x >> 3, 1), 32), r = (b >> 3) % nr;
+        const int nr = min(max(nroots >> 3, 1), 32), r = (b >> 3) % nr;
         constexpr int LINES = 2 * 4 * 9 * NPL * 64 * 16 / 128;       // 128-byte lines of a layer
         const char *w = reinterpret_cast<const char *>(a.layer[L].w3);
         for (int ln = r + lane * nr; ln < LINES; ln += 64 * nr) (void)*reinterpret_cast<const volatile int *>(w + (size_t)ln * 128);
@@ -1925,6 +1932,13 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         }
         if (wv == 0) {
             if constexpr (HEADS) __builtin_amdgcn_s_setprio(3);
+            if constexpr (RES == 2) {   // simulation rs.ds of the resident launch: the leaf's slot, its output rows and the draw counter move with it
+                lz_traverse_args ta = step.a;
+                ta.counter += (uint32_t)rs.ds;
+                dev_step_lds<1, TREE - 1>(step.t, b, step.new_node + rs.ds, step.discount, step.vps + (size_t)rs.ds * rs.B, step.values + (size_t)rs.ds * rs.B,
+                                          step.logits + (size_t)rs.ds * rs.BA, step.horizon, ta, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
+                                          heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
+            } else
             dev_step_lds<1, TREE - 1>(step.t, b, step.new_node, step.discount, step.vps, step.values, step.logits, step.horizon,
                                       step.a, step.delta, step.vtp, reinterpret_cast<float4 *>(smem), s_sel, step.ts,
                                       heads_on ? s_leaf : nullptr, s_ctr + 2, 3);
@@ -1932,7 +1946,7 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         } else {
             if constexpr (HEADS) {
                 const int hw = wv < 4 ? wv - 1 : (wv == 4 ? 6 : wv - 2);
-                if (heads_on) heads_in_prologue(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts);
+                if (heads_on) heads_in_prologue<(RES != 0)>(step.sh, b, step.t.A, hw, lane, s_leaf, s_ctr, s_red, step.ts, RES == 2 ? (size_t)rs.ds * rs.B : 0, RES == 2 ? (size_t)rs.ds * rs.BA : 0);
             }
             load_w0();
             prefetch_weights(wv - 1); prefetch_weights(wv + 6);
@@ -2123,7 +2137,7 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0 && L == 2) lz_stamp_store(step.ts + (27), __builtin_readcyclecounter()); }
         {
             float *go = reinterpret_cast<float *>(lane64(my_gout, L));
-            if (go) go += (size_t)b * HW * 64;
+            if (go) go += (size_t)b * HW * 64 + (RES == 2 ? (size_t)rs.ds * (size_t)rs.lat_step : (size_t)0);
             // The epilogue is VALU work on the SIMD both waves of a pair share (3 tiles per SIMD): with the wave's role a run-time value every
             // accumulator / partial-sum pick was a chain of v_cndmask (about 120 VALU instructions per tile, 1.4 k cycles per layer on the
             // busiest SIMD) -- so the role becomes a compile-time constant behind a scalar branch, the residual arrives masked, the
@@ -2161,7 +2175,7 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
                         *reinterpret_cast<bf16x4 *>(sBout + mpix[f] * PB + c4v[f]) = oh;
                         *reinterpret_cast<bf16x4 *>(sBout + BB + mpix[f] * PB + c4v[f]) = om;
                         *reinterpret_cast<bf16x4 *>(sBout + 2 * BB + mpix[f] * PB + c4v[f]) = ol;
-                        if (go) store_wt(go + mpix[f] * 64 + c4v[f], o);
+                        if (go) { if constexpr (RES == 2) *reinterpret_cast<f32x4 *>(go + mpix[f] * 64 + c4v[f]) = o; else store_wt(go + mpix[f] * 64 + c4v[f], o); }
                     }
                 }
             };
@@ -2183,7 +2197,9 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         v.y = fmaxf((acc[1] + c1b.y) * c1s.y + c1t.y, 0.0f);
         v.z = fmaxf((acc[2] + c1b.z) * c1s.z + c1t.z, 0.0f);
         v.w = fmaxf((acc[3] + c1b.w) * c1s.w + c1t.w, 0.0f);
-        store_wt(jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + cq * 4, (f32x4){v.x, v.y, v.z, v.w});
+        float *po = jb.out + ((size_t)b * HW + row) * jb.out_stride + jb.out_off + cq * 4;
+        if constexpr (RES == 2) *reinterpret_cast<f32x4 *>(po) = (f32x4){v.x, v.y, v.z, v.w};   // (the group's LSTM phase reads these rows from this XCD's L2)
+        else store_wt(po, (f32x4){v.x, v.y, v.z, v.w});
     };
     auto c1_tile = [&](int job, int i) {
         const float *sIn = smem + a.c1_in[job] * BUF + kq4;
@@ -2221,6 +2237,13 @@ __global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step
         for (int i = 0; i < MT; ++i) c1_tile(wv, i);
     }
     if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (24), __builtin_readcyclecounter()); }
+}
+
+template <int GW, int GH, int TREE = 0, bool HEADS = false>
+__global__ __launch_bounds__(512) void k_chain_s3(lz_chain_args a, typename step_arg<TREE>::type step)
+{
+    lz_stamp_begin(a.stamp);
+    chain_s3_body<GW, GH, TREE, HEADS, 0>(a, step, (int)blockIdx.x, (int)gridDim.x, lz_res_sim{});
     lz_stamp_end(a.stamp);
 }
 
@@ -2920,9 +2943,16 @@ constexpr int LSTM_PAD = 8;
 // OVL (with KXB > 0; round 6, the 8x8 latent's K = 1024 + 512): the h columns take the x columns' PLACE in LDS once the x part's products are
 // done (one more barrier) -- 16 rows x 1032 floats = 66 KB instead of 99 KB, so TWO workgroups fit a CU as on the 6x6 latent and one's
 // staging / cell epilogue runs under the other's matrix work (99 KB: one four-wave workgroup per CU, every phase exposed)
-template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false, bool GELU = false, int SHK = 36, bool OVL = false>
-__global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
+// The launch's body as a device function (see chain_s3_body): k_lstm2 calls it with tile = blockIdx.x, r0 = blockIdx.y MR, tid = threadIdx.x;
+// k_search_resident calls it from BOTH 256-thread halves of its 512-thread workgroups (two unit tiles of the group's row tile, each half
+// with 70 KB of LDS of its own; every __syncthreads() in here is executed by both halves alike).  RES: the rows, pool states and gather
+// indices were stored by other workgroups of the SAME launch -> sc1 loads; outputs as plain stores; `wait_inputs` is called behind the
+// weight ring's requests -- the resident form waits there for the group's chain phase.
+template <int NKB, int XV, int MR, int KXB, bool SH, bool GELU, int SHK, bool OVL, bool RES, class WAIT>
+__device__ __forceinline__ void lstm2_body(const lz_lstm_args &a, const int tile, const int r0, const int tid, float *smem, const int ntiles,
+                                           const lz_res_sim &rs, WAIT wait_inputs)
 {
+    static_assert(!RES || (KXB > 0 && XV == 0 && !OVL), "the resident form is written for the split-staging instance of the 6x6 latent");
     static_assert(!SH || MR == 16, "the split-head partials are written for 16-row workgroups");
     static_assert(!OVL || (KXB > 0 && MR == 16 && 2 * KXB >= NKB), "the overlay needs split staging and an x part at least as wide as the h part");
     static_assert(SHK == 36 || SHK == 64, "slice widths with a weight layout (finalize_conv_layouts)");
@@ -2932,13 +2962,10 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     constexpr int NTHR = 256, NQ = MR * 16 / NTHR, TPR = NTHR / MR;   // (row, unit) pairs per thread in the epilogue; threads staging one row
     constexpr bool TWO = MR == 32;                         // a wave computes both 16-row tiles of a 32-row workgroup
     static_assert(MR == 32 || (MR == 16 && XV == 0), "the input transform is written for 8 staging lanes per row");
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [MR][PS]; reused for the gate exchange
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;   // smem: [MR][PS]; reused for the gate exchange
     constexpr int mt = 0;
-    const int tile = blockIdx.x, r0 = blockIdx.y * MR;
     const int H = a.H, KX = a.KX;
     const size_t slot = (size_t)a.B * H;
-    lz_stamp_begin(a.stamp);
     // weight ring first: its L2 round trip overlaps the staging
 #ifdef LZ_DEBUG_KNOBS
     // timing experiment (debug build, LZ_DEBUG_LSTM_HOTW=1; results are then wrong): every step re-reads the first 12 fragments, i.e.
@@ -2951,6 +2978,9 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     float4 wq[R];
 #pragma unroll
     for (int s = 0; s < R; ++s) wq[s] = wp[(size_t)min(s, NKB - 1) * 64];
+    wait_inputs();
+    float *h_out = a.h_out, *c_out = a.c_out;
+    if constexpr (RES) { h_out += (size_t)rs.ds * (size_t)rs.hc_step; c_out += (size_t)rs.ds * (size_t)rs.hc_step; }
     // split heads: operands of the first-layer partial products (consumed after the K loop).  value | policy heads: A = rows r0 .. r0 + 15
     // of the combined 1x1-conv outputs, columns 36 tile .. + 35 (9 k-steps of 4), B = this wave's 16 of the 64 hidden columns;
     // value-prefix head (waves 0, 1): B = units 16 tile .. + 15 x 16 hidden columns.  Requested AFTER the row staging loads below
@@ -2963,7 +2993,8 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #ifdef LZ_DEBUG_KNOBS
         if (a.debug_hot_weights & 2) { for (int i = 0; i < SHB4; ++i) sh_bv[i] = sh_av; sh_brv = sh_av; return; }
 #endif
-        sh_av = *reinterpret_cast<const f32x4 *>(a.sh_pv + (size_t)bb * a.sh_kc + SHK * tile + 4 * c4);
+        if constexpr (RES) sh_av = load_sc1_f4(a.sh_pv, (size_t)bb * a.sh_kc + SHK * tile + 4 * c4);
+        else sh_av = *reinterpret_cast<const f32x4 *>(a.sh_pv + (size_t)bb * a.sh_kc + SHK * tile + 4 * c4);
         const float *bp = a.sh_w1c + (((size_t)tile * 4 + wv) * 64 + lane) * (4 * SHB4);
 #pragma unroll
         for (int i = 0; i < SHB4; ++i) sh_bv[i] = *reinterpret_cast<const f32x4 *>(bp + 4 * i);
@@ -2979,11 +3010,12 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
     for (int q = 0; q < NQ; ++q) {
         const int p = tid + NTHR * q, row = p >> 4, u = p & 15;
         const int b = min(r0 + row, a.B - 1), unit = tile * 16 + u;
-        c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
+        if constexpr (RES) c_prev[q] = load_sc1_f(a.c_pool + (size_t)load_sc1_i(a.gather_ix + b) * slot + (size_t)b * H + unit);
+        else c_prev[q] = a.c_pool[(size_t)a.gather_ix[b] * slot + (size_t)b * H + unit];
         const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + 4 * unit);
         gb[q][0] = b4.x; gb[q][1] = b4.y; gb[q][2] = b4.z; gb[q][3] = b4.w;
         bns[q] = bnsp[unit]; bnt[q] = bntp[unit];
-        slen[q] = slp[b];
+        slen[q] = RES ? load_sc1_i(slp + b) : slp[b];
     }
     // stage the rows: [x (KX) | h (H)] per row; TPR (8) threads per row, batches of 12 float4 loads in flight per thread
     constexpr int K4 = K / 4, NI = (K4 + TPR - 1) / TPR, NBATCH = 12;
@@ -2994,13 +3026,20 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         const int row = tid / TPR, part = tid % TPR;
         const int b = min(r0 + row, a.B - 1);
         const float *xrow = a.x + (size_t)b * KX;
-        const float *hrow = a.h_pool + (size_t)a.gather_ix[b] * slot + (size_t)b * H;
+        const size_t hoff = (size_t)(RES ? load_sc1_i(a.gather_ix + b) : a.gather_ix[b]) * slot + (size_t)b * H;
+        const float *hrow = a.h_pool + hoff;
         float *dst = smem + row * PS;
         f32x4 xv[NXS];
 #pragma unroll
-        for (int i = 0; i < NXS; ++i) xv[i] = *reinterpret_cast<const f32x4 *>(xrow + (part + TPR * i) * 4);
+        for (int i = 0; i < NXS; ++i) {
+            if constexpr (RES) xv[i] = load_sc1_f4(a.x, (size_t)b * KX + (part + TPR * i) * 4);
+            else xv[i] = *reinterpret_cast<const f32x4 *>(xrow + (part + TPR * i) * 4);
+        }
 #pragma unroll
-        for (int i = 0; i < NHS; ++i) hv[i] = *reinterpret_cast<const f32x4 *>(hrow + (part + TPR * i) * 4);
+        for (int i = 0; i < NHS; ++i) {
+            if constexpr (RES) hv[i] = load_sc1_f4(a.h_pool, hoff + (part + TPR * i) * 4);
+            else hv[i] = *reinterpret_cast<const f32x4 *>(hrow + (part + TPR * i) * 4);
+        }
         if constexpr (SH) sh_request();
 #pragma unroll
         for (int i = 0; i < NXS; ++i) *reinterpret_cast<f32x4 *>(dst + (part + TPR * i) * 4) = xv[i];
@@ -3133,10 +3172,16 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
         const float cn = sigmoidf_(gf) * c_prev[q] + sigmoidf_(gi) * tanhf_(gg);
         const float hn = sigmoidf_(go) * tanhf_(cn);
         const bool reset = a.search_len && a.horizon > 0 && (slen[q] % a.horizon) == 0;  // mcts_ctree.py:859-863
-        store_wt(a.h_out + (size_t)b * H + unit, reset ? 0.0f : hn);
-        store_wt(a.c_out + (size_t)b * H + unit, reset ? 0.0f : cn);
         const float hb = a.bn_scale ? act_<GELU>(hn * bns[q] + bnt[q]) : hn;
-        store_wt(a.hbn_out + (size_t)b * H + unit, hb);
+        if constexpr (RES) {   // plain stores: later simulations of this launch read them from this XCD's L2
+            h_out[(size_t)b * H + unit] = reset ? 0.0f : hn;
+            c_out[(size_t)b * H + unit] = reset ? 0.0f : cn;
+            a.hbn_out[(size_t)b * H + unit] = hb;
+        } else {
+            store_wt(h_out + (size_t)b * H + unit, reset ? 0.0f : hn);
+            store_wt(c_out + (size_t)b * H + unit, reset ? 0.0f : cn);
+            store_wt(a.hbn_out + (size_t)b * H + unit, hb);
+        }
         if constexpr (SH) sHb[row * 17 + u] = hb;
     }
     if constexpr (SH) {
@@ -3169,13 +3214,98 @@ __global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
 #ifdef LZ_DEBUG_KNOBS
                 if (a.debug_hot_weights & 4) continue;
 #endif
-                if (r0 + row < a.B)
-                    store_wt(a.sh_part + ((size_t)(r0 + row) * 3 + (c4 >> 3)) * (gridDim.x * 32) + (size_t)tile * 32 + (c4 & 7) * 4,
-                             *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4));
+                if (r0 + row < a.B) {
+                    float *pd = a.sh_part + ((size_t)(r0 + row) * 3 + (c4 >> 3)) * (ntiles * 32) + (size_t)tile * 32 + (c4 & 7) * 4;
+                    if constexpr (RES) *reinterpret_cast<f32x4 *>(pd) = *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4);
+                    else store_wt(pd, *reinterpret_cast<const f32x4 *>(sP + row * 96 + c4 * 4));
+                }
             }
         }
     }
+}
+
+template <int NKB, int XV = 0, int MR = 32, int KXB = 0, bool SH = false, bool GELU = false, int SHK = 36, bool OVL = false>
+__global__ __launch_bounds__(256) void k_lstm2(lz_lstm_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    lz_stamp_begin(a.stamp);
+    lstm2_body<NKB, XV, MR, KXB, SH, GELU, SHK, OVL, false>(a, (int)blockIdx.x, (int)blockIdx.y * MR, (int)threadIdx.x, smem, (int)gridDim.x, lz_res_sim{}, [] {});
     lz_stamp_end(a.stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE LAUNCH PER SIMULATION (round 6; opt-in: LZ_SIM_ONE_LAUNCH=1; EfficientZero, 6x6 latent, split heads, 128 | 256 roots): the LSTM launch of
+// simulation s - 1 and the tree-fused chain launch of simulation s -- k_lstm2<68,0,16,36,true> and k_chain_s3<6,6,1,true> -- as the two
+// PHASES of one launch.  Of a 48.9 us simulation 5.3 us are the two kernel boundaries (execution end -> the next launch's first workgroup)
+// plus two launch ramps; VERDICT r5 #3 asked for the resident form (one launch per SEARCH), whose hand-off this uses:
+//   * one workgroup per root and CU (512 threads, the chain's 153 KB of LDS); in the LSTM phase its two 256-thread halves are two unit
+//     tiles of the group's 16-row tile (2 x 70 KB of LDS);
+//   * GROUPS of 16 roots (= one LSTM row tile = the producers of a root's head partials) are formed at run time from HW_REG_XCC_ID, so that
+//     the hand-off stays inside one XCD's L2: producer = plain stores -> s_waitcnt vmcnt(0) -> barrier -> one relaxed agent-scope atomic
+//     add on the group's counter of this launch; consumer = one lane polls it (sc1 load: L2-served) -> barrier -> the partials by sc1 loads
+//     (heads_in_prologue<RES>).  No buffer_wbl2, no buffer_inv: nothing is written back or invalidated.  Everything else a phase reads
+//     was written by an EARLIER launch (rows, pool states, the tree) or by its own workgroup;
+//   * why not the loop over all simulations: inside a loop the compiler hoists both bodies' loop-invariant argument loads and keeps
+//     them live across the other body -- 256 registers + 1.7 KB of scratch per lane (measured; the chain body alone is 244 registers);
+//     straight-line, this kernel is 245 registers and no scratch.  The boundary that remains per simulation is the one behind the chain phase;
+//   * every spin is BOUNDED: a wait that runs out (a workgroup that is not resident, an XCD with another share of the workgroups) raises
+//     ctl->fault, lz_search reports LZ_ERR_STATE and the caller repeats the env-step on the two-launch path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool res_wait(const unsigned *f, unsigned want, unsigned *fault)
+{
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 18) || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(512) void k_sim_fused(lz_lstm_args la, lz_chain_args ca, lz_tree_step step, lz_resident_args ra)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // (no static LDS: with any, hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) is an invalid argument.)  Four words behind the chain's layout
+    constexpr int LDS_CHAIN = (4 * 37 * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * 3 * 256) + (3 * 4 * 37 * 80 * 2) / 4;   // floats: k_chain_s3<6,6>'s
+    int *s_ids = reinterpret_cast<int *>(smem + LDS_CHAIN);
+    const int tid = threadIdx.x;
+    lz_res_ctl *ctl = ra.ctl;
+    const int per_xcd = ra.B >> 3;                  // workgroups of an XCD (the dispatcher deals them round-robin: checked, not assumed)
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xf;
+        // tickets are monotonic over the launches of a search (the control block is zeroed once per search): launch k hands out k per_xcd ...
+        const int slot = (int)atomicAdd(&ctl->xcc_count[xcc], 1u) - ra.launch * per_xcd;
+        const bool ok = slot >= 0 && slot < per_xcd && xcc < 8;
+        if (!ok) __hip_atomic_fetch_add(&ctl->fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int sl = ok ? slot : 0;
+        s_ids[0] = (int)(xcc & 7) * (per_xcd >> 4) + (sl >> 4);
+        s_ids[1] = sl & 15;
+    }
+    __syncthreads();
+    const int grp = __builtin_amdgcn_readfirstlane(s_ids[0]), mem = __builtin_amdgcn_readfirstlane(s_ids[1]);
+    const int b = grp * 16 + mem, half = tid >> 8;
+    unsigned *flag = ctl->flags + (size_t)ra.launch * ra.ngroups + grp;
+    constexpr int LDS_HALF = 16 * (68 * 16 + LSTM_PAD);   // floats of one half's staged rows
+    lz_res_sim rs;
+    rs.ds = 0; rs.B = ra.B; rs.BA = ra.BA; rs.lat_step = 0; rs.hc_step = 0;
+    // ---- phase 1: the LSTM step of the previous simulation for the group's 16 rows, unit tiles 2 mem and 2 mem + 1 (+ the head partials)
+    // (its inputs were written by earlier launches: plain loads; its outputs stay write-through -- the pool rows are read by later launches,
+    // and a partial block that an sc1 store dropped from L2 costs the head waves' sc1 loads a memory round trip, not a stale line)
+    lstm2_body<68, 0, 16, 36, true, false, 36, false, false>(la, 2 * mem + half, grp * 16, tid & 255, smem + half * LDS_HALF, 32, rs, [] {});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ids[2] = res_wait(flag, 16u, &ctl->fault) ? 1 : 0;      // the whole group's partials are in this XCD's L2
+    }
+    __syncthreads();
+    if (s_ids[2] == 0) return;
+    // ---- phase 2: this simulation's chain launch for root b (heads of the previous leaf + tree step in the prologue)
+    chain_s3_body<6, 6, 1, true, 1>(ca, step, b, ra.B, rs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4280,6 +4410,30 @@ static bool launch_lstm2(const lz_lstm_args &a, hipStream_t s)
         if (xf) hipLaunchKernelGGL((k_lstm2<16, 4>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((k_lstm2<16>), grid, block, lds, s, a);
     } else return false;
+    return true;
+}
+
+// One launch for (the LSTM launch `la` of the previous simulation, the tree-fused chain launch `ca` / `step` of this one): k_sim_fused.
+// false: not this kernel's shape -- the caller launches the two separately.  ctl: lz_fused_ctl_bytes(...) of device memory, zeroed once per
+// search; launch = 0, 1, ... within that search.
+size_t lz_fused_ctl_bytes(int B, int nlaunches) { return sizeof(lz_res_ctl) + (size_t)(B / 16) * nlaunches * sizeof(unsigned); }
+bool lz_launch_sim_fused(const lz_lstm_args &la, const lz_chain_args &ca, const lz_tree_step &step, void *ctl, int launch, hipStream_t s)
+{
+    if (launch < 0 || !ctl) return false;
+    if (!(ca.gw == 6 && ca.gh == 6 && (ca.C == 0 || ca.C == 64)) || ca.gelu || ca.tstamp || ca.stamp || !ca.gather_ix || !ca.act_table || ca.nlayers <= 0) return false;
+    for (int i = 0; i < ca.nlayers; ++i)
+        if (!ca.layer[i].w3) return false;
+    if (!(ca.B == 256 || ca.B == 128) || step.t.B != ca.B || step.t.A > 64 || step.t.variant != LZ_TREE_EFFICIENTZERO || !step.sh.on || step.ts || step.sh.dbg_logits) return false;
+    if (!(la.KX == 576 && la.H == 512 && la.B == ca.B && la.sh_part && la.sh_kc == 1152 && la.wf && !la.gelu && !la.stamp && !la.x_ln_g && la.debug_hot_weights == 0)) return false;
+    static int cus = -1;
+    if (cus < 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0; }
+    if (cus < ca.B) return false;   // one workgroup per CU, all resident at once
+    const size_t lds = (size_t)(4 * 37 * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * 3 * 256) * 4 + (size_t)3 * 4 * 37 * 80 * 2 + 16;   // k_chain_s3's (>= the LSTM halves' 2 x 70 KB) + the group ids
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_sim_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    lz_resident_args ra{};
+    ra.ctl = reinterpret_cast<lz_res_ctl *>(ctl); ra.launch = launch; ra.ngroups = ca.B / 16; ra.B = ca.B; ra.BA = ca.B * step.t.A;
+    hipLaunchKernelGGL(k_sim_fused, dim3(ca.B), dim3(512), lds, s, la, ca, step, ra);
     return true;
 }
 

@@ -10,7 +10,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
 
+// ---- the resident search (LZ_RESIDENT=1; k_search_resident in lz_nn.hip): the launch-per-simulation kernels' bodies run inside ONE launch,
+// once per simulation.  lz_res_sim says which simulation of the launch a body call is: every per-simulation pointer of the launch
+// sequence (leaf slot, its output rows, the next latent's pool slot, the LSTM's output slot) is linear in it.
+struct lz_res_sim {
+    int ds;                 // simulations since the launch's first one
+    int B, BA;              // roots; roots x actions (policy logits per pool slot)
+    long long lat_step;     // floats between two latent pool slots
+    long long hc_step;      // floats between two h / c pool slots (B x H)
+};
+
 namespace {
+
+// Loads of data ANOTHER workgroup of the same launch stored (plain stores, then s_waitcnt vmcnt(0), then a flag): sc1 -- the load bypasses
+// this CU's vector L1 (which other CUs' stores never refresh) and is served by the XCD's L2; through a buffer descriptor / a relaxed
+// agent-scope atomic so that the compiler tracks its completion like any other load (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Correct only for producers on the SAME XCD (the resident search's groups of 16 roots are formed by HW_REG_XCC_ID).
+typedef unsigned lz_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_sc1_f4(const float *base, size_t float_off)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7ffffff0, 0x00020000);
+    const lz_v4u u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(float_off * 4), 0, 16);
+    return __builtin_bit_cast(f32x4, u);
+}
+__device__ __forceinline__ float load_sc1_f(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int load_sc1_i(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int VEC> struct vecf;
 template <> struct vecf<4> { typedef float4 type; };
@@ -96,8 +120,11 @@ __device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &h, bf16x4 &m
 // leaf is ready).  s_ctr[0..3] must be zero when this starts.  Measured (tools/tree_timing.py, root 0, simulation 49): the 155 KB of
 // second-layer weights of a root pass the CU's vector-memory path (64 B/clk) in ~4.4 k cycles, the scalars are out at ~8-10 k -- the
 // tree wave has staged its tree by ~7 k, so ~2-3 k cycles of this remain exposed in the launch.
+// RES (resident search): the partials were stored by other workgroups of THIS launch -> sc1 loads; off_b / off_ba: the leaf's slot of this
+// simulation relative to the launch's first (floats into out_value | out_vp and out_logits)
+template <bool RES = false>
 __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int b, int A, int hw, int lane, float *s_leaf, int32_t *s_ctr,
-                                                  float *s_red, unsigned long long *ts = nullptr)
+                                                  float *s_red, unsigned long long *ts = nullptr, size_t off_b = 0, size_t off_ba = 0)
 {
     const bool stamp = ts && b == 0 && hw == 0 && lane == 0;   // timing experiments (debug build): stamps of head wave 1 of root 0
 #define LZ_HPS(i) do { if (stamp) lz_stamp_store(ts + 8 + (i), __builtin_readcyclecounter()); } while (0)
@@ -109,10 +136,14 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
     // tiles][32 hidden] contiguous; lane (ug = lane >> 3, jq = lane & 7) takes the hidden quad 4 jq .. + 3 of unit tiles ug, ug + 8,
     // ug + 16, ug + 24 --, the first layer's bias / BatchNorm, then the second-layer weights of this lane's outputs
     const int NU = sh.n_unit_tiles, ug = lane >> 3, jq = lane & 7;
-    const float *pp = sh.part + ((size_t)b * 3 + head) * (NU * 32) + ug * 32 + jq * 4;
+    const size_t ppo = ((size_t)b * 3 + head) * (NU * 32) + ug * 32 + jq * 4;
+    const float *pp = sh.part + ppo;
     f32x4 pv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pv[q] = *reinterpret_cast<const f32x4 *>(pp + (size_t)q * 8 * 32);
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (RES) pv[q] = load_sc1_f4(sh.part, ppo + (size_t)q * 8 * 32);
+        else pv[q] = *reinterpret_cast<const f32x4 *>(pp + (size_t)q * 8 * 32);
+    }
     const f32x4 b1v = *reinterpret_cast<const f32x4 *>(sh.b1[head] + jq * 4), s1v = *reinterpret_cast<const f32x4 *>(sh.s1[head] + jq * 4),
                 t1v = *reinterpret_cast<const f32x4 *>(sh.t1[head] + jq * 4);
     constexpr int NT = 4;
@@ -161,7 +192,7 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
     }
     if (head == 1) {   // policy logits
         if (lane < A) {
-            sh.out_logits[(size_t)b * A + lane] = lg[0];
+            sh.out_logits[off_ba + (size_t)b * A + lane] = lg[0];
             s_leaf[2 + lane] = lg[0];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -210,7 +241,7 @@ __device__ __forceinline__ void heads_in_prologue(const lz_split_heads &sh, int 
         const float out = lz_inverse_scalar_transform(value);
         if (sh.dbg_expect && lane == 0) sh.dbg_expect[(size_t)grp * sh.dbg_B + b] = value;   // parity tests (tracing): the pre-transform expectation
         if (lane == 0) {
-            (head == 0 ? sh.out_value : sh.out_vp)[b] = out;
+            (head == 0 ? sh.out_value : sh.out_vp)[off_b + b] = out;
             s_leaf[head == 0 ? 1 : 0] = out;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

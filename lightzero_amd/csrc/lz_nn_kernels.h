@@ -160,6 +160,22 @@ struct lz_lstm_args {
     unsigned long long *stamp;       // optional [2] start / end stamps like lz_chain_args::stamp (k_lstm2 only)
 };
 void lz_launch_lstm(const lz_lstm_args &a, hipStream_t s);
+// One launch per simulation (opt-in, LZ_SIM_ONE_LAUNCH=1; lz_nn.hip: k_sim_fused): the LSTM launch of simulation s - 1 and the tree-fused chain
+// launch of simulation s as two phases of one launch whose 16-root groups hand the head partials over through one XCD's L2.  The control
+// block (device memory, zeroed once per search): ticket counters per XCD, the fault word (a bounded spin ran out: the results are void),
+// one arrival counter per (launch, group).
+struct lz_res_ctl {
+    unsigned xcc_count[16];
+    unsigned fault;
+    unsigned pad[15];
+    unsigned flags[1];          // [launches][B / 16 groups]
+};
+struct lz_resident_args {
+    lz_res_ctl *ctl;
+    int launch, ngroups, B, BA;
+};
+size_t lz_fused_ctl_bytes(int B, int nlaunches);
+bool lz_launch_sim_fused(const lz_lstm_args &la, const lz_chain_args &ca, const lz_tree_step &step, void *ctl, int launch, hipStream_t s);
 // host: wcat [4H][K] (row 4*unit + gate) -> fragment order for lz_lstm_args::wf (4*H*K floats)
 void lz_lstm_pack_fragments(const float *wcat, int H, int K, float *out);
 

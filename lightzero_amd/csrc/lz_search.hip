@@ -752,6 +752,8 @@ static int ensure_pools(lz_roots *r)
     // split heads: first-layer partial sums of the three head MLPs, one block per (16-row tile, LSTM unit tile)
     const size_t NU = H / 16;
     const size_t o_pc = take(m->sh_w1c ? B * 3 * NU * 32 * 4 : 0);
+    const size_t fc_bytes = (m->sh_w1c && (B == 256 || B == 128)) ? lz_fused_ctl_bytes((int)B, (int)NN) : 0;   // one launch per simulation (opt-in)
+    const size_t o_fc = take(fc_bytes);
     hipError_t err = lz_dev_malloc((void **)&r->pool_slab, off);
     if (err != hipSuccess) {
         lz_set_error("hipMalloc(%zu bytes) for the latent/LSTM pools failed: %s", off, hipGetErrorString(err));
@@ -766,6 +768,8 @@ static int ensure_pools(lz_roots *r)
     r->trace = (int32_t *)(base + o_tr); r->d_to_play = (int32_t *)(base + o_tp); r->d_zero_vp = (float *)(base + o_z);
     r->d_noise_off = r->d_to_play + B; r->d_noise = (float *)(r->d_noise_off + B);
     r->sh_part = m->sh_w1c ? (float *)(base + o_pc) : nullptr;
+    r->fuse_ctl = fc_bytes ? (void *)(base + o_fc) : nullptr;
+    r->fuse_ctl_bytes = fc_bytes;
     LZ_HIP_CHECK(hipMemsetAsync(r->d_zero_vp, 0, B * 4, r->eng->stream));
     return LZ_OK;
 }
@@ -796,6 +800,12 @@ static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, in
     a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.wb = w.wt; a.w3 = w.w3; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
     lz_launch_conv3x3(a, w.cin, stride, s);
+}
+
+__global__ void k_zero_words(unsigned *__restrict__ p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
 }
 
 __global__ void k_zero2(float4 *__restrict__ a, float4 *__restrict__ b, size_t n4)
@@ -1870,7 +1880,11 @@ static void split_heads_for(lz_roots *r, int leaf_slot, lz_split_heads &sh)
     }
 }
 
-static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz_tree_step *step = nullptr, bool defer_heads = false)
+// One launch per simulation (LZ_SIM_ONE_LAUNCH=1): `hold` != null -- the LSTM launch of this simulation is not enqueued, its arguments are
+// returned; `held` != null -- the LSTM launch of the PREVIOUS simulation rides in front of this simulation's chain launch (k_sim_fused,
+// launch number `fuse_launch` of this search), or is enqueued by itself first where the fused form does not apply.
+static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz_tree_step *step = nullptr, bool defer_heads = false,
+                      const lz_lstm_args *held = nullptr, lz_lstm_args *hold = nullptr, int *fuse_launch = nullptr)
 {
     lz_model *m = r->eng->model;
     if (m->cfg.model_type >= 2) { lz_mlp_recurrent(r, sim, horizon, s); return; }
@@ -1905,7 +1919,14 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
         if (r->stamps_on && r->stamps) ca.stamp = r->stamps + (size_t)slot * 4;
         {
             ProfScope ps(r->eng, s);
-            if (!dbg_skip('c')) lz_launch_chain(ca, s, step);
+            bool fused = false;
+            if (held) {
+                fused = step && !r->trace_on && !ca.stamp && !ca.tstamp && fuse_launch && r->fuse_ctl &&
+                        lz_launch_sim_fused(*held, ca, *step, r->fuse_ctl, *fuse_launch, s);
+                if (fused) { ++*fuse_launch; r->fuse_used = true; }
+                else lz_launch_lstm(*held, s);
+            }
+            if (!fused && !dbg_skip('c')) lz_launch_chain(ca, s, step);
         }
         if (r->trace_on && step) (void)hipMemcpyAsync(r->trace + (size_t)sim * 5 * B, t.res_ix, 5 * B * 4, hipMemcpyDeviceToDevice, s);
     }
@@ -1926,7 +1947,8 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
     // (running the value / policy heads on a side stream beside the LSTM was measured: the cross-stream
     // dependencies cost more than the overlap gains, 6.7 vs 5.8 ms per step)
     if (r->stamps_on && r->stamps) l.stamp = r->stamps + (size_t)slot * 4 + 2;
-    if (c.model_type == 0 && !dbg_skip('l')) lz_launch_lstm(l, s);
+    if (hold && defer_heads && c.model_type == 0) *hold = l;     // rides in front of the next chain launch
+    else if (c.model_type == 0 && !dbg_skip('l')) lz_launch_lstm(l, s);
     if (!defer_heads && !dbg_skip('h'))
         heads(r, slot, r->sim_value + (size_t)slot * B, r->sim_logits + (size_t)slot * B * A, r->dbg_logits[0], true,
               r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
@@ -2003,6 +2025,19 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
         st.horizon = horizon; st.a = ta; st.delta = delta; st.vtp = r->d_to_play;
         return st;
     };
+    // One launch per simulation (opt-in; k_sim_fused in lz_nn.hip): where a simulation defers its heads, its LSTM launch is held back and becomes
+    // the first phase of the next simulation's chain launch.  Not with tracing or stamps (their copies / stamp words sit between the launches).
+    static const char *one_launch_env = getenv("LZ_SIM_ONE_LAUNCH");
+    const bool one_launch = one_launch_env && atoi(one_launch_env) != 0 && split && r->fuse_ctl && !r->trace_on && !(r->stamps_on && r->stamps) && (B == 256 || B == 128) &&
+                            lz_fused_ctl_bytes((int)B, num_simulations) <= r->fuse_ctl_bytes && !getenv("LZ_CHAIN_NO_SPLIT");
+    r->fuse_used = false;
+    if (one_launch) {   // (a kernel, not hipMemsetAsync: as a memset NODE of the captured graph the clear was observed not to happen on a later replay)
+        const int nw = (int)(lz_fused_ctl_bytes((int)B, num_simulations) / 4);
+        hipLaunchKernelGGL(k_zero_words, dim3((nw + 255) / 256), dim3(256), 0, s, reinterpret_cast<unsigned *>(r->fuse_ctl), nw);
+    }
+    lz_lstm_args held_lstm{}, next_lstm{};
+    bool have_held = false;
+    int fuse_launch = 0;
     lz_tree_step step{};
     bool pending = false;  // a step that the next chain launch has to run
     for (int sim = 0; sim < num_simulations; ++sim) {
@@ -2016,7 +2051,10 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
             chain_args_for(r, sim + 1, ca);
             defer = lz_chain_fusable(ca, nxt);
         }
-        recurrent(r, sim, horizon, s, pending ? &step : nullptr, defer);
+        const bool hold_now = one_launch && defer;
+        recurrent(r, sim, horizon, s, pending ? &step : nullptr, defer, have_held ? &held_lstm : nullptr, hold_now ? &next_lstm : nullptr, &fuse_launch);
+        have_held = hold_now;
+        if (hold_now) held_lstm = next_lstm;
         pending = false;
         const int slot = sim + 1;
         const float *vp = r->sim_vp + (size_t)slot * B, *val = r->sim_value + (size_t)slot * B, *lg = r->sim_logits + (size_t)slot * B * A;
@@ -2050,7 +2088,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_SIM_ONE_LAUNCH", "LZ_LSTM_NO_OVL", "LZ_HEADS_MM64"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;
@@ -2104,17 +2142,36 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
     ta.tiebreak = r->tiebreak; ta.seed = r->seed; ta.counter = 0;
     ta.serial = getenv("LZ_TRAVERSE_SERIAL") ? 1 : 0;
     const bool use_graph = !r->eng->prof_on && !getenv("LZ_NO_GRAPH");
+    // LZ_SIM_ONE_LAUNCH=1: a fused launch's group barrier is a BOUNDED spin; one that ran out (a workgroup not resident, an XCD with another
+    // share of the workgroups) raised lz_res_ctl::fault and the search's results are void -- reported here, synchronously (the opt-in mode
+    // gives up the host's overlap with the search for this check), so that the caller can repeat the env-step on the two-launch path
+    auto check_fused = [&]() -> int {
+        if (!r->fuse_used || !r->fuse_ctl) return LZ_OK;
+        static const char *mode = getenv("LZ_SIM_ONE_LAUNCH");
+        if (mode && atoi(mode) == 2) return LZ_OK;   // timing experiments only: no synchronous fault check (a fault then goes unnoticed)
+        unsigned hdr[17] = {0};
+        LZ_HIP_CHECK(hipStreamSynchronize(s));
+        LZ_HIP_CHECK(hipMemcpy(hdr, r->fuse_ctl, sizeof(hdr), hipMemcpyDeviceToHost));
+        if (hdr[16]) {
+            lz_set_error("LZ_SIM_ONE_LAUNCH: %u workgroup(s) of a fused launch gave up waiting for their 16-root group (the launch needs one resident "
+                         "workgroup per root and the dispatcher's round-robin over the XCDs; tickets per XCD %u %u %u %u %u %u %u %u); the search's "
+                         "results are void -- unset LZ_SIM_ONE_LAUNCH and repeat the env-step", hdr[16], hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], hdr[6], hdr[7]);
+            return LZ_ERR_STATE;
+        }
+        return LZ_OK;
+    };
     if (!use_graph) {
         enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
         LZ_HIP_CHECK(hipGetLastError());
-        return LZ_OK;
+        return check_fused();
     }
     lz_graph_key key{};  // value-initialised: the padding takes part in the memcmp
     key.sims = num_simulations; key.pb_c_base = pb_c_base; key.pb_c_init = pb_c_init; key.discount = discount_factor;
     key.horizon = lstm_horizon_len; key.delta = value_delta_max; key.players = r->players; key.tiebreak = r->tiebreak;
     key.seed = r->seed; key.knobs = graph_knobs();
     key.model_uid = r->eng->model_uid; key.weights_gen = r->eng->weights_gen; key.trace = (r->trace_on ? 1 : 0) | (r->trace_on && r->head_debug ? 2 : 0); key.stamps = r->stamps_on ? 1 : 0;
-    return launch_captured(r, key, [&]() { enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s); });
+    if (int rc = launch_captured(r, key, [&]() { enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s); })) return rc;
+    return check_fused();
 }
 
 // GumbelMuZeroMCTSCtree.search (mcts_ctree.py:1067-1172) with an engine MuZero model: sequential-halving selection, MuZero

@@ -133,9 +133,9 @@ __device__ __forceinline__ void load_scalars(const lz_tree_dev &t, int b, tscal<
 template <int NC, int VARIANT, bool REUSE = false>
 __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &v, const tscal<NC> &sc, const lz_traverse_args &a,
                                              float delta_max, int vtp, int true_action = -1, float reuse_value = 0.0f,
-                                             int32_t *s_out = nullptr, bool use_tab = false, float tab_pbc = 0.0f, float tab_sq = 0.0f)
+                                             int32_t *s_out = nullptr, bool use_tab = false, float tab_pbc = 0.0f, float tab_sq = 0.0f, int b_in = -1)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = b_in >= 0 ? b_in : (int)blockIdx.x, lane = threadIdx.x;   // (b_in: the root of a workgroup whose block id is not its root -- k_sim_fused)
     const int A = t.A, NN = t.NN;
     const float mn = sc.mn, mx = sc.mx;
     const float discount = a.discount;
@@ -322,9 +322,9 @@ __device__ __forceinline__ void dev_traverse(const lz_tree_dev &t, const tview &
 // s_tab: [64] log((n + base + 1) / base) + init, then [64] sqrt(n) -- the exploration factors of a node with visit count n + 1.
 template <int AU, int VARIANT>
 __device__ __forceinline__ void dev_traverse_par(const lz_tree_dev &t, const tview &v, const tscal<1> &sc, const lz_traverse_args &a,
-                                                 float delta_max, int vtp, int nn, const float *s_tab, int32_t *s_out)
+                                                 float delta_max, int vtp, int nn, const float *s_tab, int32_t *s_out, int b_in = -1)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = b_in >= 0 ? b_in : (int)blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
     const float mn = sc.mn, mx = sc.mx, discount = a.discount;
     const bool nvalid = lane < nn;
@@ -512,9 +512,9 @@ template <int NC, int VARIANT, bool WT>
 __device__ __forceinline__ void dev_backprop(const lz_tree_dev &t, const tview &v, tscal<NC> &sc, int new_node, float discount,
                                              float vp_b, float value_b, const float (&lg)[NC], int d, int to_play, int reset,
                                              bool no_expand = false, int bidx = -1, const uint64_t *exptab = nullptr,
-                                             const float *prior_in = nullptr)
+                                             const float *prior_in = nullptr, int b_in = -1)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = b_in >= 0 ? b_in : (int)blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
     // ---- CNode::expand (cnode.cpp:88-151): all A actions are legal below the root
     if (!no_expand) {
@@ -855,7 +855,7 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     tview v = g;
     v.edge = s_edge; v.child = s_child; v.node_vp = s_vp; v.node_reset = s_reset; v.node_to_play = s_tp;
     v.path_node = s_pn; v.path_act = s_pa; v.link = s_link;
-    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset, false, -1, s_exp, s_leaf ? pri_early : nullptr);
+    dev_backprop<NC, VARIANT, true>(t, v, sc, new_node, discount, L.vp, L.value, L.lg, L.d, L.to_play, L.reset, false, -1, s_exp, s_leaf ? pri_early : nullptr, b);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -863,13 +863,13 @@ __device__ __forceinline__ void dev_step_lds(const lz_tree_dev &t, int b, int ne
     // trees of at most 64 nodes and 8 actions (every Atari-sized search of up to 63 simulations): all nodes scored at once
     if constexpr (NC == 1) {
         if (use_tab && A <= 8 && !a.serial) {
-            if (A <= 4) dev_traverse_par<4, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out);
-            else if (A <= 6) dev_traverse_par<6, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out);
-            else dev_traverse_par<8, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out);
+            if (A <= 4) dev_traverse_par<4, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out, b);
+            else if (A <= 6) dev_traverse_par<6, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out, b);
+            else dev_traverse_par<8, VARIANT>(t, v, sc, a, delta_max, vtp, nn, s_tab, s_out, b);
         }
-        else dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
+        else dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq, b);
     } else {
-        dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq);
+        dev_traverse<NC, VARIANT>(t, v, sc, a, delta_max, vtp, -1, 0.0f, s_out, use_tab, tab_pbc, tab_sq, b);
     }
     LZ_TTS(4);
 #undef LZ_TTS

@@ -22,3 +22,18 @@ def test_nn_goldens_hold_on_the_alternative_path(knob):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "%s=1:\n%s\n%s" % (knob, r.stdout[-3000:], r.stderr[-2000:])
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_one_launch_per_simulation_replays_exactly_and_reports_instead_of_hanging():
+    """LZ_SIM_ONE_LAUNCH=1 (k_sim_fused: the LSTM launch of simulation s - 1 and the tree-fused chain launch of simulation s as two phases of one
+    launch, 16-root groups handing the head partials over through one XCD's L2 -- VERDICT r5 #3's hand-off; measured SLOWER than two launches,
+    profiles/r06_one_launch_ab.txt, and kept opt-in): the production launch sequence at BASELINE configs[1] size still replays exactly through
+    the reference's compiled ctree, two runs are bit-identical, and a search whose batch is not 128 | 256 roots takes the two-launch path."""
+    env = dict(os.environ)
+    env["LZ_SIM_ONE_LAUNCH"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_exact_replay_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_determinism_gpu.py"), os.path.join(ROOT, "tests", "test_end_to_end_gpu.py"),
+                        "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "LZ_SIM_ONE_LAUNCH=1:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+    assert " passed" in r.stdout
