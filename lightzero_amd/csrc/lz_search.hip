@@ -519,6 +519,8 @@ static void refresh_program_free(lz_model *m)
     p = RefreshProgram{};
 }
 
+static int refresh_run(lz_engine *e, const float *flat, int64_t n_floats, int on_device);
+extern "C" int lz_model_weights_digest(lz_engine *e, uint64_t *out);
 // the recording pass: finalize_conv_layouts once more, on element codes (see RefreshRec)
 static int refresh_program_build(lz_engine *e)
 {
@@ -582,6 +584,31 @@ static int refresh_program_build(lz_engine *e)
     for (const auto &o : rec.split3) p.split3_items = std::max<int64_t>(p.split3_items, o.n);
     p.n_allocs = m->allocs.size();
     p.usable = true;
+    // Self-check: the program was RECORDED by running the host packers on element codes -- a packer that did arithmetic on two codes
+    // and still produced an integer in range would have recorded a wrong gather map silently.  Run the program once on the weights that are
+    // loaded right now (the host copy the packers just read) and require every device weight buffer to come out byte for byte as the host
+    // finalize left it; otherwise the program is unusable and the host finalize restores the buffers.
+    {
+        uint64_t d0 = 0, d1 = 0;
+        if (int rc = lz_model_weights_digest(e, &d0)) return rc;
+        std::vector<float> flat((size_t)p.raw_floats);
+        size_t i = 0;
+        for (const auto &kv : m->raw) {
+            memcpy(flat.data() + p.offsets[i], kv.second.data.data(), (size_t)p.sizes[i] * 4);
+            ++i;
+        }
+        int rc = refresh_run(e, flat.data(), p.raw_floats, 0);
+        m->raw_stale = false;              // (the flat buffer WAS the host copy)
+        if (!rc) rc = lz_model_weights_digest(e, &d1);
+        if (rc || d0 != d1) {
+            refresh_program_free(m);
+            m->refresh.tried = true;
+            m->refresh.why = rc ? "the refresh program's self-check could not run" : "the recorded refresh program does not reproduce the host re-layout of the loaded weights (self-check)";
+            (void)lz_model_finalize(e);    // the host re-layout writes every buffer again
+            m->refresh.tried = true;
+            return LZ_OK;
+        }
+    }
     return LZ_OK;
 }
 
@@ -637,6 +664,10 @@ extern "C" int lz_model_flat_host_buffer(lz_engine *e, float **out)
 extern "C" int lz_model_refresh_flat(lz_engine *e, const float *flat, int64_t n_floats, int on_device)
 {
     if (int rc = refresh_ready(e)) return rc;
+    return refresh_run(e, flat, n_floats, on_device);
+}
+static int refresh_run(lz_engine *e, const float *flat, int64_t n_floats, int on_device)
+{
     lz_model *m = e->model;
     RefreshProgram &p = m->refresh;
     LZ_REQUIRE(flat != nullptr && n_floats == p.raw_floats, "flat state_dict of another size than the model's tensors");

@@ -169,6 +169,9 @@ class EfficientZeroModel(object):
             L.check(L.lib().lz_model_set_tensor(self._engine, name.encode(), arr.reshape(-1), shape, arr.ndim))
         L.check(L.lib().lz_model_finalize(self._engine))
         self._loaded = True
+        # the shapes this (validated) load had: a later device-side refresh compares against them -- lz_model_refresh_flat only sees a flat
+        # buffer, so a tensor of the same size and another shape would otherwise be taken silently where this path rejects it
+        self._loaded_shapes = {k: tuple(int(d) for d in np.shape(v)) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
         return self
 
     def _engine_waits_for_torch(self, device):
@@ -214,14 +217,27 @@ class EfficientZeroModel(object):
             self._engine_waits_for_torch(flat.device)
             L.check(lib.lz_model_refresh_flat(self._engine, flat.data_ptr(), total, 1))
             self._flat_keep = flat
+            try:   # the copy out of the buffer is asynchronous on the engine's stream: whoever overwrites the buffer next (the in-place
+                import torch   # RCCL broadcast of shard.broadcast_state_dict) waits for this event on its own stream
+                ev = torch.cuda.Event()
+                ev.record(self._ext_streams[(flat.device.type, flat.device.index)])
+                sd.consumed_event = ev
+            except Exception:
+                pass
             return True
         if sum(1 for k in sd if not k.endswith("num_batches_tracked")) != len(ent):
             return False
         vals = []
+        shapes = self.__dict__.get("_loaded_shapes") or {}
         for name, off, size in ent:
             v = sd.get(name)
             if v is None or int(np.prod(np.shape(v))) != size:
                 return False
+            if name in shapes and tuple(int(d) for d in np.shape(v)) != shapes[name]:
+                return False     # same size, another shape: the strict host path (lz_model_set_tensor) says what is wrong
+            dt = str(getattr(v, "dtype", "float32"))
+            if dt not in ("torch.float32", "float32"):
+                return False     # another dtype: not cast silently here either
             vals.append(v)
         if all(getattr(v, "is_cuda", False) and str(v.dtype) == "torch.float32" and v.is_contiguous() for v in vals):
             import torch

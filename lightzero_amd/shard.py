@@ -224,11 +224,25 @@ def broadcast_state_dict(state_dict, src=0, device=None, on_device=False):
         return {k: arr(state_dict[k]) for k in names}
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    def still_views(sd):
+        """every entry is still the view of sd.flat it was built as (an entry re-assigned afterwards would ship a stale buffer: ADVICE r5)"""
+        off = 0
+        for k, n in zip(names, sizes):
+            v = sd[k]
+            if not hasattr(v, "data_ptr") or v.data_ptr() != sd.flat.data_ptr() + 4 * off or v.numel() != n:
+                return False
+            off += n
+        return True
     if isinstance(state_dict, FlatStateDict) and state_dict.flat is not None and state_dict.flat.device.type == torch.device(device).type \
-            and state_dict.flat.numel() == sum(sizes):
+            and state_dict.flat.numel() == sum(sizes) and still_views(state_dict):
         # already one flat buffer in name order on the collective's device (a learner's flat_state_dict, or the result of the previous
         # broadcast on the receiving ranks): broadcast it in place -- no concatenation, no staging
         flat = state_dict.flat
+        # ... but an engine model that took this buffer by pointer copies out of it asynchronously on ITS stream (lz_model_refresh_flat);
+        # the collective is ordered on torch's stream only: wait for the model's "consumed" event before overwriting the buffer
+        ev = getattr(state_dict, "consumed_event", None)
+        if ev is not None and flat.is_cuda:
+            torch.cuda.current_stream(flat.device).wait_event(ev)
     else:
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
         if dist.get_rank() == src:

@@ -72,6 +72,8 @@ def test_gumbel_fused_search_and_policy_vs_oracle_pipeline():
     roots_a.prepare_from_inference(0.25, noises, [-1] * B)
     mcts.search(roots_a, model, out.latent_state, [-1] * B)
     same = sum(int(x == y) for x, y in zip(roots_a.get_distributions(), oroots.get_distributions()))
+    import parity_record
+    parity_record.record("e2e/gmz_atari96/B%d_S%d" % (B, S), {}, extra=dict(roots=B, identical_visit_distributions=same, identical_fraction=same / float(B), gate=0.85))
     assert same >= int(0.85 * B), "only %d / %d visit-count distributions identical" % (same, B)
     # policy surface
     policy = GumbelMuZeroPolicy(cfg, model)

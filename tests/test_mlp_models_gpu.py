@@ -52,10 +52,15 @@ def test_muzero_mlp_search_matches_oracle_pipeline():
     mcts.search(roots, model, out.latent_state, [-1] * B)
     dists, values = roots.get_distributions(), roots.get_values()
     # oracle pipeline: C restatement of the reference tree + torch model
-    od, ov, _, _ = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, [-1] * B, dict(CFG, num_simulations=S),
-                                              roots_kwargs=dict(action_space_size=A, max_simulations=S), deterministic=True)
+    rec_o = []
+    od, ov, _, ol = osearch.mz_forward_collect(octree.mz_tree, ref, obs, legal, noises, [-1] * B, dict(CFG, num_simulations=S),
+                                               roots_kwargs=dict(action_space_size=A, max_simulations=S), deterministic=True, record=rec_o)
     same = sum(int(a == b) for a, b in zip(dists, od))
-    assert same >= B - 1, "only %d / %d visit-count distributions identical" % (same, B)
+    # BASELINE configs[0]: recorded + every differing root attributed (tests/e2e_common.py)
+    import e2e_common
+    e2e_common.attribute_and_gate("e2e/mz_mlp_cartpole/B%d_S%d" % (B, S), "mz", octree.mz_tree, dict(CFG, num_simulations=S), A, legal, noises, [-1] * B, ol,
+                                  np.asarray(out.policy_logits, np.float32), rec_o, e2e_common.device_records(roots, L.lib(), L, B, A, S),
+                                  od, dists, ov, values, gate=(B - 1) / float(B))
     if same == B:
         assert _rel(values, ov) < 3e-4
     # last simulation's network outputs vs torch on the latents the device itself produced
@@ -139,6 +144,8 @@ def test_sampled_mlp_fused_search_matches_oracle_pipeline():
     od = oroots.get_distributions()
     dists = roots.get_distributions()
     same = sum(int(a == b) for a, b in zip(dists, od))
+    parity_record.record("e2e/sez_mlp_dmc/B%d_S%d" % (B, S), {}, extra=dict(roots=B, identical_visit_distributions=same, identical_fraction=same / float(B), gate=(B - 1) / float(B),
+                         note="BASELINE configs[4] shape; the oracle pipeline's draws injected into the fused device search"))
     assert same >= B - 1, "only %d / %d visit-count distributions identical" % (same, B)
     assert np.array_equal(np.asarray(roots.get_sampled_actions(), np.float32), draws[0])
     # device-side sampling: a second search without injected draws still spends every simulation and replays from the graph
