@@ -34,7 +34,9 @@ def test_default_line_is_parity_mode_and_carries_the_fast_arm_separately():
     assert abs(rf["executed_bf16_tflops"] - rf["achieved"] * 8.0) < 1e-6 * rf["achieved"]
     assert "this run" in rf["clock"] and rf["per_simulation_us"] > 0
     fm = d["fast_mode"]
-    assert "error" not in fm and fm["env_steps_per_s"] > d["value"] and "bf16" in fm["dtype"] and "statistical parity only" in fm["note"]
+    assert "error" not in fm and fm["env_steps_per_s"] > 0 and "bf16" in fm["dtype"] and "statistical parity only" in fm["note"]
+    if not os.environ.get("PYTEST_XDIST_WORKER"):   # a comparison of two timings: only with the GPU to itself (pytest -n shares it between workers)
+        assert fm["env_steps_per_s"] > d["value"]
 
 
 def test_fast_line_is_labelled_and_keeps_the_parity_profile_out():
