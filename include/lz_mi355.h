@@ -255,7 +255,11 @@ typedef struct lz_model_cfg {
     /* 0: parity mode -- fp32 arithmetic throughout (the default; every parity claim is about this mode).
      * 1: fast mode (last arm; reported separately, statistical parity only): the 3x3 convolutions of the recurrent
      *    chain and the LSTM gate product run on bf16 MFMA (weights and the multiplied activations rounded to bf16, fp32 accumulation,
-     *    fp32 normalisation / cell / heads / tree).  EfficientZeroModel / MuZeroModel (conv) on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64 latent) observations only. */
+     *    fp32 normalisation / cell / heads / tree).  EfficientZeroModel / MuZeroModel (conv) on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64 latent) observations only.
+     * 2: parity mode on the fp32 matrix instructions only: the 3x3 convolutions of the tower and of the recurrent chain keep the kernels
+     *    of rounds 1-4 (Winograd / direct form on v_mfma_f32_*) instead of the split-bf16 products (three exact bf16 planes per operand, six
+     *    plane products per k-step) that mode 0 uses since round 5 -- the same 1e-5 (1 + |x|) parity bound, other roundings, slower; per
+     *    model what LZ_CHAIN_NO_SPLIT=1 LZ_CONV_NO_SPLIT=1 select per process. */
     int precision;
 } lz_model_cfg;
 

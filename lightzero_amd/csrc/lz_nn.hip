@@ -2403,8 +2403,13 @@ static void launch_conv_bf(const lz_conv_args &a, hipStream_t s)
 // three planes, [nt][k step][plane][64 lanes][8 bf16] -- stream from L2 one k-step ahead (216 registers would be needed to keep a
 // 64-channel layer's resident).
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2 ? 1 : 2))) void k_conv_s3(lz_conv_args a, int ntiles, int TR)
+// DUAL (round 6; the downsample block's conv1 and its shortcut conv3, common.py:314: both 3x3 stride 2 on the SAME input): one launch of
+// 512-thread workgroups computes both -- waves 0-3 the first convolution (a), waves 4-7 the second (d: its own weights, BatchNorm, ReLU flag
+// and output) on the halo that is staged ONCE.  The stride-2 instance is one workgroup per CU (106 KB of halo planes): per tile it spent
+// 19 k cycles for 5.2 k cycles of matrix work, most of them staging; the second convolution rides on the same staging.
+struct lz_conv_second { const void *w3; const float *scale, *shift; float *out; int relu; };
+template <int CIN, int COUT, int STRIDE, bool DUAL = false>
+__global__ __launch_bounds__(DUAL ? 512 : 256) __attribute__((amdgpu_waves_per_eu(DUAL ? 2 : (STRIDE == 2 ? 1 : 2)))) void k_conv_s3(lz_conv_args a, int ntiles, int TR, lz_conv_second d)
 {
     // Wave roles.  A wave owns TWO 16-channel output tiles for three 16-pixel tiles: every pixel fragment read from LDS feeds 4 MFMAs
     // (with one channel tile per wave it fed 2, and the LDS read pipe -- 324 KB per 96-pixel tile, 2.5 k cycles at 128 B/clk -- was as
@@ -2415,10 +2420,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
     constexpr bool TSPLIT = NP == 1;
     constexpr int KC = CIN / 32, KS = 9 * KC;           // k steps of 32: (tap, 32-channel block)
     constexpr int PBq = STRIDE == 2 ? 5 : (CIN == 32 ? 6 : 10), PB = PBq * 8;   // pixel pitch in bf16 (k_conv_bf's: conflict-free ds_read_b128)
-    constexpr int C4 = CIN / 4, NLD = STRIDE == 2 ? 14 : (CIN == 32 ? 7 : 10);  // 16-byte fp32 pieces per pixel; pieces per thread and halo (the launcher checks the bound)
+    constexpr int NTHR = DUAL ? 512 : 256;
+    constexpr int C4 = CIN / 4, NLD = STRIDE == 2 ? (DUAL ? 7 : 14) : (CIN == 32 ? 7 : 10);  // 16-byte fp32 pieces per pixel; pieces per thread and halo (the launcher checks the bound)
     static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "shapes of the tower");
+    static_assert(!DUAL || (COUT == 64 && STRIDE == 2), "the dual form is the downsample block's");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, second = DUAL ? (tid >> 8) : 0;   // second: this wave computes the second convolution
     const int np = TSPLIT ? 0 : (wv & 1), mg = TSPLIT ? (wv & 1) : (wv >> 1);
     // (two workgroups share a CU and wave i of both sits on SIMD i: the second one swaps the tap halves so that every SIMD gets 5 + 4 taps)
     const int th = TSPLIT ? ((wv >> 1) ^ ((blockIdx.x >> 8) & 1)) : 0;
@@ -2430,12 +2437,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
     const int hplane = ((HR * HC * PB + 7) & ~7);       // bf16 per plane
     __bf16 *sH = reinterpret_cast<__bf16 *>(smem);      // [3 planes][HR][HC][PB]
     float *sX = reinterpret_cast<float *>(sH + 3 * hplane);   // TSPLIT: [pixel group][sending half][3 tiles][64 lanes][4] partial sums
-    const float *in = a.in, *res = a.residual;
-    float *out = a.out;
-    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(a.w3) + (size_t)(2 * np) * KS * 3 * 64 + lane;   // [nt][ks][plane][64 lanes]; the pair's second tile: + KS * 3 * 64
+    const float *in = a.in, *res = second ? nullptr : a.residual;
+    float *out = second ? d.out : a.out;
+    const bool relu_on = (second ? d.relu : a.relu) != 0;
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(second ? d.w3 : a.w3) + (size_t)(2 * np) * KS * 3 * 64 + lane;   // [nt][ks][plane][64 lanes]; the pair's second tile: + KS * 3 * 64
     // folded-BatchNorm scale | shift wait in LDS for the epilogue (16 registers across the k loop otherwise: the 64-channel instance spilled)
-    float *sSS = sX + (TSPLIT ? 4 * 3 * 256 : 0);              // [2][COUT]
-    if (tid < 2 * COUT) sSS[tid] = tid < COUT ? a.scale[tid] : a.shift[tid - COUT];
+    float *sSS = sX + (TSPLIT ? 4 * 3 * 256 : 0) + second * 2 * COUT;   // [2][COUT] (DUAL: one block per convolution)
+    {
+        const int t2 = tid & 255;
+        const float *scp = second ? d.scale : a.scale, *shp = second ? d.shift : a.shift;
+        if (t2 < 2 * COUT) sSS[t2] = t2 < COUT ? scp[t2] : shp[t2 - COUT];
+    }
     const int co4b = (2 * np) * 16 + 4 * (lane >> 4);          // first channel of this lane in the pair's first tile (second: + 16)
     int pbase[3], prow[3], pcol[3];
 #pragma unroll
@@ -2449,10 +2461,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
     int hsrc[NLD], hpk[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-        const int idx = min(u * 256 + tid, n4 - 1);
+        const int idx = min(u * NTHR + tid, n4 - 1);
         const int pix = idx / C4, c4 = idx - pix * C4, hr = pix / HC, hc = pix - hr * HC, ix = hc - 1;
         hsrc[u] = min(max(ix, 0), Win - 1) * CIN + c4 * 4;
-        hpk[u] = ((u * 256 + tid < n4) ? pix * PB + c4 * 4 + 1 : 0) | (hr << 20) | (((ix >= 0) & (ix < Win)) ? (1 << 30) : 0);
+        hpk[u] = ((u * NTHR + tid < n4) ? pix * PB + c4 * 4 + 1 : 0) | (hr << 20) | (((ix >= 0) & (ix < Win)) ? (1 << 30) : 0);
     }
     f32x4 pv[NLD];
     auto prefetch = [&](int tile) {   // the whole fp32 halo of a tile in flight at once (clamped addresses, zero outside the image by select)
@@ -2596,7 +2608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STRIDE == 2
                 for (int q = 0; q < 4; ++q) {
                     float v = acc[n][i][q] * scn[q] + shn[q];
                     v += n == 0 ? rv0[i][q] : rv1[i][q];
-                    ov[q] = a.relu ? fmaxf(v, 0.0f) : v;
+                    ov[q] = relu_on ? fmaxf(v, 0.0f) : v;
                 }
                 if (oy0 + prow[i] < Hout) *reinterpret_cast<f32x4 *>(out + (((size_t)img * Hout + oy0 + prow[i]) * Wout + pcol[i]) * COUT + c4o) = ov;
             }
@@ -2621,9 +2633,10 @@ static bool launch_conv_s3(const lz_conv_args &a, hipStream_t s)
     const int ntiles = a.B * ((a.Hout + TR - 1) / TR);
     const int per_cu = lds > 76 * 1024 ? 1 : 2;
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;   // persistent
-    hipLaunchKernelGGL((k_conv_s3<CIN, COUT, STRIDE>), dim3(grid), dim3(256), lds, s, a, ntiles, TR);
+    hipLaunchKernelGGL((k_conv_s3<CIN, COUT, STRIDE>), dim3(grid), dim3(256), lds, s, a, ntiles, TR, lz_conv_second{});
     return true;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // The same chain for narrow networks (num_channels = 32 | 16: the reference's gomoku / tictactoe configs,
@@ -4051,6 +4064,30 @@ static void launch_wino(const lz_conv_args &a, hipStream_t s)
 void lz_launch_hinv_nn(const float *d_in, float *d_out, int64_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(k_hinv_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
+}
+
+// the downsample block's two stride-2 convolutions of one input in one launch (k_conv_s3<32, 64, 2, true>); false: not applicable --
+// the caller launches them one after the other.  LZ_CONV_NO_DUAL=1 keeps the two launches (A/B runs).
+bool lz_launch_conv3x3_pair(const lz_conv_args &a, const lz_conv_args &b, int cin, int stride, hipStream_t s)
+{
+    static const char *off = getenv("LZ_CONV_NO_DUAL"), *nosplit = getenv("LZ_CONV_NO_SPLIT"), *direct = getenv("LZ_CONV_DIRECT");
+    if (off || nosplit || direct) return false;
+    if (!(cin == 32 && a.Cout == 64 && b.Cout == 64 && stride == 2) || !a.w3 || !b.w3 || a.act_bf16 || b.act_bf16) return false;
+    if (a.in != b.in || a.gather_ix || b.gather_ix || a.act_table || b.act_table || a.residual || b.residual) return false;
+    if (a.B != b.B || a.Hin != b.Hin || a.Win != b.Win || a.Hout != b.Hout || a.Wout != b.Wout || 96 % a.Wout != 0) return false;
+    const int TR = 96 / a.Wout;
+    const int HR = (TR - 1) * 2 + 3, HC = (a.Wout - 1) * 2 + 3;
+    constexpr int PB = 5 * 8, NLD = 7;
+    if (HR * HC * (32 / 4) > NLD * 512) return false;
+    const size_t lds = (size_t)3 * (((size_t)HR * HC * PB + 7) & ~(size_t)7) * 2 + 2 * 2 * 64 * 4;
+    if (lds > 150 * 1024) return false;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_conv_s3<32, 64, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    const int ntiles = a.B * ((a.Hout + TR - 1) / TR);
+    const int grid = ntiles < 256 ? ntiles : 256;   // persistent, one workgroup per CU
+    lz_conv_second d{b.w3, b.scale, b.shift, b.out, b.relu};
+    hipLaunchKernelGGL((k_conv_s3<32, 64, 2, true>), dim3(grid), dim3(512), lds, s, a, ntiles, TR, d);
+    return true;
 }
 
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s)

@@ -31,6 +31,9 @@ struct lz_conv_args {
 };
 
 void lz_launch_conv3x3(const lz_conv_args &a, int cin, int stride, hipStream_t s);
+// two convolutions of the SAME input in one launch (the downsample block's conv1 and shortcut conv3: parity mode, 32 -> 64, stride 2);
+// false = no such instance for these arguments, nothing was launched
+bool lz_launch_conv3x3_pair(const lz_conv_args &a, const lz_conv_args &b, int cin, int stride, hipStream_t s);
 
 // first layer of DownSample: conv3x3 stride 2 from NCHW obs [B][C][H][W] (C <= 4... any small C) to NHWC
 void lz_launch_conv_first(const float *obs_nchw, const float *w /*[9][C][Cout]*/, const float *scale,

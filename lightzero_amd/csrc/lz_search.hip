@@ -54,10 +54,10 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
     LZ_REQUIRE(cfg->model_type >= 0 && cfg->model_type <= 4, "model_type must be 0 (EfficientZeroModel), 1 (MuZeroModel), 2 (MuZeroModelMLP), 3 (EfficientZeroModelMLP) or 4 (SampledEfficientZeroModelMLP)");
     LZ_REQUIRE(cfg->support_size > 0 && cfg->support_size <= 768, "support_size must be in [1, 768]");
     LZ_REQUIRE(cfg->reward_support_size >= 0 && cfg->reward_support_size <= 768, "reward_support_size must be in [0, 768] (0 = the value support)");
-    LZ_REQUIRE(cfg->precision == 0 || (cfg->precision == 1 && (cfg->model_type == 0 || cfg->model_type == 1) && cfg->num_of_sampled_actions == 0 &&
+    LZ_REQUIRE(cfg->precision == 0 || cfg->precision == 2 || (cfg->precision == 1 && (cfg->model_type == 0 || cfg->model_type == 1) && cfg->num_of_sampled_actions == 0 &&
                                         cfg->downsample && (cfg->obs_h == 96 || cfg->obs_h == 64) && cfg->obs_c == 4 && cfg->num_channels == 64 &&
                                         (cfg->model_type == 1 || cfg->lstm_hidden_size == 512)),
-               "precision must be 0 (fp32, parity mode) or 1 (bf16 fast mode: EfficientZeroModel (LSTM 512) / MuZeroModel with 4x96x96 -> 6x6x64 or 4x64x64 -> 8x8x64)");
+               "precision must be 0 (fp32, parity mode), 2 (parity mode on the fp32 matrix instructions only) or 1 (bf16 fast mode: EfficientZeroModel (LSTM 512) / MuZeroModel with 4x96x96 -> 6x6x64 or 4x64x64 -> 8x8x64)");
     LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || cfg->model_type == 2 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
                "a reward support of its own: the MuZero models only (the EfficientZero drivers transform the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {
@@ -530,7 +530,7 @@ static int refresh_program_build(lz_engine *e)
     p.tried = true;
     p.n_allocs = m->allocs.size();
     if (m->cfg.model_type >= 2) { p.why = "vector-observation (MLP) models re-lay their weights out on the host"; return LZ_OK; }
-    if (m->cfg.precision != 0) { p.why = "fast mode (bf16 fragments) re-lays its weights out on the host"; return LZ_OK; }
+    if (m->cfg.precision == 1) { p.why = "fast mode (bf16 fragments) re-lays its weights out on the host"; return LZ_OK; }
     if (!m->finalized || m->raw_stale) { p.why = "no finalized host copy of the weights to record from"; return LZ_OK; }
     RefreshRec rec;
     std::map<std::string, HostTensor> shadow;
@@ -823,14 +823,18 @@ static int ensure_ws(lz_model *m, int B)
 static int act_dyn(const lz_model_cfg &c) { return (c.model_type == 0 && c.num_of_sampled_actions > 0 && c.activation == 1) ? 2 : 1; }
 static int act_pred(const lz_model_cfg &c) { return (c.model_type == 0 && c.num_of_sampled_actions > 0) ? 2 : 1; }
 
-static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
-                 int relu, hipStream_t s, int act_bf16 = 0)
+static lz_conv_args conv_args(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, const float *residual, int relu, int act_bf16)
 {
     lz_conv_args a{};
     a.act_bf16 = act_bf16;
     a.in = in; a.w = w.w; a.wf = w.wf; a.uf = w.uf; a.wb = w.wt; a.w3 = w.w3; a.scale = w.scale; a.shift = w.shift; a.residual = residual; a.out = out;
     a.B = B; a.Hin = Hin; a.Win = Hin; a.Hout = Hout; a.Wout = Hout; a.Cout = w.cout; a.relu = relu;
-    lz_launch_conv3x3(a, w.cin, stride, s);
+    return a;
+}
+static void conv(const ConvW &w, const float *in, float *out, int B, int Hin, int Hout, int stride, const float *residual,
+                 int relu, hipStream_t s, int act_bf16 = 0)
+{
+    lz_launch_conv3x3(conv_args(w, in, out, B, Hin, Hout, residual, relu, act_bf16), w.cin, stride, s);
 }
 
 __global__ void k_zero_words(unsigned *__restrict__ p, int n)
@@ -1035,9 +1039,12 @@ extern "C" int lz_initial_inference(lz_roots *r, const float *d_obs)
     LZ_STAGE();
     conv(m->r1b, w1, w2, B, S1, S1, 1, w0, 1, s, bf);            // w2: S1 x S1 x 32
     LZ_STAGE();
-    conv(m->dn1, w2, w0, B, S1, S2, 2, nullptr, 1, s, bf);       // w0: S2 x S2 x 64
+    // conv1 (w0: S2 x S2 x 64) and the identity path's conv3 (w1: no norm, no act) read the same tensor: one launch where the pair has an instance
+    const bool pair = m->debug_stop == 0 && m->dn1.cin == m->dn3.cin &&
+                      lz_launch_conv3x3_pair(conv_args(m->dn1, w2, w0, B, S1, S2, nullptr, 1, bf), conv_args(m->dn3, w2, w1, B, S1, S2, nullptr, 0, bf), m->dn1.cin, 2, s);
+    if (!pair) conv(m->dn1, w2, w0, B, S1, S2, 2, nullptr, 1, s, bf);
     LZ_STAGE();
-    conv(m->dn3, w2, w1, B, S1, S2, 2, nullptr, 0, s, bf);       // w1: identity path (no norm, no act)
+    if (!pair) conv(m->dn3, w2, w1, B, S1, S2, 2, nullptr, 0, s, bf);
     LZ_STAGE();
     conv(m->dn2, w0, w2, B, S2, S2, 1, w1, 1, s, bf);            // w2: S2 x S2 x 64
     LZ_STAGE();
@@ -2119,7 +2126,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_SIM_ONE_LAUNCH", "LZ_LSTM_NO_OVL", "LZ_HEADS_MM64"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CONV_NO_DUAL", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_SIM_ONE_LAUNCH", "LZ_LSTM_NO_OVL", "LZ_HEADS_MM64"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

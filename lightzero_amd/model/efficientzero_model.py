@@ -71,11 +71,14 @@ class EfficientZeroModel(object):
                  reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
                  reward_support_range=(-300., 301., 1.), value_support_range=(-300., 301., 1.), downsample=True,
                  categorical_distribution=True, norm_type='BN', discrete_action_encoding_type='one_hot',
-                 engine=None, fast_mode=False, **kwargs):
+                 engine=None, fast_mode=False, fp32_matrix=False, **kwargs):
         """``fast_mode=True`` (not a reference argument): lz_model_cfg.precision = 1 -- the 3x3 convolutions of the representation tower and
         of the recurrent chain and the LSTM gate product on bf16 MFMA (fp32 accumulation; heads, h^-1 and the tree unchanged); statistical
         parity only, reported separately from the parity-mode numbers (last arm).  EfficientZeroModel /
-        MuZeroModel on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64) observations."""
+        MuZeroModel on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64) observations.
+        ``fp32_matrix=True`` (not a reference argument): lz_model_cfg.precision = 2 -- parity mode with the 3x3 convolutions on the fp32 matrix
+        instructions (the kernels of rounds 1-4) instead of the split-bf16 products of the default parity mode: same parity bound, other
+        roundings, slower; the per-model form of LZ_CHAIN_NO_SPLIT=1 LZ_CONV_NO_SPLIT=1."""
         if not 1 <= int(num_res_blocks) <= 3 or norm_type != 'BN' or not categorical_distribution \
                 or discrete_action_encoding_type not in ('one_hot', 'not_one_hot'):
             raise NotImplementedError("engine model: num_res_blocks in 1..3, norm_type='BN', categorical_distribution=True, "
@@ -122,6 +125,11 @@ class EfficientZeroModel(object):
                     or self.observation_shape not in ((4, 96, 96), (4, 64, 64)) or getattr(self, "num_of_sampled_actions", 0):
                 raise NotImplementedError("fast_mode: EfficientZeroModel / MuZeroModel on 4x96x96 (6x6x64 latent) or 4x64x64 (8x8x64) observations")
             cfg.precision = 1
+        self.fp32_matrix = bool(fp32_matrix)
+        if self.fp32_matrix:
+            if self.fast_mode:
+                raise ValueError("fast_mode and fp32_matrix exclude each other")
+            cfg.precision = 2
         self._create(cfg)
 
     def _create(self, cfg):

@@ -59,7 +59,7 @@ def test_hip_network_matches_reference_module_outputs(name):
     check_case(name, case, g, sd)
 
 
-def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None):
+def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None, engine_kw=None, keep=None):
     """engine model with the weights ``sd`` on the seeded inputs of ``case`` against the arrays ``g`` (the golden file's layout).
     ``g64``: the same arrays from a binary64 evaluation of the same network on the same teacher-forced inputs -- the device's distance
     from THEM is recorded next to its distance from the fp32 reference (entry field "device_vs_binary64") and returned under "vs64"."""
@@ -69,6 +69,7 @@ def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None):
     ekw = dict(kw)
     if fam in ("mz_mlp", "ez_mlp"):
         ekw["norm_type"] = "BN"
+    ekw.update(engine_kw or {})   # arguments of the engine model only (fast_mode, fp32_matrix)
     model = nn_cases.engine_class(fam)(**ekw).load_state_dict(sd)
     roots = _roots_for(case, model, B)
     obs, actions = nn_cases.inputs(case)
@@ -80,6 +81,8 @@ def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None):
     out = model.initial_inference(obs, roots)
     lat = np.zeros(g["init_latent"].shape, np.float32)
     L.check(lib.lz_roots_read_latent(roots._h, 0, lat.reshape(-1)))
+    if keep is not None:
+        keep["init_latent"] = lat.copy()
     worst = dict(latent=_rel(lat, g["init_latent"]), policy=_rel(out.policy_logits, g["init_policy"]),
                  scalar=_rel(out.value, g["init_value"]), logits=0.0, hc=0.0)
     w64 = dict(latent=0.0, policy=0.0, logits=0.0, hc=0.0)
@@ -138,3 +141,18 @@ def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None):
     if g64 is not None:
         worst = dict(worst, vs64=w64)
     return worst
+
+
+@pytest.mark.parametrize("name", ["ez_atari96", "ez_atari64", "mz_go9"])
+def test_fp32_matrix_arithmetic_is_a_model_argument(name):
+    """lz_model_cfg.precision = 2 (EfficientZeroModel(fp32_matrix=True)): parity mode on the fp32 matrix instructions -- the per-model form of
+    LZ_CHAIN_NO_SPLIT=1 LZ_CONV_NO_SPLIT=1 (the choice was a process-wide environment switch).  The same goldens at the same bounds
+    as the default (split-bf16) arithmetic, in the same process, and other bits than the default path's -- the other kernels did run."""
+    from oracle import torch_models as tm
+    case = nn_cases.CASES[name]
+    g = np.load(os.path.join(GOLD, "nn_%s.npz" % name))
+    sd = tm.synthetic_init(nn_cases.oracle_class(tm, case["family"])(**case["kw"]), seed=case["seed"]).state_dict()
+    a, b = {}, {}
+    check_case(name, case, g, sd, record="golden_fp32_matrix/", engine_kw=dict(fp32_matrix=True), keep=a)
+    check_case(name, case, g, sd, keep=b)
+    assert a["init_latent"].shape == b["init_latent"].shape and not np.array_equal(a["init_latent"], b["init_latent"])
