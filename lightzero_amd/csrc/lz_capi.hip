@@ -161,6 +161,7 @@ int lz_roots_alloc(lz_engine *e, int variant, int B, int A, int max_sims, lz_roo
     t.actions = D ? (float *)(base + o_act) : nullptr; t.res_last_action_f = D ? (float *)(base + o_laf) : nullptr;
     t.rng_epoch = (uint32_t *)(base + o_ep);
     r->explore_tab = (float *)(base + o_ep + 256);
+    r->tab_valid = false;
     t.node_bidx = (int32_t *)(base + o_bidx); t.res_noinf = (int32_t *)(base + o_noinf); t.node_link = (uint64_t *)(base + o_link);
     // no kernel may depend on what the allocator handed back (epoch, legal lists, results).  On the engine's own stream: that
     // stream is non-blocking, so a null-stream memset queued behind another library's work (torch's default stream) could land

@@ -140,6 +140,7 @@ struct lz_roots {
     float *h_pool = nullptr;        // [NN][B][H]       LSTM state pools (EfficientZero)
     float *c_pool = nullptr;
     float *explore_tab = nullptr;   // [128] lz_traverse_args::tab of the running search (inside the slab)
+    int tab_base = -1; float tab_init = 0.0f; bool tab_valid = false;   // what explore_tab was last filled for (lz_search refills it on a change: no launch per search)
     float *sim_vp = nullptr;        // [NN][B]          value prefix / reward of node n (after h^-1)
     float *sim_value = nullptr;     // [NN][B]
     float *sim_logits = nullptr;    // [NN][B][A]

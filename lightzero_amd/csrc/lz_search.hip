@@ -1992,6 +1992,15 @@ static void recurrent(lz_roots *r, int sim, int horizon, hipStream_t s, const lz
               r->sim_vp + (size_t)slot * B, r->dbg_logits[1], s);
 }
 
+// the exploration-factor table of lz_traverse_args::tab: a function of (pb_c_base, pb_c_init) -- computed when they change, not once per search
+// (it was a 4.6 us launch at the head of every captured search)
+static void ensure_explore_tab(lz_roots *r, int pb_c_base, float pb_c_init, hipStream_t s)
+{
+    if (!r->explore_tab || (r->tab_valid && r->tab_base == pb_c_base && r->tab_init == pb_c_init)) return;
+    lz_tree_launch_explore_tab(r->explore_tab, pb_c_base, pb_c_init, s);
+    r->tab_base = pb_c_base; r->tab_init = pb_c_init; r->tab_valid = true;
+}
+
 // the whole search: traverse, then per simulation [network, expand + backup fused with the next selection]
 static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta, float delta, int horizon, hipStream_t s)
 {
@@ -1999,7 +2008,7 @@ static void enqueue_search(lz_roots *r, int num_simulations, lz_traverse_args ta
     const size_t B = t.B;
     const size_t A = policy_width_of(r->eng->model, t);
     ta.counter = 0;
-    if (r->explore_tab) { lz_tree_launch_explore_tab(r->explore_tab, ta.pb_c_base, ta.pb_c_init, s); ta.tab = r->explore_tab; }
+    if (r->explore_tab) ta.tab = r->explore_tab;   // filled by lz_search (ensure_explore_tab) OUTSIDE the captured sequence: it depends on the search parameters only
     if (t.variant == LZ_TREE_SAMPLED_EFFICIENTZERO) {
         lz_tree_launch_minmax_reset(t, s);  // a fresh MinMaxStatsList per search (mcts_ctree.py:778-779)
         // SampledEfficientZeroMCTSCtree.search (mcts_ctree_sampled.py:480-600): the leaf's K actions are drawn on the
@@ -2198,6 +2207,7 @@ extern "C" int lz_search(lz_roots *r, int num_simulations, int pb_c_base, float 
         }
         return LZ_OK;
     };
+    ensure_explore_tab(r, pb_c_base, pb_c_init, s);
     if (!use_graph) {
         enqueue_search(r, num_simulations, ta, value_delta_max, lstm_horizon_len, s);
         LZ_HIP_CHECK(hipGetLastError());
