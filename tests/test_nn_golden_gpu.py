@@ -155,4 +155,8 @@ def test_fp32_matrix_arithmetic_is_a_model_argument(name):
     a, b = {}, {}
     check_case(name, case, g, sd, record="golden_fp32_matrix/", engine_kw=dict(fp32_matrix=True), keep=a)
     check_case(name, case, g, sd, keep=b)
-    assert a["init_latent"].shape == b["init_latent"].shape and not np.array_equal(a["init_latent"], b["init_latent"])
+    assert a["init_latent"].shape == b["init_latent"].shape
+    # (under the process-wide switches that take the split kernels away from the DEFAULT model too -- tests/test_kernel_variants_gpu.py runs this
+    # file with each of them -- the two models run the same kernels)
+    if not any(os.environ.get(k) for k in ("LZ_CHAIN_NO_SPLIT", "LZ_CONV_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_CONV_DIRECT")):
+        assert not np.array_equal(a["init_latent"], b["init_latent"])
