@@ -261,6 +261,13 @@ typedef struct lz_model_cfg {
      *    plane products per k-step) that mode 0 uses since round 5 -- the same 1e-5 (1 + |x|) parity bound, other roundings, slower; per
      *    model what LZ_CHAIN_NO_SPLIT=1 LZ_CONV_NO_SPLIT=1 select per process. */
     int precision;
+    /* ---- MLP model family, two more keywords of the reference constructors (muzero_model_mlp.py:30,33; efficientzero_model_mlp.py:32,34;
+     * sampled_efficientzero_model_mlp.py:33,36) */
+    int state_norm;         /* 1: state_norm=True -- the latent state is renormalised to [0, 1] over its features after the representation and
+                               after the dynamics network (lzero/model/utils.py:242-271: (x - min) / max(max - min, 1e-8)); the reward / value-prefix
+                               path reads the un-normalised next latent, as in the reference's dynamics networks */
+    int scalar_heads;       /* 1: categorical_distribution=False -- value and reward / value-prefix heads have ONE output, the scaled scalar itself:
+                               h^-1 is applied to it directly (scaling_transform.py:84-92); support_size (and reward_support_size) must be 1 */
 } lz_model_cfg;
 
 /* One model per engine (creating another replaces it: roots of the old one re-size their pools on the next inference).

@@ -23,7 +23,7 @@ class ModelCfg(ctypes.Structure):
                 ("activation", ctypes.c_int), ("res_connection_in_dynamics", ctypes.c_int), ("action_encoding", ctypes.c_int),
                 ("num_of_sampled_actions", ctypes.c_int), ("sigma_type", ctypes.c_int), ("bound_type", ctypes.c_int),
                 ("ln_eps", ctypes.c_float), ("num_res_blocks", ctypes.c_int), ("reward_support_size", ctypes.c_int),
-                ("reward_support_min", ctypes.c_float), ("precision", ctypes.c_int)]
+                ("reward_support_min", ctypes.c_float), ("precision", ctypes.c_int), ("state_norm", ctypes.c_int), ("scalar_heads", ctypes.c_int)]
 
 
 _lib = None

@@ -19,6 +19,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float red_sum(float v) { return wave_sum(v); }    // over the wave that owns the row
 __device__ __forceinline__ float red_max(float v) { return wave_max(v); }
 __device__ __forceinline__ float red16_sum(float v) { return group_sum<16>(v); }  // the 16 lanes (one DPP row) that share a row while staging
+// max | min over the same 16 lanes (quad permutes, then the two row mirrors: every lane of the row gets the result)
+template <bool MAX>
+__device__ __forceinline__ float red16_ext(float v)
+{
+#define LZ_DPPE(ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false))
+    { const float o = LZ_DPPE(0xB1); v = MAX ? fmaxf(v, o) : fminf(v, o); }
+    { const float o = LZ_DPPE(0x4E); v = MAX ? fmaxf(v, o) : fminf(v, o); }
+    { const float o = LZ_DPPE(0x141); v = MAX ? fmaxf(v, o) : fminf(v, o); }
+    { const float o = LZ_DPPE(0x140); v = MAX ? fmaxf(v, o) : fminf(v, o); }
+#undef LZ_DPPE
+    return v;
+}
 // GELU(approximate='tanh') with tanh(y) = 1 - 2 / (1 + e^{2y}) on the hardware exp / rcp (a libm tanhf is ~60 instructions
 // with range branches; these kernels are a few thousand instructions in total).  |error| < 3e-7 absolute.
 __device__ __forceinline__ float gelu_tanh(float u)
@@ -121,18 +133,34 @@ __global__ __launch_bounds__(256) void k_dense(lz_dense_args a)
             const float rstd_ln = 1.0f / sqrtf(red16_sum(sq) / (float)K1 + j.in_ln_eps);
             const float mean = has_ln ? mean_ln : 0.0f, rstd = has_ln ? rstd_ln : 1.0f;
             const bool wr = j.in_out && blockIdx.y == 0 && r0 + row < B;
+            // the transformed row stays in xv; state_norm=True (in_minmax) then renormalises it over the row: (x - min) / max(max - min, 1e-8),
+            // the same fp32 subtraction and division as lzero/model/utils.py:261-269
+            float rmn = __builtin_inff(), rmx = -__builtin_inff();
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
-                const int idx = part + 16 * i;
-                f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float u = (xv[i][q] - mean) * rstd;
                     u = has_ln ? u * gv[i][q] + bv[i][q] : u;
                     u = act_fn(u, j.in_act);
                     u += has_res ? rv[i][q] : 0.0f;
-                    v[q] = u;
+                    xv[i][q] = u;
+                    if (part + 16 * i < nv) { rmn = fminf(rmn, u); rmx = fmaxf(rmx, u); }
                 }
+            }
+            if (j.in_minmax != 0) {   // (uniform over the workgroup: a scalar branch around the divisions)
+                rmn = red16_ext<false>(rmn); rmx = red16_ext<true>(rmx);
+                const float d = rmx - rmn;
+                const float mm_den = d < 1e-8f ? 1e-8f : d;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xv[i][q] = (xv[i][q] - rmn) / mm_den;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int idx = part + 16 * i;
+                const f32x4 v = xv[i];
                 if (idx < nv) {
                     *reinterpret_cast<f32x4 *>(dst + 4 * idx) = v;
                     if (wr) *reinterpret_cast<f32x4 *>(j.in_out + (size_t)(r0 + row) * K1 + 4 * idx) = v;
@@ -257,6 +285,10 @@ __global__ __launch_bounds__(256) void k_rowfinal(lz_rowfinal_args a)
     if (b >= a.B) return;
     const int N = j.N;
     const float *y = j.logits + (size_t)b * N;
+    if (j.scalar) {   // categorical_distribution=False: value = logits (scaling_transform.py:88-89), then the same h^-1
+        if (lane == 0) j.out_scalar[b] = lz_inverse_scalar_transform(y[0]);
+        return;
+    }
     float mx = -__builtin_inff();
     for (int c = lane; c < N; c += 64) mx = fmaxf(mx, y[c]);
     mx = red_max(mx);
@@ -304,7 +336,7 @@ void lz_launch_dense(const lz_dense_args &a, hipStream_t s)
     int k1max = 0;
     for (int i = 0; i < a.njobs; ++i) k1max = std::max(k1max, a.job[i].K1);
     bool xf = false;
-    for (int i = 0; i < a.njobs; ++i) xf = xf || a.job[i].in_ln_g || a.job[i].in_act || a.job[i].in_res || a.job[i].in_out;
+    for (int i = 0; i < a.njobs; ++i) xf = xf || a.job[i].in_ln_g || a.job[i].in_act || a.job[i].in_res || a.job[i].in_out || a.job[i].in_minmax;
     const dim3 grid((a.B + 15) / 16, ncg, a.njobs), block(256);
     if (k1max <= 256) {
         if (xf) hipLaunchKernelGGL((k_dense<4, true>), grid, block, lds, s, a);

@@ -21,7 +21,7 @@ struct DenseW {
 struct lz_mlp_model {
     int OBS = 0, L = 0, H = 0, A = 0, ENC = 0, PA = 0, SUP = 0, RSUP = 0, Wmax = 0;   // RSUP: the reward head's support (MuZeroModelMLP may have its own)
     float rsup_min = 0.0f;
-    bool lstm = false, res = false, continuous = false;
+    bool lstm = false, res = false, continuous = false, state_norm = false, scalar = false;   // state_norm / scalar: lz_model_cfg::state_norm / scalar_heads
     int enc_mode = 2;  // lz_dense_job.x2_mode of the action encoding
     std::vector<DenseW> rep, dyn1, dyn2, rew, common, val, pol;
     float *lstm_w = nullptr, *lstm_wf = nullptr, *lstm_b = nullptr;
@@ -128,6 +128,7 @@ int lz_mlp_finalize(lz_engine *e)
     M.H = M.lstm ? c.lstm_hidden_size : 0;
     M.res = c.res_connection_in_dynamics != 0;
     M.continuous = c.model_type == 4 && c.action_encoding == 2;
+    M.state_norm = c.state_norm != 0; M.scalar = c.scalar_heads != 0;
     M.ENC = c.action_encoding == 1 ? 1 : M.A;
     M.enc_mode = c.action_encoding == 2 ? 1 : (c.action_encoding == 1 ? 3 : 2);
     M.PA = M.continuous ? 2 * M.A : M.A;
@@ -278,6 +279,7 @@ struct Act {
     const int32_t *res_gather = nullptr;
     int64_t res_slot_stride = 0;
     float *materialise = nullptr;
+    bool minmax = false;   // state_norm=True: the consumer renormalises the transformed row over its K columns (lz_dense_job::in_minmax)
 };
 
 // one inference as dependency levels of dense jobs (+ row finishers, + the LSTM after the jobs of `lstm_level`)
@@ -330,6 +332,7 @@ struct Program {
         j.in_ln_g = in.ln_g; j.in_ln_b = in.ln_b; j.in_ln_eps = ln_eps; j.in_act = in.act;
         j.in_res = in.res; j.in_res_gather = in.res_gather; j.in_res_slot_stride = in.res_slot_stride;
         j.in_out = in.materialise;
+        j.in_minmax = in.minmax ? 1 : 0;
         in.materialise = nullptr;  // one writer is enough
         j.wf = w.wf; j.bias = w.bias; j.scale = w.scale; j.shift = w.shift; j.N = w.N;
         j.act = w.ln_g ? 0 : w.act;  // with a LayerNorm the activation is deferred to the consumers together with it
@@ -384,6 +387,7 @@ int prediction(Program &P, int level, const lz_mlp_model &M, lz_roots *r, Act &l
     Act vout;
     const int lv = P.chain(lc + 1, M.val, pc, r->mt[6], r->mt[7], value_logits, &vout);
     value_final->logits = value_logits; value_final->N = M.SUP; value_final->support_min = support_min; value_final->out_scalar = out_value;
+    value_final->scalar = M.scalar ? 1 : 0;
     lz_dense_job *pl = nullptr;
     P.chain(lc + 1, M.pol, pc, r->mt[8], r->mt[9], out_policy, nullptr, &pl);
     if (M.continuous) { pl->final = 2; pl->final_split = M.A; pl->final_tanh = r->eng->model->cfg.bound_type == 1; }
@@ -408,6 +412,7 @@ int lz_mlp_initial_inference(lz_roots *r, const float *d_obs)
     Act latent;
     const int lr = P.chain(0, M.rep, obs, r->mt[0], r->mt[1], r->mt[2], &latent);
     latent.materialise = r->latent_pool;  // slot 0: written by the first consumer with the encoder's final LayerNorm applied
+    latent.minmax = M.state_norm;         // ... and, with state_norm=True, renormalised (muzero_model_mlp.py:220-221)
     lz_rowfinal_job vf{};
     const int lvv = prediction(P, lr + 1, M, r, latent, c.support_min, r->sim_value, r->sim_logits, r->dbg_logits[0], &vf);
     P.add_final(lvv + 1, vf);
@@ -450,7 +455,9 @@ void lz_mlp_recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     if (M.res) { next.res = r->latent_pool; next.res_gather = t.res_ix; next.res_slot_stride = (int64_t)lat_slot; }
     // the pool must hold the finished next latent (deferred norm / activation / residual applied): its first consumer writes
     // it; without any deferred transform the trunk's last layer writes the pool slot itself
-    const bool deferred = next.ln_g || next.act || next.res;
+    // state_norm=True (muzero_model_mlp.py:291-295, efficientzero_model_mlp.py:307-308): what the prediction network and the pool get is the
+    // renormalised next latent; the reward / value-prefix path below (`enc`) keeps the un-normalised one, like the reference's dynamics networks
+    const bool deferred = next.ln_g || next.act || next.res || M.state_norm;
     if (deferred) next.materialise = next_latent;
     else {
         P.levels[lv].back().out = next_latent;
@@ -458,6 +465,7 @@ void lz_mlp_recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     }
     // prediction first: it is the consumer that materialises the next latent
     Act enc = next;
+    next.minmax = M.state_norm;
     lz_rowfinal_job vf{};
     const int lvv = prediction(P, lv + 1, M, r, next, c.support_min, r->sim_value + (size_t)slot * B,
                                r->sim_logits + (size_t)slot * B * M.PA, r->dbg_logits[0], &vf);
@@ -481,6 +489,7 @@ void lz_mlp_recurrent(lz_roots *r, int sim, int horizon, hipStream_t s)
     const int lrw = P.chain(le + 1, M.rew, rin, r->mt[12], r->mt[1], r->dbg_logits[1], &rout);
     lz_rowfinal_job rf{};
     rf.logits = r->dbg_logits[1]; rf.N = M.RSUP; rf.support_min = M.rsup_min; rf.out_scalar = r->sim_vp + (size_t)slot * B;
+    rf.scalar = M.scalar ? 1 : 0;
     // both row finishers (value, value prefix / reward) share the last launch
     const int lfin = std::max(lrw, lvv) + 1;
     P.add_final(lfin, vf);

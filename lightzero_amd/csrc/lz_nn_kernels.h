@@ -218,6 +218,8 @@ struct lz_dense_job {
     const int32_t *in_res_gather;
     int64_t in_res_slot_stride;
     float *in_out;             // optional: the transformed rows, written by the column-group-0 workgroups ([B][K1])
+    int in_minmax;             // 1: after the transforms above the row is renormalised to [0, 1] over its K1 columns -- (x - min) / max(max - min, 1e-8):
+                               // state_norm=True of the MLP models (lzero/model/utils.py:242-271); what in_out receives is the renormalised row
     const float *x2;           // second input block (the action encoding); mode 1: float rows [B][K2]
     const int32_t *x2_idx;     // mode 2: one-hot(x2_idx[b]) of width K2 ; mode 3: the scalar x2_idx[b] / x2_div
     float x2_div;
@@ -242,6 +244,7 @@ struct lz_rowfinal_job {
     int N;
     float support_min;
     float *out_scalar;         // [B]
+    int scalar;                // 1: categorical_distribution=False -- N = 1, the head's output IS the scaled scalar: h^-1(logits[b]) (scaling_transform.py:84-92)
 };
 struct lz_rowfinal_args {
     lz_rowfinal_job job[4];

@@ -58,6 +58,9 @@ extern "C" int lz_model_create(lz_engine *e, const lz_model_cfg *cfg)
                                         cfg->downsample && (cfg->obs_h == 96 || cfg->obs_h == 64) && cfg->obs_c == 4 && cfg->num_channels == 64 &&
                                         (cfg->model_type == 1 || cfg->lstm_hidden_size == 512)),
                "precision must be 0 (fp32, parity mode), 2 (parity mode on the fp32 matrix instructions only) or 1 (bf16 fast mode: EfficientZeroModel (LSTM 512) / MuZeroModel with 4x96x96 -> 6x6x64 or 4x64x64 -> 8x8x64)");
+    LZ_REQUIRE((cfg->state_norm == 0 && cfg->scalar_heads == 0) || cfg->model_type >= 2, "state_norm / scalar_heads (categorical_distribution=False): the MLP model family only");
+    LZ_REQUIRE(cfg->scalar_heads == 0 || (cfg->support_size == 1 && (cfg->reward_support_size == 0 || cfg->reward_support_size == 1)), "scalar_heads: the heads have one output (support_size = 1)");
+    LZ_REQUIRE(cfg->state_norm == 0 || cfg->num_channels % 4 == 0, "state_norm: latent_state_dim must be a multiple of 4");
     LZ_REQUIRE(cfg->reward_support_size == 0 || cfg->model_type == 1 || cfg->model_type == 2 || (cfg->reward_support_size == cfg->support_size && cfg->reward_support_min == cfg->support_min),
                "a reward support of its own: the MuZero models only (the EfficientZero drivers transform the value prefix with the VALUE handle, mcts_ctree.py:839-841)");
     if (cfg->model_type >= 2) {

@@ -19,10 +19,16 @@ class _EngineModelMLP(EfficientZeroModel):
                  categorical_distribution=True, state_norm=False, discrete_action_encoding_type='one_hot', norm_type='BN',
                  res_connection_in_dynamics=False, continuous_action_space=False, num_of_sampled_actions=0,
                  sigma_type='conditioned', bound_type=None, engine=None, **kwargs):
-        if not categorical_distribution or state_norm:
-            raise NotImplementedError("engine model: categorical_distribution=True, state_norm=False")
         if value_support_range[2] != 1. or reward_support_range[2] != 1.:
             raise NotImplementedError("supports with step 1")
+        self.categorical_distribution = bool(categorical_distribution)
+        self.state_norm = bool(state_norm)
+        if not self.categorical_distribution:
+            # muzero_model_mlp.py:72-77: the value / reward heads have ONE output, the scaled scalar itself (h^-1 applied directly,
+            # scaling_transform.py:88-92); the support ranges are not looked at
+            reward_support_range = value_support_range = (0., 1., 1.)
+        if self.state_norm and int(latent_state_dim) % 4:
+            raise NotImplementedError("state_norm=True: latent_state_dim must be a multiple of 4")
         rsize = int(round((reward_support_range[1] - reward_support_range[0]) / reward_support_range[2]))
         vsize = int(round((value_support_range[1] - value_support_range[0]) / value_support_range[2]))
         own_reward_support = tuple(reward_support_range) != tuple(value_support_range)
@@ -55,6 +61,8 @@ class _EngineModelMLP(EfficientZeroModel):
                          1 if bound_type == 'tanh' else 0, 1e-5)
         if own_reward_support:   # MuZeroModelMLP: the MuZero driver transforms rewards with the REWARD handle (mcts_ctree.py:340-346)
             cfg.reward_support_size, cfg.reward_support_min = rsize, float(reward_support_range[0])
+        cfg.state_norm = 1 if self.state_norm else 0
+        cfg.scalar_heads = 0 if self.categorical_distribution else 1
         self._create(cfg)
 
     def _latent_shape(self):

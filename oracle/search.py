@@ -21,7 +21,7 @@ def ez_search(tree, roots, model, latent_state_roots, reward_hidden_state_roots,
               record=None, ist=None):
     """cfg: dict(num_simulations, pb_c_base, pb_c_init, discount_factor, value_delta_max, lstm_horizon_len).
     ``ist``: replaces the value_inverse_scalar_transform_handle (tests replay recorded post-transform scalars through it)."""
-    ist = ist or InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
+    ist = ist or InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), cfg.get("categorical_distribution", True), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         batch_size = roots.num
@@ -73,7 +73,7 @@ def ez_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, de
                        record=None):
     """obs: torch [B,C,H,W] on ``device``.  Returns (visit-count distributions, root values, predicted values,
     policy logits) like efficientzero.py:582-615."""
-    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
+    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), cfg.get("categorical_distribution", True), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         out = model.initial_inference(obs)
@@ -95,7 +95,7 @@ def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device
     """MuZeroMCTSCtree.search  lzero/mcts/tree_search/mcts_ctree.py:267-368 (the reference calls
     recurrent_inference twice per simulation, :338 and :340-345, and discards the first result; it is called once
     here, which leaves the outputs unchanged)."""
-    ist = ist or InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
+    ist = ist or InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), cfg.get("categorical_distribution", True), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         batch_size = roots.num
@@ -129,7 +129,7 @@ def mz_search(tree, roots, model, latent_state_roots, to_play_batch, cfg, device
 def mz_forward_collect(tree, model, obs, legal_actions, noises, to_play, cfg, device="cpu", roots_kwargs=None,
                        deterministic=None, record=None):
     """MuZeroPolicy._forward_collect up to get_distributions/get_values  lzero/policy/muzero.py:745-790."""
-    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), device=device)  # the policy builds it from cfg.model.*_support_range
+    ist = InverseScalarTransform(cfg.get("support_range", (-300., 301., 1.)), cfg.get("categorical_distribution", True), device=device)  # the policy builds it from cfg.model.*_support_range
     with torch.no_grad():
         model.eval()
         out = model.initial_inference(obs)

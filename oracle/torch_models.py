@@ -523,16 +523,25 @@ def _encode_action(action, latent, continuous, action_space_size, encoding):
     return torch.cat((latent, enc.to(latent.device).float()), dim=1)
 
 
+def renormalize(x):  # lzero/model/utils.py:242-271 with first_dim = 1 on a [B, K] tensor
+    mx, _ = torch.max(x, dim=1, keepdim=True)
+    mn, _ = torch.min(x, dim=1, keepdim=True)
+    den = mx - mn
+    den[den < 1e-8] = 1e-8
+    return (x - mn) / den
+
+
 class MuZeroModelMLP(nn.Module):  # lzero/model/muzero_model_mlp.py:13-338 (inference graph only)
     def __init__(self, observation_shape=4, action_space_size=2, latent_state_dim=128, reward_head_hidden_channels=(32,),
                  value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,), support_range=(-300., 301., 1.),
                  norm_type="BN", discrete_action_encoding_type="one_hot", res_connection_in_dynamics=False,
-                 reward_support_range=None, value_support_range=None):
+                 reward_support_range=None, value_support_range=None, categorical_distribution=True, state_norm=False):
         super().__init__()
         self.action_space_size, self.encoding = action_space_size, discrete_action_encoding_type
-        # muzero_model_mlp.py:73-74: the two heads are sized by their own supports
-        self.support_size = len(torch.arange(*(value_support_range or support_range)))
-        self.reward_support_size = len(torch.arange(*(reward_support_range or value_support_range or support_range)))
+        self.state_norm = state_norm
+        # muzero_model_mlp.py:72-77: the two heads are sized by their own supports; one output each without the categorical representation
+        self.support_size = len(torch.arange(*(value_support_range or support_range))) if categorical_distribution else 1
+        self.reward_support_size = len(torch.arange(*(reward_support_range or value_support_range or support_range))) if categorical_distribution else 1
         enc = action_space_size if discrete_action_encoding_type == "one_hot" else 1
         act = nn.ReLU(inplace=True)
         self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, None, norm_type)
@@ -543,12 +552,16 @@ class MuZeroModelMLP(nn.Module):  # lzero/model/muzero_model_mlp.py:13-338 (infe
 
     def initial_inference(self, obs):
         z = self.representation_network(obs)
+        if self.state_norm:   # muzero_model_mlp.py:220-221
+            z = renormalize(z)
         policy_logits, value = self.prediction_network(z)
         return MZNetworkOutput(value, [0. for _ in range(obs.size(0))], policy_logits, z)
 
     def recurrent_inference(self, latent_state, action):
         sa = _encode_action(action, latent_state, False, self.action_space_size, self.encoding)
         nxt, reward = self.dynamics_network(sa)
+        if self.state_norm:   # muzero_model_mlp.py:291-295 (the reward was computed on the un-normalised next latent)
+            nxt = renormalize(nxt)
         policy_logits, value = self.prediction_network(nxt)
         return MZNetworkOutput(value, reward, policy_logits, nxt)
 
@@ -557,10 +570,11 @@ class EfficientZeroModelMLP(nn.Module):  # lzero/model/efficientzero_model_mlp.p
     def __init__(self, observation_shape=4, action_space_size=2, lstm_hidden_size=512, latent_state_dim=256,
                  reward_head_hidden_channels=(32,), value_head_hidden_channels=(32,), policy_head_hidden_channels=(32,),
                  support_range=(-300., 301., 1.), norm_type="BN", discrete_action_encoding_type="one_hot",
-                 res_connection_in_dynamics=False):
+                 res_connection_in_dynamics=False, categorical_distribution=True, state_norm=False):
         super().__init__()
         self.action_space_size, self.encoding, self.lstm_hidden_size = action_space_size, discrete_action_encoding_type, lstm_hidden_size
-        self.support_size = len(torch.arange(*support_range))
+        self.state_norm = state_norm
+        self.support_size = len(torch.arange(*support_range)) if categorical_distribution else 1   # efficientzero_model_mlp.py:76-81
         enc = action_space_size if discrete_action_encoding_type == "one_hot" else 1
         act = nn.ReLU(inplace=True)
         self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, None, norm_type)
@@ -571,6 +585,8 @@ class EfficientZeroModelMLP(nn.Module):  # lzero/model/efficientzero_model_mlp.p
 
     def initial_inference(self, obs):
         z = self.representation_network(obs)
+        if self.state_norm:   # efficientzero_model_mlp.py:232-233
+            z = renormalize(z)
         policy_logits, value = self.prediction_network(z)
         B = obs.size(0)
         hc = (torch.zeros(1, B, self.lstm_hidden_size).to(obs.device), torch.zeros(1, B, self.lstm_hidden_size).to(obs.device))
@@ -579,6 +595,8 @@ class EfficientZeroModelMLP(nn.Module):  # lzero/model/efficientzero_model_mlp.p
     def recurrent_inference(self, latent_state, reward_hidden_state, action):
         sa = _encode_action(action, latent_state, False, self.action_space_size, self.encoding)
         nxt, hc, vp = self.dynamics_network(sa, reward_hidden_state)
+        if self.state_norm:   # efficientzero_model_mlp.py:307-308
+            nxt = renormalize(nxt)
         policy_logits, value = self.prediction_network(nxt)
         return EZNetworkOutput(value, vp, policy_logits, nxt, hc)
 
@@ -588,11 +606,12 @@ class SampledEfficientZeroModelMLP(nn.Module):  # lzero/model/sampled_efficientz
                  reward_head_hidden_channels=(256,), value_head_hidden_channels=(256,), policy_head_hidden_channels=(256,),
                  support_range=(-300., 301., 1.), continuous_action_space=True, num_of_sampled_actions=20,
                  sigma_type="conditioned", fixed_sigma_value=0.3, bound_type=None, norm_type="LN",
-                 discrete_action_encoding_type="one_hot", res_connection_in_dynamics=True):
+                 discrete_action_encoding_type="one_hot", res_connection_in_dynamics=True, categorical_distribution=True, state_norm=False):
         super().__init__()
         self.action_space_size, self.encoding, self.lstm_hidden_size = action_space_size, discrete_action_encoding_type, lstm_hidden_size
         self.continuous_action_space, self.num_of_sampled_actions = continuous_action_space, num_of_sampled_actions
-        self.support_size = len(torch.arange(*support_range))
+        self.state_norm = state_norm
+        self.support_size = len(torch.arange(*support_range)) if categorical_distribution else 1   # sampled_efficientzero_model_mlp.py:95-100
         enc = action_space_size if (continuous_action_space or discrete_action_encoding_type == "one_hot") else 1
         act = nn.GELU(approximate="tanh")
         self.representation_network = RepresentationNetworkMLP(observation_shape, latent_state_dim, act, norm_type)
@@ -604,6 +623,8 @@ class SampledEfficientZeroModelMLP(nn.Module):  # lzero/model/sampled_efficientz
 
     def initial_inference(self, obs):
         z = self.representation_network(obs)
+        if self.state_norm:   # sampled_efficientzero_model_mlp.py:269-270
+            z = renormalize(z)
         policy_logits, value = self.prediction_network(z)
         B = obs.size(0)
         hc = (torch.zeros(1, B, self.lstm_hidden_size).to(obs.device), torch.zeros(1, B, self.lstm_hidden_size).to(obs.device))
@@ -612,6 +633,8 @@ class SampledEfficientZeroModelMLP(nn.Module):  # lzero/model/sampled_efficientz
     def recurrent_inference(self, latent_state, reward_hidden_state, action):
         sa = _encode_action(action, latent_state, self.continuous_action_space, self.action_space_size, self.encoding)
         nxt, hc, vp = self.dynamics_network(sa, reward_hidden_state)
+        if self.state_norm:   # sampled_efficientzero_model_mlp.py:356-360
+            nxt = renormalize(nxt)
         policy_logits, value = self.prediction_network(nxt)
         return EZNetworkOutput(value, vp, policy_logits, nxt, hc)
 

@@ -44,8 +44,9 @@ def main():
         assert not res.unexpected_keys and not res.missing_keys
         rmod.eval()
         support = kw.get("value_support_range", kw.get("support_range", (-300., 301., 1.)))
-        ist = st.InverseScalarTransform(st.DiscreteSupport(*support), True)
-        rist = st.InverseScalarTransform(st.DiscreteSupport(*kw.get("reward_support_range", support)), True)   # mcts_ctree.py:726-729
+        cat = bool(kw.get("categorical_distribution", True))   # False: the heads' one output is the scaled scalar (scaling_transform.py:88-89)
+        ist = st.InverseScalarTransform(st.DiscreteSupport(*support), cat)
+        rist = st.InverseScalarTransform(st.DiscreteSupport(*kw.get("reward_support_range", support)), cat)   # mcts_ctree.py:726-729
         obs, actions = nn_cases.inputs(case)
         out = {"weights_sha256": np.frombuffer(weights_digest(ora.state_dict()).encode(), np.uint8)}
         lstm = nn_cases.has_lstm(fam)

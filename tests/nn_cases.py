@@ -41,6 +41,17 @@ CASES = {
     "mz_mlp_supports": dict(family="mz_mlp", kw=dict(observation_shape=6, action_space_size=3, latent_state_dim=128,
                                                      reward_support_range=(-5., 6., 1.), value_support_range=(-20., 21., 1.)), B=7, seed=34),
     "ez_mlp": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128), B=8, seed=16),
+    # state_norm=True (the latent renormalised to [0, 1] after the representation and after the dynamics network, lzero/model/utils.py:242-271)
+    # and categorical_distribution=False (one-output value / reward heads, h^-1 on the scalar: scaling_transform.py:88-92) -- the two
+    # constructor keywords of the MLP models the engine refused until round 6 (muzero_model_mlp.py:30,33)
+    "mz_mlp_statenorm": dict(family="mz_mlp", kw=dict(observation_shape=6, action_space_size=3, latent_state_dim=128, state_norm=True), B=7, seed=35),
+    "ez_mlp_statenorm_res": dict(family="ez_mlp", kw=dict(observation_shape=8, action_space_size=4, lstm_hidden_size=256, latent_state_dim=256, state_norm=True,
+                                                          res_connection_in_dynamics=True, norm_type='LN'), B=9, seed=36),
+    "mz_mlp_scalar": dict(family="mz_mlp", kw=dict(observation_shape=5, action_space_size=3, latent_state_dim=128, categorical_distribution=False), B=6, seed=37),
+    "ez_mlp_scalar_statenorm": dict(family="ez_mlp", kw=dict(observation_shape=6, action_space_size=3, lstm_hidden_size=128, latent_state_dim=128,
+                                                             categorical_distribution=False, state_norm=True), B=8, seed=38),
+    "sez_mlp_statenorm": dict(family="sez_mlp", kw=dict(observation_shape=5, action_space_size=2, num_of_sampled_actions=6, continuous_action_space=True,
+                                                        lstm_hidden_size=256, latent_state_dim=256, state_norm=True), B=7, seed=39),
     # 8x8 boards without downsample (64 channels): the 8x8 Winograd chain of the 64x64 Atari latents serves them
     "mz_board8": dict(family="mz", kw=dict(observation_shape=(3, 8, 8), action_space_size=65, downsample=False, num_res_blocks=2), B=6, seed=28),
     "ez_board8": dict(family="ez", kw=dict(observation_shape=(5, 8, 8), action_space_size=64, downsample=False), B=5, seed=29),
