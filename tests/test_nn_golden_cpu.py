@@ -23,8 +23,9 @@ def test_oracle_reproduces_reference_goldens(name):
     g = np.load(os.path.join(GOLD, "nn_%s.npz" % name))
     ora = tm.synthetic_init(nn_cases.oracle_class(tm, fam)(**kw), seed=case["seed"])
     assert weights_digest(ora.state_dict()) == bytes(g["weights_sha256"]).decode(), "seeded weights differ from the golden's"
-    ist = tm.InverseScalarTransform(kw.get("value_support_range", (-300., 301., 1.)))
-    rist = tm.InverseScalarTransform(kw.get("reward_support_range", kw.get("value_support_range", (-300., 301., 1.))))
+    cat = bool(kw.get("categorical_distribution", True))   # False: one-output heads, h^-1 on the scalar itself (scaling_transform.py:88-89)
+    ist = tm.InverseScalarTransform(kw.get("value_support_range", (-300., 301., 1.)), cat)
+    rist = tm.InverseScalarTransform(kw.get("reward_support_range", kw.get("value_support_range", (-300., 301., 1.))), cat)
     obs, actions = nn_cases.inputs(case)
 
     def eq(a, key):
