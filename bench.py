@@ -680,6 +680,8 @@ def main():
     fence_mode = args.gather_fence
     eng_streams = [torch.cuda.ExternalStream(lib.lz_engine_stream(e)) for e in engs]   # the engines' HIP streams, for stream-ordering only
 
+    host_obs = [None]   # set by the PCIe-inclusive secondary arm below: [sub-batch][obs batch] pinned host tensors
+
     def step(i):
         buf = i & 1
         if pending[buf] is not None:  # the all-gather that still reads this row buffer (issued two steps ago)
@@ -689,7 +691,10 @@ def main():
             torch.cuda.current_stream().synchronize()
             pending[buf] = None
         for k, r in enumerate(roots_l):  # enqueue everything of every sub-batch before reading anything back
-            L.check(lib.lz_initial_inference(r._h, obs_parts[k][i % NOBS].data_ptr()))
+            if host_obs[0] is not None:   # secondary arm only: the observations cross PCIe inside the step (pinned host memory -> HBM)
+                L.check(lib.lz_initial_inference_host(r._h, host_obs[0][k][i % NOBS].numpy()))   # (the numpy view of the pinned tensor: same memory)
+            else:
+                L.check(lib.lz_initial_inference(r._h, obs_parts[k][i % NOBS].data_ptr()))
             if fence_mode == "tower" and pending[buf ^ 1] is not None:
                 # the previous step's all-gather has had the tower to itself (thousands of workgroups: a few CUs less cost it a per
                 # cent); the search -- 256 workgroups that each need a whole CU -- starts behind it
@@ -815,6 +820,21 @@ def main():
         sync_all()
         sustained = dict(env_steps_per_s=sum(counts) * n_s / (time.perf_counter() - t_s), steps=n_s, seconds=time.perf_counter() - t_s)
         clock_windows["sustained"] = (t_s, time.perf_counter())
+    # (a2) PCIe-inclusive: the same step with the observation batch handed over in (pinned) HOST memory -- lz_initial_inference_host copies the
+    #      37.7 MB over PCIe on the engine's stream in front of the tower.  Never `value` (the contract's inputs are resident in HBM).
+    host_obs_rate = None
+    if not dist_on and hasattr(lib, "lz_initial_inference_host"):
+        host_obs[0] = [[o[k * EPS:(k + 1) * EPS].contiguous().pin_memory() for o in obs_pool_cpu] for k in range(NS)]
+        n_w = max(2, NOBS)   # every pinned batch once: the first transfer out of a freshly pinned buffer is slower
+        for j in range(n_w):
+            step(total + j)
+        sync_all()
+        t_h = time.perf_counter()
+        for j in range(args.steps):
+            step(total + n_w + j)
+        sync_all()
+        host_obs_rate = ENVS * args.steps / (time.perf_counter() - t_h)
+        host_obs[0] = None
     if clocks:
         clocks.stop()
     # (b) the other tie-break arm (the parity tests pin "first": deterministic first arg-max; collection uses the reference's
@@ -909,6 +929,9 @@ def main():
                        "root_noise": "drawn on the device inside every step (lz_roots_prepare_from_inference_dirichlet)" if args.noise == "device"
                                      else "np.random dirichlet drawn inside every step, uploaded",
                        "sustained_env_steps_per_s": sustained["env_steps_per_s"] if sustained else None,
+                       "host_obs_env_steps_per_s": host_obs_rate,
+                       "host_obs_note": "the same K steps with the observation batch handed over in pinned HOST memory (lz_initial_inference_host: %.1f MB over PCIe per step, "
+                                        "on the engine's stream in front of the tower); reported beside `value`, never as it" % (ENVS * 4 * 96 * 96 * 4 / 1e6),
                        "sustained_steps": sustained["steps"] if sustained else 0, "sustained_seconds": sustained["seconds"] if sustained else 0.0,
                        "sub_batches": NS, "whole_step_tflops": value * (SIMS * FLOP_RECURRENT + FLOP_INITIAL) / 1e12,
                        "parallelism": "env-shard x%d" % world, "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend if dist_on else None,
