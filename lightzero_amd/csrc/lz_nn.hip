@@ -1838,6 +1838,16 @@ __global__ __launch_bounds__(512) void k_chain_b(lz_chain_args a, typename step_
 // RES: 0 the launch-per-simulation kernel | 1 k_sim_fused (only the head partials come from other workgroups of the launch: sc1 loads; the
 // outputs are read by LATER launches and stay write-through) | 2 a launch that loops over simulations (per-simulation offsets `rs`, plain
 // stores for what its own later phases read; not shipped: see k_sim_fused)
+// LDS layout of the 6x6 split-bf16 chain (chain_s3_body; also k_sim_fused and the launchers): the fp32 buffers, scale / shift, selection words and the
+// partial-sum area as before; the bf16 planes start on a 256-byte boundary and every plane is padded to a multiple of 256 bytes whose LAST 256 bytes
+// are zero -- the "zero pixel" of an out-of-image tap is read from there at the 16-byte slot (bank quad) the lane's in-image read would have
+// used, so that a 16-lane group of ds_read_b128 stays on 16 distinct quads whatever mix of in-image and zero reads it holds (one shared zero pixel
+// collided with the lane that owned its quad: 1.33 M SQ_LDS_BANK_CONFLICT per launch).
+constexpr int LZ_S3_HW = 36, LZ_S3_PB = 80;
+constexpr size_t LZ_S3_SB_OFF = (((size_t)(4 * (LZ_S3_HW + 1) * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * 3 * 256) * 4 + 255) / 256) * 256;   // bytes
+constexpr size_t LZ_S3_PLANE = ((((size_t)(LZ_S3_HW + 1) * LZ_S3_PB * 2 + 255) / 256) * 256);   // bytes per plane: 6144
+static_assert(LZ_S3_PLANE - (size_t)LZ_S3_HW * LZ_S3_PB * 2 >= 256, "room for the zero line behind the pixels");
+constexpr size_t LZ_S3_LDS = LZ_S3_SB_OFF + 4 * 3 * LZ_S3_PLANE;   // 4 buffers x 3 planes
 template <int GW, int GH, int TREE, bool HEADS, int RES>
 __device__ __forceinline__ void chain_s3_body(const lz_chain_args &a, const typename step_arg<TREE>::type &step, const int b, const int nroots, const lz_res_sim &rs)
 {
@@ -1850,11 +1860,13 @@ __device__ __forceinline__ void chain_s3_body(const lz_chain_args &a, const type
     float *sSS = smem + 4 * BUF;                        // [LZ_CHAIN_MAX_LAYERS][2][64] folded-BN scale / shift
     float *sMisc = sSS + LZ_CHAIN_MAX_LAYERS * 128;     // 128 floats: the tree step's selection
     float *sP = sMisc + 128;                            // [2 tile pairs][6 tiles][3 other waves][64 lanes][4] partial sums (prologue: head scratch)
-    __bf16 *sB = reinterpret_cast<__bf16 *>(sP + 2 * 6 * 3 * 256);   // 4 buffers x 3 planes x [HW + 1][PB]: the split of the activation buffers
-    constexpr int BB = (HW + 1) * PB;                   // one plane
+    static_assert(HW == LZ_S3_HW && PB == LZ_S3_PB, "the layout constants above");
+    __bf16 *sB = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(smem) + LZ_S3_SB_OFF);   // 4 buffers x 3 planes x ([HW][PB] pixels, zeros up to the plane's end)
+    constexpr int BB = (int)(LZ_S3_PLANE / 2);          // one plane (bf16 elements)
+    constexpr int ZLINE = (int)LZ_S3_PLANE - 256;       // byte offset of the plane's zero line
     constexpr int BB3 = NPL * BB;                       // one buffer
-    // Wave roles.  What bounds this launch is the LDS read path (and behind it the weight stream), not the matrix pipe: with one 16-channel
-    // output tile per wave every pixel fragment was read by four waves (648 KB of ds_read_b128 per layer and CU, 125 B/clk at the matrix rate).
+    // Wave roles.  With one 16-channel output tile per wave every pixel fragment was read by four waves (648 KB of ds_read_b128 per layer and CU, 125 B/clk
+    // at the matrix rate) and the LDS read path bound the launch.  (Round 6, with the layout below and the zero line: the product phase is 91 % matrix work.)
     // So a wave owns TWO output-channel tiles (np: tiles 2 np, 2 np + 1) for all three pixel tiles, one half of the input channels (kh) and one
     // half of the taps (th = 0: taps 0-4, th = 1: taps 5-8; waves w and w + 4 share a SIMD, so every SIMD gets 5 + 4 taps): each pixel fragment
     // feeds 12 MFMAs instead of 6, the LDS read traffic halves.  Four waves hold partial sums of the same six output tiles; they meet in LDS.
@@ -1997,9 +2009,10 @@ __device__ __forceinline__ void chain_s3_body(const lz_chain_args &a, const type
         }
         // the all-zero pixel of every buffer (fp32: the head convolutions' padding rows; bf16: the halo of every plane)
         if (tid < 64) *reinterpret_cast<float4 *>(smem + (tid >> 4) * BUF + HW * PS + (tid & 15) * 4) = vzero4();
-        if (tid >= 64 && tid < 64 + 4 * NPL * (PB / 8)) {   // 12 (buffer, plane) pairs x 10 16-byte pieces
-            const int i = tid - 64;
-            *reinterpret_cast<float4 *>(sB + (i / (PB / 8)) * BB + HW * PB + (i % (PB / 8)) * 8) = vzero4();
+        {   // 12 (buffer, plane) pairs: everything behind the pixels (the zero line included) in 16-byte pieces
+            constexpr int NZ = (int)(LZ_S3_PLANE - (size_t)HW * PB * 2) / 16;
+            for (int i = tid - 64; i >= 0 && i < 4 * NPL * NZ; i += NTHR - 64)
+                *reinterpret_cast<float4 *>(sB + (i / NZ) * BB + HW * PB + (i % NZ) * 8) = vzero4();
         }
         if (TREE == 0) {
             for (int i = tid; i < a.nlayers * 128; i += NTHR) {
@@ -2022,7 +2035,6 @@ __device__ __forceinline__ void chain_s3_body(const lz_chain_args &a, const type
             if (m < HW && yy >= 0 && yy < GH && xx >= 0 && xx < GW) valid |= 1ull << (mt * 9 + t);
         }
     }
-    const int azero = (HW * PB + kh * 32 + (lane >> 4) * 8) * 2;
     const int kq4 = (lane >> 4) * 4, zoff = HW * PS;
     __syncthreads();
     if constexpr (TREE != 0) { if (step.ts && b == 0 && tid == 0) lz_stamp_store(step.ts + (6), __builtin_readcyclecounter()); }
@@ -2063,7 +2075,8 @@ __device__ __forceinline__ void chain_s3_body(const lz_chain_args &a, const type
             const int toff = ((t / 3 - 1) * GW + (t % 3 - 1)) * PB * 2;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int off = (valid >> (mt * 9 + t)) & 1 ? abase[mt] + toff : azero;
+                const int offv = abase[mt] + toff;
+                const int off = (valid >> (mt * 9 + t)) & 1 ? offv : (ZLINE | (offv & 0xf0));   // the zero line, at this lane's own bank quad
                 af[pl][mt] = *reinterpret_cast<const bf16x8 *>(sBin + off + pl * BB * 2);
             }
         };
@@ -3281,7 +3294,7 @@ __global__ __launch_bounds__(512) void k_sim_fused(lz_lstm_args la, lz_chain_arg
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (no static LDS: with any, hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) is an invalid argument.)  Four words behind the chain's layout
-    constexpr int LDS_CHAIN = (4 * 37 * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * 3 * 256) + (3 * 4 * 37 * 80 * 2) / 4;   // floats: k_chain_s3<6,6>'s
+    constexpr int LDS_CHAIN = (int)(LZ_S3_LDS / 4);   // floats: k_chain_s3<6,6>'s
     int *s_ids = reinterpret_cast<int *>(smem + LDS_CHAIN);
     const int tid = threadIdx.x;
     lz_res_ctl *ctl = ra.ctl;
@@ -4271,8 +4284,7 @@ void lz_launch_chain(const lz_chain_args &a, hipStream_t s, const lz_tree_step *
         bool s3 = !nosplit && !direct && !getenv("LZ_CHAIN_W4") && a.gw == 6 && a.gh == 6 && a.nlayers > 0 && !a.tstamp && !a.gelu && (a.C == 0 || a.C == 64);
         for (int i = 0; i < a.nlayers; ++i) s3 = s3 && a.layer[i].w3 != nullptr;
         if (s3) {
-            const int hw = 36, mt = 3;
-            const size_t lds = (size_t)(4 * (hw + 1) * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * mt * 256) * 4 + (size_t)3 * 4 * (hw + 1) * 80 * 2;
+            const size_t lds = LZ_S3_LDS;
             const dim3 g(a.B), blk(512);
             static bool attr = false;
             if (!attr) {
@@ -4465,7 +4477,7 @@ bool lz_launch_sim_fused(const lz_lstm_args &la, const lz_chain_args &ca, const 
     static int cus = -1;
     if (cus < 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0; }
     if (cus < ca.B) return false;   // one workgroup per CU, all resident at once
-    const size_t lds = (size_t)(4 * 37 * 68 + LZ_CHAIN_MAX_LAYERS * 128 + 128 + 2 * 6 * 3 * 256) * 4 + (size_t)3 * 4 * 37 * 80 * 2 + 16;   // k_chain_s3's (>= the LSTM halves' 2 x 70 KB) + the group ids
+    const size_t lds = LZ_S3_LDS + 16;   // k_chain_s3's (>= the LSTM halves' 2 x 70 KB) + the group ids
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_sim_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     lz_resident_args ra{};
