@@ -19,6 +19,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 UNITS = [
     ("lz_tree.hip", ["-ffp-contract=off"]),
     ("lz_tree_sampled.hip", ["-ffp-contract=off"]),
+    ("lz_tree_wide.hip", ["-ffp-contract=off"]),
     ("lz_capi.hip", []),
     ("lz_nn.hip", []),
     ("lz_chain_s3g.hip", []),

@@ -235,7 +235,9 @@ extern "C" int lz_roots_create(lz_engine *e, int variant, int root_num, int acti
     *out = nullptr;
     LZ_REQUIRE(variant == LZ_TREE_EFFICIENTZERO || variant == LZ_TREE_MUZERO || variant == LZ_TREE_GUMBEL_MUZERO, "unknown tree variant");
     LZ_REQUIRE(root_num > 0 && action_space_size > 0 && max_simulations > 0, "root_num, action_space_size, max_simulations must be positive");
-    LZ_REQUIRE(action_space_size <= 256, "action_space_size > 256 is not supported by the wave-per-root tree kernels");
+    // beyond 256 actions (Chinese chess: 2086) the MuZero / EfficientZero trees run lz_tree_wide.hip; node_link keeps the action in 16 bits
+    LZ_REQUIRE(action_space_size <= 65535, "action_space_size > 65535 is not supported");
+    LZ_REQUIRE(action_space_size <= 256 || variant != LZ_TREE_GUMBEL_MUZERO, "action_space_size > 256 is not supported by the Gumbel MuZero tree kernels");
     LZ_HIP_CHECK(hipSetDevice(e->device));
     lz_roots *r = nullptr;
     int rc = lz_roots_alloc(e, variant, root_num, action_space_size, max_simulations, &r);
@@ -642,6 +644,7 @@ extern "C" int lz_batch_traverse_with_reuse(lz_roots *r, int pb_c_base, float pb
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->prepared, "batch_traverse_with_reuse before Roots.prepare");
+    LZ_REQUIRE(r->t.A <= 256, "search_with_reuse: action_space_size > 256 is not supported");
     LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "the sampled tree has no reuse variant");
     LZ_REQUIRE(h_virtual_to_play && h_true_action && h_reuse_value && h_out_index_in_search_path && h_out_index_in_batch &&
                h_out_last_actions && h_out_search_lens, "NULL buffer");
@@ -683,6 +686,7 @@ extern "C" int lz_batch_backpropagate_with_reuse(lz_roots *r, int current_latent
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->prepared, "batch_backpropagate_with_reuse before Roots.prepare");
+    LZ_REQUIRE(r->t.A <= 256, "search_with_reuse: action_space_size > 256 is not supported");
     LZ_REQUIRE(h_to_play && h_no_inference_lst && h_reuse_lst && h_reuse_value && n_infer >= 0, "NULL input");
     LZ_REQUIRE(n_infer == 0 || (h_value_prefixs && h_values && h_policy_logits), "network outputs missing");
     const lz_tree_dev &t = r->t;

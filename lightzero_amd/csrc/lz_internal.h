@@ -242,6 +242,16 @@ void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, fl
                                       const float *d_values, const float *d_logits, int horizon,
                                       const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s);
+// lz_tree_wide.hip: the same four steps for action spaces beyond 256 (a node's children walked in 64-lane chunks by a loop instead of
+// living in at most four register chunks); the launchers above dispatch here
+void lz_tree_wide_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int noises_ragged, const int32_t *d_noise_off,
+                                 const float *d_vp, const float *d_logits, const int32_t *d_to_play, hipStream_t s);
+void lz_tree_wide_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
+void lz_tree_wide_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                  const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play, hipStream_t s);
+void lz_tree_wide_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                           const float *d_logits, int horizon, const lz_traverse_args &a, float delta,
+                                           const int32_t *d_vtp_in, hipStream_t s);
 // Gumbel MuZero (ctree_gumbel_muzero/lib/cnode.cpp): selection by sequential halving at the root and by the completed-Q
 // improved policy below it; expand / backup are the MuZero kernels (+ raw value), readout adds get_policies / get_children_values
 int lz_groots_set_considered(lz_roots *r, int num_simulations, int max_num_considered_actions, hipStream_t s);

@@ -812,6 +812,16 @@ __global__ void lz_k_trajectories(lz_tree_dev t, int32_t *__restrict__ out, int 
 }
 
 static inline int nchunks(int A) { return (A + 63) / 64; }
+// Beyond 256 actions a node's children no longer fit four register chunks per lane: lz_tree_wide.hip walks them in a loop.
+// LZ_TREE_WIDE=1 (parity tests) sends every MuZero / EfficientZero tree through those kernels, so that they can be compared bit for
+// bit with the register kernels on the action spaces both serve.
+static inline bool use_wide(const lz_tree_dev &t)
+{
+    if (t.variant != LZ_TREE_EFFICIENTZERO && t.variant != LZ_TREE_MUZERO) return false;
+    if (nchunks(t.A) > 4) return true;
+    const char *v = getenv("LZ_TREE_WIDE");
+    return v && *v && *v != '0';
+}
 
 // The exploration factors of a node with visit count n = lane (cnode.cpp:720-727: pb_c = log((N + base + 1) / base) + init, times sqrt(N)): the
 // same 64 values for every root and every simulation of a search, so they are computed once per search here instead of in front of every
@@ -836,6 +846,7 @@ void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_
                             const int32_t *d_noise_off, const float *d_vp, const float *d_logits,
                             const int32_t *d_to_play, hipStream_t s)
 {
+    if (use_wide(t)) { lz_tree_wide_launch_prepare(t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play, s); return; }
     const size_t sh = (size_t)t.A * 8;
     switch (nchunks(t.A)) {
     case 1: hipLaunchKernelGGL(k_prepare<1>, dim3(t.B), dim3(64), sh, s, t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play); break;
@@ -857,6 +868,7 @@ static void launch_traverse_v(const lz_tree_dev &t, const lz_traverse_args &a, f
 void lz_tree_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
                              hipStream_t s)
 {
+    if (use_wide(t)) { lz_tree_wide_launch_traverse(t, a, delta, d_vtp_in, s); return; }   // lz_tree_wide.hip: children walked in a loop
     if (t.variant == LZ_TREE_EFFICIENTZERO) launch_traverse_v<LZ_TREE_EFFICIENTZERO>(t, a, delta, d_vtp_in, s);
     else launch_traverse_v<LZ_TREE_MUZERO>(t, a, delta, d_vtp_in, s);
 }
@@ -876,6 +888,7 @@ void lz_tree_launch_backprop(const lz_tree_dev &t, int latent_index, float disco
                              const float *d_values, const float *d_logits, const int32_t *d_is_reset, int horizon,
                              const int32_t *d_to_play, hipStream_t s)
 {
+    if (use_wide(t)) { lz_tree_wide_launch_backprop(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s); return; }
     if (t.variant == LZ_TREE_EFFICIENTZERO)
         launch_backprop_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, s);
     else
@@ -924,6 +937,7 @@ void lz_tree_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, fl
                                       const float *d_values, const float *d_logits, int horizon,
                                       const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s)
 {
+    if (use_wide(t)) { lz_tree_wide_launch_backprop_traverse(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s); return; }
     if (t.variant == LZ_TREE_EFFICIENTZERO) launch_bt_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s);
     else launch_bt_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, horizon, a, delta, d_vtp_in, s);
 }

@@ -14,7 +14,7 @@ behind the same driver loop with handles that return the recorded scalars, and m
 (tests/test_reference_driver_gpu.py: lightzero_amd's HBM trees driven by the foreign-model loop of
 lightzero_amd/mcts/tree_search/mcts_ctree.py).  h^-1 itself is pinned in tests/test_torch_models_vs_reference.py.
 
-    python tests/golden/make_golden_driver.py          (needs /root/reference; run from the repository root)"""
+    python tests/golden/make_golden_driver.py [case ...]      (needs /root/reference; run from the repository root)"""
 import os
 import sys
 
@@ -33,6 +33,14 @@ CASES = {
     "driver_mz_gomoku_2p_b16": dict(family="mz", B=16, A=36, S=40, seed=62, two_player=True,
                                     kw=dict(observation_shape=(3, 6, 6), action_space_size=36, downsample=False, num_channels=32,
                                             reward_support_range=(-10., 11., 1.), value_support_range=(-10., 11., 1.))),
+    # the Chinese chess preset (zoo/board_games/chinese_chess/config/chinese_chess_muzero_bot_mode_config.py:31-46): 2086 moves, a few
+    # dozen legal at a root -- the action space beyond 256 of csrc/lz_tree_wide.hip behind the reference's own MuZero loop
+    "driver_mz_xiangqi_2p_b4": dict(family="mz", B=4, A=2086, S=30, seed=63, two_player=True, legal_p=0.02,
+                                    kw=dict(observation_shape=(57, 10, 9), action_space_size=2086, num_res_blocks=6,
+                                            num_channels=128, reward_head_hidden_channels=[128], value_head_hidden_channels=[128],
+                                            policy_head_hidden_channels=[256], downsample=False,
+                                            reward_support_range=(-1., 1., 1.), value_support_range=(-1., 1., 1.),
+                                            discrete_action_encoding_type='not_one_hot')),
 }
 
 
@@ -42,7 +50,7 @@ def inputs(case):
     obs = rng.random((B,) + tuple(case["kw"]["observation_shape"]), dtype=np.float32)
     legal = []
     for _ in range(B):
-        m = rng.random(A) < 0.8
+        m = rng.random(A) < case.get("legal_p", 0.8)
         m[rng.integers(0, A)] = True
         legal.append(np.nonzero(m)[0].tolist())
     to_play = rng.integers(1, 3, size=B).tolist() if case.get("two_player") else [-1] * B
@@ -129,6 +137,8 @@ def run_reference(case, tree_override=None):
 
 if __name__ == "__main__":
     for name, case in CASES.items():
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
         g = run_reference(case)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **g)
         print(name, {k: v.shape for k, v in g.items()}, "visits", g["distributions"].clip(0).sum(1)[:4])

@@ -1,7 +1,7 @@
 """Generates tests/golden/tree_<case>.npz from the reference's OWN compiled ctree (oracle/_ref/det =
 reference sources + rand()->0).  Run in the build container (needs /root/reference):
 
-    python tests/golden/make_golden_tree.py
+    python tests/golden/make_golden_tree.py [case-name-prefix ...]      (no argument: every case)
 
 Inputs are re-derived from the seeds in tests/tree_driver.py::CASES, so only outputs are stored.
 """
@@ -18,7 +18,10 @@ from oracle import build_ref  # noqa: E402
 
 assert build_ref.build(), "reference not present"
 ez_ref, mz_ref = build_ref.load("det")
+ONLY = tuple(sys.argv[1:])
 for name in sorted(td.CASES):
+    if ONLY and not name.startswith(ONLY):
+        continue
     c = td.make_inputs(td.CASES[name])
     mod = ez_ref if c["variant"] == "ez" else mz_ref
     kw = dict(traverse_kwargs=dict(deterministic=True)) if c["variant"] == "mz" else {}
@@ -34,6 +37,8 @@ for name in sorted(td.CASES):
 
 # ReZero search_with_reuse
 for name in sorted(td.REUSE_CASES):
+    if ONLY and not name.startswith(ONLY):
+        continue
     c = td.make_reuse_inputs(td.REUSE_CASES[name])
     out = td.run_tree_reuse(ez_ref if c["variant"] == "ez" else mz_ref, c)
     dist = np.full((c["B"], c["A"]), -1, np.int32)

@@ -85,6 +85,16 @@ CASES = {
                                                      reward_head_hidden_channels=[32], value_head_hidden_channels=[32],
                                                      policy_head_hidden_channels=[32]), B=4, seed=36),
 }
+# Configurations the ENGINE models do not take (128 channels on a 10 x 9 board) but whose torch restatement drives a committed golden: the
+# Chinese chess preset behind tests/golden/driver_mz_xiangqi_2p_b4.npz (foreign torch model + the device tree for 2086 actions).  Only the
+# pin of oracle/torch_models.py to the reference module runs on them (tests/test_torch_models_vs_reference.py).
+ORACLE_ONLY_CASES = {
+    "mz_xiangqi": dict(family="mz", kw=dict(observation_shape=(57, 10, 9), action_space_size=2086, num_res_blocks=6, num_channels=128,
+                                             reward_head_hidden_channels=[128], value_head_hidden_channels=[128],
+                                             policy_head_hidden_channels=[256], downsample=False,
+                                             reward_support_range=(-1., 1., 1.), value_support_range=(-1., 1., 1.),
+                                             discrete_action_encoding_type='not_one_hot'), B=3, seed=63),
+}
 STEPS = 3  # recurrent inferences chained after the initial one (teacher-forced on the reference's own states)
 
 

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="/root/refere
 
 def _build(name):
     ref = ref_loader.load()
-    case = nn_cases.CASES[name]
+    case = nn_cases.CASES[name] if name in nn_cases.CASES else nn_cases.ORACLE_ONLY_CASES[name]
     fam = case["family"]
     ora = tm.synthetic_init(nn_cases.oracle_class(tm, fam)(**case["kw"]), seed=case["seed"])
     rmod = nn_cases.reference_class(ref, fam)(**nn_cases.reference_kwargs(case))
@@ -34,7 +34,7 @@ def _eq(a, b, what):
     assert torch.equal(a, b), "%s differs: max |d| = %g" % (what, float((a.double() - b.double()).abs().max()))
 
 
-@pytest.mark.parametrize("name", sorted(nn_cases.CASES))
+@pytest.mark.parametrize("name", sorted(nn_cases.CASES) + sorted(nn_cases.ORACLE_ONLY_CASES))
 def test_oracle_model_equals_reference_module(name):
     torch.manual_seed(0)
     case, ora, rmod = _build(name)

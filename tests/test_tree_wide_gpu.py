@@ -1,0 +1,130 @@
+"""Action spaces beyond 256 (csrc/lz_tree_wide.hip; Chinese chess: 2086 moves,
+zoo/board_games/chinese_chess/config/chinese_chess_muzero_bot_mode_config.py:33).
+
+The wide cases of tests/tree_driver.py::CASES are held bit-exact to the C oracle and to the goldens of the compiled reference by
+tests/test_tree_gpu.py like every other case.  Here: (i) the wide kernels against the register kernels on action spaces BOTH serve
+(LZ_TREE_WIDE=1 sends every MuZero / EfficientZero tree through lz_tree_wide.hip), in both tie-break modes -- the stochastic draw is
+keyed by (seed, epoch, traverse counter, root, depth) and must pick the same member of the same tie list; (ii) what stays refused."""
+import os
+
+import numpy as np
+import pytest
+
+import tree_driver as td
+
+pytestmark = pytest.mark.gpu
+
+
+def _mod(variant):
+    if variant == "ez":
+        from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as m
+    else:
+        from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree as m
+    return m
+
+
+def _run(c, tiebreak, wide):
+    mod = _mod(c["variant"])
+    orig = mod.Roots
+
+    def mk(n, legal, **kw):
+        r = orig(n, legal, action_space_size=c["A"], max_simulations=c["S"])
+        r.set_tiebreak(tiebreak, seed=1234)
+        return r
+    ns = type("M", (), dict(Roots=staticmethod(mk), MinMaxStatsList=mod.MinMaxStatsList, ResultsWrapper=mod.ResultsWrapper,
+                            batch_traverse=staticmethod(mod.batch_traverse), batch_backpropagate=staticmethod(mod.batch_backpropagate)))
+    if wide:
+        os.environ["LZ_TREE_WIDE"] = "1"
+    else:
+        os.environ.pop("LZ_TREE_WIDE", None)
+    try:
+        return td.run_tree(ns, c)
+    finally:
+        os.environ.pop("LZ_TREE_WIDE", None)
+
+
+NARROW = ["ez_probe_b4", "ez_fixture16_2p", "ez_zero_ties", "ez_big_a20", "mz_go82_2p", "mz_zero_ties", "ez_wide_a150", "mz_wide_a200_2p",
+          "mz_runaway_logits", "ez_runaway_logits", "ez_deep_chain", "mz_deep_chain", "mz_fixture16_2p"]
+
+
+@pytest.mark.parametrize("tiebreak", [0, 1])
+@pytest.mark.parametrize("name", NARROW)
+def test_wide_kernels_are_bit_identical_to_the_register_kernels(name, tiebreak):
+    c = td.make_inputs(td.CASES[name])
+    a = _run(c, tiebreak, wide=False)
+    b = _run(c, tiebreak, wide=True)
+    td.assert_same(a, b, name)
+    assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32)), "min/max stats differ"
+
+
+@pytest.mark.parametrize("name", ["mz_wide_a300_zero_ties", "ez_go19_a362"])
+def test_stochastic_tie_break_on_wide_nodes_draws_from_the_tie_list(name):
+    """All-zero networks: every unvisited child of a node ties.  The deterministic mode takes the first of them (held to the
+    reference by test_tree_gpu.py); the stochastic mode must spread over the list, stay inside the legal list, and be reproducible."""
+    c = td.make_inputs(dict(td.CASES[name], zero=True, noise_w=None))
+    r1 = _run(c, 1, wide=False)
+    r2 = _run(c, 1, wide=False)
+    td.assert_same(r1, r2, name)
+    first = r1["records"][:, :, 2]        # action chosen at the end of every simulation's path
+    for b in range(c["B"]):
+        legal = set(c["legal_list"][b])
+        roots_actions = [int(a) for a, d in zip(first[:, b], r1["records"][:, b, 3]) if d == 1]
+        assert set(roots_actions) <= legal
+        assert len(set(roots_actions)) == len(roots_actions), "an unvisited root child was selected twice while others were unvisited"
+        assert roots_actions != sorted(roots_actions), "the draw never left list order"
+        assert max(roots_actions) >= 64, "no selection beyond the first 64-lane chunk"
+
+
+def test_what_stays_refused_beyond_256_actions():
+    import ctypes
+    from lightzero_amd import _lib as L
+    lib = L.lib()
+    eng = L.default_engine()
+    h = L.P()
+    rc = lib.lz_roots_create(eng, 3, 1, 300, 8, L.i32(list(range(300))), L.i32([300]), ctypes.byref(h))
+    assert rc < 0 and "Gumbel" in lib.lz_last_error().decode()
+    rc = lib.lz_roots_create(eng, 1, 1, 70000, 8, L.i32(list(range(70000))), L.i32([70000]), ctypes.byref(h))
+    assert rc < 0 and "65535" in lib.lz_last_error().decode()
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
+    roots = mz_tree.Roots(2, [list(range(300))] * 2, action_space_size=300, max_simulations=4)
+    roots.prepare_no_noise([0.0, 0.0], [[0.0] * 300] * 2, [-1, -1])
+    mm = mz_tree.MinMaxStatsList(2)
+    mm.set_delta(0.01)
+    with pytest.raises(Exception, match="with_reuse|256"):
+        mz_tree.batch_traverse_with_reuse(roots, 19652, 1.25, 0.997, mm, mz_tree.ResultsWrapper(2), [-1, -1], [0, 0], [0.0, 0.0])
+
+
+@pytest.mark.parametrize("B", [8, 256])
+def test_chinese_chess_sized_search_matches_the_compiled_reference_and_is_timed(B):
+    """2086 actions, ~40 legal at a root, 50 simulations (the preset's collector runs 8 environments; 256 = BASELINE's batch): the device
+    tree behind the fine-grained API against the reference's compiled ctree (oracle/_ref/det when the box has it, else the C oracle)
+    on the same recorded network outputs -- identical records / visit counts / bit-equal values -- with both sides' wall time per
+    simulation written to gpurun_out/tree_wide_timing.json (the committed copy: profiles/r06_tree_wide_timing.json)."""
+    import json
+    import time
+    from oracle import build_ref, ctree as octree
+    c = td.make_inputs(dict(td.CASES["mz_xiangqi_a2086_2p"], B=B, seed=40 + B))
+    # numpy rows instead of Python lists on the device side (what the foreign-model loop hands over); the reference's Cython surface takes lists
+    mods = build_ref.load("det")
+    ref_mod = mods[1] if mods else octree.mz_tree
+    kind = "reference (oracle/_ref/det)" if mods else "C oracle"
+    kw = dict(traverse_kwargs=dict(deterministic=True)) if mods else dict(roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
+    t0 = time.perf_counter()
+    ref = td.run_tree(ref_mod, c, **kw)
+    t_ref = time.perf_counter() - t0
+    _run(c, 0, wide=False)   # warm-up: allocations, handle cache
+    t0 = time.perf_counter()
+    dev = _run(c, 0, wide=False)
+    t_dev = time.perf_counter() - t0
+    td.assert_same(ref, dev, "xiangqi B=%d" % B)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "tree_wide_timing.json")
+    try:
+        data = json.load(open(path))
+    except Exception:
+        data = {"what": "MuZero tree, A = 2086, 2 % legal at the root, 50 simulations, fine-grained API (host rows in, PCIe included): "
+                        "wall ms per simulation (traverse + backpropagate of all roots)", "rows": {}}
+    data["rows"]["B=%d" % B] = {"device_ms_per_simulation": 1e3 * t_dev / c["S"], "host_tree_ms_per_simulation": 1e3 * t_ref / c["S"],
+                               "host_tree": kind, "identical": True}
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)

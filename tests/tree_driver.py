@@ -40,6 +40,14 @@ CASES = {
     # action spaces beyond 128: four 64-lane chunks per node in the device kernels
     "ez_wide_a150": dict(variant="ez", B=6, A=150, S=60, seed=13, legal="random"),
     "mz_wide_a200_2p": dict(variant="mz", B=5, A=200, S=80, seed=14, legal="random", to_play="random12", discount=1.0),
+    # action spaces beyond 256 (lz_tree_wide.hip: a node's children walked in 64-lane chunks by a loop).  Chinese chess has 2086 moves
+    # of which a few dozen are legal at a root (zoo/board_games/chinese_chess/config/chinese_chess_muzero_bot_mode_config.py:33) --
+    # below the root every action is "legal" (cnode.cpp:88-151); Go 19x19 has 362
+    "mz_xiangqi_a2086_2p": dict(variant="mz", B=8, A=2086, S=50, seed=30, legal="random", legal_p=0.02, to_play="random12", discount=1.0),
+    "ez_go19_a362": dict(variant="ez", B=6, A=362, S=60, seed=31, legal="random"),
+    "mz_wide_a300_zero_ties": dict(variant="mz", B=4, A=300, S=40, seed=32, zero=True, noise_w=None),
+    "ez_wide_a1000_runaway": dict(variant="ez", B=6, A=1000, S=40, seed=33, runaway=True),
+    "ez_wide_a257_sharp": dict(variant="ez", B=5, A=257, S=70, seed=34, scale=4.0),
     # a diverged network (random weights unrolled 40+ steps deep produce logits of 1e14 and h^-1 values of 1e4): nodes whose
     # logits all lie below FLOAT_MIN = -1e6 get priors 0 / 0 = NaN (cnode.cpp:123-137), every score at such a node is NaN, no child
     # enters the tie list and cselect_child returns its default action 0 (cnode.cpp:687-693); found by the exact replay gate at
@@ -54,7 +62,7 @@ CASES = {
 def make_inputs(case):
     """Seeded synthetic 'network outputs' for every simulation of a case (all float32)."""
     c = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.997, delta=0.01, noise_w=0.25, horizon=5, legal=None,
-             to_play=None, zero=False, scale=1.0, deep=False, runaway=False)
+             to_play=None, zero=False, scale=1.0, deep=False, runaway=False, legal_p=0.6)
     c.update(case)
     rng = np.random.default_rng(c["seed"])
     B, A, S = c["B"], c["A"], c["S"]
@@ -63,7 +71,7 @@ def make_inputs(case):
     elif c["legal"] == "random":
         legal = []
         for _ in range(B):
-            m = rng.random(A) < 0.6
+            m = rng.random(A) < c["legal_p"]
             m[A - 1] = True  # "pass" always legal
             legal.append(np.nonzero(m)[0].tolist())
     else:
