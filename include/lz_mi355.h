@@ -154,7 +154,8 @@ int lz_sbatch_backpropagate(lz_roots *r, int current_latent_state_index, float d
                             const float *h_values, const float *h_policy, const int32_t *h_is_reset,
                             const int32_t *h_to_play, const float *h_given);
 /* discrete action spaces (continuous_action_space = False, cnode.cpp:288-327): each node samples K of the action_space_size
- * actions without replacement from its policy logits; an action is the float of its index, policies are [root_num][A] logits */
+ * actions without replacement from its policy logits; an action is the float of its index, policies are [root_num][A] logits.
+ * action_space_size <= 256 (bipedalwalker_cont_disc_sampled_efficientzero_config.py: 4^4), num_of_sampled_actions <= 64. */
 int lz_sroots_create_discrete(lz_engine *e, int root_num, int action_space_size, int num_of_sampled_actions,
                               int max_simulations, lz_roots **out);
 /* parity runs of the fused sampled search: inject the post-tanh draws of every expansion, [records][root_num][K][D]

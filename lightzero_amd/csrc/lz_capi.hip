@@ -925,7 +925,7 @@ extern "C" int lz_sroots_create(lz_engine *e, int root_num, int action_dim, int 
 extern "C" int lz_sroots_create_discrete(lz_engine *e, int root_num, int action_space_size, int num_of_sampled_actions,
                                          int max_simulations, lz_roots **out)
 {
-    LZ_REQUIRE(action_space_size >= 1 && action_space_size <= 64, "action_space_size must be in [1, 64] (one lane per action)");
+    LZ_REQUIRE(action_space_size >= 1 && action_space_size <= 256, "action_space_size must be in [1, 256] (four actions per lane in the draw without replacement)");
     LZ_REQUIRE(num_of_sampled_actions <= action_space_size, "num_of_sampled_actions must not exceed action_space_size (sampling is without replacement)");
     int rc = lz_sroots_create(e, root_num, 1, num_of_sampled_actions, max_simulations, out);
     if (rc != LZ_OK) return rc;

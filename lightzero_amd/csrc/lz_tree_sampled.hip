@@ -55,25 +55,47 @@ __device__ __forceinline__ void expand_sampled(const lz_tree_dev &t, int b, int 
     float *gact = t.actions + (((size_t)b * NN + node) * K) * D;
     if (t.disc_A > 0 && !sa.given) {
         // discrete action space (cnode.cpp:288-327): K of the A actions without replacement -- the reference sorts the keys
-        // u_a^(1/p_a) in descending order and keeps the first K; log(u_a) / p_a orders the same way.  Lane = action (A <= 64).
+        // u_a^(1/p_a) in descending order and keeps the first K; log(u_a) / p_a orders the same way.  Lane l owns actions l, l + 64,
+        // l + 128, l + 192 (A <= 256: bipedalwalker_cont_disc_sampled_efficientzero_config.py's 4^4, mujoco_disc's 5^3); an action's
+        // rank is counted against every key by v_readlane, chunk by chunk.  With A <= 64 only chunk 0 exists: the draw of rounds 4-5.
+        constexpr int NCD = 4;
         const int A = t.disc_A;
         const uint32_t epoch = t.rng_epoch ? t.rng_epoch[0] : 0u;
-        const float lg = lane < A ? sa.policy[(size_t)b * A + lane] : -__builtin_inff();
-        const float ex = lane < A ? expf(lg) : 0.0f;
-        float sum = ex;
+        float ex[NCD], key[NCD];
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCD; ++c) {
+            const int a = c * 64 + lane;
+            const float lg = a < A ? sa.policy[(size_t)b * A + a] : -__builtin_inff();
+            ex[c] = a < A ? expf(lg) : 0.0f;
+            if (c == 0) sum = ex[0];
+            else if (c * 64 < A) sum += ex[c];
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-        const float p = ex / (sum + 1e-6f);
-        const uint64_t st = mix64(mix64(sa.seed ^ 0x5a3c1e0fu ^ ((uint64_t)epoch << 24) ^ (uint64_t)sa.counter) ^ ((uint64_t)b << 20) ^
-                                  ((uint64_t)node << 8) ^ (uint64_t)lane);
-        const float u = ((float)((st >> 40) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
-        const float key = lane < A ? logf(u) / fmaxf(p, 1e-30f) : -__builtin_inff();
-        int rank = 0;
-        for (int a2 = 0; a2 < A; ++a2) {
-            const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key), a2));
-            rank += (k2 > key || (k2 == key && a2 < lane)) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < NCD; ++c) {
+            const int a = c * 64 + lane;
+            const float p = ex[c] / (sum + 1e-6f);
+            const uint64_t st = mix64(mix64(sa.seed ^ 0x5a3c1e0fu ^ ((uint64_t)epoch << 24) ^ (uint64_t)sa.counter) ^ ((uint64_t)b << 20) ^
+                                      ((uint64_t)node << 8) ^ (uint64_t)a);
+            const float u = ((float)((st >> 40) & 0xffffff) + 0.5f) * (1.0f / 16777216.0f);
+            key[c] = a < A ? logf(u) / fmaxf(p, 1e-30f) : -__builtin_inff();
         }
-        if (lane < A && rank < K) s_act[rank] = (float)lane;
+        int rank[NCD] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c2 = 0; c2 < NCD; ++c2) {
+            const int cnt = min(64, A - c2 * 64);   // <= 0 beyond the last chunk
+            for (int l2 = 0; l2 < cnt; ++l2) {
+                const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key[c2]), l2));
+                const int a2 = c2 * 64 + l2;
+#pragma unroll
+                for (int c = 0; c < NCD; ++c) rank[c] += (k2 > key[c] || (k2 == key[c] && a2 < c * 64 + lane)) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCD; ++c)
+            if (c * 64 + lane < A && rank[c] < K) s_act[rank[c]] = (float)(c * 64 + lane);
         __syncthreads();
         if (lane < K) gact[lane] = s_act[lane];
     } else if (lane < K) {

@@ -169,6 +169,40 @@ def test_configs4_sampled_efficientzero_full_size_device_draws_replay_exactly(co
     _sampled_replay(model, roots, S, lambda e: node_actions2[e], noises, [-1] * B, continuous, A_disc=A)
 
 
+@pytest.mark.parametrize("obs_dim,A,K", [(11, 125, 20), (24, 256, 20)])
+def test_discretised_sampled_efficientzero_configs_beyond_64_actions_replay_exactly(obs_dim, A, K):
+    """The shipped discretised-action Sampled EfficientZero presets whose action space exceeds one 64-lane chunk:
+    zoo/mujoco/config/mujoco_disc_sampled_efficientzero_config.py (Hopper: 5^3 = 125 actions, K = 20) and
+    zoo/box2d/bipedalwalker/config/bipedalwalker_cont_disc_sampled_efficientzero_config.py (4^4 = 256 actions, K = 20).  Every node's K
+    actions are drawn WITHOUT replacement on the device inside the captured search graph (four actions per lane); read back and injected
+    into the oracle sampled tree they must reproduce the search exactly -- records, visit counts, bit-equal values."""
+    from lightzero_amd import _lib as L
+    from lightzero_amd.mcts.tree_search.mcts_ctree import SampledEfficientZeroMCTSCtree
+    B, S = 128, 50
+    model = _sez_model(False, A, K, obs_dim, seed=23)
+    cfg = dict(num_simulations=S, pb_c_base=19652, pb_c_init=1.25, discount_factor=0.997, value_delta_max=0.01, lstm_horizon_len=5,
+               root_noise_weight=0.25, model=dict(action_space_size=A, num_of_sampled_actions=K, continuous_action_space=False))
+    mcts = SampledEfficientZeroMCTSCtree(cfg)
+    roots = mcts.roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
+    roots.set_tiebreak(0, seed=4321)
+    obs = torch.randn(B, obs_dim, generator=torch.Generator().manual_seed(33)).cuda().contiguous()
+    noises = np.random.default_rng(6).dirichlet([0.3] * K, size=B).astype(np.float32)
+    out = model.initial_inference(obs, roots)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    roots.prepare_from_inference(0.25, noises, [-1] * B)
+    mcts.search(roots, model, out.latent_state, out.reward_hidden_state, [-1] * B)
+    node_actions = [roots.get_node_actions(e) for e in range(S + 1)]
+    for a in node_actions:   # K DISTINCT action indices per node, inside the action space, beyond the first chunk somewhere
+        a = np.asarray(a).reshape(B, K)
+        assert np.array_equal(a, np.rint(a)) and a.min() >= 0 and a.max() < A
+        assert all(len(set(row.tolist())) == K for row in a)
+    assert max(np.asarray(a).max() for a in node_actions) >= 64
+    ora, _ = _sampled_replay(model, roots, S, lambda e: node_actions[e], noises, [-1] * B, False, A_disc=A)
+    tr = np.zeros((S, B, 4), np.int32)
+    L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+    assert np.array_equal(ora["records"][:, :, [0, 2]], tr[:, :, [0, 2]]), "per-simulation (parent slot, search length) records differ"
+
+
 def test_conv_sampled_efficientzero_atari_config_replays_exactly():
     """The convolutional Sampled EfficientZero as the reference ships it for Atari (zoo/atari/config/atari_sampled_efficientzero_config.py:
     4 x 64 x 64 observations, discrete actions, K = 5 sampled without replacement, norm_type='BN', the class defaults GELU / 256-wide heads):

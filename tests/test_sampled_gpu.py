@@ -152,11 +152,13 @@ def test_sampled_driver_and_policy_with_foreign_model():
     assert any(np.allclose(o0["action"], a) for a in o0["root_sampled_actions"])
 
 
-def test_device_side_discrete_sampling_without_replacement():
+@pytest.mark.parametrize("A,K", [(11, 5), (125, 20), (256, 20)])
+def test_device_side_discrete_sampling_without_replacement(A, K):
     """continuous_action_space=False (cnode.cpp:288-327): every node holds K DISTINCT action indices; sampling K of A without
-    replacement through the keys u^(1/p) is the Efraimidis-Spirakis scheme, whose first draw follows p exactly."""
+    replacement through the keys u^(1/p) is the Efraimidis-Spirakis scheme, whose first draw follows p exactly.  A = 125 / 256: the
+    shipped discretised presets (mujoco_disc 5^3, bipedalwalker 4^4) -- four actions per lane in the draw."""
     from lightzero_amd.mcts.ctree.ctree_sampled_efficientzero import ezs_tree
-    B, A, K, S = 2048, 11, 5, 12
+    B, S = 2048, 12
     rng = np.random.default_rng(3)
     logits = np.tile(rng.standard_normal((1, A)).astype(np.float32), (B, 1))
     roots = ezs_tree.Roots(B, [list(range(A))] * B, A, K, False, max_simulations=S)
@@ -167,6 +169,16 @@ def test_device_side_discrete_sampling_without_replacement():
     p = np.exp(logits[0].astype(np.float64)); p /= p.sum()
     first = np.bincount(acts[:, 0].astype(int), minlength=A) / B
     assert np.abs(first - p).max() < 0.04
+    # every action's inclusion frequency against 4 sigma of a binomial around a Monte-Carlo estimate of the scheme itself (numpy, same keys' law)
+    g = np.random.default_rng(9)
+    u = g.random((20000, A))
+    keys = np.log(u) / p[None, :]
+    incl_ref = np.zeros(A)
+    top = np.argpartition(-keys, K - 1, axis=1)[:, :K]
+    np.add.at(incl_ref, top.reshape(-1), 1.0)
+    incl_ref /= 20000
+    incl = np.bincount(acts.astype(int).reshape(-1), minlength=A) / B
+    assert np.abs(incl - incl_ref).max() < 4 * np.sqrt(0.25 / B) + 4 * np.sqrt(0.25 / 20000)
     mm = ezs_tree.MinMaxStatsList(B)
     mm.set_delta(0.01)
     for s in range(S):
