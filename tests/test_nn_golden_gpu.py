@@ -67,7 +67,7 @@ def check_case(name, case, g, sd, record="golden/", bounds=None, g64=None, engin
     lib = L.lib()
     fam, kw, B = case["family"], case["kw"], case["B"]
     ekw = dict(kw)
-    if fam in ("mz_mlp", "ez_mlp"):
+    if fam in ("mz_mlp", "ez_mlp") and "norm_type" not in ekw:
         ekw["norm_type"] = "BN"
     ekw.update(engine_kw or {})   # arguments of the engine model only (fast_mode, fp32_matrix)
     model = nn_cases.engine_class(fam)(**ekw).load_state_dict(sd)
