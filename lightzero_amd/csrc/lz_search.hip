@@ -2138,7 +2138,7 @@ static uint64_t graph_knobs()
 #ifdef LZ_DEBUG_KNOBS
                            "LZ_DEBUG_SKIP",
 #endif
-                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CONV_NO_DUAL", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_SIM_ONE_LAUNCH", "LZ_LSTM_NO_OVL", "LZ_HEADS_MM64"};
+                           "LZ_LSTM_ROWS32", "LZ_LSTM_NOSPLIT", "LZ_LSTM3", "LZ_CONV_DIRECT", "LZ_CONV_NO_SPLIT", "LZ_CONV_NO_DUAL", "LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT", "LZ_CHAIN_W4", "LZ_HEADS_VALU", "LZ_HEADS_LAUNCH", "LZ_SIM_ONE_LAUNCH", "LZ_LSTM_NO_OVL", "LZ_HEADS_MM64", "LZ_TREE_WIDE"};
     for (const char *n : names) {
         const char *v = getenv(n);
         knobs = knobs * 1000003ull + 7;

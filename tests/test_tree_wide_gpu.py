@@ -128,3 +128,18 @@ def test_chinese_chess_sized_search_matches_the_compiled_reference_and_is_timed(
     data["rows"]["B=%d" % B] = {"device_ms_per_simulation": 1e3 * t_dev / c["S"], "host_tree_ms_per_simulation": 1e3 * t_ref / c["S"],
                                "host_tree": kind, "identical": True}
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+def test_baseline_sized_searches_replay_exactly_through_the_wide_kernels():
+    """LZ_TREE_WIDE=1 LZ_NO_TREE_FUSE=1: every tree step of the fused search is a separate launch of lz_tree_wide.hip's expand + backup +
+    selection kernel.  The exact-replay suite at BASELINE sizes (configs[1] 256 x 50, configs[2] 1024 x 400, configs[3] Go 64 x 200 two
+    players, ragged batches) must still reproduce the reference's compiled ctree -- in a process of its own, like the other switches."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LZ_TREE_WIDE="1", LZ_NO_TREE_FUSE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_exact_replay_gpu.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "configs1_full or configs2 or configs3 or gomoku or odd_batches or muzero_atari"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "LZ_TREE_WIDE=1:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+    assert " passed" in r.stdout
