@@ -30,7 +30,7 @@ for name in sorted(td.CASES):
     for i, d in enumerate(out["distributions"]):
         dist[i, :len(d)] = d
     rec = out["records"]
-    dt = np.int8 if rec.max() < 127 and rec.min() >= -128 else np.int16
+    dt = np.int8 if rec.max() < 127 and rec.min() >= -128 else (np.int16 if rec.max() < 32767 else np.int32)
     np.savez_compressed(os.path.join(HERE, "tree_%s.npz" % name), records=rec.astype(dt), distributions=dist,
                         values=out["values"])
     print(name, "ok", rec.shape, "max depth", rec[:, :, 3].max())
@@ -45,7 +45,7 @@ for name in sorted(td.REUSE_CASES):
     for i, d in enumerate(out["distributions"]):
         dist[i, :len(d)] = d
     rec = out["records"]
-    dt = np.int8 if rec.max() < 127 and rec.min() >= -128 else np.int16
+    dt = np.int8 if rec.max() < 127 and rec.min() >= -128 else (np.int16 if rec.max() < 32767 else np.int32)
     np.savez_compressed(os.path.join(HERE, "tree_%s.npz" % name), records=rec.astype(dt), distributions=dist,
                         values=out["values"])
     print(name, "ok", rec.shape, "inferences", out["inferences"], "of", c["B"] * c["S"])

@@ -48,6 +48,7 @@ CASES = {
     "mz_wide_a300_zero_ties": dict(variant="mz", B=4, A=300, S=40, seed=32, zero=True, noise_w=None),
     "ez_wide_a1000_runaway": dict(variant="ez", B=6, A=1000, S=40, seed=33, runaway=True),
     "ez_wide_a257_sharp": dict(variant="ez", B=5, A=257, S=70, seed=34, scale=4.0),
+    "mz_wide_a65535_max": dict(variant="mz", B=2, A=65535, S=6, seed=35, legal="random", legal_p=0.001),   # the largest action space the node links hold
     # a diverged network (random weights unrolled 40+ steps deep produce logits of 1e14 and h^-1 values of 1e4): nodes whose
     # logits all lie below FLOAT_MIN = -1e6 get priors 0 / 0 = NaN (cnode.cpp:123-137), every score at such a node is NaN, no child
     # enters the tie list and cselect_child returns its default action 0 (cnode.cpp:687-693); found by the exact replay gate at
