@@ -74,7 +74,8 @@ def main():
         mtype = model.get("model_type", "conv")
         entry = dict(policy_type=ptype, family=FAMILIES[ptype], model_type=mtype, num_simulations=mc["policy"].get("num_simulations"),
                      collector_env_num=mc["policy"].get("collector_env_num"), env_type=mc["policy"].get("env_type", "not_board_games"),
-                     discount_factor=mc["policy"].get("discount_factor", 0.997), set_by_file=sorted(model))
+                     discount_factor=mc["policy"].get("discount_factor", 0.997),
+                     max_num_considered_actions=mc["policy"].get("max_num_considered_actions"), set_by_file=sorted(model))
         cls = classes.get((FAMILIES[ptype], mtype))
         if cls is None:
             entry["model"] = plain(model)      # e.g. model_type 'conv_context': a model class outside the four families' two

@@ -268,13 +268,52 @@ def test_configs4_sampled_efficientzero_full_size_injected_draws_replay_exactly(
 
 
 # --------------------------------------------------------------------------------------------------------------- Gumbel MuZero
+def _gumbel_search_and_replay(model, mcts, B, A, S, m, legal, noises, obs, discount=0.997):
+    """lz_gsearch on the device, then the device's own network outputs through oracle/ctree_gumbel_oracle.c and the reference's compiled
+    gmz_tree: identical records, visit counts, bit-equal root values, improved policies and completed Q-values.  noises None: no root noise."""
+    from oracle import build_ref, ctree as octree
+    from lightzero_amd import _lib as L
+    roots = mcts.roots(B, legal, action_space_size=A, max_simulations=S)
+    out = model.initial_inference(obs, roots)
+    L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
+    if noises is not None:
+        roots.prepare_from_inference(0.25, noises, [-1] * B)
+    else:
+        roots.prepare_from_inference_no_noise([-1] * B)
+    mcts.search(roots, model, out.latent_state, [-1] * B)
+    pred = np.zeros(B, np.float32); pol0 = np.zeros((B, A), np.float32)
+    L.check(L.lib().lz_roots_get_root_outputs(roots._h, pred, pol0.reshape(-1)))
+    sims = _sims(roots, S, B, A)
+    tr = np.zeros((S, B, 4), np.int32)
+    L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
+    c = dict(B=B, A=A, S=S, m=m, discount=discount, delta=0.01, noise_w=0.25, legal_list=legal, root_logits=pol0,
+             root_reward=np.zeros(B, np.float32), root_value=pred, noises=noises,
+             sims=[dict(r=x["vp"], v=x["v"], logits=x["logits"]) for x in sims])
+    dev = dict(distributions=np.full((B, A), -1, np.int32), values=np.asarray(roots.get_values(), np.float32),
+               policies=np.asarray(roots.get_policies(discount, A), np.float32),
+               children_values=np.asarray(roots.get_children_values(discount, A), np.float32))
+    for i, d in enumerate(roots.get_distributions()):
+        dev["distributions"][i, :len(d)] = d
+    mods = [("oracle/ctree_gumbel_oracle.c", octree.gmz_tree, dict(action_space_size=A, max_simulations=S))]
+    ref = build_ref.load_gumbel()
+    if ref is not None:
+        mods.append(("oracle/_ref (the reference's own gmz_tree)", ref, None))
+    for name, mod, kw in mods:
+        o = gd.run_tree(mod, c, roots_kwargs=kw)
+        same = int((o["distributions"] == dev["distributions"]).all(1).sum())
+        assert same == B, "%s: only %d / %d roots have identical visit counts" % (name, same, B)
+        for k in ("values", "policies", "children_values"):
+            assert np.array_equal(o[k].view(np.uint32), dev[k].view(np.uint32)), "%s: %s not bit-equal" % (name, k)
+        assert np.array_equal(o["records"][:, :, [0, 2, 3]], tr[:, :, [0, 1, 2]]), "%s: per-simulation records differ" % name
+    assert (np.where(dev["distributions"] < 0, 0, dev["distributions"]).sum(1) == S).all()
+
+
 def test_gumbel_fused_search_replays_exactly():
     """lz_gsearch (GumbelMuZeroMCTSCtree.search, mcts_ctree.py:1067-1172) with the engine MuZero model, 64 roots x 50 simulations,
     A = 18 (the Atari full action set), m = 16 considered actions, ragged legal masks: the device's own network outputs replayed
     through oracle/ctree_gumbel_oracle.c and the reference's compiled gmz_tree -- identical records, visit counts, bit-equal root
     values, improved policies and completed Q-values."""
-    from oracle import build_ref, ctree as octree, torch_models as tm
-    from lightzero_amd import _lib as L
+    from oracle import torch_models as tm
     from lightzero_amd.mcts.tree_search.mcts_ctree import GumbelMuZeroMCTSCtree
     from lightzero_amd.model.muzero_model import MuZeroModel
     B, A, S, m = 64, 18, 50, 16
@@ -290,39 +329,7 @@ def test_gumbel_fused_search_replays_exactly():
     noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
     obs = torch.rand(B, 4, 96, 96, generator=torch.Generator().manual_seed(43)).cuda().contiguous()
     for use_noise in (True, False):
-        roots = mcts.roots(B, legal, action_space_size=A, max_simulations=S)
-        out = model.initial_inference(obs, roots)
-        L.check(L.lib().lz_roots_enable_trace(roots._h, 1))
-        if use_noise:
-            roots.prepare_from_inference(0.25, noises, [-1] * B)
-        else:
-            roots.prepare_from_inference_no_noise([-1] * B)
-        mcts.search(roots, model, out.latent_state, [-1] * B)
-        pred = np.zeros(B, np.float32); pol0 = np.zeros((B, A), np.float32)
-        L.check(L.lib().lz_roots_get_root_outputs(roots._h, pred, pol0.reshape(-1)))
-        sims = _sims(roots, S, B, A)
-        tr = np.zeros((S, B, 4), np.int32)
-        L.check(L.lib().lz_roots_read_trace(roots._h, S, tr.reshape(-1)))
-        c = dict(B=B, A=A, S=S, m=m, discount=0.997, delta=0.01, noise_w=0.25, legal_list=legal, root_logits=pol0,
-                 root_reward=np.zeros(B, np.float32), root_value=pred, noises=noises if use_noise else None,
-                 sims=[dict(r=x["vp"], v=x["v"], logits=x["logits"]) for x in sims])
-        dev = dict(distributions=np.full((B, A), -1, np.int32), values=np.asarray(roots.get_values(), np.float32),
-                   policies=np.asarray(roots.get_policies(0.997, A), np.float32),
-                   children_values=np.asarray(roots.get_children_values(0.997, A), np.float32))
-        for i, d in enumerate(roots.get_distributions()):
-            dev["distributions"][i, :len(d)] = d
-        mods = [("oracle/ctree_gumbel_oracle.c", octree.gmz_tree, dict(action_space_size=A, max_simulations=S))]
-        ref = build_ref.load_gumbel()
-        if ref is not None:
-            mods.append(("oracle/_ref (the reference's own gmz_tree)", ref, None))
-        for name, mod, kw in mods:
-            o = gd.run_tree(mod, c, roots_kwargs=kw)
-            same = int((o["distributions"] == dev["distributions"]).all(1).sum())
-            assert same == B, "%s: only %d / %d roots have identical visit counts" % (name, same, B)
-            for k in ("values", "policies", "children_values"):
-                assert np.array_equal(o[k].view(np.uint32), dev[k].view(np.uint32)), "%s: %s not bit-equal" % (name, k)
-            assert np.array_equal(o["records"][:, :, [0, 2, 3]], tr[:, :, [0, 1, 2]]), "%s: per-simulation records differ" % name
-        assert (np.where(dev["distributions"] < 0, 0, dev["distributions"]).sum(1) == S).all()
+        _gumbel_search_and_replay(model, mcts, B, A, S, m, legal, noises if use_noise else None, obs)
 
 
 # ----------------------------------------------------------------------------------------------------------------------- ReZero

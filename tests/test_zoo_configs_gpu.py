@@ -212,7 +212,20 @@ def _search_stage(e, fam, okw, ekw, ref_model):
     obs = (torch.randn(B, shape, generator=g) if isinstance(shape, int) else torch.rand(B, *shape, generator=g)).cuda().contiguous()
     what = "%d roots x %d simulations, discount %g%s" % (B, S, discount, ", two players, ragged legal actions" if board else "")
     if e["policy_type"] == "gumbel_muzero":
-        return "model only (the Gumbel search is replayed in tests/test_exact_replay_families_gpu.py / test_gumbel_gpu.py)"
+        # (the reference's Gumbel driver has no two-player mode: to_play stays -1; ragged legal lists on the boards)
+        from lightzero_amd.mcts.tree_search.mcts_ctree import GumbelMuZeroMCTSCtree
+        from test_exact_replay_families_gpu import _gumbel_search_and_replay
+        m = int(e.get("max_num_considered_actions") or min(A, 16))
+        mcts = GumbelMuZeroMCTSCtree(dict(num_simulations=S, discount_factor=discount, max_num_considered_actions=m, value_delta_max=0.01,
+                                          root_noise_weight=0.25))
+        legal = []
+        for _ in range(B):
+            k = rng.random(A) < (0.7 if board else 2.0)
+            k[rng.integers(0, A)] = True
+            legal.append(np.nonzero(k)[0].tolist())
+        noises = [rng.dirichlet([0.3] * len(l)).astype(np.float32).tolist() for l in legal]
+        _gumbel_search_and_replay(model, mcts, B, A, S, m, legal, noises, obs, discount=discount)
+        return "exact replay (Gumbel, m = %d): %s" % (m, what.replace(", two players", ""))
     if fam in ("mz", "ez", "mz_mlp", "ez_mlp"):
         if fam.startswith("ez"):
             from lightzero_amd.mcts.ctree.ctree_efficientzero import ez_tree as tree
