@@ -143,3 +143,31 @@ def test_baseline_sized_searches_replay_exactly_through_the_wide_kernels():
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "LZ_TREE_WIDE=1:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
     assert " passed" in r.stdout
+
+
+_OFF = int(os.environ.get("LZ_FUZZ_SEED_OFFSET", "0"))
+
+
+def _wide_case(seed):
+    r = np.random.default_rng(9500 + seed)
+    two = bool(r.integers(0, 2))
+    return dict(variant=["ez", "mz"][int(r.integers(0, 2))], B=int(r.integers(1, 7)), A=int(r.integers(257, 2600)), S=int(r.integers(1, 49)),
+                seed=300 + seed, legal=[None, "random"][int(r.integers(0, 2))], legal_p=float(r.choice([0.01, 0.1, 0.6])),
+                to_play="random12" if two else None, discount=float(r.choice([0.997, 1.0, 0.9])), pb_c_base=int(r.choice([19652, 1, 100])),
+                pb_c_init=float(r.choice([1.25, 0.5, 2.0])), delta=float(r.choice([0.01, 0.0, 0.1])), noise_w=[0.25, None, 0.5][int(r.integers(0, 3))],
+                horizon=int(r.choice([5, 1, 3])), scale=float(r.choice([1.0, 5.0, 0.1])), zero=bool(r.random() < 0.1))
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 16))
+def test_random_wide_configuration_matches_the_oracle(seed):
+    """the randomised sweep of tests/test_tree_fuzz_gpu.py on action spaces of 257 .. 2599: both tree variants, full and ragged legal lists (1 % .. 60 %
+    legal), one and two players, discounts, pb_c constants, min-max deltas, noise weights, LSTM horizons, logit scales -- bit-exact against the C oracle
+    (records, visit counts, root values, min-max statistics)"""
+    from oracle import ctree as octree
+    case = _wide_case(seed)
+    c = td.make_inputs(case)
+    dev = _run(c, 0, wide=False)
+    omod = octree.ez_tree if c["variant"] == "ez" else octree.mz_tree
+    ora = td.run_tree(omod, c, roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
+    td.assert_same(ora, dev, repr(case))
+    assert np.array_equal(ora["minmax"].view(np.uint32), dev["minmax"].view(np.uint32)), "min/max stats differ: %r" % (case,)
