@@ -644,7 +644,6 @@ extern "C" int lz_batch_traverse_with_reuse(lz_roots *r, int pb_c_base, float pb
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->prepared, "batch_traverse_with_reuse before Roots.prepare");
-    LZ_REQUIRE(r->t.A <= 256, "search_with_reuse: action_space_size > 256 is not supported");
     LZ_REQUIRE(r->t.variant != LZ_TREE_SAMPLED_EFFICIENTZERO, "the sampled tree has no reuse variant");
     LZ_REQUIRE(h_virtual_to_play && h_true_action && h_reuse_value && h_out_index_in_search_path && h_out_index_in_batch &&
                h_out_last_actions && h_out_search_lens, "NULL buffer");
@@ -686,7 +685,6 @@ extern "C" int lz_batch_backpropagate_with_reuse(lz_roots *r, int current_latent
 {
     LZ_REQUIRE(r != nullptr, "roots is NULL");
     LZ_REQUIRE(r->prepared, "batch_backpropagate_with_reuse before Roots.prepare");
-    LZ_REQUIRE(r->t.A <= 256, "search_with_reuse: action_space_size > 256 is not supported");
     LZ_REQUIRE(h_to_play && h_no_inference_lst && h_reuse_lst && h_reuse_value && n_infer >= 0, "NULL input");
     LZ_REQUIRE(n_infer == 0 || (h_value_prefixs && h_values && h_policy_logits), "network outputs missing");
     const lz_tree_dev &t = r->t;

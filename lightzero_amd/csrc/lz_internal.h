@@ -249,6 +249,12 @@ void lz_tree_wide_launch_prepare(const lz_tree_dev &t, float noise_w, const floa
 void lz_tree_wide_launch_traverse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in, hipStream_t s);
 void lz_tree_wide_launch_backprop(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
                                   const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play, hipStream_t s);
+void lz_tree_wide_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
+                                        const int32_t *d_true_action, const float *d_reuse_value, hipStream_t s);
+void lz_tree_wide_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
+                                        const float *d_logits, const int32_t *d_is_reset, int horizon, const int32_t *d_to_play,
+                                        const int32_t *d_mode, const int32_t *d_row, const float *d_reuse_value,
+                                        const int32_t *d_true_action, int32_t *d_infer_counter, hipStream_t s);
 void lz_tree_wide_launch_backprop_traverse(const lz_tree_dev &t, int latent_index, float discount, const float *d_vp, const float *d_values,
                                            const float *d_logits, int horizon, const lz_traverse_args &a, float delta,
                                            const int32_t *d_vtp_in, hipStream_t s);

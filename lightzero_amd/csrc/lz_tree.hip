@@ -955,6 +955,7 @@ static void launch_reuse_v(const lz_tree_dev &t, const lz_traverse_args &a, floa
 void lz_tree_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *d_vtp_in,
                                    const int32_t *d_true_action, const float *d_reuse_value, hipStream_t s)
 {
+    if (use_wide(t)) { lz_tree_wide_launch_traverse_reuse(t, a, delta, d_vtp_in, d_true_action, d_reuse_value, s); return; }
     if (t.variant == LZ_TREE_EFFICIENTZERO) launch_reuse_v<LZ_TREE_EFFICIENTZERO>(t, a, delta, d_vtp_in, d_true_action, d_reuse_value, s);
     else launch_reuse_v<LZ_TREE_MUZERO>(t, a, delta, d_vtp_in, d_true_action, d_reuse_value, s);
 }
@@ -975,6 +976,11 @@ void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float
                                    const int32_t *d_mode, const int32_t *d_row, const float *d_reuse_value,
                                    const int32_t *d_true_action, int32_t *d_infer_counter, hipStream_t s)
 {
+    if (use_wide(t)) {
+        lz_tree_wide_launch_backprop_reuse(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value,
+                                           d_true_action, d_infer_counter, s);
+        return;
+    }
     if (t.variant == LZ_TREE_EFFICIENTZERO)
         launch_bpreuse_v<LZ_TREE_EFFICIENTZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, d_infer_counter, s);
     else

@@ -25,6 +25,8 @@ struct wnode {
     int node_reset;
     float mean_q, pbc0, sq, mn, mx, delta_max, discount;
     int players;
+    int arm_action;         // ReZero, at the root only: the trajectory's true action is scored by carm_score (cnode.cpp:697-754); -1: none
+    float reuse_value;
 };
 
 // cucb_score (cnode.cpp:756-814) of the child at list position j; -inf beyond the list.  The expressions are dev_traverse's.
@@ -46,14 +48,18 @@ __device__ __forceinline__ float wide_score(const wnode &w, int j, int A)
     }
     float pb_c = w.pbc0 * (w.sq / (float)(vis + 1));
     const float prior_score = pb_c * prior;
+    const bool arm = act == w.arm_action;      // carm_score instead of cucb_score: the reuse value stands in for the child's, no prior term once visited
+    const float vchild = arm ? w.reuse_value : val;
     float value_score;
     if (vis == 0) value_score = w.mean_q;
-    else if (w.players == 1) value_score = tr + w.discount * val;
-    else value_score = tr + w.discount * (-val);
+    else if (w.players == 1) value_score = tr + w.discount * vchild;
+    else value_score = tr + w.discount * (-vchild);
     value_score = mm_normalize(value_score, w.mn, w.mx, w.delta_max);
     if (value_score < 0) value_score = 0;
     else if (value_score > 1) value_score = 1;
-    return prior_score + value_score;
+    float ucb = prior_score + value_score;
+    if (arm && vis != 0) ucb = value_score;
+    return ucb;
 }
 
 __device__ __forceinline__ int wave_min_i(int v)
@@ -63,9 +69,11 @@ __device__ __forceinline__ int wave_min_i(int v)
     return uni(v);
 }
 
-template <int VARIANT>
+// REUSE (ReZero, cnode.cpp:697-754, 816-884, 965-1072): as in dev_traverse -- the walk stops right below the root when the true action
+// is selected; res_noinf marks roots whose reached node is already expanded.
+template <int VARIANT, bool REUSE = false>
 __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tview &v, const tscal<1> &sc, const lz_traverse_args &a,
-                                                  float delta_max, int vtp)
+                                                  float delta_max, int vtp, int true_action = -1, float reuse_value = 0.0f)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = t.A, NN = t.NN;
@@ -73,7 +81,7 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
     const float base = (float)a.pb_c_base;
     const uint32_t epoch = sc.epoch;
     const int32_t *legal = t.legal + (size_t)b * A;
-    int node = 0, depth = 0, is_root = 1, last_action = -1;
+    int node = 0, depth = 0, is_root = 1, last_action = -1, noinf = 0;
     int node_visit = sc.root_visit;
     int my_node = 0, my_act = 0;   // the path record of level d stays in lane d & 63 (dev_traverse)
     auto flush_path = [&](int base_, int count) {
@@ -94,6 +102,8 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
         w.node_vp = v.node_vp[node];
         w.node_reset = v.node_reset[node];
         w.mn = sc.mn; w.mx = sc.mx; w.delta_max = delta_max; w.discount = discount; w.players = a.players;
+        w.arm_action = (REUSE && is_root) ? true_action : -1;
+        w.reuse_value = reuse_value;
         // ---- compute_mean_q (cnode.cpp:173-212): total_unsigned_q over the visited children in list order
         float total = 0.0f;
         int nv = 0;
@@ -177,6 +187,7 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
         last_action = action;
         depth += 1;
         if ((depth & 63) == 0) flush_path(depth - 64, 64);
+        if (REUSE && w.is_root && action == true_action) { noinf = nxt >= 0 ? 1 : 0; break; }  // cnode.cpp:1041-1044
         if (nxt < 0) break;  // reached an unexpanded child: the leaf
         node = nxt;
         node_visit = sel_visit;
@@ -184,10 +195,11 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
     flush_path((depth - 1) & ~63, depth - ((depth - 1) & ~63));
     if (lane == 0) {
         t.res_ix[b] = node;
-        t.res_iy[b] = b;
+        t.res_iy[b] = REUSE ? (noinf ? b : t.node_bidx[(size_t)b * NN + node]) : b;
         t.res_last_action[b] = last_action;
         t.res_search_len[b] = depth;
         t.res_vtp[b] = vtp;
+        if (REUSE) t.res_noinf[b] = noinf;
     }
 }
 
@@ -239,15 +251,16 @@ __device__ __forceinline__ wleaf load_leaf_wide(const lz_tree_dev &t, int b, con
     return L;
 }
 
+// no_expand (ReZero, cnode.cpp:626-630): the leaf is an already expanded node; bidx: the leaf's batch_index
 template <int VARIANT>
 __device__ __forceinline__ void dev_backprop_wide(const lz_tree_dev &t, const tview &v, tscal<1> &sc, int new_node, float discount,
-                                                  const wleaf &L, const float *__restrict__ lg)
+                                                  const wleaf &L, const float *__restrict__ lg, bool no_expand = false, int bidx = -1)
 {
-    float pri[1];
-    pri[0] = dev_expand_wide(v, new_node, t.A, lg);
+    float pri[1] = {0.0f};
+    if (!no_expand) pri[0] = dev_expand_wide(v, new_node, t.A, lg);
     const float unused[1] = {0.0f};
     // the first 64 edges are written once more by dev_backprop (same values); node records, the link, the backup along the path
-    dev_backprop<1, VARIANT, false>(t, v, sc, new_node, discount, L.vp, L.value, unused, L.d, L.to_play, L.reset, false, -1, nullptr, pri);
+    dev_backprop<1, VARIANT, false>(t, v, sc, new_node, discount, L.vp, L.value, unused, L.d, L.to_play, L.reset, no_expand, bidx, nullptr, pri);
 }
 
 // prepare: expand the root over its legal list + noise + visit_count += 1 (k_prepare of lz_tree.hip with the chunks in a loop)
@@ -332,6 +345,48 @@ __global__ __launch_bounds__(64) void k_backprop_wide(lz_tree_dev t, int new_nod
     dev_backprop_wide<VARIANT>(t, v, sc, new_node, discount, L, logits + (size_t)b * t.A);
 }
 
+// ReZero: cbatch_traverse_with_reuse / cbatch_backpropagate_with_reuse (cnode.cpp:603-649, 965-1072); k_traverse_reuse / k_backprop_reuse of lz_tree.hip
+template <int VARIANT>
+__global__ __launch_bounds__(64) void k_traverse_reuse_wide(lz_tree_dev t, lz_traverse_args a, float delta_max, const int32_t *__restrict__ vtp_in,
+                                                            const int32_t *__restrict__ true_action, const float *__restrict__ reuse_value)
+{
+    const int b = blockIdx.x;
+    const tview v = global_view(t, b);
+    tscal<1> sc;
+    load_scalars<1>(t, b, sc);
+    dev_traverse_wide<VARIANT, true>(t, v, sc, a, delta_max, vtp_in[b], true_action[b], reuse_value[b]);
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(64) void k_backprop_reuse_wide(lz_tree_dev t, int new_node, float discount, const float *__restrict__ vps,
+                                                            const float *__restrict__ values, const float *__restrict__ logits,
+                                                            const int32_t *__restrict__ is_reset, int horizon, const int32_t *__restrict__ to_play_in,
+                                                            const int32_t *__restrict__ mode, const int32_t *__restrict__ row,
+                                                            const float *__restrict__ reuse_value, const int32_t *__restrict__ true_action,
+                                                            int32_t *infer_counter)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const tview v = global_view(t, b);
+    tscal<1> sc;
+    load_scalars<1>(t, b, sc);
+    wleaf L;
+    L.d = uni(t.res_search_len[b]);
+    int m;   // 0 expand + back up the network value, 1 no inference (back up the reuse value), 2 expand + back up the reuse value
+    if (mode) m = uni(mode[b]);
+    else m = uni(t.res_noinf[b]) ? 1 : ((uni(t.res_ix[b]) == 0 && uni(t.res_last_action[b]) == uni(true_action[b])) ? 2 : 0);
+    const int r = row ? uni(row[b]) : b;
+    L.to_play = uni(to_play_in ? to_play_in[b] : t.res_vtp[b]);
+    L.reset = 0;
+    if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+        if (is_reset) L.reset = is_reset[b];
+        else if (horizon > 0) L.reset = (L.d % horizon == 0) ? 1 : 0;
+    }
+    L.vp = (m != 1) ? vps[r] : 0.0f;
+    L.value = (m != 0) ? reuse_value[b] : values[r];
+    if (infer_counter && lane == 0 && m != 1) atomicAdd(infer_counter, 1);
+    dev_backprop_wide<VARIANT>(t, v, sc, new_node, discount, L, logits + (size_t)r * t.A, m == 1, r);
+}
+
 // expand + backup of simulation s, then the selection of simulation s + 1, in one launch (k_backprop_traverse of lz_tree.hip)
 template <int VARIANT>
 __global__ __launch_bounds__(64) void k_backprop_traverse_wide(lz_tree_dev t, int new_node, float discount, const float *__restrict__ vps,
@@ -372,6 +427,23 @@ void lz_tree_wide_launch_backprop(const lz_tree_dev &t, int idx, float discount,
         hipLaunchKernelGGL((k_backprop_wide<LZ_TREE_EFFICIENTZERO>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp);
     else
         hipLaunchKernelGGL((k_backprop_wide<LZ_TREE_MUZERO>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp);
+}
+
+void lz_tree_wide_launch_traverse_reuse(const lz_tree_dev &t, const lz_traverse_args &a, float delta, const int32_t *vtp, const int32_t *ta,
+                                        const float *rv, hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO) hipLaunchKernelGGL((k_traverse_reuse_wide<LZ_TREE_EFFICIENTZERO>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp, ta, rv);
+    else hipLaunchKernelGGL((k_traverse_reuse_wide<LZ_TREE_MUZERO>), dim3(t.B), dim3(64), 0, s, t, a, delta, vtp, ta, rv);
+}
+
+void lz_tree_wide_launch_backprop_reuse(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val, const float *lg,
+                                        const int32_t *rst, int horizon, const int32_t *tp, const int32_t *mode, const int32_t *row,
+                                        const float *rv, const int32_t *ta, int32_t *ic, hipStream_t s)
+{
+    if (t.variant == LZ_TREE_EFFICIENTZERO)
+        hipLaunchKernelGGL((k_backprop_reuse_wide<LZ_TREE_EFFICIENTZERO>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta, ic);
+    else
+        hipLaunchKernelGGL((k_backprop_reuse_wide<LZ_TREE_MUZERO>), dim3(t.B), dim3(64), 0, s, t, idx, discount, vp, val, lg, rst, horizon, tp, mode, row, rv, ta, ic);
 }
 
 void lz_tree_wide_launch_backprop_traverse(const lz_tree_dev &t, int idx, float discount, const float *vp, const float *val, const float *lg,

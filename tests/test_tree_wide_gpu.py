@@ -85,13 +85,46 @@ def test_what_stays_refused_beyond_256_actions():
     assert rc < 0 and "Gumbel" in lib.lz_last_error().decode()
     rc = lib.lz_roots_create(eng, 1, 1, 70000, 8, L.i32(list(range(70000))), L.i32([70000]), ctypes.byref(h))
     assert rc < 0 and "65535" in lib.lz_last_error().decode()
-    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
-    roots = mz_tree.Roots(2, [list(range(300))] * 2, action_space_size=300, max_simulations=4)
-    roots.prepare_no_noise([0.0, 0.0], [[0.0] * 300] * 2, [-1, -1])
-    mm = mz_tree.MinMaxStatsList(2)
-    mm.set_delta(0.01)
-    with pytest.raises(Exception, match="with_reuse|256"):
-        mz_tree.batch_traverse_with_reuse(roots, 19652, 1.25, 0.997, mm, mz_tree.ResultsWrapper(2), [-1, -1], [0, 0], [0.0, 0.0])
+
+
+def _run_reuse(c, wide):
+    mod = _mod(c["variant"])
+    orig = mod.Roots
+
+    def mk(n, legal, **kw):
+        r = orig(n, legal, action_space_size=c["A"], max_simulations=c["S"])
+        r.set_tiebreak(0)
+        return r
+    ns = type("M", (), dict(Roots=staticmethod(mk), MinMaxStatsList=mod.MinMaxStatsList, ResultsWrapper=mod.ResultsWrapper,
+                            batch_traverse_with_reuse=staticmethod(mod.batch_traverse_with_reuse),
+                            batch_backpropagate_with_reuse=staticmethod(mod.batch_backpropagate_with_reuse)))
+    if wide:
+        os.environ["LZ_TREE_WIDE"] = "1"
+    try:
+        return td.run_tree_reuse(ns, c)
+    finally:
+        os.environ.pop("LZ_TREE_WIDE", None)
+
+
+@pytest.mark.parametrize("name", sorted(td.REUSE_CASES))
+def test_rezero_reuse_surface_on_the_wide_kernels(name):
+    """batch_traverse_with_reuse / batch_backpropagate_with_reuse (cnode.cpp:603-649, 965-1072): the cases both kernel sets serve are
+    bit-identical between them; every case -- the two beyond 256 actions included -- is bit-exact to the C oracle and to the golden of the
+    reference's compiled ctree"""
+    from oracle import ctree as octree
+    c = td.make_reuse_inputs(td.REUSE_CASES[name])
+    wide = _run_reuse(c, wide=True)
+    if c["A"] <= 256:
+        narrow = _run_reuse(c, wide=False)
+        td.assert_same(narrow, wide, name)
+        assert narrow["inferences"] == wide["inferences"]
+    omod = octree.ez_tree if c["variant"] == "ez" else octree.mz_tree
+    ora = td.run_tree_reuse(omod, c, roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
+    td.assert_same(ora, wide, name)
+    assert ora["inferences"] == wide["inferences"]
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tree_%s.npz" % name))
+    assert np.array_equal(wide["records"], g["records"])
+    assert np.array_equal(wide["values"].view(np.uint32), g["values"].view(np.uint32))
 
 
 @pytest.mark.parametrize("B", [8, 256])

@@ -169,6 +169,9 @@ REUSE_CASES = {
     "ez_reuse_fixture16_2p": dict(variant="ez", B=16, A=9, S=30, seed=22, legal="fixture", to_play=FIXTURE_TO_PLAY, discount=1.0),
     "mz_reuse_b24": dict(variant="mz", B=24, A=4, S=60, seed=23),
     "mz_reuse_fixture16_2p": dict(variant="mz", B=16, A=9, S=30, seed=24, legal="fixture", to_play=FIXTURE_TO_PLAY),
+    # action spaces beyond 256 (lz_tree_wide.hip)
+    "mz_reuse_wide_a300_2p": dict(variant="mz", B=6, A=300, S=40, seed=25, legal="random", legal_p=0.01, to_play="random12", discount=1.0),
+    "ez_reuse_wide_a1000": dict(variant="ez", B=5, A=1000, S=60, seed=27, legal="random", legal_p=0.004),
 }
 
 
