@@ -127,28 +127,66 @@ def test_rezero_reuse_surface_on_the_wide_kernels(name):
     assert np.array_equal(wide["values"].view(np.uint32), g["values"].view(np.uint32))
 
 
+def _timed_tree_loop(mod, c, roots, as_lists):
+    """the MuZero driver's per-simulation calls (mcts_ctree.py:300-368) with recorded network outputs; only batch_traverse /
+    batch_backpropagate are inside the clock.  as_lists: the reference's Cython surface takes Python lists (what its driver builds with
+    .tolist(), not timed here); the device side takes the numpy rows lightzero_amd's foreign-model loop hands over"""
+    import time
+    B, S = c["B"], c["S"]
+    mm = mod.MinMaxStatsList(B)
+    mm.set_delta(c["delta"])
+    rec = np.zeros((S, B, 5), np.int32)
+    conv = (lambda a: a.tolist()) if as_lists else (lambda a: a)
+    sims = [(conv(x["vp"]), conv(x["v"]), conv(x["logits"])) for x in c["sims"]]
+    t = 0.0
+    for s in range(S):
+        res = mod.ResultsWrapper(B)
+        tp = list(c["to_play_list"])
+        t0 = time.perf_counter()
+        if as_lists:
+            ix, iy, la, vtp = mod.batch_traverse(roots, c["pb_c_base"], c["pb_c_init"], c["discount"], mm, res, tp, deterministic=True)
+        else:
+            ix, iy, la, vtp = mod.batch_traverse(roots, c["pb_c_base"], c["pb_c_init"], c["discount"], mm, res, tp)
+        t += time.perf_counter() - t0
+        rec[s, :, 0], rec[s, :, 1], rec[s, :, 2], rec[s, :, 3], rec[s, :, 4] = ix, iy, la, res.get_search_len(), vtp
+        vp, v, lg = sims[s]
+        t0 = time.perf_counter()
+        mod.batch_backpropagate(s + 1, c["discount"], vp, v, lg, mm, res, vtp)
+        t += time.perf_counter() - t0
+    return dict(records=rec, distributions=roots.get_distributions(), values=np.asarray(roots.get_values(), np.float32)), t
+
+
 @pytest.mark.parametrize("B", [8, 256])
 def test_chinese_chess_sized_search_matches_the_compiled_reference_and_is_timed(B):
     """2086 actions, ~40 legal at a root, 50 simulations (the preset's collector runs 8 environments; 256 = BASELINE's batch): the device
     tree behind the fine-grained API against the reference's compiled ctree (oracle/_ref/det when the box has it, else the C oracle)
-    on the same recorded network outputs -- identical records / visit counts / bit-equal values -- with both sides' wall time per
-    simulation written to gpurun_out/tree_wide_timing.json (the committed copy: profiles/r06_tree_wide_timing.json)."""
+    on the same recorded network outputs -- identical records / visit counts / bit-equal values -- with both sides' time inside
+    batch_traverse + batch_backpropagate per simulation written to gpurun_out/tree_wide_timing.json (committed copy:
+    profiles/r06_tree_wide_timing.json)."""
     import json
-    import time
     from oracle import build_ref, ctree as octree
+    from lightzero_amd.mcts.ctree.ctree_muzero import mz_tree
     c = td.make_inputs(dict(td.CASES["mz_xiangqi_a2086_2p"], B=B, seed=40 + B))
-    # numpy rows instead of Python lists on the device side (what the foreign-model loop hands over); the reference's Cython surface takes lists
     mods = build_ref.load("det")
-    ref_mod = mods[1] if mods else octree.mz_tree
     kind = "reference (oracle/_ref/det)" if mods else "C oracle"
-    kw = dict(traverse_kwargs=dict(deterministic=True)) if mods else dict(roots_kwargs=dict(action_space_size=c["A"], max_simulations=c["S"]))
-    t0 = time.perf_counter()
-    ref = td.run_tree(ref_mod, c, **kw)
-    t_ref = time.perf_counter() - t0
-    _run(c, 0, wide=False)   # warm-up: allocations, handle cache
-    t0 = time.perf_counter()
-    dev = _run(c, 0, wide=False)
-    t_dev = time.perf_counter() - t0
+    if mods:
+        rr = mods[1].Roots(B, c["legal_list"])
+    else:
+        rr = octree.mz_tree.Roots(B, c["legal_list"], action_space_size=c["A"], max_simulations=c["S"])
+    rr.prepare(c["noise_w"], c["noises"], c["root_vp"].tolist(), c["root_logits"].tolist(), list(c["to_play_list"]))
+    if mods:
+        ref, t_ref = _timed_tree_loop(mods[1], c, rr, True)
+    else:   # (the C oracle's Python surface has no `deterministic` keyword: its ties are deterministic by construction)
+        class _O(object):
+            MinMaxStatsList, ResultsWrapper, batch_backpropagate = octree.mz_tree.MinMaxStatsList, octree.mz_tree.ResultsWrapper, staticmethod(octree.mz_tree.batch_backpropagate)
+            batch_traverse = staticmethod(lambda *a, **k: octree.mz_tree.batch_traverse(*a))
+        ref, t_ref = _timed_tree_loop(_O, c, rr, True)
+    t_dev = None
+    for _ in range(2):   # the first pass warms allocations and the handle cache
+        dr = mz_tree.Roots(B, c["legal_list"], action_space_size=c["A"], max_simulations=c["S"])
+        dr.set_tiebreak(0)
+        dr.prepare(c["noise_w"], c["noises"], c["root_vp"].tolist(), c["root_logits"].tolist(), list(c["to_play_list"]))
+        dev, t_dev = _timed_tree_loop(mz_tree, c, dr, False)
     td.assert_same(ref, dev, "xiangqi B=%d" % B)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -156,10 +194,11 @@ def test_chinese_chess_sized_search_matches_the_compiled_reference_and_is_timed(
     try:
         data = json.load(open(path))
     except Exception:
-        data = {"what": "MuZero tree, A = 2086, 2 % legal at the root, 50 simulations, fine-grained API (host rows in, PCIe included): "
-                        "wall ms per simulation (traverse + backpropagate of all roots)", "rows": {}}
-    data["rows"]["B=%d" % B] = {"device_ms_per_simulation": 1e3 * t_dev / c["S"], "host_tree_ms_per_simulation": 1e3 * t_ref / c["S"],
-                               "host_tree": kind, "identical": True}
+        data = {}
+    data["what"] = ("MuZero tree, A = 2086, 2 % legal at the root, 50 simulations, fine-grained API: wall ms inside batch_traverse + batch_backpropagate per "
+                    "simulation for all roots (device: numpy rows in, pinned staging and PCIe included; host tree: Python lists in, as its Cython surface requires)")
+    data.setdefault("rows", {})["B=%d" % B] = {"device_ms_per_simulation": 1e3 * t_dev / c["S"], "host_tree_ms_per_simulation": 1e3 * t_ref / c["S"],
+                                               "host_tree": kind, "identical": True}
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 
 
