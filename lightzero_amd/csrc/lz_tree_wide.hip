@@ -30,12 +30,34 @@ struct wnode {
 };
 
 // cucb_score (cnode.cpp:756-814) of the child at list position j; -inf beyond the list.  The expressions are dev_traverse's.
+// Loads of a pass are issued U chunks at a time (one round trip per U chunks instead of one per chunk: a pass over 2086 children is 33
+// chunks, and a loop that waits for every chunk's load before it requests the next is 33 round trips of ~1 us); the chunks of a group are
+// then consumed in list order.
+constexpr int WU = 8;
+struct wedge { float4 e; int act; };
+__device__ __forceinline__ void wide_load(const wnode &w, int c0, wedge (&g)[WU])
+{
+    const int lane = threadIdx.x;
+    if (w.is_root) {
+#pragma unroll
+        for (int u = 0; u < WU; ++u) { const int j = c0 + u * 64 + lane; g[u].act = j < w.n ? w.legal[j] : 0; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < WU; ++u) { const int j = c0 + u * 64 + lane; g[u].act = j < w.n ? j : 0; }
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+        const int j = c0 + u * 64 + lane;
+        g[u].e = j < w.n ? w.edge[g[u].act] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 template <int VARIANT>
-__device__ __forceinline__ float wide_score(const wnode &w, int j, int A)
+__device__ __forceinline__ float wide_score(const wnode &w, int j, const wedge &ge)
 {
     if (j >= w.n) return -__builtin_inff();
-    const int act = w.is_root ? w.legal[j] : j;
-    const float4 e = w.edge[act];
+    const int act = ge.act;
+    const float4 e = ge.e;
     const float prior = e.x;
     const int vis = __float_as_int(e.y);
     const float val = (vis == 0) ? 0.0f : e.z / (float)vis;  // CNode::value cnode.cpp:223-239
@@ -107,27 +129,32 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
         // ---- compute_mean_q (cnode.cpp:173-212): total_unsigned_q over the visited children in list order
         float total = 0.0f;
         int nv = 0;
-        for (int c0 = 0; c0 < w.n; c0 += 64) {
-            const int j = c0 + lane;
-            const bool valid = j < w.n;
-            const int act = valid ? (is_root ? legal[j] : j) : 0;
-            const float4 e = valid ? w.edge[act] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int vis = __float_as_int(e.y);
-            const float val = (vis == 0) ? 0.0f : e.z / (float)vis;
-            float tr;
-            if (VARIANT == LZ_TREE_EFFICIENTZERO) {
-                tr = e.w - w.node_vp;
-                if (w.node_reset == 1) tr = e.w;
-            } else {
-                tr = e.w;
-            }
-            const float qsa = tr + discount * val;
-            uint64_t mask = __ballot(valid && vis > 0);
-            while (mask) {
-                const int j2 = __builtin_ctzll(mask);
-                total += rl_f(qsa, j2);
-                nv += 1;
-                mask &= mask - 1;
+        for (int g0 = 0; g0 < w.n; g0 += 64 * WU) {
+            wedge g[WU];
+            wide_load(w, g0, g);
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                const int c0 = g0 + u * 64;
+                if (c0 >= w.n) break;
+                const bool valid = c0 + lane < w.n;
+                const float4 e = g[u].e;
+                const int vis = __float_as_int(e.y);
+                const float val = (vis == 0) ? 0.0f : e.z / (float)vis;
+                float tr;
+                if (VARIANT == LZ_TREE_EFFICIENTZERO) {
+                    tr = e.w - w.node_vp;
+                    if (w.node_reset == 1) tr = e.w;
+                } else {
+                    tr = e.w;
+                }
+                const float qsa = tr + discount * val;
+                uint64_t mask = __ballot(valid && vis > 0);
+                while (mask) {
+                    const int j2 = __builtin_ctzll(mask);
+                    total += rl_f(qsa, j2);
+                    nv += 1;
+                    mask &= mask - 1;
+                }
             }
         }
         float mean_q;
@@ -142,9 +169,15 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
         w.sq = sqrtf(N);
         float lbest = -__builtin_inff();
         int lpos = 0x7fffffff;
-        for (int c0 = 0; c0 < w.n; c0 += 64) {
-            const float s = wide_score<VARIANT>(w, c0 + lane, A);
-            if (s > lbest) { lbest = s; lpos = c0 + lane; }   // strict: the lane keeps the FIRST of its equal maxima
+        for (int g0 = 0; g0 < w.n; g0 += 64 * WU) {
+            wedge g[WU];
+            wide_load(w, g0, g);
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                const int j = g0 + u * 64 + lane;
+                const float s = wide_score<VARIANT>(w, j, g[u]);
+                if (s > lbest) { lbest = s; lpos = j; }   // strict: the lane keeps the FIRST of its equal maxima
+            }
         }
         const float best = wave_max(lbest);
         int pos = -1;
@@ -154,25 +187,36 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
                 // tie list = [first arg-max] + later entries with score >= max - 1e-6 (cnode.cpp:675-685)
                 const float thr = best - 0.000001f;
                 int cnt = 0;
-                for (int c0 = (pos & ~63); c0 < w.n; c0 += 64) {
-                    const int j = c0 + lane;
-                    const float s = wide_score<VARIANT>(w, j, A);
-                    cnt += __builtin_popcountll(__ballot(j == pos || (j > pos && s >= thr)));
+                for (int g0 = (pos & ~63); g0 < w.n; g0 += 64 * WU) {
+                    wedge g[WU];
+                    wide_load(w, g0, g);
+#pragma unroll
+                    for (int u = 0; u < WU; ++u) {
+                        const int j = g0 + u * 64 + lane;
+                        const float s = wide_score<VARIANT>(w, j, g[u]);
+                        cnt += __builtin_popcountll(__ballot(j == pos || (j > pos && s >= thr)));
+                    }
                 }
                 if (cnt > 1) {
                     const uint64_t h = mix64(mix64(a.seed ^ ((uint64_t)epoch << 20) ^ (uint64_t)a.counter) ^ ((uint64_t)b << 12) ^ (uint64_t)depth);
                     int r = (int)(((h >> 32) * (uint64_t)cnt) >> 32);  // uniform index in [0, cnt)
-                    for (int c0 = (pos & ~63); c0 < w.n && r >= 0; c0 += 64) {
-                        const int j = c0 + lane;
-                        const float s = wide_score<VARIANT>(w, j, A);
-                        uint64_t mk = __ballot(j == pos || (j > pos && s >= thr));
-                        const int pc = __builtin_popcountll(mk);
-                        if (r < pc) {
-                            for (int q = 0; q < r; ++q) mk &= mk - 1;
-                            pos = c0 + __builtin_ctzll(mk);
-                            r = -1;
-                        } else {
-                            r -= pc;
+                    const int first = pos;   // (pos is rewritten by the pick below; membership is relative to the first arg-max)
+                    for (int g0 = (first & ~63); g0 < w.n && r >= 0; g0 += 64 * WU) {
+                        wedge g[WU];
+                        wide_load(w, g0, g);
+#pragma unroll
+                        for (int u = 0; u < WU; ++u) {
+                            const int c0 = g0 + u * 64, j = c0 + lane;
+                            const float s = wide_score<VARIANT>(w, j, g[u]);
+                            uint64_t mk = __ballot(j == first || (j > first && s >= thr));
+                            const int pc = __builtin_popcountll(mk);
+                            if (r >= 0 && r < pc) {
+                                for (int q = 0; q < r; ++q) mk &= mk - 1;
+                                pos = c0 + __builtin_ctzll(mk);
+                                r = -1;
+                            } else if (r >= 0) {
+                                r -= pc;
+                            }
                         }
                     }
                 }
@@ -208,23 +252,42 @@ __device__ __forceinline__ void dev_traverse_wide(const lz_tree_dev &t, const tv
 __device__ __forceinline__ float dev_expand_wide(const tview &v, int new_node, int A, const float *__restrict__ lg)
 {
     const int lane = threadIdx.x;
+    auto load = [&](int g0, float (&x)[WU]) {   // WU chunks of logits per round trip (LZ_FLOAT_MIN beyond the list)
+#pragma unroll
+        for (int u = 0; u < WU; ++u) { const int j = g0 + u * 64 + lane; x[u] = j < A ? lg[j] : LZ_FLOAT_MIN; }
+    };
     float m = LZ_FLOAT_MIN;
-    for (int c0 = 0; c0 < A; c0 += 64) m = fmaxf(m, (c0 + lane < A) ? lg[c0 + lane] : LZ_FLOAT_MIN);
+    for (int g0 = 0; g0 < A; g0 += 64 * WU) {
+        float x[WU];
+        load(g0, x);
+#pragma unroll
+        for (int u = 0; u < WU; ++u) m = fmaxf(m, x[u]);
+    }
     m = wave_max(m);
     float sum = 0.0f;   // policy_sum in action order (cnode.cpp:132-137)
-    for (int c0 = 0; c0 < A; c0 += 64) {
-        const float e = lz_expf(((c0 + lane < A) ? lg[c0 + lane] : LZ_FLOAT_MIN) - m);
-        const int cnt = min(64, A - c0);
-        for (int j = 0; j < cnt; ++j) sum += rl_f(e, j);
+    for (int g0 = 0; g0 < A; g0 += 64 * WU) {
+        float x[WU];
+        load(g0, x);
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int cnt = min(64, A - (g0 + u * 64));   // <= 0 beyond the list
+            const float e = lz_expf(x[u] - m);
+            for (int j = 0; j < cnt; ++j) sum += rl_f(e, j);
+        }
     }
     float pri0 = 0.0f;
-    for (int c0 = 0; c0 < A; c0 += 64) {
-        const int j = c0 + lane;
-        if (j < A) {
-            const float p = lz_expf(lg[j] - m) / sum;
-            if (c0 == 0) pri0 = p;
-            v.edge[(size_t)new_node * A + j] = make_float4(p, __int_as_float(0), 0.0f, 0.0f);
-            v.child[(size_t)new_node * A + j] = -1;
+    for (int g0 = 0; g0 < A; g0 += 64 * WU) {
+        float x[WU];
+        load(g0, x);
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int j = g0 + u * 64 + lane;
+            if (j < A) {
+                const float p = lz_expf(x[u] - m) / sum;
+                if (g0 + u == 0) pri0 = p;
+                v.edge[(size_t)new_node * A + j] = make_float4(p, __int_as_float(0), 0.0f, 0.0f);
+                v.child[(size_t)new_node * A + j] = -1;
+            }
         }
     }
     return pri0;
