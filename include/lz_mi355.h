@@ -72,8 +72,8 @@ void *lz_engine_stream(lz_engine *e);
  * (max_simulations + 1) expanded nodes x action_space_size edges per root, resident in HBM.
  * action_space_size: up to 65535 for LZ_TREE_MUZERO / LZ_TREE_EFFICIENTZERO (beyond 256 -- Chinese chess has 2086 moves,
  * zoo/board_games/chinese_chess/config/chinese_chess_muzero_bot_mode_config.py:33 -- a node's children are walked in 64-lane chunks,
- * csrc/lz_tree_wide.hip, the *_with_reuse entry points included; the fused lz_search stays at 256 with the engine models), up to 256 for
- * LZ_TREE_GUMBEL_MUZERO. */
+ * csrc/lz_tree_wide.hip, the *_with_reuse entry points included; the fused lz_search stays at 256 with the engine models), up to 1024 for
+ * LZ_TREE_GUMBEL_MUZERO (its kernels' 8- / 16-chunk instances). */
 int lz_roots_create(lz_engine *e, int variant, int root_num, int action_space_size, int max_simulations,
                     const int32_t *h_legal_flat, const int32_t *h_legal_count, lz_roots **out);
 /* Re-arm an existing batch of trees for the next env-step with new legal-action lists (same root_num and

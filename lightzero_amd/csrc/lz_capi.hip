@@ -237,7 +237,7 @@ extern "C" int lz_roots_create(lz_engine *e, int variant, int root_num, int acti
     LZ_REQUIRE(root_num > 0 && action_space_size > 0 && max_simulations > 0, "root_num, action_space_size, max_simulations must be positive");
     // beyond 256 actions (Chinese chess: 2086) the MuZero / EfficientZero trees run lz_tree_wide.hip; node_link keeps the action in 16 bits
     LZ_REQUIRE(action_space_size <= 65535, "action_space_size > 65535 is not supported");
-    LZ_REQUIRE(action_space_size <= 256 || variant != LZ_TREE_GUMBEL_MUZERO, "action_space_size > 256 is not supported by the Gumbel MuZero tree kernels");
+    LZ_REQUIRE(action_space_size <= 1024 || variant != LZ_TREE_GUMBEL_MUZERO, "action_space_size > 1024 is not supported by the Gumbel MuZero tree kernels (16 register chunks per node)");
     LZ_HIP_CHECK(hipSetDevice(e->device));
     lz_roots *r = nullptr;
     int rc = lz_roots_alloc(e, variant, root_num, action_space_size, max_simulations, &r);

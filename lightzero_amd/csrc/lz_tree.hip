@@ -846,7 +846,8 @@ void lz_tree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_
                             const int32_t *d_noise_off, const float *d_vp, const float *d_logits,
                             const int32_t *d_to_play, hipStream_t s)
 {
-    if (use_wide(t)) { lz_tree_wide_launch_prepare(t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play, s); return; }
+    // (the root expansion is the same for every tree variant: the Gumbel tree beyond 256 actions takes the chunk-loop kernel too)
+    if (use_wide(t) || nchunks(t.A) > 4) { lz_tree_wide_launch_prepare(t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play, s); return; }
     const size_t sh = (size_t)t.A * 8;
     switch (nchunks(t.A)) {
     case 1: hipLaunchKernelGGL(k_prepare<1>, dim3(t.B), dim3(64), sh, s, t, noise_w, d_noises, ragged, d_noise_off, d_vp, d_logits, d_to_play); break;
@@ -987,50 +988,41 @@ void lz_tree_launch_backprop_reuse(const lz_tree_dev &t, int latent_index, float
         launch_bpreuse_v<LZ_TREE_MUZERO>(t, latent_index, discount, d_vp, d_values, d_logits, d_is_reset, horizon, d_to_play, d_mode, d_row, d_reuse_value, d_true_action, d_infer_counter, s);
 }
 
+// The Gumbel tree's kernels keep a node's children in NC register chunks; beyond 256 actions they are instantiated with 8 / 16 chunks
+// (512 / 1024 actions: ten per-child values per chunk still fit the register file of a one-wave workgroup)
+#define LZ_G_DISPATCH(LAUNCH)                                       \
+    {                                                               \
+        const int nc_ = nchunks(t.A);                               \
+        if (nc_ <= 1) { constexpr int NCV = 1; LAUNCH; }            \
+        else if (nc_ <= 2) { constexpr int NCV = 2; LAUNCH; }       \
+        else if (nc_ <= 4) { constexpr int NCV = 4; LAUNCH; }       \
+        else if (nc_ <= 8) { constexpr int NCV = 8; LAUNCH; }       \
+        else { constexpr int NCV = 16; LAUNCH; }                    \
+    }
 void lz_gtree_launch_prepare(const lz_tree_dev &t, float noise_w, const float *d_noises, int ragged, const int32_t *d_noise_off,
                              const float *d_rewards, const float *d_values, const float *d_logits, const int32_t *d_to_play, hipStream_t s)
 {
     lz_tree_launch_prepare(t, noise_w, d_noises, ragged, d_noise_off, d_rewards, d_logits, d_to_play, s);
     hipLaunchKernelGGL(k_graw_root, dim3((t.B + 255) / 256), dim3(256), 0, s, t, d_values);
-    switch (nchunks(t.A)) {
-    case 1: hipLaunchKernelGGL((k_gsoft_root<1>), dim3(t.B), dim3(64), 0, s, t); break;
-    case 2: hipLaunchKernelGGL((k_gsoft_root<2>), dim3(t.B), dim3(64), 0, s, t); break;
-    default: hipLaunchKernelGGL((k_gsoft_root<4>), dim3(t.B), dim3(64), 0, s, t); break;
-    }
+    LZ_G_DISPATCH(hipLaunchKernelGGL((k_gsoft_root<NCV>), dim3(t.B), dim3(64), 0, s, t))
 }
 void lz_gtree_launch_traverse(const lz_tree_dev &t, float discount, hipStream_t s)
 {
-    switch (nchunks(t.A)) {
-    case 1: hipLaunchKernelGGL(k_gtraverse<1>, dim3(t.B), dim3(64), 0, s, t, discount); break;
-    case 2: hipLaunchKernelGGL(k_gtraverse<2>, dim3(t.B), dim3(64), 0, s, t, discount); break;
-    default: hipLaunchKernelGGL(k_gtraverse<4>, dim3(t.B), dim3(64), 0, s, t, discount); break;
-    }
+    LZ_G_DISPATCH(hipLaunchKernelGGL(k_gtraverse<NCV>, dim3(t.B), dim3(64), 0, s, t, discount))
 }
 void lz_gtree_launch_backprop(const lz_tree_dev &t, int idx, float discount, const float *r, const float *v, const float *lg, hipStream_t s)
 {
-    switch (nchunks(t.A)) {
-    case 1: hipLaunchKernelGGL((k_gbackprop<1, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
-    case 2: hipLaunchKernelGGL((k_gbackprop<2, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
-    default: hipLaunchKernelGGL((k_gbackprop<4, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
-    }
+    LZ_G_DISPATCH(hipLaunchKernelGGL((k_gbackprop<NCV, false>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg))
 }
 void lz_gtree_launch_backprop_traverse(const lz_tree_dev &t, int idx, float discount, const float *r, const float *v, const float *lg,
                                        hipStream_t s)
 {
-    switch (nchunks(t.A)) {
-    case 1: hipLaunchKernelGGL((k_gbackprop<1, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
-    case 2: hipLaunchKernelGGL((k_gbackprop<2, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
-    default: hipLaunchKernelGGL((k_gbackprop<4, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg); break;
-    }
+    LZ_G_DISPATCH(hipLaunchKernelGGL((k_gbackprop<NCV, true>), dim3(t.B), dim3(64), 0, s, t, idx, discount, r, v, lg))
 }
 void lz_gtree_launch_policies(const lz_tree_dev &t, float discount, float *d_policies, float *d_children_values, hipStream_t s)
 {
     const size_t sh = (size_t)t.A * 4;
-    switch (nchunks(t.A)) {
-    case 1: hipLaunchKernelGGL(k_gpolicies<1>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values); break;
-    case 2: hipLaunchKernelGGL(k_gpolicies<2>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values); break;
-    default: hipLaunchKernelGGL(k_gpolicies<4>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values); break;
-    }
+    LZ_G_DISPATCH(hipLaunchKernelGGL(k_gpolicies<NCV>, dim3(t.B), dim3(64), sh, s, t, discount, d_policies, d_children_values))
 }
 
 void lz_tree_launch_bump_epoch(const lz_tree_dev &t, hipStream_t s)

@@ -1,5 +1,5 @@
 """Generates tests/golden/gumbel_<case>.npz from the reference's OWN compiled Gumbel MuZero ctree (oracle/_ref/stock).
-Run in the build container (needs /root/reference):  python tests/golden/make_golden_gumbel.py"""
+Run in the build container (needs /root/reference):  python tests/golden/make_golden_gumbel.py [case ...]"""
 import os
 import sys
 
@@ -14,6 +14,8 @@ from oracle import build_ref  # noqa: E402
 assert build_ref.build(), "reference not present"
 mod = build_ref.load_gumbel()
 for name in sorted(gd.CASES):
+    if sys.argv[1:] and name not in sys.argv[1:]:
+        continue
     c = gd.make_inputs(gd.CASES[name])
     out = gd.run_tree(mod, c)
     np.savez_compressed(os.path.join(HERE, "gumbel_%s.npz" % name), records=out["records"].astype(np.int16),

@@ -12,6 +12,9 @@ CASES = {
     "gmz_few_sims": dict(B=8, A=4, S=5, m=8, seed=43, noise_w=None),
     "gmz_zero_ties": dict(B=4, A=5, S=20, m=4, seed=44, zero=True, noise_w=None),
     "gmz_m1": dict(B=4, A=6, S=12, m=1, seed=45),
+    # action spaces beyond 256: the kernels' 8- and 16-chunk instances (512 / 1024 actions)
+    "gmz_wide_a300": dict(B=6, A=300, S=40, m=16, seed=46, legal="random"),
+    "gmz_wide_a1000": dict(B=4, A=1000, S=50, m=8, seed=47),
 }
 
 

@@ -154,7 +154,17 @@ NAMED = [
     ("fuzz1447", "conv", 1447, dict(policy=5.4e-6, logits=3.3e-6)),     # round 5: policy 1.026e-5 against 1e-5
     ("fuzz_sez600", "sez", 600, dict(policy=2.71e-5, latent=2.11e-5)),  # round 5: policy 3.28e-5 against 3.12e-5
     ("fuzz_sez14", "sez", 14, dict(policy=8.4e-6, hc=1.25e-5)),         # round 5: scalar 9.35e-4 against 8.69e-4 (post-h^-1: held to the sweep's bound)
+    # Round 6, offset 56 of the final sweep (profiles/r06_parity_sweeps.json: 1 of 1743 networks): 4x64x64 -> 8x8 latent, THREE residual blocks,
+    # ReLU dynamics / GELU prediction, 64-wide heads, B = 29 -- a network on which torch's own fp32 evaluation is 1.9e-5 (latent) / 1.5e-5 (logits)
+    # from a binary64 evaluation of the same inputs.  |device - torch| is 1.525e-5 on the policy logits against the sweep's 1.415e-5 (= 3 x torch's
+    # own 4.7e-6) and 6.6e-4 against 5.1e-4 on the post-h^-1 scalars.  Found by switching kernels (tools/r06_sez63.py, profiles/r06_sez63.json): only
+    # the recurrent CHAIN moves the numbers, and BOTH of its arithmetic forms are outside (split-bf16 k_chain_s3g: policy 1.53e-5; the fp32 chain
+    # k_chain_w<8,8>: 1.84e-5) -- the tower, LSTM and head switches leave every digit as it is.  Against the binary64 values the device is INSIDE the
+    # same 3 x rule in every class (policy 1.20e-5 <= 1.41e-5, latent 2.49e-5 <= 5.64e-5, logits 2.17e-5 <= 4.64e-5, h / c 1.38e-5 <= 7.45e-5): device
+    # and torch err in different directions, and |device - torch| adds the two.  Held here to that anchor and to ceilings on the torch distances.
+    ("fuzz_sez63", "sez", 63, dict(policy=1.76e-5, latent=3.53e-5, logits=2.96e-5, hc=3.34e-5, scalar=7.61e-4)),
 ]
+ANCHORED_TO_BINARY64 = {"fuzz_sez63"}   # networks above the sweep's |device - torch| bound: asserted against the binary64 evaluation instead
 
 
 @pytest.mark.parametrize("name,kind,seed,ceil", NAMED, ids=[n[0] for n in NAMED])
@@ -167,8 +177,14 @@ def test_named_network_stays_inside_its_bound(name, kind, seed, ceil):
     g64 = _oracle_outputs(case, copy.deepcopy(model).double(), forced=g32)
     cost = _fp32_cost(g32, g64)
     bounds = {k: max(parity_record.BOUNDS[k], 3.0 * cost[k]) for k in cost}
-    worst = check_case(name, case, g32, model.state_dict(), record="named/", bounds=bounds, g64=g64)
+    held = dict(bounds)
+    if name in ANCHORED_TO_BINARY64:   # |device - torch| is held to the ceilings, the sweep's 3 x rule to |device - binary64| below
+        held = {k: max(bounds[k], ceil.get(k, bounds[k])) for k in bounds}
+    worst = check_case(name, case, g32, model.state_dict(), record="named/", bounds=held, g64=g64)
     parity_record.record("named/" + name, {}, extra=dict(torch_fp32_vs_binary64=cost))
+    if name in ANCHORED_TO_BINARY64:
+        far = {k: (v, bounds[k]) for k, v in worst["vs64"].items() if not v <= bounds[k]}
+        assert not far, "%s: further from the binary64 evaluation than 3 x torch fp32 is (measured, bound): %s" % (name, far)
     if not any(os.environ.get(k) for k in ("LZ_CHAIN_NO_SPLIT", "LZ_CHAIN_DIRECT")):   # (the old kernels are allowed their old values)
         bad = {k: (worst[k], c) for k, c in ceil.items() if not worst[k] <= c}
         assert not bad, "%s: above its round-6 ceiling (measured, ceiling): %s" % (name, bad)

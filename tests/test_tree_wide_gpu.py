@@ -81,7 +81,7 @@ def test_what_stays_refused_beyond_256_actions():
     lib = L.lib()
     eng = L.default_engine()
     h = L.P()
-    rc = lib.lz_roots_create(eng, 3, 1, 300, 8, L.i32(list(range(300))), L.i32([300]), ctypes.byref(h))
+    rc = lib.lz_roots_create(eng, 3, 1, 1100, 8, L.i32(list(range(1100))), L.i32([1100]), ctypes.byref(h))   # the Gumbel tree: 16 register chunks
     assert rc < 0 and "Gumbel" in lib.lz_last_error().decode()
     rc = lib.lz_roots_create(eng, 1, 1, 70000, 8, L.i32(list(range(70000))), L.i32([70000]), ctypes.byref(h))
     assert rc < 0 and "65535" in lib.lz_last_error().decode()
