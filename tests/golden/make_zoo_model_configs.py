@@ -76,6 +76,8 @@ def main():
                      collector_env_num=mc["policy"].get("collector_env_num"), env_type=mc["policy"].get("env_type", "not_board_games"),
                      discount_factor=mc["policy"].get("discount_factor", 0.997),
                      max_num_considered_actions=mc["policy"].get("max_num_considered_actions"), set_by_file=sorted(model))
+        # the policy dictionary as the file sets it (without the model), for the policy surface (_forward_collect / _forward_eval)
+        entry["policy"] = plain({k: v for k, v in mc["policy"].items() if k != "model"})
         cls = classes.get((FAMILIES[ptype], mtype))
         if cls is None:
             entry["model"] = plain(model)      # e.g. model_type 'conv_context': a model class outside the four families' two

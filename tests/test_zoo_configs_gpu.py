@@ -193,7 +193,70 @@ def test_shipped_configuration_is_served_or_refused_with_a_reason(path_rel):
     outcome = dict(base, served=True, worst={k: float(v) for k, v in worst.items() if not isinstance(v, dict)},
                    bounds={k: float(v) for k, v in bounds.items()})
     outcome["search"] = _search_stage(e, fam, okw, ekw, ref_model)
+    outcome["policy_surface"] = _policy_stage(e, fam, okw, ekw, ref_model)
     _write(path_rel, outcome)
+
+
+def _policy_stage(e, fam, okw, ekw, ref_model):
+    """the reference-named policy class built from the FILE'S OWN policy dictionary (num_simulations, eps, env_type, discount, root noise ...):
+    _forward_collect and _forward_eval on the file's collector batch return the reference's per-env dictionary -- a legal action, visit
+    counts over the legal (or sampled) actions that sum to num_simulations, the value / entropy / logits fields"""
+    from lightzero_amd.policy.efficientzero import EfficientZeroPolicy
+    from lightzero_amd.policy.muzero import MuZeroPolicy
+    from lightzero_amd.policy.sampled_efficientzero import SampledEfficientZeroPolicy
+    from lightzero_amd.policy.gumbel_muzero import GumbelMuZeroPolicy
+    cls = {"efficientzero": EfficientZeroPolicy, "muzero": MuZeroPolicy, "sampled_efficientzero": SampledEfficientZeroPolicy,
+           "gumbel_muzero": GumbelMuZeroPolicy}[e["policy_type"]]
+    B, S = int(e["collector_env_num"] or 8), int(e["num_simulations"] or 50)
+    A = int(okw["action_space_size"])
+    board = e["env_type"] == "board_games"
+    sampled = e["policy_type"] == "sampled_efficientzero"
+    cont = sampled and bool(okw.get("continuous_action_space", False))
+    K = int(okw.get("num_of_sampled_actions", 0))
+    model = nn_cases.engine_class(fam)(**ekw).load_state_dict(ref_model.state_dict())
+    pcfg = dict(e.get("policy") or {})
+    pcfg["model"] = dict(e["model"])
+    policy = cls(pcfg, model)
+    rng = np.random.default_rng(11)
+    shape = okw["observation_shape"]
+    g = torch.Generator().manual_seed(12)
+    obs = (torch.randn(B, shape, generator=g) if isinstance(shape, int) else torch.rand(B, *shape, generator=g)).cuda().contiguous()
+    if cont:
+        mask = [None] * B
+        legal_n = [K] * B
+    else:
+        m2 = np.ones((B, A), np.int8)
+        if board:
+            m2 = (rng.random((B, A)) < 0.7).astype(np.int8)
+            m2[np.arange(B), rng.integers(0, A, size=B)] = 1
+        mask = [m2[i] for i in range(B)]
+        legal_n = m2.sum(1).tolist()
+    to_play = rng.integers(1, 3, size=B).tolist() if board and e["policy_type"] != "gumbel_muzero" else [-1] * B
+    ids = np.arange(100, 100 + B)
+    for which in ("collect", "eval"):
+        if which == "collect":
+            out = policy._forward_collect(obs, action_mask=mask, temperature=1.0, to_play=to_play, epsilon=0.25, ready_env_id=ids)
+        else:
+            out = policy._forward_eval(obs, action_mask=mask, to_play=to_play, ready_env_id=ids)
+        assert sorted(out) == sorted(ids.tolist()), "output not keyed by ready_env_id"
+        pure = which == "collect" and bool(pcfg.get("collect_with_pure_policy", False))
+        for i, env_id in enumerate(ids.tolist()):
+            o = out[env_id]
+            if pure:   # efficientzero.py:644-656: no search in the collect forward -- an action sampled from the policy, four fields
+                assert sorted(o) == ["action", "predicted_policy_logits", "predicted_value", "searched_value"], sorted(o)
+                assert mask[i][int(o["action"])] == 1
+                continue
+            for key in ("action", "visit_count_distributions", "visit_count_distribution_entropy", "searched_value", "predicted_value", "predicted_policy_logits"):
+                assert key in o, (which, key, sorted(o))
+            dist = list(o["visit_count_distributions"])
+            assert sum(dist) == S, (which, "visit counts sum to %d, not num_simulations %d" % (sum(dist), S))
+            if sampled:
+                assert len(dist) == K and "root_sampled_actions" in o
+            else:
+                assert len(dist) == legal_n[i]
+                assert mask[i][int(o["action"])] == 1, (which, "illegal action")
+            assert np.isfinite(float(np.asarray(o["searched_value"]).reshape(-1)[0]))
+    return "%s(cfg.policy, model): _forward_collect + _forward_eval on %d envs, %d simulations" % (cls.__name__, B, S)
 
 
 def _search_stage(e, fam, okw, ekw, ref_model):
